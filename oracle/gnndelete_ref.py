@@ -1,0 +1,361 @@
+"""CPU restatement of the code the reference OWNS on the GNNDelete hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Pinned against the reference
+itself by tests/golden/make_golden.py -> tests/golden/*.npz (run in the build
+container, where /root/reference can be imported under third-party stubs) and
+checked in tests/test_oracle_golden.py.
+
+What each piece follows (paths relative to /root/reference):
+
+  DeletionLayer            framework/models/deletion.py:8-29
+  TwoLayer / TwoLayerDelete framework/models/{gcn,gat,gin}.py, rgcn.py:9-47,
+                           deletion.py:52-163 (conv1 -> Del1 -> relu -> conv2 -> Del2)
+  decode / distmult        framework/models/gcn.py:26-36, rgcn.py:40-47
+  LOSSES                   framework/trainer/gnndelete_nodeemb.py:19-97
+  nodeemb_terms / epoch    framework/trainer/gnndelete_nodeemb.py:169-299
+  edgeprob_epoch           framework/trainer/gnndelete.py:211-258
+  eval_linkpred            framework/trainer/base.py:229-305
+  negative_sampling_kg     framework/utils.py:46-58
+
+Build semantics: the backbone is truly frozen - conv1
+runs under no_grad for every architecture (upstream does so for GAT/GIN/RGCN; for GCN
+it leaves conv1 differentiable, which only adds a wasted weight-gradient and makes
+GCN + both_layerwise crash).  ``grad_through_conv1=True`` restores the upstream GCN
+behaviour for the golden-vector comparison.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pyg_semantics as pyg
+
+
+# ----------------------------------------------------------------------------
+# Del operator + model wiring
+# ----------------------------------------------------------------------------
+class DeletionLayer(nn.Module):
+    """x[mask] <- x[mask] @ W_D on a copy; identity when no mask (deletion.py:17-29)."""
+
+    def __init__(self, dim, mask):
+        super().__init__()
+        self.dim = dim
+        self.mask = mask
+        self.deletion_weight = nn.Parameter(torch.full((dim, dim), 1.0 / 1000))
+
+    def forward(self, x, mask=None):
+        m = self.mask if mask is None else mask
+        if m is None:
+            return x
+        out = x.clone()
+        out[m] = out[m] @ self.deletion_weight
+        return out
+
+
+def _make_convs(gnn, in_dim, hidden, out_dim, num_edge_type=None):
+    if gnn == 'gcn':
+        return pyg.GCNConv(in_dim, hidden), pyg.GCNConv(hidden, out_dim)
+    if gnn == 'gat':
+        return pyg.GATConv(in_dim, hidden), pyg.GATConv(hidden, out_dim)
+    if gnn == 'gin':
+        return pyg.GINConv(nn.Linear(in_dim, hidden)), pyg.GINConv(nn.Linear(hidden, out_dim))
+    if gnn == 'rgcn':
+        nb = 4 if num_edge_type > 20 else None          # rgcn.py:17-22
+        return (pyg.RGCNConv(in_dim, hidden, 2 * num_edge_type, nb),
+                pyg.RGCNConv(hidden, out_dim, 2 * num_edge_type, nb))
+    raise NotImplementedError(gnn)
+
+
+class TwoLayer(nn.Module):
+    """The reference's 2-layer backbones; ``gnn`` in {gcn, gat, gin, rgcn}."""
+
+    def __init__(self, gnn, in_dim, hidden, out_dim, num_nodes=None, num_edge_type=None):
+        super().__init__()
+        self.gnn = gnn
+        self.relational = gnn == 'rgcn'
+        if self.relational:
+            self.num_edge_type = num_edge_type
+            self.node_emb = nn.Embedding(num_nodes, in_dim)
+        self.conv1, self.conv2 = _make_convs(gnn, in_dim, hidden, out_dim, num_edge_type)
+        if self.relational:
+            self.W = nn.Parameter(torch.empty(num_edge_type, out_dim))
+            nn.init.xavier_uniform_(self.W, gain=nn.init.calculate_gain('relu'))
+
+    def _args(self, edge_index, edge_type):
+        return (edge_index, edge_type) if self.relational else (edge_index,)
+
+    def backbone(self, x, edge_index, edge_type=None, return_all_emb=False):
+        if self.relational:
+            x = self.node_emb(x)
+        g = self._args(edge_index, edge_type)
+        x1 = self.conv1(x, *g)
+        x2 = self.conv2(F.relu(x1), *g)
+        return (x1, x2) if return_all_emb else x2
+
+    def forward(self, x, edge_index, edge_type=None, return_all_emb=False):
+        return self.backbone(x, edge_index, edge_type, return_all_emb)
+
+    def decode(self, z, pos_edge_index, neg_or_type=None):
+        if self.relational:                                           # DistMult
+            return (z[pos_edge_index[0]] * self.W[neg_or_type] * z[pos_edge_index[1]]).sum(1)
+        ei = pos_edge_index if neg_or_type is None else torch.cat([pos_edge_index, neg_or_type], -1)
+        return (z[ei[0]] * z[ei[1]]).sum(-1)
+
+
+class TwoLayerDelete(TwoLayer):
+    def __init__(self, gnn, in_dim, hidden, out_dim, mask_1hop=None, mask_2hop=None,
+                 num_nodes=None, num_edge_type=None, grad_through_conv1=False):
+        super().__init__(gnn, in_dim, hidden, out_dim, num_nodes, num_edge_type)
+        self.deletion1 = DeletionLayer(hidden, mask_1hop)
+        self.deletion2 = DeletionLayer(out_dim, mask_2hop)
+        self.grad_through_conv1 = grad_through_conv1
+
+    def forward(self, x, edge_index, edge_type=None, mask_1hop=None, mask_2hop=None,
+                return_all_emb=False):
+        g = self._args(edge_index, edge_type)
+        with torch.set_grad_enabled(self.grad_through_conv1 and torch.is_grad_enabled()):
+            if self.relational:
+                x = self.node_emb(x)
+            p1 = self.conv1(x, *g)
+        x1 = self.deletion1(p1, mask_1hop)
+        x2 = self.deletion2(self.conv2(F.relu(x1), *g), mask_2hop)
+        return (x1, x2) if return_all_emb else x2
+
+    def get_original_embeddings(self, x, edge_index, edge_type=None, return_all_emb=False):
+        return self.backbone(x, edge_index, edge_type, return_all_emb)
+
+
+# ----------------------------------------------------------------------------
+# loss zoo (gnndelete_nodeemb.py:19-97)
+# ----------------------------------------------------------------------------
+def _bounded_kld(reduction):
+    def f(logits, truth):
+        kl = F.kl_div(F.log_softmax(logits, -1), truth.softmax(-1), reduction=reduction)
+        return 1 - torch.exp(-kl)
+    return f
+
+
+def _cosine(reduce):
+    def f(logits, truth):
+        d = 1 - F.cosine_similarity(logits, truth)
+        return d.mean() if reduce == 'mean' else d.sum()
+    return f
+
+
+def _center(k):
+    n = k.shape[0]
+    h = torch.eye(n, dtype=k.dtype) - torch.ones(n, n, dtype=k.dtype) / n
+    return h @ k @ h
+
+
+def _linear_hsic(x, y):
+    return (_center(x @ x.T) * _center(y @ y.T)).sum()
+
+
+def linear_cka(x, y):
+    return _linear_hsic(x, y) / (torch.sqrt(_linear_hsic(x, x)) * torch.sqrt(_linear_hsic(y, y)))
+
+
+LOSSES = {
+    'mse_mean': nn.MSELoss(reduction='mean'),
+    'mse_sum': nn.MSELoss(reduction='sum'),
+    'kld_mean': _bounded_kld('batchmean'),
+    'kld_sum': _bounded_kld('sum'),
+    'cosine_mean': _cosine('mean'),
+    'cosine_sum': _cosine('sum'),
+    'linear_cka': linear_cka,
+}
+
+
+# ----------------------------------------------------------------------------
+# node-embedding trainer, full batch (gnndelete_nodeemb.py:169-299)
+# ----------------------------------------------------------------------------
+def non_df_masks(num_nodes, directed_df_edge_index, sdf1, sdf2):
+    keep = torch.ones(num_nodes, dtype=torch.bool)
+    keep[directed_df_edge_index.flatten().unique()] = False
+    return sdf1 & keep, sdf2 & keep
+
+
+def nodeemb_terms(z1, z2, z1_ori, z2_ori, pos_edge, neg_edge, ni_mask1, ni_mask2, loss_fct):
+    """Deleted-Edge-Consistency (r) and Neighborhood-Influence (l) terms per layer."""
+    def dec(z, zo):
+        return loss_fct(torch.cat([z[pos_edge[0]], z[pos_edge[1]]], 0),
+                        torch.cat([zo[neg_edge[0]], zo[neg_edge[1]]], 0))
+    r1, r2 = dec(z1, z1_ori), dec(z2, z2_ori)
+    l1 = loss_fct(z1[ni_mask1], z1_ori[ni_mask1])
+    l2 = loss_fct(z2[ni_mask2], z2_ori[ni_mask2])
+    return r1, r2, l1, l2
+
+
+def nodeemb_epoch(model, fwd, targets, optimizer, loss_type, alpha, loss_fct):
+    """One pass of the loop body.  ``fwd()`` -> (z1, z2); ``targets`` = dict with
+    z1_ori, z2_ori, pos_edge, neg_edge, ni_mask1, ni_mask2.  ``optimizer`` is a list of
+    two Adams for *layerwise* types, one Adam otherwise (delete_gnn.py:221-226).
+    Reproduces the zero_grad placement of every branch, including the gradient
+    carry-over of both_layerwise and the never-zeroed grads of both_all."""
+    z1, z2 = fwd()
+    r1, r2, l1, l2 = nodeemb_terms(z1, z2, targets['z1_ori'], targets['z2_ori'],
+                                   targets['pos_edge'], targets['neg_edge'],
+                                   targets['ni_mask1'], targets['ni_mask2'], loss_fct)
+    if loss_type == 'both_all':
+        loss_l, loss_r = l1 + l2, r1 + r2
+        loss = alpha * loss_r + (1 - alpha) * loss_l
+        loss.backward()
+        optimizer.step()
+    elif loss_type == 'both_layerwise':
+        loss_l, loss_r = l1 + l2, r1 + r2
+        loss1 = alpha * r1 + (1 - alpha) * l1
+        loss1.backward(retain_graph=True)
+        optimizer[0].step()
+        optimizer[0].zero_grad()
+        loss2 = alpha * r2 + (1 - alpha) * l2
+        loss2.backward(retain_graph=True)
+        optimizer[1].step()
+        optimizer[1].zero_grad()
+        loss = loss1 + loss2
+    elif loss_type == 'only2_layerwise':
+        loss_l, loss_r = l1 + l2, r1 + r2
+        optimizer[0].zero_grad()
+        loss = alpha * r2 + (1 - alpha) * l2
+        loss.backward()
+        optimizer[1].step()
+        optimizer[1].zero_grad()
+    elif loss_type == 'only2_all':
+        loss_l, loss_r = l2, r2
+        loss = loss_l + alpha * loss_r
+        loss.backward()
+        optimizer.step()
+        optimizer.zero_grad()
+    elif loss_type == 'only1':
+        loss_l, loss_r = l1, r1
+        loss = loss_l + alpha * loss_r
+        loss.backward()
+        optimizer.step()
+        optimizer.zero_grad()
+    else:
+        raise NotImplementedError(loss_type)
+    return {'train_loss': loss.item(), 'loss_r': loss_r.item(), 'loss_l': loss_l.item(),
+            'z1': z1.detach(), 'z2': z2.detach()}
+
+
+def make_optimizer(model, loss_type, lr):
+    if 'layerwise' in loss_type:
+        return [torch.optim.Adam(model.deletion1.parameters(), lr=lr),
+                torch.optim.Adam(model.deletion2.parameters(), lr=lr)]
+    dels = [p for n, p in model.named_parameters() if 'del' in n]
+    return torch.optim.Adam([{'params': dels, 'weight_decay': 0.0}], lr=lr)
+
+
+def nodeemb_fullbatch(model, data, epochs, loss_type='both_layerwise', alpha=0.5,
+                      loss_fct='mse_mean', lr=1e-3, neg_edge=None, optimizer=None):
+    """train_fullbatch without logging/validation.  ``data`` is a dict with the
+    reference's Data attributes; ``neg_edge`` is injected (PyG negative_sampling uses
+    Python's ``random`` and cannot be reproduced)."""
+    relational = model.relational
+    et = data.get('edge_type')
+    ni1, ni2 = non_df_masks(data['x'].shape[0], data['directed_df_edge_index'],
+                            data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    E = data['train_pos_edge_index']
+    dr, sdf, df = data['dr_mask'], data['sdf_mask'], data['df_mask']
+    with torch.no_grad():
+        z1o, z2o = model.get_original_embeddings(
+            data['x'], E[:, dr], et[dr] if relational else None, return_all_emb=True)
+    targets = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=E[:, df], neg_edge=neg_edge,
+                   ni_mask1=ni1, ni_mask2=ni2)
+    opt = optimizer if optimizer is not None else make_optimizer(model, loss_type, lr)
+    fct = LOSSES[loss_fct]
+
+    def fwd():
+        return model(data['x'], E[:, sdf], et[sdf] if relational else None, return_all_emb=True)
+
+    logs = []
+    for _ in range(epochs):
+        model.train()
+        logs.append(nodeemb_epoch(model, fwd, targets, opt, loss_type, alpha, fct))
+    return logs, targets
+
+
+# ----------------------------------------------------------------------------
+# edge-probability trainer (gnndelete.py:138-309)
+# ----------------------------------------------------------------------------
+def sdf_pair_index(num_nodes, sdf_node_mask, df_edges):
+    """Strictly-lower-triangular pairs (i>j) of S_Df nodes, minus the Df pairs
+    (gnndelete.py:174-193), as a [2,P] index instead of an N x N mask, in the
+    row-major order boolean indexing of the N x N matrix would give."""
+    nodes = sdf_node_mask.nonzero().flatten()
+    i, j = torch.meshgrid(nodes, nodes, indexing='ij')
+    sel = i > j
+    i, j = i[sel], j[sel]
+    dfk = set((torch.maximum(df_edges[0], df_edges[1]) * num_nodes
+               + torch.minimum(df_edges[0], df_edges[1])).tolist())
+    key = (i * num_nodes + j).tolist()
+    keep = torch.tensor([k not in dfk for k in key], dtype=torch.bool)
+    return torch.stack([i[keep], j[keep]])
+
+
+def edgeprob_terms(model, z, df_edges, neg_edge, pair_index, logits_ori_pairs):
+    """loss_r = MSE(logit(Df), logit(neg)); loss_l = MSE(sigma(z z^T)[pairs], sigma(ori)[pairs])."""
+    n = df_edges.shape[1]
+    lg = model.decode(z, df_edges, neg_edge)
+    loss_r = F.mse_loss(lg[:n], lg[n:])
+    if pair_index.shape[1] == 0:
+        return loss_r, torch.zeros(())
+    cur = (z[pair_index[0]] * z[pair_index[1]]).sum(-1).sigmoid()
+    return loss_r, F.mse_loss(cur, logits_ori_pairs.sigmoid())
+
+
+# ----------------------------------------------------------------------------
+# evaluation (base.py:229-305) and KG negatives (utils.py:46-58)
+# ----------------------------------------------------------------------------
+def eval_linkpred(model, data, stage, df_pos_masks, unlearning_model='gnndelete_nodeemb'):
+    """Trainer.eval.  ``df_pos_masks`` = the cached list of boolean Dr-subset masks
+    (base.py:263-268; drawn with torch.randperm by the caller).  Quirks kept: BCE
+    *with logits* applied to already-sigmoided scores; Df labelled 0, Dr labelled 1."""
+    from sklearn.metrics import roc_auc_score, average_precision_score
+    model.eval()
+    with torch.no_grad():
+        pos, neg = data[f'{stage}_pos_edge_index'], data[f'{stage}_neg_edge_index']
+        E = data['train_pos_edge_index']
+        mask = data['dtrain_mask'] if 'dtrain_mask' in data else data['dr_mask']
+        z = model(data['x'], E[:, mask])
+        prob = model.decode(z, pos, neg).sigmoid()
+        label = torch.zeros(pos.shape[1] + neg.shape[1])
+        label[:pos.shape[1]] = 1.0
+        loss = F.binary_cross_entropy_with_logits(prob, label).item()
+        dt_auc = roc_auc_score(label.numpy(), prob.numpy())
+        dt_aup = average_precision_score(label.numpy(), prob.numpy())
+        if unlearning_model == 'original':
+            df_logit = []
+        else:
+            df_logit = model.decode(z, data['directed_df_edge_index']).sigmoid().tolist()
+        if df_logit:
+            dr_edges = E[:, data['dr_mask']]
+            aucs, aups = [], []
+            lab = [0] * len(df_logit) + [1] * len(df_logit)
+            for m in df_pos_masks:
+                pl = model.decode(z, dr_edges[:, m]).sigmoid().tolist()
+                aucs.append(roc_auc_score(lab, df_logit + pl))
+                aups.append(average_precision_score(lab, df_logit + pl))
+            df_auc, df_aup = float(np.mean(aucs)), float(np.mean(aups))
+        else:
+            df_auc = df_aup = float('nan')
+    return {'loss': loss, 'dt_auc': dt_auc, 'dt_aup': dt_aup, 'df_auc': df_auc,
+            'df_aup': df_aup, 'df_logit': df_logit, 'z': z}
+
+
+def negative_sampling_kg(edge_index, edge_type, generator=None):
+    """Per relation type, permute the head column with torch.randperm (global RNG)."""
+    out = edge_index.clone()
+    for et in edge_type.unique():
+        sel = edge_type == et
+        heads = out[0, sel]
+        perm = torch.randperm(heads.shape[0], generator=generator)
+        out[0, sel] = heads[perm]
+    return out
+
+
+def df_size_from_arg(df_size, num_train_edges):
+    """delete_gnn.py:88-91."""
+    return int(df_size) if df_size >= 100 else int(df_size / 100 * num_train_edges)

@@ -1,0 +1,237 @@
+"""CPU restatement of the torch_geometric arithmetic the reference calls.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  **Parity unpinned**: the
+reference depends on an un-vendored, un-pinned ``torch_geometric`` (API usage implies
+2.0.4 - 2.2; no requirements file) and holds no tests at this boundary.  What is
+restated here is the published PyG algorithm for each call site:
+
+  GCNConv           framework/models/gcn.py:11-12      (gcn_norm + propagate, bias)
+  GATConv           framework/models/gat.py:11-12      (heads=1, slope .2, self loops)
+  GINConv(Linear)   framework/models/gin.py:11-12      (eps=0, sum aggregation)
+  RGCNConv          framework/models/rgcn.py:17-22     (mean aggr, block-diag, root, bias)
+  k_hop_subgraph    delete_gnn.py:128-140
+  to_undirected     delete_gnn.py:175
+  is_undirected     delete_gnn.py:156,182
+
+and is pinned by the dense closed-form known-answer tests in
+tests/test_oracle_kat.py.  Everything is plain index_add_/scatter arithmetic on CPU
+tensors (the same gather + scatter-add PyG's CPU path performs), differentiable
+through torch autograd.  Edge convention: ``edge_index[0]`` = source j,
+``edge_index[1]`` = target i (flow source_to_target).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------
+# graph utilities
+# ----------------------------------------------------------------------------
+def with_single_self_loops(edge_index, num_nodes):
+    """PyG ``add_remaining_self_loops`` for unweighted graphs: drop every existing
+    self loop, keep all other edges in order, append exactly one loop per node."""
+    keep = edge_index[0] != edge_index[1]
+    loops = torch.arange(num_nodes, dtype=edge_index.dtype, device=edge_index.device)
+    return torch.cat([edge_index[:, keep], torch.stack([loops, loops])], dim=1)
+
+
+def gcn_norm(edge_index, num_nodes, dtype=torch.float32):
+    """Symmetric normalisation D^-1/2 (A+I) D^-1/2; degree = weighted IN-degree
+    (scatter over the target column) including the loop; multi-edges count."""
+    ei = with_single_self_loops(edge_index, num_nodes)
+    src, dst = ei[0], ei[1]
+    w = torch.ones(ei.shape[1], dtype=dtype)
+    deg = torch.zeros(num_nodes, dtype=dtype).index_add_(0, dst, w)
+    dis = deg.pow(-0.5)
+    dis[torch.isinf(dis)] = 0.0
+    return ei, dis[src] * w * dis[dst]
+
+
+def scatter_rows(msg, dst, num_nodes):
+    out = torch.zeros(num_nodes, msg.shape[1], dtype=msg.dtype)
+    return out.index_add(0, dst, msg)
+
+
+def k_hop_subgraph(node_idx, num_hops, edge_index, num_nodes):
+    """PyG k_hop_subgraph(relabel_nodes=False, flow='source_to_target').
+
+    Each hop looks at the PREVIOUS frontier only and adds the *sources* of edges
+    whose *target* is in it.  Returns (subset, induced edge_index, edge_mask)."""
+    src, dst = edge_index[0], edge_index[1]
+    node_idx = torch.as_tensor(node_idx, dtype=torch.long).flatten()
+    frontier = node_idx
+    collected = [node_idx]
+    for _ in range(num_hops):
+        in_frontier = torch.zeros(num_nodes, dtype=torch.bool)
+        in_frontier[frontier] = True
+        frontier = src[in_frontier[dst]]
+        collected.append(frontier)
+    subset = torch.cat(collected).unique()
+    member = torch.zeros(num_nodes, dtype=torch.bool)
+    member[subset] = True
+    edge_mask = member[src] & member[dst]
+    return subset, edge_index[:, edge_mask], edge_mask
+
+
+def coalesce(edge_index, attrs, num_nodes):
+    """Sort by (row, col), merge duplicates, sum integer/float attributes."""
+    key = edge_index[0] * num_nodes + edge_index[1]
+    uniq, inv = torch.unique(key, sorted=True, return_inverse=True)
+    out_index = torch.stack([uniq // num_nodes, uniq % num_nodes])
+    out_attrs = []
+    for a in attrs:
+        acc = torch.zeros(uniq.shape[0], dtype=a.dtype)
+        out_attrs.append(acc.index_add_(0, inv, a))
+    return out_index, out_attrs
+
+
+def to_undirected(edge_index, attrs, num_nodes):
+    """PyG to_undirected(edge_index, [attrs], reduce='add'): concatenate the reversed
+    edges, duplicate the attributes, coalesce."""
+    both = torch.cat([edge_index, edge_index.flip(0)], dim=1)
+    return coalesce(both, [torch.cat([a, a]) for a in attrs], num_nodes)
+
+
+def is_undirected(edge_index, num_nodes):
+    a, _ = coalesce(edge_index, [], num_nodes)
+    b, _ = coalesce(edge_index.flip(0), [], num_nodes)
+    return a.shape == b.shape and bool((a == b).all())
+
+
+# ----------------------------------------------------------------------------
+# conv arithmetic (functional)
+# ----------------------------------------------------------------------------
+def gcn_conv(x, edge_index, weight, bias):
+    """out = D^-1/2 (A+I) D^-1/2 (x W^T) + b ; weight is [out, in] (PyG Linear)."""
+    n = x.shape[0]
+    ei, w = gcn_norm(edge_index, n, x.dtype)
+    h = x @ weight.t()
+    out = scatter_rows(h[ei[0]] * w[:, None], ei[1], n)
+    return out + bias if bias is not None else out
+
+
+def segment_softmax(score, dst, num_nodes):
+    """PyG utils.softmax: per-target max-shifted exp / (sum + 1e-16)."""
+    smax = torch.full((num_nodes,), -math.inf, dtype=score.dtype)
+    smax = smax.scatter_reduce(0, dst, score.detach(), reduce='amax', include_self=True)
+    e = (score - smax[dst]).exp()
+    denom = torch.zeros(num_nodes, dtype=score.dtype).index_add(0, dst, e)
+    return e / (denom[dst] + 1e-16)
+
+
+def gat_conv(x, edge_index, weight, att_src, att_dst, bias, negative_slope=0.2):
+    """GATConv heads=1: h = xW^T; e_ij = LeakyReLU(a_s.h_j + a_d.h_i); softmax over the
+    in-edges of i (existing loops removed, one loop per node appended); out = sum a_ij h_j + b."""
+    n = x.shape[0]
+    ei = with_single_self_loops(edge_index, n)
+    src, dst = ei[0], ei[1]
+    h = x @ weight.t()
+    a_s = (h * att_src.view(1, -1)).sum(-1)
+    a_d = (h * att_dst.view(1, -1)).sum(-1)
+    alpha = segment_softmax(F.leaky_relu(a_s[src] + a_d[dst], negative_slope), dst, n)
+    out = scatter_rows(h[src] * alpha[:, None], dst, n)
+    return out + bias if bias is not None else out
+
+
+def gin_conv(x, edge_index, weight, bias, eps=0.0):
+    """GINConv(nn.Linear): Linear((1+eps) x_i + sum_{j->i} x_j); no loops, no norm."""
+    n = x.shape[0]
+    agg = scatter_rows(x[edge_index[0]], edge_index[1], n)
+    return F.linear((1.0 + eps) * x + agg, weight, bias)
+
+
+def rgcn_conv(x, edge_index, edge_type, weight, root, bias, num_blocks=None):
+    """RGCNConv(aggr='mean', root_weight=True): per relation r, mean of x_j over the
+    in-edges of type r, times W_r (dense [in,out] or block-diagonal
+    [num_blocks, in/nb, out/nb]); plus x @ root + bias."""
+    n = x.shape[0]
+    num_rel = weight.shape[0]
+    out_dim = root.shape[1]
+    out = torch.zeros(n, out_dim, dtype=x.dtype)
+    for r in range(num_rel):
+        sel = edge_type == r
+        src, dst = edge_index[0, sel], edge_index[1, sel]
+        cnt = torch.zeros(n, dtype=x.dtype).index_add_(0, dst, torch.ones(src.shape[0], dtype=x.dtype))
+        h = scatter_rows(x[src], dst, n) / cnt.clamp(min=1.0)[:, None]
+        if num_blocks is not None:
+            hb = h.view(n, num_blocks, -1)
+            out = out + torch.einsum('abc,bcd->abd', hb, weight[r]).reshape(n, out_dim)
+        else:
+            out = out + h @ weight[r]
+    out = out + x @ root
+    return out + bias if bias is not None else out
+
+
+# ----------------------------------------------------------------------------
+# nn.Module wrappers with PyG's parameter names (state_dict keys are part of the
+# checkpoint contract: delete_gnn.py:206-207 loads model_best.pt with strict=False)
+# ----------------------------------------------------------------------------
+def glorot_(t):
+    fan = t.size(-2) + t.size(-1)
+    bound = math.sqrt(6.0 / fan)
+    with torch.no_grad():
+        return t.uniform_(-bound, bound)
+
+
+class _BiaslessLinear(nn.Module):
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.weight = nn.Parameter(glorot_(torch.empty(out_dim, in_dim)))
+
+
+class GCNConv(nn.Module):
+    """keys: lin.weight [out,in], bias [out]"""
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.lin = _BiaslessLinear(in_dim, out_dim)
+        self.bias = nn.Parameter(torch.zeros(out_dim))
+
+    def forward(self, x, edge_index):
+        return gcn_conv(x, edge_index, self.lin.weight, self.bias)
+
+
+class GATConv(nn.Module):
+    """keys: lin_src.weight (shared with lin_dst), att_src, att_dst [1,1,out], bias"""
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.lin_src = _BiaslessLinear(in_dim, out_dim)
+        self.lin_dst = self.lin_src
+        self.att_src = nn.Parameter(glorot_(torch.empty(1, 1, out_dim)))
+        self.att_dst = nn.Parameter(glorot_(torch.empty(1, 1, out_dim)))
+        self.bias = nn.Parameter(torch.zeros(out_dim))
+
+    def forward(self, x, edge_index):
+        return gat_conv(x, edge_index, self.lin_src.weight, self.att_src, self.att_dst, self.bias)
+
+
+class GINConv(nn.Module):
+    """keys: nn.weight, nn.bias (the wrapped nn.Linear)"""
+    def __init__(self, lin):
+        super().__init__()
+        self.nn = lin
+        self.eps = 0.0
+
+    def forward(self, x, edge_index):
+        return gin_conv(x, edge_index, self.nn.weight, self.nn.bias, self.eps)
+
+
+class RGCNConv(nn.Module):
+    """keys: weight [R,in,out] or [R,nb,in/nb,out/nb], root [in,out], bias [out]"""
+    def __init__(self, in_dim, out_dim, num_relations, num_blocks=None):
+        super().__init__()
+        self.num_blocks = num_blocks
+        if num_blocks is None:
+            self.weight = nn.Parameter(glorot_(torch.empty(num_relations, in_dim, out_dim)))
+        else:
+            self.weight = nn.Parameter(glorot_(torch.empty(
+                num_relations, num_blocks, in_dim // num_blocks, out_dim // num_blocks)))
+        self.root = nn.Parameter(glorot_(torch.empty(in_dim, out_dim)))
+        self.bias = nn.Parameter(torch.zeros(out_dim))
+
+    def forward(self, x, edge_index, edge_type):
+        return rgcn_conv(x, edge_index, edge_type, self.weight, self.root, self.bias, self.num_blocks)
+
+
+FastRGCNConv = RGCNConv

@@ -1,0 +1,549 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference code.
+
+Runs only in the build container (needs /root/reference); the outputs (*.npz / *.json,
+inputs AND expected outputs, a few hundred KB in total) are committed and are what
+travels to the GPU box.  No reference source is copied: the reference is imported in
+place, under stubs for the third-party modules this image lacks.
+
+How the import works:
+  * torch_geometric / torch_scatter / torch_sparse / wandb / ogb are replaced by stub
+    modules; the conv classes the reference instantiates (GCNConv, GATConv, GINConv,
+    RGCNConv) are oracle.pyg_semantics' restatements, so what these vectors pin is the
+    code the reference OWNS (DeletionLayer, *Delete wiring, loss zoo, the trainer loop
+    with every loss_type branch, Trainer.eval, parse_args, negative_sampling_kg, the
+    delete_gnn.py preprocessing) - not PyG's arithmetic (pinned by closed-form KATs).
+  * framework/__init__.py is bypassed with synthetic package objects because it
+    imports modules that do not exist upstream (graph_editor, MIAttackTrainerNode).
+  * PyG's negative_sampling draws from Python's `random`; it is stubbed to return the
+    negatives stored in the fixture.
+
+Usage:  python tests/golden/make_golden.py        (rewrites every fixture)
+"""
+import importlib
+import json
+import os
+import pickle
+import runpy
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+
+from oracle import pyg_semantics as pyg  # noqa: E402
+
+STATE = {'neg': None, 'wandb': []}
+
+
+# --------------------------------------------------------------------------- stubs
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _neg_stub(edge_index=None, num_nodes=None, num_neg_samples=None, **kw):
+    neg = STATE['neg']
+    assert neg is not None and neg.shape[1] == int(num_neg_samples), (neg.shape, num_neg_samples)
+    return neg.clone()
+
+
+def _khop_stub(node_idx, num_hops, edge_index, relabel_nodes=False, num_nodes=None, **kw):
+    subset, ei, mask = pyg.k_hop_subgraph(node_idx, num_hops, edge_index, num_nodes)
+    return subset, ei, None, mask
+
+
+def _to_undirected_stub(edge_index, edge_attr=None, num_nodes=None, reduce='add'):
+    n = int(edge_index.max()) + 1 if num_nodes is None else num_nodes
+    if edge_attr is None:
+        return pyg.to_undirected(edge_index, [], n)[0]
+    return pyg.to_undirected(edge_index, list(edge_attr), n)
+
+
+def _is_undirected_stub(edge_index, *a, **kw):
+    return pyg.is_undirected(edge_index, int(edge_index.max()) + 1)
+
+
+def _seed_everything(seed):
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+class Bag(dict):
+    """Attribute bag standing in for torch_geometric.data.Data (AttributeError on a
+    missing key so hasattr(data, 'dtrain_mask') is False, base.py:238)."""
+    __setattr__ = dict.__setitem__
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def to(self, *a, **k):
+        return self
+
+    def cpu(self):
+        return self
+
+    def __getstate__(self):
+        return dict(self)
+
+    def __setstate__(self, s):
+        self.update(s)
+
+
+class FakeDataset:
+    def __init__(self, num_features):
+        self.num_features = num_features
+
+    def __repr__(self):
+        return 'SynthDataset()'
+
+
+def install_stubs():
+    _mod('torch_geometric')
+    _mod('torch_geometric.nn', GCNConv=pyg.GCNConv, GATConv=pyg.GATConv, GINConv=pyg.GINConv,
+         RGCNConv=pyg.RGCNConv, FastRGCNConv=pyg.RGCNConv)
+    _mod('torch_geometric.nn.conv', MessagePassing=nn.Module)
+    _mod('torch_geometric.nn.dense')
+    _mod('torch_geometric.nn.dense.linear', Linear=nn.Linear)
+    _mod('torch_geometric.nn.inits', glorot=None, ones=None, zeros=None)
+    _mod('torch_geometric.typing', Adj=object, OptTensor=object, Size=object, OptPairTensor=object)
+    _mod('torch_geometric.utils', softmax=None, negative_sampling=_neg_stub, k_hop_subgraph=_khop_stub,
+         to_undirected=_to_undirected_stub, is_undirected=_is_undirected_stub, to_networkx=None)
+    _mod('torch_geometric.loader', GraphSAINTRandomWalkSampler=None)
+    _mod('torch_geometric.data', DataLoader=None, Data=Bag)
+    _mod('torch_geometric.seed', seed_everything=_seed_everything)
+    _mod('torch_scatter', scatter_add=None)
+    _mod('torch_sparse', SparseTensor=object)
+    _mod('wandb', log=lambda d, *a, **k: STATE['wandb'].append(dict(d)), init=lambda *a, **k: None,
+         watch=lambda *a, **k: None)
+    _mod('ogb')
+    _mod('ogb.graphproppred', Evaluator=None)
+    _mod('train_mi', MLPAttacker=None)
+    for name, path in [('framework', f'{REF}/framework'), ('framework.trainer', f'{REF}/framework/trainer')]:
+        pkg = types.ModuleType(name)
+        pkg.__path__ = [path]
+        sys.modules[name] = pkg
+
+
+def load_reference():
+    install_stubs()
+    D = importlib.import_module('framework.models.deletion')
+    T = importlib.import_module('framework.trainer.gnndelete_nodeemb')
+    TE = importlib.import_module('framework.trainer.gnndelete')
+    A = importlib.import_module('framework.training_args')
+    U = importlib.import_module('framework.utils')
+    B = importlib.import_module('framework.trainer.base')
+    return D, T, TE, A, U, B
+
+
+# --------------------------------------------------------------------------- inputs
+def np_(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def synth_graph(n, m, f, seed, relations=0):
+    """Small random simple graph: unique row<col edges, features, 90/5/5 split."""
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randint(0, n, (4 * m,), generator=g)
+    b = torch.randint(0, n, (4 * m,), generator=g)
+    lo, hi = torch.minimum(a, b), torch.maximum(a, b)
+    keep = lo != hi
+    key = torch.unique(lo[keep] * n + hi[keep])
+    key = key[torch.randperm(key.shape[0], generator=g)][:m]
+    ei = torch.stack([key // n, key % n])
+    nv = max(1, int(0.05 * ei.shape[1]))
+    val, test, train = ei[:, :nv], ei[:, nv:2 * nv], ei[:, 2 * nv:]
+    x = torch.randn(n, f, generator=g) * 0.5
+    out = dict(x=x, num_nodes=n, train=train, val_pos=val, test_pos=test,
+               val_neg=torch.randint(0, n, val.shape, generator=g),
+               test_neg=torch.randint(0, n, test.shape, generator=g))
+    if relations:
+        out['train_type'] = torch.randint(0, relations, (train.shape[1],), generator=g)
+    return out
+
+
+def prepare_deletion(g, df_count, seed):
+    """The delete_gnn.py:85-189 recipe on the synthetic graph (non-KG branch), written
+    against the same stubs the reference main() gets - used for the trainer fixtures.
+    (The real main() is exercised separately by golden_prep().)"""
+    gen = torch.Generator().manual_seed(seed)
+    E, n = g['train'], g['num_nodes']
+    df_idx = torch.randperm(E.shape[1], generator=gen)[:df_count]
+    df_mask = torch.zeros(E.shape[1], dtype=torch.bool)
+    df_mask[df_idx] = True
+    seeds = E[:, df_mask].flatten().unique()
+    _, e2, m2 = pyg.k_hop_subgraph(seeds, 2, E, n)
+    _, e1, _ = pyg.k_hop_subgraph(seeds, 1, E, n)
+    s1 = torch.zeros(n, dtype=torch.bool)
+    s2 = torch.zeros(n, dtype=torch.bool)
+    s1[e1.flatten().unique()] = True
+    s2[e2.flatten().unique()] = True
+    und, (dfu, m2u) = pyg.to_undirected(E, [df_mask.int(), m2.int()], n)
+    dfu, m2u = dfu.bool(), m2u.bool()
+    neg = torch.randint(0, n, (2, int(dfu.sum())), generator=gen)
+    d = Bag(x=g['x'], num_nodes=n, train_pos_edge_index=und, edge_index=und,
+            val_pos_edge_index=g['val_pos'], val_neg_edge_index=g['val_neg'],
+            test_pos_edge_index=g['test_pos'], test_neg_edge_index=g['test_neg'],
+            df_mask=dfu, dr_mask=~dfu, sdf_mask=m2u, sdf_node_1hop_mask=s1, sdf_node_2hop_mask=s2,
+            directed_df_edge_index=E[:, df_mask])
+    return d, neg
+
+
+def make_args(A, argv):
+    old = sys.argv
+    sys.argv = ['x'] + argv
+    try:
+        return A.parse_args()
+    finally:
+        sys.argv = old
+
+
+def state_np(model):
+    return {f'w::{k}': np_(v) for k, v in model.state_dict().items()}
+
+
+def data_np(d, neg):
+    out = {f'd::{k}': np_(v) for k, v in d.items() if torch.is_tensor(v)}
+    out['d::num_nodes'] = np.int64(d['num_nodes'])
+    out['neg'] = np_(neg)
+    return out
+
+
+# --------------------------------------------------------------------------- fixtures
+def golden_del_layer(D):
+    out = {}
+    g = torch.Generator().manual_seed(1)
+    for tag, n, d, frac in [('partial', 37, 16, 0.4), ('empty', 11, 8, 0.0), ('full', 9, 64, 1.0),
+                            ('odd', 23, 12, 0.5)]:
+        x = torch.randn(n, d, generator=g, requires_grad=True)
+        mask = torch.rand(n, generator=g) < frac if 0 < frac < 1 else torch.full((n,), bool(frac))
+        layer = D.DeletionLayer(d, mask)
+        with torch.no_grad():
+            layer.deletion_weight.copy_(torch.randn(d, d, generator=g) * 0.3)
+        up = torch.randn(n, d, generator=g)
+        y = layer(x)
+        y.backward(up)
+        out.update({f'{tag}::x': np_(x), f'{tag}::mask': np_(mask), f'{tag}::w': np_(layer.deletion_weight),
+                    f'{tag}::up': np_(up), f'{tag}::y': np_(y), f'{tag}::gx': np_(x.grad),
+                    f'{tag}::gw': np_(layer.deletion_weight.grad)})
+    layer = D.DeletionLayer(4, None)          # no mask => identity, same object
+    x = torch.randn(5, 4, generator=g)
+    out['nomask::x'] = np_(x)
+    out['nomask::y'] = np_(layer(x))
+    out['init::w'] = np_(D.DeletionLayer(6, None).deletion_weight)
+    np.savez_compressed(os.path.join(HERE, 'del_layer.npz'), **out)
+
+
+def golden_losses(T):
+    out = {}
+    g = torch.Generator().manual_seed(2)
+    a0 = torch.randn(29, 16, generator=g)
+    b0 = torch.randn(29, 16, generator=g)
+    out['a'], out['b'] = np_(a0), np_(b0)
+    for name in ['mse_mean', 'mse_sum', 'kld_mean', 'kld_sum', 'cosine_mean', 'cosine_sum', 'linear_cka']:
+        a = a0.clone().requires_grad_(True)
+        v = T.get_loss_fct(name)(a, b0)
+        v.backward()
+        out[f'{name}::value'] = np_(v)
+        out[f'{name}::grad'] = np_(a.grad)
+    np.savez_compressed(os.path.join(HERE, 'losses.npz'), **out)
+
+
+GNN_CLASS = {'gcn': 'GCNDelete', 'gat': 'GATDelete', 'gin': 'GINDelete', 'rgcn': 'RGCNDelete'}
+
+
+def build_ref_model(D, A, gnn, d, in_dim, seed, num_edge_type=None, hidden=32, out=16):
+    args = make_args(A, ['--gnn', 'gcn', '--in_dim', str(in_dim), '--hidden_dim', str(hidden),
+                         '--out_dim', str(out)])
+    torch.manual_seed(seed)
+    cls = getattr(D, GNN_CLASS[gnn])
+    if gnn == 'rgcn':
+        model = cls(args, d['num_nodes'], num_edge_type, d['sdf_node_1hop_mask'], d['sdf_node_2hop_mask'])
+    else:
+        model = cls(args, d['sdf_node_1hop_mask'], d['sdf_node_2hop_mask'])
+    with torch.no_grad():                      # non-trivial biases / Del weights
+        for n_, p in model.named_parameters():
+            if n_.endswith('bias'):
+                p.copy_(torch.randn_like(p) * 0.1)
+            if 'deletion_weight' in n_:
+                p.copy_(torch.eye(p.shape[0]) * 0.5 + torch.randn_like(p) * 0.05)
+    return model, args
+
+
+def golden_wiring(D, A):
+    for gnn in ['gcn', 'gat', 'gin', 'rgcn']:
+        R = 3 if gnn == 'rgcn' else 0
+        g = synth_graph(60, 220, 12, seed=10 + len(gnn), relations=R)
+        d, neg = prepare_deletion(g, 8, seed=5)
+        out = {}
+        if gnn == 'rgcn':
+            # KG branch of delete_gnn.py:158-171: reverse edges get type + R, masks repeat(2)
+            E = g['train']
+            df = torch.zeros(E.shape[1], dtype=torch.bool)
+            df[:8] = True
+            ei = torch.cat([E, E.flip(0)], 1)
+            et = torch.cat([g['train_type'], g['train_type'] + R])
+            model, _ = build_ref_model(D, A, gnn, d, 12, seed=3, num_edge_type=R)
+            x = torch.arange(60)
+            z1, z2 = model(x, ei, et, return_all_emb=True)
+            o1, o2 = model.get_original_embeddings(x, ei, et, return_all_emb=True)
+            score = model.decode(z2, E, g['train_type'])
+            out.update(edge_index=np_(ei), edge_type=np_(et), x=np_(x), dec_edge=np_(E),
+                       dec_type=np_(g['train_type']), score=np_(score), num_edge_type=np.int64(R))
+        else:
+            model, _ = build_ref_model(D, A, gnn, d, 12, seed=3)
+            ei = d['train_pos_edge_index'][:, d['sdf_mask']]
+            z1, z2 = model(d['x'], ei, return_all_emb=True)
+            o1, o2 = model.get_original_embeddings(d['x'], ei, return_all_emb=True)
+            score = model.decode(z2, d['val_pos_edge_index'], d['val_neg_edge_index'])
+            # per-call mask override path (used by the mini-batch trainers)
+            alt1 = torch.rand(60, generator=torch.Generator().manual_seed(9)) < 0.3
+            alt2 = torch.rand(60, generator=torch.Generator().manual_seed(8)) < 0.6
+            a1, a2 = model(d['x'], ei, alt1, alt2, return_all_emb=True)
+            out.update(edge_index=np_(ei), x=np_(d['x']), score=np_(score), alt1=np_(alt1), alt2=np_(alt2),
+                       a1=np_(a1), a2=np_(a2), val_pos=np_(d['val_pos_edge_index']),
+                       val_neg=np_(d['val_neg_edge_index']))
+        out.update(state_np(model))
+        out.update(mask1=np_(d['sdf_node_1hop_mask']), mask2=np_(d['sdf_node_2hop_mask']),
+                   z1=np_(z1), z2=np_(z2), o1=np_(o1), o2=np_(o2))
+        np.savez_compressed(os.path.join(HERE, f'wiring_{gnn}.npz'), **out)
+
+
+def golden_trajectories(D, T, A):
+    """The real train_fullbatch loop (gnndelete_nodeemb.py:108-349) for every loss_type."""
+    cases = [('gat', 'both_layerwise'), ('gat', 'both_all'), ('gat', 'only2_layerwise'),
+             ('gat', 'only2_all'), ('gat', 'only1'), ('gin', 'both_layerwise'),
+             ('gcn', 'both_all'), ('gcn', 'only2_layerwise'), ('gcn', 'only1')]
+    for gnn, loss_type in cases:
+        g = synth_graph(80, 300, 10, seed=21)
+        d, neg = prepare_deletion(g, 10, seed=6)
+        model, _ = build_ref_model(D, A, gnn, d, 10, seed=4)
+        with torch.no_grad():                 # start from the reference's own init
+            model.deletion1.deletion_weight.fill_(1 / 1000)
+            model.deletion2.deletion_weight.fill_(1 / 1000)
+        init = state_np(model)
+        model.to = lambda *a, **k: model      # trainer hard-codes .to('cuda')
+        tmp = tempfile.mkdtemp()
+        args = make_args(A, ['--gnn', gnn, '--unlearning_model', 'gnndelete_nodeemb', '--epochs', '6',
+                             '--valid_freq', '3', '--loss_type', loss_type, '--checkpoint_dir', tmp,
+                             '--dataset', 'Cora', '--lr', '0.01', '--alpha', '0.4'])
+        if 'layerwise' in loss_type:
+            opt = [torch.optim.Adam(model.deletion1.parameters(), lr=args.lr),
+                   torch.optim.Adam(model.deletion2.parameters(), lr=args.lr)]
+        else:
+            opt = torch.optim.Adam([{'params': [p for n_, p in model.named_parameters() if 'del' in n_],
+                                     'weight_decay': 0.0}], lr=args.lr)
+        STATE['neg'], STATE['wandb'] = neg, []
+        torch.manual_seed(77)                 # Trainer.eval draws 500 randperm subsets
+        trainer = T.GNNDeleteNodeembTrainer(args)
+        trainer.train_fullbatch(model, d, opt, args)
+        steps = [w for w in STATE['wandb'] if 'Epoch' in w]
+        vals = [w for w in STATE['wandb'] if 'val_loss' in w]
+        out = dict(init)
+        out.update(data_np(d, neg))
+        out.update(train_loss=np.array([s['train_loss'] for s in steps]),
+                   loss_r=np.array([s['loss_r'] for s in steps]),
+                   loss_l=np.array([s['loss_l'] for s in steps]),
+                   final_w1=np_(model.deletion1.deletion_weight), final_w2=np_(model.deletion2.deletion_weight),
+                   val_dt_auc=np.array([v['val_dt_auc'] for v in vals]),
+                   val_df_auc=np.array([v['val_df_auc'] for v in vals]),
+                   val_loss=np.array([v['val_loss'] for v in vals]),
+                   val_df_logit_mean=np.array([v['val_df_logit_mean'] for v in vals]),
+                   lr=np.float64(args.lr), alpha=np.float64(args.alpha), epochs=np.int64(6),
+                   eval_seed=np.int64(77))
+        np.savez_compressed(os.path.join(HERE, f'traj_{gnn}_{loss_type}.npz'), **out)
+
+
+def golden_gcn_layerwise_crash(D, T, A):
+    """record that upstream GCNDelete + both_layerwise raises."""
+    g = synth_graph(40, 120, 6, seed=31)
+    d, neg = prepare_deletion(g, 5, seed=7)
+    model, _ = build_ref_model(D, A, 'gcn', d, 6, seed=4)
+    model.to = lambda *a, **k: model
+    tmp = tempfile.mkdtemp()
+    args = make_args(A, ['--gnn', 'gcn', '--unlearning_model', 'gnndelete_nodeemb', '--epochs', '2',
+                         '--checkpoint_dir', tmp, '--dataset', 'Cora'])
+    opt = [torch.optim.Adam(model.deletion1.parameters(), lr=args.lr),
+           torch.optim.Adam(model.deletion2.parameters(), lr=args.lr)]
+    STATE['neg'] = neg
+    try:
+        T.GNNDeleteNodeembTrainer(args).train_fullbatch(model, d, opt, args)
+        msg = 'no error'
+    except RuntimeError as e:
+        msg = str(e).splitlines()[0]
+    return msg
+
+
+def golden_parse_args(A):
+    cases = {
+        'default': [],
+        'cora_nodeemb': ['--unlearning_model', 'gnndelete_nodeemb', '--gnn', 'gcn', '--dataset', 'Cora',
+                         '--df', 'out', '--df_size', '0.5', '--epochs', '1500'],
+        'dblp_nodeemb': ['--unlearning_model', 'gnndelete_nodeemb', '--gnn', 'gcn', '--dataset', 'DBLP',
+                         '--df', 'out', '--df_size', '2.5', '--random_seed', '21'],
+        'collab_gnndelete': ['--unlearning_model', 'gnndelete', '--gnn', 'gcn', '--dataset', 'ogbl-collab',
+                             '--df', 'in', '--df_size', '5', '--epochs', '1500'],
+        'biokg_rgcn': ['--unlearning_model', 'gnndelete_nodeemb', '--gnn', 'rgcn', '--dataset', 'ogbl-biokg',
+                       '--df', 'in', '--df_size', '2.5'],
+        'wn18_rgcn': ['--unlearning_model', 'gnndelete', '--gnn', 'rgcn', '--dataset', 'WordNet18'],
+        'original_collab': ['--unlearning_model', 'original', '--gnn', 'gat', '--dataset', 'ogbl-collab'],
+        'retrain_rgcn_biokg': ['--unlearning_model', 'retrain', '--gnn', 'rgcn', '--dataset', 'ogbl-biokg'],
+        'grad_ascent': ['--unlearning_model', 'gradient_ascent', '--gnn', 'gin', '--dataset', 'PubMed'],
+        'dtd': ['--unlearning_model', 'descent_to_delete'],
+        'graph_editor': ['--unlearning_model', 'graph_editor'],
+        'molhiv': ['--dataset', 'ogbg-molhiv'],
+        'flags': ['--regen_feats', '--regen_links', '--eval_on_cpu', 'x', '--loss_fct', 'kld_mean',
+                  '--loss_type', 'only1', '--alpha', '0.25', '--num_edge_type', '7', '--topk', '10'],
+    }
+    out = {k: {'argv': v, 'args': vars(make_args(A, v))} for k, v in cases.items()}
+    with open(os.path.join(HERE, 'parse_args.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+def golden_eval(D, T, A):
+    """Trainer.eval / Trainer.test on a fixed model (base.py:229-375)."""
+    g = synth_graph(70, 260, 9, seed=41)
+    d, neg = prepare_deletion(g, 9, seed=8)
+    model, _ = build_ref_model(D, A, 'gat', d, 9, seed=12)
+    tmp = tempfile.mkdtemp()
+    args = make_args(A, ['--gnn', 'gat', '--unlearning_model', 'gnndelete_nodeemb', '--checkpoint_dir', tmp,
+                         '--dataset', 'Cora'])
+    trainer = T.GNNDeleteNodeembTrainer(args)
+    torch.manual_seed(123)
+    loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, _, log = trainer.eval(model, d, 'val')
+    masks = torch.stack(trainer.df_pos_edge)
+    torch.save({'model_state': model.state_dict()}, os.path.join(tmp, 'model_best.pt'))
+    tl, tdt_auc, tdt_aup, tdf_auc, tdf_aup, tdf_logit, all_pair, tlog = trainer.test(model, d)
+    out = dict(state_np(model))
+    out.update(data_np(d, neg))
+    out.update(val_loss=np.float64(loss), val_dt_auc=np.float64(dt_auc), val_dt_aup=np.float64(dt_aup),
+               val_df_auc=np.float64(df_auc), val_df_aup=np.float64(df_aup), val_df_logit=np.array(df_logit),
+               df_pos_masks=np_(masks), eval_seed=np.int64(123),
+               test_loss=np.float64(tl), test_dt_auc=np.float64(tdt_auc), test_df_auc=np.float64(tdf_auc),
+               test_auc_sum=np.float64(trainer.trainer_log['auc_sum']),
+               test_auc_gap=np.float64(trainer.trainer_log['auc_gap']),
+               test_all_pair=np_(all_pair))
+    np.savez_compressed(os.path.join(HERE, 'eval.npz'), **out)
+
+
+def golden_neg_kg(U):
+    g = torch.Generator().manual_seed(3)
+    ei = torch.randint(0, 50, (2, 90), generator=g)
+    et = torch.randint(0, 5, (90,), generator=g)
+    torch.manual_seed(2024)
+    neg = U.negative_sampling_kg(ei, et)
+    np.savez_compressed(os.path.join(HERE, 'neg_kg.npz'), edge_index=np_(ei), edge_type=np_(et),
+                        neg=np_(neg), seed=np.int64(2024))
+
+
+def golden_prep(D):
+    """Run the reference's real delete_gnn.main() (delete_gnn.py:57-283) up to the
+    trainer hand-off and capture the Data it built: Df selection, k-hop S_Df masks,
+    symmetrisation, optimizer construction.  get_trainer returns a recorder."""
+    captured = {}
+
+    class Recorder:
+        def __init__(self, args):
+            self.args = args
+
+        def train(self, model, data, optimizer, args, *rest):
+            captured['data'] = data
+            captured['opt'] = optimizer
+            captured['args'] = args
+            captured['model'] = model
+
+        def test(self, *a, **k):
+            return [{}]
+
+        def save_log(self):
+            pass
+
+    fw = sys.modules['framework']
+    for gnn, seed in [('gcn', 42), ('gat', 21)]:
+        g = synth_graph(120, 500, 7, seed=51)
+        E, n = g['train'], g['num_nodes']
+        # IN / OUT candidate masks as prepare_dataset.py:205-214 defines them
+        _, _, m2 = pyg.k_hop_subgraph(g['test_pos'].flatten().unique(), 2, E, n)
+        cand = {'in': m2, 'out': ~m2}
+        tmp = tempfile.mkdtemp()
+        os.makedirs(os.path.join(tmp, 'data', 'Cora'))
+        d0 = Bag(x=g['x'], num_nodes=n, train_pos_edge_index=E,
+                 val_pos_edge_index=g['val_pos'], val_neg_edge_index=g['val_neg'],
+                 test_pos_edge_index=g['test_pos'], test_neg_edge_index=g['test_neg'])
+        with open(os.path.join(tmp, 'data', 'Cora', f'd_{seed}.pkl'), 'wb') as f:
+            pickle.dump((FakeDataset(7), d0), f)
+        torch.save(cand, os.path.join(tmp, 'data', 'Cora', f'df_{seed}.pt'))
+
+        def get_model(args, m1=None, m2_=None, num_nodes=None, num_edge_type=None):
+            return getattr(D, GNN_CLASS[args.gnn])(args, m1, m2_)
+        fw.get_model, fw.get_trainer = get_model, Recorder
+        ck = os.path.join(tmp, 'ck')
+        op = os.path.join(ck, 'Cora', gnn, 'original', str(seed))
+        os.makedirs(op)
+        a0 = types.SimpleNamespace(in_dim=7, hidden_dim=128, out_dim=64)
+        base = getattr(D, GNN_CLASS[gnn])(a0)
+        torch.save({'model_state': base.state_dict()}, os.path.join(op, 'model_best.pt'))
+        for df, size, lt in [('out', 2.5, 'both_layerwise'), ('in', 100, 'both_all')]:
+            argv = ['--unlearning_model', 'gnndelete_nodeemb', '--gnn', gnn, '--dataset', 'Cora', '--df', df,
+                    '--df_size', str(size), '--random_seed', str(seed), '--data_dir', os.path.join(tmp, 'data'),
+                    '--checkpoint_dir', ck, '--loss_type', lt]
+            old_argv, old_cwd = sys.argv, os.getcwd()
+            sys.argv = ['delete_gnn.py'] + argv
+            os.chdir(tmp)
+            sys.path.insert(0, REF)
+            try:
+                runpy.run_path(os.path.join(REF, 'delete_gnn.py'), run_name='ref_delete_gnn')['main']()
+            finally:
+                sys.argv = old_argv
+                os.chdir(old_cwd)
+                sys.path.remove(REF)
+                torch.autograd.set_detect_anomaly(False)
+            d = captured['data']
+            out = {'in::train': np_(E), 'in::cand': np_(cand[df]), 'in::num_nodes': np.int64(n),
+                   'in::df_size': np.float64(size), 'in::seed': np.int64(seed)}
+            for k in ['train_pos_edge_index', 'df_mask', 'dr_mask', 'sdf_mask', 'sdf_node_1hop_mask',
+                      'sdf_node_2hop_mask', 'directed_df_edge_index']:
+                out[f'out::{k}'] = np_(d[k])
+            out['out::n_opt'] = np.int64(len(captured['opt']) if isinstance(captured['opt'], list) else 1)
+            out['out::ckpt_dir'] = np.array(os.path.relpath(captured['args'].checkpoint_dir, ck))
+            out['out::in_dim'] = np.int64(captured['args'].in_dim)
+            np.savez_compressed(os.path.join(HERE, f'prep_{gnn}_{df}.npz'), **out)
+
+
+def main():
+    torch.set_num_threads(4)
+    D, T, TE, A, U, B = load_reference()
+    golden_del_layer(D)
+    golden_losses(T)
+    golden_wiring(D, A)
+    golden_trajectories(D, T, A)
+    crash = golden_gcn_layerwise_crash(D, T, A)
+    golden_parse_args(A)
+    golden_eval(D, T, A)
+    golden_neg_kg(U)
+    golden_prep(D)
+    with open(os.path.join(HERE, 'MANIFEST.json'), 'w') as f:
+        json.dump({'generated_by': 'tests/golden/make_golden.py', 'reference': REF,
+                   'torch': torch.__version__,
+                   'gcn_both_layerwise_upstream_error': crash,
+                   'files': sorted(x for x in os.listdir(HERE) if x.endswith(('.npz', '.json')))},
+                  f, indent=1)
+    print('golden vectors written to', HERE)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,51 @@
+"""Shared helpers for the test-suite (fixture loading, oracle model construction)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def split_fixture(fx):
+    """-> (state_dict, data dict of tensors, everything else)."""
+    state = {k[3:]: t(v) for k, v in fx.items() if k.startswith('w::')}
+    data = {k[3:]: (int(v) if k == 'd::num_nodes' else t(v)) for k, v in fx.items() if k.startswith('d::')}
+    rest = {k: v for k, v in fx.items() if '::' not in k}
+    return state, data, rest
+
+
+def dims_from_state(gnn, state):
+    if gnn == 'gcn':
+        w1, w2 = state['conv1.lin.weight'], state['conv2.lin.weight']
+    elif gnn == 'gat':
+        w1, w2 = state['conv1.lin_src.weight'], state['conv2.lin_src.weight']
+    elif gnn == 'gin':
+        w1, w2 = state['conv1.nn.weight'], state['conv2.nn.weight']
+    else:
+        r1, r2 = state['conv1.root'], state['conv2.root']
+        return r1.shape[0], r1.shape[1], r2.shape[1]
+    return w1.shape[1], w1.shape[0], w2.shape[0]
+
+
+def oracle_model(gnn, state, mask1=None, mask2=None, num_nodes=None, num_edge_type=None, **kw):
+    from oracle import gnndelete_ref as R
+    i, h, o = dims_from_state(gnn, state)
+    m = R.TwoLayerDelete(gnn, i, h, o, mask1, mask2, num_nodes=num_nodes, num_edge_type=num_edge_type, **kw)
+    missing = m.load_state_dict(state, strict=False)
+    assert not [k for k in missing.missing_keys if 'lin_dst' not in k], missing
+    return m
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a, dtype=torch.float64), torch.as_tensor(b, dtype=torch.float64)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))

@@ -1,0 +1,153 @@
+"""oracle.gnndelete_ref vs the golden vectors generated from the real reference code
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, oracle_model, rel_l2, split_fixture, t
+from oracle import gnndelete_ref as R
+from oracle import pyg_semantics as pyg
+
+TOL = 1e-6        # fp32 arithmetic restated op-for-op: agree to rounding
+
+
+def test_deletion_layer_matches_reference():
+    fx = load_golden('del_layer.npz')
+    for tag in ['partial', 'empty', 'full', 'odd']:
+        x = t(fx[f'{tag}::x']).requires_grad_(True)
+        layer = R.DeletionLayer(x.shape[1], t(fx[f'{tag}::mask']))
+        with torch.no_grad():
+            layer.deletion_weight.copy_(t(fx[f'{tag}::w']))
+        y = layer(x)
+        y.backward(t(fx[f'{tag}::up']))
+        assert torch.equal(y.detach(), t(fx[f'{tag}::y'])), tag
+        assert torch.equal(x.grad, t(fx[f'{tag}::gx'])), tag
+        assert torch.equal(layer.deletion_weight.grad, t(fx[f'{tag}::gw'])), tag
+    x = t(fx['nomask::x'])
+    assert R.DeletionLayer(4, None)(x) is x
+    assert torch.equal(R.DeletionLayer(6, None).deletion_weight.detach(), t(fx['init::w']))
+
+
+@pytest.mark.parametrize('name', ['mse_mean', 'mse_sum', 'kld_mean', 'kld_sum', 'cosine_mean',
+                                  'cosine_sum', 'linear_cka'])
+def test_loss_zoo_matches_reference(name):
+    fx = load_golden('losses.npz')
+    a = t(fx['a']).requires_grad_(True)
+    v = R.LOSSES[name](a, t(fx['b']))
+    v.backward()
+    assert rel_l2(v.detach(), fx[f'{name}::value']) < TOL
+    assert rel_l2(a.grad, fx[f'{name}::grad']) < 1e-5
+
+
+@pytest.mark.parametrize('gnn', ['gcn', 'gat', 'gin'])
+def test_delete_wiring_matches_reference(gnn):
+    fx = load_golden(f'wiring_{gnn}.npz')
+    state, _, rest = split_fixture(fx)
+    m = oracle_model(gnn, state, t(rest['mask1']), t(rest['mask2']), grad_through_conv1=(gnn == 'gcn'))
+    x, ei = t(rest['x']), t(rest['edge_index'])
+    z1, z2 = m(x, ei, return_all_emb=True)
+    o1, o2 = m.get_original_embeddings(x, ei, return_all_emb=True)
+    for got, key in [(z1, 'z1'), (z2, 'z2'), (o1, 'o1'), (o2, 'o2')]:
+        assert rel_l2(got.detach(), rest[key]) < TOL, key
+    a1, a2 = m(x, ei, mask_1hop=t(rest['alt1']), mask_2hop=t(rest['alt2']), return_all_emb=True)
+    assert rel_l2(a1.detach(), rest['a1']) < TOL and rel_l2(a2.detach(), rest['a2']) < TOL
+    s = m.decode(z2, t(rest['val_pos']), t(rest['val_neg']))
+    assert rel_l2(s.detach(), rest['score']) < TOL
+    assert m(x, ei).shape == z2.shape          # return_all_emb=False -> z2 only
+
+
+def test_rgcn_wiring_matches_reference():
+    fx = load_golden('wiring_rgcn.npz')
+    state, _, rest = split_fixture(fx)
+    R_ = int(rest['num_edge_type'])
+    m = oracle_model('rgcn', state, t(rest['mask1']), t(rest['mask2']),
+                     num_nodes=state['node_emb.weight'].shape[0], num_edge_type=R_)
+    x, ei, et = t(rest['x']), t(rest['edge_index']), t(rest['edge_type'])
+    z1, z2 = m(x, ei, et, return_all_emb=True)
+    o1, o2 = m.get_original_embeddings(x, ei, et, return_all_emb=True)
+    for got, key in [(z1, 'z1'), (z2, 'z2'), (o1, 'o1'), (o2, 'o2')]:
+        assert rel_l2(got.detach(), rest[key]) < TOL, key
+    s = m.decode(z2, t(rest['dec_edge']), t(rest['dec_type']))
+    assert rel_l2(s.detach(), rest['score']) < TOL
+
+
+TRAJ = [('gat', 'both_layerwise'), ('gat', 'both_all'), ('gat', 'only2_layerwise'), ('gat', 'only2_all'),
+        ('gat', 'only1'), ('gin', 'both_layerwise'), ('gcn', 'both_all'), ('gcn', 'only2_layerwise'),
+        ('gcn', 'only1')]
+
+
+@pytest.mark.parametrize('gnn,loss_type', TRAJ)
+def test_training_trajectory_matches_reference_loop(gnn, loss_type):
+    """Per-epoch losses and the final Del weights of the reference's real train_fullbatch
+    loop, incl. the zero_grad quirks.  The oracle runs with the backbone frozen
+    (build semantics) - for GCN upstream back-props into conv1 too, which must not change
+    the Del-weight trajectory."""
+    fx = load_golden(f'traj_{gnn}_{loss_type}.npz')
+    state, data, rest = split_fixture(fx)
+    m = oracle_model(gnn, state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    logs, _ = R.nodeemb_fullbatch(m, data, int(rest['epochs']), loss_type, float(rest['alpha']),
+                                  'mse_mean', float(rest['lr']), neg_edge=t(rest['neg']))
+    for key in ['train_loss', 'loss_r', 'loss_l']:
+        got = np.array([l[key] for l in logs])
+        np.testing.assert_allclose(got, rest[key], rtol=2e-5, atol=1e-9, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach(), rest['final_w1']) < 1e-5
+    assert rel_l2(m.deletion2.deletion_weight.detach(), rest['final_w2']) < 1e-5
+
+
+def test_eval_matches_reference():
+    fx = load_golden('eval.npz')
+    state, data, rest = split_fixture(fx)
+    m = oracle_model('gat', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    out = R.eval_linkpred(m, data, 'val', list(t(rest['df_pos_masks'])))
+    assert abs(out['loss'] - float(rest['val_loss'])) < 1e-6
+    assert abs(out['dt_auc'] - float(rest['val_dt_auc'])) < 1e-9
+    assert abs(out['dt_aup'] - float(rest['val_dt_aup'])) < 1e-9
+    assert abs(out['df_auc'] - float(rest['val_df_auc'])) < 1e-9
+    assert abs(out['df_aup'] - float(rest['val_df_aup'])) < 1e-9
+    np.testing.assert_allclose(np.array(out['df_logit']), rest['val_df_logit'], rtol=1e-6)
+    # the 500 cached Dr subsets come from torch.randperm under the recorded seed
+    torch.manual_seed(int(rest['eval_seed']))
+    n_dr, k = int(data['dr_mask'].sum()), len(out['df_logit'])
+    for i in range(3):
+        mk = torch.zeros(n_dr, dtype=torch.bool)
+        mk[torch.randperm(n_dr)[:k]] = True
+        assert torch.equal(mk, t(rest['df_pos_masks'])[i])
+    out_t = R.eval_linkpred(m, data, 'test', list(t(rest['df_pos_masks'])))
+    assert abs(out_t['dt_auc'] - float(rest['test_dt_auc'])) < 1e-9
+    assert abs(out_t['df_auc'] - float(rest['test_df_auc'])) < 1e-9
+    assert rel_l2(out_t['z'] @ out_t['z'].t(), rest['test_all_pair']) < TOL
+
+
+def test_negative_sampling_kg_matches_reference():
+    fx = load_golden('neg_kg.npz')
+    torch.manual_seed(int(fx['seed']))
+    neg = R.negative_sampling_kg(t(fx['edge_index']), t(fx['edge_type']))
+    assert torch.equal(neg, t(fx['neg']))
+
+
+@pytest.mark.parametrize('name', ['prep_gcn_out.npz', 'prep_gcn_in.npz', 'prep_gat_out.npz', 'prep_gat_in.npz'])
+def test_preprocessing_matches_reference_main(name):
+    """Df selection + S_Df masks + symmetrisation exactly as delete_gnn.main() built them."""
+    fx = load_golden(name)
+    E, n = t(fx['in::train']), int(fx['in::num_nodes'])
+    torch.manual_seed(int(fx['in::seed']))
+    size = R.df_size_from_arg(float(fx['in::df_size']), E.shape[1])
+    cand = t(fx['in::cand']).nonzero().squeeze()
+    df_idx = cand[torch.randperm(cand.shape[0])[:size]]
+    df = torch.zeros(E.shape[1], dtype=torch.bool)
+    df[df_idx] = True
+    seeds = E[:, df].flatten().unique()
+    _, e2, m2 = pyg.k_hop_subgraph(seeds, 2, E, n)
+    _, e1, _ = pyg.k_hop_subgraph(seeds, 1, E, n)
+    und, (dfu, m2u) = pyg.to_undirected(E, [df.int(), m2.int()], n)
+    assert torch.equal(und, t(fx['out::train_pos_edge_index']))
+    assert torch.equal(dfu.bool(), t(fx['out::df_mask']))
+    assert torch.equal(~dfu.bool(), t(fx['out::dr_mask']))
+    assert torch.equal(m2u.bool(), t(fx['out::sdf_mask']))
+    s1 = torch.zeros(n, dtype=torch.bool)
+    s1[e1.flatten().unique()] = True
+    s2 = torch.zeros(n, dtype=torch.bool)
+    s2[e2.flatten().unique()] = True
+    assert torch.equal(s1, t(fx['out::sdf_node_1hop_mask']))
+    assert torch.equal(s2, t(fx['out::sdf_node_2hop_mask']))
+    assert torch.equal(E[:, df], t(fx['out::directed_df_edge_index']))
