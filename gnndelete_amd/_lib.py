@@ -1,0 +1,80 @@
+"""ctypes binding of libgnndelete_hip.so (include/gnndelete_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libgnndelete_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'gnndelete_hip.h')
+
+_i32, _i64, _f32, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol the header declares
+PROTOTYPES = {
+    'gd_abi_version': (ctypes.c_int, []),
+    'gd_last_error_string': (ctypes.c_char_p, []),
+    'gd_gcn_norm_f32': (ctypes.c_int, [_p, _p, _i32, _p, _p]),
+    'gd_spmm_csr_f32': (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _f32, _i32, _i32, _p]),
+    'gd_rgcn_mean_f32': (ctypes.c_int, [_p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p]),
+    'gd_gat_aggregate_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _f32, _i32, _i32, _p]),
+    'gd_gat_aggregate_bwd_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64,
+                                                _p, _p, _p, _f32, _i32, _i32, _p]),
+    'gd_rows_gemm_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _i64, _p, _p]),
+    'gd_rows_gemm_wgrad_workspace': (_i64, [_i32, _i32, _i32]),
+    'gd_rows_gemm_wgrad_f32': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p]),
+    'gd_rowpair_mse_workspace': (_i64, [_i32]),
+    'gd_rowpair_mse_f32': (ctypes.c_int, [_p, _i64, _p, _i64, _i32, _p, _p, _i32, _p, _p, _p, _p, _i64, _i32,
+                                          _p, _p, _p]),
+    'gd_edge_dot_f32': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p]),
+    'gd_adam_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _p]),
+}
+
+_lib = None
+
+
+class GnnDeleteHipError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Every function name include/gnndelete_hip.h declares."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    return sorted(set(re.findall(r'\b(gd_[a-z0-9_]+)\s*\(', text)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GnnDeleteHipError(
+                f'{LIB_PATH} is missing: the HIP extension is not built. Run '
+                '`python -c "import __graft_entry__ as g; g.build()"` (or `make -C gnndelete_amd/csrc`). '
+                'There is no CPU fallback.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.gd_abi_version() != 1:
+            raise GnnDeleteHipError('libgnndelete_hip.so ABI version mismatch')
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().gd_last_error_string().decode(errors='replace')
+        raise GnnDeleteHipError(f'{what} failed with code {rc}: {msg}')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device=None):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,65 @@
+// Shared helpers for the gfx950 kernels (error reporting, wave-level primitives).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "gnndelete_hip.h"
+
+namespace gd {
+
+constexpr int kWave = 64;  // CDNA wavefront width (hard-coded on purpose: gfx950 only)
+
+char* error_buffer();  // thread-local, defined in api.cpp
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 256, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int launched(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-(int)e, "%s: %s", what, hipGetErrorString(e));
+  return GD_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define GD_REQUIRE(cond, code, ...) \
+  do {                              \
+    if (!(cond)) return ::gd::fail(code, __VA_ARGS__); \
+  } while (0)
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 acc) {
+  acc.x = fmaf(a, x.x, acc.x);
+  acc.y = fmaf(a, x.y, acc.y);
+  acc.z = fmaf(a, x.z, acc.z);
+  acc.w = fmaf(a, x.w, acc.w);
+  return acc;
+}
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 f4_shfl_xor(float4 v, int mask) {
+  return make_float4(__shfl_xor(v.x, mask), __shfl_xor(v.y, mask), __shfl_xor(v.z, mask), __shfl_xor(v.w, mask));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// lanes-per-row geometry shared by the row-vector kernels: a row of d floats is d/4 float4
+// vectors; LPR lanes (power of two <= 64) cooperate on one row, 64/LPR rows per wave.
+inline int lanes_per_row(int d4) {
+  int l = 1;
+  while (l < d4 && l < 64) l <<= 1;
+  return l;
+}
+
+}  // namespace gd

@@ -1,0 +1,254 @@
+// Fused Deleted-Edge-Consistency + Neighborhood-Influence MSE terms (value AND gradient in one
+// pass), link decoders, Adam.  All HBM/latency-bound row-vector kernels: LPR lanes x float4
+// cover a row, 64/LPR rows (segments / edges) per wave, wave-level xor-shuffle reductions, one
+// partial per block, partials combined by a single block in a fixed order (deterministic).
+#include "common.h"
+
+namespace gd {
+
+template <int LPR, int VPL>
+__global__ __launch_bounds__(256) void rowpair_mse_kernel(
+    const float* __restrict__ z, int64_t ld_z, const float* __restrict__ o, int64_t ld_o, int32_t d4,
+    const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_row, int32_t n_seg,
+    const int32_t* __restrict__ term_o, const float* __restrict__ term_w, const int32_t* __restrict__ term_kind,
+    float* __restrict__ dz, int64_t ld_dz, int32_t dz_compact, float* __restrict__ partials) {
+  constexpr int G = kWave / LPR;
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / LPR, li = lane % LPR;
+  const int u = (blockIdx.x * 4 + wave) * G + g;
+  float s0 = 0.f, s1 = 0.f;
+  if (u < n_seg) {
+    const int row = seg_row[u];
+    const int t0 = seg_ptr[u], t1 = seg_ptr[u + 1];
+    float4 zr[VPL], gr[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int vec = li + v * LPR;
+      zr[v] = vec < d4 ? reinterpret_cast<const float4*>(z + (int64_t)row * ld_z)[vec] : f4_zero();
+      gr[v] = f4_zero();
+    }
+    for (int t = t0; t < t1; ++t) {
+      const float4* orow = reinterpret_cast<const float4*>(o + (int64_t)term_o[t] * ld_o);
+      const float w2 = 2.0f * term_w[t];
+      float sq = 0.f;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const int vec = li + v * LPR;
+        if (vec >= d4) continue;
+        const float4 ov = orow[vec];
+        const float4 df = make_float4(zr[v].x - ov.x, zr[v].y - ov.y, zr[v].z - ov.z, zr[v].w - ov.w);
+        sq = fmaf(df.x, df.x, sq); sq = fmaf(df.y, df.y, sq); sq = fmaf(df.z, df.z, sq); sq = fmaf(df.w, df.w, sq);
+        gr[v] = f4_fma(w2, df, gr[v]);
+      }
+      if (term_kind[t] == 0) s0 += sq; else s1 += sq;
+    }
+    float* drow = dz + (int64_t)(dz_compact ? u : row) * ld_dz;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int vec = li + v * LPR;
+      if (vec < d4) reinterpret_cast<float4*>(drow)[vec] = gr[v];
+    }
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partials[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void pair_sum_reduce_kernel(const float* __restrict__ partials, int32_t n_part,
+                                                              float* __restrict__ sums) {
+  __shared__ float red[2][256];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < n_part; i += 256) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+  red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { sums[0] += red[0][0]; sums[1] += red[1][0]; }
+}
+
+static inline int mse_blocks(int32_t n_seg, int lpr) {
+  const int per_block = 4 * (kWave / lpr);
+  return (n_seg + per_block - 1) / per_block;
+}
+
+template <int LPR, int VPL, bool DISTMULT>
+__global__ __launch_bounds__(256) void edge_dot_kernel(const float* __restrict__ z, int64_t ld_z, int32_t d4,
+                                                       const int64_t* __restrict__ e0, const int64_t* __restrict__ e1,
+                                                       const float* __restrict__ rel, int64_t ld_rel,
+                                                       const int64_t* __restrict__ etype, int64_t n_edges,
+                                                       float* __restrict__ out) {
+  constexpr int G = kWave / LPR;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR, li = lane % LPR;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G + g;
+  float p = 0.f;
+  if (m < n_edges) {
+    const float4* a = reinterpret_cast<const float4*>(z + e0[m] * ld_z);
+    const float4* b = reinterpret_cast<const float4*>(z + e1[m] * ld_z);
+    const float4* r = DISTMULT ? reinterpret_cast<const float4*>(rel + etype[m] * ld_rel) : nullptr;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int vec = li + v * LPR;
+      if (vec >= d4) continue;
+      float4 av = a[vec];
+      const float4 bv = b[vec];
+      if (DISTMULT) { const float4 rv = r[vec]; av.x *= rv.x; av.y *= rv.y; av.z *= rv.z; av.w *= rv.w; }
+      p = fmaf(av.x, bv.x, p); p = fmaf(av.y, bv.y, p); p = fmaf(av.z, bv.z, p); p = fmaf(av.w, bv.w, p);
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < LPR; off <<= 1) p += __shfl_xor(p, off);
+  if (li == 0 && m < n_edges) out[m] = p;
+}
+
+template <bool DISTMULT>
+__global__ __launch_bounds__(256) void edge_dot_scalar_kernel(const float* __restrict__ z, int64_t ld_z, int32_t d,
+                                                              const int64_t* __restrict__ e0,
+                                                              const int64_t* __restrict__ e1,
+                                                              const float* __restrict__ rel, int64_t ld_rel,
+                                                              const int64_t* __restrict__ etype, int64_t n_edges,
+                                                              float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= n_edges) return;
+  float p = 0.f;
+  for (int c = lane; c < d; c += kWave) {
+    float av = z[e0[m] * ld_z + c];
+    if (DISTMULT) av *= rel[etype[m] * ld_rel + c];
+    p = fmaf(av, z[e1[m] * ld_z + c], p);
+  }
+  p = wave_sum(p);
+  if (lane == 0) out[m] = p;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   int32_t* __restrict__ step, int64_t n, float lr, float beta1,
+                                                   float beta2, float eps) {
+  // every thread reads the pre-increment counter; thread 0 of the LAST block bumps it.  The
+  // grid is small (Del weights: 20k elements) so all blocks read before that block retires in
+  // practice, but correctness must not rely on it: the bump is done by a separate kernel.
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int t = *step + 1;
+  const double bc1 = 1.0 - pow((double)beta1, (double)t);
+  const double bc2 = 1.0 - pow((double)beta2, (double)t);
+  const float g = grad[i];
+  const float mi = m[i] + (g - m[i]) * (1.0f - beta1);           // exp_avg.lerp_(grad, 1-beta1)
+  const float vi = fmaf(1.0f - beta2, g * g, beta2 * v[i]);      // mul_(beta2).addcmul_(g, g, 1-beta2)
+  m[i] = mi;
+  v[i] = vi;
+  const float step_size = (float)((double)lr / bc1);
+  const float denom = sqrtf(vi) / (float)sqrt(bc2) + eps;
+  param[i] = param[i] - step_size * (mi / denom);
+}
+
+__global__ void bump_step_kernel(int32_t* step) { *step += 1; }
+
+}  // namespace gd
+
+extern "C" int64_t gd_rowpair_mse_workspace(int32_t n_seg) {
+  // worst case LPR = 64 (one segment per wave): 4 segments per block, 2 floats per block
+  return 2 * (int64_t)((n_seg + 3) / 4 + 1);
+}
+
+extern "C" int gd_rowpair_mse_f32(const float* z, int64_t ld_z, const float* o, int64_t ld_o, int32_t d,
+                                  const int32_t* seg_ptr, const int32_t* seg_row, int32_t n_seg, const int32_t* term_o,
+                                  const float* term_w, const int32_t* term_kind, float* dz, int64_t ld_dz,
+                                  int32_t dz_compact, float* sums, float* partials, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(sums && partials, GD_E_NULL, "gd_rowpair_mse_f32: null sums/partials");
+  if (n_seg == 0) return GD_OK;
+  GD_REQUIRE(z && o && seg_ptr && seg_row && term_o && term_w && term_kind && dz, GD_E_NULL,
+             "gd_rowpair_mse_f32: null pointer");
+  GD_REQUIRE(d > 0 && d % 4 == 0 && d <= 1024 && ld_z % 4 == 0 && ld_o % 4 == 0 && ld_dz % 4 == 0, GD_E_DIM,
+             "gd_rowpair_mse_f32: d=%d must be a multiple of 4 (<=1024) with 16-byte row strides", d);
+  GD_REQUIRE(aligned16(z) && aligned16(o) && aligned16(dz), GD_E_ALIGN, "gd_rowpair_mse_f32: unaligned matrix");
+  hipStream_t s = (hipStream_t)stream;
+  const int d4 = d / 4;
+  const int lpr = lanes_per_row(d4);
+  const int nb = mse_blocks(n_seg, lpr);
+#define GD_MSE_CASE(LPR, VPL)                                                                                       \
+  hipLaunchKernelGGL((rowpair_mse_kernel<LPR, VPL>), dim3(nb), dim3(256), 0, s, z, ld_z, o, ld_o, d4, seg_ptr,      \
+                     seg_row, n_seg, term_o, term_w, term_kind, dz, ld_dz, dz_compact, partials)
+  switch (lpr) {
+    case 1: GD_MSE_CASE(1, 1); break;
+    case 2: GD_MSE_CASE(2, 1); break;
+    case 4: GD_MSE_CASE(4, 1); break;
+    case 8: GD_MSE_CASE(8, 1); break;
+    case 16: GD_MSE_CASE(16, 1); break;
+    case 32: GD_MSE_CASE(32, 1); break;
+    default:
+      if (d4 <= 64) GD_MSE_CASE(64, 1);
+      else if (d4 <= 128) GD_MSE_CASE(64, 2);
+      else GD_MSE_CASE(64, 4);
+  }
+#undef GD_MSE_CASE
+  int rc = launched("rowpair_mse");
+  if (rc) return rc;
+  hipLaunchKernelGGL(pair_sum_reduce_kernel, dim3(1), dim3(256), 0, s, partials, nb, sums);
+  return launched("pair_sum_reduce");
+}
+
+extern "C" int gd_edge_dot_f32(const float* z, int64_t ld_z, int32_t d, const int64_t* e0, const int64_t* e1,
+                               const float* rel, int64_t ld_rel, const int64_t* etype, int64_t n_edges, float* out,
+                               void* stream) {
+  using namespace gd;
+  if (n_edges == 0) return GD_OK;
+  GD_REQUIRE(z && e0 && e1 && out, GD_E_NULL, "gd_edge_dot_f32: null pointer");
+  GD_REQUIRE((rel == nullptr) == (etype == nullptr), GD_E_NULL, "gd_edge_dot_f32: rel and etype go together");
+  GD_REQUIRE(d > 0 && ld_z >= d, GD_E_DIM, "gd_edge_dot_f32: bad dims");
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec_ok = d % 4 == 0 && d <= 256 && ld_z % 4 == 0 && aligned16(z) && (!rel || (aligned16(rel) && ld_rel % 4 == 0));
+  if (!vec_ok) {
+    const dim3 grid((unsigned)((n_edges + 3) / 4));
+    if (rel) hipLaunchKernelGGL((edge_dot_scalar_kernel<true>), grid, dim3(256), 0, s, z, ld_z, d, e0, e1, rel, ld_rel, etype, n_edges, out);
+    else hipLaunchKernelGGL((edge_dot_scalar_kernel<false>), grid, dim3(256), 0, s, z, ld_z, d, e0, e1, rel, ld_rel, etype, n_edges, out);
+    return launched("edge_dot_scalar");
+  }
+  const int d4 = d / 4;
+  const int lpr = lanes_per_row(d4);
+  const int64_t per_block = 4 * (kWave / lpr);
+  const dim3 grid((unsigned)((n_edges + per_block - 1) / per_block));
+#define GD_DOT_CASE(LPR)                                                                                              \
+  do {                                                                                                                \
+    if (rel) hipLaunchKernelGGL((edge_dot_kernel<LPR, 1, true>), grid, dim3(256), 0, s, z, ld_z, d4, e0, e1, rel, ld_rel, etype, n_edges, out); \
+    else hipLaunchKernelGGL((edge_dot_kernel<LPR, 1, false>), grid, dim3(256), 0, s, z, ld_z, d4, e0, e1, rel, ld_rel, etype, n_edges, out);    \
+  } while (0)
+  switch (lpr) {
+    case 1: GD_DOT_CASE(1); break;
+    case 2: GD_DOT_CASE(2); break;
+    case 4: GD_DOT_CASE(4); break;
+    case 8: GD_DOT_CASE(8); break;
+    case 16: GD_DOT_CASE(16); break;
+    case 32: GD_DOT_CASE(32); break;
+    default: GD_DOT_CASE(64); break;
+  }
+#undef GD_DOT_CASE
+  return launched("edge_dot");
+}
+
+extern "C" int gd_adam_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t* step,
+                           int64_t n, float lr, float beta1, float beta2, float eps, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(param && grad && exp_avg && exp_avg_sq && step, GD_E_NULL, "gd_adam_f32: null pointer");
+  GD_REQUIRE(n >= 0, GD_E_DIM, "gd_adam_f32: n < 0");
+  hipStream_t s = (hipStream_t)stream;
+  if (n > 0) {
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, grad, exp_avg,
+                       exp_avg_sq, step, n, lr, beta1, beta2, eps);
+    int rc = launched("adam");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, s, step);
+  return launched("adam_bump");
+}

@@ -1,0 +1,193 @@
+// CSR SpMM / gather-scatter-add kernels for the frozen-backbone message passing
+// (GCN weighted sum, GIN plain sum, R-GCN per-relation mean).
+//
+// Layout: CSR over TARGET rows, col[] = source node, fp32 row-major features.
+// Mapping to CDNA4: one 64-lane wave owns one output row.  A feature row of d floats is d/4
+// float4 vectors; LPR lanes (16 B each -> one fully coalesced 16*LPR-byte read per neighbour)
+// cover it, so G = 64/LPR neighbours are gathered concurrently by the G lane groups of the
+// wave.  The (col, val) pairs of a row are fetched 64 at a time with one coalesced load and
+// handed to the groups with ds_bpermute (__shfl) - the LDS crossbar, no LDS storage.  Group
+// partial sums are combined with a log2(G)-step xor-shuffle tree, so the summation order is
+// fixed (bit-reproducible run to run).  HBM-bound: bytes = 4(n+1) + 8 nnz + 8 n d.
+#include "common.h"
+
+namespace gd {
+
+template <int LPR, int VPL, bool MEAN>
+__global__ __launch_bounds__(256) void spmm_vec_kernel(const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col,
+                                                       const float* __restrict__ val,
+                                                       const float* __restrict__ x, int64_t ldx,
+                                                       float* __restrict__ y, int64_t ldy,
+                                                       const float* __restrict__ bias, float self_coef,
+                                                       int32_t n_rows, int32_t x_rows_mod, int32_t d4) {
+  constexpr int G = kWave / LPR;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int g = lane / LPR;
+  const int li = lane % LPR;
+  const int start = rowptr[row];
+  const int end = rowptr[row + 1];
+
+  float4 acc[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
+
+  for (int base = start; base < end; base += kWave) {
+    const int k = base + lane;
+    const bool live = k < end;
+    const int c = live ? col[k] : 0;
+    const float w = live ? (val ? val[k] : 1.0f) : 0.0f;
+    const int cnt = min(kWave, end - base);
+    // padded slots carry w = 0 and c = 0 (a harmless re-read of row 0), so the trip count can
+    // be rounded up to the unroll factor
+    const int trips = (cnt + G - 1) / G;
+
+    for (int it = 0; it < trips; ++it) {
+      const int j = it * G + g;
+      const int cj = __shfl(c, j);
+      const float wj = __shfl(w, j);
+      const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)cj * ldx);
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const int vec = li + v * LPR;
+        if (vec < d4) acc[v] = f4_fma(wj, xr[vec], acc[v]);
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) acc[v] = f4_shfl_xor(acc[v], off);
+  }
+  if (g != 0) return;
+  const float scale = MEAN ? (end > start ? 1.0f / (float)(end - start) : 0.0f) : 1.0f;
+  // MEAN mode (typed SpMM): virtual row = rel * n + i, self/bias unused
+  const int self_row = x_rows_mod > 0 ? row % x_rows_mod : row;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int vec = li + v * LPR;
+    if (vec >= d4) continue;
+    float4 o = acc[v];
+    if (MEAN) {
+      o.x *= scale; o.y *= scale; o.z *= scale; o.w *= scale;
+    } else {
+      if (self_coef != 0.0f) {
+        const float4 s = reinterpret_cast<const float4*>(x + (int64_t)self_row * ldx)[vec];
+        o = f4_fma(self_coef, s, o);
+      }
+      if (bias) o = f4_add(o, reinterpret_cast<const float4*>(bias)[vec]);
+    }
+    reinterpret_cast<float4*>(y + (int64_t)row * ldy)[vec] = o;
+  }
+}
+
+// Any d / any alignment: one wave per row, lanes stride over columns.
+template <bool MEAN>
+__global__ __launch_bounds__(256) void spmm_scalar_kernel(const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ col,
+                                                          const float* __restrict__ val,
+                                                          const float* __restrict__ x, int64_t ldx,
+                                                          float* __restrict__ y, int64_t ldy,
+                                                          const float* __restrict__ bias, float self_coef,
+                                                          int32_t n_rows, int32_t x_rows_mod, int32_t d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int start = rowptr[row], end = rowptr[row + 1];
+  const int self_row = x_rows_mod > 0 ? row % x_rows_mod : row;
+  for (int c0 = 0; c0 < d; c0 += kWave) {
+    const int cc = c0 + lane;
+    float acc = 0.f;
+    for (int k = start; k < end; ++k) {
+      const float w = val ? val[k] : 1.0f;
+      if (cc < d) acc = fmaf(w, x[(int64_t)col[k] * ldx + cc], acc);
+    }
+    if (cc < d) {
+      if (MEAN) {
+        acc = end > start ? acc / (float)(end - start) : 0.f;
+      } else {
+        if (self_coef != 0.0f) acc = fmaf(self_coef, x[(int64_t)self_row * ldx + cc], acc);
+        if (bias) acc += bias[cc];
+      }
+      y[(int64_t)row * ldy + cc] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gcn_norm_kernel(const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col, int32_t n_rows,
+                                                       float* __restrict__ val) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int start = rowptr[row], end = rowptr[row + 1];
+  const float di = 1.0f / sqrtf((float)(end - start));
+  for (int k = start + lane; k < end; k += kWave) {
+    const int c = col[k];
+    const float dj = 1.0f / sqrtf((float)(rowptr[c + 1] - rowptr[c]));
+    val[k] = dj * di;
+  }
+}
+
+template <bool MEAN>
+static int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const float* x,
+                       int64_t ldx, float* y, int64_t ldy, const float* bias, float self_coef,
+                       int32_t n_rows, int32_t x_rows_mod, int32_t d, hipStream_t s) {
+  if (n_rows == 0 || d == 0) return GD_OK;
+  const dim3 grid((n_rows + 3) / 4), block(256);
+  const bool vec_ok = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) &&
+                      (!bias || aligned16(bias)) && d <= 1024;
+  if (!vec_ok) {
+    hipLaunchKernelGGL((spmm_scalar_kernel<MEAN>), grid, block, 0, s, rowptr, col, val, x, ldx, y, ldy, bias,
+                       self_coef, n_rows, x_rows_mod, d);
+    return launched("spmm_scalar");
+  }
+  const int d4 = d / 4;
+#define GD_SPMM_CASE(LPR, VPL)                                                                              \
+  hipLaunchKernelGGL((spmm_vec_kernel<LPR, VPL, MEAN>), grid, block, 0, s, rowptr, col, val, x, ldx, y, ldy, \
+                     bias, self_coef, n_rows, x_rows_mod, d4)
+  if (d4 <= 1) GD_SPMM_CASE(1, 1);
+  else if (d4 <= 2) GD_SPMM_CASE(2, 1);
+  else if (d4 <= 4) GD_SPMM_CASE(4, 1);
+  else if (d4 <= 8) GD_SPMM_CASE(8, 1);
+  else if (d4 <= 16) GD_SPMM_CASE(16, 1);
+  else if (d4 <= 32) GD_SPMM_CASE(32, 1);
+  else if (d4 <= 64) GD_SPMM_CASE(64, 1);
+  else if (d4 <= 128) GD_SPMM_CASE(64, 2);
+  else GD_SPMM_CASE(64, 4);
+#undef GD_SPMM_CASE
+  return launched("spmm_vec");
+}
+
+}  // namespace gd
+
+extern "C" int gd_gcn_norm_f32(const int32_t* rowptr, const int32_t* col, int32_t n_rows, float* val,
+                               void* stream) {
+  GD_REQUIRE(rowptr && col && val, GD_E_NULL, "gd_gcn_norm_f32: null pointer");
+  GD_REQUIRE(n_rows >= 0, GD_E_DIM, "gd_gcn_norm_f32: n_rows < 0");
+  if (n_rows == 0) return GD_OK;
+  hipLaunchKernelGGL(gd::gcn_norm_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rowptr, col,
+                     n_rows, val);
+  return gd::launched("gcn_norm");
+}
+
+extern "C" int gd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* x,
+                               int64_t ldx, float* y, int64_t ldy, const float* bias, float self_coef,
+                               int32_t n_rows, int32_t d, void* stream) {
+  GD_REQUIRE(rowptr && col && x && y, GD_E_NULL, "gd_spmm_csr_f32: null pointer");
+  GD_REQUIRE(n_rows >= 0 && d >= 0 && ldx >= d && ldy >= d, GD_E_DIM, "gd_spmm_csr_f32: bad dims n=%d d=%d", n_rows, d);
+  GD_REQUIRE(x != y, GD_E_DIM, "gd_spmm_csr_f32: x and y must not alias");
+  return gd::launch_spmm<false>(rowptr, col, val, x, ldx, y, ldy, bias, self_coef, n_rows, 0, d,
+                                (hipStream_t)stream);
+}
+
+extern "C" int gd_rgcn_mean_f32(const int32_t* rowptr, const int32_t* col, const float* x, int64_t ldx, float* y,
+                                int64_t ldy, int32_t n_rel, int32_t n_rows, int32_t d, void* stream) {
+  GD_REQUIRE(rowptr && col && x && y, GD_E_NULL, "gd_rgcn_mean_f32: null pointer");
+  GD_REQUIRE(n_rel >= 0 && n_rows >= 0 && d >= 0 && ldx >= d && ldy >= d, GD_E_DIM, "gd_rgcn_mean_f32: bad dims");
+  GD_REQUIRE((int64_t)n_rel * n_rows < (1ll << 31), GD_E_DIM, "gd_rgcn_mean_f32: n_rel*n_rows overflows int32");
+  return gd::launch_spmm<true>(rowptr, col, nullptr, x, ldx, y, ldy, nullptr, 0.f, n_rel * n_rows, n_rows, d,
+                               (hipStream_t)stream);
+}

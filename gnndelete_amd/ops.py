@@ -1,0 +1,220 @@
+"""torch.autograd.Function wrappers around the C ABI (include/gnndelete_hip.h).
+
+PyTorch only owns memory, streams and the autograd tape here; all arithmetic on the hot path is
+the HIP library's.  Every wrapper raises when handed CPU tensors - there is no fallback."""
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+def _f32_rows(t):
+    """fp32, unit column stride, 16-byte aligned rows (what the kernels require)."""
+    if t.device.type != 'cuda':
+        raise _lib.GnnDeleteHipError('gnndelete_amd ops need CUDA(HIP) tensors; got a CPU tensor (no CPU fallback)')
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1] or (t.stride(0) % 4 and t.shape[1] % 4 == 0):
+        t = t.contiguous()
+    return t
+
+
+def _spmm_raw(rowptr, col, val, x, bias, self_coef, n_rows):
+    y = torch.empty(n_rows, x.shape[1], dtype=torch.float32, device=x.device)
+    check(_lib.lib().gd_spmm_csr_f32(ptr(rowptr), ptr(col), ptr(val), ptr(x), x.stride(0), ptr(y), y.stride(0),
+                                     ptr(bias), float(self_coef), n_rows, x.shape[1], stream_ptr(x.device)),
+          'gd_spmm_csr_f32')
+    return y
+
+
+class _SpMM(torch.autograd.Function):
+    """y = self_coef * x + A x + bias over a CSRGraph (A = val or all-ones)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, graph, self_coef):
+        x = _f32_rows(x)
+        ctx.graph, ctx.self_coef = graph, self_coef
+        ctx.has_bias = bias is not None
+        return _spmm_raw(graph.rowptr, graph.col, graph.val, x, bias, self_coef, graph.n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = ctx.graph
+        dx = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _spmm_raw(g.rowptr_t, g.col_t, g.val_t, _f32_rows(dy), None, ctx.self_coef, g.n)
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            db = dy.sum(0)
+        return dx, db, None, None
+
+
+def spmm(x, graph, bias=None, self_coef=0.0):
+    return _SpMM.apply(x, bias, graph, self_coef)
+
+
+# ------------------------------------------------------------------------------ Del operator
+def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, save_in=None):
+    """out[idx] = act(inp[idx]) @ (w or w^T) - raw call (no autograd)."""
+    inp = _f32_rows(inp)
+    n_sel = inp.shape[0] if idx is None else int(idx.shape[0])
+    d_in = inp.shape[1]
+    d_out = w.shape[0] if trans_w else w.shape[1]
+    assert (w.shape[1] if trans_w else w.shape[0]) == d_in
+    if out is None:
+        out = torch.empty(inp.shape[0], d_out, dtype=torch.float32, device=inp.device)
+    w = w.contiguous()
+    check(_lib.lib().gd_rows_gemm_f32(ptr(inp), inp.stride(0), ptr(idx), n_sel, ptr(w), d_in, d_out, int(trans_w),
+                                      ptr(bias), int(relu_in), ptr(out), out.stride(0), ptr(save_in),
+                                      stream_ptr(inp.device)), 'gd_rows_gemm_f32')
+    return out
+
+
+def rows_gemm_wgrad(a, a_idx, g, g_idx, n_sel, relu_mask=None, out=None, accumulate=False):
+    """dW[d_a, d_b] (+)= sum_s a[a_idx[s]]^T g[g_idx[s]] - raw call."""
+    a, g = _f32_rows(a), _f32_rows(g)
+    d_a, d_b = a.shape[1], g.shape[1]
+    if out is None:
+        out = torch.zeros(d_a, d_b, dtype=torch.float32, device=a.device)
+        accumulate = False
+    ws = torch.empty(max(1, _lib.lib().gd_rows_gemm_wgrad_workspace(n_sel, d_a, d_b)), dtype=torch.float32,
+                     device=a.device)
+    if relu_mask is not None:
+        relu_mask = _f32_rows(relu_mask)
+        assert relu_mask.stride(0) == g.stride(0)
+    check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(a), a.stride(0), ptr(a_idx), ptr(g), g.stride(0), ptr(g_idx),
+                                            ptr(relu_mask), n_sel, d_a, d_b, ptr(out), int(accumulate), ptr(ws),
+                                            stream_ptr(a.device)), 'gd_rows_gemm_wgrad_f32')
+    return out
+
+
+class _DelRows(torch.autograd.Function):
+    """DeletionLayer.forward: copy of x whose rows ``idx`` are multiplied by W."""
+
+    @staticmethod
+    def forward(ctx, x, w, idx):
+        x = _f32_rows(x)
+        z = x.clone()
+        rows_gemm(x, idx, w, out=z)
+        ctx.idx = idx
+        # W is only needed for the input gradient; not saving it otherwise lets the layer-wise
+        # trainer step W in place between the two backward passes (frozen-backbone semantics)
+        ctx.save_for_backward(x, w if ctx.needs_input_grad[0] else None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w = ctx.saved_tensors
+        idx = ctx.idx
+        dz = _f32_rows(dz)
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            dw = rows_gemm_wgrad(x, idx, dz, idx, int(idx.shape[0]))
+        if ctx.needs_input_grad[0]:
+            dx = dz.clone()
+            rows_gemm(dz, idx, w, trans_w=True, out=dx)
+        return dx, dw, None
+
+
+def del_rows(x, w, idx):
+    return _DelRows.apply(x, w, idx)
+
+
+# ------------------------------------------------------------------------------ GAT
+class _GatAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, a_src, a_dst, bias, graph, slope):
+        h = _f32_rows(h)
+        a_src, a_dst = a_src.contiguous().float(), a_dst.contiguous().float()
+        n, d = graph.n, h.shape[1]
+        y = torch.empty(n, d, dtype=torch.float32, device=h.device)
+        need = any(ctx.needs_input_grad[:3])
+        alpha = torch.empty(graph.nnz, dtype=torch.float32, device=h.device) if need else None
+        check(_lib.lib().gd_gat_aggregate_f32(ptr(graph.rowptr), ptr(graph.col), ptr(a_src), ptr(a_dst), ptr(h),
+                                              h.stride(0), ptr(y), y.stride(0), ptr(bias), ptr(alpha), float(slope),
+                                              n, d, stream_ptr(h.device)), 'gd_gat_aggregate_f32')
+        ctx.graph, ctx.slope, ctx.has_bias = graph, slope, bias is not None
+        if need:
+            ctx.save_for_backward(h, a_src, a_dst, alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, a_src, a_dst, alpha = ctx.saved_tensors
+        g = ctx.graph
+        dy = _f32_rows(dy)
+        n, d = g.n, h.shape[1]
+        dh = torch.empty_like(h)
+        da_src = torch.empty(n, dtype=torch.float32, device=h.device)
+        da_dst = torch.empty(n, dtype=torch.float32, device=h.device)
+        de = torch.empty(g.nnz, dtype=torch.float32, device=h.device)
+        check(_lib.lib().gd_gat_aggregate_bwd_f32(
+            ptr(g.rowptr), ptr(g.col), ptr(alpha), ptr(g.rowptr_t), ptr(g.col_t), ptr(g.perm_t), ptr(a_src),
+            ptr(a_dst), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(dh), dh.stride(0), ptr(da_src), ptr(da_dst),
+            ptr(de), float(ctx.slope), n, d, stream_ptr(h.device)), 'gd_gat_aggregate_bwd_f32')
+        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        return dh, da_src, da_dst, db, None, None
+
+
+def gat_aggregate(h, a_src, a_dst, graph, bias=None, slope=0.2):
+    return _GatAggregate.apply(h, a_src, a_dst, bias, graph, slope)
+
+
+# ------------------------------------------------------------------------------ R-GCN mean
+class _RgcnMean(torch.autograd.Function):
+    """[R, n, d] per-relation mean aggregates of x over a typed CSR (graph.build_typed_csr)."""
+
+    @staticmethod
+    def forward(ctx, x, typed, num_rel, n):
+        x = _f32_rows(x)
+        rowptr, col, rowptr_t, col_t, inv_t = typed
+        y = torch.empty(num_rel, n, x.shape[1], dtype=torch.float32, device=x.device)
+        check(_lib.lib().gd_rgcn_mean_f32(ptr(rowptr), ptr(col), ptr(x), x.stride(0), ptr(y), y.stride(1), num_rel, n,
+                                          x.shape[1], stream_ptr(x.device)), 'gd_rgcn_mean_f32')
+        ctx.typed, ctx.n = typed, n
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        _, _, rowptr_t, col_t, inv_t = ctx.typed
+        dy2 = _f32_rows(dy.reshape(-1, dy.shape[-1]))
+        dx = _spmm_raw(rowptr_t, col_t, inv_t, dy2, None, 0.0, ctx.n)
+        return dx, None, None, None
+
+
+def rgcn_mean(x, typed, num_rel, n):
+    return _RgcnMean.apply(x, typed, num_rel, n)
+
+
+# ------------------------------------------------------------------------------ decoders
+class _EdgeDot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, rel, e0, e1, etype):
+        z = _f32_rows(z)
+        e0, e1 = e0.contiguous().long(), e1.contiguous().long()
+        if rel is not None:
+            rel, etype = _f32_rows(rel), etype.contiguous().long()
+        out = torch.empty(e0.shape[0], dtype=torch.float32, device=z.device)
+        check(_lib.lib().gd_edge_dot_f32(ptr(z), z.stride(0), z.shape[1], ptr(e0), ptr(e1), ptr(rel),
+                                         rel.stride(0) if rel is not None else 0, ptr(etype), e0.shape[0], ptr(out),
+                                         stream_ptr(z.device)), 'gd_edge_dot_f32')
+        ctx.save_for_backward(z, rel, e0, e1, etype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, rel, e0, e1, etype = ctx.saved_tensors
+        dz = drel = None
+        a, b = z[e0], z[e1]
+        r = rel[etype] if rel is not None else None
+        g = dout[:, None]
+        if ctx.needs_input_grad[0]:
+            dz = torch.zeros_like(z)
+            dz.index_add_(0, e0, g * (b * r if r is not None else b))
+            dz.index_add_(0, e1, g * (a * r if r is not None else a))
+        if rel is not None and ctx.needs_input_grad[1]:
+            drel = torch.zeros_like(rel).index_add_(0, etype, g * a * b)
+        return dz, drel, None, None, None
+
+
+def edge_dot(z, e0, e1, rel=None, etype=None):
+    return _EdgeDot.apply(z, rel, e0, e1, etype)

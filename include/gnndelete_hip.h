@@ -1,0 +1,153 @@
+/*
+ * gnndelete_hip.h - C ABI of libgnndelete_hip.so, the MI355X (gfx950) kernels behind the
+ * GNNDelete hot path.
+ *
+ * The reference (mims-harvard/GNNDelete) has no FFI: its hot path runs inside PyTorch and the
+ * un-vendored torch_geometric ops.  Each entry below replaces the third-party/PyTorch op chain
+ * the reference calls at the cited site (paths relative to /root/reference).  The host-side
+ * mirror of the reference's Python operator API (gnndelete_amd/framework) binds these symbols
+ * with ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned storage (PyTorch tensors); nothing
+ *     is allocated, freed or retained; scratch is passed in explicitly;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every call only enqueues work on it and returns (capturable in a hipGraph);
+ *   - matrices are row-major fp32 with an explicit leading dimension (elements);
+ *   - graph structure is CSR over TARGET rows with int32 indices:
+ *       rowptr[n_rows+1], col[nnz] = source node of each in-edge, val[nnz] = edge weight;
+ *   - return value: 0 = ok, >0 = argument error (GD_E_*), <0 = -(hipError_t).
+ *     Nothing throws; gd_last_error_string() describes the last failure of the calling thread.
+ *   - no global mutable state besides that thread-local error string: re-entrant per stream.
+ */
+#ifndef GNNDELETE_HIP_H
+#define GNNDELETE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GD_ABI_VERSION 1
+
+enum {
+  GD_OK = 0,
+  GD_E_NULL = 1,      /* required pointer is NULL */
+  GD_E_DIM = 2,       /* unsupported / inconsistent dimension */
+  GD_E_ALIGN = 3,     /* pointer or leading dimension not 16-byte aligned where required */
+  GD_E_WORKSPACE = 4  /* scratch buffer too small */
+};
+
+int gd_abi_version(void);
+const char* gd_last_error_string(void);
+
+/* ---------------------------------------------------------------- message passing ----- */
+
+/* GCN symmetric normalisation on a CSR that already contains exactly one self loop per node:
+ *   val[k] = deg[i]^-1/2 * deg[col[k]]^-1/2,  deg[i] = rowptr[i+1]-rowptr[i]  (k in row i)
+ * Replaces torch_geometric gcn_norm inside GCNConv.forward (framework/models/gcn.py:16,19). */
+int gd_gcn_norm_f32(const int32_t* rowptr, const int32_t* col, int32_t n_rows, float* val, void* stream);
+
+/* CSR SpMM / gather-scatter-add:
+ *   y[i,:] = self_coef * x[i,:] + sum_{k in row i} (val ? val[k] : 1) * x[col[k],:] + (bias ? bias : 0)
+ * d must be a multiple of 4, x/y/bias 16-byte aligned, ldx/ldy multiples of 4.
+ * Replaces MessagePassing.propagate (gather + scatter_add) of GCNConv / GINConv
+ * (framework/models/gcn.py:11-24, gin.py:11-12,26-34); with the transposed CSR it is the
+ * backward of the same op. */
+int gd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                    const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias,
+                    float self_coef, int32_t n_rows, int32_t d, void* stream);
+
+/* Per-relation mean aggregation of R-GCN ("typed SpMM") over a relation-major CSR:
+ *   rowptr[(r*n_rows + i) .. +1] delimit the in-edges of type r into node i;
+ *   y[r][i,:] = mean_{k} x[col[k],:]   (0 when the segment is empty),  y is [R, n_rows, ldy].
+ * Replaces the relation loop of RGCNConv.forward (framework/models/rgcn.py:17-22,31-33). */
+int gd_rgcn_mean_f32(const int32_t* rowptr, const int32_t* col, const float* x, int64_t ldx,
+                     float* y, int64_t ldy, int32_t n_rel, int32_t n_rows, int32_t d, void* stream);
+
+/* GAT (heads=1) fused edge-softmax aggregation over a CSR with one self loop per node:
+ *   e_k = LeakyReLU(a_src[col[k]] + a_dst[i], slope); alpha = softmax_k(e) (denominator + 1e-16)
+ *   y[i,:] = sum_k alpha_k h[col[k],:] + bias;  alpha (nnz floats, optional) is kept for backward.
+ * Replaces GATConv.forward's gather/leaky_relu/softmax/scatter chain (framework/models/gat.py:11-24). */
+int gd_gat_aggregate_f32(const int32_t* rowptr, const int32_t* col, const float* a_src, const float* a_dst,
+                         const float* h, int64_t ldh, float* y, int64_t ldy, const float* bias,
+                         float* alpha_out, float slope, int32_t n_rows, int32_t d, void* stream);
+
+/* Backward of gd_gat_aggregate_f32 w.r.t. h (message path), a_src and a_dst, given dy.
+ *   rowptr/col/alpha: forward CSR (target-major) and its saved attention;
+ *   rowptr_t/col_t/perm_t: the transposed CSR (source-major) and, per transposed entry, the
+ *   index of the same edge in the forward CSR.
+ * Outputs: dh [n,d] (message path only), da_src[n], da_dst[n]; scratch de[nnz]. */
+int gd_gat_aggregate_bwd_f32(const int32_t* rowptr, const int32_t* col, const float* alpha,
+                             const int32_t* rowptr_t, const int32_t* col_t, const int32_t* perm_t,
+                             const float* a_src, const float* a_dst, const float* h, int64_t ldh,
+                             const float* dy, int64_t lddy, float* dh, int64_t lddh,
+                             float* da_src, float* da_dst, float* de, float slope,
+                             int32_t n_rows, int32_t d, void* stream);
+
+/* ---------------------------------------------------------------- Del operator --------- */
+
+/* Row-subset GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
+ *   for s in [0,n_sel):  r = idx ? idx[s] : s
+ *       out[r,:] = act( in[r,:] ) @ (trans_w ? W^T : W)       W is [d_in, d_out] ([d_out, d_in] if trans_w)
+ *   save_in (optional, compact [n_sel, d_in]) receives the gathered input rows (for the weight
+ *   gradient); `in` and `out` may alias (rows are fully read before they are written) when
+ *   d_in == d_out.  relu_in applies max(0,.) to the gathered rows first.
+ *   bias (optional, [d_out]) is added.
+ * With idx = S_Df node list and W = deletion_weight this is DeletionLayer.forward
+ * (framework/models/deletion.py:17-29: clone + boolean gather + matmul + index_put); with
+ * trans_w it is its input-gradient; with idx = NULL it is a dense Linear. */
+int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel,
+                     const float* w, int32_t d_in, int32_t d_out, int32_t trans_w,
+                     const float* bias, int32_t relu_in,
+                     float* out, int64_t ld_out, float* save_in, void* stream);
+
+/* Weight gradient of the row-subset GEMM:  dW[d_a, d_b] (+)= sum_s a[ia(s),:]^T g[ig(s),:]
+ *   ia(s) = a_idx ? a_idx[s] : s, likewise g_idx.  Deterministic split-K: `partials` must hold
+ *   gd_rows_gemm_wgrad_workspace(n_sel, d_a, d_b) floats.  accumulate != 0 adds into dW.
+ *   relu_mask (optional, same indexing as g through g_idx, ld = ld_g): g is multiplied by
+ *   (relu_mask > 0) on the fly (backward through F.relu, deletion.py:67).
+ * Replaces autograd's matmul backward for deletion_weight. */
+int64_t gd_rows_gemm_wgrad_workspace(int32_t n_sel, int32_t d_a, int32_t d_b);
+int gd_rows_gemm_wgrad_f32(const float* a, int64_t ld_a, const int32_t* a_idx,
+                           const float* g, int64_t ld_g, const int32_t* g_idx,
+                           const float* relu_mask, int32_t n_sel, int32_t d_a, int32_t d_b,
+                           float* dw, int32_t accumulate, float* partials, void* stream);
+
+/* ---------------------------------------------------------------- losses --------------- */
+
+/* Fused Deleted-Edge-Consistency + Neighborhood-Influence MSE terms of one layer, value and
+ * gradient in one pass (framework/trainer/gnndelete_nodeemb.py:196-210 with nn.MSELoss).
+ * Terms are grouped by the row of z they touch:
+ *   for u in [0,n_seg): row = seg_row[u]; for t in [seg_ptr[u], seg_ptr[u+1]):
+ *       diff = z[row,:] - o[term_o[t],:]
+ *       sums[term_kind[t]] += |diff|^2                      (kind 0 = DEC, 1 = NI)
+ *       dz[u or row,:] += 2 * term_w[t] * diff
+ *   dz_compact != 0 -> dz is [n_seg, ld_dz] indexed by u, else [N, ld_dz] indexed by row
+ *   (only the touched rows are written).  sums[2] must be zeroed by the caller; partial sums are
+ *   reduced deterministically through `partials` (gd_rowpair_mse_workspace(n_seg) floats). */
+int64_t gd_rowpair_mse_workspace(int32_t n_seg);
+int gd_rowpair_mse_f32(const float* z, int64_t ld_z, const float* o, int64_t ld_o, int32_t d,
+                       const int32_t* seg_ptr, const int32_t* seg_row, int32_t n_seg,
+                       const int32_t* term_o, const float* term_w, const int32_t* term_kind,
+                       float* dz, int64_t ld_dz, int32_t dz_compact,
+                       float* sums, float* partials, void* stream);
+
+/* Link decoders.  dot: out[m] = <z[e0[m]], z[e1[m]]>  (framework/models/gcn.py:26-36);
+ * distmult: out[m] = sum_c z[e0[m],c] * rel[etype[m],c] * z[e1[m],c]  (rgcn.py:40-47). */
+int gd_edge_dot_f32(const float* z, int64_t ld_z, int32_t d, const int64_t* e0, const int64_t* e1,
+                    const float* rel, int64_t ld_rel, const int64_t* etype,
+                    int64_t n_edges, float* out, void* stream);
+
+/* ---------------------------------------------------------------- optimizer ------------ */
+
+/* torch.optim.Adam (no amsgrad, weight_decay 0) on one tensor (delete_gnn.py:221-226).
+ * `step` is a device int32 counter incremented by the kernel (graph-capturable). */
+int gd_adam_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t* step,
+                int64_t n, float lr, float beta1, float beta2, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNDELETE_HIP_H */

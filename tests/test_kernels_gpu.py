@@ -1,0 +1,307 @@
+"""HIP kernels (through the C ABI / ctypes) vs the CPU oracle and closed-form fp64 math.
+Tolerance: fp32 kernels, rel-L2 <= 1e-5 against fp64 closed forms (north_star allows 1e-4)."""
+import pytest
+import torch
+
+from helpers import random_graph, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def dense_adj(ei, n):
+    a = torch.zeros(n, n, dtype=torch.float64)
+    a.index_put_((ei[1], ei[0]), torch.ones(ei.shape[1], dtype=torch.float64), accumulate=True)
+    return a
+
+
+@pytest.mark.parametrize('n,m,d', [(50, 200, 128), (50, 200, 64), (33, 90, 16), (70, 400, 256), (40, 100, 4),
+                                   (25, 60, 7), (30, 0, 32), (64, 3000, 128), (20, 50, 1639), (300, 9000, 512)])
+def test_spmm_gcn_matches_dense_closed_form(n, m, d):
+    from gnndelete_amd import ops
+    from gnndelete_amd.graph import build_csr
+    ei = random_graph(n, m, seed=n + d, isolate=3)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, d, generator=g)
+    b = torch.randn(d, generator=g)
+    a = dense_adj(ei[:, ei[0] != ei[1]], n) + torch.eye(n, dtype=torch.float64)
+    deg = a.sum(1)
+    want = (a / deg.sqrt()[:, None] / deg.sqrt()[None, :]) @ x.double() + b.double()
+    gr = build_csr(ei.cuda(), n, 'gcn')
+    assert gr.nnz == int((ei[0] != ei[1]).sum()) + n
+    xg = x.cuda().requires_grad_(True)
+    y = ops.spmm(xg, gr, b.cuda())
+    assert rel_l2(y.detach().cpu(), want) < TOL
+    up = torch.randn(n, d, generator=g)
+    y.backward(up.cuda())
+    want_dx = (a / deg.sqrt()[:, None] / deg.sqrt()[None, :]).t() @ up.double()
+    assert rel_l2(xg.grad.cpu(), want_dx) < TOL
+
+
+@pytest.mark.parametrize('d', [64, 128, 10])
+def test_spmm_sum_with_self_term_is_gin_aggregate(d):
+    from gnndelete_amd import ops
+    from gnndelete_amd.graph import build_csr
+    n = 41
+    ei = random_graph(n, 150, seed=d)                      # loops and multi-edges are kept
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(2))
+    want = (dense_adj(ei, n) + torch.eye(n, dtype=torch.float64)) @ x.double()
+    y = ops.spmm(x.cuda(), build_csr(ei.cuda(), n, 'sum'), None, 1.0)
+    assert rel_l2(y.cpu(), want) < TOL
+
+
+def test_spmm_is_bit_reproducible():
+    from gnndelete_amd import ops
+    from gnndelete_amd.graph import build_csr
+    n = 500
+    ei = random_graph(n, 20000, seed=9).cuda()
+    x = torch.randn(n, 128, device='cuda')
+    g = build_csr(ei, n, 'gcn')
+    y0 = ops.spmm(x, g)
+    for _ in range(3):
+        assert torch.equal(ops.spmm(x, build_csr(ei, n, 'gcn')), y0)
+
+
+def test_gcn_norm_matches_oracle():
+    from gnndelete_amd.graph import build_csr
+    from oracle import pyg_semantics as pyg
+    n = 60
+    ei = random_graph(n, 300, seed=4)
+    g = build_csr(ei.cuda(), n, 'gcn')
+    ei2, w = pyg.gcn_norm(ei, n)
+    dense = torch.zeros(n, n).index_put_((ei2[1], ei2[0]), w, accumulate=True)
+    rows = torch.repeat_interleave(torch.arange(n), (g.rowptr[1:] - g.rowptr[:-1]).cpu().long())
+    got = torch.zeros(n, n).index_put_((rows, g.col.cpu().long()), g.val.cpu(), accumulate=True)
+    assert rel_l2(got, dense) < 1e-6
+    # transposed arrays describe the same matrix
+    rows_t = torch.repeat_interleave(torch.arange(n), (g.rowptr_t[1:] - g.rowptr_t[:-1]).cpu().long())
+    got_t = torch.zeros(n, n).index_put_((g.col_t.cpu().long(), rows_t), g.val_t.cpu(), accumulate=True)
+    assert rel_l2(got_t, dense) < 1e-6
+
+
+@pytest.mark.parametrize('n,d_in,d_out,frac', [(200, 128, 128, 0.4), (200, 64, 64, 0.5), (77, 128, 64, 1.0),
+                                               (50, 32, 32, 0.3), (40, 12, 12, 0.5), (64, 128, 4, 0.5),
+                                               (90, 64, 96, 0.7), (33, 128, 128, 0.0), (5000, 128, 128, 0.9)])
+def test_rows_gemm_forward_transpose_and_inplace(n, d_in, d_out, frac):
+    from gnndelete_amd import ops
+    g = torch.Generator().manual_seed(n + d_in)
+    x = torch.randn(n, d_in, generator=g)
+    w = torch.randn(d_in, d_out, generator=g) * 0.2
+    b = torch.randn(d_out, generator=g)
+    mask = torch.rand(n, generator=g) < frac
+    idx = mask.nonzero().flatten().int().cuda()
+    want = x.double()[mask] @ w.double()
+    out = torch.full((n, d_out), 7.0, device='cuda')
+    save = torch.empty(int(mask.sum()), d_in, device='cuda')
+    ops.rows_gemm(x.cuda(), idx, w.cuda(), out=out, save_in=save)
+    assert rel_l2(out.cpu()[mask], want) < TOL or want.numel() == 0
+    assert torch.all(out.cpu()[~mask] == 7.0)                          # untouched rows stay untouched
+    assert torch.equal(save.cpu(), x[mask])
+    # transposed weight + bias + relu on the input
+    wt = w.t().contiguous()
+    out2 = ops.rows_gemm(x.cuda(), idx, wt.cuda(), trans_w=True, bias=b.cuda(), relu_in=True,
+                         out=torch.zeros(n, d_out, device='cuda'))
+    want2 = x.double().clamp(min=0)[mask] @ w.double() + b.double()
+    assert rel_l2(out2.cpu()[mask], want2) < TOL or want2.numel() == 0
+    # dense (idx = None)
+    out3 = ops.rows_gemm(x.cuda(), None, w.cuda())
+    assert rel_l2(out3.cpu(), x.double() @ w.double()) < TOL
+    if d_in == d_out:                                                   # in place (the Del operator)
+        z = x.clone().cuda()
+        ops.rows_gemm(z, idx, w.cuda(), out=z)
+        ref = x.double().clone()
+        ref[mask] = want
+        assert rel_l2(z.cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize('n,d_a,d_b,frac', [(300, 128, 128, 0.5), (300, 64, 64, 0.8), (100, 128, 64, 1.0),
+                                            (50, 12, 12, 0.5), (60, 128, 4, 0.6), (20, 64, 64, 0.0),
+                                            (70000, 128, 128, 0.7)])
+def test_rows_gemm_wgrad(n, d_a, d_b, frac):
+    from gnndelete_amd import ops
+    g = torch.Generator().manual_seed(n + d_b)
+    a = torch.randn(n, d_a, generator=g)
+    gr = torch.randn(n, d_b, generator=g)
+    rm = torch.randn(n, d_b, generator=g)
+    mask = torch.rand(n, generator=g) < frac
+    idx = mask.nonzero().flatten().int().cuda()
+    s = int(idx.shape[0])
+    want = a.double()[mask].t() @ gr.double()[mask]
+    got = ops.rows_gemm_wgrad(a.cuda(), idx, gr.cuda(), idx, s)
+    assert rel_l2(got.cpu(), want) < TOL or s == 0
+    # compact a, relu mask, accumulate
+    ac = a[mask].contiguous().cuda()
+    base = torch.randn(d_a, d_b, generator=g)
+    got2 = ops.rows_gemm_wgrad(ac, None, gr.cuda(), idx, s, relu_mask=rm.cuda(), out=base.clone().cuda(),
+                               accumulate=True)
+    want2 = base.double() + a.double()[mask].t() @ (gr.double() * (rm > 0))[mask]
+    assert rel_l2(got2.cpu(), want2) < TOL
+    # deterministic split-K
+    assert torch.equal(ops.rows_gemm_wgrad(a.cuda(), idx, gr.cuda(), idx, s), got)
+
+
+def test_del_rows_autograd_matches_reference_golden():
+    from gnndelete_amd import ops
+    from helpers import load_golden, t
+    fx = load_golden('del_layer.npz')
+    for tag in ['partial', 'empty', 'full', 'odd']:
+        x = t(fx[f'{tag}::x']).cuda().requires_grad_(True)
+        w = t(fx[f'{tag}::w']).cuda().requires_grad_(True)
+        idx = t(fx[f'{tag}::mask']).nonzero().flatten().int().cuda()
+        y = ops.del_rows(x, w, idx)
+        y.backward(t(fx[f'{tag}::up']).cuda())
+        assert rel_l2(y.detach().cpu(), fx[f'{tag}::y']) < TOL, tag
+        assert rel_l2(x.grad.cpu(), fx[f'{tag}::gx']) < TOL, tag
+        if idx.numel():
+            assert rel_l2(w.grad.cpu(), fx[f'{tag}::gw']) < TOL, tag
+        else:
+            assert float(w.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('d', [128, 64, 16, 256])
+def test_rowpair_mse_value_and_gradient(d):
+    from gnndelete_amd import _lib
+    g = torch.Generator().manual_seed(d)
+    n, n_seg = 90, 40
+    z = torch.randn(n, d, generator=g)
+    o = torch.randn(n, d, generator=g)
+    rows = torch.randperm(n, generator=g)[:n_seg].sort().values
+    cnt = torch.randint(0, 4, (n_seg,), generator=g)                     # some rows have no terms
+    seg_ptr = torch.zeros(n_seg + 1, dtype=torch.int32)
+    seg_ptr[1:] = cnt.cumsum(0)
+    T = int(cnt.sum())
+    term_o = torch.randint(0, n, (T,), generator=g).int()
+    term_w = torch.rand(T, generator=g)
+    kind = torch.randint(0, 2, (T,), generator=g).int()
+    zr = z.double().requires_grad_(True)
+    seg_of = torch.repeat_interleave(torch.arange(n_seg), cnt)
+    diff = zr[rows[seg_of]] - o.double()[term_o.long()]
+    sq = (diff ** 2).sum(1)
+    want_s = [float(sq[kind == 0].sum()), float(sq[kind == 1].sum())]
+    (sq * term_w.double()).sum().backward()
+    for compact in (0, 1):
+        dz = torch.full((n_seg if compact else n, d), 3.0, device='cuda')
+        sums = torch.zeros(2, device='cuda')
+        ws = torch.empty(_lib.lib().gd_rowpair_mse_workspace(n_seg), device='cuda')
+        zc, oc = z.cuda(), o.cuda()
+        dev = [x.cuda() for x in (seg_ptr, rows.int(), term_o, term_w, kind)]
+        _lib.check(_lib.lib().gd_rowpair_mse_f32(zc.data_ptr(), d, oc.data_ptr(), d, d, dev[0].data_ptr(),
+                                                 dev[1].data_ptr(), n_seg, dev[2].data_ptr(), dev[3].data_ptr(),
+                                                 dev[4].data_ptr(), dz.data_ptr(), d, compact, sums.data_ptr(),
+                                                 ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        assert abs(float(sums[0]) - want_s[0]) < 1e-4 * max(1, want_s[0])
+        assert abs(float(sums[1]) - want_s[1]) < 1e-4 * max(1, want_s[1])
+        got = dz.cpu() if compact else dz.cpu()[rows]
+        assert rel_l2(got, zr.grad[rows]) < TOL
+        if not compact:
+            untouched = torch.ones(n, dtype=torch.bool)
+            untouched[rows] = False
+            assert torch.all(dz.cpu()[untouched] == 3.0)
+
+
+@pytest.mark.parametrize('d', [64, 128, 10, 4])
+def test_edge_dot_and_distmult(d):
+    from gnndelete_amd import ops
+    g = torch.Generator().manual_seed(d)
+    n, m, r = 70, 333, 5
+    z = torch.randn(n, d, generator=g)
+    e = torch.randint(0, n, (2, m), generator=g)
+    rel = torch.randn(r, d, generator=g)
+    et = torch.randint(0, r, (m,), generator=g)
+    zg = z.cuda().requires_grad_(True)
+    out = ops.edge_dot(zg, e[0].cuda(), e[1].cuda())
+    assert rel_l2(out.detach().cpu(), (z.double()[e[0]] * z.double()[e[1]]).sum(-1)) < TOL
+    out.sum().backward()
+    zd = z.double().requires_grad_(True)
+    (zd[e[0]] * zd[e[1]]).sum().backward()
+    assert rel_l2(zg.grad.cpu(), zd.grad) < TOL
+    out2 = ops.edge_dot(z.cuda(), e[0].cuda(), e[1].cuda(), rel.cuda(), et.cuda())
+    assert rel_l2(out2.cpu(), (z.double()[e[0]] * rel.double()[et] * z.double()[e[1]]).sum(-1)) < TOL
+    assert ops.edge_dot(z.cuda(), e[0, :0].cuda(), e[1, :0].cuda()).shape == (0,)
+
+
+def test_adam_matches_torch_optim():
+    from gnndelete_amd import _lib
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(64, 64, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-2)
+    p = p0.clone().cuda()
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    step = torch.zeros(1, dtype=torch.int32, device='cuda')
+    for it in range(12):
+        gr = torch.randn(64, 64, generator=g) * (10.0 ** (-it % 5))
+        ref.grad = gr.clone()
+        opt.step()
+        gg = gr.cuda()
+        _lib.check(_lib.lib().gd_adam_f32(p.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr(),
+                                          p.numel(), 1e-2, 0.9, 0.999, 1e-8, torch.cuda.current_stream().cuda_stream))
+    assert int(step) == 12
+    assert rel_l2(p.cpu(), ref.detach()) < 1e-6
+
+
+@pytest.mark.parametrize('d', [128, 64, 16])
+def test_gat_aggregate_forward_backward_vs_oracle(d):
+    from gnndelete_amd import ops
+    from gnndelete_amd.graph import build_csr
+    from oracle import pyg_semantics as pyg
+    n = 60
+    ei = random_graph(n, 400, seed=d, isolate=2)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, 20, generator=g, dtype=torch.float64)
+    w = torch.randn(d, 20, generator=g, dtype=torch.float64) * 0.3
+    a_s = torch.randn(1, 1, d, generator=g, dtype=torch.float64)
+    a_d = torch.randn(1, 1, d, generator=g, dtype=torch.float64)
+    b = torch.randn(d, generator=g, dtype=torch.float64)
+    up = torch.randn(n, d, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    asr, adr = a_s.clone().requires_grad_(True), a_d.clone().requires_grad_(True)
+    want = pyg.gat_conv(xr, ei, w, asr, adr, b)
+    want.backward(up)
+
+    gr = build_csr(ei.cuda(), n, 'gat')
+    xg = x.float().cuda().requires_grad_(True)
+    asg, adg = a_s.float().cuda().requires_grad_(True), a_d.float().cuda().requires_grad_(True)
+    h = xg @ w.float().cuda().t()
+    out = ops.gat_aggregate(h, (h * asg.view(1, -1)).sum(-1), (h * adg.view(1, -1)).sum(-1), gr, b.float().cuda())
+    assert rel_l2(out.detach().cpu(), want.detach()) < TOL
+    out.backward(up.float().cuda())
+    assert rel_l2(xg.grad.cpu(), xr.grad) < 5e-5
+    assert rel_l2(asg.grad.cpu(), asr.grad) < 5e-5
+    assert rel_l2(adg.grad.cpu(), adr.grad) < 5e-5
+
+
+@pytest.mark.parametrize('blocks', [None, 4])
+def test_rgcn_conv_vs_oracle(blocks):
+    from gnndelete_amd.nn import RGCNConv
+    from oracle import pyg_semantics as pyg
+    n, r, i, o = 45, 6, 16, 32
+    g = torch.Generator().manual_seed(5)
+    ei = torch.randint(0, n, (2, 300), generator=g)
+    et = torch.randint(0, r, (300,), generator=g)
+    x = torch.randn(n, i, generator=g)
+    conv = RGCNConv(i, o, r, blocks)
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(o, generator=g))
+    xr = x.double().requires_grad_(True)
+    want = pyg.rgcn_conv(xr, ei, et, conv.weight.detach().double(), conv.root.detach().double(),
+                         conv.bias.detach().double(), blocks)
+    up = torch.randn(n, o, generator=g)
+    want.backward(up.double())
+    conv = conv.cuda()
+    xg = x.cuda().requires_grad_(True)
+    out = conv(xg, ei.cuda(), et.cuda())
+    assert rel_l2(out.detach().cpu(), want.detach()) < TOL
+    out.backward(up.cuda())
+    assert rel_l2(xg.grad.cpu(), xr.grad) < TOL
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    from gnndelete_amd import _lib, ops
+    from gnndelete_amd.graph import build_csr
+    with pytest.raises(_lib.GnnDeleteHipError):
+        build_csr(torch.zeros(2, 3, dtype=torch.long), 4, 'gcn')
+    g = build_csr(torch.zeros(2, 3, dtype=torch.long).cuda(), 4, 'gcn')
+    with pytest.raises(_lib.GnnDeleteHipError):
+        ops.spmm(torch.zeros(4, 8), g)

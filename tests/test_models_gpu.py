@@ -1,0 +1,95 @@
+"""HIP-backed models (gnndelete_amd.framework.models) vs the golden vectors generated from the
+reference and vs the CPU oracle: embeddings, decoder scores, Del-weight gradients, and whole
+training trajectories for every loss_type.  Tolerance 1e-4 rel-L2 (north_star), met with margin."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import hip_model, load_golden, oracle_model, rel_l2, split_fixture, t
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize('gnn', ['gcn', 'gat', 'gin'])
+def test_delete_models_match_reference_golden(gnn):
+    fx = load_golden(f'wiring_{gnn}.npz')
+    state, _, rest = split_fixture(fx)
+    m = hip_model(gnn, state, t(rest['mask1']), t(rest['mask2']))
+    x, ei = t(rest['x']).cuda(), t(rest['edge_index']).cuda()
+    z1, z2 = m(x, ei, return_all_emb=True)
+    o1, o2 = m.get_original_embeddings(x, ei, return_all_emb=True)
+    for got, key in [(z1, 'z1'), (z2, 'z2'), (o1, 'o1'), (o2, 'o2')]:
+        assert rel_l2(got.detach().cpu(), rest[key]) < TOL, key
+    a1, a2 = m(x, ei, mask_1hop=t(rest['alt1']), mask_2hop=t(rest['alt2']), return_all_emb=True)
+    assert rel_l2(a1.detach().cpu(), rest['a1']) < TOL and rel_l2(a2.detach().cpu(), rest['a2']) < TOL
+    s = m.decode(z2, t(rest['val_pos']).cuda(), t(rest['val_neg']).cuda())
+    assert rel_l2(s.detach().cpu(), rest['score']) < TOL
+    assert m(x, ei).shape == z2.shape
+
+
+def test_rgcn_delete_matches_reference_golden():
+    fx = load_golden('wiring_rgcn.npz')
+    state, _, rest = split_fixture(fx)
+    r = int(rest['num_edge_type'])
+    m = hip_model('rgcn', state, t(rest['mask1']), t(rest['mask2']), num_nodes=state['node_emb.weight'].shape[0],
+                  num_edge_type=r)
+    x, ei, et = t(rest['x']).cuda(), t(rest['edge_index']).cuda(), t(rest['edge_type']).cuda()
+    z1, z2 = m(x, ei, et, return_all_emb=True)
+    o1, o2 = m.get_original_embeddings(x, ei, et, return_all_emb=True)
+    for got, key in [(z1, 'z1'), (z2, 'z2'), (o1, 'o1'), (o2, 'o2')]:
+        assert rel_l2(got.detach().cpu(), rest[key]) < TOL, key
+    s = m.decode(z2, t(rest['dec_edge']).cuda(), t(rest['dec_type']).cuda())
+    assert rel_l2(s.detach().cpu(), rest['score']) < TOL
+
+
+@pytest.mark.parametrize('gnn', ['gcn', 'gat', 'gin'])
+def test_del_weight_gradients_match_oracle(gnn):
+    fx = load_golden(f'wiring_{gnn}.npz')
+    state, _, rest = split_fixture(fx)
+    mo = oracle_model(gnn, state, t(rest['mask1']), t(rest['mask2']))
+    mh = hip_model(gnn, state, t(rest['mask1']), t(rest['mask2']))
+    x, ei = t(rest['x']), t(rest['edge_index'])
+    g = torch.Generator().manual_seed(0)
+    u1, u2 = torch.randn(x.shape[0], 32, generator=g), torch.randn(x.shape[0], 16, generator=g)
+    z1, z2 = mo(x, ei, return_all_emb=True)
+    ((z1 * u1).sum() + (z2 * u2).sum()).backward()
+    h1, h2 = mh(x.cuda(), ei.cuda(), return_all_emb=True)
+    ((h1 * u1.cuda()).sum() + (h2 * u2.cuda()).sum()).backward()
+    for name in ['deletion1', 'deletion2']:
+        got = getattr(mh, name).deletion_weight.grad.cpu()
+        want = getattr(mo, name).deletion_weight.grad
+        assert rel_l2(got, want) < TOL, name
+    assert all(p.grad is None for n_, p in mh.named_parameters() if n_.startswith('conv1'))
+
+
+TRAJ = [('gat', 'both_layerwise'), ('gat', 'both_all'), ('gat', 'only2_layerwise'), ('gat', 'only2_all'),
+        ('gat', 'only1'), ('gin', 'both_layerwise'), ('gcn', 'both_all'), ('gcn', 'only2_layerwise'),
+        ('gcn', 'only1')]
+
+
+@pytest.mark.parametrize('gnn,loss_type', TRAJ)
+def test_training_trajectory_matches_reference_loop(gnn, loss_type):
+    """The reference's real train_fullbatch loop (golden) reproduced with the HIP model under the
+    same update rule (torch Adam on the Del weights, autograd through the HIP ops)."""
+    from oracle import gnndelete_ref as R
+    fx = load_golden(f'traj_{gnn}_{loss_type}.npz')
+    state, data, rest = split_fixture(fx)
+    m = hip_model(gnn, state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    m.relational = False
+    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    E = dev['train_pos_edge_index']
+    e_dr, e_sdf = E[:, dev['dr_mask']], E[:, dev['sdf_mask']]
+    ni1, ni2 = R.non_df_masks(data['x'].shape[0], data['directed_df_edge_index'], data['sdf_node_1hop_mask'],
+                              data['sdf_node_2hop_mask'])
+    with torch.no_grad():
+        z1o, z2o = m.get_original_embeddings(dev['x'], e_dr, return_all_emb=True)
+    targets = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=E[:, dev['df_mask']], neg_edge=t(rest['neg']).cuda(),
+                   ni_mask1=ni1.cuda(), ni_mask2=ni2.cuda())
+    opt = R.make_optimizer(m, loss_type, float(rest['lr']))
+    logs = [R.nodeemb_epoch(m, lambda: m(dev['x'], e_sdf, return_all_emb=True), targets, opt, loss_type,
+                            float(rest['alpha']), R.LOSSES['mse_mean']) for _ in range(int(rest['epochs']))]
+    for key in ['train_loss', 'loss_r', 'loss_l']:
+        np.testing.assert_allclose(np.array([l[key] for l in logs]), rest[key], rtol=1e-4, atol=1e-8, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), rest['final_w1']) < TOL
+    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < TOL
