@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void gat_fwd_kernel(const int32_t* __restrict_
 #pragma unroll
   for (int v = 0; v < VPL; ++v)
 #pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1) acc[v] = f4_shfl_xor(acc[v], off);
+    for (int off = LPR; off < kWave; off <<= 1) acc[v] = f4_add(acc[v], f4_shfl_xor(acc[v], off));
   if (g != 0) return;
 #pragma unroll
   for (int v = 0; v < VPL; ++v) {
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(const int32_t* __restr
 #pragma unroll
   for (int v = 0; v < VPL; ++v)
 #pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1) acc[v] = f4_shfl_xor(acc[v], off);
+    for (int off = LPR; off < kWave; off <<= 1) acc[v] = f4_add(acc[v], f4_shfl_xor(acc[v], off));
   if (g != 0) return;
 #pragma unroll
   for (int v = 0; v < VPL; ++v) {

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(const int32_t* __restrict
 #pragma unroll
   for (int v = 0; v < VPL; ++v) {
 #pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1) acc[v] = f4_shfl_xor(acc[v], off);
+    for (int off = LPR; off < kWave; off <<= 1) acc[v] = f4_add(acc[v], f4_shfl_xor(acc[v], off));
   }
   if (g != 0) return;
   const float scale = MEAN ? (end > start ? 1.0f / (float)(end - start) : 0.0f) : 1.0f;
