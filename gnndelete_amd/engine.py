@@ -1,0 +1,314 @@
+"""Fused Del-operator training step (the reference's hot loop body,
+framework/trainer/gnndelete_nodeemb.py:188-299) for MSE losses.
+
+The reference runs this iteration as ~60 autograd-dispatched PyTorch/PyG ops with three
+``.item()`` syncs.  Here the iteration is an explicit forward + hand-derived backward over the
+HIP kernels - no autograd tape - laid out once over static buffers and captured into a hipGraph
+(torch.cuda.CUDAGraph), so a step is a single graph launch:
+
+  forward   p1 = conv1(x)                      frozen backbone, written straight into z1
+            z1[S1] = p1[S1] @ W_D1             Del-1 in place, MFMA; the gathered p1[S1] is kept
+            p2 = conv2(relu(z1)) -> z2         relu fused into the W2 GEMM (MFMA), SpMM
+            z2[S2] = p2[S2] @ W_D2             Del-2 in place
+  losses    DEC + NI of both layers            one fused value+gradient kernel per layer
+  backward  dW_D2 = p2[S2]^T dz2[S2]
+            dz2[S2] <- dz2[S2] @ W_D2^T ; dt2 = A^T dz2 ; dh[S1] = dt2[S1] @ W2
+            dW_D1  = p1[S1]^T (dz1 [+ relu'(z1) * dh])[S1]
+  update    Adam on W_D1 / W_D2 with the zero_grad placement of the chosen --loss_type
+            (including the gradient carry-over of both_layerwise and the never-zeroed grads of
+            both_all).
+
+Per-step loss sums are appended to a device-side history without a host sync.
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import check, ptr, stream_ptr
+from .graph import graph_for
+from .nn import GATConv, GCNConv, GINConv
+
+LOSS_TYPES = ('both_all', 'both_layerwise', 'only2_layerwise', 'only2_all', 'only1')
+
+
+def _loss_coefficients(loss_type, alpha):
+    """(coef_r, coef_l) multiplying the DEC / NI terms inside the differentiated loss."""
+    if loss_type in ('both_all', 'both_layerwise', 'only2_layerwise'):
+        return alpha, 1.0 - alpha
+    return alpha, 1.0                      # only2_all / only1: loss_l + alpha * loss_r
+
+
+class _LayerTerms:
+    """DEC + NI terms of one layer grouped by the row of z they touch."""
+
+    def __init__(self, pos_edge, neg_edge, ni_mask, d, coef_r, coef_l, reduction, device):
+        pos, neg = pos_edge.cpu().long(), neg_edge.cpu().long()
+        ni_rows = ni_mask.cpu().nonzero().flatten()
+        m = pos.shape[1]
+        self.n_r = (2 * m * d) if reduction == 'mean' else 1
+        self.n_l = (ni_rows.numel() * d) if reduction == 'mean' else 1
+        self.count_r, self.count_l = 2 * m, int(ni_rows.numel())
+        rows = torch.cat([pos[0], pos[1], ni_rows])
+        tgt = torch.cat([neg[0], neg[1], ni_rows])
+        kind = torch.cat([torch.zeros(2 * m, dtype=torch.int32), torch.ones(ni_rows.numel(), dtype=torch.int32)])
+        w = torch.cat([torch.full((2 * m,), coef_r / max(self.n_r, 1), dtype=torch.float32),
+                       torch.full((ni_rows.numel(),), coef_l / max(self.n_l, 1), dtype=torch.float32)])
+        order = torch.argsort(rows, stable=True)
+        rows, tgt, kind, w = rows[order], tgt[order], kind[order], w[order]
+        seg_row, counts = torch.unique_consecutive(rows, return_counts=True)
+        seg_ptr = torch.zeros(seg_row.numel() + 1, dtype=torch.int32)
+        seg_ptr[1:] = torch.cumsum(counts, 0)
+        self.n_seg = int(seg_row.numel())
+        self.seg_ptr = seg_ptr.to(device)
+        self.seg_row = seg_row.to(device=device, dtype=torch.int32)
+        self.term_o = tgt.to(device=device, dtype=torch.int32)
+        self.term_w = w.to(device)
+        self.term_kind = kind.to(device)
+        self.partials = torch.empty(max(2, _lib.lib().gd_rowpair_mse_workspace(self.n_seg)), dtype=torch.float32,
+                                    device=device)
+
+
+class _Adam:
+    def __init__(self, param, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.param, self.lr, self.betas, self.eps = param, lr, betas, eps
+        self.m = torch.zeros_like(param)
+        self.v = torch.zeros_like(param)
+        self.step = torch.zeros(1, dtype=torch.int32, device=param.device)
+
+    def apply(self, grad):
+        check(_lib.lib().gd_adam_f32(ptr(self.param), ptr(grad), ptr(self.m), ptr(self.v), ptr(self.step),
+                                     self.param.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                     stream_ptr(self.param.device)), 'gd_adam_f32')
+
+    def state_dict(self):
+        return {'exp_avg': self.m.clone(), 'exp_avg_sq': self.v.clone(), 'step': int(self.step)}
+
+
+class NodeembEngine:
+    """One object per unlearning request (fixed graph, fixed Df, fixed negatives)."""
+
+    def __init__(self, model, x, edge_index, z1_ori, z2_ori, pos_edge, neg_edge, ni_mask1, ni_mask2,
+                 loss_type='both_layerwise', alpha=0.5, lr=1e-3, reduction='mean', mask_1hop=None, mask_2hop=None,
+                 use_graph=True, history=4096):
+        assert loss_type in LOSS_TYPES, loss_type
+        conv1, conv2 = model.conv1, model.conv2
+        if not isinstance(conv2, (GCNConv, GINConv, GATConv)):
+            raise NotImplementedError(f'NodeembEngine: unsupported conv {type(conv2).__name__}')
+        dev = x.device
+        if dev.type != 'cuda':
+            raise _lib.GnnDeleteHipError('NodeembEngine needs CUDA(HIP) tensors (no CPU fallback)')
+        self.model, self.loss_type, self.alpha = model, loss_type, alpha
+        self.x, self.edge_index = x, edge_index
+        self.n = n = x.shape[0]
+        self.wd1, self.wd2 = model.deletion1.deletion_weight, model.deletion2.deletion_weight
+        self.h, self.o = self.wd1.shape[0], self.wd2.shape[0]
+        m1 = model.deletion1.mask if mask_1hop is None else mask_1hop
+        m2 = model.deletion2.mask if mask_2hop is None else mask_2hop
+        self.idx1 = m1.nonzero().flatten().to(device=dev, dtype=torch.int32)
+        self.idx2 = m2.nonzero().flatten().to(device=dev, dtype=torch.int32)
+        self.s1, self.s2 = int(self.idx1.numel()), int(self.idx2.numel())
+        self.z1_ori, self.z2_ori = ops._f32_rows(z1_ori), ops._f32_rows(z2_ori)
+        coef_r, coef_l = _loss_coefficients(loss_type, alpha)
+        self.t1 = _LayerTerms(pos_edge, neg_edge, ni_mask1, self.h, coef_r, coef_l, reduction, dev)
+        self.t2 = _LayerTerms(pos_edge, neg_edge, ni_mask2, self.o, coef_r, coef_l, reduction, dev)
+        self.uses_l1 = loss_type in ('both_all', 'both_layerwise', 'only1')
+        self.uses_l2 = loss_type != 'only1'
+        # does a gradient of loss-2 w.r.t. W_D1 (through conv2) ever reach an optimizer step?
+        self.needs_l2_to_w1 = loss_type in ('both_all', 'both_layerwise', 'only2_all')
+
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.z1 = torch.empty(n, self.h, **f32)
+        self.z2 = torch.empty(n, self.o, **f32)
+        self.xs1 = torch.empty(max(1, self.s1), self.h, **f32)       # p1[S1] (input rows of Del-1)
+        self.xs2 = torch.empty(max(1, self.s2), self.o, **f32)
+        self.dz1 = torch.zeros(n, self.h, **f32)                     # only loss rows are ever written
+        self.dz2 = torch.zeros(n, self.o, **f32)
+        self.dh = torch.zeros(n, self.h, **f32)                      # only S1 rows are ever written
+        self.g1 = torch.zeros_like(self.wd1)                         # the .grad of W_D1 / W_D2
+        self.g2 = torch.zeros_like(self.wd2)
+        self.sums = torch.zeros(4, **f32)                            # r1, l1, r2, l2 (sums of squares)
+        self.ws1 = torch.empty(max(1, _lib.lib().gd_rows_gemm_wgrad_workspace(self.s1, self.h, self.h)), **f32)
+        self.ws2 = torch.empty(max(1, _lib.lib().gd_rows_gemm_wgrad_workspace(self.s2, self.o, self.o)), **f32)
+        self.adam1, self.adam2 = _Adam(self.wd1, lr), _Adam(self.wd2, lr)
+        self.hist = torch.zeros(history, 4, **f32)
+        self.hist_pos = torch.zeros(1, dtype=torch.long, device=dev)
+        self.steps_done = 0
+        self._graph = None
+        self._use_graph = use_graph
+        self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat'}[type(conv2)]
+        gmode = {'gcn': 'gcn', 'gin': 'sum', 'gat': 'gat'}[self._mode]
+        self.graph = graph_for(edge_index, n, gmode)
+
+    # ------------------------------------------------------------------ pieces
+    def _conv2_forward(self):
+        c = self.model.conv2
+        if self._mode == 'gcn':
+            t2 = ops.rows_gemm(self.z1, None, c.lin.weight, trans_w=True, relu_in=True)
+            self._spmm(self.graph.rowptr, self.graph.col, self.graph.val, t2, self.z2, c.bias, 0.0)
+        elif self._mode == 'gin':
+            lin = c.nn
+            if lin.out_features <= lin.in_features:
+                t2 = ops.rows_gemm(self.z1, None, lin.weight, trans_w=True, relu_in=True)
+                self._spmm(self.graph.rowptr, self.graph.col, None, t2, self.z2, lin.bias, 1.0 + c.eps)
+            else:
+                raise NotImplementedError('GIN layer that widens its input is not on the fused path')
+        else:   # gat
+            h2 = ops.rows_gemm(self.z1, None, c.lin_src.weight, trans_w=True, relu_in=True)
+            self._h2 = h2
+            self._a_src = (h2 * c.att_src.view(1, -1)).sum(-1)
+            self._a_dst = (h2 * c.att_dst.view(1, -1)).sum(-1)
+            if not hasattr(self, '_alpha'):
+                self._alpha = torch.empty(self.graph.nnz, dtype=torch.float32, device=self.x.device)
+            g = self.graph
+            check(_lib.lib().gd_gat_aggregate_f32(ptr(g.rowptr), ptr(g.col), ptr(self._a_src), ptr(self._a_dst),
+                                                  ptr(h2), h2.stride(0), ptr(self.z2), self.z2.stride(0), ptr(c.bias),
+                                                  ptr(self._alpha), c.negative_slope, self.n, self.o,
+                                                  stream_ptr(self.x.device)), 'gd_gat_aggregate_f32')
+
+    def _conv2_backward_to_s1(self):
+        """dh[S1] = d loss2 / d relu(z1) restricted to the S1 rows (all that Del-1 needs)."""
+        c = self.model.conv2
+        g = self.graph
+        if self._mode in ('gcn', 'gin'):
+            dt2 = torch.empty(self.n, self.o, dtype=torch.float32, device=self.x.device)
+            if self._mode == 'gcn':
+                self._spmm(g.rowptr_t, g.col_t, g.val_t, self.dz2, dt2, None, 0.0)
+                w2 = c.lin.weight
+            else:
+                self._spmm(g.rowptr_t, g.col_t, None, self.dz2, dt2, None, 1.0 + c.eps)
+                w2 = c.nn.weight
+        else:
+            dt2 = torch.empty(self.n, self.o, dtype=torch.float32, device=self.x.device)
+            da_s = torch.empty(self.n, dtype=torch.float32, device=self.x.device)
+            da_d = torch.empty(self.n, dtype=torch.float32, device=self.x.device)
+            de = torch.empty(g.nnz, dtype=torch.float32, device=self.x.device)
+            check(_lib.lib().gd_gat_aggregate_bwd_f32(
+                ptr(g.rowptr), ptr(g.col), ptr(self._alpha), ptr(g.rowptr_t), ptr(g.col_t), ptr(g.perm_t),
+                ptr(self._a_src), ptr(self._a_dst), ptr(self._h2), self._h2.stride(0), ptr(self.dz2),
+                self.dz2.stride(0), ptr(dt2), dt2.stride(0), ptr(da_s), ptr(da_d), ptr(de), c.negative_slope, self.n,
+                self.o, stream_ptr(self.x.device)), 'gd_gat_aggregate_bwd_f32')
+            dt2.addcmul_(da_s[:, None], c.att_src.view(1, -1)).addcmul_(da_d[:, None], c.att_dst.view(1, -1))
+            w2 = c.lin_src.weight
+        # dh[S1] = dt2[S1] @ W2   (W2 is [out, in] = [d_in, d_out] of this product)
+        ops.rows_gemm(dt2, self.idx1, w2, trans_w=False, out=self.dh)
+
+    def _spmm(self, rowptr, col, val, x, y, bias, self_coef):
+        check(_lib.lib().gd_spmm_csr_f32(ptr(rowptr), ptr(col), ptr(val), ptr(x), x.stride(0), ptr(y), y.stride(0),
+                                         ptr(bias), float(self_coef), self.n, x.shape[1], stream_ptr(x.device)),
+              'gd_spmm_csr_f32')
+
+    def _losses(self, z, z_ori, terms, dz, sums):
+        d = z.shape[1]
+        check(_lib.lib().gd_rowpair_mse_f32(ptr(z), z.stride(0), ptr(z_ori), z_ori.stride(0), d, ptr(terms.seg_ptr),
+                                            ptr(terms.seg_row), terms.n_seg, ptr(terms.term_o), ptr(terms.term_w),
+                                            ptr(terms.term_kind), ptr(dz), dz.stride(0), 0, ptr(sums),
+                                            ptr(terms.partials), stream_ptr(z.device)), 'gd_rowpair_mse_f32')
+
+    def _wgrad(self, a_compact, g, g_idx, n_sel, relu_mask, out, accumulate, ws):
+        d_a, d_b = a_compact.shape[1], g.shape[1]
+        check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(a_compact), a_compact.stride(0), None, ptr(g), g.stride(0),
+                                                ptr(g_idx), ptr(relu_mask), n_sel, d_a, d_b, ptr(out),
+                                                int(accumulate), ptr(ws), stream_ptr(g.device)),
+              'gd_rows_gemm_wgrad_f32')
+
+    # ------------------------------------------------------------------ one iteration
+    def _iteration(self):
+        m = self.model
+        with torch.no_grad():
+            # ---- forward
+            p1 = m.conv1(self.x, self.edge_index)
+            self.z1.copy_(p1)
+            ops.rows_gemm(self.z1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1)
+            self._conv2_forward()
+            ops.rows_gemm(self.z2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
+            # ---- losses (value + dz)
+            self.sums.zero_()
+            self._losses(self.z1, self.z1_ori, self.t1, self.dz1, self.sums[0:2])
+            self._losses(self.z2, self.z2_ori, self.t2, self.dz2, self.sums[2:4])
+            self.hist.index_copy_(0, self.hist_pos, self.sums[None])
+            self.hist_pos.add_(1).remainder_(self.hist.shape[0])
+            # ---- backward + update
+            lt = self.loss_type
+            if lt == 'both_layerwise':
+                self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, True, self.ws1)
+                self.adam1.apply(self.g1)
+                self._layer2_backward(g1_accumulate=False)       # g1 = zero_grad() + loss2 path (carry-over)
+                self.adam2.apply(self.g2)
+            elif lt == 'both_all':
+                self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, True, self.ws1)
+                self._layer2_backward(g1_accumulate=True, g2_accumulate=True)
+                self.adam1.apply(self.g1)
+                self.adam2.apply(self.g2)
+            elif lt == 'only2_layerwise':
+                self._layer2_backward(g1_accumulate=None)
+                self.adam2.apply(self.g2)
+            elif lt == 'only2_all':
+                self._layer2_backward(g1_accumulate=False)
+                self.adam1.apply(self.g1)
+                self.adam2.apply(self.g2)
+            else:  # only1
+                self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, False, self.ws1)
+                self.adam1.apply(self.g1)
+
+    def _layer2_backward(self, g1_accumulate, g2_accumulate=False):
+        """g2 (+)= dW_D2; if g1_accumulate is not None also g1 (+)= d loss2 / d W_D1."""
+        self._wgrad(self.xs2, self.dz2, self.idx2, self.s2, None, self.g2, g2_accumulate, self.ws2)
+        if g1_accumulate is None:
+            return
+        # dz2 -> dp2 in place (Del-2 input gradient on the masked rows, identity elsewhere)
+        ops.rows_gemm(self.dz2, self.idx2, self.wd2, trans_w=True, out=self.dz2)
+        self._conv2_backward_to_s1()
+        self._wgrad(self.xs1, self.dh, self.idx1, self.s1, self.z1, self.g1, g1_accumulate, self.ws1)
+
+    # ------------------------------------------------------------------ public
+    def step(self):
+        if not self._use_graph:
+            self._iteration()
+        elif self._graph is None:
+            # two eager warm-up iterations would change the trajectory: warm the libraries up on
+            # a scratch copy of the mutable state instead, then capture
+            self._capture()
+            self._graph.replay()
+        else:
+            self._graph.replay()
+        self.steps_done += 1
+
+    def _mutable_state(self):
+        return [self.wd1.data, self.wd2.data, self.g1, self.g2, self.adam1.m, self.adam1.v, self.adam1.step,
+                self.adam2.m, self.adam2.v, self.adam2.step, self.hist, self.hist_pos, self.dz1, self.dz2, self.dh]
+
+    def _capture(self):
+        saved = [t.clone() for t in self._mutable_state()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._iteration()                      # warm-up (allocator, rocBLAS handles, code objects)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._iteration()
+        for t, s in zip(self._mutable_state(), saved):
+            t.copy_(s)                             # capture does not execute; undo the warm-up
+        self._graph = graph
+
+    def loss_history(self):
+        """[steps, 3] host tensor: train_loss, loss_r, loss_l as the reference logs them."""
+        k = min(self.steps_done, self.hist.shape[0])
+        s = self.hist[:k].double().cpu()
+        r1, l1 = s[:, 0] / self.t1.n_r if self.t1.count_r else s[:, 0] * float('nan'), \
+            s[:, 1] / self.t1.n_l if self.t1.count_l else s[:, 1] * float('nan')
+        r2, l2 = s[:, 2] / self.t2.n_r if self.t2.count_r else s[:, 2] * float('nan'), \
+            s[:, 3] / self.t2.n_l if self.t2.count_l else s[:, 3] * float('nan')
+        a, lt = self.alpha, self.loss_type
+        if lt in ('both_all', 'both_layerwise'):
+            loss_r, loss_l = r1 + r2, l1 + l2
+            loss = a * loss_r + (1 - a) * loss_l
+        elif lt == 'only2_layerwise':
+            loss_r, loss_l = r1 + r2, l1 + l2
+            loss = a * r2 + (1 - a) * l2
+        elif lt == 'only2_all':
+            loss_r, loss_l = r2, l2
+            loss = l2 + a * r2
+        else:
+            loss_r, loss_l = r1, l1
+            loss = l1 + a * r1
+        return torch.stack([loss, loss_r, loss_l], 1)

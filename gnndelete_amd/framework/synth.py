@@ -1,0 +1,91 @@
+"""Seeded synthetic stand-ins for the reference's datasets (no dataset is reachable offline;
+prepare_dataset.py:141-150,270-302 download them).  Same shapes and the same preparation recipe
+as prepare_dataset.py:31-136,186-264: unique ``row < col`` edges, randperm split with test and
+validation edges taken first, negatives that avoid the positives, and the IN / OUT Df candidate
+masks = inside / outside the 2-hop enclosing subgraph of the test edges.
+
+The graph model is a degree-corrected stochastic block model: heavy-tailed expected degrees
+(w_i ~ rank^-1/2, like citation / co-authorship graphs) and communities that carry both the
+majority of the edges and a feature mean, so link prediction on it is learnable.  Node ids are
+randomly permuted: no locality is baked into the numbering."""
+import math
+
+import torch
+
+from .data import Data
+from .graph_utils import k_hop_subgraph, negative_sampling
+
+# name -> (num_nodes, num_features, unique row<col edges, feature style)
+SHAPES = {
+    'synth-cora': (19793, 8710, 63421, 'sparse'),
+    'synth-dblp': (17716, 1639, 52867, 'sparse'),
+    'synth-collab': (235868, 128, 1179052, 'dense'),
+    'synth-tiny': (600, 32, 2400, 'dense'),
+    'synth-small': (5000, 64, 30000, 'dense'),
+}
+
+
+def _sample_by_weight(cdf, k, gen):
+    u = torch.rand(k, generator=gen, dtype=torch.float64)
+    return torch.searchsorted(cdf, u).clamp(max=cdf.numel() - 1)
+
+
+def dcsbm_edges(n, m, seed, comm_size=128, p_in=0.8, gamma=0.5):
+    """m unique undirected edges (row < col) of a degree-corrected SBM on n nodes."""
+    gen = torch.Generator().manual_seed(seed)
+    n_comm = max(1, n // comm_size)
+    rank = torch.arange(n, dtype=torch.float64)
+    w = (rank + 1.0).pow(-gamma)
+    cdf = torch.cumsum(w / w.sum(), 0)
+    per_comm = (n + n_comm - 1) // n_comm
+    wr = (torch.arange(per_comm, dtype=torch.float64) * n_comm + 1.0).pow(-gamma)
+    cdf_r = torch.cumsum(wr / wr.sum(), 0)
+    relabel = torch.randperm(n, generator=gen)
+    keys = torch.empty(0, dtype=torch.long)
+    while keys.numel() < m:
+        k = int((m - keys.numel()) * 1.3) + 1024
+        u = _sample_by_weight(cdf, k, gen)                     # latent index; community = u % n_comm
+        inside = torch.rand(k, generator=gen) < p_in
+        v_in = (_sample_by_weight(cdf_r, k, gen) * n_comm + u % n_comm).clamp(max=n - 1)
+        v = torch.where(inside, v_in, _sample_by_weight(cdf, k, gen))
+        a, b = relabel[u], relabel[v]
+        lo, hi = torch.minimum(a, b), torch.maximum(a, b)
+        new = (lo * n + hi)[lo != hi]
+        keys = torch.unique(torch.cat([keys, new]))
+    keys = keys[torch.randperm(keys.numel(), generator=gen)[:m]]
+    community = torch.empty(n, dtype=torch.long)
+    community[relabel] = torch.arange(n) % n_comm
+    return torch.stack([keys // n, keys % n]), community
+
+
+def _features(n, f, style, community, gen):
+    if style == 'dense':
+        n_comm = int(community.max()) + 1
+        means = torch.randn(n_comm, f, generator=gen) * 0.1
+        return means[community] + torch.randn(n, f, generator=gen) * 0.1
+    # ~1 % dense bag-of-words rows, row-normalised (T.NormalizeFeatures, prepare_dataset.py:142)
+    nnz_per_row = max(1, int(0.01 * f))
+    x = torch.zeros(n, f)
+    cols = torch.randint(0, f, (n, nnz_per_row), generator=gen)
+    x.scatter_(1, cols, torch.rand(n, nnz_per_row, generator=gen) + 0.05)
+    return x / x.sum(1, keepdim=True).clamp(min=1e-12)
+
+
+def make_linkpred_dataset(name='synth-collab', seed=42, val_ratio=0.05, test_ratio=0.05, shape=None):
+    """-> (data, df_masks) where data has x, num_nodes, train_pos_edge_index (directed row<col),
+    {val,test}_{pos,neg}_edge_index and df_masks = {'in': mask, 'out': mask} over the train edges
+    (the content of the reference's d_<seed>.pkl and df_<seed>.pt)."""
+    n, f, m, style = shape if shape is not None else SHAPES[name]
+    gen = torch.Generator().manual_seed(seed)
+    edges, community = dcsbm_edges(n, m, seed)
+    x = _features(n, f, style, community, gen)
+    n_v, n_t = int(math.floor(val_ratio * m)), int(math.floor(test_ratio * m))
+    perm = torch.randperm(m, generator=gen)
+    edges = edges[:, perm]
+    test_pos, val_pos, train = edges[:, :n_t], edges[:, n_t:n_t + n_v], edges[:, n_t + n_v:]
+    data = Data(x=x, num_nodes=n, num_features=f, train_pos_edge_index=train,
+                test_pos_edge_index=test_pos, val_pos_edge_index=val_pos,
+                test_neg_edge_index=negative_sampling(test_pos, n, n_t, generator=gen),
+                val_neg_edge_index=negative_sampling(val_pos, n, n_v, generator=gen))
+    _, _, _, local = k_hop_subgraph(test_pos.flatten().unique(), 2, train, num_nodes=n)
+    return data, {'in': local, 'out': ~local}

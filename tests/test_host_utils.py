@@ -1,0 +1,91 @@
+"""Host-side preprocessing of gnndelete_amd.framework vs the oracle and vs what the reference's
+delete_gnn.main() produced (tests/golden/prep_*.npz).  Bit-exact (integer / boolean work)."""
+import pytest
+import torch
+
+from helpers import load_golden, t
+from oracle import gnndelete_ref as R
+from oracle import pyg_semantics as pyg
+
+from gnndelete_amd.framework import graph_utils as G
+from gnndelete_amd.framework.data import Data, prepare_edge_deletion, resolve_df_size
+from gnndelete_amd.framework.utils import get_link_labels, negative_sampling_kg
+
+
+@pytest.mark.parametrize('name', ['prep_gcn_out.npz', 'prep_gcn_in.npz', 'prep_gat_out.npz', 'prep_gat_in.npz'])
+def test_prepare_edge_deletion_reproduces_reference_main(name):
+    fx = load_golden(name)
+    E, n = t(fx['in::train']), int(fx['in::num_nodes'])
+    data = Data(train_pos_edge_index=E, num_nodes=n)
+    torch.manual_seed(int(fx['in::seed']))
+    size = resolve_df_size(float(fx['in::df_size']), E.shape[1])
+    prepare_edge_deletion(data, t(fx['in::cand']), size)
+    for k in ['train_pos_edge_index', 'df_mask', 'dr_mask', 'sdf_mask', 'sdf_node_1hop_mask', 'sdf_node_2hop_mask',
+              'directed_df_edge_index']:
+        assert torch.equal(data[k], t(fx[f'out::{k}'])), k
+    assert data.edge_index is data.train_pos_edge_index
+
+
+def test_prepare_edge_deletion_relational_branch():
+    g = torch.Generator().manual_seed(0)
+    n, m, r = 40, 120, 3
+    lo = torch.randint(0, n - 1, (m,), generator=g)
+    E = torch.unique(torch.stack([lo, lo + 1 + torch.randint(0, 5, (m,), generator=g)]).clamp(max=n - 1), dim=1)
+    E = E[:, E[0] < E[1]]
+    et = torch.randint(0, r, (E.shape[1],), generator=g)
+    data = Data(train_pos_edge_index=E, train_edge_type=et, num_nodes=n)
+    torch.manual_seed(1)
+    prepare_edge_deletion(data, torch.ones(E.shape[1], dtype=torch.bool), 7, relational=True, num_edge_type=r)
+    m1 = E.shape[1]
+    assert data.edge_index.shape[1] == 2 * m1 and torch.equal(data.edge_index[:, m1:], E.flip(0))
+    assert torch.equal(data.edge_type[m1:], et + r)
+    assert int(data.df_mask.sum()) == 14 and torch.equal(data.df_mask[:m1], data.df_mask[m1:])
+    assert torch.equal(data.dr_mask, ~data.df_mask)
+    assert torch.equal(data.directed_df_edge_type, et[data.df_mask[:m1]])
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_k_hop_and_to_undirected_match_oracle(seed):
+    g = torch.Generator().manual_seed(seed)
+    n = 50
+    ei = torch.randint(0, n, (2, 160), generator=g)
+    seeds = torch.randperm(n, generator=g)[:4]
+    for hops in (1, 2, 3):
+        s0, e0, m0 = pyg.k_hop_subgraph(seeds, hops, ei, n)
+        s1, e1, inv, m1 = G.k_hop_subgraph(seeds, hops, ei, num_nodes=n)
+        assert torch.equal(s0, s1) and torch.equal(e0, e1) and torch.equal(m0, m1)
+        assert torch.equal(s1[inv], seeds)
+    a = torch.randint(0, 2, (160,), generator=g).int()
+    u0, (a0,) = pyg.to_undirected(ei, [a], n)
+    u1, [a1] = G.to_undirected(ei, [a], n)
+    assert torch.equal(u0, u1) and torch.equal(a0, a1)
+    assert torch.equal(G.to_undirected(ei, num_nodes=n), u0)
+    assert G.is_undirected(u1, n) and (G.is_undirected(ei, n) == pyg.is_undirected(ei, n))
+
+
+def test_negative_sampling_contract():
+    n = 30
+    ei = torch.randint(0, n, (2, 200), generator=torch.Generator().manual_seed(3))
+    neg = G.negative_sampling(ei, n, 150)
+    assert neg.shape == (2, 150) and neg.dtype == torch.long
+    pos = set((ei[0] * n + ei[1]).tolist())
+    assert not (set((neg[0] * n + neg[1]).tolist()) & pos)
+    assert bool((neg[0] != neg[1]).all())
+    assert G.negative_sampling(ei, n, 0).shape == (2, 0)
+
+
+def test_negative_sampling_kg_matches_reference_golden():
+    fx = load_golden('neg_kg.npz')
+    torch.manual_seed(int(fx['seed']))
+    assert torch.equal(negative_sampling_kg(t(fx['edge_index']), t(fx['edge_type'])), t(fx['neg']))
+
+
+def test_labels_and_data_bag():
+    lab = get_link_labels(torch.zeros(2, 3, dtype=torch.long), torch.zeros(2, 2, dtype=torch.long))
+    assert lab.tolist() == [1, 1, 1, 0, 0]
+    d = Data(x=torch.zeros(2, 2), num_nodes=2)
+    assert not hasattr(d, 'dtrain_mask') and d['x'] is d.x
+    d.foo = torch.ones(1)
+    assert 'foo' in d and d.to('cpu') is d
+    assert R.df_size_from_arg(2.5, 1000) == resolve_df_size(2.5, 1000) == 25
+    assert resolve_df_size(100, 1000) == 100
