@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the GNNDelete hot path on MI355X: Del-operator training iterations per second.
+
+One step = one pass of the reference's loop body (framework/trainer/gnndelete_nodeemb.py:188-299:
+frozen-backbone forward on E[:, sdf_mask] -> Del -> DEC/NI losses -> Del-weight gradients ->
+Adam) over the whole synthetic OGB-Collab-shaped graph (GCN, 5 % IN edge deletion, --loss_type
+both_layerwise, mse_mean), all inputs resident in HBM.  Nothing is cached across steps: the
+frozen X W1^T GEMM and both SpMMs are recomputed every iteration exactly as upstream does.
+
+Prints ONE JSON line (see README / DESIGN.md for the field contract).  Launch for N > 1:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=200)
+    p.add_argument('--warmup', type=int, default=20)
+    p.add_argument('--workload', default='synth-collab')
+    p.add_argument('--gnn', default='gcn', choices=['gcn', 'gat', 'gin'])
+    p.add_argument('--df', default='in')
+    p.add_argument('--df_size', type=float, default=5.0)
+    p.add_argument('--loss_type', default='both_layerwise')
+    p.add_argument('--seed', type=int, default=42)
+    p.add_argument('--cpu_baseline_iters', type=int, default=3)
+    p.add_argument('--no_cpu_baseline', action='store_true')
+    p.add_argument('--no_graph', action='store_true')
+    return p.parse_args()
+
+
+def build_request(args, device):
+    """Synthetic dataset + unlearning request + randomly initialised frozen backbone."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework.data import prepare_edge_deletion, resolve_df_size
+    from gnndelete_amd.framework.graph_utils import negative_sampling
+    from gnndelete_amd.framework.models import GATDelete, GCNDelete, GINDelete
+    from gnndelete_amd.framework.synth import make_linkpred_dataset
+    from gnndelete_amd.framework.utils import seed_everything
+
+    data, df_masks = make_linkpred_dataset(args.workload, seed=args.seed)
+    seed_everything(args.seed)
+    size = resolve_df_size(args.df_size, data.train_pos_edge_index.shape[1])
+    prepare_edge_deletion(data, df_masks[args.df], size)
+    margs = SimpleNamespace(in_dim=data.x.shape[1], hidden_dim=128, out_dim=64)
+    cls = {'gcn': GCNDelete, 'gat': GATDelete, 'gin': GINDelete}[args.gnn]
+    model = cls(margs, data.sdf_node_1hop_mask, data.sdf_node_2hop_mask)
+    neg = negative_sampling(data.train_pos_edge_index, data.num_nodes, int(data.df_mask.sum()))
+    keep = torch.ones(data.num_nodes, dtype=torch.bool)
+    keep[data.directed_df_edge_index.flatten().unique()] = False
+    ni1, ni2 = data.sdf_node_1hop_mask & keep, data.sdf_node_2hop_mask & keep
+    return data, model, neg, ni1, ni2
+
+
+def make_engine(args, data, model, neg, ni1, ni2, device):
+    from gnndelete_amd.engine import NodeembEngine
+    model = model.to(device)
+    x = data.x.to(device)
+    E = data.train_pos_edge_index.to(device)
+    e_sdf = E[:, data.sdf_mask.to(device)].contiguous()
+    e_dr = E[:, data.dr_mask.to(device)].contiguous()
+    with torch.no_grad():
+        z1o, z2o = model.get_original_embeddings(x, e_dr, return_all_emb=True)
+    eng = NodeembEngine(model, x, e_sdf, z1o, z2o, E[:, data.df_mask.to(device)], neg.to(device), ni1, ni2,
+                        loss_type=args.loss_type, alpha=0.5, lr=1e-3, use_graph=not args.no_graph)
+    return eng
+
+
+def spmm_algorithmic_bytes(n, nnz, d):
+    """rowptr + col + val + read X once + write Y once (fp32 / int32)."""
+    return 4 * (n + 1) + 4 * nnz + 4 * nnz + 4 * n * d + 4 * n * d
+
+
+def time_dominant_kernel(eng, reps=20):
+    """Average duration of the layer-1 SpMM (d = 128), launched back to back on the current
+    stream between two HIP events, with the same operands the step uses."""
+    from gnndelete_amd import _lib
+    g = eng.graph
+    h = eng.h
+    t1 = torch.randn(eng.n, h, device=eng.x.device)
+    y = torch.empty_like(t1)
+    bias = eng.model.conv1.bias if hasattr(eng.model.conv1, 'bias') else None
+
+    def launch():
+        eng._spmm(g.rowptr, g.col, g.val, t1, y, bias, 0.0)
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    dur_s = e0.elapsed_time(e1) / 1e3 / reps
+    return dur_s, spmm_algorithmic_bytes(eng.n, g.nnz, h)
+
+
+def cpu_baseline(args, data, model_state, neg, iters):
+    """The CPU oracle (oracle/gnndelete_ref.py, the validated restatement of the reference's
+    loop) timed on this box's host cores on the SAME request; a bounded sample of `iters` steps."""
+    from oracle import gnndelete_ref as R
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    m = R.TwoLayerDelete(args.gnn, data.x.shape[1], 128, 64, data.sdf_node_1hop_mask, data.sdf_node_2hop_mask)
+    m.load_state_dict(model_state, strict=False)
+    d = {k: v for k, v in data.items()}
+    ni1, ni2 = R.non_df_masks(data.num_nodes, data.directed_df_edge_index, data.sdf_node_1hop_mask,
+                              data.sdf_node_2hop_mask)
+    E = data.train_pos_edge_index
+    with torch.no_grad():
+        z1o, z2o = m.get_original_embeddings(data.x, E[:, data.dr_mask], return_all_emb=True)
+    targets = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=E[:, data.df_mask], neg_edge=neg, ni_mask1=ni1, ni_mask2=ni2)
+    opt = R.make_optimizer(m, args.loss_type, 1e-3)
+    e_sdf = E[:, data.sdf_mask]
+
+    def fwd():
+        return m(data.x, e_sdf, return_all_emb=True)
+    R.nodeemb_epoch(m, fwd, targets, opt, args.loss_type, 0.5, R.LOSSES['mse_mean'])     # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        R.nodeemb_epoch(m, fwd, targets, opt, args.loss_type, 0.5, R.LOSSES['mse_mean'])
+    dt = time.perf_counter() - t0
+    return {'value': iters / dt, 'unit': 'iters/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{iters} full-graph iterations of the same request after 1 warm-up '
+                      f'({dt / iters:.2f} s each, torch CPU, {threads} threads)'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+
+    data, model, neg, ni1, ni2 = build_request(args, device)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    eng = make_engine(args, data, model, neg, ni1, ni2, device)
+
+    for _ in range(args.warmup):
+        eng.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    losses = eng.loss_history()
+
+    if rank == 0:
+        kdur, kbytes = time_dominant_kernel(eng)
+        achieved = kbytes / kdur / 1e9
+        out = {
+            'metric': 'Del-op train iters/sec', 'value': world * args.steps / dt, 'unit': 'iters/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.workload} {args.gnn.upper()} 2-layer, {args.df_size}% {args.df.upper()} '
+                                   f'edge deletion, full-graph Del step ({args.loss_type}, mse_mean)',
+                       'num_nodes': data.num_nodes, 'in_dim': int(data.x.shape[1]), 'hidden_dim': 128, 'out_dim': 64,
+                       'train_edges_undirected': int(data.train_pos_edge_index.shape[1]),
+                       'df_edges': int(data.directed_df_edge_index.shape[1]),
+                       'sdf_edges': int(data.sdf_mask.sum()), 'spmm_nnz': eng.graph.nnz,
+                       'S1': eng.s1, 'S2': eng.s2, 'hip_graph': not args.no_graph,
+                       'parallelism': 'single' if world == 1 else f'replicas{world}'},
+            'roofline': {'kernel': 'spmm_vec_kernel<32,1> (layer-1 CSR SpMM, d=128)', 'bound': 'hbm',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6},
+            'final_loss': float(losses[-1, 0]) if len(losses) else None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cpu_data = data.clone().cpu() if hasattr(data, 'clone') else data
+            out['cpu_baseline'] = cpu_baseline(args, cpu_data, state, neg, args.cpu_baseline_iters)
+            out['speedup_vs_cpu'] = out['value'] / out['cpu_baseline']['value']
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
