@@ -94,7 +94,7 @@ def time_dominant_kernel(eng, reps=20):
     bias = eng.model.conv1.bias if hasattr(eng.model.conv1, 'bias') else None
 
     def launch():
-        eng._spmm(g.rowptr, g.col, g.val, t1, y, bias, 0.0)
+        eng._spmm(False, g.val, t1, y, bias, 0.0)
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
@@ -188,7 +188,7 @@ def main():
                        'sdf_edges': int(data.sdf_mask.sum()), 'spmm_nnz': eng.graph.nnz,
                        'S1': eng.s1, 'S2': eng.s2, 'hip_graph': not args.no_graph,
                        'parallelism': 'single' if world == 1 else f'replicas{world}'},
-            'roofline': {'kernel': 'spmm_vec_kernel<32,1> (layer-1 CSR SpMM, d=128)', 'bound': 'hbm',
+            'roofline': {'kernel': 'spmm_items_kernel<32,1> (layer-1 CSR SpMM, d=128)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': None, 'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6},
             'final_loss': float(losses[-1, 0]) if len(losses) else None,

@@ -138,18 +138,26 @@ __global__ __launch_bounds__(256) void rows_gemm_scalar_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight gradient
-template <int TPW>  // output tiles per wave (tiles = (d_a/32)*(d_b/32) dealt round-robin to 4 waves)
+// weight gradient:  dW[32 TA, 32 TB] = sum_s a[ia(s),:]^T g[ig(s),:]
+// The reduction dimension is the (gathered) row index.  A block streams tiles of 32 rows of both
+// operands through LDS (float4 global loads, double-buffered: the loads of tile t+1 are in flight
+// while tile t feeds the matrix cores); its 4 waves split the TA x TB output tiles and read their
+// MFMA operands straight out of the row-major tiles (lane -> consecutive column: conflict-free).
+// HBM bytes S (d_a + d_b) 4 and flops 2 S d_a d_b are balanced at d = 128 (ridge ~20 flop/B).
+template <int TA, int TB>
 __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
     const float* __restrict__ a, int64_t ld_a, const int32_t* __restrict__ a_idx, const float* __restrict__ g,
     int64_t ld_g, const int32_t* __restrict__ g_idx, const float* __restrict__ relu_mask, int32_t n_sel,
-    int32_t d_a, int32_t d_b, int32_t rows_per_block, float* __restrict__ partials) {
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int c_lo = lane & 31;
-  const int khalf = lane >> 5;
-  const int tb = d_b >> 5;
-  const int n_tiles = (d_a >> 5) * tb;
+    int32_t rows_per_block, float* __restrict__ partials) {
+  constexpr int DA = 32 * TA, DB = 32 * TB, KT = 32;
+  constexpr int TILES = TA * TB, TPW = (TILES + 3) / 4;
+  constexpr int FA = DA / 4, FB = DB / 4;            // float4 per row
+  constexpr int LA = KT * FA / 256, LB = KT * FB / 256;  // float4 loads per thread per tile (TA, TB)
+  __shared__ __attribute__((aligned(16))) float sa[2][KT * DA];
+  __shared__ __attribute__((aligned(16))) float sg[2][KT * DB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int c_lo = lane & 31, khalf = lane >> 5;
 
   f32x16 acc[TPW];
 #pragma unroll
@@ -159,46 +167,82 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
 
   const int s_begin = blockIdx.x * rows_per_block;
   const int s_end = min(n_sel, s_begin + rows_per_block);
-  // 8 rows per iteration: lanes < 32 take rows s0..s0+3, lanes >= 32 rows s0+4..s0+7
-  for (int s0 = s_begin; s0 < s_end; s0 += 8) {
-    int64_t ra[4], rg[4];
-    bool ok[4];
+  const int n_tiles = (s_end - s_begin + KT - 1) / KT;
+
+  float4 ra[LA], rg[LB];
+  auto fetch = [&](int tile) {
+    const int s0 = s_begin + tile * KT;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int ss = s0 + khalf * 4 + s;
-      ok[s] = ss < s_end;
-      ra[s] = ok[s] ? (a_idx ? a_idx[ss] : ss) : 0;
-      rg[s] = ok[s] ? (g_idx ? g_idx[ss] : ss) : 0;
-    }
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-      const int id = wave + 4 * q;
-      if (id >= n_tiles) continue;
-      const int ca = (id / tb) * 32 + c_lo;
-      const int cb = (id % tb) * 32 + c_lo;
-      float av[4], gv[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        av[s] = ok[s] ? a[ra[s] * ld_a + ca] : 0.f;
-        float gg = ok[s] ? g[rg[s] * ld_g + cb] : 0.f;
-        if (relu_mask && ok[s]) gg = relu_mask[rg[s] * ld_g + cb] > 0.f ? gg : 0.f;
-        gv[s] = gg;
+    for (int i = 0; i < LA; ++i) {
+      const int f = tid + 256 * i, r = f / FA, c4 = f % FA, ss = s0 + r;
+      if (ss < s_end) {
+        const int64_t row = a_idx ? a_idx[ss] : ss;
+        ra[i] = reinterpret_cast<const float4*>(a + row * ld_a)[c4];
+      } else {
+        ra[i] = f4_zero();
       }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], gv[s], acc[q], 0, 0, 0);
     }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const int f = tid + 256 * i, r = f / FB, c4 = f % FB, ss = s0 + r;
+      if (ss < s_end) {
+        const int64_t row = g_idx ? g_idx[ss] : ss;
+        float4 v = reinterpret_cast<const float4*>(g + row * ld_g)[c4];
+        if (relu_mask) {
+          const float4 m = reinterpret_cast<const float4*>(relu_mask + row * ld_g)[c4];
+          v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+          v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        rg[i] = v;
+      } else {
+        rg[i] = f4_zero();
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) reinterpret_cast<float4*>(sa[buf])[tid + 256 * i] = ra[i];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) reinterpret_cast<float4*>(sg[buf])[tid + 256 * i] = rg[i];
+  };
+
+  if (n_tiles > 0) {
+    fetch(0);
+    stash(0);
+  }
+  __syncthreads();
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const int cur = tile & 1;
+    if (tile + 1 < n_tiles) fetch(tile + 1);
+    const float* pa = sa[cur];
+    const float* pg = sg[cur];
+#pragma unroll 4
+    for (int kk = 0; kk < KT / 2; ++kk) {
+      const int k = 2 * kk + khalf;
+#pragma unroll
+      for (int q = 0; q < TPW; ++q) {
+        const int id = wave + 4 * q;
+        if (id < TILES) {
+          const float av = pa[k * DA + (id / TB) * 32 + c_lo];
+          const float gv = pg[k * DB + (id % TB) * 32 + c_lo];
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gv, acc[q], 0, 0, 0);
+        }
+      }
+    }
+    if (tile + 1 < n_tiles) stash(cur ^ 1);
+    __syncthreads();
   }
 
-  float* dst = partials + (int64_t)blockIdx.x * d_a * d_b;
+  float* dst = partials + (int64_t)blockIdx.x * DA * DB;
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
     const int id = wave + 4 * q;
-    if (id >= n_tiles) continue;
-    const int i0 = (id / tb) * 32, j0 = (id % tb) * 32;
+    if (id >= TILES) continue;
+    const int i0 = (id / TB) * 32, j0 = (id % TB) * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rr = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-      dst[(int64_t)(i0 + rr) * d_b + j0 + c_lo] = acc[q][r];
+      dst[(int64_t)(i0 + rr) * DB + j0 + c_lo] = acc[q][r];
     }
   }
 }
@@ -224,9 +268,39 @@ __global__ __launch_bounds__(256) void rows_wgrad_scalar_kernel(
   }
 }
 
+// dW[e] = (accumulate ? dW[e] : 0) + sum_b partials[b][e], summed in a fixed order: a block owns
+// 64 consecutive elements (16 float4 lanes) x 16 interleaved slices of the partial list, then
+// folds the 16 slice sums through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, int32_t n_part,
                                                            int32_t n_elem, int32_t accumulate,
                                                            float* __restrict__ dw) {
+  __shared__ float4 red[16][16];
+  const int v = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int e4 = blockIdx.x * 16 + v;                     // float4 index
+  const int n4 = n_elem >> 2;
+  float4 s0 = f4_zero(), s1 = f4_zero();
+  if (e4 < n4) {
+    int b = slice;
+    for (; b + 16 < n_part; b += 32) {
+      s0 = f4_add(s0, reinterpret_cast<const float4*>(partials + (int64_t)b * n_elem)[e4]);
+      s1 = f4_add(s1, reinterpret_cast<const float4*>(partials + (int64_t)(b + 16) * n_elem)[e4]);
+    }
+    if (b < n_part) s0 = f4_add(s0, reinterpret_cast<const float4*>(partials + (int64_t)b * n_elem)[e4]);
+  }
+  red[slice][v] = f4_add(s0, s1);
+  __syncthreads();
+  if (slice == 0 && e4 < n4) {
+    float4 t = accumulate ? reinterpret_cast<float4*>(dw)[e4] : f4_zero();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t = f4_add(t, red[i][v]);
+    reinterpret_cast<float4*>(dw)[e4] = t;
+  }
+}
+
+// any n_elem (not a multiple of 4): one thread per element
+__global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* __restrict__ partials, int32_t n_part,
+                                                                  int32_t n_elem, int32_t accumulate,
+                                                                  float* __restrict__ dw) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n_elem) return;
   float s = accumulate ? dw[e] : 0.f;
@@ -235,12 +309,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 static inline void wgrad_geometry(int32_t n_sel, int* n_blocks, int* rows_per_block) {
-  int nb = (n_sel + 63) / 64;
+  int nb = (n_sel + 127) / 128;
   if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
   int rpb = (n_sel + nb - 1) / nb;
-  rpb = (rpb + 7) / 8 * 8;
-  if (rpb < 8) rpb = 8;
+  rpb = (rpb + 31) / 32 * 32;
+  if (rpb < 32) rpb = 32;
   *n_blocks = (n_sel + rpb - 1) / rpb;
   if (*n_blocks < 1) *n_blocks = 1;
   *rows_per_block = rpb;
@@ -302,17 +376,24 @@ extern "C" int gd_rows_gemm_wgrad_f32(const float* a, int64_t ld_a, const int32_
   int nb = 0, rpb = 8;
   if (n_sel > 0) {
     wgrad_geometry(n_sel, &nb, &rpb);
-    const int tiles = (d_a / 32) * (d_b / 32);
-    const bool mfma_ok = (d_a % 32 == 0) && (d_b % 32 == 0) && tiles <= 16;
+    const int ta = d_a / 32, tb = d_b / 32;
+    const bool mfma_ok = (d_a % 32 == 0) && (d_b % 32 == 0) && ta <= 4 && tb <= 4 && ta != 3 && tb != 3 &&
+                         aligned16(a) && aligned16(g) && ld_a % 4 == 0 && ld_g % 4 == 0 &&
+                         (!relu_mask || aligned16(relu_mask));
     if (mfma_ok) {
-#define GD_WG_CASE(TPW)                                                                                           \
-  hipLaunchKernelGGL((rows_wgrad_mfma_kernel<TPW>), dim3(nb), dim3(256), 0, s, a, ld_a, a_idx, g, ld_g, g_idx, \
-                     relu_mask, n_sel, d_a, d_b, rpb, partials)
-      switch ((tiles + 3) / 4) {
-        case 1: GD_WG_CASE(1); break;
-        case 2: GD_WG_CASE(2); break;
-        case 3: GD_WG_CASE(3); break;
-        default: GD_WG_CASE(4); break;
+#define GD_WG_CASE(TA, TB)                                                                                        \
+  hipLaunchKernelGGL((rows_wgrad_mfma_kernel<TA, TB>), dim3(nb), dim3(256), 0, s, a, ld_a, a_idx, g, ld_g, g_idx, \
+                     relu_mask, n_sel, rpb, partials)
+      switch (ta * 8 + tb) {
+        case 1 * 8 + 1: GD_WG_CASE(1, 1); break;
+        case 1 * 8 + 2: GD_WG_CASE(1, 2); break;
+        case 1 * 8 + 4: GD_WG_CASE(1, 4); break;
+        case 2 * 8 + 1: GD_WG_CASE(2, 1); break;
+        case 2 * 8 + 2: GD_WG_CASE(2, 2); break;
+        case 2 * 8 + 4: GD_WG_CASE(2, 4); break;
+        case 4 * 8 + 1: GD_WG_CASE(4, 1); break;
+        case 4 * 8 + 2: GD_WG_CASE(4, 2); break;
+        default: GD_WG_CASE(4, 4); break;
       }
 #undef GD_WG_CASE
     } else {
@@ -322,7 +403,11 @@ extern "C" int gd_rows_gemm_wgrad_f32(const float* a, int64_t ld_a, const int32_
     int rc = launched("rows_wgrad");
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_elem + 255) / 256), dim3(256), 0, s, partials, nb, n_elem,
-                     accumulate, dw);
+  if (n_elem % 4 == 0 && aligned16(dw) && aligned16(partials))
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_elem / 4 + 15) / 16), dim3(256), 0, s, partials, nb, n_elem,
+                       accumulate, dw);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3((n_elem + 255) / 256), dim3(256), 0, s, partials, nb, n_elem,
+                       accumulate, dw);
   return launched("wgrad_reduce");
 }

@@ -83,6 +83,101 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(const int32_t* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Load-balanced variant: the CSR is cut into work items of at most 64 in-edges (one coalesced
+// (col,val) fetch each).  A heavy-tailed graph otherwise serialises its hub rows on single
+// waves (a degree-2000 row = 1000 dependent gather rounds = the whole kernel's run time).
+// Items that cover a whole row write y directly; the pieces of a split row go to `scratch` and
+// a second tiny kernel adds them up in slot order - no atomics, bit-reproducible.
+// items[i] = {row, start, end, slot (-1 = whole row)};  split[i] = {row, first_slot, n_slots, 0}.
+template <int LPR, int VPL>
+__global__ __launch_bounds__(256) void spmm_items_kernel(const int4* __restrict__ items, int32_t n_items,
+                                                         const int32_t* __restrict__ col,
+                                                         const float* __restrict__ val,
+                                                         const float* __restrict__ x, int64_t ldx,
+                                                         float* __restrict__ y, int64_t ldy,
+                                                         const float* __restrict__ bias, float self_coef,
+                                                         float* __restrict__ scratch, int32_t d4) {
+  constexpr int G = kWave / LPR;
+  constexpr int U = (kWave / G) >= 4 ? 4 : (kWave / G);   // neighbours in flight per lane group
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= n_items) return;
+  const int4 it = items[item];
+  const int row = it.x, start = it.y, end = it.z, slot = it.w;
+  const int g = lane / LPR, li = lane % LPR;
+  const int cnt = end - start;                    // <= 64
+  const int k = start + lane;
+  const bool live = lane < cnt;
+  const int c = live ? col[k] : 0;
+  const float w = live ? (val ? val[k] : 1.0f) : 0.0f;
+
+  float4 acc[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
+  const int trips = (cnt + G - 1) / G;
+  for (int t0 = 0; t0 < trips; t0 += U) {
+    float4 xv[U][VPL];
+    float wj[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = (t0 + u) * G + g;
+      const bool ok = j < cnt;
+      const int cj = __shfl(c, j & 63);
+      wj[u] = __shfl(w, j & 63);
+      const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)cj * ldx);
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const int vec = li + v * LPR;
+        xv[u][v] = (ok && vec < d4) ? xr[vec] : f4_zero();
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
+  }
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) acc[v] = f4_add(acc[v], f4_shfl_xor(acc[v], off));
+  }
+  if (g != 0) return;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int vec = li + v * LPR;
+    if (vec >= d4) continue;
+    float4 o = acc[v];
+    if (slot < 0) {
+      if (self_coef != 0.0f) o = f4_fma(self_coef, reinterpret_cast<const float4*>(x + (int64_t)row * ldx)[vec], o);
+      if (bias) o = f4_add(o, reinterpret_cast<const float4*>(bias)[vec]);
+      reinterpret_cast<float4*>(y + (int64_t)row * ldy)[vec] = o;
+    } else {
+      reinterpret_cast<float4*>(scratch + (int64_t)slot * d4 * 4)[vec] = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void spmm_fixup_kernel(const int4* __restrict__ split, int32_t n_split,
+                                                         const float* __restrict__ scratch,
+                                                         const float* __restrict__ x, int64_t ldx,
+                                                         float* __restrict__ y, int64_t ldy,
+                                                         const float* __restrict__ bias, float self_coef,
+                                                         int32_t d4) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_split) return;
+  const int4 sp = split[i];
+  const int row = sp.x, slot0 = sp.y, n = sp.z;
+  for (int vec = lane; vec < d4; vec += kWave) {
+    float4 o = f4_zero();
+    for (int s = 0; s < n; ++s) o = f4_add(o, reinterpret_cast<const float4*>(scratch + (int64_t)(slot0 + s) * d4 * 4)[vec]);
+    if (self_coef != 0.0f) o = f4_fma(self_coef, reinterpret_cast<const float4*>(x + (int64_t)row * ldx)[vec], o);
+    if (bias) o = f4_add(o, reinterpret_cast<const float4*>(bias)[vec]);
+    reinterpret_cast<float4*>(y + (int64_t)row * ldy)[vec] = o;
+  }
+}
+
 // Any d / any alignment: one wave per row, lanes stride over columns.
 template <bool MEAN>
 __global__ __launch_bounds__(256) void spmm_scalar_kernel(const int32_t* __restrict__ rowptr,
@@ -190,4 +285,42 @@ extern "C" int gd_rgcn_mean_f32(const int32_t* rowptr, const int32_t* col, const
   GD_REQUIRE((int64_t)n_rel * n_rows < (1ll << 31), GD_E_DIM, "gd_rgcn_mean_f32: n_rel*n_rows overflows int32");
   return gd::launch_spmm<true>(rowptr, col, nullptr, x, ldx, y, ldy, nullptr, 0.f, n_rel * n_rows, n_rows, d,
                                (hipStream_t)stream);
+}
+
+extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
+                                        const int32_t* col, const float* val, const float* x, int64_t ldx, float* y,
+                                        int64_t ldy, const float* bias, float self_coef, float* scratch, int32_t d,
+                                        void* stream) {
+  using namespace gd;
+  GD_REQUIRE(items && col && x && y, GD_E_NULL, "gd_spmm_csr_balanced_f32: null pointer");
+  GD_REQUIRE(n_split == 0 || (split && scratch), GD_E_NULL, "gd_spmm_csr_balanced_f32: split rows need scratch");
+  GD_REQUIRE(n_items >= 0 && n_split >= 0 && d > 0 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldy % 4 == 0, GD_E_DIM,
+             "gd_spmm_csr_balanced_f32: d=%d must be a multiple of 4 (<=1024) with 16-byte row strides", d);
+  GD_REQUIRE(aligned16(x) && aligned16(y) && aligned16(items) && (!bias || aligned16(bias)) &&
+                 (!scratch || aligned16(scratch)) && (!split || aligned16(split)), GD_E_ALIGN,
+             "gd_spmm_csr_balanced_f32: unaligned pointer");
+  GD_REQUIRE(x != y, GD_E_DIM, "gd_spmm_csr_balanced_f32: x and y must not alias");
+  if (n_items == 0) return GD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int d4 = d / 4;
+  const dim3 grid((n_items + 3) / 4), block(256);
+  const int4* it = reinterpret_cast<const int4*>(items);
+#define GD_ITEMS_CASE(LPR, VPL)                                                                                   \
+  hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL>), grid, block, 0, s, it, n_items, col, val, x, ldx, y, ldy, bias, \
+                     self_coef, scratch, d4)
+  if (d4 <= 1) GD_ITEMS_CASE(1, 1);
+  else if (d4 <= 2) GD_ITEMS_CASE(2, 1);
+  else if (d4 <= 4) GD_ITEMS_CASE(4, 1);
+  else if (d4 <= 8) GD_ITEMS_CASE(8, 1);
+  else if (d4 <= 16) GD_ITEMS_CASE(16, 1);
+  else if (d4 <= 32) GD_ITEMS_CASE(32, 1);
+  else if (d4 <= 64) GD_ITEMS_CASE(64, 1);
+  else if (d4 <= 128) GD_ITEMS_CASE(64, 2);
+  else GD_ITEMS_CASE(64, 4);
+#undef GD_ITEMS_CASE
+  int rc = launched("spmm_items");
+  if (rc || n_split == 0) return rc;
+  hipLaunchKernelGGL(spmm_fixup_kernel, dim3((n_split + 3) / 4), block, 0, s, reinterpret_cast<const int4*>(split),
+                     n_split, scratch, x, ldx, y, ldy, bias, self_coef, d4);
+  return launched("spmm_fixup");
 }

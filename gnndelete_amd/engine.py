@@ -143,12 +143,12 @@ class NodeembEngine:
         c = self.model.conv2
         if self._mode == 'gcn':
             t2 = ops.rows_gemm(self.z1, None, c.lin.weight, trans_w=True, relu_in=True)
-            self._spmm(self.graph.rowptr, self.graph.col, self.graph.val, t2, self.z2, c.bias, 0.0)
+            self._spmm(False, self.graph.val, t2, self.z2, c.bias, 0.0)
         elif self._mode == 'gin':
             lin = c.nn
             if lin.out_features <= lin.in_features:
                 t2 = ops.rows_gemm(self.z1, None, lin.weight, trans_w=True, relu_in=True)
-                self._spmm(self.graph.rowptr, self.graph.col, None, t2, self.z2, lin.bias, 1.0 + c.eps)
+                self._spmm(False, None, t2, self.z2, lin.bias, 1.0 + c.eps)
             else:
                 raise NotImplementedError('GIN layer that widens its input is not on the fused path')
         else:   # gat
@@ -171,10 +171,10 @@ class NodeembEngine:
         if self._mode in ('gcn', 'gin'):
             dt2 = torch.empty(self.n, self.o, dtype=torch.float32, device=self.x.device)
             if self._mode == 'gcn':
-                self._spmm(g.rowptr_t, g.col_t, g.val_t, self.dz2, dt2, None, 0.0)
+                self._spmm(True, g.val_t, self.dz2, dt2, None, 0.0)
                 w2 = c.lin.weight
             else:
-                self._spmm(g.rowptr_t, g.col_t, None, self.dz2, dt2, None, 1.0 + c.eps)
+                self._spmm(True, None, self.dz2, dt2, None, 1.0 + c.eps)
                 w2 = c.nn.weight
         else:
             dt2 = torch.empty(self.n, self.o, dtype=torch.float32, device=self.x.device)
@@ -191,10 +191,12 @@ class NodeembEngine:
         # dh[S1] = dt2[S1] @ W2   (W2 is [out, in] = [d_in, d_out] of this product)
         ops.rows_gemm(dt2, self.idx1, w2, trans_w=False, out=self.dh)
 
-    def _spmm(self, rowptr, col, val, x, y, bias, self_coef):
-        check(_lib.lib().gd_spmm_csr_f32(ptr(rowptr), ptr(col), ptr(val), ptr(x), x.stride(0), ptr(y), y.stride(0),
-                                         ptr(bias), float(self_coef), self.n, x.shape[1], stream_ptr(x.device)),
-              'gd_spmm_csr_f32')
+    def _spmm(self, transposed, val, x, y, bias, self_coef):
+        g = self.graph
+        if transposed:
+            ops._spmm_raw(g.rowptr_t, g.col_t, val, x, bias, self_coef, self.n, g.plan_t, out=y)
+        else:
+            ops._spmm_raw(g.rowptr, g.col, val, x, bias, self_coef, self.n, g.plan, out=y)
 
     def _losses(self, z, z_ori, terms, dz, sums):
         d = z.shape[1]

@@ -13,6 +13,46 @@ import torch
 from . import _lib
 
 
+CHUNK = 64   # in-edges per SpMM work item (one coalesced (col, val) fetch of a 64-lane wave)
+
+
+class SplitPlan:
+    """Work items of the load-balanced SpMM (gd_spmm_csr_balanced_f32): every CSR row is cut
+    into pieces of at most CHUNK in-edges so that hub rows are spread over many waves."""
+
+    def __init__(self, rowptr, chunk=CHUNK):
+        dev = rowptr.device
+        rp = rowptr.long()
+        n = rp.numel() - 1
+        deg = rp[1:] - rp[:-1]
+        pieces = torch.clamp((deg + chunk - 1) // chunk, min=1)
+        first = torch.cumsum(pieces, 0) - pieces
+        row = torch.repeat_interleave(torch.arange(n, device=dev), pieces)
+        k = torch.arange(row.numel(), device=dev) - first[row]
+        start = rp[row] + k * chunk
+        end = torch.minimum(rp[row + 1], start + chunk)
+        is_split = pieces[row] > 1
+        slot = torch.where(is_split, torch.cumsum(is_split, 0) - 1, torch.full_like(row, -1))
+        self.items = torch.stack([row, start, end, slot], 1).to(torch.int32).contiguous()
+        self.n_items = int(row.numel())
+        srows = (pieces > 1).nonzero().flatten()
+        split_pieces = torch.where(pieces > 1, pieces, torch.zeros_like(pieces))
+        slot0 = (torch.cumsum(split_pieces, 0) - split_pieces)[srows]
+        self.split = torch.stack([srows, slot0, pieces[srows], torch.zeros_like(srows)], 1).to(torch.int32).contiguous()
+        self.n_split = int(srows.numel())
+        self.n_slots = int(split_pieces.sum())
+        self._scratch = {}
+
+    def scratch(self, d, device):
+        if self.n_slots == 0:
+            return None
+        buf = self._scratch.get(d)
+        if buf is None:
+            buf = torch.empty(self.n_slots, d, dtype=torch.float32, device=device)
+            self._scratch[d] = buf
+        return buf
+
+
 class CSRGraph:
     """Target-major CSR + its transpose (source-major) for the backward pass."""
 
@@ -21,7 +61,8 @@ class CSRGraph:
         self.rowptr, self.col, self.val = rowptr, col, val
         self.rowptr_t, self.col_t, self.val_t, self.perm_t = rowptr_t, col_t, val_t, perm_t
         self.nnz = int(col.shape[0])
-        self._keepalive = None
+        self.plan = SplitPlan(rowptr)
+        self.plan_t = SplitPlan(rowptr_t)
 
     @property
     def device(self):

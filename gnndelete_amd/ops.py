@@ -19,10 +19,20 @@ def _f32_rows(t):
     return t
 
 
-def _spmm_raw(rowptr, col, val, x, bias, self_coef, n_rows):
-    y = torch.empty(n_rows, x.shape[1], dtype=torch.float32, device=x.device)
+def _spmm_raw(rowptr, col, val, x, bias, self_coef, n_rows, plan=None, out=None):
+    """y = self_coef * x + A x + bias.  With a SplitPlan (and a float4-able width) the
+    load-balanced kernel is used, otherwise the one-wave-per-row kernel."""
+    d = x.shape[1]
+    y = out if out is not None else torch.empty(n_rows, d, dtype=torch.float32, device=x.device)
+    if plan is not None and d % 4 == 0 and d <= 1024 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
+        scratch = plan.scratch(d, x.device)
+        check(_lib.lib().gd_spmm_csr_balanced_f32(ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split,
+                                                  ptr(col), ptr(val), ptr(x), x.stride(0), ptr(y), y.stride(0),
+                                                  ptr(bias), float(self_coef), ptr(scratch), d,
+                                                  stream_ptr(x.device)), 'gd_spmm_csr_balanced_f32')
+        return y
     check(_lib.lib().gd_spmm_csr_f32(ptr(rowptr), ptr(col), ptr(val), ptr(x), x.stride(0), ptr(y), y.stride(0),
-                                     ptr(bias), float(self_coef), n_rows, x.shape[1], stream_ptr(x.device)),
+                                     ptr(bias), float(self_coef), n_rows, d, stream_ptr(x.device)),
           'gd_spmm_csr_f32')
     return y
 
@@ -35,14 +45,14 @@ class _SpMM(torch.autograd.Function):
         x = _f32_rows(x)
         ctx.graph, ctx.self_coef = graph, self_coef
         ctx.has_bias = bias is not None
-        return _spmm_raw(graph.rowptr, graph.col, graph.val, x, bias, self_coef, graph.n)
+        return _spmm_raw(graph.rowptr, graph.col, graph.val, x, bias, self_coef, graph.n, graph.plan)
 
     @staticmethod
     def backward(ctx, dy):
         g = ctx.graph
         dx = db = None
         if ctx.needs_input_grad[0]:
-            dx = _spmm_raw(g.rowptr_t, g.col_t, g.val_t, _f32_rows(dy), None, ctx.self_coef, g.n)
+            dx = _spmm_raw(g.rowptr_t, g.col_t, g.val_t, _f32_rows(dy), None, ctx.self_coef, g.n, g.plan_t)
         if ctx.has_bias and ctx.needs_input_grad[1]:
             db = dy.sum(0)
         return dx, db, None, None

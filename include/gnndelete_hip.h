@@ -59,6 +59,17 @@ int gd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                     const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias,
                     float self_coef, int32_t n_rows, int32_t d, void* stream);
 
+/* Load-balanced form of gd_spmm_csr_f32 for heavy-tailed graphs.  The CSR rows are pre-cut into
+ * work items of at most 64 in-edges: items[4*i..] = {row, start, end, slot}; slot = -1 when the
+ * item covers its whole row (y written directly), else the index of a d-float partial in
+ * `scratch`.  split[4*i..] = {row, first_slot, n_slots, 0} lists the rows cut into several
+ * items; their partials are added in slot order by a second kernel (no atomics: deterministic).
+ * Same arithmetic, same call sites as gd_spmm_csr_f32. */
+int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
+                             const int32_t* col, const float* val, const float* x, int64_t ldx,
+                             float* y, int64_t ldy, const float* bias, float self_coef,
+                             float* scratch, int32_t d, void* stream);
+
 /* Per-relation mean aggregation of R-GCN ("typed SpMM") over a relation-major CSR:
  *   rowptr[(r*n_rows + i) .. +1] delimit the in-edges of type r into node i;
  *   y[r][i,:] = mean_{k} x[col[k],:]   (0 when the segment is empty),  y is [R, n_rows, ldy].

@@ -305,3 +305,30 @@ def test_cpu_tensors_are_rejected_loudly():
     g = build_csr(torch.zeros(2, 3, dtype=torch.long).cuda(), 4, 'gcn')
     with pytest.raises(_lib.GnnDeleteHipError):
         ops.spmm(torch.zeros(4, 8), g)
+
+
+@pytest.mark.parametrize('d', [128, 64, 8, 260])
+def test_balanced_spmm_splits_hub_rows_and_matches_plain_kernel(d):
+    """A star + random graph: the hub has thousands of in-edges, so its row is cut into many work
+    items whose partials are combined by the fix-up kernel; result must equal the dense product."""
+    from gnndelete_amd import ops
+    from gnndelete_amd.graph import build_csr
+    n = 3000
+    g = torch.Generator().manual_seed(d)
+    ei = torch.cat([random_graph(n, 9000, seed=d), torch.stack([torch.arange(1, n), torch.zeros(n - 1, dtype=torch.long)]),
+                    torch.stack([torch.randint(0, n, (700,), generator=g), torch.full((700,), 5)])], 1)
+    x = torch.randn(n, d, generator=g)
+    b = torch.randn(d, generator=g)
+    gr = build_csr(ei.cuda(), n, 'gcn')
+    assert gr.plan.n_split >= 2 and gr.plan.n_items > n and gr.plan.n_slots >= 50
+    a = dense_adj(ei[:, ei[0] != ei[1]], n) + torch.eye(n, dtype=torch.float64)
+    deg = a.sum(1)
+    want = (a / deg.sqrt()[:, None] / deg.sqrt()[None, :]) @ x.double() + b.double()
+    y = ops._spmm_raw(gr.rowptr, gr.col, gr.val, x.cuda(), b.cuda(), 0.0, n, gr.plan)
+    assert rel_l2(y.cpu(), want) < TOL
+    y_plain = ops._spmm_raw(gr.rowptr, gr.col, gr.val, x.cuda(), b.cuda(), 0.0, n, None)
+    assert rel_l2(y.cpu(), y_plain.cpu()) < 1e-6
+    assert torch.equal(y, ops._spmm_raw(gr.rowptr, gr.col, gr.val, x.cuda(), b.cuda(), 0.0, n, gr.plan))
+    yt = ops._spmm_raw(gr.rowptr_t, gr.col_t, gr.val_t, x.cuda(), None, 0.5, n, gr.plan_t)
+    want_t = (a / deg.sqrt()[:, None] / deg.sqrt()[None, :]).t() @ x.double() + 0.5 * x.double()
+    assert rel_l2(yt.cpu(), want_t) < TOL
