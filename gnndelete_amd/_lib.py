@@ -29,6 +29,8 @@ PROTOTYPES = {
     'gd_rowpair_mse_workspace': (_i64, [_i32]),
     'gd_rowpair_mse_f32': (ctypes.c_int, [_p, _i64, _p, _i64, _i32, _p, _p, _i32, _p, _p, _p, _p, _i64, _i32,
                                           _p, _p, _p]),
+    'gd_rowtarget_mse_workspace': (_i64, [_i32]),
+    'gd_rowtarget_mse_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p, _p, _p]),
     'gd_edge_dot_f32': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     'gd_adam_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _p]),
 }

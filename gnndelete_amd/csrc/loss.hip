@@ -75,6 +75,86 @@ __global__ __launch_bounds__(256) void pair_sum_reduce_kernel(const float* __res
   if (threadIdx.x == 0) { sums[0] += red[0][0]; sums[1] += red[1][0]; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Regular ("row-target") form used when the targets are fixed for the whole run (full-batch
+// training: z_ori and the negatives are drawn once, gnndelete_nodeemb.py:177-185).  All terms
+// that touch row i are folded, once, into their mean target tbar_i, their count c_i and a
+// constant:   sum_t |z_i - o_t|^2 = c_i |z_i - tbar_i|^2 + K_i     (exact, no cancellation)
+// so the per-step work is a pure stream:  read z[row_u], read tm[u] (compact, sequential),
+// write dz[row_u] = coef_u (z - tbar),  sums[kind_u] += cnt_u |z - tbar|^2.
+// A wave takes 64 consecutive loss rows: one coalesced fetch of their (row, coef, cnt, kind),
+// then its G lane groups walk them 4 rows at a time (8 row loads in flight per group).
+template <int LPR, int VPL>
+__global__ __launch_bounds__(256) void rowtarget_mse_kernel(
+    const float* __restrict__ z, int64_t ld_z, const float* __restrict__ tm, int32_t d4,
+    const int32_t* __restrict__ row_idx, const float* __restrict__ coef, const float* __restrict__ cnt,
+    const int32_t* __restrict__ kind, int32_t n_rows, float* __restrict__ dz, int64_t ld_dz,
+    float* __restrict__ partials) {
+  constexpr int G = kWave / LPR;
+  constexpr int U = (kWave / G) >= 4 ? 4 : (kWave / G);
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / LPR, li = lane % LPR;
+  const int u0 = (blockIdx.x * 4 + wave) * kWave;
+  float s0 = 0.f, s1 = 0.f;
+  if (u0 < n_rows) {
+    const int n_here = min(kWave, n_rows - u0);
+    const bool live = lane < n_here;
+    const int row_l = live ? row_idx[u0 + lane] : 0;
+    const float coef_l = live ? coef[u0 + lane] : 0.f;
+    // count with the kind folded into the sign: DEC (kind 0) >= 0, NI (kind 1) stored negative
+    const float cnt_l = live ? (kind[u0 + lane] ? -cnt[u0 + lane] : cnt[u0 + lane]) : 0.f;
+    const int trips = (n_here + G - 1) / G;
+    for (int t0 = 0; t0 < trips; t0 += U) {
+      float4 zv[U][VPL], tv[U][VPL];
+      int rows[U];
+      float cf[U], cn[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = (t0 + u) * G + g;
+        ok[u] = j < n_here;
+        rows[u] = __shfl(row_l, j & 63);
+        cf[u] = __shfl(coef_l, j & 63);
+        cn[u] = __shfl(cnt_l, j & 63);
+        const float4* zr = reinterpret_cast<const float4*>(z + (int64_t)rows[u] * ld_z);
+        const float4* tr = reinterpret_cast<const float4*>(tm + (int64_t)(u0 + j) * d4 * 4);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int vec = li + v * LPR;
+          const bool in = ok[u] && vec < d4;
+          zv[u][v] = in ? zr[vec] : f4_zero();
+          tv[u][v] = in ? tr[vec] : f4_zero();
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float sq = 0.f;
+        float* drow = dz + (int64_t)rows[u] * ld_dz;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int vec = li + v * LPR;
+          const float4 df = make_float4(zv[u][v].x - tv[u][v].x, zv[u][v].y - tv[u][v].y,
+                                        zv[u][v].z - tv[u][v].z, zv[u][v].w - tv[u][v].w);
+          sq = fmaf(df.x, df.x, sq); sq = fmaf(df.y, df.y, sq); sq = fmaf(df.z, df.z, sq); sq = fmaf(df.w, df.w, sq);
+          if (ok[u] && vec < d4)
+            reinterpret_cast<float4*>(drow)[vec] = make_float4(cf[u] * df.x, cf[u] * df.y, cf[u] * df.z, cf[u] * df.w);
+        }
+        if (cn[u] >= 0.f) s0 = fmaf(cn[u], sq, s0); else s1 = fmaf(-cn[u], sq, s1);
+      }
+    }
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partials[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
 static inline int mse_blocks(int32_t n_seg, int lpr) {
   const int per_block = 4 * (kWave / lpr);
   return (n_seg + per_block - 1) / per_block;
@@ -194,6 +274,44 @@ extern "C" int gd_rowpair_mse_f32(const float* z, int64_t ld_z, const float* o, 
   }
 #undef GD_MSE_CASE
   int rc = launched("rowpair_mse");
+  if (rc) return rc;
+  hipLaunchKernelGGL(pair_sum_reduce_kernel, dim3(1), dim3(256), 0, s, partials, nb, sums);
+  return launched("pair_sum_reduce");
+}
+
+extern "C" int64_t gd_rowtarget_mse_workspace(int32_t n_rows) { return 2 * (int64_t)((n_rows + 255) / 256 + 1); }
+
+extern "C" int gd_rowtarget_mse_f32(const float* z, int64_t ld_z, const float* tm, int32_t d, const int32_t* row_idx,
+                                    const float* coef, const float* cnt, const int32_t* kind, int32_t n_rows,
+                                    float* dz, int64_t ld_dz, float* sums, float* partials, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(sums && partials, GD_E_NULL, "gd_rowtarget_mse_f32: null sums/partials");
+  if (n_rows == 0) return GD_OK;
+  GD_REQUIRE(z && tm && row_idx && coef && cnt && kind && dz, GD_E_NULL, "gd_rowtarget_mse_f32: null pointer");
+  GD_REQUIRE(d > 0 && d % 4 == 0 && d <= 1024 && ld_z % 4 == 0 && ld_dz % 4 == 0, GD_E_DIM,
+             "gd_rowtarget_mse_f32: d=%d must be a multiple of 4 (<=1024) with 16-byte row strides", d);
+  GD_REQUIRE(aligned16(z) && aligned16(tm) && aligned16(dz), GD_E_ALIGN, "gd_rowtarget_mse_f32: unaligned matrix");
+  hipStream_t s = (hipStream_t)stream;
+  const int d4 = d / 4;
+  const int lpr = lanes_per_row(d4);
+  const int nb = (n_rows + 255) / 256;
+#define GD_RT_CASE(LPR, VPL)                                                                                      \
+  hipLaunchKernelGGL((rowtarget_mse_kernel<LPR, VPL>), dim3(nb), dim3(256), 0, s, z, ld_z, tm, d4, row_idx, coef, \
+                     cnt, kind, n_rows, dz, ld_dz, partials)
+  switch (lpr) {
+    case 1: GD_RT_CASE(1, 1); break;
+    case 2: GD_RT_CASE(2, 1); break;
+    case 4: GD_RT_CASE(4, 1); break;
+    case 8: GD_RT_CASE(8, 1); break;
+    case 16: GD_RT_CASE(16, 1); break;
+    case 32: GD_RT_CASE(32, 1); break;
+    default:
+      if (d4 <= 64) GD_RT_CASE(64, 1);
+      else if (d4 <= 128) GD_RT_CASE(64, 2);
+      else GD_RT_CASE(64, 4);
+  }
+#undef GD_RT_CASE
+  int rc = launched("rowtarget_mse");
   if (rc) return rc;
   hipLaunchKernelGGL(pair_sum_reduce_kernel, dim3(1), dim3(256), 0, s, partials, nb, sums);
   return launched("pair_sum_reduce");

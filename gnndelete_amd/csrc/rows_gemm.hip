@@ -21,6 +21,7 @@
 namespace gd {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int kWgradMaxRows = 1024;   // rows of the reduction dimension one wgrad block owns
 
 template <int NT>
 __global__ __launch_bounds__(256, 2) void rows_gemm_mfma_kernel(
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
   constexpr int LA = KT * FA / 256, LB = KT * FB / 256;  // float4 loads per thread per tile (TA, TB)
   __shared__ __attribute__((aligned(16))) float sa[2][KT * DA];
   __shared__ __attribute__((aligned(16))) float sg[2][KT * DB];
+  __shared__ int32_t sia[kWgradMaxRows], sig[kWgradMaxRows];   // this block's gather lists
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int c_lo = lane & 31, khalf = lane >> 5;
@@ -169,6 +171,13 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
   const int s_end = min(n_sel, s_begin + rows_per_block);
   const int n_tiles = (s_end - s_begin + KT - 1) / KT;
 
+  // stage the row indices once so the per-tile row loads do not wait on an index load
+  for (int i = tid; i < s_end - s_begin; i += 256) {
+    sia[i] = a_idx ? a_idx[s_begin + i] : s_begin + i;
+    sig[i] = g_idx ? g_idx[s_begin + i] : s_begin + i;
+  }
+  __syncthreads();
+
   float4 ra[LA], rg[LB];
   auto fetch = [&](int tile) {
     const int s0 = s_begin + tile * KT;
@@ -176,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
     for (int i = 0; i < LA; ++i) {
       const int f = tid + 256 * i, r = f / FA, c4 = f % FA, ss = s0 + r;
       if (ss < s_end) {
-        const int64_t row = a_idx ? a_idx[ss] : ss;
+        const int64_t row = sia[ss - s_begin];
         ra[i] = reinterpret_cast<const float4*>(a + row * ld_a)[c4];
       } else {
         ra[i] = f4_zero();
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
     for (int i = 0; i < LB; ++i) {
       const int f = tid + 256 * i, r = f / FB, c4 = f % FB, ss = s0 + r;
       if (ss < s_end) {
-        const int64_t row = g_idx ? g_idx[ss] : ss;
+        const int64_t row = sig[ss - s_begin];
         float4 v = reinterpret_cast<const float4*>(g + row * ld_g)[c4];
         if (relu_mask) {
           const float4 m = reinterpret_cast<const float4*>(relu_mask + row * ld_g)[c4];
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
         const int id = wave + 4 * q;
-        if (id < TILES) {
+        if (TILES % 4 == 0 || id < TILES) {
           const float av = pa[k * DA + (id / TB) * 32 + c_lo];
           const float gv = pg[k * DB + (id % TB) * 32 + c_lo];
           acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gv, acc[q], 0, 0, 0);
@@ -311,6 +320,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* _
 static inline void wgrad_geometry(int32_t n_sel, int* n_blocks, int* rows_per_block) {
   int nb = (n_sel + 127) / 128;
   if (nb > 512) nb = 512;
+  if (nb < (n_sel + kWgradMaxRows - 1) / kWgradMaxRows) nb = (n_sel + kWgradMaxRows - 1) / kWgradMaxRows;
   if (nb < 1) nb = 1;
   int rpb = (n_sel + nb - 1) / nb;
   rpb = (rpb + 31) / 32 * 32;

@@ -38,33 +38,76 @@ def _loss_coefficients(loss_type, alpha):
 
 
 class _LayerTerms:
-    """DEC + NI terms of one layer grouped by the row of z they touch."""
+    """DEC + NI terms of one layer, folded per touched row (targets are fixed for the run).
 
-    def __init__(self, pos_edge, neg_edge, ni_mask, d, coef_r, coef_l, reduction, device):
-        pos, neg = pos_edge.cpu().long(), neg_edge.cpu().long()
-        ni_rows = ni_mask.cpu().nonzero().flatten()
+    Every term is (row of z, row of z_ori, weight, kind).  All terms of a row are merged into the
+    mean target ``tm[u]``, the count ``cnt[u]`` and a constant, using
+        sum_t |z - o_t|^2 = c |z - mean_t o_t|^2 + (sum_t |o_t|^2 - c |mean_t o_t|^2)
+    (folded once in fp64).  If some row carries both kinds (never the case for the reference's
+    masks, where NI rows exclude the Df endpoints) the general segmented kernel is used instead."""
+
+    def __init__(self, pos_edge, neg_edge, ni_mask, z_ori, coef_r, coef_l, reduction):
+        device = z_ori.device
+        d = z_ori.shape[1]
+        pos, neg = pos_edge.to(device).long(), neg_edge.to(device).long()
+        ni_rows = ni_mask.to(device).nonzero().flatten()
         m = pos.shape[1]
         self.n_r = (2 * m * d) if reduction == 'mean' else 1
         self.n_l = (ni_rows.numel() * d) if reduction == 'mean' else 1
         self.count_r, self.count_l = 2 * m, int(ni_rows.numel())
+        w_r, w_l = coef_r / max(self.n_r, 1), coef_l / max(self.n_l, 1)
         rows = torch.cat([pos[0], pos[1], ni_rows])
         tgt = torch.cat([neg[0], neg[1], ni_rows])
-        kind = torch.cat([torch.zeros(2 * m, dtype=torch.int32), torch.ones(ni_rows.numel(), dtype=torch.int32)])
-        w = torch.cat([torch.full((2 * m,), coef_r / max(self.n_r, 1), dtype=torch.float32),
-                       torch.full((ni_rows.numel(),), coef_l / max(self.n_l, 1), dtype=torch.float32)])
-        order = torch.argsort(rows, stable=True)
-        rows, tgt, kind, w = rows[order], tgt[order], kind[order], w[order]
-        seg_row, counts = torch.unique_consecutive(rows, return_counts=True)
-        seg_ptr = torch.zeros(seg_row.numel() + 1, dtype=torch.int32)
-        seg_ptr[1:] = torch.cumsum(counts, 0)
-        self.n_seg = int(seg_row.numel())
-        self.seg_ptr = seg_ptr.to(device)
-        self.seg_row = seg_row.to(device=device, dtype=torch.int32)
-        self.term_o = tgt.to(device=device, dtype=torch.int32)
-        self.term_w = w.to(device)
-        self.term_kind = kind.to(device)
-        self.partials = torch.empty(max(2, _lib.lib().gd_rowpair_mse_workspace(self.n_seg)), dtype=torch.float32,
-                                    device=device)
+        kind = torch.cat([torch.zeros(2 * m, dtype=torch.int32, device=device),
+                          torch.ones(ni_rows.numel(), dtype=torch.int32, device=device)])
+        self.k_const = [0.0, 0.0]
+        mixed = bool(ni_mask.to(device)[pos.flatten()].any()) if m else False
+        self.folded = not mixed
+        if self.folded:
+            uniq, inv, c = torch.unique(rows, return_inverse=True, return_counts=True)
+            o64 = z_ori[tgt].double()
+            tbar = torch.zeros(uniq.numel(), d, dtype=torch.float64, device=device).index_add_(0, inv, o64)
+            tbar /= c[:, None].double()
+            q = torch.zeros(uniq.numel(), dtype=torch.float64, device=device).index_add_(0, inv, (o64 * o64).sum(1))
+            k_row = (q - c.double() * (tbar * tbar).sum(1)).clamp_(min=0.0)
+            kind_u = torch.zeros(uniq.numel(), dtype=torch.int32, device=device)
+            kind_u[inv] = kind
+            self.k_const = [float(k_row[kind_u == 0].sum()), float(k_row[kind_u == 1].sum())]
+            self.n_rows = int(uniq.numel())
+            self.row_idx = uniq.to(torch.int32)
+            self.tm = tbar.float().contiguous()
+            self.cnt = c.float()
+            self.coef = (2.0 * torch.where(kind_u == 0, w_r, w_l) * c.double()).float()
+            self.kind = kind_u
+            ws = _lib.lib().gd_rowtarget_mse_workspace(self.n_rows)
+        else:
+            w = torch.cat([torch.full((2 * m,), w_r, dtype=torch.float32, device=device),
+                           torch.full((ni_rows.numel(),), w_l, dtype=torch.float32, device=device)])
+            order = torch.argsort(rows, stable=True)
+            rows, tgt, kind, w = rows[order], tgt[order], kind[order], w[order]
+            seg_row, counts = torch.unique_consecutive(rows, return_counts=True)
+            seg_ptr = torch.zeros(seg_row.numel() + 1, dtype=torch.int32, device=device)
+            seg_ptr[1:] = torch.cumsum(counts, 0)
+            self.n_seg = int(seg_row.numel())
+            self.seg_ptr, self.seg_row = seg_ptr, seg_row.to(torch.int32)
+            self.term_o, self.term_w, self.term_kind = tgt.to(torch.int32), w, kind
+            self.z_ori = z_ori
+            ws = _lib.lib().gd_rowpair_mse_workspace(self.n_seg)
+        self.partials = torch.empty(max(2, ws), dtype=torch.float32, device=device)
+
+    def launch(self, z, dz, sums):
+        d = z.shape[1]
+        if self.folded:
+            check(_lib.lib().gd_rowtarget_mse_f32(ptr(z), z.stride(0), ptr(self.tm), d, ptr(self.row_idx),
+                                                  ptr(self.coef), ptr(self.cnt), ptr(self.kind), self.n_rows, ptr(dz),
+                                                  dz.stride(0), ptr(sums), ptr(self.partials), stream_ptr(z.device)),
+                  'gd_rowtarget_mse_f32')
+        else:
+            zo = self.z_ori
+            check(_lib.lib().gd_rowpair_mse_f32(ptr(z), z.stride(0), ptr(zo), zo.stride(0), d, ptr(self.seg_ptr),
+                                                ptr(self.seg_row), self.n_seg, ptr(self.term_o), ptr(self.term_w),
+                                                ptr(self.term_kind), ptr(dz), dz.stride(0), 0, ptr(sums),
+                                                ptr(self.partials), stream_ptr(z.device)), 'gd_rowpair_mse_f32')
 
 
 class _Adam:
@@ -108,8 +151,8 @@ class NodeembEngine:
         self.s1, self.s2 = int(self.idx1.numel()), int(self.idx2.numel())
         self.z1_ori, self.z2_ori = ops._f32_rows(z1_ori), ops._f32_rows(z2_ori)
         coef_r, coef_l = _loss_coefficients(loss_type, alpha)
-        self.t1 = _LayerTerms(pos_edge, neg_edge, ni_mask1, self.h, coef_r, coef_l, reduction, dev)
-        self.t2 = _LayerTerms(pos_edge, neg_edge, ni_mask2, self.o, coef_r, coef_l, reduction, dev)
+        self.t1 = _LayerTerms(pos_edge, neg_edge, ni_mask1, self.z1_ori, coef_r, coef_l, reduction)
+        self.t2 = _LayerTerms(pos_edge, neg_edge, ni_mask2, self.z2_ori, coef_r, coef_l, reduction)
         self.uses_l1 = loss_type in ('both_all', 'both_layerwise', 'only1')
         self.uses_l2 = loss_type != 'only1'
         # does a gradient of loss-2 w.r.t. W_D1 (through conv2) ever reach an optimizer step?
@@ -139,20 +182,50 @@ class NodeembEngine:
         self.graph = graph_for(edge_index, n, gmode)
 
     # ------------------------------------------------------------------ pieces
+    def _linear(self, x, weight, relu_in=False):
+        """x @ weight^T: the MFMA row kernel when the weight fits its LDS image, else rocBLAS."""
+        out_f, in_f = weight.shape
+        if in_f % 8 == 0 and out_f % 32 == 0 and out_f <= 128 and in_f * out_f * 4 <= 64 * 1024:
+            return ops.rows_gemm(x, None, weight, trans_w=True, relu_in=relu_in)
+        return torch.nn.functional.linear(torch.relu(x) if relu_in else x, weight)
+
+    def _conv1_forward(self):
+        """Frozen layer 1, recomputed every step exactly as upstream does, written into z1."""
+        c = self.model.conv1
+        g = self.graph
+        if self._mode == 'gcn':
+            self._spmm(False, g.val, self._linear(self.x, c.lin.weight), self.z1, c.bias, 0.0)
+        elif self._mode == 'gin':
+            lin = c.nn
+            if lin.out_features <= lin.in_features:
+                self._spmm(False, None, self._linear(self.x, lin.weight), self.z1, lin.bias, 1.0 + c.eps)
+            else:
+                agg = torch.empty_like(self.x)
+                self._spmm(False, None, self.x, agg, None, 1.0 + c.eps)
+                self.z1.copy_(torch.nn.functional.linear(agg, lin.weight, lin.bias))
+        else:
+            h1 = self._linear(self.x, c.lin_src.weight)
+            a_src = (h1 * c.att_src.view(1, -1)).sum(-1)
+            a_dst = (h1 * c.att_dst.view(1, -1)).sum(-1)
+            check(_lib.lib().gd_gat_aggregate_f32(ptr(g.rowptr), ptr(g.col), ptr(a_src), ptr(a_dst), ptr(h1),
+                                                  h1.stride(0), ptr(self.z1), self.z1.stride(0), ptr(c.bias), None,
+                                                  c.negative_slope, self.n, self.h, stream_ptr(self.x.device)),
+                  'gd_gat_aggregate_f32')
+
     def _conv2_forward(self):
         c = self.model.conv2
         if self._mode == 'gcn':
-            t2 = ops.rows_gemm(self.z1, None, c.lin.weight, trans_w=True, relu_in=True)
+            t2 = self._linear(self.z1, c.lin.weight, relu_in=True)
             self._spmm(False, self.graph.val, t2, self.z2, c.bias, 0.0)
         elif self._mode == 'gin':
             lin = c.nn
             if lin.out_features <= lin.in_features:
-                t2 = ops.rows_gemm(self.z1, None, lin.weight, trans_w=True, relu_in=True)
+                t2 = self._linear(self.z1, lin.weight, relu_in=True)
                 self._spmm(False, None, t2, self.z2, lin.bias, 1.0 + c.eps)
             else:
                 raise NotImplementedError('GIN layer that widens its input is not on the fused path')
         else:   # gat
-            h2 = ops.rows_gemm(self.z1, None, c.lin_src.weight, trans_w=True, relu_in=True)
+            h2 = self._linear(self.z1, c.lin_src.weight, relu_in=True)
             self._h2 = h2
             self._a_src = (h2 * c.att_src.view(1, -1)).sum(-1)
             self._a_dst = (h2 * c.att_dst.view(1, -1)).sum(-1)
@@ -198,13 +271,6 @@ class NodeembEngine:
         else:
             ops._spmm_raw(g.rowptr, g.col, val, x, bias, self_coef, self.n, g.plan, out=y)
 
-    def _losses(self, z, z_ori, terms, dz, sums):
-        d = z.shape[1]
-        check(_lib.lib().gd_rowpair_mse_f32(ptr(z), z.stride(0), ptr(z_ori), z_ori.stride(0), d, ptr(terms.seg_ptr),
-                                            ptr(terms.seg_row), terms.n_seg, ptr(terms.term_o), ptr(terms.term_w),
-                                            ptr(terms.term_kind), ptr(dz), dz.stride(0), 0, ptr(sums),
-                                            ptr(terms.partials), stream_ptr(z.device)), 'gd_rowpair_mse_f32')
-
     def _wgrad(self, a_compact, g, g_idx, n_sel, relu_mask, out, accumulate, ws):
         d_a, d_b = a_compact.shape[1], g.shape[1]
         check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(a_compact), a_compact.stride(0), None, ptr(g), g.stride(0),
@@ -217,15 +283,14 @@ class NodeembEngine:
         m = self.model
         with torch.no_grad():
             # ---- forward
-            p1 = m.conv1(self.x, self.edge_index)
-            self.z1.copy_(p1)
+            self._conv1_forward()
             ops.rows_gemm(self.z1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1)
             self._conv2_forward()
             ops.rows_gemm(self.z2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
             # ---- losses (value + dz)
             self.sums.zero_()
-            self._losses(self.z1, self.z1_ori, self.t1, self.dz1, self.sums[0:2])
-            self._losses(self.z2, self.z2_ori, self.t2, self.dz2, self.sums[2:4])
+            self.t1.launch(self.z1, self.dz1, self.sums[0:2])
+            self.t2.launch(self.z2, self.dz2, self.sums[2:4])
             self.hist.index_copy_(0, self.hist_pos, self.sums[None])
             self.hist_pos.add_(1).remainder_(self.hist.shape[0])
             # ---- backward + update
@@ -296,10 +361,11 @@ class NodeembEngine:
         """[steps, 3] host tensor: train_loss, loss_r, loss_l as the reference logs them."""
         k = min(self.steps_done, self.hist.shape[0])
         s = self.hist[:k].double().cpu()
-        r1, l1 = s[:, 0] / self.t1.n_r if self.t1.count_r else s[:, 0] * float('nan'), \
-            s[:, 1] / self.t1.n_l if self.t1.count_l else s[:, 1] * float('nan')
-        r2, l2 = s[:, 2] / self.t2.n_r if self.t2.count_r else s[:, 2] * float('nan'), \
-            s[:, 3] / self.t2.n_l if self.t2.count_l else s[:, 3] * float('nan')
+        nan = float('nan')
+        r1 = (s[:, 0] + self.t1.k_const[0]) / self.t1.n_r if self.t1.count_r else s[:, 0] * nan
+        l1 = (s[:, 1] + self.t1.k_const[1]) / self.t1.n_l if self.t1.count_l else s[:, 1] * nan
+        r2 = (s[:, 2] + self.t2.k_const[0]) / self.t2.n_r if self.t2.count_r else s[:, 2] * nan
+        l2 = (s[:, 3] + self.t2.k_const[1]) / self.t2.n_l if self.t2.count_l else s[:, 3] * nan
         a, lt = self.alpha, self.loss_type
         if lt in ('both_all', 'both_layerwise'):
             loss_r, loss_l = r1 + r2, l1 + l2

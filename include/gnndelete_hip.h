@@ -145,6 +145,19 @@ int gd_rowpair_mse_f32(const float* z, int64_t ld_z, const float* o, int64_t ld_
                        float* dz, int64_t ld_dz, int32_t dz_compact,
                        float* sums, float* partials, void* stream);
 
+/* Pre-folded form of the same losses for runs whose targets never change (full-batch training:
+ * z_ori and the negatives are fixed outside the loop, gnndelete_nodeemb.py:177-185).  For every
+ * touched row u (row_idx[u], ascending) the caller folds its terms once into the mean target
+ * tm[u,:] (compact [n_rows, d]), cnt[u] = number of terms, coef[u] = 2 * w * cnt and a constant
+ * K (sum_t |o_t|^2 - cnt |tbar|^2, added on the host):
+ *       diff = z[row,:] - tm[u,:];  dz[row,:] = coef[u] * diff;  sums[kind[u]] += cnt[u] * |diff|^2
+ * Pure streaming, deterministic; `partials` holds gd_rowtarget_mse_workspace(n_rows) floats;
+ * sums[2] is accumulated into (zero it first). */
+int64_t gd_rowtarget_mse_workspace(int32_t n_rows);
+int gd_rowtarget_mse_f32(const float* z, int64_t ld_z, const float* tm, int32_t d,
+                         const int32_t* row_idx, const float* coef, const float* cnt, const int32_t* kind,
+                         int32_t n_rows, float* dz, int64_t ld_dz, float* sums, float* partials, void* stream);
+
 /* Link decoders.  dot: out[m] = <z[e0[m]], z[e1[m]]>  (framework/models/gcn.py:26-36);
  * distmult: out[m] = sum_c z[e0[m],c] * rel[etype[m],c] * z[e1[m],c]  (rgcn.py:40-47). */
 int gd_edge_dot_f32(const float* z, int64_t ld_z, int32_t d, const int64_t* e0, const int64_t* e1,

@@ -75,3 +75,34 @@ def test_gcn_both_layerwise_runs_where_upstream_crashes():
     np.testing.assert_allclose(hist[:, 0], [l['train_loss'] for l in logs], rtol=1e-4)
     assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), mo.deletion1.deletion_weight.detach()) < 1e-4
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
+
+
+def test_engine_handles_rows_that_carry_both_loss_kinds():
+    """NI masks that include Df endpoints (not what the reference builds, but legal for the
+    API) take the general segmented loss kernel; result must equal the oracle's."""
+    from gnndelete_amd.engine import NodeembEngine
+    from oracle import gnndelete_ref as R
+    from helpers import oracle_model
+    fx = load_golden('traj_gin_both_layerwise.npz')
+    state, data, rest = split_fixture(fx)
+    m = hip_model('gin', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    mo = oracle_model('gin', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    E = data['train_pos_edge_index']
+    ni1, ni2 = data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask']       # Df endpoints NOT removed
+    neg = t(rest['neg'])
+    with torch.no_grad():
+        z1o, z2o = mo.get_original_embeddings(data['x'], E[:, data['dr_mask']], return_all_emb=True)
+    targets = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=E[:, data['df_mask']], neg_edge=neg, ni_mask1=ni1, ni_mask2=ni2)
+    opt = R.make_optimizer(mo, 'both_layerwise', 0.01)
+    e_sdf = E[:, data['sdf_mask']]
+    logs = [R.nodeemb_epoch(mo, lambda: mo(data['x'], e_sdf, return_all_emb=True), targets, opt, 'both_layerwise',
+                            0.4, R.LOSSES['mse_mean']) for _ in range(4)]
+    Ec = E.cuda()
+    eng = NodeembEngine(m, data['x'].cuda(), Ec[:, data['sdf_mask'].cuda()].contiguous(), z1o.cuda(), z2o.cuda(),
+                        Ec[:, data['df_mask'].cuda()], neg.cuda(), ni1, ni2, loss_type='both_layerwise', alpha=0.4,
+                        lr=0.01)
+    assert not eng.t1.folded and not eng.t2.folded
+    for _ in range(4):
+        eng.step()
+    np.testing.assert_allclose(eng.loss_history().numpy()[:, 0], [l['train_loss'] for l in logs], rtol=1e-4)
+    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4

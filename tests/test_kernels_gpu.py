@@ -332,3 +332,32 @@ def test_balanced_spmm_splits_hub_rows_and_matches_plain_kernel(d):
     yt = ops._spmm_raw(gr.rowptr_t, gr.col_t, gr.val_t, x.cuda(), None, 0.5, n, gr.plan_t)
     want_t = (a / deg.sqrt()[:, None] / deg.sqrt()[None, :]).t() @ x.double() + 0.5 * x.double()
     assert rel_l2(yt.cpu(), want_t) < TOL
+
+
+@pytest.mark.parametrize('d', [128, 64, 16, 260])
+def test_rowtarget_mse_matches_direct_formula(d):
+    from gnndelete_amd import _lib
+    g = torch.Generator().manual_seed(d + 1)
+    n, u = 500, 333
+    z = torch.randn(n, d, generator=g)
+    tm = torch.randn(u, d, generator=g)
+    rows = torch.randperm(n, generator=g)[:u].sort().values
+    cnt = torch.randint(1, 5, (u,), generator=g).float()
+    coef = torch.rand(u, generator=g)
+    kind = torch.randint(0, 2, (u,), generator=g).int()
+    diff = z.double()[rows] - tm.double()
+    sq = (diff ** 2).sum(1) * cnt.double()
+    want = [float(sq[kind == 0].sum()), float(sq[kind == 1].sum())]
+    dz = torch.full((n, d), 5.0, device='cuda')
+    sums = torch.zeros(2, device='cuda')
+    ws = torch.empty(_lib.lib().gd_rowtarget_mse_workspace(u), device='cuda')
+    dev = [t_.cuda() for t_ in (z, tm, rows.int(), coef, cnt, kind)]
+    _lib.check(_lib.lib().gd_rowtarget_mse_f32(dev[0].data_ptr(), d, dev[1].data_ptr(), d, dev[2].data_ptr(),
+                                               dev[3].data_ptr(), dev[4].data_ptr(), dev[5].data_ptr(), u,
+                                               dz.data_ptr(), d, sums.data_ptr(), ws.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream))
+    assert abs(float(sums[0]) - want[0]) < 1e-5 * want[0] and abs(float(sums[1]) - want[1]) < 1e-5 * want[1]
+    assert rel_l2(dz.cpu()[rows], coef.double()[:, None] * diff) < TOL
+    rest = torch.ones(n, dtype=torch.bool)
+    rest[rows] = False
+    assert torch.all(dz.cpu()[rest] == 5.0)
