@@ -54,6 +54,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Bijective remap of the hardware block id so that the blocks resident on one XCD (b % 8) cover a
+// contiguous range of logical block ids (placement is a speed assumption only, never correctness).
+__device__ __forceinline__ int xcd_contiguous_block(int b, int n_blocks) {
+  constexpr int kXcd = 8;
+  const int q = n_blocks / kXcd, r = n_blocks % kXcd;
+  const int xcd = b % kXcd, local = b / kXcd;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
 // lanes-per-row geometry shared by the row-vector kernels: a row of d floats is d/4 float4
 // vectors; LPR lanes (power of two <= 64) cooperate on one row, 64/LPR rows per wave.
 inline int lanes_per_row(int d4) {

@@ -9,9 +9,9 @@
 // forward kernel: the [d_in, d_out] weight lives in LDS for the life of the block (XOR-swizzled
 // columns so the straight fill, the transposed fill and the reads are bank-conflict free); every wave owns
 // one 32-row tile at a time and feeds its A operand STRAIGHT from global memory: lane l holds
-// row (l&31) and loads one float4 = k-slots {8kb + 4(l>>5) + s, s=0..3}, i.e. the k index of
-// MFMA step s is permuted (both operands agree), which turns the gather into 16-byte loads with
-// no LDS round trip.  Output rows are written after the k loop, so `in` may alias `out`.
+// row (l&31) and loads 64 contiguous bytes per 32-wide k chunk = k-slots {32kc + 16(l>>5) + j},
+// i.e. the k index of each MFMA step is permuted (both operands agree), which turns the gather
+// into 16-byte loads that use every byte of the cache lines they touch, with no LDS round trip.  Output rows are written after the k loop, so `in` may alias `out`.
 //
 // wgrad kernel: the reduction runs over the selected rows; consecutive lanes read consecutive
 // features of one row (128-byte coalesced), blocks own contiguous row chunks and write partial
@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_mfma_kernel(
     const int s_a = tile * 32 + r_lo;
     const bool live = s_a < n_sel;
     const int64_t row_a = live ? (idx ? idx[s_a] : s_a) : 0;
-    const float4* src = reinterpret_cast<const float4*>(in + row_a * ld_in) + khalf;
-    float4* sav = save_in ? reinterpret_cast<float4*>(save_in + (int64_t)s_a * d_in) + khalf : nullptr;
+    // lane (r_lo, khalf) owns 64 contiguous bytes of every 128-byte line of its row: the four
+    // float4 loads of a chunk touch the same 32 cache lines back to back (one L1 miss, 3 hits)
+    const float4* src = reinterpret_cast<const float4*>(in + row_a * ld_in) + khalf * 4;
+    float4* sav = save_in ? reinterpret_cast<float4*>(save_in + (int64_t)s_a * d_in) + khalf * 4 : nullptr;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -67,24 +69,38 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const int kblocks = d_in >> 3;
-    float4 a_next = live ? src[0] : f4_zero();
-    for (int kb = 0; kb < kblocks; ++kb) {
-      float4 a4 = a_next;
-      if (kb + 1 < kblocks) a_next = live ? src[2 * (kb + 1)] : f4_zero();
-      if (sav && live) sav[2 * kb] = a4;
-      if (relu_in) {
-        a4.x = fmaxf(a4.x, 0.f); a4.y = fmaxf(a4.y, 0.f); a4.z = fmaxf(a4.z, 0.f); a4.w = fmaxf(a4.w, 0.f);
+    const int kchunks = d_in >> 5;
+    float4 a_next[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_next[i] = live ? src[i] : f4_zero();
+    for (int kc = 0; kc < kchunks; ++kc) {
+      float4 a4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a4[i] = a_next[i];
+      if (kc + 1 < kchunks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_next[i] = live ? src[(kc + 1) * 8 + i] : f4_zero();
       }
-      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-      const int k0 = kb * 8 + khalf * 4;
+      if (sav && live) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float* wk = wl + (k0 + s) * d_out + ((r_lo ^ (k0 + s)) & 31);
+        for (int i = 0; i < 4; ++i) sav[kc * 8 + i] = a4[i];
+      }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const float b = wk[t * 32];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b, acc[t], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        if (relu_in) {
+          a4[i].x = fmaxf(a4[i].x, 0.f); a4[i].y = fmaxf(a4[i].y, 0.f);
+          a4[i].z = fmaxf(a4[i].z, 0.f); a4[i].w = fmaxf(a4[i].w, 0.f);
+        }
+        const float av[4] = {a4[i].x, a4[i].y, a4[i].z, a4[i].w};
+        const int k0 = kc * 32 + khalf * 16 + i * 4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float* wk = wl + (k0 + s) * d_out + ((r_lo ^ (k0 + s)) & 31);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const float b = wk[t * 32];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b, acc[t], 0, 0, 0);
+          }
         }
       }
     }
@@ -343,7 +359,7 @@ extern "C" int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* i
   if (n_sel == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)d_in * d_out * sizeof(float);
-  const bool mfma_ok = (d_out % 32 == 0) && d_out <= 128 && (d_in % 8 == 0) && lds <= 64 * 1024 && aligned16(in) &&
+  const bool mfma_ok = (d_out % 32 == 0) && d_out <= 128 && (d_in % 32 == 0) && lds <= 64 * 1024 && aligned16(in) &&
                        (ld_in % 4 == 0) && (!save_in || aligned16(save_in));
   if (mfma_ok) {
     const int n_tiles = (n_sel + 31) / 32;

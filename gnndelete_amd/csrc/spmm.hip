@@ -90,70 +90,98 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(const int32_t* __restrict
 // Items that cover a whole row write y directly; the pieces of a split row go to `scratch` and
 // a second tiny kernel adds them up in slot order - no atomics, bit-reproducible.
 // items[i] = {row, start, end, slot (-1 = whole row)};  split[i] = {row, first_slot, n_slots, 0}.
-template <int LPR, int VPL>
-__global__ __launch_bounds__(256) void spmm_items_kernel(const int4* __restrict__ items, int32_t n_items,
-                                                         const int32_t* __restrict__ col,
-                                                         const float* __restrict__ val,
-                                                         const float* __restrict__ x, int64_t ldx,
-                                                         float* __restrict__ y, int64_t ldy,
-                                                         const float* __restrict__ bias, float self_coef,
-                                                         float* __restrict__ scratch, int32_t d4) {
+// ---------------------------------------------------------------------------------------------
+// Persistent, XCD-windowed variant.  The grid is exactly the resident set (8 XCDs x 32 CUs x 8
+// blocks); XCD k owns the k-th contiguous eighth of the work items and its 1024 resident waves
+// sweep that range TOGETHER: wave w visits items base + t*1024 + w, so at any moment one XCD is
+// working inside a window of ~1024 consecutive rows.  With a locality-preserving node order the
+// feature rows those rows gather are shared and stay in that XCD's private 4 MB L2, instead of
+// every edge going out to the fabric (measured: 18 % L2 hit rate and 5.4x the algorithmic bytes
+// with one block per 64 random rows).
+template <int LPR, int VPL, bool EXACT>
+__global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restrict__ items, int32_t n_items,
+                                                           const int32_t* __restrict__ col,
+                                                           const float* __restrict__ val,
+                                                           const float* __restrict__ x, int64_t ldx,
+                                                           float* __restrict__ y, int64_t ldy,
+                                                           const float* __restrict__ bias, float self_coef,
+                                                           float* __restrict__ scratch, int32_t d4, int32_t nnz) {
   constexpr int G = kWave / LPR;
-  constexpr int U = (kWave / G) >= 4 ? 4 : (kWave / G);   // neighbours in flight per lane group
+  constexpr int U = (kWave / G) >= 4 ? 4 : (kWave / G);
+  constexpr int kXcd = 8;
   const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= n_items) return;
-  const int4 it = items[item];
-  const int row = it.x, start = it.y, end = it.z, slot = it.w;
   const int g = lane / LPR, li = lane % LPR;
-  const int cnt = end - start;                    // <= 64
-  const int k = start + lane;
-  const bool live = lane < cnt;
-  const int c = live ? col[k] : 0;
-  const float w = live ? (val ? val[k] : 1.0f) : 0.0f;
+  const int xcd = blockIdx.x % kXcd;
+  const int waves_per_xcd = (gridDim.x / kXcd) * 4;
+  const int wx = (blockIdx.x / kXcd) * 4 + (threadIdx.x >> 6);
+  const int per = (n_items + kXcd - 1) / kXcd;
+  const int i0 = xcd * per, i1 = min(n_items, i0 + per);
+  int i = i0 + wx;
+  if (i >= i1) return;
 
-  float4 acc[VPL];
+  int4 desc = items[i];
+  int kk = min(desc.y + lane, nnz - 1);
+  int c = col[kk];
+  float w = val ? val[kk] : 1.0f;
+  for (; i < i1; i += waves_per_xcd) {
+    const int row = desc.x, slot = desc.w;
+    const int cnt = desc.z - desc.y;
+    const int c_cur = c;
+    const float w_cur = lane < cnt ? w : 0.f;
+    // prefetch the next visit (clamped, branch-free)
+    desc = items[min(i + waves_per_xcd, i1 - 1)];
+    kk = min(desc.y + lane, nnz - 1);
+    c = col[kk];
+    w = val ? val[kk] : 1.0f;
+
+    float4 acc[VPL];
 #pragma unroll
-  for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
-  const int trips = (cnt + G - 1) / G;
-  for (int t0 = 0; t0 < trips; t0 += U) {
-    float4 xv[U][VPL];
-    float wj[U];
+    for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
+    const int trips = (cnt + G - 1) / G;
+    for (int t0 = 0; t0 < trips; t0 += U) {
+      float4 xv[U][VPL];
+      float wj[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int j = (t0 + u) * G + g;
-      const bool ok = j < cnt;
-      const int cj = __shfl(c, j & 63);
-      wj[u] = __shfl(w, j & 63);
-      const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)cj * ldx);
+      for (int u = 0; u < U; ++u) {
+        const int j = (t0 + u) * G + g;
+        // shuffles stay outside any lane-dependent condition (a permute issued under a
+        // partial exec mask cannot read the lanes that are switched off)
+        const int cj = __shfl(c_cur, j & 63);
+        const float wsh = __shfl(w_cur, j & 63);
+        const int c0 = __shfl(c_cur, 0);
+        wj[u] = j < cnt ? wsh : 0.f;
+        const int cs = j < cnt ? cj : c0;
+        const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)cs * ldx);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int vec = li + v * LPR;
+          xv[u][v] = EXACT ? xr[vec] : xr[min(vec, d4 - 1)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+      for (int off = LPR; off < kWave; off <<= 1) acc[v] = f4_add(acc[v], f4_shfl_xor(acc[v], off));
+    }
+    if (g == 0) {
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
         const int vec = li + v * LPR;
-        xv[u][v] = (ok && vec < d4) ? xr[vec] : f4_zero();
+        if (!EXACT && vec >= d4) continue;
+        float4 o = acc[v];
+        if (slot < 0) {
+          if (self_coef != 0.0f) o = f4_fma(self_coef, reinterpret_cast<const float4*>(x + (int64_t)row * ldx)[vec], o);
+          if (bias) o = f4_add(o, reinterpret_cast<const float4*>(bias)[vec]);
+          reinterpret_cast<float4*>(y + (int64_t)row * ldy)[vec] = o;
+        } else {
+          reinterpret_cast<float4*>(scratch + (int64_t)slot * d4 * 4)[vec] = o;
+        }
       }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
-  }
-#pragma unroll
-  for (int v = 0; v < VPL; ++v) {
-#pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1) acc[v] = f4_add(acc[v], f4_shfl_xor(acc[v], off));
-  }
-  if (g != 0) return;
-#pragma unroll
-  for (int v = 0; v < VPL; ++v) {
-    const int vec = li + v * LPR;
-    if (vec >= d4) continue;
-    float4 o = acc[v];
-    if (slot < 0) {
-      if (self_coef != 0.0f) o = f4_fma(self_coef, reinterpret_cast<const float4*>(x + (int64_t)row * ldx)[vec], o);
-      if (bias) o = f4_add(o, reinterpret_cast<const float4*>(bias)[vec]);
-      reinterpret_cast<float4*>(y + (int64_t)row * ldy)[vec] = o;
-    } else {
-      reinterpret_cast<float4*>(scratch + (int64_t)slot * d4 * 4)[vec] = o;
     }
   }
 }
@@ -290,7 +318,7 @@ extern "C" int gd_rgcn_mean_f32(const int32_t* rowptr, const int32_t* col, const
 extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
                                         const int32_t* col, const float* val, const float* x, int64_t ldx, float* y,
                                         int64_t ldy, const float* bias, float self_coef, float* scratch, int32_t d,
-                                        void* stream) {
+                                        int32_t nnz, void* stream) {
   using namespace gd;
   GD_REQUIRE(items && col && x && y, GD_E_NULL, "gd_spmm_csr_balanced_f32: null pointer");
   GD_REQUIRE(n_split == 0 || (split && scratch), GD_E_NULL, "gd_spmm_csr_balanced_f32: split rows need scratch");
@@ -303,11 +331,21 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   if (n_items == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
   const int d4 = d / 4;
-  const dim3 grid((n_items + 3) / 4), block(256);
+  // persistent grid: the resident set (256 CUs x 8 blocks), a multiple of the 8 XCDs
+  int nblk = (n_items + 3) / 4;
+  if (nblk > 2048) nblk = 2048;
+  nblk = (nblk + 7) / 8 * 8;
+  const dim3 grid(nblk), block(256);
   const int4* it = reinterpret_cast<const int4*>(items);
-#define GD_ITEMS_CASE(LPR, VPL)                                                                                   \
-  hipLaunchKernelGGL((spmm_items_kernel<LPR, VPL>), grid, block, 0, s, it, n_items, col, val, x, ldx, y, ldy, bias, \
-                     self_coef, scratch, d4)
+#define GD_ITEMS_CASE(LPR, VPL)                                                                                    \
+  do {                                                                                                             \
+    if (d4 == LPR * VPL)                                                                                           \
+      hipLaunchKernelGGL((spmm_persist_kernel<LPR, VPL, true>), grid, block, 0, s, it, n_items, col, val, x, ldx, y, \
+                         ldy, bias, self_coef, scratch, d4, nnz);                                                  \
+    else                                                                                                           \
+      hipLaunchKernelGGL((spmm_persist_kernel<LPR, VPL, false>), grid, block, 0, s, it, n_items, col, val, x, ldx, \
+                         y, ldy, bias, self_coef, scratch, d4, nnz);                                               \
+  } while (0)
   if (d4 <= 1) GD_ITEMS_CASE(1, 1);
   else if (d4 <= 2) GD_ITEMS_CASE(2, 1);
   else if (d4 <= 4) GD_ITEMS_CASE(4, 1);
@@ -318,7 +356,7 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   else if (d4 <= 128) GD_ITEMS_CASE(64, 2);
   else GD_ITEMS_CASE(64, 4);
 #undef GD_ITEMS_CASE
-  int rc = launched("spmm_items");
+  int rc = launched("spmm_persist");
   if (rc || n_split == 0) return rc;
   hipLaunchKernelGGL(spmm_fixup_kernel, dim3((n_split + 3) / 4), block, 0, s, reinterpret_cast<const int4*>(split),
                      n_split, scratch, x, ldx, y, ldy, bias, self_coef, d4);

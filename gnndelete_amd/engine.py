@@ -185,7 +185,7 @@ class NodeembEngine:
     def _linear(self, x, weight, relu_in=False):
         """x @ weight^T: the MFMA row kernel when the weight fits its LDS image, else rocBLAS."""
         out_f, in_f = weight.shape
-        if in_f % 8 == 0 and out_f % 32 == 0 and out_f <= 128 and in_f * out_f * 4 <= 64 * 1024:
+        if in_f % 32 == 0 and out_f % 32 == 0 and out_f <= 128 and in_f * out_f * 4 <= 64 * 1024:
             return ops.rows_gemm(x, None, weight, trans_w=True, relu_in=relu_in)
         return torch.nn.functional.linear(torch.relu(x) if relu_in else x, weight)
 

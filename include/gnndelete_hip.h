@@ -64,11 +64,12 @@ int gd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
  * item covers its whole row (y written directly), else the index of a d-float partial in
  * `scratch`.  split[4*i..] = {row, first_slot, n_slots, 0} lists the rows cut into several
  * items; their partials are added in slot order by a second kernel (no atomics: deterministic).
+ * nnz = length of col/val (index loads are clamped to it instead of being predicated).
  * Same arithmetic, same call sites as gd_spmm_csr_f32. */
 int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
                              const int32_t* col, const float* val, const float* x, int64_t ldx,
                              float* y, int64_t ldy, const float* bias, float self_coef,
-                             float* scratch, int32_t d, void* stream);
+                             float* scratch, int32_t d, int32_t nnz, void* stream);
 
 /* Per-relation mean aggregation of R-GCN ("typed SpMM") over a relation-major CSR:
  *   rowptr[(r*n_rows + i) .. +1] delimit the in-edges of type r into node i;
