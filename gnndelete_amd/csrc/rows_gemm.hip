@@ -23,13 +23,16 @@ namespace gd {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kWgradMaxRows = 1024;   // rows of the reduction dimension one wgrad block owns
 
+constexpr int kGemmThreads = 512;   // 8 waves share one LDS weight image; 2 blocks per CU
+
 template <int NT>
-__global__ __launch_bounds__(256, 2) void rows_gemm_mfma_kernel(
+__global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
     const float* in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel,
     const float* __restrict__ w, int32_t d_in, int32_t trans_w, const float* __restrict__ bias, int32_t relu_in,
     float* out, int64_t ld_out, float* __restrict__ save_in) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   constexpr int d_out = 32 * NT;
+  constexpr int kWaves = kGemmThreads / 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -37,14 +40,14 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_mfma_kernel(
   // ---- weight image: wl[k][n] = W[k][n] or W[n][k]
   const int n_w = d_in * d_out;
   // (column index XOR-swizzled with k inside each 32-wide group: conflict-free for the
-  //  straight fill, the transposed fill and the B-fragment reads, with no padding)
+  //  straight fill, the transposed fill and the fragment reads, with no padding)
   if (!trans_w) {
-    for (int e = tid; e < n_w; e += 256) {
+    for (int e = tid; e < n_w; e += kGemmThreads) {
       const int k = e / d_out, n = e % d_out;
       wl[k * d_out + ((n & ~31) | ((n ^ k) & 31))] = w[e];
     }
   } else {
-    for (int e = tid; e < n_w; e += 256) {
+    for (int e = tid; e < n_w; e += kGemmThreads) {
       const int k = e % d_in, n = e / d_in;
       wl[k * d_out + ((n & ~31) | ((n ^ k) & 31))] = w[e];
     }
@@ -52,9 +55,9 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_mfma_kernel(
   __syncthreads();
 
   const int n_tiles = (n_sel + 31) >> 5;
-  const int r_lo = lane & 31;       // A row owned by this lane
-  const int khalf = lane >> 5;      // which half of the 8-wide k block
-  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+  const int r_lo = lane & 31;       // the sample (row of `in`) this lane owns
+  const int khalf = lane >> 5;      // which 16-float half of each 32-wide k chunk
+  for (int tile = blockIdx.x * kWaves + wave; tile < n_tiles; tile += gridDim.x * kWaves) {
     const int s_a = tile * 32 + r_lo;
     const bool live = s_a < n_sel;
     const int64_t row_a = live ? (idx ? idx[s_a] : s_a) : 0;
@@ -98,26 +101,27 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_mfma_kernel(
           const float* wk = wl + (k0 + s) * d_out + ((r_lo ^ (k0 + s)) & 31);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            const float b = wk[t * 32];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], b, acc[t], 0, 0, 0);
+            // transposed product: the weight is the MFMA "A" operand (D rows = output features),
+            // the sample row the "B" operand (D cols = samples), so every lane ends up holding
+            // 4-float runs of ITS OWN output row -> float4 stores, no index reload
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[t * 32], av[s], acc[t], 0, 0, 0);
           }
         }
       }
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rr = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-      const int s_o = tile * 32 + rr;
-      if (s_o >= n_sel) continue;
-      const int64_t row_o = idx ? idx[s_o] : s_o;
-      float* dst = out + row_o * ld_out + r_lo;
+    // ---- epilogue: D[i][j], j = lane&31 = sample, i = (r&3) + 8*(r>>2) + 4*(lane>>5) = feature
+    if (live) {
+      float* dst = out + row_a * ld_out + 4 * khalf;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        float v = acc[t][r];
-        if (bias) v += bias[t * 32 + r_lo];
-        dst[t * 32] = v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 v = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+          const int n0 = 32 * t + 8 * q;
+          if (bias) v = f4_add(v, *reinterpret_cast<const float4*>(bias + n0 + 4 * khalf));
+          *reinterpret_cast<float4*>(dst + n0) = v;
+        }
       }
     }
   }
@@ -360,14 +364,15 @@ extern "C" int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* i
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)d_in * d_out * sizeof(float);
   const bool mfma_ok = (d_out % 32 == 0) && d_out <= 128 && (d_in % 32 == 0) && lds <= 64 * 1024 && aligned16(in) &&
-                       (ld_in % 4 == 0) && (!save_in || aligned16(save_in));
+                       (ld_in % 4 == 0) && (!save_in || aligned16(save_in)) && aligned16(out) && (ld_out % 4 == 0) &&
+                       (!bias || aligned16(bias));
   if (mfma_ok) {
     const int n_tiles = (n_sel + 31) / 32;
-    int grid = (n_tiles + 3) / 4;
+    int grid = (n_tiles + 7) / 8;
     if (grid > 512) grid = 512;
-#define GD_RG_CASE(NT)                                                                                            \
-  hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT>), dim3(grid), dim3(256), lds, s, in, ld_in, idx, n_sel, w, d_in, \
-                     trans_w, bias, relu_in, out, ld_out, save_in)
+#define GD_RG_CASE(NT)                                                                                        \
+  hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in, idx, n_sel, w, \
+                     d_in, trans_w, bias, relu_in, out, ld_out, save_in)
     switch (d_out / 32) {
       case 1: GD_RG_CASE(1); break;
       case 2: GD_RG_CASE(2); break;

@@ -9,6 +9,8 @@
 // handed to the groups with ds_bpermute (__shfl) - the LDS crossbar, no LDS storage.  Group
 // partial sums are combined with a log2(G)-step xor-shuffle tree, so the summation order is
 // fixed (bit-reproducible run to run).  HBM-bound: bytes = 4(n+1) + 8 nnz + 8 n d.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gd {
@@ -331,9 +333,12 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   if (n_items == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
   const int d4 = d / 4;
-  // persistent grid: the resident set (256 CUs x 8 blocks), a multiple of the 8 XCDs
+  // grid: a few visits per wave (4 x the resident set of 256 CUs x 8 blocks measured best), a
+  // multiple of the 8 XCDs
   int nblk = (n_items + 3) / 4;
-  if (nblk > 2048) nblk = 2048;
+  const char* cap_env = getenv("GD_SPMM_GRID_CAP");                 // tuning knob (blocks)
+  const int cap = cap_env ? atoi(cap_env) : 8192;
+  if (nblk > cap) nblk = cap;
   nblk = (nblk + 7) / 8 * 8;
   const dim3 grid(nblk), block(256);
   const int4* it = reinterpret_cast<const int4*>(items);

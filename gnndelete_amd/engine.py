@@ -131,7 +131,7 @@ class NodeembEngine:
 
     def __init__(self, model, x, edge_index, z1_ori, z2_ori, pos_edge, neg_edge, ni_mask1, ni_mask2,
                  loss_type='both_layerwise', alpha=0.5, lr=1e-3, reduction='mean', mask_1hop=None, mask_2hop=None,
-                 use_graph=True, history=4096):
+                 use_graph=True, history=4096, reorder=True):
         assert loss_type in LOSS_TYPES, loss_type
         conv1, conv2 = model.conv1, model.conv2
         if not isinstance(conv2, (GCNConv, GINConv, GATConv)):
@@ -140,12 +140,25 @@ class NodeembEngine:
         if dev.type != 'cuda':
             raise _lib.GnnDeleteHipError('NodeembEngine needs CUDA(HIP) tensors (no CPU fallback)')
         self.model, self.loss_type, self.alpha = model, loss_type, alpha
-        self.x, self.edge_index = x, edge_index
         self.n = n = x.shape[0]
+        m1 = (model.deletion1.mask if mask_1hop is None else mask_1hop).to(dev)
+        m2 = (model.deletion2.mask if mask_2hop is None else mask_2hop).to(dev)
+        ni_mask1, ni_mask2 = ni_mask1.to(dev), ni_mask2.to(dev)
+        pos_edge, neg_edge = pos_edge.to(dev), neg_edge.to(dev)
+        self.perm = None
+        if reorder and edge_index.shape[1] > 0 and n > 4096:
+            # internal locality-preserving numbering (see reorder.py); everything below lives in it
+            from .reorder import locality_order
+            perm, inv = locality_order(edge_index, n)
+            self.perm = perm
+            x = x[perm].contiguous()
+            edge_index = inv[edge_index]
+            z1_ori, z2_ori = z1_ori[perm], z2_ori[perm]
+            m1, m2, ni_mask1, ni_mask2 = m1[perm], m2[perm], ni_mask1[perm], ni_mask2[perm]
+            pos_edge, neg_edge = inv[pos_edge], inv[neg_edge]
+        self.x, self.edge_index = x, edge_index
         self.wd1, self.wd2 = model.deletion1.deletion_weight, model.deletion2.deletion_weight
         self.h, self.o = self.wd1.shape[0], self.wd2.shape[0]
-        m1 = model.deletion1.mask if mask_1hop is None else mask_1hop
-        m2 = model.deletion2.mask if mask_2hop is None else mask_2hop
         self.idx1 = m1.nonzero().flatten().to(device=dev, dtype=torch.int32)
         self.idx2 = m2.nonzero().flatten().to(device=dev, dtype=torch.int32)
         self.s1, self.s2 = int(self.idx1.numel()), int(self.idx2.numel())

@@ -106,3 +106,39 @@ def test_engine_handles_rows_that_carry_both_loss_kinds():
         eng.step()
     np.testing.assert_allclose(eng.loss_history().numpy()[:, 0], [l['train_loss'] for l in logs], rtol=1e-4)
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
+
+
+def test_internal_reordering_does_not_change_the_result():
+    """The engine's locality renumbering (label propagation) is invisible outside: with and
+    without it the learnt Del weights and the logged losses agree to fp32 rounding."""
+    import gnndelete_amd.engine as eng_mod
+    from gnndelete_amd.engine import NodeembEngine
+    from gnndelete_amd.framework.data import prepare_edge_deletion
+    from gnndelete_amd.framework.graph_utils import negative_sampling
+    from gnndelete_amd.framework.models import GCNDelete
+    from gnndelete_amd.framework.synth import make_linkpred_dataset
+    from types import SimpleNamespace
+    torch.manual_seed(0)
+    data, dfm = make_linkpred_dataset('synth-small', seed=1)
+    prepare_edge_deletion(data, dfm['in'], 600)
+    neg = negative_sampling(data.train_pos_edge_index, data.num_nodes, int(data.df_mask.sum()))
+    keep = torch.ones(data.num_nodes, dtype=torch.bool)
+    keep[data.directed_df_edge_index.flatten().unique()] = False
+    ni1, ni2 = data.sdf_node_1hop_mask & keep, data.sdf_node_2hop_mask & keep
+    out = []
+    for reorder in (False, True):
+        torch.manual_seed(5)
+        m = GCNDelete(SimpleNamespace(in_dim=64, hidden_dim=128, out_dim=64), data.sdf_node_1hop_mask,
+                      data.sdf_node_2hop_mask).cuda()
+        x, E = data.x.cuda(), data.train_pos_edge_index.cuda()
+        with torch.no_grad():
+            z1o, z2o = m.get_original_embeddings(x, E[:, data.dr_mask.cuda()].contiguous(), return_all_emb=True)
+        e = NodeembEngine(m, x, E[:, data.sdf_mask.cuda()].contiguous(), z1o, z2o, E[:, data.df_mask.cuda()],
+                          neg.cuda(), ni1, ni2, lr=1e-2, reorder=reorder)
+        assert (e.perm is not None) == reorder
+        for _ in range(8):
+            e.step()
+        out.append((m.deletion1.deletion_weight.detach().cpu(), m.deletion2.deletion_weight.detach().cpu(),
+                    e.loss_history()))
+    assert rel_l2(out[1][0], out[0][0]) < 1e-4 and rel_l2(out[1][1], out[0][1]) < 1e-4
+    np.testing.assert_allclose(out[1][2].numpy(), out[0][2].numpy(), rtol=1e-4)
