@@ -1,0 +1,86 @@
+"""GNNDeleteTrainer - the edge-probability variant (`--unlearning_model gnndelete`, reference:
+framework/trainer/gnndelete.py:138-309):
+
+  loss_r = MSE( logit(Df edges), logit(fresh negatives) )            (per-epoch negatives :221-225)
+  loss_l = MSE( sigmoid(z z^T)[P], sigmoid(logits_ori)[P] )          (:239-241)
+  P = strictly-lower-triangular pairs of 2-hop S_Df nodes minus the Df pairs (:174-193)
+  loss = 0.5 loss_r + 0.5 loss_l, single Adam, zero_grad after the step (:249-255)
+
+Upstream materialises z z^T over ALL N x N node pairs plus an N x N boolean mask on the CPU and
+indexes it every epoch.  Only the |S| x |S| block of S_Df nodes is ever read, so only that block
+is formed here (one [|S|, d] x [d, |S|] library GEMM), with the pair mask and the original
+probabilities gathered once.  Autograd runs through the HIP-backed model."""
+import os
+import time
+
+import torch
+import torch.nn.functional as F
+
+from ..graph_utils import negative_sampling
+from .base import Trainer, _require_gpu, device
+
+
+def sdf_pair_mask(num_nodes, sdf_node_mask, df_edges):
+    """(nodes S sorted, [|S|,|S|] bool mask of the pairs i > j of S that are not Df edges)."""
+    nodes = sdf_node_mask.nonzero().flatten()
+    s = nodes.numel()
+    mask = torch.ones(s, s, dtype=torch.bool, device=nodes.device).tril_(-1)
+    pos = torch.full((num_nodes,), -1, dtype=torch.long, device=nodes.device)
+    pos[nodes] = torch.arange(s, device=nodes.device)
+    a, b = pos[df_edges[0]], pos[df_edges[1]]
+    ok = (a >= 0) & (b >= 0)
+    mask[a[ok], b[ok]] = False
+    mask[b[ok], a[ok]] = False
+    return nodes, mask
+
+
+class GNNDeleteTrainer(Trainer):
+
+    def train(self, model, data, optimizer, args, logits_ori=None, attack_model_all=None, attack_model_sub=None):
+        return self.train_fullbatch(model, data, optimizer, args, logits_ori, attack_model_all, attack_model_sub)
+
+    def train_fullbatch(self, model, data, optimizer, args, logits_ori=None, attack_model_all=None,
+                        attack_model_sub=None):
+        _require_gpu()
+        model = model.to(device)
+        data = data.to(device)
+        edges = data.train_pos_edge_index
+        e_sdf = edges[:, data.sdf_mask].contiguous()
+        df_edges = edges[:, data.df_mask]
+        nodes, pair_mask = sdf_pair_mask(data.num_nodes, data.sdf_node_2hop_mask, df_edges)
+        target = None
+        if bool(pair_mask.any()):
+            if logits_ori is None:
+                raise ValueError('GNNDeleteTrainer needs logits_ori (pred_proba.pt of the original model)')
+            ori = logits_ori.to(device) if logits_ori.device != nodes.device else logits_ori
+            target = ori[nodes][:, nodes][pair_mask].sigmoid()
+        neg_size = int(data.df_mask.sum())
+        best_metric = 0
+        for epoch in range(args.epochs):
+            model.train()
+            start = time.time()
+            z = model(data.x, e_sdf)
+            neg = negative_sampling(edge_index=edges, num_nodes=data.num_nodes, num_neg_samples=neg_size)
+            df_logits = model.decode(z, df_edges, neg)
+            loss_r = F.mse_loss(df_logits[:neg_size], df_logits[neg_size:])
+            if target is not None:
+                zs = z[nodes]
+                loss_l = F.mse_loss((zs @ zs.t())[pair_mask].sigmoid(), target)
+            else:
+                loss_l = torch.tensor(0.0, device=device)
+            loss = 0.5 * loss_r + 0.5 * loss_l
+            loss.backward()
+            optimizer.step()
+            optimizer.zero_grad()
+            if (epoch + 1) % self.args.valid_freq == 0:
+                valid_loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, _, valid_log = self.eval(model, data, 'val')
+                valid_log['epoch'] = epoch
+                self._record({'epoch': epoch, 'train_loss': loss.item(), 'train_loss_l': loss_l.item(),
+                              'train_loss_r': loss_r.item(), 'train_time': time.time() - start}, valid_log)
+                if dt_auc + df_auc > best_metric:
+                    best_metric = dt_auc + df_auc
+                    print(f'Save best checkpoint at epoch {epoch:04d}. Valid loss = {valid_loss:.4f}')
+                    torch.save({'model_state': model.state_dict(), 'optimizer_state': optimizer.state_dict()},
+                               os.path.join(args.checkpoint_dir, 'model_best.pt'))
+        torch.save({'model_state': {k: v.to('cpu') for k, v in model.state_dict().items()},
+                    'optimizer_state': optimizer.state_dict()}, os.path.join(args.checkpoint_dir, 'model_final.pt'))

@@ -1,0 +1,118 @@
+"""GraphSAINT random-walk mini-batching (reference: GraphSAINTRandomWalkSampler from
+torch_geometric.loader, used at gnndelete_nodeemb.py:379-381 with batch_size roots, walk_length 2,
+num_steps batches per epoch) and the mini-batch unlearning loop of gnndelete_nodeemb.py:352-495.
+
+Kept for iteration-level parity studies: upstream needs it because ogbl-* graphs do not fit its
+GPUs; here the full graph is a single batch (NodeembEngine).  The sampler's random stream
+cannot match PyG's (torch_sparse random_walk), so parity with upstream is statistical."""
+import os
+
+import torch
+import torch.nn as nn
+
+from ..graph_utils import negative_sampling
+from .base import _require_gpu, device
+
+
+class RandomWalkSubgraphSampler:
+    """Yields induced subgraphs over the nodes visited by `batch_size` random walks of length
+    `walk_length`; node- and edge-sized attributes are sliced like PyG's saint_subgraph."""
+
+    def __init__(self, data, batch_size, walk_length=2, num_steps=32, generator=None):
+        self.data, self.batch_size, self.walk_length, self.num_steps = data, batch_size, walk_length, num_steps
+        self.gen = generator
+        ei = data.edge_index
+        self.n = int(data.num_nodes)
+        order = torch.argsort(ei[0] * self.n + ei[1])
+        self.src_sorted, self.dst_sorted, self.order = ei[0][order], ei[1][order], order
+        counts = torch.bincount(self.src_sorted, minlength=self.n)
+        self.rowptr = torch.zeros(self.n + 1, dtype=torch.long)
+        self.rowptr[1:] = torch.cumsum(counts, 0)
+
+    def __len__(self):
+        return self.num_steps
+
+    def _walk(self):
+        cur = torch.randint(0, self.n, (self.batch_size,), generator=self.gen)
+        visited = [cur]
+        for _ in range(self.walk_length):
+            deg = self.rowptr[cur + 1] - self.rowptr[cur]
+            step = (torch.rand(cur.shape[0], generator=self.gen) * deg.clamp(min=1)).long()
+            nxt = self.dst_sorted[(self.rowptr[cur] + step).clamp(max=self.dst_sorted.numel() - 1)]
+            cur = torch.where(deg > 0, nxt, cur)
+            visited.append(cur)
+        return torch.cat(visited).unique()
+
+    def __iter__(self):
+        from ..data import Data
+        d = self.data
+        n_edges = d.edge_index.shape[1]
+        for _ in range(self.num_steps):
+            nodes = self._walk()
+            member = torch.zeros(self.n, dtype=torch.bool)
+            member[nodes] = True
+            emask = member[d.edge_index[0]] & member[d.edge_index[1]]
+            relabel = torch.full((self.n,), -1, dtype=torch.long)
+            relabel[nodes] = torch.arange(nodes.numel())
+            batch = Data(num_nodes=int(nodes.numel()), edge_index=relabel[d.edge_index[:, emask]], node_id=nodes)
+            for key, val in d.items():
+                if not torch.is_tensor(val) or key in ('edge_index', 'node_id'):
+                    continue
+                if val.dim() >= 1 and val.shape[0] == self.n:
+                    batch[key] = val[nodes]
+                elif val.dim() == 1 and val.shape[0] == n_edges:
+                    batch[key] = val[emask]
+            yield batch
+
+
+def train_minibatch(trainer, model, data, optimizer, args):
+    """gnndelete_nodeemb.py:352-495: per batch, original embeddings on all batch edges, Del forward
+    on the batch's S_Df edges with per-batch masks, fresh negatives, layer-wise update."""
+    from .gnndelete_nodeemb import _four_terms, _non_df_masks
+    _require_gpu()
+    loss_fct = nn.MSELoss()
+    data = data.to('cpu')
+    _non_df_masks(data)
+    data.edge_index = data.train_pos_edge_index
+    data.node_id = torch.arange(data.x.shape[0])
+    loader = RandomWalkSubgraphSampler(data, batch_size=args.batch_size, walk_length=2, num_steps=args.num_steps)
+    model = model.to(device)
+    best_metric = 0
+    for epoch in range(args.epochs):
+        model.train()
+        sums = {'loss': 0.0, 'loss_l': 0.0, 'loss_r': 0.0}
+        steps = 0
+        for batch in loader:
+            batch = batch.to(device)
+            with torch.no_grad():
+                z1_ori, z2_ori = model.get_original_embeddings(batch.x, batch.edge_index, return_all_emb=True)
+            z1, z2 = model(batch.x, batch.edge_index[:, batch.sdf_mask].contiguous(), batch.sdf_node_1hop_mask,
+                           batch.sdf_node_2hop_mask, return_all_emb=True)
+            pos_edge = batch.edge_index[:, batch.df_mask]
+            neg_edge = negative_sampling(batch.edge_index, batch.x.shape[0], pos_edge.shape[1])
+            r1, r2, l1, l2 = _four_terms(loss_fct, z1, z2, z1_ori, z2_ori, pos_edge, neg_edge,
+                                         batch.sdf_node_1hop_mask_non_df_mask, batch.sdf_node_2hop_mask_non_df_mask)
+            loss1 = trainer.args.alpha * r1 + (1 - trainer.args.alpha) * l1
+            loss1.backward(retain_graph=True)
+            optimizer[0].step()
+            optimizer[0].zero_grad()
+            loss2 = trainer.args.alpha * r2 + (1 - trainer.args.alpha) * l2
+            loss2.backward(retain_graph=True)
+            optimizer[1].step()
+            optimizer[1].zero_grad()
+            sums['loss'] += (loss1 + loss2).item()
+            sums['loss_l'] += (l1 + l2).item()
+            sums['loss_r'] += (r1 + r2).item()
+            steps += 1
+        if (epoch + 1) % args.valid_freq == 0:
+            valid_loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, _, valid_log = trainer.eval(model, data, 'val')
+            denom = max(steps - 1, 1)          # upstream divides by the last enumerate index
+            train_log = {'epoch': epoch, 'train_loss': sums['loss'] / denom, 'train_loss_l': sums['loss_l'] / denom,
+                         'train_loss_r': sums['loss_r'] / denom}
+            trainer._record(train_log, valid_log)
+            if dt_auc + df_auc > best_metric:
+                best_metric = dt_auc + df_auc
+                torch.save({'model_state': model.state_dict()}, os.path.join(args.checkpoint_dir, 'model_best.pt'))
+            data = data.to('cpu')
+    torch.save({'model_state': {k: v.to('cpu') for k, v in model.state_dict().items()}},
+               os.path.join(args.checkpoint_dir, 'model_final.pt'))

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Write the datasets the CLIs read: <data_dir>/<name>/d_<seed>.pt (the Data dict: x, num_nodes,
+num_features, train_pos_edge_index as directed row<col edges, val/test pos/neg edges) and
+df_<seed>.pt ({'in': mask, 'out': mask} over the train edges) - the content of the reference's
+d_<seed>.pkl / df_<seed>.pt (prepare_dataset.py:186-264), as plain tensors instead of pickled
+torch_geometric objects.  No real dataset can be downloaded here, so `--dataset` names one of
+the seeded synthetic stand-ins of gnndelete_amd.framework.synth (same shapes as the originals).
+
+  python prepare_dataset.py --dataset synth-dblp --seeds 42 21 13 87 100"""
+import argparse
+import os
+
+import torch
+
+from gnndelete_amd.framework.synth import SHAPES, make_linkpred_dataset
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('--dataset', default='synth-dblp', choices=sorted(SHAPES))
+    p.add_argument('--data_dir', default='./data')
+    p.add_argument('--seeds', type=int, nargs='+', default=[42, 21, 13, 87, 100])
+    a = p.parse_args()
+    out = os.path.join(a.data_dir, a.dataset)
+    os.makedirs(out, exist_ok=True)
+    for seed in a.seeds:
+        data, df = make_linkpred_dataset(a.dataset, seed=seed)
+        data.save(os.path.join(out, f'd_{seed}.pt'))
+        torch.save(df, os.path.join(out, f'df_{seed}.pt'))
+        print(seed, data, {k: int(v.sum()) for k, v in df.items()})
+
+
+if __name__ == '__main__':
+    main()

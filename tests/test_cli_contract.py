@@ -1,0 +1,43 @@
+"""framework.training_args vs the reference's own parse_args (tests/golden/parse_args.json),
+factories and registry names.  CPU only."""
+import json
+import os
+from types import SimpleNamespace
+
+import pytest
+
+from helpers import GOLDEN
+from gnndelete_amd.framework import get_model, get_trainer
+from gnndelete_amd.framework.training_args import build_parser, apply_overrides
+
+with open(os.path.join(GOLDEN, 'parse_args.json')) as f:
+    CASES = json.load(f)
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_parse_args_matches_reference(name):
+    case = CASES[name]
+    got = vars(apply_overrides(build_parser(extra=False).parse_args(case['argv'])))
+    assert got == case['args']
+
+
+def test_extra_flags_do_not_disturb_reference_defaults():
+    got = vars(apply_overrides(build_parser().parse_args([])))
+    for k, v in CASES['default']['args'].items():
+        assert got[k] == v
+    assert got['minibatch'] is False and got['no_fused_step'] is False
+
+
+def test_factories_and_registry():
+    a = SimpleNamespace(unlearning_model='gnndelete_nodeemb', gnn='gcn', in_dim=8, hidden_dim=16, out_dim=8)
+    assert type(get_model(a)).__name__ == 'GCNDelete'
+    a.gnn = 'rgcn'
+    assert type(get_model(a, num_nodes=5, num_edge_type=3)).__name__ == 'RGCNDelete'
+    a.unlearning_model, a.gnn = 'original', 'gat'
+    assert type(get_model(a)).__name__ == 'GAT'
+    a.gnn = 'rgat'
+    with pytest.raises(NotImplementedError):
+        get_model(a)
+    a.gnn, a.unlearning_model = 'gcn', 'graph_eraser'
+    with pytest.raises(NotImplementedError, match='out of scope'):
+        get_trainer(a)

@@ -1,0 +1,76 @@
+"""End-to-end run of the CLI scripts on the GPU (prepare -> train original -> unlearn -> test),
+and the HIP trainer's eval against the values the reference's Trainer.eval produced (golden)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import hip_model, load_golden, split_fixture, t
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd, cwd):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable] + cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_trainer_eval_matches_reference_golden(tmp_path):
+    from types import SimpleNamespace
+    from gnndelete_amd.framework.data import Data
+    from gnndelete_amd.framework.trainer.gnndelete_nodeemb import GNNDeleteNodeembTrainer
+    fx = load_golden('eval.npz')
+    state, data, rest = split_fixture(fx)
+    m = hip_model('gat', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    args = SimpleNamespace(unlearning_model='gnndelete_nodeemb', dataset='Cora', checkpoint_dir=str(tmp_path),
+                           eval_on_cpu=False)
+    tr = GNNDeleteNodeembTrainer(args)
+    torch.manual_seed(int(rest['eval_seed']))
+    loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, _, log = tr.eval(m, Data(data), 'val')
+    assert torch.equal(torch.stack(tr.df_pos_edge), t(rest['df_pos_masks']))
+    assert abs(loss - float(rest['val_loss'])) < 1e-5
+    assert abs(dt_auc - float(rest['val_dt_auc'])) < 2e-3 and abs(df_auc - float(rest['val_df_auc'])) < 2e-3
+    np.testing.assert_allclose(np.array(df_logit), rest['val_df_logit'], rtol=1e-4)
+    torch.save({'model_state': m.state_dict()}, os.path.join(str(tmp_path), 'model_best.pt'))
+    out = tr.test(m, Data(data))
+    assert abs(out[1] - float(rest['test_dt_auc'])) < 2e-3 and abs(out[3] - float(rest['test_df_auc'])) < 2e-3
+    assert abs(tr.trainer_log['auc_sum'] - float(rest['test_auc_sum'])) < 4e-3
+    tr.save_log()
+    assert os.path.exists(os.path.join(str(tmp_path), 'trainer_log.json'))
+
+
+@pytest.mark.parametrize('gnn,method,loss_type', [('gcn', 'gnndelete_nodeemb', 'both_layerwise'),
+                                                  ('gat', 'gnndelete_nodeemb', 'both_all'),
+                                                  ('gin', 'gnndelete', 'both_layerwise')])
+def test_cli_pipeline(tmp_path, gnn, method, loss_type):
+    cwd = str(tmp_path)
+    run([os.path.join(ROOT, 'prepare_dataset.py'), '--dataset', 'synth-tiny', '--seeds', '42'], cwd)
+    common = ['--dataset', 'synth-tiny', '--gnn', gnn, '--random_seed', '42']
+    run([os.path.join(ROOT, 'train_gnn.py')] + common + ['--epochs', '30', '--valid_freq', '10'], cwd)
+    orig = os.path.join(cwd, 'checkpoint', 'synth-tiny', gnn, 'original', '42')
+    # upstream forces 2000 epochs for the original model; the files must exist either way
+    assert os.path.exists(os.path.join(orig, 'model_best.pt')) and os.path.exists(os.path.join(orig, 'pred_proba.pt'))
+    run([os.path.join(ROOT, 'delete_gnn.py')] + common + ['--unlearning_model', method, '--df', 'in', '--df_size', '5',
+                                                          '--epochs', '40', '--valid_freq', '20', '--loss_type', loss_type], cwd)
+    if 'nodeemb' in method:
+        out = os.path.join(cwd, 'checkpoint', 'synth-tiny', gnn, method, f'mse_mean-{loss_type}-0.5-non_connected',
+                           'in-5.0-42')
+    else:
+        out = os.path.join(cwd, 'checkpoint', 'synth-tiny', gnn, method, f'mse_mean-{loss_type}-0.5-non_connected',
+                           'in-5.0-42')
+    with open(os.path.join(out, 'trainer_log.json')) as f:
+        log = json.load(f)
+    for key in ['dt_auc', 'df_auc', 'auc_sum', 'auc_gap', 'df_logit', 'log']:
+        assert key in log, key
+    assert 0.0 <= log['dt_auc'] <= 1.0 and len(log['log']) >= 2
+    for name in ['model_best.pt', 'model_final.pt', 'training_args.json', 'pred_proba.pt']:
+        assert os.path.exists(os.path.join(out, name)), name
+    state = torch.load(os.path.join(out, 'model_final.pt'))['model_state']
+    assert not torch.allclose(state['deletion2.deletion_weight'], torch.full_like(state['deletion2.deletion_weight'], 1e-3))
