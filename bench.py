@@ -38,6 +38,9 @@ def parse():
     p.add_argument('--cpu_baseline_iters', type=int, default=3)
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_graph', action='store_true')
+    p.add_argument('--parallel', default='partition', choices=['partition', 'replicas'],
+                   help='N>1: row-partition ONE request over the GPUs (RCCL all-gather + all-reduce, strong '
+                        'scaling) or run N independent requests (no exchange, weak scaling)')
     return p.parse_args()
 
 
@@ -64,7 +67,7 @@ def build_request(args, device):
     return data, model, neg, ni1, ni2
 
 
-def make_engine(args, data, model, neg, ni1, ni2, device):
+def make_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1):
     from gnndelete_amd.engine import NodeembEngine
     model = model.to(device)
     x = data.x.to(device)
@@ -73,9 +76,13 @@ def make_engine(args, data, model, neg, ni1, ni2, device):
     e_dr = E[:, data.dr_mask.to(device)].contiguous()
     with torch.no_grad():
         z1o, z2o = model.get_original_embeddings(x, e_dr, return_all_emb=True)
-    eng = NodeembEngine(model, x, e_sdf, z1o, z2o, E[:, data.df_mask.to(device)], neg.to(device), ni1, ni2,
-                        loss_type=args.loss_type, alpha=0.5, lr=1e-3, use_graph=not args.no_graph)
-    return eng
+    common = (model, x, e_sdf, z1o, z2o, E[:, data.df_mask.to(device)], neg.to(device), ni1, ni2)
+    if world > 1 and args.parallel == 'partition':
+        # ONE request, rows partitioned over the ranks (strong scaling)
+        from gnndelete_amd.dist_engine import PartitionedNodeembEngine
+        return PartitionedNodeembEngine(*common, rank, world, loss_type=args.loss_type, alpha=0.5, lr=1e-3,
+                                        use_graph=not args.no_graph)
+    return NodeembEngine(*common, loss_type=args.loss_type, alpha=0.5, lr=1e-3, use_graph=not args.no_graph)
 
 
 def spmm_algorithmic_bytes(n, nnz, d):
@@ -93,8 +100,11 @@ def time_dominant_kernel(eng, reps=20):
     y = torch.empty_like(t1)
     bias = eng.model.conv1.bias if hasattr(eng.model.conv1, 'bias') else None
 
+    from gnndelete_amd import ops
+    plan = getattr(eng, 'plan', None) or g.plan          # a rank's own rows when partitioned
+
     def launch():
-        eng._spmm(False, g.val, t1, y, bias, 0.0)
+        ops._spmm_raw(g.rowptr, g.col, g.val, t1, bias, 0.0, eng.n, plan, out=y)
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
@@ -105,7 +115,9 @@ def time_dominant_kernel(eng, reps=20):
     e1.record()
     torch.cuda.synchronize()
     dur_s = e0.elapsed_time(e1) / 1e3 / reps
-    return dur_s, spmm_algorithmic_bytes(eng.n, g.nnz, h)
+    rows = plan.n_items - plan.n_slots + plan.n_split      # rows this launch produces
+    frac = rows / max(1, eng.n)
+    return dur_s, int(spmm_algorithmic_bytes(eng.n, g.nnz, h) * frac) if frac < 0.999 else spmm_algorithmic_bytes(eng.n, g.nnz, h)
 
 
 def cpu_baseline(args, data, model_state, neg, iters):
@@ -145,15 +157,22 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    # GD_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a one-GPU box (all ranks on cuda:0)
+    backend = os.environ.get('GD_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl' and torch.cuda.device_count() < world:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     data, model, neg, ni1, ni2 = build_request(args, device)
     state = {k: v.clone() for k, v in model.state_dict().items()}
-    eng = make_engine(args, data, model, neg, ni1, ni2, device)
+    eng = make_engine(args, data, model, neg, ni1, ni2, device, rank, world)
 
     for _ in range(args.warmup):
         eng.step()
@@ -173,13 +192,15 @@ def main():
         dt = float(tmax)
     losses = eng.loss_history()
 
+    partitioned = world > 1 and args.parallel == 'partition'
+    units = args.steps if partitioned else world * args.steps      # iterations of whole requests
     if rank == 0:
         kdur, kbytes = time_dominant_kernel(eng)
         achieved = kbytes / kdur / 1e9
         out = {
-            'metric': 'Del-op train iters/sec', 'value': world * args.steps / dt, 'unit': 'iters/s',
+            'metric': 'Del-op train iters/sec', 'value': units / dt, 'unit': 'iters/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong' if partitioned else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.workload} {args.gnn.upper()} 2-layer, {args.df_size}% {args.df.upper()} '
                                    f'edge deletion, full-graph Del step ({args.loss_type}, mse_mean)',
                        'num_nodes': data.num_nodes, 'in_dim': int(data.x.shape[1]), 'hidden_dim': 128, 'out_dim': 64,
@@ -187,8 +208,9 @@ def main():
                        'df_edges': int(data.directed_df_edge_index.shape[1]),
                        'sdf_edges': int(data.sdf_mask.sum()), 'spmm_nnz': eng.graph.nnz,
                        'S1': eng.s1, 'S2': eng.s2, 'hip_graph': not args.no_graph,
-                       'parallelism': 'single' if world == 1 else f'replicas{world}'},
-            'roofline': {'kernel': 'spmm_items_kernel<32,1> (layer-1 CSR SpMM, d=128)', 'bound': 'hbm',
+                       'parallelism': 'single' if world == 1 else (f'row-partition x{world} (RCCL all-gather + all-reduce)'
+                                                                  if partitioned else f'replicas x{world}')},
+            'roofline': {'kernel': 'spmm_persist_kernel<32,1,true> (layer-1 CSR SpMM, d=128)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': None, 'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6},
             'final_loss': float(losses[-1, 0]) if len(losses) else None,

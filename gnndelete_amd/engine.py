@@ -46,7 +46,9 @@ class _LayerTerms:
     (folded once in fp64).  If some row carries both kinds (never the case for the reference's
     masks, where NI rows exclude the Df endpoints) the general segmented kernel is used instead."""
 
-    def __init__(self, pos_edge, neg_edge, ni_mask, z_ori, coef_r, coef_l, reduction):
+    def __init__(self, pos_edge, neg_edge, ni_mask, z_ori, coef_r, coef_l, reduction, row_range=None):
+        """row_range=(lo, hi): keep only the terms whose z row lies in [lo, hi) (1-D row
+        partition); the mean normalisers stay the GLOBAL term counts."""
         device = z_ori.device
         d = z_ori.shape[1]
         pos, neg = pos_edge.to(device).long(), neg_edge.to(device).long()
@@ -60,8 +62,11 @@ class _LayerTerms:
         tgt = torch.cat([neg[0], neg[1], ni_rows])
         kind = torch.cat([torch.zeros(2 * m, dtype=torch.int32, device=device),
                           torch.ones(ni_rows.numel(), dtype=torch.int32, device=device)])
-        self.k_const = [0.0, 0.0]
         mixed = bool(ni_mask.to(device)[pos.flatten()].any()) if m else False
+        if row_range is not None:
+            mine = (rows >= row_range[0]) & (rows < row_range[1])
+            rows, tgt, kind = rows[mine], tgt[mine], kind[mine]
+        self.k_const = [0.0, 0.0]
         self.folded = not mixed
         if self.folded:
             uniq, inv, c = torch.unique(rows, return_inverse=True, return_counts=True)
@@ -81,8 +86,7 @@ class _LayerTerms:
             self.kind = kind_u
             ws = _lib.lib().gd_rowtarget_mse_workspace(self.n_rows)
         else:
-            w = torch.cat([torch.full((2 * m,), w_r, dtype=torch.float32, device=device),
-                           torch.full((ni_rows.numel(),), w_l, dtype=torch.float32, device=device)])
+            w = torch.where(kind == 0, w_r, w_l).float()
             order = torch.argsort(rows, stable=True)
             rows, tgt, kind, w = rows[order], tgt[order], kind[order], w[order]
             seg_row, counts = torch.unique_consecutive(rows, return_counts=True)

@@ -1,0 +1,31 @@
+"""world_size-2 (and 3) runs over gloo on CPU: collectives, row-partition planner and the
+algebra of the partitioned Del step (dense emulation) vs single-process autograd."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def launch(mode, world, timeout=600):
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS='2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
+           '--master-addr', '127.0.0.1', '--master-port', str(29500 + world + (7 if mode == 'gpu' else 0)),
+           os.path.join(ROOT, 'tests', 'dist_worker.py'), mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and 'DIST_OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_partitioned_step_algebra_and_collectives_over_gloo(world):
+    launch('cpu', world)
+
+
+@pytest.mark.gpu
+def test_partitioned_engine_matches_single_gpu_engine():
+    """Two ranks sharing cuda:0 over gloo (the box has one GPU): the real HIP engine."""
+    out = launch('gpu', 2, timeout=900)
+    assert out.count('partitioned == single') == 3
