@@ -207,7 +207,7 @@ def main():
                        'train_edges_undirected': int(data.train_pos_edge_index.shape[1]),
                        'df_edges': int(data.directed_df_edge_index.shape[1]),
                        'sdf_edges': int(data.sdf_mask.sum()), 'spmm_nnz': eng.graph.nnz,
-                       'S1': eng.s1, 'S2': eng.s2, 'hip_graph': not args.no_graph,
+                       'S1': int(data.sdf_node_1hop_mask.sum()), 'S2': int(data.sdf_node_2hop_mask.sum()), 'hip_graph': not args.no_graph,
                        'parallelism': 'single' if world == 1 else (f'row-partition x{world} (RCCL all-gather + all-reduce)'
                                                                   if partitioned else f'replicas x{world}')},
             'roofline': {'kernel': 'spmm_persist_kernel<32,1,true> (layer-1 CSR SpMM, d=128)', 'bound': 'hbm',

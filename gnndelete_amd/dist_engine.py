@@ -231,7 +231,8 @@ class PartitionedNodeembEngine:
         with torch.no_grad():
             for seg in self._segments():
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: the RCCL watchdog thread must not invalidate the capture
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     seg()
                 graphs.append(g)
         for t, s in zip(self._mutable_state(), saved):
