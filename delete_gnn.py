@@ -27,7 +27,8 @@ def build_optimizer(model, args):
     if 'gnndelete' in args.unlearning_model:
         dels = [p for n, p in model.named_parameters() if 'del' in n]
         print('parameters_to_optimize', [n for n, p in model.named_parameters() if 'del' in n])
-        if 'nodeemb' in args.unlearning_model and 'layerwise' in args.loss_type:
+        relational = args.gnn in ['rgcn', 'rgat']
+        if ('nodeemb' in args.unlearning_model or relational) and 'layerwise' in args.loss_type:
             return [torch.optim.Adam(model.deletion1.parameters(), lr=args.lr),
                     torch.optim.Adam(model.deletion2.parameters(), lr=args.lr)]
         return torch.optim.Adam([{'params': dels, 'weight_decay': 0.0}], lr=args.lr)

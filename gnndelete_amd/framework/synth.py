@@ -14,6 +14,7 @@ import torch
 
 from .data import Data
 from .graph_utils import k_hop_subgraph, negative_sampling
+from .utils import negative_sampling_kg
 
 # name -> (num_nodes, num_features, unique row<col edges, feature style)
 SHAPES = {
@@ -88,4 +89,39 @@ def make_linkpred_dataset(name='synth-collab', seed=42, val_ratio=0.05, test_rat
                 test_neg_edge_index=negative_sampling(test_pos, n, n_t, generator=gen),
                 val_neg_edge_index=negative_sampling(val_pos, n, n_v, generator=gen))
     _, _, _, local = k_hop_subgraph(test_pos.flatten().unique(), 2, train, num_nodes=n)
+    return data, {'in': local, 'out': ~local}
+
+
+# name -> (num_nodes, num_relations, unique triples)
+KG_SHAPES = {
+    'synth-kg-tiny': (500, 4, 3000),
+    'synth-wn18': (40943, 18, 151442),
+    'synth-biokg': (93773, 51, 4762678),
+}
+
+
+def make_kg_dataset(name='synth-kg-tiny', seed=42, val_ratio=0.05, test_ratio=0.05, shape=None):
+    """Knowledge-graph stand-in in the layout prepare_dataset.py:266-399 writes: x = arange(N)
+    (entity ids for the embedding table), directed train triples (head < tail) with relation
+    types whose sizes follow a Zipf law, val / test triples with per-relation head-shuffled
+    negatives (framework/utils.py:46-58), and the IN / OUT Df candidate masks."""
+    n, r, m = shape if shape is not None else KG_SHAPES[name]
+    gen = torch.Generator().manual_seed(seed)
+    edges, _ = dcsbm_edges(n, m, seed, comm_size=64, p_in=0.6)
+    m = edges.shape[1]
+    w = 1.0 / torch.arange(1, r + 1, dtype=torch.float64)
+    rel = torch.searchsorted(torch.cumsum(w / w.sum(), 0), torch.rand(m, generator=gen, dtype=torch.float64)).clamp(max=r - 1)
+    perm = torch.randperm(m, generator=gen)
+    edges, rel = edges[:, perm], rel[perm]
+    n_v, n_t = int(math.floor(val_ratio * m)), int(math.floor(test_ratio * m))
+    state = torch.get_rng_state()
+    torch.manual_seed(seed)
+    data = Data(x=torch.arange(n), num_nodes=n, num_features=0,
+                train_pos_edge_index=edges[:, n_t + n_v:], train_edge_type=rel[n_t + n_v:],
+                test_pos_edge_index=edges[:, :n_t], test_edge_type=rel[:n_t],
+                val_pos_edge_index=edges[:, n_t:n_t + n_v], val_edge_type=rel[n_t:n_t + n_v])
+    data.test_neg_edge_index = negative_sampling_kg(data.test_pos_edge_index, data.test_edge_type)
+    data.val_neg_edge_index = negative_sampling_kg(data.val_pos_edge_index, data.val_edge_type)
+    torch.set_rng_state(state)
+    _, _, _, local = k_hop_subgraph(data.test_pos_edge_index.flatten().unique(), 2, data.train_pos_edge_index, num_nodes=n)
     return data, {'in': local, 'out': ~local}

@@ -1,0 +1,167 @@
+"""Knowledge-graph trainers for the R-GCN path (reference: KGTrainer base.py:394-692,
+KGGNNDeleteNodeembTrainer gnndelete_nodeemb.py:659-846).  Mini-batches of random-walk subgraphs
+(.sampler), message passing on the relation-typed HIP kernels (per-relation mean + block-diagonal /
+dense relation weights), DistMult decoder, per-relation head-shuffled negatives."""
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from sklearn.metrics import average_precision_score, roc_auc_score
+
+from ..evaluation import verification_error
+from ..utils import get_link_labels, negative_sampling_kg
+from .base import Trainer, _require_gpu, device
+from .gnndelete_nodeemb import _four_terms, _non_df_masks, get_loss_fct
+from .sampler import RandomWalkSubgraphSampler
+
+
+class KGTrainer(Trainer):
+    def train(self, model, data, optimizer, args):
+        """BCE link prediction with DistMult on random-walk subgraphs of 128 roots (base.py:394-493);
+        only forward-direction relation types are decoded; model selection on validation AUP."""
+        _require_gpu()
+        model = model.to(device)
+        data = data.to('cpu')
+        loader = RandomWalkSubgraphSampler(data, batch_size=128, walk_length=2, num_steps=args.num_steps)
+        best_metric, best_epoch = 0, 0
+        start = time.time()
+        for epoch in range(args.epochs):
+            model.train()
+            epoch_loss, steps = 0.0, 0
+            for batch in loader:
+                batch = batch.to(device)
+                edge_index, edge_type = batch.edge_index, batch.edge_type
+                z = model(batch.x, edge_index, edge_type)
+                decoding = edge_type < args.num_edge_type
+                dec_index, dec_type = edge_index[:, decoding], edge_type[decoding]
+                neg_index = negative_sampling_kg(edge_index=dec_index, edge_type=dec_type)
+                logits = torch.cat([model.decode(z, dec_index, dec_type), model.decode(z, neg_index, dec_type)], dim=-1)
+                loss = F.binary_cross_entropy_with_logits(logits, get_link_labels(dec_index, neg_index))
+                loss.backward()
+                optimizer.step()
+                optimizer.zero_grad()
+                epoch_loss += loss.item()
+                steps += 1
+            if (epoch + 1) % args.valid_freq == 0:
+                valid_loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, _, valid_log = self.eval(model, data, 'val')
+                self._record({'epoch': epoch, 'train_loss': epoch_loss / max(steps - 1, 1)}, valid_log)
+                if dt_aup > best_metric:
+                    best_metric, best_epoch = dt_aup, epoch
+                    print(f'Save best checkpoint at epoch {epoch:04d}. Valid loss = {valid_loss:.4f}')
+                    torch.save({'model_state': model.state_dict(), 'optimizer_state': optimizer.state_dict()},
+                               os.path.join(args.checkpoint_dir, 'model_best.pt'))
+        self.trainer_log['training_time'] = time.time() - start
+        torch.save({'model_state': model.state_dict(), 'optimizer_state': optimizer.state_dict()},
+                   os.path.join(args.checkpoint_dir, 'model_final.pt'))
+        self.trainer_log['best_epoch'], self.trainer_log['best_metric'] = best_epoch, best_metric
+
+    @torch.no_grad()
+    def eval(self, model, data, stage='val', pred_all=False):
+        """KGTrainer.eval (base.py:495-567): full-graph message passing on Dr, DistMult scores
+        WITHOUT sigmoid for the Dt metrics, 500 fresh Dr subsets per call for the Df metrics."""
+        _require_gpu()
+        model.eval()
+        model = model.to(device)
+        data = data.to(device)
+        pos, neg = data[f'{stage}_pos_edge_index'], data[f'{stage}_neg_edge_index']
+        etype = data[f'{stage}_edge_type']
+        z = model(data.x, data.edge_index[:, data.dr_mask].contiguous(), data.edge_type[data.dr_mask].contiguous())
+        logits = model.decode(z, torch.cat([pos, neg], dim=-1), torch.cat([etype, etype], dim=-1))
+        label = get_link_labels(pos, neg)
+        loss = F.binary_cross_entropy_with_logits(logits, label).cpu().item()
+        dt_auc = roc_auc_score(label.cpu(), logits.cpu())
+        dt_aup = average_precision_score(label.cpu(), logits.cpu())
+
+        if self.args.unlearning_model in ['original']:
+            df_logit = []
+        else:
+            df_logit = model.decode(z, data.directed_df_edge_index, data.directed_df_edge_type).sigmoid().tolist()
+        if len(df_logit) > 0:
+            half = data.dr_mask[:data.dr_mask.shape[0] // 2]
+            dr_edges, dr_types = data.train_pos_edge_index[:, half], data.train_edge_type[half]
+            dr_score = model.decode(z, dr_edges, dr_types).sigmoid().cpu()
+            labels = [0] * len(df_logit) + [1] * len(df_logit)
+            df_auc, df_aup = [], []
+            for _ in range(500):
+                pick = torch.randperm(dr_edges.shape[1])[:len(df_logit)].sort().values
+                scores = df_logit + dr_score[pick].tolist()
+                df_auc.append(roc_auc_score(labels, scores))
+                df_aup.append(average_precision_score(labels, scores))
+            df_auc, df_aup = np.mean(df_auc), np.mean(df_aup)
+        else:
+            df_auc = df_aup = np.nan
+        logit_all_pair = (z @ z.t()).cpu() if pred_all else None
+        log = {f'{stage}_loss': loss, f'{stage}_dt_auc': dt_auc, f'{stage}_dt_aup': dt_aup, f'{stage}_df_auc': df_auc,
+               f'{stage}_df_aup': df_aup,
+               f'{stage}_df_logit_mean': np.mean(df_logit) if len(df_logit) > 0 else np.nan,
+               f'{stage}_df_logit_std': np.std(df_logit) if len(df_logit) > 0 else np.nan}
+        return loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, logit_all_pair, log
+
+    @torch.no_grad()
+    def test(self, model, data, model_retrain=None, attack_model_all=None, attack_model_sub=None, ckpt='best'):
+        if ckpt == 'best':
+            state = torch.load(os.path.join(self.args.checkpoint_dir, 'model_best.pt'), map_location='cpu')
+            model.load_state_dict(state['model_state'])
+        loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, logit_all_pair, test_log = self.eval(model, data, 'test', False)
+        self.logit_all_pair = logit_all_pair
+        self.trainer_log.update({'dt_loss': loss, 'dt_auc': dt_auc, 'dt_aup': dt_aup, 'df_logit': df_logit,
+                                 'df_auc': df_auc, 'df_aup': df_aup, 'auc_sum': dt_auc + df_auc,
+                                 'aup_sum': dt_aup + df_aup, 'auc_gap': abs(dt_auc - df_auc),
+                                 'aup_gap': abs(dt_aup - df_aup)})
+        if model_retrain is not None:
+            self.trainer_log['ve'] = verification_error(model, model_retrain).cpu().item()
+        return loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, logit_all_pair, test_log
+
+
+class KGGNNDeleteNodeembTrainer(KGTrainer):
+    def train(self, model, data, optimizer, args, logits_ori=None, attack_model_all=None, attack_model_sub=None):
+        """gnndelete_nodeemb.py:659-846: per batch, message passing on the batch's Dr edges with the
+        S_Df-minus-Df node masks as Del masks, DEC on the forward-direction Df triples vs
+        per-relation head-shuffled negatives, NI on the masked nodes, layer-wise update."""
+        _require_gpu()
+        loss_fct = get_loss_fct(self.args.loss_fct)
+        model = model.to(device)
+        data = data.to('cpu')
+        _non_df_masks(data)
+        loader = RandomWalkSubgraphSampler(data, batch_size=args.batch_size, walk_length=2, num_steps=args.num_steps)
+        best_metric = 0
+        alpha = self.args.alpha
+        for epoch in range(args.epochs):
+            model.train()
+            last = None
+            for batch in loader:
+                batch = batch.to(device)
+                edge_index = batch.edge_index[:, batch.dr_mask].contiguous()
+                edge_type = batch.edge_type[batch.dr_mask].contiguous()
+                m1, m2 = batch.sdf_node_1hop_mask_non_df_mask, batch.sdf_node_2hop_mask_non_df_mask
+                z1, z2 = model(batch.x, edge_index, edge_type, m1, m2, return_all_emb=True)
+                with torch.no_grad():
+                    z1_ori, z2_ori = model.get_original_embeddings(batch.x, edge_index, edge_type, return_all_emb=True)
+                pos_index, pos_type = batch.edge_index[:, batch.df_mask], batch.edge_type[batch.df_mask]
+                forward = pos_type < self.args.num_edge_type
+                dec_index, dec_type = pos_index[:, forward], pos_type[forward]
+                neg_index = negative_sampling_kg(edge_index=dec_index, edge_type=dec_type)
+                r1, r2, l1, l2 = _four_terms(loss_fct, z1, z2, z1_ori, z2_ori, dec_index, neg_index, m1, m2)
+                loss1 = alpha * r1 + (1 - alpha) * l1
+                loss1.backward(retain_graph=True)
+                optimizer[0].step()
+                optimizer[0].zero_grad()
+                loss2 = alpha * r2 + (1 - alpha) * l2
+                loss2.backward(retain_graph=True)
+                optimizer[1].step()
+                optimizer[1].zero_grad()
+                last = (loss1 + loss2, r1 + r2, l1 + l2)
+            if (epoch + 1) % self.args.valid_freq == 0 and last is not None:
+                valid_loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, _, valid_log = self.eval(model, data, 'val')
+                valid_log['epoch'] = epoch
+                self._record({'epoch': epoch, 'train_loss': last[0].item(), 'loss_r': last[1].item(),
+                              'loss_l': last[2].item()}, valid_log)
+                if dt_auc + df_auc > best_metric:
+                    best_metric = dt_auc + df_auc
+                    print(f'Save best checkpoint at epoch {epoch:04d}. Valid loss = {valid_loss:.4f}')
+                    torch.save({'model_state': model.state_dict()}, os.path.join(args.checkpoint_dir, 'model_best.pt'))
+                data = data.to('cpu')
+        torch.save({'model_state': {k: v.to('cpu') for k, v in model.state_dict().items()}},
+                   os.path.join(args.checkpoint_dir, 'model_final.pt'))

@@ -6,7 +6,9 @@ reference's own parse_args by tests/golden/parse_args.json.  Flags added by this
 listed in EXTRA_FLAGS and never change a reference default."""
 import argparse
 
-num_edge_type_mapping = {'FB15k-237': 237, 'WordNet18': 18, 'WordNet18RR': 11, 'ogbl-biokg': 51}
+num_edge_type_mapping = {'FB15k-237': 237, 'WordNet18': 18, 'WordNet18RR': 11, 'ogbl-biokg': 51,
+                         # synthetic stand-ins written by prepare_dataset.py (same relation counts)
+                         'synth-kg-tiny': 4, 'synth-wn18': 18, 'synth-biokg': 51}
 
 # (name, type, default, help); type None = store_true switch
 FLAGS = [
@@ -111,5 +113,16 @@ def apply_overrides(args):
     return args
 
 
+def _test_knobs(args):
+    """GNNDELETE_FORCE_{EPOCHS,VALID_FREQ,NUM_STEPS}: applied AFTER the upstream overrides (which
+    replace --epochs for original / KG runs); used by the end-to-end tests to keep runs short."""
+    import os
+    for env, attr in [('GNNDELETE_FORCE_EPOCHS', 'epochs'), ('GNNDELETE_FORCE_VALID_FREQ', 'valid_freq'),
+                      ('GNNDELETE_FORCE_NUM_STEPS', 'num_steps')]:
+        if os.environ.get(env):
+            setattr(args, attr, int(os.environ[env]))
+    return args
+
+
 def parse_args(argv=None):
-    return apply_overrides(build_parser().parse_args(argv))
+    return _test_knobs(apply_overrides(build_parser().parse_args(argv)))

@@ -12,19 +12,20 @@ import os
 
 import torch
 
-from gnndelete_amd.framework.synth import SHAPES, make_linkpred_dataset
+from gnndelete_amd.framework.synth import KG_SHAPES, SHAPES, make_kg_dataset, make_linkpred_dataset
 
 
 def main():
     p = argparse.ArgumentParser()
-    p.add_argument('--dataset', default='synth-dblp', choices=sorted(SHAPES))
+    p.add_argument('--dataset', default='synth-dblp', choices=sorted(SHAPES) + sorted(KG_SHAPES))
     p.add_argument('--data_dir', default='./data')
     p.add_argument('--seeds', type=int, nargs='+', default=[42, 21, 13, 87, 100])
     a = p.parse_args()
     out = os.path.join(a.data_dir, a.dataset)
     os.makedirs(out, exist_ok=True)
     for seed in a.seeds:
-        data, df = make_linkpred_dataset(a.dataset, seed=seed)
+        make = make_kg_dataset if a.dataset in KG_SHAPES else make_linkpred_dataset
+        data, df = make(a.dataset, seed=seed)
         data.save(os.path.join(out, f'd_{seed}.pt'))
         torch.save(df, os.path.join(out, f'df_{seed}.pt'))
         print(seed, data, {k: int(v.sum()) for k, v in df.items()})

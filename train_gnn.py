@@ -30,10 +30,18 @@ def main():
         args.in_dim = data.num_features
     wandb_init(args)
 
-    data.train_pos_edge_index = to_undirected(data.train_pos_edge_index, num_nodes=data.num_nodes)
-    data.dtrain_mask = torch.ones(data.train_pos_edge_index.shape[1], dtype=torch.bool)
-    data.dr_mask = data.dtrain_mask
-    assert is_undirected(data.train_pos_edge_index, data.num_nodes)
+    if args.gnn in ['rgcn', 'rgat']:
+        # reverse edges carry relation type + R (train_gnn.py:46-56)
+        rev = data.train_pos_edge_index.flip(0)
+        data.edge_index = torch.cat([data.train_pos_edge_index, rev], dim=1)
+        data.edge_type = torch.cat([data.train_edge_type, data.train_edge_type + args.num_edge_type], dim=0)
+        data.dr_mask = torch.ones(data.edge_index.shape[1], dtype=torch.bool)
+        assert is_undirected(data.edge_index, data.num_nodes)
+    else:
+        data.train_pos_edge_index = to_undirected(data.train_pos_edge_index, num_nodes=data.num_nodes)
+        data.dtrain_mask = torch.ones(data.train_pos_edge_index.shape[1], dtype=torch.bool)
+        data.dr_mask = data.dtrain_mask
+        assert is_undirected(data.train_pos_edge_index, data.num_nodes)
     print('Undirected dataset:', data)
 
     model = get_model(args, num_nodes=data.num_nodes, num_edge_type=args.num_edge_type).to(device)
