@@ -125,3 +125,25 @@ def make_kg_dataset(name='synth-kg-tiny', seed=42, val_ratio=0.05, test_ratio=0.
     torch.set_rng_state(state)
     _, _, _, local = k_hop_subgraph(data.test_pos_edge_index.flatten().unique(), 2, data.train_pos_edge_index, num_nodes=n)
     return data, {'in': local, 'out': ~local}
+
+
+def make_nodecls_dataset(name='synth-dblp', seed=42, num_classes=4, shape=None):
+    """Node-classification stand-in for delete_node.py's CitationFull-DBLP + RandomNodeSplit
+    (delete_node.py:54-64): undirected edge_index, features, labels tied to the planted
+    communities, train_rest split with 500 validation and 1000 test nodes (scaled down for
+    graphs smaller than 3000 nodes)."""
+    n, f, m, style = shape if shape is not None else SHAPES[name]
+    gen = torch.Generator().manual_seed(seed)
+    edges, community = dcsbm_edges(n, m, seed)
+    x = _features(n, f, style, community, gen)
+    und = torch.cat([edges, edges.flip(0)], dim=1)
+    order = torch.argsort(und[0] * n + und[1])
+    y = community % num_classes
+    num_val, num_test = (500, 1000) if n >= 3000 else (n // 6, n // 3)
+    perm = torch.randperm(n, generator=gen)
+    val_mask = torch.zeros(n, dtype=torch.bool)
+    test_mask = torch.zeros(n, dtype=torch.bool)
+    val_mask[perm[:num_val]] = True
+    test_mask[perm[num_val:num_val + num_test]] = True
+    return Data(x=x, y=y, num_nodes=n, num_features=f, num_classes=num_classes, edge_index=und[:, order],
+                train_mask=~(val_mask | test_mask), val_mask=val_mask, test_mask=test_mask)

@@ -94,3 +94,48 @@ def test_cli_pipeline_knowledge_graph(tmp_path, monkeypatch):
     assert 0.0 <= log['dt_auc'] <= 1.0 and 0.0 <= log['df_auc'] <= 1.0
     state = torch.load(os.path.join(out, 'model_final.pt'))['model_state']
     assert 'node_emb.weight' in state and 'W' in state and state['conv1.weight'].shape[0] == 8
+
+
+@pytest.mark.parametrize('gnn', ['gat', 'gcn'])
+def test_cli_node_deletion(tmp_path, monkeypatch, gnn):
+    """delete_node.py: node unlearning with accuracy / F1 evaluation (out_dim = #classes = 4, so
+    the Del-2 GEMM takes the generic-dimension kernels)."""
+    cwd = str(tmp_path)
+    monkeypatch.setenv('GNNDELETE_FORCE_EPOCHS', '20')
+    monkeypatch.setenv('GNNDELETE_FORCE_VALID_FREQ', '10')
+    common = ['--dataset', 'synth-tiny', '--gnn', gnn, '--random_seed', '42']
+    run([os.path.join(ROOT, 'train_node.py')] + common, cwd)
+    run([os.path.join(ROOT, 'delete_node.py')] + common + ['--unlearning_model', 'gnndelete_nodeemb', '--df', 'in',
+                                                           '--df_size', '5'], cwd)
+    out = os.path.join(cwd, 'checkpoint_node', 'synth-tiny', gnn, 'gnndelete_nodeemb-node_deletion',
+                       'mse_mean-both_layerwise-0.5-non_connected', 'in-5.0-42')
+    with open(os.path.join(out, 'trainer_log.json')) as f:
+        log = json.load(f)
+    assert 0.0 <= log['dt_acc'] <= 1.0 and 'dt_f1' in log
+    state = torch.load(os.path.join(out, 'model_final.pt'))['model_state']
+    assert state['deletion2.deletion_weight'].shape == (4, 4)
+    assert not torch.allclose(state['deletion1.deletion_weight'], torch.full((128, 128), 1e-3))
+
+
+def test_minibatch_trainer_runs(tmp_path, monkeypatch):
+    """--minibatch: the GraphSAINT-style loop of gnndelete_nodeemb.py:352-495 (per-batch CSR,
+    per-batch mask overrides, autograd path)."""
+    cwd = str(tmp_path)
+    monkeypatch.setenv('GNNDELETE_FORCE_EPOCHS', '2')
+    monkeypatch.setenv('GNNDELETE_FORCE_VALID_FREQ', '2')
+    monkeypatch.setenv('GNNDELETE_FORCE_NUM_STEPS', '3')
+    data_dir = os.path.join(cwd, 'data', 'ogbl-synth')
+    os.makedirs(data_dir)
+    from gnndelete_amd.framework.synth import make_linkpred_dataset
+    data, df = make_linkpred_dataset(None, seed=42, shape=(800, 32, 4000, 'dense'))
+    data.save(os.path.join(data_dir, 'd_42.pt'))
+    torch.save(df, os.path.join(data_dir, 'df_42.pt'))
+    common = ['--dataset', 'ogbl-synth', '--gnn', 'gcn', '--random_seed', '42', '--batch_size', '200']
+    run([os.path.join(ROOT, 'train_gnn.py')] + common, cwd)
+    run([os.path.join(ROOT, 'delete_gnn.py')] + common + ['--unlearning_model', 'gnndelete_nodeemb', '--df', 'in',
+                                                          '--df_size', '5', '--minibatch'], cwd)
+    out = os.path.join(cwd, 'checkpoint', 'ogbl-synth', 'gcn', 'gnndelete_nodeemb', 'mse_mean-both_layerwise-0.5-non_connected',
+                       'in-5.0-42')
+    with open(os.path.join(out, 'trainer_log.json')) as f:
+        log = json.load(f)
+    assert 0.0 <= log['dt_auc'] <= 1.0
