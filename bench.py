@@ -150,6 +150,22 @@ def cpu_baseline(args, data, model_state, neg, iters):
                       f'({dt / iters:.2f} s each, torch CPU, {threads} threads)'}
 
 
+def recorded_traffic(n, nnz, d):
+    """HBM bytes per launch of the dominant kernel from the committed PMC run (separate rocprofv3
+    --pmc passes, gfx950 correction applied: profiles/r01_spmm_traffic.json); None when the
+    workload differs from the one that was profiled."""
+    path = os.path.join(ROOT, 'profiles', 'r01_spmm_traffic.json')
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        w = rec['workload']
+        if (w['num_nodes'], w['spmm_nnz'], w['d']) == (n, nnz, d):
+            return rec['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -212,7 +228,8 @@ def main():
                                                                   if partitioned else f'replicas x{world}')},
             'roofline': {'kernel': 'spmm_persist_kernel<32,1,true> (layer-1 CSR SpMM, d=128)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6},
+                         'traffic': recorded_traffic(data.num_nodes, eng.graph.nnz, 128) if world == 1 else None,
+                         'traffic_unit': 'bytes/launch (PMC, profiles/r01_spmm_traffic.json)', 'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6},
             'final_loss': float(losses[-1, 0]) if len(losses) else None,
         }
         if not args.no_cpu_baseline and world == 1:
