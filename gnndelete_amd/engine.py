@@ -194,6 +194,7 @@ class NodeembEngine:
         self.steps_done = 0
         self._graph = None
         self._use_graph = use_graph
+        self._side = torch.cuda.Stream(device=dev)
         self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat'}[type(conv2)]
         gmode = {'gcn': 'gcn', 'gin': 'sum', 'gat': 'gat'}[self._mode]
         self.graph = graph_for(edge_index, n, gmode)
@@ -297,50 +298,65 @@ class NodeembEngine:
 
     # ------------------------------------------------------------------ one iteration
     def _iteration(self):
-        m = self.model
+        """One training iteration.  The layer-1 loss, its weight gradient and (layer-wise types)
+        the W_D1 Adam step only depend on z1, so they run on a side stream concurrently with the
+        layer-2 forward (conv2, Del-2, layer-2 loss): memory-bound and MFMA-bound kernels overlap
+        and fill each other's tails.  Inside the hipGraph this is a fork/join of two branches."""
+        lt = self.loss_type
+        main = torch.cuda.current_stream()
+        side = self._side
         with torch.no_grad():
-            # ---- forward
+            # ---- forward, layer 1
             self._conv1_forward()
             ops.rows_gemm(self.z1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1)
+            self.sums.zero_()
+            # ---- fork: layer-1 loss branch
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.t1.launch(self.z1, self.dz1, self.sums[0:2])
+                if lt in ('both_layerwise', 'both_all'):
+                    self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, True, self.ws1)
+                elif lt == 'only1':
+                    self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, False, self.ws1)
+                if lt in ('both_layerwise', 'only1'):
+                    self.adam1.apply(self.g1)
+            # ---- main: forward layer 2 + its loss
             self._conv2_forward()
             ops.rows_gemm(self.z2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
-            # ---- losses (value + dz)
-            self.sums.zero_()
-            self.t1.launch(self.z1, self.dz1, self.sums[0:2])
             self.t2.launch(self.z2, self.dz2, self.sums[2:4])
-            self.hist.index_copy_(0, self.hist_pos, self.sums[None])
-            self.hist_pos.add_(1).remainder_(self.hist.shape[0])
-            # ---- backward + update
-            lt = self.loss_type
+            # ---- backward + update (the layer-2 path joins before it touches g1 / W_D1 state)
             if lt == 'both_layerwise':
-                self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, True, self.ws1)
-                self.adam1.apply(self.g1)
-                self._layer2_backward(g1_accumulate=False)       # g1 = zero_grad() + loss2 path (carry-over)
+                self._layer2_backward(g1_accumulate=False, join=side)   # g1 = zero_grad() + loss2 path (carry-over)
                 self.adam2.apply(self.g2)
             elif lt == 'both_all':
-                self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, True, self.ws1)
-                self._layer2_backward(g1_accumulate=True, g2_accumulate=True)
+                self._layer2_backward(g1_accumulate=True, g2_accumulate=True, join=side)
                 self.adam1.apply(self.g1)
                 self.adam2.apply(self.g2)
             elif lt == 'only2_layerwise':
                 self._layer2_backward(g1_accumulate=None)
                 self.adam2.apply(self.g2)
+                main.wait_stream(side)
             elif lt == 'only2_all':
-                self._layer2_backward(g1_accumulate=False)
+                self._layer2_backward(g1_accumulate=False, join=side)
                 self.adam1.apply(self.g1)
                 self.adam2.apply(self.g2)
             else:  # only1
-                self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, False, self.ws1)
-                self.adam1.apply(self.g1)
+                main.wait_stream(side)
+            self.hist.index_copy_(0, self.hist_pos, self.sums[None])
+            self.hist_pos.add_(1).remainder_(self.hist.shape[0])
 
-    def _layer2_backward(self, g1_accumulate, g2_accumulate=False):
-        """g2 (+)= dW_D2; if g1_accumulate is not None also g1 (+)= d loss2 / d W_D1."""
+    def _layer2_backward(self, g1_accumulate, g2_accumulate=False, join=None):
+        """g2 (+)= dW_D2; if g1_accumulate is not None also g1 (+)= d loss2 / d W_D1.  `join`: the
+        side stream whose work (layer-1 gradient / Adam on g1, ws1) must be finished before g1 and
+        its split-K workspace are written here."""
         self._wgrad(self.xs2, self.dz2, self.idx2, self.s2, None, self.g2, g2_accumulate, self.ws2)
         if g1_accumulate is None:
             return
         # dz2 -> dp2 in place (Del-2 input gradient on the masked rows, identity elsewhere)
         ops.rows_gemm(self.dz2, self.idx2, self.wd2, trans_w=True, out=self.dz2)
         self._conv2_backward_to_s1()
+        if join is not None:
+            torch.cuda.current_stream().wait_stream(join)
         self._wgrad(self.xs1, self.dh, self.idx1, self.s1, self.z1, self.g1, g1_accumulate, self.ws1)
 
     # ------------------------------------------------------------------ public
