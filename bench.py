@@ -190,7 +190,29 @@ def main():
 
     data, model, neg, ni1, ni2 = build_request(args, device)
     state = {k: v.clone() for k, v in model.state_dict().items()}
-    eng = make_engine(args, data, model, neg, ni1, ni2, device, rank, world)
+    mode, note = ('single' if world == 1 else args.parallel), None
+    if mode == 'partition':
+        # build the partitioned engine and take one step; if ANY rank fails (RCCL set-up, capture),
+        # every rank falls back to independent replicas so that the run still reports a number
+        ok = 1
+        try:
+            eng = make_engine(args, data, model, neg, ni1, ni2, device, rank, world)
+            eng.step()
+            torch.cuda.synchronize()
+        except Exception as e:                                   # noqa: BLE001
+            ok, note = 0, f'{type(e).__name__}: {str(e)[:160]}'
+        try:
+            flag = torch.tensor([ok], device=device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag)
+        except Exception as e:                                   # noqa: BLE001
+            ok, note = 0, note or f'{type(e).__name__}: {str(e)[:160]}'
+        if not ok:
+            mode = 'replicas'
+            args.parallel = 'replicas'
+            model.load_state_dict(state)
+    if mode != 'partition':
+        eng = make_engine(args, data, model, neg, ni1, ni2, device, rank, world)
 
     for _ in range(args.warmup):
         eng.step()
@@ -210,7 +232,7 @@ def main():
         dt = float(tmax)
     losses = eng.loss_history()
 
-    partitioned = world > 1 and args.parallel == 'partition'
+    partitioned = mode == 'partition'
     units = args.steps if partitioned else world * args.steps      # iterations of whole requests
     if rank == 0:
         kdur, kbytes = time_dominant_kernel(eng)
@@ -234,6 +256,8 @@ def main():
                          'traffic_unit': 'bytes/launch (PMC, profiles/r01_spmm_traffic.json)', 'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6},
             'final_loss': float(losses[-1, 0]) if len(losses) else None,
         }
+        if note:
+            out['config']['partition_fallback'] = note
         if not args.no_cpu_baseline and world == 1:
             cpu_data = data.clone().cpu() if hasattr(data, 'clone') else data
             out['cpu_baseline'] = cpu_baseline(args, cpu_data, state, neg, args.cpu_baseline_iters)
