@@ -41,3 +41,15 @@ def test_factories_and_registry():
     a.gnn, a.unlearning_model = 'gcn', 'graph_eraser'
     with pytest.raises(NotImplementedError, match='out of scope'):
         get_trainer(a)
+
+
+def test_reference_import_paths_resolve():
+    import importlib
+    import sys
+    sys.modules.pop('framework', None)
+    fw = importlib.import_module('framework')
+    from framework.models.deletion import DeletionLayer, GATDelete          # noqa: F401
+    from framework.models.gcn import GCN                                    # noqa: F401
+    from framework.trainer.gnndelete_nodeemb import get_loss_fct            # noqa: F401
+    from framework.training_args import parse_args                          # noqa: F401
+    assert fw.get_model is get_model
