@@ -9,13 +9,19 @@ aggregates into an all-gather of the layer input instead of an all-reduce of [N,
   every rank   t1 = x W1^T for ALL rows (the input is static and replicated; recomputing 7.7 GF
                is cheaper than gathering 121 MB over xGMI)
   own rows     z1 = A t1 + b1, Del-1, t2 = relu(z1) W2^T
-  exchange 1   all-gather t2            [N, out] fp32
+  exchange 1   t2 rows                  [N, out] fp32 (see "exchange" below)
   own rows     z2 = A t2 + b2, Del-2, DEC + NI losses, dW_D2 partial, dz2 <- dz2 W_D2^T
-  exchange 2   all-gather dz2           [N, out] fp32
+  exchange 2   dz2 rows                 [N, out] fp32
   own rows     dt2 = A^T dz2, dh = dt2 W2, dW_D1 partials
   exchange 3   all-reduce of ONE packed buffer: dW_D1 (loss-1 part), dW_D1 (loss-2 part), dW_D2,
                4 loss sums  (~144 KiB)
   every rank   the --loss_type bookkeeping + Adam, identically (replicated Del weights)
+
+Exchange 1/2 are sparse by default (`exchange='halo'`): a rank sends each peer only the rows
+that peer's SpMM gathers (all-to-all with per-pair sorted row lists that both sides derive from
+the replicated CSR); with the locality order most gathers are rank-local, so this is a fraction
+of the dense all-gather (`exchange='allgather'`), which matters most at N=2 where a pair shares
+a single xGMI link.
 
 The four compute segments are captured as hipGraphs; the three collectives are issued between
 the replays.  GCN and GIN backbones (GAT's backward would need the per-edge attention of remote
@@ -24,7 +30,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
-from .collectives import all_gather_rows, all_reduce_sum, row_blocks
+from .collectives import all_gather_rows, all_reduce_sum, exchange_rows, halo_lists, row_blocks
 from .engine import LOSS_TYPES, _Adam, _LayerTerms, _loss_coefficients
 from .graph import SplitPlan, graph_for
 from .nn import GCNConv, GINConv
@@ -33,7 +39,7 @@ from .nn import GCNConv, GINConv
 class PartitionedNodeembEngine:
     def __init__(self, model, x, edge_index, z1_ori, z2_ori, pos_edge, neg_edge, ni_mask1, ni_mask2, rank, world,
                  loss_type='both_layerwise', alpha=0.5, lr=1e-3, reduction='mean', use_graph=True, history=4096,
-                 reorder=True, group=None):
+                 reorder=True, group=None, exchange='halo'):
         assert loss_type in LOSS_TYPES, loss_type
         conv2 = model.conv2
         if not isinstance(conv2, (GCNConv, GINConv)):
@@ -111,6 +117,15 @@ class PartitionedNodeembEngine:
         self._graphs = None
         self.needs_b = loss_type in ('both_all', 'both_layerwise', 'only2_all')
         self.needs_a = loss_type in ('both_all', 'both_layerwise', 'only1')
+        # sparse exchange: only the rows a peer's SpMM gathers travel (with the locality order that
+        # is a fraction of a full all-gather); 'allgather' keeps the dense collective
+        assert exchange in ('halo', 'allgather')
+        self.exchange = exchange if world > 1 else 'allgather'
+        if self.exchange == 'halo':
+            self.halo_f = halo_lists(g.rowptr, g.col, n, rank, world, self.chunk)
+            self.halo_b = halo_lists(g.rowptr_t, g.col_t, n, rank, world, self.chunk)
+            self.recv_f = torch.empty(sum(self.halo_f[3]), self.o, **f32)
+            self.recv_b = torch.empty(sum(self.halo_b[3]), self.o, **f32)
 
     # ------------------------------------------------------------------ helpers
     def _linear(self, x, weight, relu_in=False, out=None):
@@ -204,11 +219,22 @@ class PartitionedNodeembEngine:
     def _segments(self):
         return [self._seg_forward1, self._seg_forward2_backward1, self._seg_backward2, self._seg_update]
 
+    def _halo(self, full, lists, recv_buf):
+        send_rows, in_splits, recv_rows, out_splits = lists
+        exchange_rows(full.index_select(0, send_rows), recv_buf, in_splits, out_splits, self.world, self.group)
+        full.index_copy_(0, recv_rows, recv_buf)
+
     def _exchange(self, after_segment):
         if after_segment == 0:
-            all_gather_rows(self.t2_full, self.rank, self.world, self.chunk, self.group)
+            if self.exchange == 'halo':
+                self._halo(self.t2_full, self.halo_f, self.recv_f)
+            else:
+                all_gather_rows(self.t2_full, self.rank, self.world, self.chunk, self.group)
         elif after_segment == 1 and self.needs_b:
-            all_gather_rows(self.dz2, self.rank, self.world, self.chunk, self.group)
+            if self.exchange == 'halo':
+                self._halo(self.dz2, self.halo_b, self.recv_b)
+            else:
+                all_gather_rows(self.dz2, self.rank, self.world, self.chunk, self.group)
         elif after_segment == 2:
             all_reduce_sum(self.pack, self.world, self.group)
 

@@ -67,6 +67,20 @@ def cpu_checks(rank, world):
     all_reduce_sum(counts, world)
     assert counts.tolist() == [whole.n_items, whole.n_slots]
 
+    # ---- sparse (halo) exchange delivers exactly the rows the local SpMM gathers
+    from gnndelete_amd.collectives import exchange_rows, halo_lists
+    col = ei[0][order]
+    send_rows, in_splits, recv_rows, out_splits = halo_lists(rowptr, col, n, rank, world, chunk)
+    truth = torch.arange(n_pad, dtype=torch.float32)[:, None].repeat(1, 3)          # row r holds value r
+    mine_full = torch.full((n_pad, 3), -1.0)
+    mine_full[lo:hi] = truth[lo:hi]
+    recv = torch.empty(sum(out_splits), 3)
+    exchange_rows(mine_full.index_select(0, send_rows), recv, in_splits, out_splits, world)
+    mine_full.index_copy_(0, recv_rows, recv)
+    gathered = torch.unique(col[int(rowptr[lo]):int(rowptr[hi])])
+    assert torch.equal(mine_full[gathered], truth[gathered])
+    assert recv_rows.numel() < n - (hi - lo) or world == 1
+
     # ---- dense emulation of the partitioned step vs single-process autograd
     torch.manual_seed(0)
     model = R.TwoLayerDelete('gcn', f, h, o, data.sdf_node_1hop_mask, data.sdf_node_2hop_mask)
@@ -146,7 +160,8 @@ def gpu_checks(rank, world):
                 z1o, z2o = m.get_original_embeddings(x, E[:, data.dr_mask.to(dev)].contiguous(), return_all_emb=True)
             args = (m, x, e_sdf, z1o, z2o, E[:, data.df_mask.to(dev)], neg.to(dev), ni1, ni2)
             if partitioned:
-                eng = PartitionedNodeembEngine(*args, rank, world, loss_type=lt, alpha=0.5, lr=1e-2)
+                eng = PartitionedNodeembEngine(*args, rank, world, loss_type=lt, alpha=0.5, lr=1e-2,
+                                               exchange='allgather' if lt == 'only2_all' else 'halo')
             else:
                 eng = NodeembEngine(*args, loss_type=lt, alpha=0.5, lr=1e-2)
             for _ in range(6):
