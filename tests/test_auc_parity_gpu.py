@@ -1,0 +1,79 @@
+"""north_star parity gate at moderate scale: after Del training on the same request with the same
+injected negatives, the HIP engine and the CPU oracle (reference update rule) must agree on
+post-deletion link-prediction AUC within +-0.002 and on affected-node embeddings within 1e-4
+rel-L2 (z1 on the 1-hop S_Df nodes, z2 on the 2-hop S_Df nodes)."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+from sklearn.metrics import roc_auc_score
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('gnn', ['gcn', 'gat'])
+def test_post_deletion_auc_and_affected_embeddings(gnn):
+    from gnndelete_amd.engine import NodeembEngine
+    from gnndelete_amd.framework.data import prepare_edge_deletion
+    from gnndelete_amd.framework.graph_utils import negative_sampling
+    from gnndelete_amd.framework.models import GATDelete, GCNDelete
+    from gnndelete_amd.framework.synth import make_linkpred_dataset
+    from oracle import gnndelete_ref as R
+
+    data, dfm = make_linkpred_dataset(None, seed=7, shape=(3000, 48, 15000, 'dense'))
+    torch.manual_seed(7)
+    prepare_edge_deletion(data, dfm['in'], 400)
+    gen = torch.Generator().manual_seed(7)
+    neg = negative_sampling(data.train_pos_edge_index, data.num_nodes, int(data.df_mask.sum()), generator=gen)
+    keep = torch.ones(data.num_nodes, dtype=torch.bool)
+    keep[data.directed_df_edge_index.flatten().unique()] = False
+    ni1, ni2 = data.sdf_node_1hop_mask & keep, data.sdf_node_2hop_mask & keep
+    E = data.train_pos_edge_index
+    e_dr, e_sdf, pos = E[:, data.dr_mask], E[:, data.sdf_mask], E[:, data.df_mask]
+
+    torch.manual_seed(3)
+    cls = {'gcn': GCNDelete, 'gat': GATDelete}[gnn]
+    hip = cls(SimpleNamespace(in_dim=48, hidden_dim=128, out_dim=64), data.sdf_node_1hop_mask, data.sdf_node_2hop_mask)
+    # a backbone with some signal: scale the random weights up so that scores spread
+    with torch.no_grad():
+        for n_, p in hip.named_parameters():
+            if 'deletion' not in n_ and p.dim() > 1:
+                p.mul_(2.0)
+    ref = R.TwoLayerDelete(gnn, 48, 128, 64, data.sdf_node_1hop_mask, data.sdf_node_2hop_mask)
+    ref.load_state_dict(hip.state_dict(), strict=False)
+
+    with torch.no_grad():
+        z1o, z2o = ref.get_original_embeddings(data.x, e_dr, return_all_emb=True)
+    targets = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=pos, neg_edge=neg, ni_mask1=ni1, ni_mask2=ni2)
+    opt = R.make_optimizer(ref, 'both_layerwise', 1e-2)
+    epochs = 60
+    for _ in range(epochs):
+        R.nodeemb_epoch(ref, lambda: ref(data.x, e_sdf, return_all_emb=True), targets, opt, 'both_layerwise', 0.5,
+                        R.LOSSES['mse_mean'])
+
+    hip = hip.cuda()
+    eng = NodeembEngine(hip, data.x.cuda(), e_sdf.cuda().contiguous(), z1o.cuda(), z2o.cuda(), pos.cuda(), neg.cuda(),
+                        ni1, ni2, loss_type='both_layerwise', alpha=0.5, lr=1e-2)
+    for _ in range(epochs):
+        eng.step()
+
+    with torch.no_grad():
+        r1, r2 = ref(data.x, e_dr, return_all_emb=True)
+        h1, h2 = hip(data.x.cuda(), e_dr.cuda().contiguous(), return_all_emb=True)
+    assert rel_l2(h1.cpu()[data.sdf_node_1hop_mask], r1[data.sdf_node_1hop_mask]) < 1e-4
+    assert rel_l2(h2.cpu()[data.sdf_node_2hop_mask], r2[data.sdf_node_2hop_mask]) < 1e-4
+
+    def auc(z, pos_e, neg_e):
+        ei = torch.cat([pos_e, neg_e], 1)
+        s = (z[ei[0]] * z[ei[1]]).sum(-1).sigmoid()
+        y = torch.cat([torch.ones(pos_e.shape[1]), torch.zeros(neg_e.shape[1])])
+        return roc_auc_score(y.numpy(), s.numpy())
+    dt_ref = auc(r2, data.test_pos_edge_index, data.test_neg_edge_index)
+    dt_hip = auc(h2.cpu(), data.test_pos_edge_index, data.test_neg_edge_index)
+    dr_sample = e_dr[:, torch.randperm(e_dr.shape[1], generator=gen)[:data.directed_df_edge_index.shape[1]]]
+    df_ref = auc(r2, dr_sample, data.directed_df_edge_index)        # Dr labelled 1, Df labelled 0
+    df_hip = auc(h2.cpu(), dr_sample, data.directed_df_edge_index)
+    assert abs(dt_ref - dt_hip) <= 0.002 and abs(df_ref - df_hip) <= 0.002, (dt_ref, dt_hip, df_ref, df_hip)
+    assert rel_l2(hip.deletion1.deletion_weight.detach().cpu(), ref.deletion1.deletion_weight.detach()) < 1e-3
