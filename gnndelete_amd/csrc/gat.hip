@@ -197,6 +197,262 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(const int32_t* __restr
   }
 }
 
+// =============================================================================================
+// Load-balanced GAT (same work items as gd_spmm_csr_balanced_f32: <= 64 in-edges per piece, hub
+// rows spread over many waves, XCD-contiguous item ranges).  A piece computes a LOCAL softmax
+// (m_p = max score, s_p = sum exp(e - m_p), acc_p = sum exp(e - m_p) h_j); pieces of one row are
+// merged flash-attention style:  M = max m_p,  S = sum s_p e^(m_p-M),  y = sum acc_p e^(m_p-M) / S.
+// The row statistics (M, S) are all the backward needs to rebuild the attention weights.
+template <int LPR, int VPL, bool EXACT>
+__global__ __launch_bounds__(256) void gat_items_fwd_kernel(
+    const int4* __restrict__ items, int32_t n_items, const int32_t* __restrict__ col,
+    const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ h, int64_t ldh,
+    float* __restrict__ y, int64_t ldy, const float* __restrict__ bias, float* __restrict__ rowmax,
+    float* __restrict__ rowsum, float* __restrict__ scratch, float* __restrict__ scratch_ms, float slope, int32_t d4,
+    int32_t nnz) {
+  constexpr int G = kWave / LPR;
+  constexpr int U = (kWave / G) >= 4 ? 4 : (kWave / G);
+  constexpr int kXcd = 8;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR, li = lane % LPR;
+  const int xcd = blockIdx.x % kXcd;
+  const int waves_per_xcd = (gridDim.x / kXcd) * 4;
+  const int wx = (blockIdx.x / kXcd) * 4 + (threadIdx.x >> 6);
+  const int per = (n_items + kXcd - 1) / kXcd;
+  const int i0 = xcd * per, i1 = min(n_items, i0 + per);
+  int i = i0 + wx;
+  if (i >= i1) return;
+
+  int4 desc = items[i];
+  int c = col[min(desc.y + lane, nnz - 1)];
+  for (; i < i1; i += waves_per_xcd) {
+    const int row = desc.x, slot = desc.w;
+    const int cnt = desc.z - desc.y;
+    const int c_cur = c;
+    desc = items[min(i + waves_per_xcd, i1 - 1)];
+    c = col[min(desc.y + lane, nnz - 1)];
+
+    const float e = lane < cnt ? leaky(a_src[c_cur] + a_dst[row], slope) : -INFINITY;
+    const float m = wave_max(e);
+    const float p_cur = lane < cnt ? expf(e - m) : 0.f;
+    const float ssum = wave_sum(p_cur);
+
+    float4 acc[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
+    const int trips = (cnt + G - 1) / G;
+    for (int t0 = 0; t0 < trips; t0 += U) {
+      float4 xv[U][VPL];
+      float wj[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = (t0 + u) * G + g;
+        const int cj = __shfl(c_cur, j & 63);
+        const float wsh = __shfl(p_cur, j & 63);
+        const int c0 = __shfl(c_cur, 0);
+        wj[u] = j < cnt ? wsh : 0.f;
+        const int cs = j < cnt ? cj : c0;
+        const float4* xr = reinterpret_cast<const float4*>(h + (int64_t)cs * ldh);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int vec = li + v * LPR;
+          xv[u][v] = EXACT ? xr[vec] : xr[min(vec, d4 - 1)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+      for (int off = LPR; off < kWave; off <<= 1) acc[v] = f4_add(acc[v], f4_shfl_xor(acc[v], off));
+    if (lane == 0) {
+      if (slot < 0) { rowmax[row] = m; rowsum[row] = ssum; }
+      else { scratch_ms[2 * slot] = m; scratch_ms[2 * slot + 1] = ssum; }
+    }
+    if (g == 0) {
+      const float inv = 1.0f / (ssum + 1e-16f);
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const int vec = li + v * LPR;
+        if (!EXACT && vec >= d4) continue;
+        float4 o = acc[v];
+        if (slot < 0) {
+          o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+          if (bias) o = f4_add(o, reinterpret_cast<const float4*>(bias)[vec]);
+          reinterpret_cast<float4*>(y + (int64_t)row * ldy)[vec] = o;
+        } else {
+          reinterpret_cast<float4*>(scratch + (int64_t)slot * d4 * 4)[vec] = o;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gat_fixup_fwd_kernel(const int4* __restrict__ split, int32_t n_split,
+                                                            const float* __restrict__ scratch,
+                                                            const float* __restrict__ scratch_ms,
+                                                            float* __restrict__ y, int64_t ldy,
+                                                            const float* __restrict__ bias, float* __restrict__ rowmax,
+                                                            float* __restrict__ rowsum, int32_t d4) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_split) return;
+  const int4 sp = split[i];
+  const int row = sp.x, slot0 = sp.y, n = sp.z;
+  float mx = -INFINITY;
+  for (int s = 0; s < n; ++s) mx = fmaxf(mx, scratch_ms[2 * (slot0 + s)]);
+  float tot = 0.f;
+  for (int s = 0; s < n; ++s) tot += scratch_ms[2 * (slot0 + s) + 1] * expf(scratch_ms[2 * (slot0 + s)] - mx);
+  const float inv = 1.0f / (tot + 1e-16f);
+  for (int vec = lane; vec < d4; vec += kWave) {
+    float4 o = f4_zero();
+    for (int s = 0; s < n; ++s) {
+      const float f = expf(scratch_ms[2 * (slot0 + s)] - mx);
+      o = f4_fma(f, reinterpret_cast<const float4*>(scratch + (int64_t)(slot0 + s) * d4 * 4)[vec], o);
+    }
+    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+    if (bias) o = f4_add(o, reinterpret_cast<const float4*>(bias)[vec]);
+    reinterpret_cast<float4*>(y + (int64_t)row * ldy)[vec] = o;
+  }
+  if (lane == 0) { rowmax[row] = mx; rowsum[row] = tot; }
+}
+
+// backward pass 1 (target-major pieces): alpha_k, d_alpha_k = <dy_i, h_j> (stored in de),
+// per-piece T = sum alpha d_alpha -> t[row] (whole rows) or a scratch slot (split rows)
+template <int LPR, int VPL, bool EXACT>
+__global__ __launch_bounds__(256) void gat_items_bwd_dalpha_kernel(
+    const int4* __restrict__ items, int32_t n_items, const int32_t* __restrict__ col,
+    const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ rowmax,
+    const float* __restrict__ rowsum, const float* __restrict__ h, int64_t ldh, const float* __restrict__ dy,
+    int64_t lddy, float* __restrict__ alpha, float* __restrict__ de, float* __restrict__ t_row,
+    float* __restrict__ scratch_t, float slope, int32_t d4, int32_t nnz) {
+  constexpr int G = kWave / LPR;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR, li = lane % LPR;
+  const int bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int item = bid * 4 + (threadIdx.x >> 6);
+  if (item >= n_items) return;
+  const int4 desc = items[item];
+  const int row = desc.x, start = desc.y, slot = desc.w;
+  const int cnt = desc.z - start;
+  const int c = col[min(start + lane, nnz - 1)];
+  const float e = leaky(a_src[c] + a_dst[row], slope);
+  const float al = lane < cnt ? expf(e - rowmax[row]) / (rowsum[row] + 1e-16f) : 0.f;
+  if (lane < cnt) alpha[start + lane] = al;
+
+  float4 dyr[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int vec = li + v * LPR;
+    dyr[v] = reinterpret_cast<const float4*>(dy + (int64_t)row * lddy)[EXACT ? vec : min(vec, d4 - 1)];
+    if (!EXACT && vec >= d4) dyr[v] = f4_zero();
+  }
+  float tpart = 0.f;
+  const int trips = (cnt + G - 1) / G;
+  for (int it = 0; it < trips; ++it) {
+    const int j = it * G + g;
+    const int cj = __shfl(c, j & 63);
+    const float aj = __shfl(al, j & 63);
+    const int c0 = __shfl(c, 0);
+    const float4* hr = reinterpret_cast<const float4*>(h + (int64_t)(j < cnt ? cj : c0) * ldh);
+    float p = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int vec = li + v * LPR;
+      const float4 hv = hr[EXACT ? vec : min(vec, d4 - 1)];
+      p = fmaf(dyr[v].x, hv.x, p); p = fmaf(dyr[v].y, hv.y, p); p = fmaf(dyr[v].z, hv.z, p); p = fmaf(dyr[v].w, hv.w, p);
+    }
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) p += __shfl_xor(p, off);
+    if (j < cnt && li == 0) {
+      de[start + j] = p;
+      tpart = fmaf(aj, p, tpart);
+    }
+  }
+  tpart = wave_sum(tpart);
+  if (lane == 0) {
+    if (slot < 0) t_row[row] = tpart; else scratch_t[slot] = tpart;
+  }
+}
+
+__global__ __launch_bounds__(256) void scalar_fixup_kernel(const int4* __restrict__ split, int32_t n_split,
+                                                           const float* __restrict__ scratch, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_split) return;
+  const int4 sp = split[i];
+  float s = 0.f;
+  for (int k = 0; k < sp.z; ++k) s += scratch[sp.y + k];
+  out[sp.x] = s;
+}
+
+// backward pass 2 (edge-parallel inside pieces): de_k = alpha_k (d_alpha_k - t_i) leaky'(s_k); da_dst partials
+__global__ __launch_bounds__(256) void gat_items_bwd_de_kernel(
+    const int4* __restrict__ items, int32_t n_items, const int32_t* __restrict__ col,
+    const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ alpha,
+    const float* __restrict__ t_row, float* __restrict__ de, float* __restrict__ da_dst,
+    float* __restrict__ scratch_d, float slope, int32_t nnz) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= n_items) return;
+  const int4 desc = items[item];
+  const int row = desc.x, start = desc.y, slot = desc.w;
+  const int cnt = desc.z - start;
+  float v = 0.f;
+  if (lane < cnt) {
+    const int k = start + lane;
+    const float s = a_src[col[k]] + a_dst[row];
+    v = alpha[k] * (de[k] - t_row[row]) * (s > 0.f ? 1.0f : slope);
+    de[k] = v;
+  }
+  v = wave_sum(v);
+  if (lane == 0) {
+    if (slot < 0) da_dst[row] = v; else scratch_d[slot] = v;
+  }
+}
+
+// a1[i] = <h[i,:], v1>, a2[i] = <h[i,:], v2>  (the GAT attention logits a_src / a_dst): one pass over h
+template <int LPR>
+__global__ __launch_bounds__(256) void row_dots_kernel(const float* __restrict__ h, int64_t ldh, int32_t n,
+                                                       int32_t d4, const float* __restrict__ v1,
+                                                       const float* __restrict__ v2, float* __restrict__ a1,
+                                                       float* __restrict__ a2) {
+  constexpr int G = kWave / LPR;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR, li = lane % LPR;
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * G + g;
+  float p1 = 0.f, p2 = 0.f;
+  if (row < n) {
+    const float4* hr = reinterpret_cast<const float4*>(h + (int64_t)row * ldh);
+    for (int vec = li; vec < d4; vec += LPR) {
+      const float4 hv = hr[vec];
+      const float4 x1 = reinterpret_cast<const float4*>(v1)[vec];
+      const float4 x2 = reinterpret_cast<const float4*>(v2)[vec];
+      p1 = fmaf(hv.x, x1.x, p1); p1 = fmaf(hv.y, x1.y, p1); p1 = fmaf(hv.z, x1.z, p1); p1 = fmaf(hv.w, x1.w, p1);
+      p2 = fmaf(hv.x, x2.x, p2); p2 = fmaf(hv.y, x2.y, p2); p2 = fmaf(hv.z, x2.z, p2); p2 = fmaf(hv.w, x2.w, p2);
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < LPR; off <<= 1) { p1 += __shfl_xor(p1, off); p2 += __shfl_xor(p2, off); }
+  if (row < n && li == 0) { a1[row] = p1; a2[row] = p2; }
+}
+
+// out[i] = sum_{k in [rowptr[i], rowptr[i+1])} x[perm ? perm[k] : k]   (deterministic, one wave per row)
+__global__ __launch_bounds__(256) void segment_sum_kernel(const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ perm,
+                                                          const float* __restrict__ x, int32_t n,
+                                                          float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  float s = 0.f;
+  for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += kWave) s += x[perm ? perm[k] : k];
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
 #define GD_GAT_DISPATCH(KERNEL, ...)                                                         \
   do {                                                                                       \
     const int lpr = lanes_per_row(d4);                                                       \
@@ -252,4 +508,127 @@ extern "C" int gd_gat_aggregate_bwd_f32(const int32_t* rowptr, const int32_t* co
   if (rc) return rc;
   GD_GAT_DISPATCH(gat_bwd_col_kernel, rowptr_t, col_t, perm_t, alpha, de, dy, lddy, dh, lddh, da_src, n_rows, d4);
   return launched("gat_bwd_col");
+}
+
+#define GD_GAT_ITEMS(KERNEL, ...)                                                                              \
+  do {                                                                                                         \
+    const int lpr = lanes_per_row(d4);                                                                         \
+    const bool ex = (lpr == 64) ? (d4 == 64 || d4 == 256) : (d4 == lpr);                                        \
+    switch (lpr) {                                                                                             \
+      case 1: hipLaunchKernelGGL((KERNEL<1, 1, true>), grid, dim3(256), 0, s, __VA_ARGS__); break;             \
+      case 2: hipLaunchKernelGGL((KERNEL<2, 1, true>), grid, dim3(256), 0, s, __VA_ARGS__); break;             \
+      case 4: hipLaunchKernelGGL((KERNEL<4, 1, true>), grid, dim3(256), 0, s, __VA_ARGS__); break;             \
+      case 8: hipLaunchKernelGGL((KERNEL<8, 1, true>), grid, dim3(256), 0, s, __VA_ARGS__); break;             \
+      case 16: hipLaunchKernelGGL((KERNEL<16, 1, true>), grid, dim3(256), 0, s, __VA_ARGS__); break;           \
+      case 32: hipLaunchKernelGGL((KERNEL<32, 1, true>), grid, dim3(256), 0, s, __VA_ARGS__); break;           \
+      default:                                                                                                 \
+        if (d4 == 64) hipLaunchKernelGGL((KERNEL<64, 1, true>), grid, dim3(256), 0, s, __VA_ARGS__);           \
+        else if (d4 < 64) hipLaunchKernelGGL((KERNEL<64, 1, false>), grid, dim3(256), 0, s, __VA_ARGS__);      \
+        else if (d4 == 256) hipLaunchKernelGGL((KERNEL<64, 4, true>), grid, dim3(256), 0, s, __VA_ARGS__);     \
+        else hipLaunchKernelGGL((KERNEL<64, 4, false>), grid, dim3(256), 0, s, __VA_ARGS__);                   \
+    }                                                                                                          \
+    (void)ex;                                                                                                  \
+  } while (0)
+
+extern "C" int64_t gd_gat_balanced_scratch(int32_t n_slots, int32_t d) { return (int64_t)n_slots * (d + 4) + 4; }
+
+extern "C" int gd_gat_aggregate_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split,
+                                             int32_t n_split, int32_t n_slots, const int32_t* col, const float* a_src,
+                                             const float* a_dst, const float* h, int64_t ldh, float* y, int64_t ldy,
+                                             const float* bias, float* rowmax, float* rowsum, float* scratch,
+                                             float slope, int32_t d, int32_t nnz, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(items && col && a_src && a_dst && h && y && rowmax && rowsum, GD_E_NULL,
+             "gd_gat_aggregate_balanced_f32: null pointer");
+  GD_REQUIRE(n_split == 0 || (split && scratch), GD_E_NULL, "gd_gat_aggregate_balanced_f32: split rows need scratch");
+  GD_REQUIRE(d > 0 && d % 4 == 0 && d <= 1024 && ldh % 4 == 0 && ldy % 4 == 0 && (d & (d - 1)) == 0, GD_E_DIM,
+             "gd_gat_aggregate_balanced_f32: d=%d must be a power of two in [4,1024]", d);
+  GD_REQUIRE(aligned16(h) && aligned16(y) && aligned16(items) && (!bias || aligned16(bias)) &&
+                 (!scratch || aligned16(scratch)), GD_E_ALIGN, "gd_gat_aggregate_balanced_f32: unaligned pointer");
+  if (n_items == 0) return GD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int d4 = d / 4;
+  int nblk = (n_items + 3) / 4;
+  if (nblk > 8192) nblk = 8192;
+  nblk = (nblk + 7) / 8 * 8;
+  const dim3 grid(nblk);
+  float* scratch_ms = scratch ? scratch + (int64_t)n_slots * d : nullptr;
+  const int4* it = reinterpret_cast<const int4*>(items);
+  GD_GAT_ITEMS(gat_items_fwd_kernel, it, n_items, col, a_src, a_dst, h, ldh, y, ldy, bias, rowmax, rowsum, scratch,
+               scratch_ms, slope, d4, nnz);
+  int rc = launched("gat_items_fwd");
+  if (rc || n_split == 0) return rc;
+  hipLaunchKernelGGL(gat_fixup_fwd_kernel, dim3((n_split + 3) / 4), dim3(256), 0, s,
+                     reinterpret_cast<const int4*>(split), n_split, scratch, scratch_ms, y, ldy, bias, rowmax, rowsum, d4);
+  return launched("gat_fixup_fwd");
+}
+
+extern "C" int gd_gat_edge_grads_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split,
+                                              int32_t n_split, const int32_t* col, const float* a_src,
+                                              const float* a_dst, const float* rowmax, const float* rowsum,
+                                              const float* h, int64_t ldh, const float* dy, int64_t lddy,
+                                              float* alpha, float* de, float* da_dst, float* t_row, float* scratch,
+                                              float slope, int32_t d, int32_t nnz, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(items && col && a_src && a_dst && rowmax && rowsum && h && dy && alpha && de && da_dst && t_row, GD_E_NULL,
+             "gd_gat_edge_grads_balanced_f32: null pointer");
+  GD_REQUIRE(n_split == 0 || (split && scratch), GD_E_NULL, "gd_gat_edge_grads_balanced_f32: split rows need scratch");
+  GD_REQUIRE(d > 0 && d % 4 == 0 && d <= 1024 && ldh % 4 == 0 && lddy % 4 == 0 && (d & (d - 1)) == 0, GD_E_DIM,
+             "gd_gat_edge_grads_balanced_f32: d=%d must be a power of two in [4,1024]", d);
+  GD_REQUIRE(aligned16(h) && aligned16(dy) && aligned16(items), GD_E_ALIGN, "gd_gat_edge_grads_balanced_f32: unaligned");
+  if (n_items == 0) return GD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int d4 = d / 4;
+  const dim3 grid(((n_items + 3) / 4 + 7) / 8 * 8);
+  const int4* it = reinterpret_cast<const int4*>(items);
+  const int4* sp = reinterpret_cast<const int4*>(split);
+  GD_GAT_ITEMS(gat_items_bwd_dalpha_kernel, it, n_items, col, a_src, a_dst, rowmax, rowsum, h, ldh, dy, lddy, alpha, de,
+               t_row, scratch, slope, d4, nnz);
+  int rc = launched("gat_items_bwd_dalpha");
+  if (rc) return rc;
+  if (n_split) {
+    hipLaunchKernelGGL(scalar_fixup_kernel, dim3((n_split + 255) / 256), dim3(256), 0, s, sp, n_split, scratch, t_row);
+    if ((rc = launched("gat_fixup_t"))) return rc;
+  }
+  hipLaunchKernelGGL(gat_items_bwd_de_kernel, dim3((n_items + 3) / 4), dim3(256), 0, s, it, n_items, col, a_src, a_dst,
+                     alpha, t_row, de, da_dst, scratch, slope, nnz);
+  if ((rc = launched("gat_items_bwd_de"))) return rc;
+  if (n_split) {
+    hipLaunchKernelGGL(scalar_fixup_kernel, dim3((n_split + 255) / 256), dim3(256), 0, s, sp, n_split, scratch, da_dst);
+    rc = launched("gat_fixup_dadst");
+  }
+  return rc;
+}
+
+extern "C" int gd_row_dots_f32(const float* h, int64_t ldh, int32_t n, int32_t d, const float* v1, const float* v2,
+                               float* a1, float* a2, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(h && v1 && v2 && a1 && a2, GD_E_NULL, "gd_row_dots_f32: null pointer");
+  GD_REQUIRE(n >= 0 && d > 0 && d % 4 == 0 && ldh % 4 == 0, GD_E_DIM, "gd_row_dots_f32: d must be a multiple of 4");
+  GD_REQUIRE(aligned16(h) && aligned16(v1) && aligned16(v2), GD_E_ALIGN, "gd_row_dots_f32: unaligned pointer");
+  if (n == 0) return GD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int d4 = d / 4;
+  const int lpr = lanes_per_row(d4);
+  const int per_block = 4 * (kWave / lpr);
+  const dim3 grid((n + per_block - 1) / per_block);
+  switch (lpr) {
+    case 1: hipLaunchKernelGGL((row_dots_kernel<1>), grid, dim3(256), 0, s, h, ldh, n, d4, v1, v2, a1, a2); break;
+    case 2: hipLaunchKernelGGL((row_dots_kernel<2>), grid, dim3(256), 0, s, h, ldh, n, d4, v1, v2, a1, a2); break;
+    case 4: hipLaunchKernelGGL((row_dots_kernel<4>), grid, dim3(256), 0, s, h, ldh, n, d4, v1, v2, a1, a2); break;
+    case 8: hipLaunchKernelGGL((row_dots_kernel<8>), grid, dim3(256), 0, s, h, ldh, n, d4, v1, v2, a1, a2); break;
+    case 16: hipLaunchKernelGGL((row_dots_kernel<16>), grid, dim3(256), 0, s, h, ldh, n, d4, v1, v2, a1, a2); break;
+    case 32: hipLaunchKernelGGL((row_dots_kernel<32>), grid, dim3(256), 0, s, h, ldh, n, d4, v1, v2, a1, a2); break;
+    default: hipLaunchKernelGGL((row_dots_kernel<64>), grid, dim3(256), 0, s, h, ldh, n, d4, v1, v2, a1, a2); break;
+  }
+  return launched("row_dots");
+}
+
+extern "C" int gd_segment_sum_f32(const int32_t* rowptr, const int32_t* perm, const float* x, int32_t n, float* out,
+                                  void* stream) {
+  using namespace gd;
+  GD_REQUIRE(rowptr && x && out, GD_E_NULL, "gd_segment_sum_f32: null pointer");
+  if (n <= 0) return GD_OK;
+  hipLaunchKernelGGL(segment_sum_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, rowptr, perm, x, n, out);
+  return launched("segment_sum");
 }

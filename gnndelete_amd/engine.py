@@ -223,12 +223,8 @@ class NodeembEngine:
                 self.z1.copy_(torch.nn.functional.linear(agg, lin.weight, lin.bias))
         else:
             h1 = self._linear(self.x, c.lin_src.weight)
-            a_src = (h1 * c.att_src.view(1, -1)).sum(-1)
-            a_dst = (h1 * c.att_dst.view(1, -1)).sum(-1)
-            check(_lib.lib().gd_gat_aggregate_f32(ptr(g.rowptr), ptr(g.col), ptr(a_src), ptr(a_dst), ptr(h1),
-                                                  h1.stride(0), ptr(self.z1), self.z1.stride(0), ptr(c.bias), None,
-                                                  c.negative_slope, self.n, self.h, stream_ptr(self.x.device)),
-                  'gd_gat_aggregate_f32')
+            a_src, a_dst = ops.row_dots(h1, c.att_src, c.att_dst)
+            ops.gat_forward_raw(g, h1, a_src, a_dst, c.bias, c.negative_slope, out=self.z1)
 
     def _conv2_forward(self):
         c = self.model.conv2
@@ -245,15 +241,9 @@ class NodeembEngine:
         else:   # gat
             h2 = self._linear(self.z1, c.lin_src.weight, relu_in=True)
             self._h2 = h2
-            self._a_src = (h2 * c.att_src.view(1, -1)).sum(-1)
-            self._a_dst = (h2 * c.att_dst.view(1, -1)).sum(-1)
-            if not hasattr(self, '_alpha'):
-                self._alpha = torch.empty(self.graph.nnz, dtype=torch.float32, device=self.x.device)
-            g = self.graph
-            check(_lib.lib().gd_gat_aggregate_f32(ptr(g.rowptr), ptr(g.col), ptr(self._a_src), ptr(self._a_dst),
-                                                  ptr(h2), h2.stride(0), ptr(self.z2), self.z2.stride(0), ptr(c.bias),
-                                                  ptr(self._alpha), c.negative_slope, self.n, self.o,
-                                                  stream_ptr(self.x.device)), 'gd_gat_aggregate_f32')
+            self._a_src, self._a_dst = ops.row_dots(h2, c.att_src, c.att_dst)
+            _, self._rowmax, self._rowsum = ops.gat_forward_raw(self.graph, h2, self._a_src, self._a_dst, c.bias,
+                                                                c.negative_slope, out=self.z2)
 
     def _conv2_backward_to_s1(self):
         """dh[S1] = d loss2 / d relu(z1) restricted to the S1 rows (all that Del-1 needs)."""
@@ -268,15 +258,8 @@ class NodeembEngine:
                 self._spmm(True, None, self.dz2, dt2, None, 1.0 + c.eps)
                 w2 = c.nn.weight
         else:
-            dt2 = torch.empty(self.n, self.o, dtype=torch.float32, device=self.x.device)
-            da_s = torch.empty(self.n, dtype=torch.float32, device=self.x.device)
-            da_d = torch.empty(self.n, dtype=torch.float32, device=self.x.device)
-            de = torch.empty(g.nnz, dtype=torch.float32, device=self.x.device)
-            check(_lib.lib().gd_gat_aggregate_bwd_f32(
-                ptr(g.rowptr), ptr(g.col), ptr(self._alpha), ptr(g.rowptr_t), ptr(g.col_t), ptr(g.perm_t),
-                ptr(self._a_src), ptr(self._a_dst), ptr(self._h2), self._h2.stride(0), ptr(self.dz2),
-                self.dz2.stride(0), ptr(dt2), dt2.stride(0), ptr(da_s), ptr(da_d), ptr(de), c.negative_slope, self.n,
-                self.o, stream_ptr(self.x.device)), 'gd_gat_aggregate_bwd_f32')
+            dt2, da_s, da_d = ops.gat_backward_raw(g, self._h2, self._a_src, self._a_dst, self._rowmax, self._rowsum,
+                                                   self.dz2, c.negative_slope)
             dt2.addcmul_(da_s[:, None], c.att_src.view(1, -1)).addcmul_(da_d[:, None], c.att_dst.view(1, -1))
             w2 = c.lin_src.weight
         # dh[S1] = dt2[S1] @ W2   (W2 is [out, in] = [d_in, d_out] of this product)

@@ -46,6 +46,14 @@ class SplitPlan:
         self.n_slots = int(split_pieces.sum())
         self._scratch = {}
 
+    def scratch_flat(self, tag, n_floats, device):
+        """Named flat work buffers (e.g. the GAT kernels' merge scratch), kept per plan."""
+        buf = self._scratch.get(tag)
+        if buf is None or buf.numel() < n_floats:
+            buf = torch.empty(max(int(n_floats), 4), dtype=torch.float32, device=device)
+            self._scratch[tag] = buf
+        return buf
+
     def scratch(self, d, device):
         if self.n_slots == 0:
             return None

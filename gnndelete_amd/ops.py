@@ -130,37 +130,94 @@ def del_rows(x, w, idx):
 
 
 # ------------------------------------------------------------------------------ GAT
+def _pow2(d):
+    return d >= 4 and (d & (d - 1)) == 0 and d <= 1024
+
+
+def gat_forward_raw(graph, h, a_src, a_dst, bias, slope, out=None):
+    """Fused edge-softmax aggregation; returns (y, rowmax, rowsum) - balanced kernels when the
+    width allows, else the one-wave-per-row kernel (then rowmax is the saved alpha, rowsum None)."""
+    n, d = graph.n, h.shape[1]
+    y = out if out is not None else torch.empty(n, d, dtype=torch.float32, device=h.device)
+    plan = graph.plan
+    if _pow2(d) and h.stride(0) % 4 == 0:
+        rowmax = torch.empty(n, dtype=torch.float32, device=h.device)
+        rowsum = torch.empty(n, dtype=torch.float32, device=h.device)
+        scratch = plan.scratch_flat('gat', _lib.lib().gd_gat_balanced_scratch(plan.n_slots, d), h.device)
+        check(_lib.lib().gd_gat_aggregate_balanced_f32(
+            ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split, plan.n_slots, ptr(graph.col), ptr(a_src),
+            ptr(a_dst), ptr(h), h.stride(0), ptr(y), y.stride(0), ptr(bias), ptr(rowmax), ptr(rowsum), ptr(scratch),
+            float(slope), d, graph.nnz, stream_ptr(h.device)), 'gd_gat_aggregate_balanced_f32')
+        return y, rowmax, rowsum
+    alpha = torch.empty(graph.nnz, dtype=torch.float32, device=h.device)
+    check(_lib.lib().gd_gat_aggregate_f32(ptr(graph.rowptr), ptr(graph.col), ptr(a_src), ptr(a_dst), ptr(h),
+                                          h.stride(0), ptr(y), y.stride(0), ptr(bias), ptr(alpha), float(slope), n, d,
+                                          stream_ptr(h.device)), 'gd_gat_aggregate_f32')
+    return y, alpha, None
+
+
+def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope):
+    """-> (dh message path, da_src, da_dst)."""
+    g = graph
+    n, d = g.n, h.shape[1]
+    dev = h.device
+    da_dst = torch.empty(n, dtype=torch.float32, device=dev)
+    de = torch.empty(g.nnz, dtype=torch.float32, device=dev)
+    if rowsum is None:                     # saved alpha from the row kernel
+        alpha = rowmax
+        dh = torch.empty_like(h)
+        da_src = torch.empty(n, dtype=torch.float32, device=dev)
+        check(_lib.lib().gd_gat_aggregate_bwd_f32(
+            ptr(g.rowptr), ptr(g.col), ptr(alpha), ptr(g.rowptr_t), ptr(g.col_t), ptr(g.perm_t), ptr(a_src),
+            ptr(a_dst), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(dh), dh.stride(0), ptr(da_src), ptr(da_dst),
+            ptr(de), float(slope), n, d, stream_ptr(dev)), 'gd_gat_aggregate_bwd_f32')
+        return dh, da_src, da_dst
+    plan = g.plan
+    alpha = torch.empty(g.nnz, dtype=torch.float32, device=dev)
+    t_row = torch.empty(n, dtype=torch.float32, device=dev)
+    scratch = plan.scratch_flat('gat_bwd', max(4, plan.n_slots), dev)
+    check(_lib.lib().gd_gat_edge_grads_balanced_f32(
+        ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split, ptr(g.col), ptr(a_src), ptr(a_dst), ptr(rowmax),
+        ptr(rowsum), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(alpha), ptr(de), ptr(da_dst), ptr(t_row),
+        ptr(scratch), float(slope), d, g.nnz, stream_ptr(dev)), 'gd_gat_edge_grads_balanced_f32')
+    perm = g.perm_t.long()
+    dh = _spmm_raw(g.rowptr_t, g.col_t, alpha[perm], dy, None, 0.0, n, g.plan_t)
+    da_src = torch.empty(n, dtype=torch.float32, device=dev)
+    check(_lib.lib().gd_segment_sum_f32(ptr(g.rowptr_t), ptr(g.perm_t), ptr(de), n, ptr(da_src), stream_ptr(dev)),
+          'gd_segment_sum_f32')
+    return dh, da_src, da_dst
+
+
+def row_dots(h, v1, v2):
+    """(h @ v1, h @ v2) in one pass (raw, no autograd)."""
+    h = _f32_rows(h)
+    n, d = h.shape
+    a1 = torch.empty(n, dtype=torch.float32, device=h.device)
+    a2 = torch.empty(n, dtype=torch.float32, device=h.device)
+    v1, v2 = v1.reshape(-1).contiguous(), v2.reshape(-1).contiguous()
+    if d % 4 or h.stride(0) % 4:
+        return h @ v1, h @ v2
+    check(_lib.lib().gd_row_dots_f32(ptr(h), h.stride(0), n, d, ptr(v1), ptr(v2), ptr(a1), ptr(a2),
+                                     stream_ptr(h.device)), 'gd_row_dots_f32')
+    return a1, a2
+
+
 class _GatAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, a_src, a_dst, bias, graph, slope):
         h = _f32_rows(h)
         a_src, a_dst = a_src.contiguous().float(), a_dst.contiguous().float()
-        n, d = graph.n, h.shape[1]
-        y = torch.empty(n, d, dtype=torch.float32, device=h.device)
-        need = any(ctx.needs_input_grad[:3])
-        alpha = torch.empty(graph.nnz, dtype=torch.float32, device=h.device) if need else None
-        check(_lib.lib().gd_gat_aggregate_f32(ptr(graph.rowptr), ptr(graph.col), ptr(a_src), ptr(a_dst), ptr(h),
-                                              h.stride(0), ptr(y), y.stride(0), ptr(bias), ptr(alpha), float(slope),
-                                              n, d, stream_ptr(h.device)), 'gd_gat_aggregate_f32')
-        ctx.graph, ctx.slope, ctx.has_bias = graph, slope, bias is not None
-        if need:
-            ctx.save_for_backward(h, a_src, a_dst, alpha)
+        y, rowmax, rowsum = gat_forward_raw(graph, h, a_src, a_dst, bias, slope)
+        ctx.graph, ctx.slope, ctx.has_bias, ctx.no_sum = graph, slope, bias is not None, rowsum is None
+        if any(ctx.needs_input_grad[:3]):
+            ctx.save_for_backward(h, a_src, a_dst, rowmax, rowsum if rowsum is not None else rowmax)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        h, a_src, a_dst, alpha = ctx.saved_tensors
-        g = ctx.graph
-        dy = _f32_rows(dy)
-        n, d = g.n, h.shape[1]
-        dh = torch.empty_like(h)
-        da_src = torch.empty(n, dtype=torch.float32, device=h.device)
-        da_dst = torch.empty(n, dtype=torch.float32, device=h.device)
-        de = torch.empty(g.nnz, dtype=torch.float32, device=h.device)
-        check(_lib.lib().gd_gat_aggregate_bwd_f32(
-            ptr(g.rowptr), ptr(g.col), ptr(alpha), ptr(g.rowptr_t), ptr(g.col_t), ptr(g.perm_t), ptr(a_src),
-            ptr(a_dst), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(dh), dh.stride(0), ptr(da_src), ptr(da_dst),
-            ptr(de), float(ctx.slope), n, d, stream_ptr(h.device)), 'gd_gat_aggregate_bwd_f32')
+        h, a_src, a_dst, rowmax, rowsum = ctx.saved_tensors
+        dh, da_src, da_dst = gat_backward_raw(ctx.graph, h, a_src, a_dst, rowmax, None if ctx.no_sum else rowsum,
+                                              _f32_rows(dy), ctx.slope)
         db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
         return dh, da_src, da_dst, db, None, None
 

@@ -98,6 +98,38 @@ int gd_gat_aggregate_bwd_f32(const int32_t* rowptr, const int32_t* col, const fl
                              float* da_src, float* da_dst, float* de, float slope,
                              int32_t n_rows, int32_t d, void* stream);
 
+/* Load-balanced forms of the two GAT entries over the work items of gd_spmm_csr_balanced_f32
+ * (<= 64 in-edges per item, hub rows spread over many waves).  Forward: every item computes a
+ * local softmax, the items of a split row are merged flash-attention style; instead of the
+ * per-edge attention it returns the row statistics rowmax[n] / rowsum[n] (alpha_k =
+ * exp(e_k - rowmax_i) / (rowsum_i + 1e-16)).  d must be a power of two in [4, 1024];
+ * scratch: gd_gat_balanced_scratch(n_slots, d) floats.
+ * gd_gat_edge_grads_balanced_f32 is the target-major half of the backward: alpha[nnz] (rebuilt),
+ * de[nnz] = d loss / d score, da_dst[n]; t_row[n] and scratch (n_slots floats) are work space.
+ * The source-major half (dh = sum alpha dy, da_src = sum de) is gd_spmm_csr_balanced_f32 on the
+ * transposed CSR with val = alpha permuted, plus a segment sum of de. */
+int64_t gd_gat_balanced_scratch(int32_t n_slots, int32_t d);
+int gd_gat_aggregate_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
+                                  int32_t n_slots, const int32_t* col, const float* a_src, const float* a_dst,
+                                  const float* h, int64_t ldh, float* y, int64_t ldy, const float* bias,
+                                  float* rowmax, float* rowsum, float* scratch, float slope,
+                                  int32_t d, int32_t nnz, void* stream);
+int gd_gat_edge_grads_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
+                                   const int32_t* col, const float* a_src, const float* a_dst,
+                                   const float* rowmax, const float* rowsum, const float* h, int64_t ldh,
+                                   const float* dy, int64_t lddy, float* alpha, float* de, float* da_dst,
+                                   float* t_row, float* scratch, float slope, int32_t d, int32_t nnz, void* stream);
+
+/* GAT attention logits: a1[i] = <h[i,:], v1>, a2[i] = <h[i,:], v2> in one pass over h
+ * (alpha_src / alpha_dst of GATConv.forward, framework/models/gat.py:11-12). */
+int gd_row_dots_f32(const float* h, int64_t ldh, int32_t n, int32_t d, const float* v1, const float* v2,
+                    float* a1, float* a2, void* stream);
+
+/* out[i] = sum of x[perm ? perm[k] : k] over k in [rowptr[i], rowptr[i+1]) - deterministic
+ * segment sum (the da_src reduction of the GAT backward). */
+int gd_segment_sum_f32(const int32_t* rowptr, const int32_t* perm, const float* x, int32_t n, float* out,
+                       void* stream);
+
 /* ---------------------------------------------------------------- Del operator --------- */
 
 /* Row-subset GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
