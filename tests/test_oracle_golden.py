@@ -20,9 +20,10 @@ def test_deletion_layer_matches_reference():
             layer.deletion_weight.copy_(t(fx[f'{tag}::w']))
         y = layer(x)
         y.backward(t(fx[f'{tag}::up']))
-        assert torch.equal(y.detach(), t(fx[f'{tag}::y'])), tag
-        assert torch.equal(x.grad, t(fx[f'{tag}::gx'])), tag
-        assert torch.equal(layer.deletion_weight.grad, t(fx[f'{tag}::gw'])), tag
+        # same op sequence as the reference; only the host BLAS may differ between machines
+        assert torch.allclose(y.detach(), t(fx[f'{tag}::y']), rtol=1e-5, atol=1e-6), tag
+        assert torch.allclose(x.grad, t(fx[f'{tag}::gx']), rtol=1e-5, atol=1e-6), tag
+        assert torch.allclose(layer.deletion_weight.grad, t(fx[f'{tag}::gw']), rtol=1e-5, atol=1e-6), tag
     x = t(fx['nomask::x'])
     assert R.DeletionLayer(4, None)(x) is x
     assert torch.equal(R.DeletionLayer(6, None).deletion_weight.detach(), t(fx['init::w']))
