@@ -57,14 +57,34 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
   const int n_tiles = (n_sel + 31) >> 5;
   const int r_lo = lane & 31;       // the sample (row of `in`) this lane owns
   const int khalf = lane >> 5;      // which 16-float half of each 32-wide k chunk
-  for (int tile = blockIdx.x * kWaves + wave; tile < n_tiles; tile += gridDim.x * kWaves) {
+  const int stride = gridDim.x * kWaves;
+  const int kchunks = d_in >> 5;
+
+  // Software pipeline over chunks AND tiles: while chunk kc feeds the matrix cores, chunk kc+1 -
+  // or chunk 0 of this wave's NEXT tile - is already in flight, so a tile never starts with an
+  // exposed index + HBM round trip.  All loads are unconditional (clamped rows), no branches.
+  auto row_of = [&](int tile_) -> int64_t {
+    const int s_ = min(tile_ * 32 + r_lo, n_sel - 1);
+    return idx ? (int64_t)idx[s_] : (int64_t)s_;
+  };
+  int tile = blockIdx.x * kWaves + wave;
+  if (tile >= n_tiles) return;
+  int64_t row_cur = row_of(tile);
+  int64_t row_nxt = row_of(min(tile + stride, n_tiles - 1));
+  float4 a_next[4];
+  {
+    const float4* src0 = reinterpret_cast<const float4*>(in + row_cur * ld_in) + khalf * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_next[i] = src0[i];
+  }
+  for (; tile < n_tiles; tile += stride) {
     const int s_a = tile * 32 + r_lo;
     const bool live = s_a < n_sel;
-    const int64_t row_a = live ? (idx ? idx[s_a] : s_a) : 0;
-    // lane (r_lo, khalf) owns 64 contiguous bytes of every 128-byte line of its row: the four
-    // float4 loads of a chunk touch the same 32 cache lines back to back (one L1 miss, 3 hits)
-    const float4* src = reinterpret_cast<const float4*>(in + row_a * ld_in) + khalf * 4;
+    const float4* src = reinterpret_cast<const float4*>(in + row_cur * ld_in) + khalf * 4;
+    const float4* src_n = reinterpret_cast<const float4*>(in + row_nxt * ld_in) + khalf * 4;
     float4* sav = save_in ? reinterpret_cast<float4*>(save_in + (int64_t)s_a * d_in) + khalf * 4 : nullptr;
+    // row index of the tile after next (consumed two iterations from now)
+    const int64_t row_nn = row_of(min(tile + 2 * stride, n_tiles - 1));
 
     f32x16 acc[NT];
 #pragma unroll
@@ -72,18 +92,13 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const int kchunks = d_in >> 5;
-    float4 a_next[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a_next[i] = live ? src[i] : f4_zero();
     for (int kc = 0; kc < kchunks; ++kc) {
       float4 a4[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a4[i] = a_next[i];
-      if (kc + 1 < kchunks) {
+      const float4* nsrc = (kc + 1 < kchunks) ? src + (kc + 1) * 8 : src_n;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_next[i] = live ? src[(kc + 1) * 8 + i] : f4_zero();
-      }
+      for (int i = 0; i < 4; ++i) a_next[i] = nsrc[i];
       if (sav && live) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) sav[kc * 8 + i] = a4[i];
@@ -112,7 +127,7 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
 
     // ---- epilogue: D[i][j], j = lane&31 = sample, i = (r&3) + 8*(r>>2) + 4*(lane>>5) = feature
     if (live) {
-      float* dst = out + row_a * ld_out + 4 * khalf;
+      float* dst = out + row_cur * ld_out + 4 * khalf;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -124,6 +139,8 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
         }
       }
     }
+    row_cur = row_nxt;
+    row_nxt = row_nn;
   }
 }
 
