@@ -8,9 +8,9 @@ import time
 import numpy as np
 import torch
 import torch.nn.functional as F
-from sklearn.metrics import average_precision_score, roc_auc_score
 
 from ..evaluation import verification_error
+from ..metrics import batched_average_precision, batched_roc_auc
 from ..utils import get_link_labels, negative_sampling_kg
 from .base import Trainer, _require_gpu, device
 from .gnndelete_nodeemb import _four_terms, _non_df_masks, get_loss_fct
@@ -71,8 +71,8 @@ class KGTrainer(Trainer):
         logits = model.decode(z, torch.cat([pos, neg], dim=-1), torch.cat([etype, etype], dim=-1))
         label = get_link_labels(pos, neg)
         loss = F.binary_cross_entropy_with_logits(logits, label).cpu().item()
-        dt_auc = roc_auc_score(label.cpu(), logits.cpu())
-        dt_aup = average_precision_score(label.cpu(), logits.cpu())
+        dt_auc = float(batched_roc_auc(logits, label)[0])
+        dt_aup = float(batched_average_precision(logits, label)[0])
 
         if self.args.unlearning_model in ['original']:
             df_logit = []
@@ -81,15 +81,14 @@ class KGTrainer(Trainer):
         if len(df_logit) > 0:
             half = data.dr_mask[:data.dr_mask.shape[0] // 2]
             dr_edges, dr_types = data.train_pos_edge_index[:, half], data.train_edge_type[half]
-            dr_score = model.decode(z, dr_edges, dr_types).sigmoid().cpu()
-            labels = [0] * len(df_logit) + [1] * len(df_logit)
-            df_auc, df_aup = [], []
-            for _ in range(500):
-                pick = torch.randperm(dr_edges.shape[1])[:len(df_logit)].sort().values
-                scores = df_logit + dr_score[pick].tolist()
-                df_auc.append(roc_auc_score(labels, scores))
-                df_aup.append(average_precision_score(labels, scores))
-            df_auc, df_aup = np.mean(df_auc), np.mean(df_aup)
+            k = len(df_logit)
+            dr_score = model.decode(z, dr_edges, dr_types).sigmoid()
+            picks = torch.stack([torch.randperm(dr_edges.shape[1])[:k].sort().values for _ in range(500)])
+            df_score = torch.tensor(df_logit, dtype=dr_score.dtype, device=dr_score.device)
+            scores = torch.cat([df_score[None].expand(500, k), dr_score[picks.to(dr_score.device)]], dim=1)
+            labels = torch.cat([torch.zeros(k), torch.ones(k)]).to(dr_score.device)
+            df_auc = float(batched_roc_auc(scores, labels).mean())
+            df_aup = float(batched_average_precision(scores, labels).mean())
         else:
             df_auc = df_aup = np.nan
         logit_all_pair = (z @ z.t()).cpu() if pred_all else None
