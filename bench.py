@@ -38,6 +38,7 @@ def parse():
     p.add_argument('--cpu_baseline_iters', type=int, default=8)
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_graph', action='store_true')
+    p.add_argument('--no_cached_rate', action='store_true')
     p.add_argument('--parallel', default='partition', choices=['partition', 'replicas'],
                    help='N>1: row-partition ONE request over the GPUs (RCCL all-gather + all-reduce, strong '
                         'scaling) or run N independent requests (no exchange, weak scaling)')
@@ -77,6 +78,8 @@ def make_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1):
     with torch.no_grad():
         z1o, z2o = model.get_original_embeddings(x, e_dr, return_all_emb=True)
     common = (model, x, e_sdf, z1o, z2o, E[:, data.df_mask.to(device)], neg.to(device), ni1, ni2)
+    global eng_args
+    eng_args = common
     if world > 1 and args.parallel == 'partition':
         # ONE request, rows partitioned over the ranks (strong scaling)
         from gnndelete_amd.dist_engine import PartitionedNodeembEngine
@@ -258,6 +261,20 @@ def main():
         }
         if note:
             out['config']['partition_fallback'] = note
+        if world == 1 and not args.no_cached_rate:
+            # informational only (never `value`): the same step with the loop-invariant frozen layer-1
+            # output computed once, which is how the trainer runs by default
+            from gnndelete_amd.engine import NodeembEngine
+            model.load_state_dict(state)
+            ceng = NodeembEngine(*eng_args, loss_type=args.loss_type, alpha=0.5, lr=1e-3, cache_layer1=True)
+            for _ in range(args.warmup):
+                ceng.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                ceng.step()
+            torch.cuda.synchronize()
+            out['extras'] = {'iters_per_s_with_loop_invariant_layer1_cached': args.steps / (time.perf_counter() - t1)}
         if not args.no_cpu_baseline and world == 1:
             cpu_data = data.clone().cpu() if hasattr(data, 'clone') else data
             out['cpu_baseline'] = cpu_baseline(args, cpu_data, state, neg, args.cpu_baseline_iters)

@@ -135,7 +135,7 @@ class NodeembEngine:
 
     def __init__(self, model, x, edge_index, z1_ori, z2_ori, pos_edge, neg_edge, ni_mask1, ni_mask2,
                  loss_type='both_layerwise', alpha=0.5, lr=1e-3, reduction='mean', mask_1hop=None, mask_2hop=None,
-                 use_graph=True, history=4096, reorder=True):
+                 use_graph=True, history=4096, reorder=True, cache_layer1=False):
         assert loss_type in LOSS_TYPES, loss_type
         conv1, conv2 = model.conv1, model.conv2
         if not isinstance(conv2, (GCNConv, GINConv, GATConv)):
@@ -145,8 +145,11 @@ class NodeembEngine:
             raise _lib.GnnDeleteHipError('NodeembEngine needs CUDA(HIP) tensors (no CPU fallback)')
         self.model, self.loss_type, self.alpha = model, loss_type, alpha
         self.n = n = x.shape[0]
-        m1 = (model.deletion1.mask if mask_1hop is None else mask_1hop).to(dev)
-        m2 = (model.deletion2.mask if mask_2hop is None else mask_2hop).to(dev)
+        none = torch.zeros(n, dtype=torch.bool)           # a model built without masks: Del = identity
+        m1 = model.deletion1.mask if mask_1hop is None else mask_1hop
+        m2 = model.deletion2.mask if mask_2hop is None else mask_2hop
+        m1 = (none if m1 is None else m1).to(dev)
+        m2 = (none if m2 is None else m2).to(dev)
         ni_mask1, ni_mask2 = ni_mask1.to(dev), ni_mask2.to(dev)
         pos_edge, neg_edge = pos_edge.to(dev), neg_edge.to(dev)
         self.perm = None
@@ -198,6 +201,16 @@ class NodeembEngine:
         self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat'}[type(conv2)]
         gmode = {'gcn': 'gcn', 'gin': 'sum', 'gat': 'gat'}[self._mode]
         self.graph = graph_for(edge_index, n, gmode)
+        # Optional: the frozen layer-1 output p1 = conv1(x) is loop-invariant (fixed x, edges and
+        # weights), so it can be computed once.  OFF by default: upstream recomputes it every epoch and
+        # the benchmark's `value` is measured that way; the trainer turns it on (identical results).
+        self.cache_layer1 = cache_layer1
+        if cache_layer1:
+            with torch.no_grad():
+                self._conv1_forward()
+                self.p1 = self.z1.clone()
+                if self.s1:
+                    self.xs1.copy_(self.p1[self.idx1.long()])
 
     # ------------------------------------------------------------------ pieces
     def _linear(self, x, weight, relu_in=False):
@@ -290,8 +303,11 @@ class NodeembEngine:
         side = self._side
         with torch.no_grad():
             # ---- forward, layer 1
-            self._conv1_forward()
-            ops.rows_gemm(self.z1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1)
+            if self.cache_layer1:
+                ops.rows_gemm(self.p1, self.idx1, self.wd1, out=self.z1)     # unmasked rows of z1 stay = p1
+            else:
+                self._conv1_forward()
+                ops.rows_gemm(self.z1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1)
             self.sums.zero_()
             # ---- fork: layer-1 loss branch
             side.wait_stream(main)

@@ -195,7 +195,8 @@ class _EmbeddingUnlearner:
             engine = NodeembEngine(model, data.x, e_sdf, z1_ori, z2_ori, pos_edge, neg_edge, ni1, ni2,
                                    loss_type=loss_type, alpha=self.args.alpha, lr=lr,
                                    reduction='mean' if loss_name == 'mse_mean' else 'sum',
-                                   history=max(16, args.epochs))
+                                   history=max(16, args.epochs),
+                                   cache_layer1=not getattr(args, 'no_layer1_cache', False))
             engine.adam1.betas = engine.adam2.betas = betas
             engine.adam1.eps = engine.adam2.eps = eps
         loss_fct = get_loss_fct(loss_name)

@@ -66,6 +66,7 @@ FLAGS = [
 EXTRA_FLAGS = [
     ('minibatch', None, False, 'train ogbl-* graphs on GraphSAINT mini-batches as upstream does (default: full graph)'),
     ('no_fused_step', None, False, 'use the autograd path even where the fused hipGraph step applies'),
+    ('no_layer1_cache', None, False, 'recompute the frozen layer-1 output every epoch as upstream does (identical results)'),
 ]
 
 

@@ -142,3 +142,39 @@ def test_internal_reordering_does_not_change_the_result():
                     e.loss_history()))
     assert rel_l2(out[1][0], out[0][0]) < 1e-4 and rel_l2(out[1][1], out[0][1]) < 1e-4
     np.testing.assert_allclose(out[1][2].numpy(), out[0][2].numpy(), rtol=1e-4)
+
+
+def test_layer1_cache_and_maskless_model():
+    """cache_layer1=True (loop-invariant frozen layer computed once) gives the same trajectory;
+    a model built WITHOUT Del masks (upstream's delete_node.py) trains nothing and stays finite."""
+    a, ma, rest = make_engine('gcn', 'both_layerwise', True, load_golden('traj_gcn_both_all.npz'))
+    from gnndelete_amd.engine import NodeembEngine
+    fx = load_golden('traj_gcn_both_all.npz')
+    state, data, rest = split_fixture(fx)
+    from oracle import gnndelete_ref as R
+    outs = []
+    for cache in (False, True):
+        m = hip_model('gcn', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+        dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+        E = dev['train_pos_edge_index']
+        ni1, ni2 = R.non_df_masks(data['x'].shape[0], data['directed_df_edge_index'], data['sdf_node_1hop_mask'],
+                                  data['sdf_node_2hop_mask'])
+        with torch.no_grad():
+            z1o, z2o = m.get_original_embeddings(dev['x'], E[:, dev['dr_mask']], return_all_emb=True)
+        e = NodeembEngine(m, dev['x'], E[:, dev['sdf_mask']].contiguous(), z1o, z2o, E[:, dev['df_mask']],
+                          t(rest['neg']).cuda(), ni1, ni2, loss_type='both_layerwise', alpha=0.4, lr=0.01,
+                          cache_layer1=cache)
+        for _ in range(6):
+            e.step()
+        outs.append((m.deletion1.deletion_weight.detach().cpu(), e.loss_history()))
+    assert rel_l2(outs[1][0], outs[0][0]) < 1e-5
+    np.testing.assert_allclose(outs[1][1].numpy(), outs[0][1].numpy(), rtol=1e-5)
+
+    m = hip_model('gcn', state, None, None)
+    e = NodeembEngine(m, dev['x'], E[:, dev['sdf_mask']].contiguous(), z1o, z2o, E[:, dev['df_mask']],
+                      t(rest['neg']).cuda(), ni1, ni2, loss_type='both_layerwise')
+    w0 = m.deletion1.deletion_weight.detach().clone()
+    for _ in range(3):
+        e.step()
+    assert e.s1 == 0 and e.s2 == 0 and torch.equal(m.deletion1.deletion_weight.detach(), w0)
+    assert torch.isfinite(e.loss_history()).all()
