@@ -3,7 +3,8 @@ factories (get_model / get_trainer), registry names and class names (framework/_
 Registry entries whose upstream implementation is outside the hot path (competing baselines,
 membership-inference attack, the unfinished graph_eraser / missing graph_editor) are not built;
 asking for one raises NotImplementedError naming it."""
-from .models import GAT, GCN, GIN, RGCN, GATDelete, GCNDelete, GINDelete, RGCNDelete  # noqa: F401
+from .models import (GAT, GCN, GIN, RGCN, SAGE, GATDelete, GCNDelete, GINDelete, RGCNDelete,  # noqa: F401
+                     SAGEDelete)
 from .trainer.base import NodeClassificationTrainer, Trainer
 from .trainer.gnndelete_nodeemb import GNNDeleteNodeClassificationTrainer, GNNDeleteNodeembTrainer
 
@@ -36,9 +37,9 @@ def _lazy_trainers():
 
 def get_model(args, mask_1hop=None, mask_2hop=None, num_nodes=None, num_edge_type=None):
     if 'gnndelete' in args.unlearning_model:
-        model_mapping = {'gcn': GCNDelete, 'gat': GATDelete, 'gin': GINDelete, 'rgcn': RGCNDelete}
+        model_mapping = {'gcn': GCNDelete, 'gat': GATDelete, 'gin': GINDelete, 'rgcn': RGCNDelete, 'sage': SAGEDelete}
     else:
-        model_mapping = {'gcn': GCN, 'gat': GAT, 'gin': GIN, 'rgcn': RGCN}
+        model_mapping = {'gcn': GCN, 'gat': GAT, 'gin': GIN, 'rgcn': RGCN, 'sage': SAGE}
     if args.gnn not in model_mapping:
         raise NotImplementedError(f"gnn '{args.gnn}' is outside the hot-path scope of this build (have: "
                                   f"{sorted(model_mapping)})")

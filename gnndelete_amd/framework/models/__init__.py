@@ -1,5 +1,5 @@
-from .backbones import GAT, GCN, GIN, RGCN
-from .deletion import DeletionLayer, DeletionLayerKG, GATDelete, GCNDelete, GINDelete, RGCNDelete
+from .backbones import GAT, GCN, GIN, RGCN, SAGE
+from .deletion import DeletionLayer, DeletionLayerKG, GATDelete, GCNDelete, GINDelete, RGCNDelete, SAGEDelete
 
 __all__ = ['GCN', 'GAT', 'GIN', 'RGCN', 'DeletionLayer', 'DeletionLayerKG', 'GCNDelete', 'GATDelete',
-           'GINDelete', 'RGCNDelete']
+           'GINDelete', 'RGCNDelete', 'SAGE', 'SAGEDelete']

@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...nn import GATConv, GCNConv, GINConv, RGCNConv
+from ...nn import GATConv, GCNConv, GINConv, RGCNConv, SAGEConv
 
 
 class _Homogeneous(nn.Module):
@@ -46,6 +46,14 @@ class GIN(_Homogeneous):
     def _make_convs(self, args):
         return (GINConv(nn.Linear(args.in_dim, args.hidden_dim)),
                 GINConv(nn.Linear(args.hidden_dim, args.out_dim)))
+
+
+class SAGE(_Homogeneous):
+    """2-layer GraphSAGE (mean) - not in the reference's registry; added because BASELINE.json's
+    config 3 names it.  Same wiring and decoder as GCN / GAT / GIN."""
+
+    def _make_convs(self, args):
+        return SAGEConv(args.in_dim, args.hidden_dim), SAGEConv(args.hidden_dim, args.out_dim)
 
 
 class RGCN(nn.Module):

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from .backbones import GAT, GCN, GIN, RGCN
+from .backbones import GAT, GCN, GIN, RGCN, SAGE
 
 
 class _RowList:
@@ -113,3 +113,4 @@ GCNDelete = _with_deletion(GCN)
 GATDelete = _with_deletion(GAT)
 GINDelete = _with_deletion(GIN)
 RGCNDelete = _with_deletion(RGCN)
+SAGEDelete = _with_deletion(SAGE)

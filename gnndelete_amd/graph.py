@@ -6,6 +6,7 @@ Three aggregation flavours, matching what each torch_geometric conv does to the 
   'gcn'  drop existing self loops, append exactly one per node, val = D^-1/2 (A+I) D^-1/2
   'gat'  same structure, no values (attention is computed by the kernel)
   'sum'  edges as given (GIN), no values
+  'mean' edges as given, val = 1 / in-degree of the target (GraphSAGE mean aggregation)
 Rows are sorted by (target, source), so the per-row summation order is deterministic.
 """
 import torch
@@ -90,7 +91,7 @@ def _sorted_csr(src, dst, n):
 
 
 def build_csr(edge_index, num_nodes, mode='gcn'):
-    assert mode in ('gcn', 'gat', 'sum')
+    assert mode in ('gcn', 'gat', 'sum', 'mean')
     assert edge_index.dim() == 2 and edge_index.shape[0] == 2
     dev = edge_index.device
     n = int(num_nodes)
@@ -115,6 +116,12 @@ def build_csr(edge_index, num_nodes, mode='gcn'):
             raise _lib.GnnDeleteHipError('build_csr(mode="gcn") needs a GPU tensor: gcn_norm runs in the HIP library')
         _lib.check(_lib.lib().gd_gcn_norm_f32(rowptr.data_ptr(), col.data_ptr(), n, val.data_ptr(),
                                               _lib.stream_ptr(dev)), 'gd_gcn_norm_f32')
+        val_t = val[perm_t.long()]
+    elif mode == 'mean':
+        # 1 / in-degree on every in-edge (SAGE mean aggregation); rows without in-edges stay empty
+        deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32).clamp(min=1.0)
+        rows = torch.repeat_interleave(torch.arange(n, device=dev), (rowptr[1:] - rowptr[:-1]).long())
+        val = (1.0 / deg)[rows]
         val_t = val[perm_t.long()]
     return CSRGraph(n, rowptr, col, val, rowptr_t, col_t, val_t, perm_t, mode)
 

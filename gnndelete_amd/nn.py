@@ -85,6 +85,26 @@ class GINConv(nn.Module):
         return self.nn(ops.spmm(x, g, None, 1.0 + self.eps))
 
 
+class SAGEConv(nn.Module):
+    """GraphSAGE, mean aggregation: W_l mean_j x_j + b_l + W_r x_i (PyG parameter names lin_l /
+    lin_r).  Extension: the reference has no SAGE model, BASELINE.json's config 3 names one.  The
+    neighbour transform is applied before the (linear) mean when the layer narrows."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin_l = nn.Linear(in_channels, out_channels)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, x, edge_index):
+        g = graph_for(edge_index, x.shape[0], 'mean')
+        if self.out_channels <= self.in_channels:
+            agg = ops.spmm(F.linear(x, self.lin_l.weight), g, self.lin_l.bias)
+        else:
+            agg = self.lin_l(ops.spmm(x, g))
+        return agg + self.lin_r(x)
+
+
 class RGCNConv(nn.Module):
     """aggr='mean', root_weight, bias; dense [R, in, out] or block-diagonal
     [R, num_blocks, in/nb, out/nb] relation weights."""

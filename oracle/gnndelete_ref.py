@@ -61,6 +61,8 @@ def _make_convs(gnn, in_dim, hidden, out_dim, num_edge_type=None):
         return pyg.GATConv(in_dim, hidden), pyg.GATConv(hidden, out_dim)
     if gnn == 'gin':
         return pyg.GINConv(nn.Linear(in_dim, hidden)), pyg.GINConv(nn.Linear(hidden, out_dim))
+    if gnn == 'sage':
+        return pyg.SAGEConv(in_dim, hidden), pyg.SAGEConv(hidden, out_dim)
     if gnn == 'rgcn':
         nb = 4 if num_edge_type > 20 else None          # rgcn.py:17-22
         return (pyg.RGCNConv(in_dim, hidden, 2 * num_edge_type, nb),

@@ -142,6 +142,18 @@ def gin_conv(x, edge_index, weight, bias, eps=0.0):
     return F.linear((1.0 + eps) * x + agg, weight, bias)
 
 
+def sage_conv(x, edge_index, w_l, b_l, w_r):
+    """SAGEConv (aggr='mean', root_weight=True, bias on lin_l only, no loops, no normalisation):
+    out_i = W_l mean_{j->i} x_j + b_l + W_r x_i ; a node without in-edges aggregates zeros.
+    NOT used by the reference (it has no SAGE model; BASELINE.json config 3 names one) - an
+    extension pinned only by the dense known-answer test."""
+    n = x.shape[0]
+    src, dst = edge_index[0], edge_index[1]
+    cnt = torch.zeros(n, dtype=x.dtype).index_add_(0, dst, torch.ones(src.shape[0], dtype=x.dtype))
+    mean = scatter_rows(x[src], dst, n) / cnt.clamp(min=1.0)[:, None]
+    return F.linear(mean, w_l, b_l) + F.linear(x, w_r)
+
+
 def rgcn_conv(x, edge_index, edge_type, weight, root, bias, num_blocks=None):
     """RGCNConv(aggr='mean', root_weight=True): per relation r, mean of x_j over the
     in-edges of type r, times W_r (dense [in,out] or block-diagonal
@@ -215,6 +227,17 @@ class GINConv(nn.Module):
 
     def forward(self, x, edge_index):
         return gin_conv(x, edge_index, self.nn.weight, self.nn.bias, self.eps)
+
+
+class SAGEConv(nn.Module):
+    """keys: lin_l.weight, lin_l.bias, lin_r.weight"""
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.lin_l = nn.Linear(in_dim, out_dim)
+        self.lin_r = nn.Linear(in_dim, out_dim, bias=False)
+
+    def forward(self, x, edge_index):
+        return sage_conv(x, edge_index, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight)
 
 
 class RGCNConv(nn.Module):

@@ -31,6 +31,8 @@ def dims_from_state(gnn, state):
         w1, w2 = state['conv1.lin_src.weight'], state['conv2.lin_src.weight']
     elif gnn == 'gin':
         w1, w2 = state['conv1.nn.weight'], state['conv2.nn.weight']
+    elif gnn == 'sage':
+        w1, w2 = state['conv1.lin_l.weight'], state['conv2.lin_l.weight']
     else:
         r1, r2 = state['conv1.root'], state['conv2.root']
         return r1.shape[0], r1.shape[1], r2.shape[1]
@@ -67,7 +69,7 @@ def hip_model(gnn, state, mask1=None, mask2=None, num_nodes=None, num_edge_type=
     from gnndelete_amd.framework import models as M
     i, h, o = dims_from_state(gnn, state)
     args = SimpleNamespace(in_dim=i, hidden_dim=h, out_dim=o)
-    cls = {'gcn': M.GCNDelete, 'gat': M.GATDelete, 'gin': M.GINDelete, 'rgcn': M.RGCNDelete}[gnn]
+    cls = {'gcn': M.GCNDelete, 'gat': M.GATDelete, 'gin': M.GINDelete, 'rgcn': M.RGCNDelete, 'sage': M.SAGEDelete}[gnn]
     if gnn == 'rgcn':
         m = cls(args, num_nodes, num_edge_type, mask1, mask2)
     else:

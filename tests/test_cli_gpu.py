@@ -48,7 +48,8 @@ def test_trainer_eval_matches_reference_golden(tmp_path):
 
 @pytest.mark.parametrize('gnn,method,loss_type', [('gcn', 'gnndelete_nodeemb', 'both_layerwise'),
                                                   ('gat', 'gnndelete_nodeemb', 'both_all'),
-                                                  ('gin', 'gnndelete', 'both_layerwise')])
+                                                  ('gin', 'gnndelete', 'both_layerwise'),
+                                                  ('sage', 'gnndelete_nodeemb', 'both_layerwise')])
 def test_cli_pipeline(tmp_path, gnn, method, loss_type):
     cwd = str(tmp_path)
     run([os.path.join(ROOT, 'prepare_dataset.py'), '--dataset', 'synth-tiny', '--seeds', '42'], cwd)

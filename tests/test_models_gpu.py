@@ -93,3 +93,35 @@ def test_training_trajectory_matches_reference_loop(gnn, loss_type):
         np.testing.assert_allclose(np.array([l[key] for l in logs]), rest[key], rtol=1e-4, atol=1e-8, err_msg=key)
     assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), rest['final_w1']) < TOL
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < TOL
+
+
+def test_sage_extension_matches_oracle_forward_and_gradients():
+    """GraphSAGE (mean) - named by BASELINE.json config 3, absent from the reference: the HIP model
+    against the oracle restatement (itself pinned by a dense KAT only)."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework import get_model
+    from oracle import gnndelete_ref as R
+    from helpers import random_graph
+    torch.manual_seed(1)
+    n, f = 400, 24
+    ei = random_graph(n, 2500, seed=5, isolate=4)
+    x = torch.randn(n, f)
+    m1, m2 = torch.rand(n) < 0.4, torch.rand(n) < 0.7
+    args = SimpleNamespace(unlearning_model='gnndelete_nodeemb', gnn='sage', in_dim=f, hidden_dim=128, out_dim=64)
+    hip = get_model(args, m1, m2)
+    with torch.no_grad():
+        hip.deletion1.deletion_weight.copy_(torch.eye(128) * 0.5 + 0.02 * torch.randn(128, 128))
+        hip.deletion2.deletion_weight.copy_(torch.eye(64) * 0.5 + 0.02 * torch.randn(64, 64))
+    ref = R.TwoLayerDelete('sage', f, 128, 64, m1, m2)
+    ref.load_state_dict(hip.state_dict())
+    hip = hip.cuda()
+    z1, z2 = hip(x.cuda(), ei.cuda(), return_all_emb=True)
+    r1, r2 = ref(x, ei, return_all_emb=True)
+    assert rel_l2(z1.detach().cpu(), r1.detach()) < TOL and rel_l2(z2.detach().cpu(), r2.detach()) < TOL
+    (z1.pow(2).mean() + z2.pow(2).mean()).backward()
+    (r1.pow(2).mean() + r2.pow(2).mean()).backward()
+    assert rel_l2(hip.deletion1.deletion_weight.grad.cpu(), ref.deletion1.deletion_weight.grad) < TOL
+    assert rel_l2(hip.deletion2.deletion_weight.grad.cpu(), ref.deletion2.deletion_weight.grad) < TOL
+    o1, o2 = hip.get_original_embeddings(x.cuda(), ei.cuda(), return_all_emb=True)
+    q1, q2 = ref.get_original_embeddings(x, ei, return_all_emb=True)
+    assert rel_l2(o2.detach().cpu(), q2.detach()) < TOL

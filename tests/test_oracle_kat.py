@@ -159,3 +159,18 @@ def test_module_state_dict_keys_are_pygs():
     assert set(pyg.GINConv(nn.Linear(3, 2)).state_dict()) == {'nn.weight', 'nn.bias'}
     assert set(pyg.RGCNConv(4, 4, 6, 2).state_dict()) == {'weight', 'root', 'bias'}
     assert pyg.RGCNConv(4, 4, 6, 2).weight.shape == (6, 2, 2, 2)
+
+
+def test_sage_conv_is_row_mean_plus_root():
+    n, f, o = 12, 5, 3
+    ei = rand_graph(n, 28, 9)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(n, f, generator=g, dtype=torch.float64)
+    wl = torch.randn(o, f, generator=g, dtype=torch.float64)
+    wr = torch.randn(o, f, generator=g, dtype=torch.float64)
+    bl = torch.randn(o, generator=g, dtype=torch.float64)
+    a = dense_adj(ei, n)
+    a = a / a.sum(1).clamp(min=1)[:, None]
+    want = (a @ x) @ wl.t() + bl + x @ wr.t()
+    assert torch.allclose(pyg.sage_conv(x, ei, wl, bl, wr), want, atol=1e-12)
+    assert set(pyg.SAGEConv(3, 2).state_dict()) == {'lin_l.weight', 'lin_l.bias', 'lin_r.weight'}
