@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libgnndelete_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'gnndelete_hip.h')
 
-_i32, _i64, _f32, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+_i32, _i64, _f32, _f64, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
 # name -> (restype, argtypes); must list every symbol the header declares
 PROTOTYPES = {
@@ -40,7 +40,12 @@ PROTOTYPES = {
     'gd_rowtarget_mse_workspace': (_i64, [_i32]),
     'gd_rowtarget_mse_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p, _p, _p]),
     'gd_edge_dot_f32': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p]),
-    'gd_adam_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _p]),
+    'gd_rows_gemm_wgrad_adam_f32': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _p, _i32, _i32, _i32, _p, _i32, _p,
+                                                   _p, _p, _p, _p, _f64, _f64, _f64, _f64, _p]),
+    'gd_rowtarget_mse_blocks': (_i32, [_i32]),
+    'gd_loss_finalize_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p]),
+    'gd_adam_at_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _p]),
+    'gd_adam_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _p]),
 }
 
 _lib = None

@@ -54,6 +54,30 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// torch.optim.Adam (single-tensor CPU path: lerp_, mul_/addcmul_, sqrt/div/add_, addcdiv_) with the
+// rounding sequence of that path spelled out, so every kernel that applies it (stand-alone or in a
+// reduction epilogue) is bit-identical to the others: hyper-parameters arrive as the Python doubles the
+// optimizer holds and are derived in fp64 before one rounding to fp32, as torch's scalar handling does.
+struct AdamScalars { float w1, b2, c2, neg_step, rs, eps; };
+__device__ __forceinline__ AdamScalars adam_scalars(double lr, double beta1, double beta2, double eps, int t) {
+  const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+  AdamScalars s;
+  s.w1 = (float)(1.0 - beta1);
+  s.b2 = (float)beta2;
+  s.c2 = (float)(1.0 - beta2);
+  s.neg_step = (float)(-(lr / bc1));
+  s.rs = (float)sqrt(bc2);
+  s.eps = (float)eps;
+  return s;
+}
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, const AdamScalars& s) {
+#pragma clang fp contract(off)
+  m = __builtin_fmaf(g - m, s.w1, m);                       // exp_avg.lerp_(grad, 1 - beta1)
+  v = __builtin_fmaf(s.c2 * g, g, v * s.b2);                // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+  const float den = sqrtf(v) / s.rs + s.eps;           // (sqrt / sqrt(bc2)).add_(eps)
+  p = p + (s.neg_step * m) / den;                           // param.addcdiv_(exp_avg, denom, -step_size)
+}
+
 // Bijective remap of the hardware block id so that the blocks resident on one XCD (b % 8) cover a
 // contiguous range of logical block ids (placement is a speed assumption only, never correctness).
 __device__ __forceinline__ int xcd_contiguous_block(int b, int n_blocks) {

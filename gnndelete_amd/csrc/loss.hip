@@ -212,27 +212,62 @@ __global__ __launch_bounds__(256) void edge_dot_scalar_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                    float* __restrict__ m, float* __restrict__ v,
-                                                   int32_t* __restrict__ step, int64_t n, float lr, float beta1,
-                                                   float beta2, float eps) {
+                                                   int32_t* __restrict__ step, int64_t n, double lr, double beta1,
+                                                   double beta2, double eps) {
   // every thread reads the pre-increment counter; thread 0 of the LAST block bumps it.  The
   // grid is small (Del weights: 20k elements) so all blocks read before that block retires in
   // practice, but correctness must not rely on it: the bump is done by a separate kernel.
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const int t = *step + 1;
-  const double bc1 = 1.0 - pow((double)beta1, (double)t);
-  const double bc2 = 1.0 - pow((double)beta2, (double)t);
-  const float g = grad[i];
-  const float mi = m[i] + (g - m[i]) * (1.0f - beta1);           // exp_avg.lerp_(grad, 1-beta1)
-  const float vi = fmaf(1.0f - beta2, g * g, beta2 * v[i]);      // mul_(beta2).addcmul_(g, g, 1-beta2)
-  m[i] = mi;
-  v[i] = vi;
-  const float step_size = (float)((double)lr / bc1);
-  const float denom = sqrtf(vi) / (float)sqrt(bc2) + eps;
-  param[i] = param[i] - step_size * (mi / denom);
+  const AdamScalars sc = adam_scalars(lr, beta1, beta2, eps, *step + 1);
+  float pi = param[i], mi = m[i], vi = v[i];
+  adam_update(pi, mi, vi, grad[i], sc);
+  param[i] = pi; m[i] = mi; v[i] = vi;
 }
 
 __global__ void bump_step_kernel(int32_t* step) { *step += 1; }
+
+// Adam whose step number is read from a shared iteration counter (t = *iter + 1, not modified)
+__global__ __launch_bounds__(256) void adam_at_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                      float* __restrict__ m, float* __restrict__ v,
+                                                      const int32_t* __restrict__ iter, int64_t n, double lr,
+                                                      double beta1, double beta2, double eps) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const AdamScalars sc = adam_scalars(lr, beta1, beta2, eps, *iter + 1);
+  float pi = param[i], mi = m[i], vi = v[i];
+  adam_update(pi, mi, vi, grad[i], sc);
+  param[i] = pi; m[i] = mi; v[i] = vi;
+}
+
+// One block: reduce the per-block partial sums of both layers' loss kernels in a fixed order, append
+// the four sums (r1, l1, r2, l2) to the device-side history ring and advance the ring position and
+// the iteration counter.  Replaces memset + 2 reductions + 3 tiny index kernels per step.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ p1, int32_t n1,
+                                                            const float* __restrict__ p2, int32_t n2,
+                                                            const float* __restrict__ extra, float* __restrict__ hist,
+                                                            int32_t capacity, int32_t* __restrict__ pos,
+                                                            int32_t* __restrict__ iter) {
+  __shared__ float red[4][256];
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+  for (int i = threadIdx.x; i < n1; i += 256) { a += p1[2 * i]; b += p1[2 * i + 1]; }
+  for (int i = threadIdx.x; i < n2; i += 256) { c += p2[2 * i]; d += p2[2 * i + 1]; }
+  red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = c; red[3][threadIdx.x] = d;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) hist[(int64_t)(*pos) * 4 + threadIdx.x] = red[threadIdx.x][0] + (extra ? extra[threadIdx.x] : 0.f);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *pos = (*pos + 1) % capacity;
+    *iter += 1;
+  }
+}
 
 }  // namespace gd
 
@@ -285,7 +320,7 @@ extern "C" int gd_rowtarget_mse_f32(const float* z, int64_t ld_z, const float* t
                                     const float* coef, const float* cnt, const int32_t* kind, int32_t n_rows,
                                     float* dz, int64_t ld_dz, float* sums, float* partials, void* stream) {
   using namespace gd;
-  GD_REQUIRE(sums && partials, GD_E_NULL, "gd_rowtarget_mse_f32: null sums/partials");
+  GD_REQUIRE(partials, GD_E_NULL, "gd_rowtarget_mse_f32: null partials");
   if (n_rows == 0) return GD_OK;
   GD_REQUIRE(z && tm && row_idx && coef && cnt && kind && dz, GD_E_NULL, "gd_rowtarget_mse_f32: null pointer");
   GD_REQUIRE(d > 0 && d % 4 == 0 && d <= 1024 && ld_z % 4 == 0 && ld_dz % 4 == 0, GD_E_DIM,
@@ -312,7 +347,7 @@ extern "C" int gd_rowtarget_mse_f32(const float* z, int64_t ld_z, const float* t
   }
 #undef GD_RT_CASE
   int rc = launched("rowtarget_mse");
-  if (rc) return rc;
+  if (rc || !sums) return rc;          // sums == NULL: the caller reduces the partials (gd_loss_finalize_f32)
   hipLaunchKernelGGL(pair_sum_reduce_kernel, dim3(1), dim3(256), 0, s, partials, nb, sums);
   return launched("pair_sum_reduce");
 }
@@ -355,8 +390,31 @@ extern "C" int gd_edge_dot_f32(const float* z, int64_t ld_z, int32_t d, const in
   return launched("edge_dot");
 }
 
+extern "C" int32_t gd_rowtarget_mse_blocks(int32_t n_rows) { return (n_rows + 255) / 256; }
+
+extern "C" int gd_loss_finalize_f32(const float* partials1, int32_t n1, const float* partials2, int32_t n2,
+                                    const float* extra_sums, float* hist, int32_t capacity, int32_t* pos,
+                                    int32_t* iter, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(hist && pos && iter && capacity > 0, GD_E_NULL, "gd_loss_finalize_f32: null pointer");
+  GD_REQUIRE((n1 == 0 || partials1) && (n2 == 0 || partials2), GD_E_NULL, "gd_loss_finalize_f32: null partials");
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials1, n1, partials2, n2,
+                     extra_sums, hist, capacity, pos, iter);
+  return launched("loss_finalize");
+}
+
+extern "C" int gd_adam_at_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int32_t* iter,
+                              int64_t n, double lr, double beta1, double beta2, double eps, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(param && grad && exp_avg && exp_avg_sq && iter, GD_E_NULL, "gd_adam_at_f32: null pointer");
+  if (n <= 0) return GD_OK;
+  hipLaunchKernelGGL(adam_at_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param,
+                     grad, exp_avg, exp_avg_sq, iter, n, lr, beta1, beta2, eps);
+  return launched("adam_at");
+}
+
 extern "C" int gd_adam_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t* step,
-                           int64_t n, float lr, float beta1, float beta2, float eps, void* stream) {
+                           int64_t n, double lr, double beta1, double beta2, double eps, void* stream) {
   using namespace gd;
   GD_REQUIRE(param && grad && exp_avg && exp_avg_sq && step, GD_E_NULL, "gd_adam_f32: null pointer");
   GD_REQUIRE(n >= 0, GD_E_DIM, "gd_adam_f32: n < 0");

@@ -343,6 +343,47 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// Same reduction with torch.optim.Adam applied to the freshly reduced gradient in the epilogue
+// (t = *iter + 1 from the shared iteration counter): saves the separate optimizer launch.
+__global__ __launch_bounds__(256) void wgrad_reduce_adam_kernel(const float* __restrict__ partials, int32_t n_part,
+                                                                int32_t n_elem, int32_t accumulate,
+                                                                float* __restrict__ dw, float* __restrict__ param,
+                                                                float* __restrict__ m, float* __restrict__ v,
+                                                                const int32_t* __restrict__ iter, double lr, double beta1,
+                                                                double beta2, double eps) {
+  __shared__ float4 red[16][16];
+  const int vv = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int e4 = blockIdx.x * 16 + vv;
+  const int n4 = n_elem >> 2;
+  float4 s0 = f4_zero(), s1 = f4_zero();
+  if (e4 < n4) {
+    int b = slice;
+    for (; b + 16 < n_part; b += 32) {
+      s0 = f4_add(s0, reinterpret_cast<const float4*>(partials + (int64_t)b * n_elem)[e4]);
+      s1 = f4_add(s1, reinterpret_cast<const float4*>(partials + (int64_t)(b + 16) * n_elem)[e4]);
+    }
+    if (b < n_part) s0 = f4_add(s0, reinterpret_cast<const float4*>(partials + (int64_t)b * n_elem)[e4]);
+  }
+  red[slice][vv] = f4_add(s0, s1);
+  __syncthreads();
+  if (slice == 0 && e4 < n4) {
+    float4 t4 = accumulate ? reinterpret_cast<float4*>(dw)[e4] : f4_zero();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t4 = f4_add(t4, red[i][vv]);
+    reinterpret_cast<float4*>(dw)[e4] = t4;
+    const AdamScalars sc = adam_scalars(lr, beta1, beta2, eps, *iter + 1);
+    float4 p4 = reinterpret_cast<float4*>(param)[e4], m4 = reinterpret_cast<float4*>(m)[e4],
+           v4 = reinterpret_cast<float4*>(v)[e4];
+    adam_update(p4.x, m4.x, v4.x, t4.x, sc);
+    adam_update(p4.y, m4.y, v4.y, t4.y, sc);
+    adam_update(p4.z, m4.z, v4.z, t4.z, sc);
+    adam_update(p4.w, m4.w, v4.w, t4.w, sc);
+    reinterpret_cast<float4*>(param)[e4] = p4;
+    reinterpret_cast<float4*>(m)[e4] = m4;
+    reinterpret_cast<float4*>(v)[e4] = v4;
+  }
+}
+
 // any n_elem (not a multiple of 4): one thread per element
 __global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* __restrict__ partials, int32_t n_part,
                                                                   int32_t n_elem, int32_t accumulate,
@@ -411,9 +452,13 @@ extern "C" int64_t gd_rows_gemm_wgrad_workspace(int32_t n_sel, int32_t d_a, int3
   return (int64_t)nb * d_a * d_b;
 }
 
-extern "C" int gd_rows_gemm_wgrad_f32(const float* a, int64_t ld_a, const int32_t* a_idx, const float* g, int64_t ld_g,
-                                      const int32_t* g_idx, const float* relu_mask, int32_t n_sel, int32_t d_a,
-                                      int32_t d_b, float* dw, int32_t accumulate, float* partials, void* stream) {
+namespace gd {
+struct AdamArgs { float* param; float* m; float* v; const int32_t* iter; double lr, beta1, beta2, eps; };
+}
+
+static int wgrad_impl(const float* a, int64_t ld_a, const int32_t* a_idx, const float* g, int64_t ld_g,
+                      const int32_t* g_idx, const float* relu_mask, int32_t n_sel, int32_t d_a, int32_t d_b, float* dw,
+                      int32_t accumulate, float* partials, const gd::AdamArgs* adam, void* stream) {
   using namespace gd;
   GD_REQUIRE(dw && partials, GD_E_NULL, "gd_rows_gemm_wgrad_f32: null output");
   GD_REQUIRE(n_sel == 0 || (a && g), GD_E_NULL, "gd_rows_gemm_wgrad_f32: null input");
@@ -451,11 +496,39 @@ extern "C" int gd_rows_gemm_wgrad_f32(const float* a, int64_t ld_a, const int32_
     int rc = launched("rows_wgrad");
     if (rc) return rc;
   }
-  if (n_elem % 4 == 0 && aligned16(dw) && aligned16(partials))
+  const bool vec = n_elem % 4 == 0 && aligned16(dw) && aligned16(partials);
+  if (adam && vec) {
+    hipLaunchKernelGGL(wgrad_reduce_adam_kernel, dim3((n_elem / 4 + 15) / 16), dim3(256), 0, s, partials, nb, n_elem,
+                       accumulate, dw, adam->param, adam->m, adam->v, adam->iter, adam->lr, adam->beta1, adam->beta2,
+                       adam->eps);
+    return launched("wgrad_reduce_adam");
+  }
+  if (vec)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n_elem / 4 + 15) / 16), dim3(256), 0, s, partials, nb, n_elem,
                        accumulate, dw);
   else
     hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3((n_elem + 255) / 256), dim3(256), 0, s, partials, nb, n_elem,
                        accumulate, dw);
-  return launched("wgrad_reduce");
+  int rc = launched("wgrad_reduce");
+  if (rc || !adam) return rc;
+  return gd_adam_at_f32(adam->param, dw, adam->m, adam->v, adam->iter, n_elem, adam->lr, adam->beta1, adam->beta2,
+                        adam->eps, stream);
+}
+
+extern "C" int gd_rows_gemm_wgrad_f32(const float* a, int64_t ld_a, const int32_t* a_idx, const float* g, int64_t ld_g,
+                                      const int32_t* g_idx, const float* relu_mask, int32_t n_sel, int32_t d_a,
+                                      int32_t d_b, float* dw, int32_t accumulate, float* partials, void* stream) {
+  return wgrad_impl(a, ld_a, a_idx, g, ld_g, g_idx, relu_mask, n_sel, d_a, d_b, dw, accumulate, partials, nullptr,
+                    stream);
+}
+
+extern "C" int gd_rows_gemm_wgrad_adam_f32(const float* a, int64_t ld_a, const int32_t* a_idx, const float* g,
+                                           int64_t ld_g, const int32_t* g_idx, const float* relu_mask, int32_t n_sel,
+                                           int32_t d_a, int32_t d_b, float* dw, int32_t accumulate, float* partials,
+                                           float* param, float* exp_avg, float* exp_avg_sq, const int32_t* iter,
+                                           double lr, double beta1, double beta2, double eps, void* stream) {
+  GD_REQUIRE(param && exp_avg && exp_avg_sq && iter, GD_E_NULL, "gd_rows_gemm_wgrad_adam_f32: null optimizer state");
+  const gd::AdamArgs adam{param, exp_avg, exp_avg_sq, iter, lr, beta1, beta2, eps};
+  return wgrad_impl(a, ld_a, a_idx, g, ld_g, g_idx, relu_mask, n_sel, d_a, d_b, dw, accumulate, partials, &adam,
+                    stream);
 }

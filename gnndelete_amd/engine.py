@@ -99,7 +99,12 @@ class _LayerTerms:
             ws = _lib.lib().gd_rowpair_mse_workspace(self.n_seg)
         self.partials = torch.empty(max(2, ws), dtype=torch.float32, device=device)
 
+    def n_partial_blocks(self):
+        """Blocks of per-block loss partials the folded kernel writes (for gd_loss_finalize_f32)."""
+        return _lib.lib().gd_rowtarget_mse_blocks(self.n_rows) if self.folded and self.n_rows else 0
+
     def launch(self, z, dz, sums):
+        """sums = None (folded form only): leave the partials for gd_loss_finalize_f32."""
         d = z.shape[1]
         if self.folded:
             check(_lib.lib().gd_rowtarget_mse_f32(ptr(z), z.stride(0), ptr(self.tm), d, ptr(self.row_idx),
@@ -115,13 +120,25 @@ class _LayerTerms:
 
 
 class _Adam:
-    def __init__(self, param, lr, betas=(0.9, 0.999), eps=1e-8):
+    """torch.optim.Adam state for one Del weight.  With a shared iteration counter (`iter_ctr`, a
+    device int32 the step's finalize kernel advances) the step number is read from it and the
+    update can be fused into the weight-gradient reduction; without one it keeps its own counter."""
+
+    def __init__(self, param, lr, betas=(0.9, 0.999), eps=1e-8, iter_ctr=None):
         self.param, self.lr, self.betas, self.eps = param, lr, betas, eps
         self.m = torch.zeros_like(param)
         self.v = torch.zeros_like(param)
-        self.step = torch.zeros(1, dtype=torch.int32, device=param.device)
+        self.iter_ctr = iter_ctr
+        self.step = torch.zeros(1, dtype=torch.int32, device=param.device) if iter_ctr is None else iter_ctr
+        self.applied = 0                  # host-side count of updates (for state export)
 
     def apply(self, grad):
+        self.applied += 1
+        if self.iter_ctr is not None:
+            check(_lib.lib().gd_adam_at_f32(ptr(self.param), ptr(grad), ptr(self.m), ptr(self.v), ptr(self.iter_ctr),
+                                            self.param.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
+                                            stream_ptr(self.param.device)), 'gd_adam_at_f32')
+            return
         check(_lib.lib().gd_adam_f32(ptr(self.param), ptr(grad), ptr(self.m), ptr(self.v), ptr(self.step),
                                      self.param.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
                                      stream_ptr(self.param.device)), 'gd_adam_f32')
@@ -191,9 +208,10 @@ class NodeembEngine:
         self.sums = torch.zeros(4, **f32)                            # r1, l1, r2, l2 (sums of squares)
         self.ws1 = torch.empty(max(1, _lib.lib().gd_rows_gemm_wgrad_workspace(self.s1, self.h, self.h)), **f32)
         self.ws2 = torch.empty(max(1, _lib.lib().gd_rows_gemm_wgrad_workspace(self.s2, self.o, self.o)), **f32)
-        self.adam1, self.adam2 = _Adam(self.wd1, lr), _Adam(self.wd2, lr)
+        self.iter_ctr = torch.zeros(1, dtype=torch.int32, device=dev)       # advanced once per step
+        self.adam1, self.adam2 = _Adam(self.wd1, lr, iter_ctr=self.iter_ctr), _Adam(self.wd2, lr, iter_ctr=self.iter_ctr)
         self.hist = torch.zeros(history, 4, **f32)
-        self.hist_pos = torch.zeros(1, dtype=torch.long, device=dev)
+        self.hist_pos = torch.zeros(1, dtype=torch.int32, device=dev)
         self.steps_done = 0
         self._graph = None
         self._use_graph = use_graph
@@ -285,8 +303,17 @@ class NodeembEngine:
         else:
             ops._spmm_raw(g.rowptr, g.col, val, x, bias, self_coef, self.n, g.plan, out=y)
 
-    def _wgrad(self, a_compact, g, g_idx, n_sel, relu_mask, out, accumulate, ws):
+    def _wgrad(self, a_compact, g, g_idx, n_sel, relu_mask, out, accumulate, ws, adam=None):
+        """out (+)= a^T g over the selected rows; with `adam` the optimizer update of that Del weight
+        is applied inside the split-K reduction (one launch less)."""
         d_a, d_b = a_compact.shape[1], g.shape[1]
+        if adam is not None:
+            adam.applied += 1
+            check(_lib.lib().gd_rows_gemm_wgrad_adam_f32(
+                ptr(a_compact), a_compact.stride(0), None, ptr(g), g.stride(0), ptr(g_idx), ptr(relu_mask), n_sel, d_a,
+                d_b, ptr(out), int(accumulate), ptr(ws), ptr(adam.param), ptr(adam.m), ptr(adam.v), ptr(adam.iter_ctr),
+                adam.lr, adam.betas[0], adam.betas[1], adam.eps, stream_ptr(g.device)), 'gd_rows_gemm_wgrad_adam_f32')
+            return
         check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(a_compact), a_compact.stride(0), None, ptr(g), g.stride(0),
                                                 ptr(g_idx), ptr(relu_mask), n_sel, d_a, d_b, ptr(out),
                                                 int(accumulate), ptr(ws), stream_ptr(g.device)),
@@ -308,21 +335,25 @@ class NodeembEngine:
             else:
                 self._conv1_forward()
                 ops.rows_gemm(self.z1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1)
-            self.sums.zero_()
+            fused_fin = self.t1.folded and self.t2.folded       # partials reduced by the finalize kernel
+            if not fused_fin:
+                self.sums.zero_()
+            s1 = None if fused_fin else self.sums[0:2]
+            s2 = None if fused_fin else self.sums[2:4]
             # ---- fork: layer-1 loss branch
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                self.t1.launch(self.z1, self.dz1, self.sums[0:2])
-                if lt in ('both_layerwise', 'both_all'):
+                self.t1.launch(self.z1, self.dz1, s1)
+                if lt == 'both_layerwise':
+                    self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, True, self.ws1, adam=self.adam1)
+                elif lt == 'both_all':
                     self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, True, self.ws1)
                 elif lt == 'only1':
-                    self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, False, self.ws1)
-                if lt in ('both_layerwise', 'only1'):
-                    self.adam1.apply(self.g1)
+                    self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, False, self.ws1, adam=self.adam1)
             # ---- main: forward layer 2 + its loss
             self._conv2_forward()
             ops.rows_gemm(self.z2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
-            self.t2.launch(self.z2, self.dz2, self.sums[2:4])
+            self.t2.launch(self.z2, self.dz2, s2)
             # ---- backward + update (the layer-2 path joins before it touches g1 / W_D1 state)
             if lt == 'both_layerwise':
                 self._layer2_backward(g1_accumulate=False, join=side)   # g1 = zero_grad() + loss2 path (carry-over)
@@ -341,8 +372,12 @@ class NodeembEngine:
                 self.adam2.apply(self.g2)
             else:  # only1
                 main.wait_stream(side)
-            self.hist.index_copy_(0, self.hist_pos, self.sums[None])
-            self.hist_pos.add_(1).remainder_(self.hist.shape[0])
+            # ---- loss sums -> history ring, advance the iteration counter (Adam's step number)
+            check(_lib.lib().gd_loss_finalize_f32(
+                ptr(self.t1.partials) if fused_fin else None, self.t1.n_partial_blocks() if fused_fin else 0,
+                ptr(self.t2.partials) if fused_fin else None, self.t2.n_partial_blocks() if fused_fin else 0,
+                None if fused_fin else ptr(self.sums), ptr(self.hist), self.hist.shape[0], ptr(self.hist_pos),
+                ptr(self.iter_ctr), stream_ptr(self.x.device)), 'gd_loss_finalize_f32')
 
     def _layer2_backward(self, g1_accumulate, g2_accumulate=False, join=None):
         """g2 (+)= dW_D2; if g1_accumulate is not None also g1 (+)= d loss2 / d W_D1.  `join`: the
@@ -372,8 +407,8 @@ class NodeembEngine:
         self.steps_done += 1
 
     def _mutable_state(self):
-        return [self.wd1.data, self.wd2.data, self.g1, self.g2, self.adam1.m, self.adam1.v, self.adam1.step,
-                self.adam2.m, self.adam2.v, self.adam2.step, self.hist, self.hist_pos, self.dz1, self.dz2, self.dh]
+        return [self.wd1.data, self.wd2.data, self.g1, self.g2, self.adam1.m, self.adam1.v, self.iter_ctr,
+                self.adam2.m, self.adam2.v, self.hist, self.hist_pos, self.dz1, self.dz2, self.dh]
 
     def _capture(self):
         saved = [t.clone() for t in self._mutable_state()]

@@ -158,7 +158,7 @@ def _export_adam_state(engine, model, optimizer):
     opts = list(optimizer) if isinstance(optimizer, (list, tuple)) else [optimizer, optimizer]
     for opt, adam, p in [(opts[0], engine.adam1, model.deletion1.deletion_weight),
                          (opts[1], engine.adam2, model.deletion2.deletion_weight)]:
-        steps = int(adam.step)
+        steps = adam.applied if adam.iter_ctr is not None else int(adam.step)
         if steps:
             opt.state[p] = {'step': torch.tensor(float(steps)), 'exp_avg': adam.m.clone(),
                             'exp_avg_sq': adam.v.clone()}

@@ -159,6 +159,16 @@ int gd_rows_gemm_wgrad_f32(const float* a, int64_t ld_a, const int32_t* a_idx,
                            const float* relu_mask, int32_t n_sel, int32_t d_a, int32_t d_b,
                            float* dw, int32_t accumulate, float* partials, void* stream);
 
+/* gd_rows_gemm_wgrad_f32 followed by torch.optim.Adam on `param` with the freshly reduced dW,
+ * fused into the split-K reduction (t = *iter + 1; `iter` is a shared iteration counter that
+ * gd_loss_finalize_f32 advances once per step). */
+int gd_rows_gemm_wgrad_adam_f32(const float* a, int64_t ld_a, const int32_t* a_idx,
+                                const float* g, int64_t ld_g, const int32_t* g_idx,
+                                const float* relu_mask, int32_t n_sel, int32_t d_a, int32_t d_b,
+                                float* dw, int32_t accumulate, float* partials,
+                                float* param, float* exp_avg, float* exp_avg_sq, const int32_t* iter,
+                                double lr, double beta1, double beta2, double eps, void* stream);
+
 /* ---------------------------------------------------------------- losses --------------- */
 
 /* Fused Deleted-Edge-Consistency + Neighborhood-Influence MSE terms of one layer, value and
@@ -191,6 +201,15 @@ int gd_rowtarget_mse_f32(const float* z, int64_t ld_z, const float* tm, int32_t 
                          const int32_t* row_idx, const float* coef, const float* cnt, const int32_t* kind,
                          int32_t n_rows, float* dz, int64_t ld_dz, float* sums, float* partials, void* stream);
 
+/* End-of-step bookkeeping in one launch: reduce the per-block partials of the two layers' loss
+ * kernels (called with sums = NULL; n1/n2 = gd_rowtarget_mse_blocks(n_rows)) in a fixed order,
+ * add extra_sums[4] (optional), write (r1, l1, r2, l2) to hist[*pos], advance the ring position
+ * (mod capacity) and the iteration counter *iter (the Adam step number source). */
+int32_t gd_rowtarget_mse_blocks(int32_t n_rows);
+int gd_loss_finalize_f32(const float* partials1, int32_t n1, const float* partials2, int32_t n2,
+                         const float* extra_sums, float* hist, int32_t capacity, int32_t* pos, int32_t* iter,
+                         void* stream);
+
 /* Link decoders.  dot: out[m] = <z[e0[m]], z[e1[m]]>  (framework/models/gcn.py:26-36);
  * distmult: out[m] = sum_c z[e0[m],c] * rel[etype[m],c] * z[e1[m],c]  (rgcn.py:40-47). */
 int gd_edge_dot_f32(const float* z, int64_t ld_z, int32_t d, const int64_t* e0, const int64_t* e1,
@@ -202,7 +221,11 @@ int gd_edge_dot_f32(const float* z, int64_t ld_z, int32_t d, const int64_t* e0, 
 /* torch.optim.Adam (no amsgrad, weight_decay 0) on one tensor (delete_gnn.py:221-226).
  * `step` is a device int32 counter incremented by the kernel (graph-capturable). */
 int gd_adam_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t* step,
-                int64_t n, float lr, float beta1, float beta2, float eps, void* stream);
+                int64_t n, double lr, double beta1, double beta2, double eps, void* stream);
+
+/* gd_adam_f32 with the step number read from a shared iteration counter (t = *iter + 1). */
+int gd_adam_at_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int32_t* iter,
+                   int64_t n, double lr, double beta1, double beta2, double eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 """HIP kernels (through the C ABI / ctypes) vs the CPU oracle and closed-form fp64 math.
 Tolerance: fp32 kernels, rel-L2 <= 1e-5 against fp64 closed forms (north_star allows 1e-4)."""
 import pytest
+import numpy as np
 import torch
 
 from helpers import random_graph, rel_l2
@@ -239,6 +240,61 @@ def test_adam_matches_torch_optim():
                                           p.numel(), 1e-2, 0.9, 0.999, 1e-8, torch.cuda.current_stream().cuda_stream))
     assert int(step) == 12
     assert rel_l2(p.cpu(), ref.detach()) < 1e-6
+
+
+def test_adam_rounding_sequence_and_fused_entry_points():
+    """One step from a non-trivial state: the kernel spells out torch's single-tensor rounding
+    sequence (fp64-derived scalars, lerp as fma, addcmul, IEEE sqrt/div), so it lands within a couple
+    of ulp of torch.optim.Adam element by element (torch's vectorised CPU sqrt is itself not
+    correctly rounded everywhere), and the stand-alone, counter-driven and reduction-fused
+    entry points are bit-identical to each other."""
+    from gnndelete_amd import _lib
+    from gnndelete_amd._lib import ptr, check
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(7)
+    d, S, t0 = 128, 3000, 4
+    p0 = torch.randn(d, d, generator=g) * 1e-3
+    m0 = torch.randn(d, d, generator=g) * 1e-4
+    v0 = torch.rand(d, d, generator=g) * 1e-8
+    a = torch.randn(S, d, generator=g).cuda()
+    up = (torch.randn(S, d, generator=g) * 1e-4).cuda()
+    ws = torch.empty(L.gd_rows_gemm_wgrad_workspace(S, d, d), device='cuda')
+    dw = torch.empty(d, d, device='cuda')
+    check(L.gd_rows_gemm_wgrad_f32(ptr(a), d, None, ptr(up), d, None, None, S, d, d, ptr(dw), 0, ptr(ws), s))
+    hyper = (1e-3, 0.9, 0.999, 1e-8)
+
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=hyper[0], betas=hyper[1:3], eps=hyper[3])
+    opt.state[ref] = {'step': torch.tensor(float(t0)), 'exp_avg': m0.clone(), 'exp_avg_sq': v0.clone()}
+    ref.grad = dw.cpu()
+    opt.step()
+
+    outs = []
+    for kind in ('step', 'at', 'fused'):
+        p, m, v = p0.clone().cuda(), m0.clone().cuda(), v0.clone().cuda()
+        ctr = torch.tensor([t0], dtype=torch.int32, device='cuda')
+        if kind == 'step':
+            check(L.gd_adam_f32(ptr(p), ptr(dw), ptr(m), ptr(v), ptr(ctr), d * d, *hyper, s))
+            assert int(ctr) == t0 + 1
+        elif kind == 'at':
+            check(L.gd_adam_at_f32(ptr(p), ptr(dw), ptr(m), ptr(v), ptr(ctr), d * d, *hyper, s))
+            assert int(ctr) == t0
+        else:
+            dw2 = torch.empty_like(dw)
+            check(L.gd_rows_gemm_wgrad_adam_f32(ptr(a), d, None, ptr(up), d, None, None, S, d, d, ptr(dw2), 0, ptr(ws),
+                                                ptr(p), ptr(m), ptr(v), ptr(ctr), *hyper, s))
+            assert torch.equal(dw2, dw)
+        outs.append((p.cpu(), m.cpu(), v.cpu()))
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert torch.equal(x, y)
+    st = opt.state[ref]
+    assert torch.equal(outs[0][1], st['exp_avg'])
+    assert torch.equal(outs[0][2], st['exp_avg_sq'])
+    # p' = p + q: the two can cancel, so the bound is in ulps of the operands, not of the result
+    ulp = float(np.spacing(np.float32(max(float(p0.abs().max()), hyper[0]))))
+    assert float((outs[0][0] - ref.detach()).abs().max()) <= 2 * ulp
 
 
 @pytest.mark.parametrize('d', [128, 64, 16])
