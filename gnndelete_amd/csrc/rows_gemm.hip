@@ -29,7 +29,7 @@ template <int NT>
 __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
     const float* in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel,
     const float* __restrict__ w, int32_t d_in, int32_t trans_w, const float* __restrict__ bias, int32_t relu_in,
-    float* out, int64_t ld_out, float* __restrict__ save_in) {
+    float* out, int64_t ld_out, float* __restrict__ save_in, const float* __restrict__ out_gate, int64_t ld_gate) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   constexpr int d_out = 32 * NT;
   constexpr int kWaves = kGemmThreads / 64;
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
     // ---- epilogue: D[i][j], j = lane&31 = sample, i = (r&3) + 8*(r>>2) + 4*(lane>>5) = feature
     if (live) {
       float* dst = out + row_cur * ld_out + 4 * khalf;
+      const float* gate = out_gate ? out_gate + row_cur * ld_gate + 4 * khalf : nullptr;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -135,6 +136,11 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
           float4 v = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
           const int n0 = 32 * t + 8 * q;
           if (bias) v = f4_add(v, *reinterpret_cast<const float4*>(bias + n0 + 4 * khalf));
+          if (gate) {   // ReLU backward: pass the gradient where the forward activation input was > 0
+            const float4 m = *reinterpret_cast<const float4*>(gate + n0);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+            v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+          }
           *reinterpret_cast<float4*>(dst + n0) = v;
         }
       }
@@ -149,7 +155,8 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
 __global__ __launch_bounds__(256) void rows_gemm_scalar_kernel(
     const float* in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel,
     const float* __restrict__ w, int32_t d_in, int32_t d_out, int32_t trans_w, const float* __restrict__ bias,
-    int32_t relu_in, float* out, int64_t ld_out, float* __restrict__ save_in) {
+    int32_t relu_in, float* out, int64_t ld_out, float* __restrict__ save_in, const float* __restrict__ out_gate,
+    int64_t ld_gate) {
   constexpr int kMaxPerLane = 16;  // d_in <= 1024
   const int lane = threadIdx.x & 63;
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -171,7 +178,11 @@ __global__ __launch_bounds__(256) void rows_gemm_scalar_kernel(
       if (k < d_in) p = fmaf(xr[q], trans_w ? w[(int64_t)j * d_in + k] : w[(int64_t)k * d_out + j], p);
     }
     p = wave_sum(p);
-    if (lane == 0) out[row * ld_out + j] = p + (bias ? bias[j] : 0.f);
+    if (lane == 0) {
+      p += bias ? bias[j] : 0.f;
+      if (out_gate && !(out_gate[row * ld_gate + j] > 0.f)) p = 0.f;
+      out[row * ld_out + j] = p;
+    }
   }
 }
 
@@ -185,8 +196,8 @@ __global__ __launch_bounds__(256) void rows_gemm_scalar_kernel(
 template <int TA, int TB>
 __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
     const float* __restrict__ a, int64_t ld_a, const int32_t* __restrict__ a_idx, const float* __restrict__ g,
-    int64_t ld_g, const int32_t* __restrict__ g_idx, const float* __restrict__ relu_mask, int32_t n_sel,
-    int32_t rows_per_block, float* __restrict__ partials) {
+    int64_t ld_g, const int32_t* __restrict__ g_idx, const float* __restrict__ relu_mask,
+    const float* __restrict__ g_add, int32_t n_sel, int32_t rows_per_block, float* __restrict__ partials) {
   constexpr int DA = 32 * TA, DB = 32 * TB, KT = 32;
   constexpr int TILES = TA * TB, TPW = (TILES + 3) / 4;
   constexpr int FA = DA / 4, FB = DB / 4;            // float4 per row
@@ -239,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
           v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
+        if (g_add) v = f4_add(v, reinterpret_cast<const float4*>(g_add + row * ld_g)[c4]);
         rg[i] = v;
       } else {
         rg[i] = f4_zero();
@@ -296,8 +308,9 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
 // generic dims: one thread per dW element, loop over the block's rows
 __global__ __launch_bounds__(256) void rows_wgrad_scalar_kernel(
     const float* __restrict__ a, int64_t ld_a, const int32_t* __restrict__ a_idx, const float* __restrict__ g,
-    int64_t ld_g, const int32_t* __restrict__ g_idx, const float* __restrict__ relu_mask, int32_t n_sel,
-    int32_t d_a, int32_t d_b, int32_t rows_per_block, float* __restrict__ partials) {
+    int64_t ld_g, const int32_t* __restrict__ g_idx, const float* __restrict__ relu_mask,
+    const float* __restrict__ g_add, int32_t n_sel, int32_t d_a, int32_t d_b, int32_t rows_per_block,
+    float* __restrict__ partials) {
   const int s_begin = blockIdx.x * rows_per_block;
   const int s_end = min(n_sel, s_begin + rows_per_block);
   float* dst = partials + (int64_t)blockIdx.x * d_a * d_b;
@@ -308,6 +321,7 @@ __global__ __launch_bounds__(256) void rows_wgrad_scalar_kernel(
       const int64_t ra = a_idx ? a_idx[s] : s, rg = g_idx ? g_idx[s] : s;
       float gg = g[rg * ld_g + j];
       if (relu_mask) gg = relu_mask[rg * ld_g + j] > 0.f ? gg : 0.f;
+      if (g_add) gg += g_add[rg * ld_g + j];
       p = fmaf(a[ra * ld_a + i], gg, p);
     }
     dst[e] = p;
@@ -410,10 +424,12 @@ static inline void wgrad_geometry(int32_t n_sel, int* n_blocks, int* rows_per_bl
 
 }  // namespace gd
 
-extern "C" int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w,
-                                int32_t d_in, int32_t d_out, int32_t trans_w, const float* bias, int32_t relu_in,
-                                float* out, int64_t ld_out, float* save_in, void* stream) {
+static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w,
+                          int32_t d_in, int32_t d_out, int32_t trans_w, const float* bias, int32_t relu_in,
+                          const float* out_gate, int64_t ld_gate, float* out, int64_t ld_out, float* save_in,
+                          void* stream) {
   using namespace gd;
+  GD_REQUIRE(!out_gate || (ld_gate >= d_out && out_gate != out), GD_E_DIM, "gd_rows_gemm_gated_f32: bad gate");
   GD_REQUIRE(in && w && out, GD_E_NULL, "gd_rows_gemm_f32: null pointer");
   GD_REQUIRE(n_sel >= 0 && d_in > 0 && d_out > 0 && ld_in >= d_in && ld_out >= d_out, GD_E_DIM,
              "gd_rows_gemm_f32: bad dims n_sel=%d d_in=%d d_out=%d", n_sel, d_in, d_out);
@@ -423,14 +439,14 @@ extern "C" int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* i
   const size_t lds = (size_t)d_in * d_out * sizeof(float);
   const bool mfma_ok = (d_out % 32 == 0) && d_out <= 128 && (d_in % 32 == 0) && lds <= 64 * 1024 && aligned16(in) &&
                        (ld_in % 4 == 0) && (!save_in || aligned16(save_in)) && aligned16(out) && (ld_out % 4 == 0) &&
-                       (!bias || aligned16(bias));
+                       (!bias || aligned16(bias)) && (!out_gate || (aligned16(out_gate) && ld_gate % 4 == 0));
   if (mfma_ok) {
     const int n_tiles = (n_sel + 31) / 32;
     int grid = (n_tiles + 7) / 8;
     if (grid > 512) grid = 512;
 #define GD_RG_CASE(NT)                                                                                        \
   hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in, idx, n_sel, w, \
-                     d_in, trans_w, bias, relu_in, out, ld_out, save_in)
+                     d_in, trans_w, bias, relu_in, out, ld_out, save_in, out_gate, ld_gate)
     switch (d_out / 32) {
       case 1: GD_RG_CASE(1); break;
       case 2: GD_RG_CASE(2); break;
@@ -442,8 +458,24 @@ extern "C" int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* i
   }
   GD_REQUIRE(d_in <= 1024, GD_E_DIM, "gd_rows_gemm_f32: fallback path needs d_in <= 1024 (got %d)", d_in);
   hipLaunchKernelGGL(rows_gemm_scalar_kernel, dim3((n_sel + 3) / 4), dim3(256), 0, s, in, ld_in, idx, n_sel, w, d_in,
-                     d_out, trans_w, bias, relu_in, out, ld_out, save_in);
+                     d_out, trans_w, bias, relu_in, out, ld_out, save_in, out_gate, ld_gate);
   return launched("rows_gemm_scalar");
+}
+
+extern "C" int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w,
+                                int32_t d_in, int32_t d_out, int32_t trans_w, const float* bias, int32_t relu_in,
+                                float* out, int64_t ld_out, float* save_in, void* stream) {
+  return rows_gemm_impl(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, bias, relu_in, nullptr, 0, out, ld_out,
+                        save_in, stream);
+}
+
+extern "C" int gd_rows_gemm_gated_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel,
+                                      const float* w, int32_t d_in, int32_t d_out, int32_t trans_w,
+                                      const float* out_gate, int64_t ld_gate, float* out, int64_t ld_out,
+                                      void* stream) {
+  GD_REQUIRE(out_gate, GD_E_NULL, "gd_rows_gemm_gated_f32: null gate");
+  return rows_gemm_impl(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, nullptr, 0, out_gate, ld_gate, out, ld_out,
+                        nullptr, stream);
 }
 
 extern "C" int64_t gd_rows_gemm_wgrad_workspace(int32_t n_sel, int32_t d_a, int32_t d_b) {
@@ -457,7 +489,7 @@ struct AdamArgs { float* param; float* m; float* v; const int32_t* iter; double 
 }
 
 static int wgrad_impl(const float* a, int64_t ld_a, const int32_t* a_idx, const float* g, int64_t ld_g,
-                      const int32_t* g_idx, const float* relu_mask, int32_t n_sel, int32_t d_a, int32_t d_b, float* dw,
+                      const int32_t* g_idx, const float* relu_mask, const float* g_add, int32_t n_sel, int32_t d_a, int32_t d_b, float* dw,
                       int32_t accumulate, float* partials, const gd::AdamArgs* adam, void* stream) {
   using namespace gd;
   GD_REQUIRE(dw && partials, GD_E_NULL, "gd_rows_gemm_wgrad_f32: null output");
@@ -472,11 +504,11 @@ static int wgrad_impl(const float* a, int64_t ld_a, const int32_t* a_idx, const 
     const int ta = d_a / 32, tb = d_b / 32;
     const bool mfma_ok = (d_a % 32 == 0) && (d_b % 32 == 0) && ta <= 4 && tb <= 4 && ta != 3 && tb != 3 &&
                          aligned16(a) && aligned16(g) && ld_a % 4 == 0 && ld_g % 4 == 0 &&
-                         (!relu_mask || aligned16(relu_mask));
+                         (!relu_mask || aligned16(relu_mask)) && (!g_add || aligned16(g_add));
     if (mfma_ok) {
 #define GD_WG_CASE(TA, TB)                                                                                        \
   hipLaunchKernelGGL((rows_wgrad_mfma_kernel<TA, TB>), dim3(nb), dim3(256), 0, s, a, ld_a, a_idx, g, ld_g, g_idx, \
-                     relu_mask, n_sel, rpb, partials)
+                     relu_mask, g_add, n_sel, rpb, partials)
       switch (ta * 8 + tb) {
         case 1 * 8 + 1: GD_WG_CASE(1, 1); break;
         case 1 * 8 + 2: GD_WG_CASE(1, 2); break;
@@ -491,7 +523,7 @@ static int wgrad_impl(const float* a, int64_t ld_a, const int32_t* a_idx, const 
 #undef GD_WG_CASE
     } else {
       hipLaunchKernelGGL(rows_wgrad_scalar_kernel, dim3(nb), dim3(256), 0, s, a, ld_a, a_idx, g, ld_g, g_idx,
-                         relu_mask, n_sel, d_a, d_b, rpb, partials);
+                         relu_mask, g_add, n_sel, d_a, d_b, rpb, partials);
     }
     int rc = launched("rows_wgrad");
     if (rc) return rc;
@@ -516,19 +548,21 @@ static int wgrad_impl(const float* a, int64_t ld_a, const int32_t* a_idx, const 
 }
 
 extern "C" int gd_rows_gemm_wgrad_f32(const float* a, int64_t ld_a, const int32_t* a_idx, const float* g, int64_t ld_g,
-                                      const int32_t* g_idx, const float* relu_mask, int32_t n_sel, int32_t d_a,
-                                      int32_t d_b, float* dw, int32_t accumulate, float* partials, void* stream) {
-  return wgrad_impl(a, ld_a, a_idx, g, ld_g, g_idx, relu_mask, n_sel, d_a, d_b, dw, accumulate, partials, nullptr,
-                    stream);
+                                      const int32_t* g_idx, const float* relu_mask, const float* g_add,
+                                      int32_t n_sel, int32_t d_a, int32_t d_b, float* dw, int32_t accumulate,
+                                      float* partials, void* stream) {
+  return wgrad_impl(a, ld_a, a_idx, g, ld_g, g_idx, relu_mask, g_add, n_sel, d_a, d_b, dw, accumulate, partials,
+                    nullptr, stream);
 }
 
 extern "C" int gd_rows_gemm_wgrad_adam_f32(const float* a, int64_t ld_a, const int32_t* a_idx, const float* g,
-                                           int64_t ld_g, const int32_t* g_idx, const float* relu_mask, int32_t n_sel,
-                                           int32_t d_a, int32_t d_b, float* dw, int32_t accumulate, float* partials,
+                                           int64_t ld_g, const int32_t* g_idx, const float* relu_mask,
+                                           const float* g_add, int32_t n_sel, int32_t d_a, int32_t d_b, float* dw,
+                                           int32_t accumulate, float* partials,
                                            float* param, float* exp_avg, float* exp_avg_sq, const int32_t* iter,
                                            double lr, double beta1, double beta2, double eps, void* stream) {
   GD_REQUIRE(param && exp_avg && exp_avg_sq && iter, GD_E_NULL, "gd_rows_gemm_wgrad_adam_f32: null optimizer state");
   const gd::AdamArgs adam{param, exp_avg, exp_avg_sq, iter, lr, beta1, beta2, eps};
-  return wgrad_impl(a, ld_a, a_idx, g, ld_g, g_idx, relu_mask, n_sel, d_a, d_b, dw, accumulate, partials, &adam,
-                    stream);
+  return wgrad_impl(a, ld_a, a_idx, g, ld_g, g_idx, relu_mask, g_add, n_sel, d_a, d_b, dw, accumulate, partials,
+                    &adam, stream);
 }

@@ -149,7 +149,7 @@ class PartitionedNodeembEngine:
 
     def _wgrad(self, a_compact, g, g_idx, n_sel, relu_mask, out, ws):
         check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(a_compact), a_compact.stride(0), None, ptr(g), g.stride(0),
-                                                ptr(g_idx), ptr(relu_mask), n_sel, a_compact.shape[1], g.shape[1],
+                                                ptr(g_idx), ptr(relu_mask), None, n_sel, a_compact.shape[1], g.shape[1],
                                                 ptr(out), 0, ptr(ws), stream_ptr(g.device)), 'gd_rows_gemm_wgrad_f32')
 
     def _weights(self):

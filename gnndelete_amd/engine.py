@@ -276,8 +276,8 @@ class NodeembEngine:
             _, self._rowmax, self._rowsum = ops.gat_forward_raw(self.graph, h2, self._a_src, self._a_dst, c.bias,
                                                                 c.negative_slope, out=self.z2)
 
-    def _conv2_backward_to_s1(self):
-        """dh[S1] = d loss2 / d relu(z1) restricted to the S1 rows (all that Del-1 needs)."""
+    def _conv2_backward_to_s1(self, join=None):
+        """dh[S1] = d loss2 / d z1 (post-Del, pre-ReLU) restricted to the S1 rows (all that Del-1 needs)."""
         c = self.model.conv2
         g = self.graph
         if self._mode in ('gcn', 'gin'):
@@ -293,8 +293,11 @@ class NodeembEngine:
                                                    self.dz2, c.negative_slope)
             dt2.addcmul_(da_s[:, None], c.att_src.view(1, -1)).addcmul_(da_d[:, None], c.att_dst.view(1, -1))
             w2 = c.lin_src.weight
-        # dh[S1] = dt2[S1] @ W2   (W2 is [out, in] = [d_in, d_out] of this product)
-        ops.rows_gemm(dt2, self.idx1, w2, trans_w=False, out=self.dh)
+        # dh[S1] = (dt2[S1] @ W2) * [z1[S1] > 0]   (W2 is [out, in] = [d_in, d_out] of this product; the
+        # ReLU backward is applied in the GEMM epilogue so dh can outlive this iteration's z1)
+        if join is not None:
+            torch.cuda.current_stream().wait_stream(join)      # the side branch may still read last step's dh
+        ops.rows_gemm(dt2, self.idx1, w2, trans_w=False, out=self.dh, out_gate=self.z1)
 
     def _spmm(self, transposed, val, x, y, bias, self_coef):
         g = self.graph
@@ -303,28 +306,38 @@ class NodeembEngine:
         else:
             ops._spmm_raw(g.rowptr, g.col, val, x, bias, self_coef, self.n, g.plan, out=y)
 
-    def _wgrad(self, a_compact, g, g_idx, n_sel, relu_mask, out, accumulate, ws, adam=None):
-        """out (+)= a^T g over the selected rows; with `adam` the optimizer update of that Del weight
-        is applied inside the split-K reduction (one launch less)."""
+    def _wgrad(self, a_compact, g, g_idx, n_sel, out, accumulate, ws, adam=None, g_add=None):
+        """out (+)= a^T (g + g_add) over the selected rows; with `adam` the optimizer update of that Del
+        weight is applied inside the split-K reduction (one launch less)."""
         d_a, d_b = a_compact.shape[1], g.shape[1]
         if adam is not None:
             adam.applied += 1
             check(_lib.lib().gd_rows_gemm_wgrad_adam_f32(
-                ptr(a_compact), a_compact.stride(0), None, ptr(g), g.stride(0), ptr(g_idx), ptr(relu_mask), n_sel, d_a,
-                d_b, ptr(out), int(accumulate), ptr(ws), ptr(adam.param), ptr(adam.m), ptr(adam.v), ptr(adam.iter_ctr),
-                adam.lr, adam.betas[0], adam.betas[1], adam.eps, stream_ptr(g.device)), 'gd_rows_gemm_wgrad_adam_f32')
+                ptr(a_compact), a_compact.stride(0), None, ptr(g), g.stride(0), ptr(g_idx), None, ptr(g_add), n_sel,
+                d_a, d_b, ptr(out), int(accumulate), ptr(ws), ptr(adam.param), ptr(adam.m), ptr(adam.v),
+                ptr(adam.iter_ctr), adam.lr, adam.betas[0], adam.betas[1], adam.eps, stream_ptr(g.device)),
+                'gd_rows_gemm_wgrad_adam_f32')
             return
         check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(a_compact), a_compact.stride(0), None, ptr(g), g.stride(0),
-                                                ptr(g_idx), ptr(relu_mask), n_sel, d_a, d_b, ptr(out),
+                                                ptr(g_idx), None, ptr(g_add), n_sel, d_a, d_b, ptr(out),
                                                 int(accumulate), ptr(ws), stream_ptr(g.device)),
               'gd_rows_gemm_wgrad_f32')
 
     # ------------------------------------------------------------------ one iteration
     def _iteration(self):
-        """One training iteration.  The layer-1 loss, its weight gradient and (layer-wise types)
-        the W_D1 Adam step only depend on z1, so they run on a side stream concurrently with the
+        """One training iteration.  The layer-1 loss (and, for the layer-wise types, the W_D1
+        gradient + Adam step) only depend on z1, so they run on a side stream concurrently with the
         layer-2 forward (conv2, Del-2, layer-2 loss): memory-bound and MFMA-bound kernels overlap
-        and fill each other's tails.  Inside the hipGraph this is a fork/join of two branches."""
+        and fill each other's tails.  Inside the hipGraph this is a fork/join of two branches.
+
+        W_D1 receives gradient from the layer-1 loss (dz1 rows) and, through conv2, from the layer-2
+        loss (dh rows, already ReLU-gated).  Both are products with the same loop-invariant operand
+        xs1 = conv1(x)[S1], so they are taken in ONE pass: xs1^T (dz1 + dh).
+          both_all        the two belong to the same iteration; g1 accumulates for ever (upstream
+                          never calls zero_grad on this path, gnndelete_nodeemb.py:215-230);
+          both_layerwise  optimizer[0].step() sees loss-1 of THIS iteration plus the loss-2 gradient
+                          left in .grad by the PREVIOUS one (zero_grad only after loss-1's step,
+                          :232-262), i.e. dh is consumed one iteration late (zeros at iteration 0)."""
         lt = self.loss_type
         main = torch.cuda.current_stream()
         side = self._side
@@ -345,30 +358,30 @@ class NodeembEngine:
             with torch.cuda.stream(side):
                 self.t1.launch(self.z1, self.dz1, s1)
                 if lt == 'both_layerwise':
-                    self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, True, self.ws1, adam=self.adam1)
-                elif lt == 'both_all':
-                    self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, True, self.ws1)
+                    self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, self.g1, False, self.ws1, adam=self.adam1,
+                                g_add=self.dh)
                 elif lt == 'only1':
-                    self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.g1, False, self.ws1, adam=self.adam1)
+                    self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, self.g1, False, self.ws1, adam=self.adam1)
             # ---- main: forward layer 2 + its loss
             self._conv2_forward()
             ops.rows_gemm(self.z2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
             self.t2.launch(self.z2, self.dz2, s2)
-            # ---- backward + update (the layer-2 path joins before it touches g1 / W_D1 state)
+            # ---- backward + update (joins the side branch before dh / dz1 / W_D1 state are touched)
             if lt == 'both_layerwise':
-                self._layer2_backward(g1_accumulate=False, join=side)   # g1 = zero_grad() + loss2 path (carry-over)
+                self._layer2_backward(join=side)                 # leaves dh for the next iteration
                 self.adam2.apply(self.g2)
             elif lt == 'both_all':
-                self._layer2_backward(g1_accumulate=True, g2_accumulate=True, join=side)
-                self.adam1.apply(self.g1)
+                self._layer2_backward(g2_accumulate=True, join=side)
+                self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, self.g1, True, self.ws1, adam=self.adam1,
+                            g_add=self.dh)
                 self.adam2.apply(self.g2)
             elif lt == 'only2_layerwise':
-                self._layer2_backward(g1_accumulate=None)
+                self._layer2_backward(to_w1=False)
                 self.adam2.apply(self.g2)
                 main.wait_stream(side)
             elif lt == 'only2_all':
-                self._layer2_backward(g1_accumulate=False, join=side)
-                self.adam1.apply(self.g1)
+                self._layer2_backward(join=side)
+                self._wgrad(self.xs1, self.dh, self.idx1, self.s1, self.g1, False, self.ws1, adam=self.adam1)
                 self.adam2.apply(self.g2)
             else:  # only1
                 main.wait_stream(side)
@@ -379,19 +392,15 @@ class NodeembEngine:
                 None if fused_fin else ptr(self.sums), ptr(self.hist), self.hist.shape[0], ptr(self.hist_pos),
                 ptr(self.iter_ctr), stream_ptr(self.x.device)), 'gd_loss_finalize_f32')
 
-    def _layer2_backward(self, g1_accumulate, g2_accumulate=False, join=None):
-        """g2 (+)= dW_D2; if g1_accumulate is not None also g1 (+)= d loss2 / d W_D1.  `join`: the
-        side stream whose work (layer-1 gradient / Adam on g1, ws1) must be finished before g1 and
-        its split-K workspace are written here."""
-        self._wgrad(self.xs2, self.dz2, self.idx2, self.s2, None, self.g2, g2_accumulate, self.ws2)
-        if g1_accumulate is None:
+    def _layer2_backward(self, to_w1=True, g2_accumulate=False, join=None):
+        """g2 (+)= dW_D2; with to_w1 also dh[S1] = d loss2 / d z1[S1].  `join`: the side stream whose
+        work must be finished before dh is overwritten."""
+        self._wgrad(self.xs2, self.dz2, self.idx2, self.s2, self.g2, g2_accumulate, self.ws2)
+        if not to_w1:
             return
         # dz2 -> dp2 in place (Del-2 input gradient on the masked rows, identity elsewhere)
         ops.rows_gemm(self.dz2, self.idx2, self.wd2, trans_w=True, out=self.dz2)
-        self._conv2_backward_to_s1()
-        if join is not None:
-            torch.cuda.current_stream().wait_stream(join)
-        self._wgrad(self.xs1, self.dh, self.idx1, self.s1, self.z1, self.g1, g1_accumulate, self.ws1)
+        self._conv2_backward_to_s1(join=join)
 
     # ------------------------------------------------------------------ public
     def step(self):

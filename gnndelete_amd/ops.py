@@ -63,8 +63,9 @@ def spmm(x, graph, bias=None, self_coef=0.0):
 
 
 # ------------------------------------------------------------------------------ Del operator
-def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, save_in=None):
-    """out[idx] = act(inp[idx]) @ (w or w^T) - raw call (no autograd)."""
+def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, save_in=None, out_gate=None):
+    """out[idx] = act(inp[idx]) @ (w or w^T) - raw call (no autograd).  With `out_gate` (a [N, d_out]
+    tensor) the product is zeroed where the gate is <= 0 (ReLU backward in the epilogue)."""
     inp = _f32_rows(inp)
     n_sel = inp.shape[0] if idx is None else int(idx.shape[0])
     d_in = inp.shape[1]
@@ -73,14 +74,20 @@ def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, sa
     if out is None:
         out = torch.empty(inp.shape[0], d_out, dtype=torch.float32, device=inp.device)
     w = w.contiguous()
+    if out_gate is not None:
+        assert bias is None and not relu_in and save_in is None
+        check(_lib.lib().gd_rows_gemm_gated_f32(ptr(inp), inp.stride(0), ptr(idx), n_sel, ptr(w), d_in, d_out,
+                                                int(trans_w), ptr(out_gate), out_gate.stride(0), ptr(out),
+                                                out.stride(0), stream_ptr(inp.device)), 'gd_rows_gemm_gated_f32')
+        return out
     check(_lib.lib().gd_rows_gemm_f32(ptr(inp), inp.stride(0), ptr(idx), n_sel, ptr(w), d_in, d_out, int(trans_w),
                                       ptr(bias), int(relu_in), ptr(out), out.stride(0), ptr(save_in),
                                       stream_ptr(inp.device)), 'gd_rows_gemm_f32')
     return out
 
 
-def rows_gemm_wgrad(a, a_idx, g, g_idx, n_sel, relu_mask=None, out=None, accumulate=False):
-    """dW[d_a, d_b] (+)= sum_s a[a_idx[s]]^T g[g_idx[s]] - raw call."""
+def rows_gemm_wgrad(a, a_idx, g, g_idx, n_sel, relu_mask=None, out=None, accumulate=False, g_add=None):
+    """dW[d_a, d_b] (+)= sum_s a[a_idx[s]]^T (mask(g) + g_add)[g_idx[s]] - raw call."""
     a, g = _f32_rows(a), _f32_rows(g)
     d_a, d_b = a.shape[1], g.shape[1]
     if out is None:
@@ -91,8 +98,11 @@ def rows_gemm_wgrad(a, a_idx, g, g_idx, n_sel, relu_mask=None, out=None, accumul
     if relu_mask is not None:
         relu_mask = _f32_rows(relu_mask)
         assert relu_mask.stride(0) == g.stride(0)
+    if g_add is not None:
+        g_add = _f32_rows(g_add)
+        assert g_add.stride(0) == g.stride(0) and g_add.shape == g.shape
     check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(a), a.stride(0), ptr(a_idx), ptr(g), g.stride(0), ptr(g_idx),
-                                            ptr(relu_mask), n_sel, d_a, d_b, ptr(out), int(accumulate), ptr(ws),
+                                            ptr(relu_mask), ptr(g_add), n_sel, d_a, d_b, ptr(out), int(accumulate), ptr(ws),
                                             stream_ptr(a.device)), 'gd_rows_gemm_wgrad_f32')
     return out
 

@@ -147,25 +147,36 @@ int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t
                      const float* bias, int32_t relu_in,
                      float* out, int64_t ld_out, float* save_in, void* stream);
 
+/* The same product with the ReLU backward folded into its epilogue:
+ *       out[r,n] = out_gate[r,n] > 0 ? (in[r,:] @ W)[n] : 0
+ * (input gradient of `relu -> conv2.lin`, deletion.py:67-68: dh = (dt2 @ W2) * [z1 > 0]); the
+ * gate must not alias `out`. */
+int gd_rows_gemm_gated_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel,
+                           const float* w, int32_t d_in, int32_t d_out, int32_t trans_w,
+                           const float* out_gate, int64_t ld_gate, float* out, int64_t ld_out, void* stream);
+
 /* Weight gradient of the row-subset GEMM:  dW[d_a, d_b] (+)= sum_s a[ia(s),:]^T g[ig(s),:]
  *   ia(s) = a_idx ? a_idx[s] : s, likewise g_idx.  Deterministic split-K: `partials` must hold
  *   gd_rows_gemm_wgrad_workspace(n_sel, d_a, d_b) floats.  accumulate != 0 adds into dW.
  *   relu_mask (optional, same indexing as g through g_idx, ld = ld_g): g is multiplied by
  *   (relu_mask > 0) on the fly (backward through F.relu, deletion.py:67).
+ *   g_add (optional, same indexing and ld as g): a second upstream gradient added row by row
+ *   after the mask, dW = a^T (mask(g) + g_add) - one pass over `a` for a weight that receives
+ *   gradient from two losses (both_all / both_layerwise, gnndelete_nodeemb.py:215-262).
  * Replaces autograd's matmul backward for deletion_weight. */
 int64_t gd_rows_gemm_wgrad_workspace(int32_t n_sel, int32_t d_a, int32_t d_b);
 int gd_rows_gemm_wgrad_f32(const float* a, int64_t ld_a, const int32_t* a_idx,
                            const float* g, int64_t ld_g, const int32_t* g_idx,
-                           const float* relu_mask, int32_t n_sel, int32_t d_a, int32_t d_b,
-                           float* dw, int32_t accumulate, float* partials, void* stream);
+                           const float* relu_mask, const float* g_add, int32_t n_sel, int32_t d_a,
+                           int32_t d_b, float* dw, int32_t accumulate, float* partials, void* stream);
 
 /* gd_rows_gemm_wgrad_f32 followed by torch.optim.Adam on `param` with the freshly reduced dW,
  * fused into the split-K reduction (t = *iter + 1; `iter` is a shared iteration counter that
  * gd_loss_finalize_f32 advances once per step). */
 int gd_rows_gemm_wgrad_adam_f32(const float* a, int64_t ld_a, const int32_t* a_idx,
                                 const float* g, int64_t ld_g, const int32_t* g_idx,
-                                const float* relu_mask, int32_t n_sel, int32_t d_a, int32_t d_b,
-                                float* dw, int32_t accumulate, float* partials,
+                                const float* relu_mask, const float* g_add, int32_t n_sel, int32_t d_a,
+                                int32_t d_b, float* dw, int32_t accumulate, float* partials,
                                 float* param, float* exp_avg, float* exp_avg_sq, const int32_t* iter,
                                 double lr, double beta1, double beta2, double eps, void* stream);
 

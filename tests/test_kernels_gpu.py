@@ -107,6 +107,10 @@ def test_rows_gemm_forward_transpose_and_inplace(n, d_in, d_out, frac):
     # dense (idx = None)
     out3 = ops.rows_gemm(x.cuda(), None, w.cuda())
     assert rel_l2(out3.cpu(), x.double() @ w.double()) < TOL
+    # ReLU backward folded into the epilogue
+    gate = torch.randn(n, d_out, generator=torch.Generator().manual_seed(5))
+    out4 = ops.rows_gemm(x.cuda(), idx, w.cuda(), out=torch.zeros(n, d_out, device='cuda'), out_gate=gate.cuda())
+    assert rel_l2(out4.cpu()[mask], want * (gate[mask] > 0)) < TOL or want.numel() == 0
     if d_in == d_out:                                                   # in place (the Del operator)
         z = x.clone().cuda()
         ops.rows_gemm(z, idx, w.cuda(), out=z)
@@ -139,6 +143,11 @@ def test_rows_gemm_wgrad(n, d_a, d_b, frac):
     assert rel_l2(got2.cpu(), want2) < TOL
     # deterministic split-K
     assert torch.equal(ops.rows_gemm_wgrad(a.cuda(), idx, gr.cuda(), idx, s), got)
+    # second gradient source added after the mask: a^T (mask(g) + g_add)
+    g2 = torch.randn(n, d_b, generator=g)
+    got3 = ops.rows_gemm_wgrad(ac, None, gr.cuda(), idx, s, relu_mask=rm.cuda(), g_add=g2.cuda())
+    want3 = a.double()[mask].t() @ (gr.double() * (rm > 0) + g2.double())[mask]
+    assert rel_l2(got3.cpu(), want3) < TOL or s == 0
 
 
 def test_del_rows_autograd_matches_reference_golden():
@@ -261,7 +270,7 @@ def test_adam_rounding_sequence_and_fused_entry_points():
     up = (torch.randn(S, d, generator=g) * 1e-4).cuda()
     ws = torch.empty(L.gd_rows_gemm_wgrad_workspace(S, d, d), device='cuda')
     dw = torch.empty(d, d, device='cuda')
-    check(L.gd_rows_gemm_wgrad_f32(ptr(a), d, None, ptr(up), d, None, None, S, d, d, ptr(dw), 0, ptr(ws), s))
+    check(L.gd_rows_gemm_wgrad_f32(ptr(a), d, None, ptr(up), d, None, None, None, S, d, d, ptr(dw), 0, ptr(ws), s))
     hyper = (1e-3, 0.9, 0.999, 1e-8)
 
     ref = torch.nn.Parameter(p0.clone())
@@ -282,7 +291,7 @@ def test_adam_rounding_sequence_and_fused_entry_points():
             assert int(ctr) == t0
         else:
             dw2 = torch.empty_like(dw)
-            check(L.gd_rows_gemm_wgrad_adam_f32(ptr(a), d, None, ptr(up), d, None, None, S, d, d, ptr(dw2), 0, ptr(ws),
+            check(L.gd_rows_gemm_wgrad_adam_f32(ptr(a), d, None, ptr(up), d, None, None, None, S, d, d, ptr(dw2), 0, ptr(ws),
                                                 ptr(p), ptr(m), ptr(v), ptr(ctr), *hyper, s))
             assert torch.equal(dw2, dw)
         outs.append((p.cpu(), m.cpu(), v.cpu()))
