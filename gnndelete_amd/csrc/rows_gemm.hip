@@ -25,11 +25,13 @@ constexpr int kWgradMaxRows = 1024;   // rows of the reduction dimension one wgr
 
 constexpr int kGemmThreads = 512;   // 8 waves share one LDS weight image; 2 blocks per CU
 
-template <int NT>
+// MODE 0: plain, 1: also emit the packed sign pattern of the output, 2: gate the output by such a pattern
+template <int NT, int MODE>
 __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
     const float* in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel,
     const float* __restrict__ w, int32_t d_in, int32_t trans_w, const float* __restrict__ bias, int32_t relu_in,
-    float* out, int64_t ld_out, float* __restrict__ save_in, const float* __restrict__ out_gate, int64_t ld_gate) {
+    float* out, int64_t ld_out, float* __restrict__ save_in, const uint32_t* __restrict__ gate_bits,
+    uint32_t* __restrict__ sign_out) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   constexpr int d_out = 32 * NT;
   constexpr int kWaves = kGemmThreads / 64;
@@ -63,34 +65,39 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
   // Software pipeline over chunks AND tiles: while chunk kc feeds the matrix cores, chunk kc+1 -
   // or chunk 0 of this wave's NEXT tile - is already in flight, so a tile never starts with an
   // exposed index + HBM round trip.  All loads are unconditional (clamped rows), no branches.
-  auto row_of = [&](int tile_) -> int64_t {
+  auto row_of = [&](int tile_) -> int32_t {       // 32-bit row ids: registers are the scarce resource here
     const int s_ = min(tile_ * 32 + r_lo, n_sel - 1);
-    return idx ? (int64_t)idx[s_] : (int64_t)s_;
+    return idx ? idx[s_] : s_;
   };
   int tile = blockIdx.x * kWaves + wave;
   if (tile >= n_tiles) return;
-  int64_t row_cur = row_of(tile);
-  int64_t row_nxt = row_of(min(tile + stride, n_tiles - 1));
+  int32_t row_cur = row_of(tile);
+  int32_t row_nxt = row_of(min(tile + stride, n_tiles - 1));
   float4 a_next[4];
   {
-    const float4* src0 = reinterpret_cast<const float4*>(in + row_cur * ld_in) + khalf * 4;
+    const float4* src0 = reinterpret_cast<const float4*>(in + (int64_t)row_cur * ld_in) + khalf * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) a_next[i] = src0[i];
   }
   for (; tile < n_tiles; tile += stride) {
     const int s_a = tile * 32 + r_lo;
     const bool live = s_a < n_sel;
-    const float4* src = reinterpret_cast<const float4*>(in + row_cur * ld_in) + khalf * 4;
-    const float4* src_n = reinterpret_cast<const float4*>(in + row_nxt * ld_in) + khalf * 4;
+    const float4* src = reinterpret_cast<const float4*>(in + (int64_t)row_cur * ld_in) + khalf * 4;
+    const float4* src_n = reinterpret_cast<const float4*>(in + (int64_t)row_nxt * ld_in) + khalf * 4;
     float4* sav = save_in ? reinterpret_cast<float4*>(save_in + (int64_t)s_a * d_in) + khalf * 4 : nullptr;
-    // row index of the tile after next (consumed two iterations from now)
-    const int64_t row_nn = row_of(min(tile + 2 * stride, n_tiles - 1));
 
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // packed ReLU gate of this lane's row (one bit per output feature), in flight during the k loop
+    uint32_t gate_w[NT];
+    if (MODE == 2) {
+      const uint32_t* gsrc = gate_bits + (int64_t)min(s_a, n_sel - 1) * NT;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) gate_w[t] = gsrc[t];
+    }
 
     for (int kc = 0; kc < kchunks; ++kc) {
       float4 a4[4];
@@ -126,27 +133,35 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
     }
 
     // ---- epilogue: D[i][j], j = lane&31 = sample, i = (r&3) + 8*(r>>2) + 4*(lane>>5) = feature
-    if (live) {
-      float* dst = out + row_cur * ld_out + 4 * khalf;
-      const float* gate = out_gate ? out_gate + row_cur * ld_gate + 4 * khalf : nullptr;
+    // (feature 32t + 8q + 4 khalf + c sits in acc[t][4q + c]; bit b of word t of a row's packed
+    //  sign / gate mask is feature 32t + b, so this lane owns bits 8q + 4 khalf + c of each word)
+    float* dst = out + (int64_t)row_cur * ld_out + 4 * khalf;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NT; ++t) {
+      uint32_t pos = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float4 v = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
-          const int n0 = 32 * t + 8 * q;
-          if (bias) v = f4_add(v, *reinterpret_cast<const float4*>(bias + n0 + 4 * khalf));
-          if (gate) {   // ReLU backward: pass the gradient where the forward activation input was > 0
-            const float4 m = *reinterpret_cast<const float4*>(gate + n0);
-            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
-            v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-          }
-          *reinterpret_cast<float4*>(dst + n0) = v;
+      for (int q = 0; q < 4; ++q) {
+        float4 v = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+        const int n0 = 32 * t + 8 * q;
+        if (bias) v = f4_add(v, *reinterpret_cast<const float4*>(bias + n0 + 4 * khalf));
+        if (MODE == 2) {   // ReLU backward: pass the gradient where the forward activation input was > 0
+          const uint32_t m = gate_w[t] >> (8 * q + 4 * khalf);
+          v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f;
+          v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
         }
+        if (MODE == 1)
+          pos |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
+                 << (8 * q + 4 * khalf);
+        if (live) *reinterpret_cast<float4*>(dst + n0) = v;
+      }
+      if (MODE == 1) {     // the two half-row lanes merge their bits (all lanes shuffle)
+        pos |= (uint32_t)__shfl_xor((int)pos, 32);
+        if (live && khalf == 0) sign_out[(int64_t)s_a * NT + t] = pos;
       }
     }
     row_cur = row_nxt;
-    row_nxt = row_nn;
+    // row index of the tile after next: its first loads are only issued at the end of the next tile
+    row_nxt = row_of(min(tile + 2 * stride, n_tiles - 1));
   }
 }
 
@@ -155,8 +170,8 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
 __global__ __launch_bounds__(256) void rows_gemm_scalar_kernel(
     const float* in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel,
     const float* __restrict__ w, int32_t d_in, int32_t d_out, int32_t trans_w, const float* __restrict__ bias,
-    int32_t relu_in, float* out, int64_t ld_out, float* __restrict__ save_in, const float* __restrict__ out_gate,
-    int64_t ld_gate) {
+    int32_t relu_in, float* out, int64_t ld_out, float* __restrict__ save_in, const uint32_t* __restrict__ gate_bits,
+    uint32_t* __restrict__ sign_out) {
   constexpr int kMaxPerLane = 16;  // d_in <= 1024
   const int lane = threadIdx.x & 63;
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -170,6 +185,8 @@ __global__ __launch_bounds__(256) void rows_gemm_scalar_kernel(
     if (save_in && k < d_in) save_in[(int64_t)s * d_in + k] = v;
     xr[q] = relu_in ? fmaxf(v, 0.f) : v;
   }
+  const int n_words = (d_out + 31) >> 5;
+  uint32_t word = 0;
   for (int j = 0; j < d_out; ++j) {
     float p = 0.f;
 #pragma unroll
@@ -178,11 +195,14 @@ __global__ __launch_bounds__(256) void rows_gemm_scalar_kernel(
       if (k < d_in) p = fmaf(xr[q], trans_w ? w[(int64_t)j * d_in + k] : w[(int64_t)k * d_out + j], p);
     }
     p = wave_sum(p);
+    p += bias ? bias[j] : 0.f;
+    if (gate_bits && !((gate_bits[(int64_t)s * n_words + (j >> 5)] >> (j & 31)) & 1u)) p = 0.f;
+    if (p > 0.f) word |= 1u << (j & 31);
     if (lane == 0) {
-      p += bias ? bias[j] : 0.f;
-      if (out_gate && !(out_gate[row * ld_gate + j] > 0.f)) p = 0.f;
       out[row * ld_out + j] = p;
+      if (sign_out && ((j & 31) == 31 || j == d_out - 1)) sign_out[(int64_t)s * n_words + (j >> 5)] = word;
     }
+    if ((j & 31) == 31) word = 0;
   }
 }
 
@@ -426,55 +446,70 @@ static inline void wgrad_geometry(int32_t n_sel, int* n_blocks, int* rows_per_bl
 
 static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w,
                           int32_t d_in, int32_t d_out, int32_t trans_w, const float* bias, int32_t relu_in,
-                          const float* out_gate, int64_t ld_gate, float* out, int64_t ld_out, float* save_in,
-                          void* stream) {
+                          const uint32_t* gate_bits, uint32_t* sign_out, float* out, int64_t ld_out,
+                          float* save_in, void* stream) {
   using namespace gd;
-  GD_REQUIRE(!out_gate || (ld_gate >= d_out && out_gate != out), GD_E_DIM, "gd_rows_gemm_gated_f32: bad gate");
   GD_REQUIRE(in && w && out, GD_E_NULL, "gd_rows_gemm_f32: null pointer");
   GD_REQUIRE(n_sel >= 0 && d_in > 0 && d_out > 0 && ld_in >= d_in && ld_out >= d_out, GD_E_DIM,
              "gd_rows_gemm_f32: bad dims n_sel=%d d_in=%d d_out=%d", n_sel, d_in, d_out);
   GD_REQUIRE(in != out || d_in == d_out, GD_E_DIM, "gd_rows_gemm_f32: in-place needs d_in == d_out");
+  GD_REQUIRE(!(gate_bits && sign_out), GD_E_DIM, "gd_rows_gemm_f32: gate and sign output are exclusive");
   if (n_sel == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)d_in * d_out * sizeof(float);
   const bool mfma_ok = (d_out % 32 == 0) && d_out <= 128 && (d_in % 32 == 0) && lds <= 64 * 1024 && aligned16(in) &&
                        (ld_in % 4 == 0) && (!save_in || aligned16(save_in)) && aligned16(out) && (ld_out % 4 == 0) &&
-                       (!bias || aligned16(bias)) && (!out_gate || (aligned16(out_gate) && ld_gate % 4 == 0));
+                       (!bias || aligned16(bias));
   if (mfma_ok) {
     const int n_tiles = (n_sel + 31) / 32;
     int grid = (n_tiles + 7) / 8;
     if (grid > 512) grid = 512;
-#define GD_RG_CASE(NT)                                                                                        \
-  hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in, idx, n_sel, w, \
-                     d_in, trans_w, bias, relu_in, out, ld_out, save_in, out_gate, ld_gate)
+#define GD_RG_LAUNCH(NT, MODE)                                                                                    \
+  hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT, MODE>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in, idx,   \
+                     n_sel, w, d_in, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out)
+#define GD_RG_CASE(NT)                                                                                            \
+  do {                                                                                                            \
+    if (gate_bits) GD_RG_LAUNCH(NT, 2);                                                                           \
+    else if (sign_out) GD_RG_LAUNCH(NT, 1);                                                                       \
+    else GD_RG_LAUNCH(NT, 0);                                                                                     \
+  } while (0)
     switch (d_out / 32) {
       case 1: GD_RG_CASE(1); break;
       case 2: GD_RG_CASE(2); break;
       case 3: GD_RG_CASE(3); break;
       default: GD_RG_CASE(4); break;
     }
+#undef GD_RG_LAUNCH
 #undef GD_RG_CASE
     return launched("rows_gemm_mfma");
   }
   GD_REQUIRE(d_in <= 1024, GD_E_DIM, "gd_rows_gemm_f32: fallback path needs d_in <= 1024 (got %d)", d_in);
   hipLaunchKernelGGL(rows_gemm_scalar_kernel, dim3((n_sel + 3) / 4), dim3(256), 0, s, in, ld_in, idx, n_sel, w, d_in,
-                     d_out, trans_w, bias, relu_in, out, ld_out, save_in, out_gate, ld_gate);
+                     d_out, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out);
   return launched("rows_gemm_scalar");
 }
 
 extern "C" int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w,
                                 int32_t d_in, int32_t d_out, int32_t trans_w, const float* bias, int32_t relu_in,
                                 float* out, int64_t ld_out, float* save_in, void* stream) {
-  return rows_gemm_impl(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, bias, relu_in, nullptr, 0, out, ld_out,
+  return rows_gemm_impl(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, bias, relu_in, nullptr, nullptr, out, ld_out,
+                        save_in, stream);
+}
+
+extern "C" int gd_rows_gemm_signs_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel,
+                                      const float* w, int32_t d_in, int32_t d_out, int32_t trans_w, const float* bias,
+                                      int32_t relu_in, float* out, int64_t ld_out, float* save_in,
+                                      uint32_t* sign_bits, void* stream) {
+  GD_REQUIRE(sign_bits, GD_E_NULL, "gd_rows_gemm_signs_f32: null sign_bits");
+  return rows_gemm_impl(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, bias, relu_in, nullptr, sign_bits, out, ld_out,
                         save_in, stream);
 }
 
 extern "C" int gd_rows_gemm_gated_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel,
                                       const float* w, int32_t d_in, int32_t d_out, int32_t trans_w,
-                                      const float* out_gate, int64_t ld_gate, float* out, int64_t ld_out,
-                                      void* stream) {
-  GD_REQUIRE(out_gate, GD_E_NULL, "gd_rows_gemm_gated_f32: null gate");
-  return rows_gemm_impl(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, nullptr, 0, out_gate, ld_gate, out, ld_out,
+                                      const uint32_t* gate_bits, float* out, int64_t ld_out, void* stream) {
+  GD_REQUIRE(gate_bits, GD_E_NULL, "gd_rows_gemm_gated_f32: null gate");
+  return rows_gemm_impl(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, nullptr, 0, gate_bits, nullptr, out, ld_out,
                         nullptr, stream);
 }
 

@@ -203,6 +203,7 @@ class NodeembEngine:
         self.dz1 = torch.zeros(n, self.h, **f32)                     # only loss rows are ever written
         self.dz2 = torch.zeros(n, self.o, **f32)
         self.dh = torch.zeros(n, self.h, **f32)                      # only S1 rows are ever written
+        self.z1_pos = torch.zeros(max(1, self.s1), (self.h + 31) // 32, dtype=torch.int32, device=dev)   # [z1[S1] > 0]
         self.g1 = torch.zeros_like(self.wd1)                         # the .grad of W_D1 / W_D2
         self.g2 = torch.zeros_like(self.wd2)
         self.sums = torch.zeros(4, **f32)                            # r1, l1, r2, l2 (sums of squares)
@@ -297,7 +298,7 @@ class NodeembEngine:
         # ReLU backward is applied in the GEMM epilogue so dh can outlive this iteration's z1)
         if join is not None:
             torch.cuda.current_stream().wait_stream(join)      # the side branch may still read last step's dh
-        ops.rows_gemm(dt2, self.idx1, w2, trans_w=False, out=self.dh, out_gate=self.z1)
+        ops.rows_gemm(dt2, self.idx1, w2, trans_w=False, out=self.dh, gate_bits=self.z1_pos)
 
     def _spmm(self, transposed, val, x, y, bias, self_coef):
         g = self.graph
@@ -344,10 +345,10 @@ class NodeembEngine:
         with torch.no_grad():
             # ---- forward, layer 1
             if self.cache_layer1:
-                ops.rows_gemm(self.p1, self.idx1, self.wd1, out=self.z1)     # unmasked rows of z1 stay = p1
+                ops.rows_gemm(self.p1, self.idx1, self.wd1, out=self.z1, sign_bits=self.z1_pos)   # other rows stay = p1
             else:
                 self._conv1_forward()
-                ops.rows_gemm(self.z1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1)
+                ops.rows_gemm(self.z1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1, sign_bits=self.z1_pos)
             fused_fin = self.t1.folded and self.t2.folded       # partials reduced by the finalize kernel
             if not fused_fin:
                 self.sums.zero_()

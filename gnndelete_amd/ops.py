@@ -63,9 +63,11 @@ def spmm(x, graph, bias=None, self_coef=0.0):
 
 
 # ------------------------------------------------------------------------------ Del operator
-def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, save_in=None, out_gate=None):
-    """out[idx] = act(inp[idx]) @ (w or w^T) - raw call (no autograd).  With `out_gate` (a [N, d_out]
-    tensor) the product is zeroed where the gate is <= 0 (ReLU backward in the epilogue)."""
+def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, save_in=None, gate_bits=None,
+              sign_bits=None):
+    """out[idx] = act(inp[idx]) @ (w or w^T) - raw call (no autograd).
+    sign_bits (int32 [n_sel, ceil(d_out/32)], written): packed [out > 0] of the rows just produced;
+    gate_bits (same layout, read): zero the product where the bit is clear (ReLU backward in the epilogue)."""
     inp = _f32_rows(inp)
     n_sel = inp.shape[0] if idx is None else int(idx.shape[0])
     d_in = inp.shape[1]
@@ -74,11 +76,20 @@ def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, sa
     if out is None:
         out = torch.empty(inp.shape[0], d_out, dtype=torch.float32, device=inp.device)
     w = w.contiguous()
-    if out_gate is not None:
-        assert bias is None and not relu_in and save_in is None
+    n_words = (d_out + 31) // 32
+    if gate_bits is not None:
+        assert bias is None and not relu_in and save_in is None and sign_bits is None
+        assert gate_bits.dtype == torch.int32 and gate_bits.is_contiguous() and gate_bits.numel() >= n_sel * n_words
         check(_lib.lib().gd_rows_gemm_gated_f32(ptr(inp), inp.stride(0), ptr(idx), n_sel, ptr(w), d_in, d_out,
-                                                int(trans_w), ptr(out_gate), out_gate.stride(0), ptr(out),
-                                                out.stride(0), stream_ptr(inp.device)), 'gd_rows_gemm_gated_f32')
+                                                int(trans_w), ptr(gate_bits), ptr(out), out.stride(0),
+                                                stream_ptr(inp.device)), 'gd_rows_gemm_gated_f32')
+        return out
+    if sign_bits is not None:
+        assert sign_bits.dtype == torch.int32 and sign_bits.is_contiguous() and sign_bits.numel() >= n_sel * n_words
+        check(_lib.lib().gd_rows_gemm_signs_f32(ptr(inp), inp.stride(0), ptr(idx), n_sel, ptr(w), d_in, d_out,
+                                                int(trans_w), ptr(bias), int(relu_in), ptr(out), out.stride(0),
+                                                ptr(save_in), ptr(sign_bits), stream_ptr(inp.device)),
+              'gd_rows_gemm_signs_f32')
         return out
     check(_lib.lib().gd_rows_gemm_f32(ptr(inp), inp.stride(0), ptr(idx), n_sel, ptr(w), d_in, d_out, int(trans_w),
                                       ptr(bias), int(relu_in), ptr(out), out.stride(0), ptr(save_in),

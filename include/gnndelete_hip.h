@@ -147,13 +147,23 @@ int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t
                      const float* bias, int32_t relu_in,
                      float* out, int64_t ld_out, float* save_in, void* stream);
 
-/* The same product with the ReLU backward folded into its epilogue:
- *       out[r,n] = out_gate[r,n] > 0 ? (in[r,:] @ W)[n] : 0
- * (input gradient of `relu -> conv2.lin`, deletion.py:67-68: dh = (dt2 @ W2) * [z1 > 0]); the
- * gate must not alias `out`. */
+/* gd_rows_gemm_f32 that also emits the sign pattern of what it wrote, packed one bit per output
+ * feature: sign_bits is compact [n_sel, ceil(d_out/32)] words, bit b of word k of entry s is set
+ * iff out[idx[s], 32k + b] > 0.  With W = deletion_weight this is the ReLU gate of F.relu(x1)
+ * (deletion.py:66-67) recorded while the Del output is still in registers. */
+int gd_rows_gemm_signs_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel,
+                           const float* w, int32_t d_in, int32_t d_out, int32_t trans_w,
+                           const float* bias, int32_t relu_in,
+                           float* out, int64_t ld_out, float* save_in, uint32_t* sign_bits, void* stream);
+
+/* The product with the ReLU backward folded into its epilogue:
+ *       out[r,n] = gate bit (s,n) ? (in[r,:] @ W)[n] : 0,   r = idx[s]
+ * gate_bits: what gd_rows_gemm_signs_f32 wrote for the SAME idx list and d_out (input gradient of
+ * `relu -> conv2.lin`, deletion.py:67-68: dh = (dt2 @ W2) * [z1 > 0]).  16 B of gate per row
+ * instead of a second [n_sel, d_out] fp32 read. */
 int gd_rows_gemm_gated_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel,
                            const float* w, int32_t d_in, int32_t d_out, int32_t trans_w,
-                           const float* out_gate, int64_t ld_gate, float* out, int64_t ld_out, void* stream);
+                           const uint32_t* gate_bits, float* out, int64_t ld_out, void* stream);
 
 /* Weight gradient of the row-subset GEMM:  dW[d_a, d_b] (+)= sum_s a[ia(s),:]^T g[ig(s),:]
  *   ia(s) = a_idx ? a_idx[s] : s, likewise g_idx.  Deterministic split-K: `partials` must hold

@@ -107,10 +107,16 @@ def test_rows_gemm_forward_transpose_and_inplace(n, d_in, d_out, frac):
     # dense (idx = None)
     out3 = ops.rows_gemm(x.cuda(), None, w.cuda())
     assert rel_l2(out3.cpu(), x.double() @ w.double()) < TOL
-    # ReLU backward folded into the epilogue
-    gate = torch.randn(n, d_out, generator=torch.Generator().manual_seed(5))
-    out4 = ops.rows_gemm(x.cuda(), idx, w.cuda(), out=torch.zeros(n, d_out, device='cuda'), out_gate=gate.cuda())
-    assert rel_l2(out4.cpu()[mask], want * (gate[mask] > 0)) < TOL or want.numel() == 0
+    # packed sign pattern of the output, and the ReLU backward gated by such a pattern
+    n_words = (d_out + 31) // 32
+    bits = torch.zeros(max(1, int(mask.sum())), n_words, dtype=torch.int32, device='cuda')
+    out4 = ops.rows_gemm(x.cuda(), idx, w.cuda(), out=torch.zeros(n, d_out, device='cuda'), sign_bits=bits)
+    assert torch.equal(out4, out.where(torch.from_numpy(np.asarray(mask))[:, None].cuda(), torch.zeros((), device='cuda')))
+    sel = out4.cpu()[mask]
+    got_bits = (bits.cpu()[:sel.shape[0], :, None] >> torch.arange(32, dtype=torch.int32)) & 1
+    assert torch.equal(got_bits.reshape(sel.shape[0], n_words * 32)[:, :d_out].bool(), sel > 0)
+    out5 = ops.rows_gemm(x.cuda(), idx, (w * 1.5).cuda(), out=torch.zeros(n, d_out, device='cuda'), gate_bits=bits)
+    assert rel_l2(out5.cpu()[mask], 1.5 * want * (sel > 0)) < TOL or want.numel() == 0
     if d_in == d_out:                                                   # in place (the Del operator)
         z = x.clone().cuda()
         ops.rows_gemm(z, idx, w.cuda(), out=z)
