@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32-input matrix peak, v_mfma_f32_32x32x2_f32 (same guide)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -121,6 +122,35 @@ def time_dominant_kernel(eng, reps=20):
     rows = plan.n_items - plan.n_slots + plan.n_split      # rows this launch produces
     frac = rows / max(1, eng.n)
     return dur_s, int(spmm_algorithmic_bytes(eng.n, g.nnz, h) * frac) if frac < 0.999 else spmm_algorithmic_bytes(eng.n, g.nnz, h)
+
+
+def time_del_gemm(eng, reps=20):
+    """Average duration of the layer-1 Del operator (row-subset GEMM over the S1 rows, d = 128) launched
+    back to back between two HIP events with the step's own operands; flops = 2 S d^2."""
+    from gnndelete_amd import ops
+    if eng.s1 == 0:
+        return None
+    z = torch.randn(eng.n, eng.h, device=eng.x.device)
+    out = torch.empty_like(z)
+    w = eng.wd1.detach()
+
+    def launch():
+        ops.rows_gemm(z, eng.idx1, w, out=out)
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    dur_s = e0.elapsed_time(e1) / 1e3 / reps
+    flops = 2.0 * eng.s1 * eng.h * eng.h
+    return {'kernel': 'rows_gemm_mfma_kernel<4,0> (Del operator, S1 rows, d=128)', 'bound': 'mfma',
+            'achieved': flops / dur_s / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': flops / dur_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 'avg_us': dur_s * 1e6, 'rows': eng.s1,
+            'hbm_gbs': 4.0 * (2 * eng.s1 * eng.h + eng.h * eng.h + eng.s1) / dur_s / 1e9}
 
 
 def cpu_baseline(args, data, model_state, neg, iters):
@@ -275,6 +305,8 @@ def main():
                 ceng.step()
             torch.cuda.synchronize()
             out['extras'] = {'iters_per_s_with_loop_invariant_layer1_cached': args.steps / (time.perf_counter() - t1)}
+        if world == 1 and hasattr(eng, 'idx1'):
+            out.setdefault('extras', {})['roofline_del_gemm'] = time_del_gemm(eng)
         if not args.no_cpu_baseline and world == 1:
             cpu_data = data.clone().cpu() if hasattr(data, 'clone') else data
             out['cpu_baseline'] = cpu_baseline(args, cpu_data, state, neg, args.cpu_baseline_iters)
