@@ -7,15 +7,17 @@ framework/trainer/gnndelete.py:138-309):
   loss = 0.5 loss_r + 0.5 loss_l, single Adam, zero_grad after the step (:249-255)
 
 Upstream materialises z z^T over ALL N x N node pairs plus an N x N boolean mask on the CPU and
-indexes it every epoch.  Only the |S| x |S| block of S_Df nodes is ever read, so only that block
-is formed here (one [|S|, d] x [d, |S|] library GEMM), with the pair mask and the original
-probabilities gathered once.  Autograd runs through the HIP-backed model."""
+indexes it every epoch.  Only the |S| x |S| block of S_Df nodes is ever read, and even that block is
+never formed here: gd_pairs_sigmoid_mse_f32 (csrc/pairs.hip) computes the loss and its gradient tile
+by tile on the matrix cores; the original probabilities of the included pairs are gathered once into
+a dense [|S|, |S|] target (negative = pair excluded).  Autograd runs through the HIP-backed model."""
 import os
 import time
 
 import torch
 import torch.nn.functional as F
 
+from ... import ops
 from ..graph_utils import negative_sampling
 from .base import Trainer, _require_gpu, device
 
@@ -48,12 +50,19 @@ class GNNDeleteTrainer(Trainer):
         e_sdf = edges[:, data.sdf_mask].contiguous()
         df_edges = edges[:, data.df_mask]
         nodes, pair_mask = sdf_pair_mask(data.num_nodes, data.sdf_node_2hop_mask, df_edges)
-        target = None
-        if bool(pair_mask.any()):
+        target, n_pairs = None, int(pair_mask.sum())
+        if n_pairs:
             if logits_ori is None:
                 raise ValueError('GNNDeleteTrainer needs logits_ori (pred_proba.pt of the original model)')
             ori = logits_ori.to(device) if logits_ori.device != nodes.device else logits_ori
-            target = ori[nodes][:, nodes][pair_mask].sigmoid()
+            target = ori[nodes][:, nodes].float().sigmoid()
+            target.masked_fill_(~pair_mask, -1.0)           # excluded: upper triangle, diagonal, Df pairs
+            s_pad = (target.shape[0] + 3) // 4 * 4          # 16-byte aligned rows for the kernel's float4 loads
+            if s_pad != target.shape[0]:
+                target = F.pad(target, (0, s_pad - target.shape[0]), value=-1.0)
+            target = target.contiguous()
+            nodes32 = nodes.to(torch.int32).contiguous()
+        del pair_mask
         neg_size = int(data.df_mask.sum())
         best_metric = 0
         for epoch in range(args.epochs):
@@ -64,8 +73,7 @@ class GNNDeleteTrainer(Trainer):
             df_logits = model.decode(z, df_edges, neg)
             loss_r = F.mse_loss(df_logits[:neg_size], df_logits[neg_size:])
             if target is not None:
-                zs = z[nodes]
-                loss_l = F.mse_loss((zs @ zs.t())[pair_mask].sigmoid(), target)
+                loss_l = ops.pairs_sigmoid_mse(z, nodes32, target, n_pairs)
             else:
                 loss_l = torch.tensor(0.0, device=device)
             loss = 0.5 * loss_r + 0.5 * loss_l

@@ -306,3 +306,43 @@ class _EdgeDot(torch.autograd.Function):
 
 def edge_dot(z, e0, e1, rel=None, etype=None):
     return _EdgeDot.apply(z, rel, e0, e1, etype)
+
+
+# ------------------------------------------------------------------------------ edge-probability NI term
+class _PairsSigmoidMse(torch.autograd.Function):
+    """mean over the included pairs i > j of (sigmoid(z[nodes[i]] . z[nodes[j]]) - target[i, j])^2,
+    value and gradient from one fused pass (gd_pairs_sigmoid_mse_f32); nothing |S| x |S| is written."""
+
+    @staticmethod
+    def forward(ctx, z, nodes, target, count):
+        z = _f32_rows(z)
+        n_s, d = int(nodes.shape[0]), z.shape[1]
+        assert nodes.dtype == torch.int32 and nodes.is_contiguous()
+        assert target.dtype == torch.float32 and target.dim() == 2 and target.stride(1) == 1
+        assert target.shape[0] >= n_s and target.shape[1] >= n_s
+        loss = torch.zeros((), dtype=torch.float32, device=z.device)
+        dz = torch.empty(max(1, n_s), d, dtype=torch.float32, device=z.device)
+        if count > 0 and n_s > 0:
+            ws = torch.empty(_lib.lib().gd_pairs_sigmoid_mse_workspace(n_s, d), dtype=torch.float32, device=z.device)
+            check(_lib.lib().gd_pairs_sigmoid_mse_f32(ptr(z), z.stride(0), ptr(nodes), n_s, d, ptr(target),
+                                                      target.stride(0), 1.0 / count, ptr(loss), ptr(dz), ptr(ws),
+                                                      stream_ptr(z.device)), 'gd_pairs_sigmoid_mse_f32')
+        else:
+            dz.zero_()
+        ctx.save_for_backward(dz, nodes)
+        ctx.shape = z.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        dz, nodes = ctx.saved_tensors
+        out = torch.zeros(ctx.shape, dtype=torch.float32, device=dz.device)
+        if nodes.numel():
+            out.index_copy_(0, nodes.long(), dz[:nodes.numel()] * dloss)
+        return out, None, None, None
+
+
+def pairs_sigmoid_mse(z, nodes, target, count):
+    """`target`: dense [|S|, |S|] float32, entry (i, j) with i > j = target probability of the pair
+    (nodes[i], nodes[j]), negative = pair excluded; `count` = number of included pairs."""
+    return _PairsSigmoidMse.apply(z, nodes, target, count)

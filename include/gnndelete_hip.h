@@ -237,6 +237,20 @@ int gd_edge_dot_f32(const float* z, int64_t ld_z, int32_t d, const int64_t* e0, 
                     const float* rel, int64_t ld_rel, const int64_t* etype,
                     int64_t n_edges, float* out, void* stream);
 
+/* Edge-probability Neighborhood-Influence term of GNNDeleteTrainer
+ * (framework/trainer/gnndelete.py:174-193 pair mask, :239-241 loss) over the n_s x n_s block of
+ * 2-hop S_Df nodes, value and gradient in one pass, without forming z z^T:
+ *     loss = inv_count * sum_{i>j, T[i][j] >= 0} (sigmoid(z[nodes[i]] . z[nodes[j]]) - T[i][j])^2
+ *     dz[i,:] = d loss / d z[nodes[i],:]                      (compact [n_s, d])
+ * target: [n_s, n_s] row-major (ld_t), only the strictly lower triangle is read; a negative entry
+ * excludes the pair (the Df pairs, :186-190).  inv_count = 1 / number of included pairs.
+ * workspace: gd_pairs_sigmoid_mse_workspace(n_s, d) floats.  Replaces the N x N `z @ z.t()`,
+ * the N x N boolean mask indexing and their autograd backward. */
+int64_t gd_pairs_sigmoid_mse_workspace(int32_t n_s, int32_t d);
+int gd_pairs_sigmoid_mse_f32(const float* z, int64_t ld_z, const int32_t* nodes, int32_t n_s, int32_t d,
+                             const float* target, int64_t ld_t, float inv_count,
+                             float* loss, float* dz, float* workspace, void* stream);
+
 /* ---------------------------------------------------------------- optimizer ------------ */
 
 /* torch.optim.Adam (no amsgrad, weight_decay 0) on one tensor (delete_gnn.py:221-226).

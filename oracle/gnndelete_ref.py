@@ -13,7 +13,7 @@ What each piece follows (paths relative to /root/reference):
   decode / distmult        framework/models/gcn.py:26-36, rgcn.py:40-47
   LOSSES                   framework/trainer/gnndelete_nodeemb.py:19-97
   nodeemb_terms / epoch    framework/trainer/gnndelete_nodeemb.py:169-299
-  edgeprob_epoch           framework/trainer/gnndelete.py:211-258
+  edgeprob_terms/fullbatch framework/trainer/gnndelete.py:174-193, 211-258
   eval_linkpred            framework/trainer/base.py:229-305
   negative_sampling_kg     framework/utils.py:46-58
 
@@ -306,6 +306,28 @@ def edgeprob_terms(model, z, df_edges, neg_edge, pair_index, logits_ori_pairs):
         return loss_r, torch.zeros(())
     cur = (z[pair_index[0]] * z[pair_index[1]]).sum(-1).sigmoid()
     return loss_r, F.mse_loss(cur, logits_ori_pairs.sigmoid())
+
+
+def edgeprob_fullbatch(model, data, epochs, logits_ori, lr, neg_edge):
+    """GNNDeleteTrainer.train_fullbatch (gnndelete.py:211-258) without evaluation: fixed injected
+    negatives, loss = 0.5 loss_r + 0.5 loss_l, ONE Adam over the Del weights, zero_grad after the
+    step.  -> per-epoch dicts(train_loss, loss_r, loss_l)."""
+    E = data['train_pos_edge_index']
+    df_edges, e_sdf = E[:, data['df_mask']], E[:, data['sdf_mask']]
+    pairs = sdf_pair_index(data['x'].shape[0], data['sdf_node_2hop_mask'], df_edges)
+    ori_pairs = logits_ori[pairs[0], pairs[1]]
+    opt = torch.optim.Adam([p for n, p in model.named_parameters() if 'del' in n], lr=lr)
+    logs = []
+    for _ in range(epochs):
+        model.train()
+        z = model(data['x'], e_sdf)
+        loss_r, loss_l = edgeprob_terms(model, z, df_edges, neg_edge, pairs, ori_pairs)
+        loss = 0.5 * loss_r + 0.5 * loss_l
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        logs.append(dict(train_loss=float(loss), loss_r=float(loss_r), loss_l=float(loss_l)))
+    return logs
 
 
 # ----------------------------------------------------------------------------

@@ -368,6 +368,45 @@ def golden_trajectories(D, T, A):
         np.savez_compressed(os.path.join(HERE, f'traj_{gnn}_{loss_type}.npz'), **out)
 
 
+def golden_edgeprob_trajectories(D, TE, A):
+    """The real GNNDeleteTrainer.train_fullbatch loop (framework/trainer/gnndelete.py:138-309): N x N
+    pair masks, per-epoch negatives (the stub returns the same injected set), sigmoid(z z^T) against
+    logits_ori, 0.5 / 0.5 mix, single Adam with zero_grad after the step."""
+    for gnn in ['gcn', 'gat']:
+        g = synth_graph(90, 340, 10, seed=23)
+        d, neg = prepare_deletion(g, 9, seed=8)
+        model, _ = build_ref_model(D, A, gnn, d, 10, seed=5)
+        with torch.no_grad():
+            model.deletion1.deletion_weight.fill_(1 / 1000)
+            model.deletion2.deletion_weight.fill_(1 / 1000)
+            z_ori = model.get_original_embeddings(d['x'], d['train_pos_edge_index'][:, d['dr_mask']])
+            logits_ori = z_ori @ z_ori.t()          # what Trainer.test stores as pred_proba.pt (base.py:288)
+        init = state_np(model)
+        model.to = lambda *a, **k: model
+        tmp = tempfile.mkdtemp()
+        args = make_args(A, ['--gnn', gnn, '--unlearning_model', 'gnndelete', '--epochs', '6', '--valid_freq', '3',
+                             '--checkpoint_dir', tmp, '--dataset', 'Cora', '--lr', '0.01'])
+        opt = torch.optim.Adam([{'params': [p for n_, p in model.named_parameters() if 'del' in n_],
+                                 'weight_decay': 0.0}], lr=args.lr)
+        STATE['neg'], STATE['wandb'] = neg, []
+        torch.manual_seed(78)
+        trainer = TE.GNNDeleteTrainer(args)
+        trainer.train_fullbatch(model, d, opt, args, logits_ori=logits_ori)
+        steps = [w for w in STATE['wandb'] if 'Epoch' in w]
+        vals = [w for w in STATE['wandb'] if 'val_loss' in w]
+        out = dict(init)
+        out.update(data_np(d, neg))
+        out.update(logits_ori=np_(logits_ori),
+                   train_loss=np.array([s['train_loss'] for s in steps]),
+                   loss_r=np.array([s['loss_r'] for s in steps]),
+                   loss_l=np.array([s['loss_l'] for s in steps]),
+                   final_w1=np_(model.deletion1.deletion_weight), final_w2=np_(model.deletion2.deletion_weight),
+                   val_dt_auc=np.array([v['val_dt_auc'] for v in vals]),
+                   val_df_auc=np.array([v['val_df_auc'] for v in vals]),
+                   lr=np.float64(args.lr), epochs=np.int64(6), eval_seed=np.int64(78))
+        np.savez_compressed(os.path.join(HERE, f'traj_edgeprob_{gnn}.npz'), **out)
+
+
 def golden_gcn_layerwise_crash(D, T, A):
     """record that upstream GCNDelete + both_layerwise raises."""
     g = synth_graph(40, 120, 6, seed=31)
@@ -527,10 +566,14 @@ def golden_prep(D):
 def main():
     torch.set_num_threads(4)
     D, T, TE, A, U, B = load_reference()
+    if sys.argv[1:] == ['edgeprob']:            # add these fixtures without rewriting the others
+        golden_edgeprob_trajectories(D, TE, A)
+        return
     golden_del_layer(D)
     golden_losses(T)
     golden_wiring(D, A)
     golden_trajectories(D, T, A)
+    golden_edgeprob_trajectories(D, TE, A)
     crash = golden_gcn_layerwise_crash(D, T, A)
     golden_parse_args(A)
     golden_eval(D, T, A)

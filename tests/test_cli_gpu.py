@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import hip_model, load_golden, split_fixture, t
+from helpers import hip_model, load_golden, rel_l2, split_fixture, t
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -140,3 +140,31 @@ def test_minibatch_trainer_runs(tmp_path, monkeypatch):
     with open(os.path.join(out, 'trainer_log.json')) as f:
         log = json.load(f)
     assert 0.0 <= log['dt_auc'] <= 1.0
+
+
+@pytest.mark.parametrize('gnn', ['gcn', 'gat'])
+def test_edgeprob_trainer_reproduces_reference_trajectory(tmp_path, monkeypatch, gnn):
+    """GNNDeleteTrainer.train_fullbatch on the HIP path (fused pair kernel, csrc/pairs.hip) against the
+    trajectory of the reference's real loop (gnndelete.py:138-309), same injected negatives."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework.data import Data
+    from gnndelete_amd.framework.trainer import gnndelete as TE
+    fx = load_golden(f'traj_edgeprob_{gnn}.npz')
+    state, data, rest = split_fixture(fx)
+    m = hip_model(gnn, state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    neg = t(rest['neg']).cuda()
+    monkeypatch.setattr(TE, 'negative_sampling', lambda **kw: neg)
+    epochs = int(rest['epochs'])
+    args = SimpleNamespace(unlearning_model='gnndelete', dataset='Cora', checkpoint_dir=str(tmp_path),
+                           eval_on_cpu=False, epochs=epochs, valid_freq=1, lr=float(rest['lr']))
+    opt = torch.optim.Adam([p for n, p in m.named_parameters() if 'del' in n], lr=args.lr)
+    tr = TE.GNNDeleteTrainer(args)
+    torch.manual_seed(int(rest['eval_seed']))
+    tr.train(m, Data(data), opt, args, logits_ori=t(rest['logits_ori']))
+    logs = [r for r in tr.trainer_log['log'] if 'train_loss_l' in r]
+    assert len(logs) == epochs
+    np.testing.assert_allclose([r['train_loss'] for r in logs], rest['train_loss'], rtol=1e-4)
+    np.testing.assert_allclose([r['train_loss_l'] for r in logs], rest['loss_l'], rtol=1e-4)
+    np.testing.assert_allclose([r['train_loss_r'] for r in logs], rest['loss_r'], rtol=1e-4)
+    assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), rest['final_w1']) < 1e-4
+    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < 1e-4

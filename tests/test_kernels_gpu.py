@@ -432,3 +432,48 @@ def test_rowtarget_mse_matches_direct_formula(d):
     rest = torch.ones(n, dtype=torch.bool)
     rest[rows] = False
     assert torch.all(dz.cpu()[rest] == 5.0)
+
+
+@pytest.mark.parametrize('n,s,d,n_df', [(400, 300, 64, 40), (200, 70, 64, 10), (90, 90, 128, 0), (50, 33, 32, 5),
+                                        (40, 1, 64, 0), (40, 0, 64, 0), (60, 45, 20, 6), (3000, 2500, 64, 300)])
+def test_pairs_sigmoid_mse_matches_oracle_pairs(n, s, d, n_df):
+    """Edge-probability NI term (gnndelete.py:174-193, 239-241): the fused tile kernel against the
+    oracle's explicit pair list in float64 - value and gradient - including a ragged last tile, a
+    single node, no node at all, excluded (Df) pairs and a feature width off the MFMA path."""
+    from gnndelete_amd import ops
+    from oracle import gnndelete_ref as R
+    g = torch.Generator().manual_seed(n + s + d)
+    z = torch.randn(n, d, generator=g) * 0.4
+    mask = torch.zeros(n, dtype=torch.bool)
+    mask[torch.randperm(n, generator=g)[:s]] = True
+    nodes = mask.nonzero().flatten()
+    df = torch.stack([nodes[torch.randint(0, max(s, 1), (n_df,), generator=g)],
+                      nodes[torch.randint(0, max(s, 1), (n_df,), generator=g)]]) if s else torch.zeros(2, 0, dtype=torch.long)
+    ori = torch.randn(n, n, generator=g)
+    pairs = R.sdf_pair_index(n, mask, df) if s else torch.zeros(2, 0, dtype=torch.long)
+    count = pairs.shape[1]
+
+    zd = z.double().requires_grad_(True)
+    if count:
+        want = ((zd[pairs[0]] * zd[pairs[1]]).sum(-1).sigmoid() - ori.double()[pairs[0], pairs[1]].sigmoid()).pow(2).mean()
+        want.backward()
+
+    pos = torch.full((n,), -1, dtype=torch.long)
+    pos[nodes] = torch.arange(s)
+    s_pad = (s + 3) // 4 * 4
+    target = torch.full((max(s, 1), max(s_pad, 4)), -1.0)
+    target[pos[pairs[0]], pos[pairs[1]]] = ori[pairs[0], pairs[1]].sigmoid()
+    zg = z.cuda().requires_grad_(True)
+    got = ops.pairs_sigmoid_mse(zg, nodes.int().cuda(), target.cuda(), count)
+    (got * 3.0).backward()
+    if count == 0:
+        assert float(got) == 0.0 and float(zg.grad.abs().max()) == 0.0
+        return
+    assert abs(float(got) - float(want)) <= 1e-5 * abs(float(want))
+    assert rel_l2(zg.grad.cpu() / 3.0, zd.grad) < TOL
+    assert torch.all(zg.grad.cpu()[~mask] == 0)
+    # deterministic (fixed-order split reduction)
+    zg2 = z.cuda().requires_grad_(True)
+    got2 = ops.pairs_sigmoid_mse(zg2, nodes.int().cuda(), target.cuda(), count)
+    (got2 * 3.0).backward()
+    assert torch.equal(got2, got) and torch.equal(zg2.grad, zg.grad)

@@ -95,6 +95,20 @@ def test_training_trajectory_matches_reference_loop(gnn, loss_type):
     assert rel_l2(m.deletion2.deletion_weight.detach(), rest['final_w2']) < 1e-5
 
 
+@pytest.mark.parametrize('gnn', ['gcn', 'gat'])
+def test_edgeprob_trajectory_matches_reference_loop(gnn):
+    """The reference's real GNNDeleteTrainer.train_fullbatch (gnndelete.py:138-309: N x N pair masks,
+    sigmoid(z z^T) against logits_ori) vs the oracle's pair-list restatement."""
+    fx = load_golden(f'traj_edgeprob_{gnn}.npz')
+    state, data, rest = split_fixture(fx)
+    m = oracle_model(gnn, state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    logs = R.edgeprob_fullbatch(m, data, int(rest['epochs']), t(rest['logits_ori']), float(rest['lr']), t(rest['neg']))
+    for key in ['train_loss', 'loss_r', 'loss_l']:
+        np.testing.assert_allclose(np.array([l[key] for l in logs]), rest[key], rtol=2e-5, atol=1e-9, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach(), rest['final_w1']) < 1e-5
+    assert rel_l2(m.deletion2.deletion_weight.detach(), rest['final_w2']) < 1e-5
+
+
 def test_eval_matches_reference():
     fx = load_golden('eval.npz')
     state, data, rest = split_fixture(fx)
