@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(const int32_t* __restrict
 // feature rows those rows gather are shared and stay in that XCD's private 4 MB L2, instead of
 // every edge going out to the fabric (measured: 18 % L2 hit rate and 5.4x the algorithmic bytes
 // with one block per 64 random rows).
-template <int LPR, int VPL, bool EXACT>
+// ADDR32: byte offsets of x rows fit 32 bits and (row id, row pitch in bytes) fit 24 bits, so a row
+// address is ONE full-rate v_mul_u32_u24 instead of a 64-bit multiply (three quarter-rate integer
+// multiplies per gathered row made the kernel issue-bound, not memory-bound, once the rows hit in L2).
+template <int LPR, int VPL, bool EXACT, bool ADDR32>
 __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restrict__ items, int32_t n_items,
                                                            const int32_t* __restrict__ col,
                                                            const float* __restrict__ val,
@@ -121,13 +124,16 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
   int i = i0 + wx;
   if (i >= i1) return;
 
+  const uint32_t pitch_b = (uint32_t)ldx * 4u;
   int4 desc = items[i];
   int kk = min(desc.y + lane, nnz - 1);
   int c = col[kk];
   float w = val ? val[kk] : 1.0f;
   for (; i < i1; i += waves_per_xcd) {
     const int row = desc.x, slot = desc.w;
-    const int cnt = desc.z - desc.y;
+    // the descriptor is the same in every lane: keep the edge count in an SGPR so that the trip
+    // structure below is scalar control flow
+    const int cnt = __builtin_amdgcn_readfirstlane(desc.z - desc.y);
     const int c_cur = c;
     const float w_cur = lane < cnt ? w : 0.f;
     // prefetch the next visit (clamped, branch-free)
@@ -140,24 +146,36 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
     const int trips = (cnt + G - 1) / G;
+    // Slot j of the item (j = trip * G + g) is fetched from lane j of (c_cur, w_cur) through the LDS
+    // crossbar (byte-addressed ds_bpermute, everything kept pre-multiplied by 4).  The gathers are
+    // what this kernel is bound by - a wave64 x 16-byte load occupies the CU's texture addresser for
+    // 16 cycles whether or not its rows are useful - so a trip past the end of the item is skipped
+    // by a SCALAR branch (no load issued at all); only the last, partly filled trip pads: its extra
+    // lane groups re-read the item's last neighbour (cached) and take weight 0 from lane `cnt`.
+    const int last4 = 4 * cnt - 4, end4 = 4 * cnt;
     for (int t0 = 0; t0 < trips; t0 += U) {
       float4 xv[U][VPL];
       float wj[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int j = (t0 + u) * G + g;
-        // shuffles stay outside any lane-dependent condition (a permute issued under a
-        // partial exec mask cannot read the lanes that are switched off)
-        const int cj = __shfl(c_cur, j & 63);
-        const float wsh = __shfl(w_cur, j & 63);
-        const int c0 = __shfl(c_cur, 0);
-        wj[u] = j < cnt ? wsh : 0.f;
-        const int cs = j < cnt ? cj : c0;
-        const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)cs * ldx);
+        if (t0 + u < trips) {
+          const int j4 = 4 * ((t0 + u) * G) + 4 * g;
+          const int cs = __builtin_amdgcn_ds_bpermute(min(j4, last4), c_cur);
+          wj[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(min(j4, end4), __float_as_int(w_cur)));
+          const float4* xr;
+          if (ADDR32)   // row byte offset by one full-rate 24-bit multiply
+            xr = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + __umul24((uint32_t)cs, pitch_b));
+          else
+            xr = reinterpret_cast<const float4*>(x + (int64_t)cs * ldx);
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          const int vec = li + v * LPR;
-          xv[u][v] = EXACT ? xr[vec] : xr[min(vec, d4 - 1)];
+          for (int v = 0; v < VPL; ++v) {
+            const int vec = li + v * LPR;
+            xv[u][v] = EXACT ? xr[vec] : xr[min(vec, d4 - 1)];
+          }
+        } else {
+          wj[u] = 0.f;
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) xv[u][v] = f4_zero();
         }
       }
 #pragma unroll
@@ -320,7 +338,7 @@ extern "C" int gd_rgcn_mean_f32(const int32_t* rowptr, const int32_t* col, const
 extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
                                         const int32_t* col, const float* val, const float* x, int64_t ldx, float* y,
                                         int64_t ldy, const float* bias, float self_coef, float* scratch, int32_t d,
-                                        int32_t nnz, void* stream) {
+                                        int32_t nnz, int32_t x_rows, void* stream) {
   using namespace gd;
   GD_REQUIRE(items && col && x && y, GD_E_NULL, "gd_spmm_csr_balanced_f32: null pointer");
   GD_REQUIRE(n_split == 0 || (split && scratch), GD_E_NULL, "gd_spmm_csr_balanced_f32: split rows need scratch");
@@ -342,14 +360,21 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   nblk = (nblk + 7) / 8 * 8;
   const dim3 grid(nblk), block(256);
   const int4* it = reinterpret_cast<const int4*>(items);
+  // 24-bit fast addressing needs: column ids < 2^24, row pitch in bytes < 2^24, x smaller than 4 GiB
+  const bool addr32 = x_rows > 0 && x_rows <= (1 << 24) && ldx * 4 < (1 << 24) &&
+                      (int64_t)x_rows * ldx * 4 < (1ll << 32);
+#define GD_ITEMS_LAUNCH(LPR, VPL, EXACT, A32)                                                                      \
+  hipLaunchKernelGGL((spmm_persist_kernel<LPR, VPL, EXACT, A32>), grid, block, 0, s, it, n_items, col, val, x, ldx, \
+                     y, ldy, bias, self_coef, scratch, d4, nnz)
 #define GD_ITEMS_CASE(LPR, VPL)                                                                                    \
   do {                                                                                                             \
-    if (d4 == LPR * VPL)                                                                                           \
-      hipLaunchKernelGGL((spmm_persist_kernel<LPR, VPL, true>), grid, block, 0, s, it, n_items, col, val, x, ldx, y, \
-                         ldy, bias, self_coef, scratch, d4, nnz);                                                  \
-    else                                                                                                           \
-      hipLaunchKernelGGL((spmm_persist_kernel<LPR, VPL, false>), grid, block, 0, s, it, n_items, col, val, x, ldx, \
-                         y, ldy, bias, self_coef, scratch, d4, nnz);                                               \
+    if (d4 == LPR * VPL) {                                                                                         \
+      if (addr32) GD_ITEMS_LAUNCH(LPR, VPL, true, true);                                                           \
+      else GD_ITEMS_LAUNCH(LPR, VPL, true, false);                                                                 \
+    } else {                                                                                                       \
+      if (addr32) GD_ITEMS_LAUNCH(LPR, VPL, false, true);                                                          \
+      else GD_ITEMS_LAUNCH(LPR, VPL, false, false);                                                                \
+    }                                                                                                              \
   } while (0)
   if (d4 <= 1) GD_ITEMS_CASE(1, 1);
   else if (d4 <= 2) GD_ITEMS_CASE(2, 1);
@@ -361,6 +386,7 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   else if (d4 <= 128) GD_ITEMS_CASE(64, 2);
   else GD_ITEMS_CASE(64, 4);
 #undef GD_ITEMS_CASE
+#undef GD_ITEMS_LAUNCH
   int rc = launched("spmm_persist");
   if (rc || n_split == 0) return rc;
   hipLaunchKernelGGL(spmm_fixup_kernel, dim3((n_split + 3) / 4), block, 0, s, reinterpret_cast<const int4*>(split),

@@ -65,11 +65,13 @@ int gd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
  * `scratch`.  split[4*i..] = {row, first_slot, n_slots, 0} lists the rows cut into several
  * items; their partials are added in slot order by a second kernel (no atomics: deterministic).
  * nnz = length of col/val (index loads are clamped to it instead of being predicated).
+ * x_rows = number of rows of x (every col id is < x_rows); when x is smaller than 4 GiB the
+ * gathers use 32-bit row offsets (pass 0 if unknown: 64-bit addressing).
  * Same arithmetic, same call sites as gd_spmm_csr_f32. */
 int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
                              const int32_t* col, const float* val, const float* x, int64_t ldx,
                              float* y, int64_t ldy, const float* bias, float self_coef,
-                             float* scratch, int32_t d, int32_t nnz, void* stream);
+                             float* scratch, int32_t d, int32_t nnz, int32_t x_rows, void* stream);
 
 /* Per-relation mean aggregation of R-GCN ("typed SpMM") over a relation-major CSR:
  *   rowptr[(r*n_rows + i) .. +1] delimit the in-edges of type r into node i;
