@@ -48,6 +48,25 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
 __device__ __forceinline__ float4 f4_shfl_xor(float4 v, int mask) {
   return make_float4(__shfl_xor(v.x, mask), __shfl_xor(v.y, mask), __shfl_xor(v.z, mask), __shfl_xor(v.w, mask));
 }
+// v[l] + v[l ^ 32] / v[l ^ 16] in every lane without the LDS crossbar: gfx950's v_permlane{32,16}_swap
+// exchanges the upper/lower 32 lanes (odd/even 16-lane rows) of two registers in one VALU op
+__device__ __forceinline__ float xor32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// acc[l] += acc[l ^ off] for off = LPR, 2 LPR, ... < 64 (the sum over the 64 / LPR lane groups)
+template <int LPR>
+__device__ __forceinline__ float4 f4_group_sum(float4 a) {
+#pragma unroll
+  for (int off = LPR; off < 16; off <<= 1) a = f4_add(a, f4_shfl_xor(a, off));
+  if (LPR <= 16) a = make_float4(xor16_sum(a.x), xor16_sum(a.y), xor16_sum(a.z), xor16_sum(a.w));
+  if (LPR <= 32) a = make_float4(xor32_sum(a.x), xor32_sum(a.y), xor32_sum(a.z), xor32_sum(a.w));
+  return a;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);

@@ -184,10 +184,7 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
         for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
     }
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-#pragma unroll
-      for (int off = LPR; off < kWave; off <<= 1) acc[v] = f4_add(acc[v], f4_shfl_xor(acc[v], off));
-    }
+    for (int v = 0; v < VPL; ++v) acc[v] = f4_group_sum<LPR>(acc[v]);
     if (g == 0) {
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
@@ -197,7 +194,10 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
         if (slot < 0) {
           if (self_coef != 0.0f) o = f4_fma(self_coef, reinterpret_cast<const float4*>(x + (int64_t)row * ldx)[vec], o);
           if (bias) o = f4_add(o, reinterpret_cast<const float4*>(bias)[vec]);
-          reinterpret_cast<float4*>(y + (int64_t)row * ldy)[vec] = o;
+          if (ADDR32)
+            reinterpret_cast<float4*>(reinterpret_cast<char*>(y) + __umul24((uint32_t)row, (uint32_t)ldy * 4u))[vec] = o;
+          else
+            reinterpret_cast<float4*>(y + (int64_t)row * ldy)[vec] = o;
         } else {
           reinterpret_cast<float4*>(scratch + (int64_t)slot * d4 * 4)[vec] = o;
         }
@@ -360,9 +360,9 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   nblk = (nblk + 7) / 8 * 8;
   const dim3 grid(nblk), block(256);
   const int4* it = reinterpret_cast<const int4*>(items);
-  // 24-bit fast addressing needs: column ids < 2^24, row pitch in bytes < 2^24, x smaller than 4 GiB
-  const bool addr32 = x_rows > 0 && x_rows <= (1 << 24) && ldx * 4 < (1 << 24) &&
-                      (int64_t)x_rows * ldx * 4 < (1ll << 32);
+  // 24-bit fast addressing needs: row ids < 2^24, row pitches in bytes < 2^24, x and y smaller than 4 GiB
+  const bool addr32 = x_rows > 0 && x_rows <= (1 << 24) && ldx * 4 < (1 << 24) && ldy * 4 < (1 << 24) &&
+                      (int64_t)x_rows * ldx * 4 < (1ll << 32) && (int64_t)x_rows * ldy * 4 < (1ll << 32);
 #define GD_ITEMS_LAUNCH(LPR, VPL, EXACT, A32)                                                                      \
   hipLaunchKernelGGL((spmm_persist_kernel<LPR, VPL, EXACT, A32>), grid, block, 0, s, it, n_items, col, val, x, ldx, \
                      y, ldy, bias, self_coef, scratch, d4, nnz)

@@ -65,8 +65,9 @@ int gd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
  * `scratch`.  split[4*i..] = {row, first_slot, n_slots, 0} lists the rows cut into several
  * items; their partials are added in slot order by a second kernel (no atomics: deterministic).
  * nnz = length of col/val (index loads are clamped to it instead of being predicated).
- * x_rows = number of rows of x (every col id is < x_rows); when x is smaller than 4 GiB the
- * gathers use 32-bit row offsets (pass 0 if unknown: 64-bit addressing).
+ * x_rows = an upper bound on the number of rows of x AND of y (every col id and every item row
+ * is < x_rows); when both matrices are smaller than 4 GiB the kernel uses 32-bit row offsets
+ * (pass 0 if unknown: 64-bit addressing).
  * Same arithmetic, same call sites as gd_spmm_csr_f32. */
 int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
                              const int32_t* col, const float* val, const float* x, int64_t ldx,
