@@ -40,6 +40,7 @@ def parse():
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_graph', action='store_true')
     p.add_argument('--no_cached_rate', action='store_true')
+    p.add_argument('--probe_partition', action='store_true', help=argparse.SUPPRESS)   # child-process self test
     p.add_argument('--parallel', default='partition', choices=['partition', 'replicas'],
                    help='N>1: row-partition ONE request over the GPUs (RCCL all-gather + all-reduce, strong '
                         'scaling) or run N independent requests (no exchange, weak scaling)')
@@ -69,7 +70,7 @@ def build_request(args, device):
     return data, model, neg, ni1, ni2
 
 
-def make_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1):
+def make_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1, group=None):
     from gnndelete_amd.engine import NodeembEngine
     model = model.to(device)
     x = data.x.to(device)
@@ -85,7 +86,7 @@ def make_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1):
         # ONE request, rows partitioned over the ranks (strong scaling)
         from gnndelete_amd.dist_engine import PartitionedNodeembEngine
         return PartitionedNodeembEngine(*common, rank, world, loss_type=args.loss_type, alpha=0.5, lr=1e-3,
-                                        use_graph=not args.no_graph)
+                                        use_graph=not args.no_graph, group=group)
     return NodeembEngine(*common, loss_type=args.loss_type, alpha=0.5, lr=1e-3, use_graph=not args.no_graph)
 
 
@@ -201,67 +202,102 @@ def recorded_traffic(n, nnz, d):
     return None
 
 
+def probe_partition_in_child(args, rank):
+    """Run a few partitioned steps of a small request in CHILD processes (one per rank, rendezvous on
+    their own port) under a hard timeout, before this process touches the GPU or RCCL.  A collective
+    that hangs inside RCCL cannot be caught as an exception - but a child can be killed.  -> (ok, note)"""
+    import subprocess
+    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get('MASTER_PORT', '29500')) + 23))
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(args.gpus), '--probe_partition', '--workload',
+           'synth-dblp', '--df', 'out', '--df_size', '2.5', '--gnn', args.gnn, '--loss_type', args.loss_type]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        if r.returncode == 0:
+            return 1, None
+        tail = [l for l in r.stdout.strip().splitlines() if l.strip()][-1:] or ['']
+        return 0, f'partition self-test failed on rank {rank} (exit {r.returncode}): {tail[0][:160]}'
+    except subprocess.TimeoutExpired:
+        return 0, f'partition self-test timed out on rank {rank} (300 s)'
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    assert torch.cuda.is_available(), 'bench.py needs a GPU'
     # GD_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a one-GPU box (all ranks on cuda:0)
     backend = os.environ.get('GD_BENCH_BACKEND', 'nccl')
+    mode, note, probe_ok = ('single' if world == 1 else args.parallel), None, 1
+    if world > 1 and mode == 'partition' and backend == 'nccl' and not args.probe_partition:
+        probe_ok, note = probe_partition_in_child(args, rank)      # before any GPU / RCCL initialisation here
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
     if backend != 'nccl' and torch.cuda.device_count() < world:
         local = 0
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    ctl = group = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
-        else:
-            dist.init_process_group(backend)
+        # control plane (flags, barriers, max-over-ranks of the wall time): gloo on the host, so that it
+        # keeps working whatever state the data-path communicator is in
+        dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=600))
+        ctl = dist.group.WORLD
+        flag = torch.tensor([probe_ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)
+        if mode == 'partition' and not int(flag):
+            mode = args.parallel = 'replicas'
+            note = note or 'partition self-test failed on another rank'
+        if mode == 'partition' and backend == 'nccl':
+            group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=300), device_id=device)
+
+    def barrier():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier(group=ctl)
 
     data, model, neg, ni1, ni2 = build_request(args, device)
     state = {k: v.clone() for k, v in model.state_dict().items()}
-    mode, note = ('single' if world == 1 else args.parallel), None
     if mode == 'partition':
         # build the partitioned engine and take one step; if ANY rank fails (RCCL set-up, capture),
         # every rank falls back to independent replicas so that the run still reports a number
         ok = 1
         try:
-            eng = make_engine(args, data, model, neg, ni1, ni2, device, rank, world)
+            eng = make_engine(args, data, model, neg, ni1, ni2, device, rank, world, group)
             eng.step()
             torch.cuda.synchronize()
         except Exception as e:                                   # noqa: BLE001
             ok, note = 0, f'{type(e).__name__}: {str(e)[:160]}'
-        try:
-            flag = torch.tensor([ok], device=device, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag)
-        except Exception as e:                                   # noqa: BLE001
-            ok, note = 0, note or f'{type(e).__name__}: {str(e)[:160]}'
-        if not ok:
-            mode = 'replicas'
-            args.parallel = 'replicas'
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)
+        if not int(flag):
+            mode = args.parallel = 'replicas'
+            note = note or 'partitioned engine failed on another rank'
             model.load_state_dict(state)
+    if args.probe_partition:
+        for _ in range(3):
+            eng.step()
+        barrier()
+        assert bool(torch.isfinite(eng.loss_history()).all())
+        dist.destroy_process_group()
+        return
     if mode != 'partition':
         eng = make_engine(args, data, model, neg, ni1, ni2, device, rank, world)
 
     for _ in range(args.warmup):
         eng.step()
-    if world > 1:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=ctl)
         dt = float(tmax)
     losses = eng.loss_history()
 
@@ -281,7 +317,7 @@ def main():
                        'df_edges': int(data.directed_df_edge_index.shape[1]),
                        'sdf_edges': int(data.sdf_mask.sum()), 'spmm_nnz': eng.graph.nnz,
                        'S1': int(data.sdf_node_1hop_mask.sum()), 'S2': int(data.sdf_node_2hop_mask.sum()), 'hip_graph': not args.no_graph,
-                       'parallelism': 'single' if world == 1 else (f'row-partition x{world} (RCCL all-gather + all-reduce)'
+                       'parallelism': 'single' if world == 1 else (f'row-partition x{world} (RCCL halo all-to-all + all-reduce)'
                                                                   if partitioned else f'replicas x{world}')},
             'roofline': {'kernel': 'spmm_persist_kernel<32,1,true,true> (layer-1 CSR SpMM, d=128)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
