@@ -208,6 +208,7 @@ def probe_partition_in_child(args, rank):
     that hangs inside RCCL cannot be caught as an exception - but a child can be killed.  -> (ok, note)"""
     import subprocess
     env = dict(os.environ, MASTER_PORT=str(int(os.environ.get('MASTER_PORT', '29500')) + 23))
+    env.pop('TORCHELASTIC_USE_AGENT_STORE', None)      # the children's rank 0 hosts its own rendezvous store
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(args.gpus), '--probe_partition', '--workload',
            'synth-dblp', '--df', 'out', '--df_size', '2.5', '--gnn', args.gnn, '--loss_type', args.loss_type]
     try:
@@ -229,7 +230,8 @@ def main():
     # GD_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a one-GPU box (all ranks on cuda:0)
     backend = os.environ.get('GD_BENCH_BACKEND', 'nccl')
     mode, note, probe_ok = ('single' if world == 1 else args.parallel), None, 1
-    if world > 1 and mode == 'partition' and backend == 'nccl' and not args.probe_partition:
+    force_probe = os.environ.get('GD_BENCH_FORCE_PROBE') == '1'          # lets the gloo test exercise the probe
+    if world > 1 and mode == 'partition' and (backend == 'nccl' or force_probe) and not args.probe_partition:
         probe_ok, note = probe_partition_in_child(args, rank)      # before any GPU / RCCL initialisation here
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     if backend != 'nccl' and torch.cuda.device_count() < world:
