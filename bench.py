@@ -31,7 +31,7 @@ def parse():
     p.add_argument('--steps', type=int, default=200)
     p.add_argument('--warmup', type=int, default=20)
     p.add_argument('--workload', default='synth-collab')
-    p.add_argument('--gnn', default='gcn', choices=['gcn', 'gat', 'gin'])
+    p.add_argument('--gnn', default='gcn', choices=['gcn', 'gat', 'gin', 'sage'])
     p.add_argument('--df', default='in')
     p.add_argument('--df_size', type=float, default=5.0)
     p.add_argument('--loss_type', default='both_layerwise')
@@ -52,7 +52,7 @@ def build_request(args, device):
     from types import SimpleNamespace
     from gnndelete_amd.framework.data import prepare_edge_deletion, resolve_df_size
     from gnndelete_amd.framework.graph_utils import negative_sampling
-    from gnndelete_amd.framework.models import GATDelete, GCNDelete, GINDelete
+    from gnndelete_amd.framework.models import GATDelete, GCNDelete, GINDelete, SAGEDelete
     from gnndelete_amd.framework.synth import make_linkpred_dataset
     from gnndelete_amd.framework.utils import seed_everything
 
@@ -61,7 +61,7 @@ def build_request(args, device):
     size = resolve_df_size(args.df_size, data.train_pos_edge_index.shape[1])
     prepare_edge_deletion(data, df_masks[args.df], size)
     margs = SimpleNamespace(in_dim=data.x.shape[1], hidden_dim=128, out_dim=64)
-    cls = {'gcn': GCNDelete, 'gat': GATDelete, 'gin': GINDelete}[args.gnn]
+    cls = {'gcn': GCNDelete, 'gat': GATDelete, 'gin': GINDelete, 'sage': SAGEDelete}[args.gnn]
     model = cls(margs, data.sdf_node_1hop_mask, data.sdf_node_2hop_mask)
     neg = negative_sampling(data.train_pos_edge_index, data.num_nodes, int(data.df_mask.sum()))
     keep = torch.ones(data.num_nodes, dtype=torch.bool)

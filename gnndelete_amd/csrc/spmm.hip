@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
                                                            const float* __restrict__ x, int64_t ldx,
                                                            float* __restrict__ y, int64_t ldy,
                                                            const float* __restrict__ bias, float self_coef,
+                                                           const float* __restrict__ xs,
                                                            float* __restrict__ scratch, int32_t d4, int32_t nnz) {
   constexpr int G = kWave / LPR;
   constexpr int U = (kWave / G) >= 4 ? 4 : (kWave / G);
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
         if (!EXACT && vec >= d4) continue;
         float4 o = acc[v];
         if (slot < 0) {
-          if (self_coef != 0.0f) o = f4_fma(self_coef, reinterpret_cast<const float4*>(x + (int64_t)row * ldx)[vec], o);
+          if (self_coef != 0.0f) o = f4_fma(self_coef, reinterpret_cast<const float4*>(xs + (int64_t)row * ldx)[vec], o);
           if (bias) o = f4_add(o, reinterpret_cast<const float4*>(bias)[vec]);
           if (ADDR32)
             reinterpret_cast<float4*>(reinterpret_cast<char*>(y) + __umul24((uint32_t)row, (uint32_t)ldy * 4u))[vec] = o;
@@ -337,8 +338,8 @@ extern "C" int gd_rgcn_mean_f32(const int32_t* rowptr, const int32_t* col, const
 
 extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
                                         const int32_t* col, const float* val, const float* x, int64_t ldx, float* y,
-                                        int64_t ldy, const float* bias, float self_coef, float* scratch, int32_t d,
-                                        int32_t nnz, int32_t x_rows, void* stream) {
+                                        int64_t ldy, const float* bias, float self_coef, const float* x_self,
+                                        float* scratch, int32_t d, int32_t nnz, int32_t x_rows, void* stream) {
   using namespace gd;
   GD_REQUIRE(items && col && x && y, GD_E_NULL, "gd_spmm_csr_balanced_f32: null pointer");
   GD_REQUIRE(n_split == 0 || (split && scratch), GD_E_NULL, "gd_spmm_csr_balanced_f32: split rows need scratch");
@@ -351,6 +352,8 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   if (n_items == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
   const int d4 = d / 4;
+  const float* xs = x_self ? x_self : x;            // rows of the self / residual term (same pitch as x)
+  GD_REQUIRE(aligned16(xs) && xs != y, GD_E_ALIGN, "gd_spmm_csr_balanced_f32: bad x_self");
   // grid: a few visits per wave (4 x the resident set of 256 CUs x 8 blocks measured best), a
   // multiple of the 8 XCDs
   int nblk = (n_items + 3) / 4;
@@ -365,7 +368,7 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
                       (int64_t)x_rows * ldx * 4 < (1ll << 32) && (int64_t)x_rows * ldy * 4 < (1ll << 32);
 #define GD_ITEMS_LAUNCH(LPR, VPL, EXACT, A32)                                                                      \
   hipLaunchKernelGGL((spmm_persist_kernel<LPR, VPL, EXACT, A32>), grid, block, 0, s, it, n_items, col, val, x, ldx, \
-                     y, ldy, bias, self_coef, scratch, d4, nnz)
+                     y, ldy, bias, self_coef, xs, scratch, d4, nnz)
 #define GD_ITEMS_CASE(LPR, VPL)                                                                                    \
   do {                                                                                                             \
     if (d4 == LPR * VPL) {                                                                                         \
@@ -390,6 +393,6 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   int rc = launched("spmm_persist");
   if (rc || n_split == 0) return rc;
   hipLaunchKernelGGL(spmm_fixup_kernel, dim3((n_split + 3) / 4), block, 0, s, reinterpret_cast<const int4*>(split),
-                     n_split, scratch, x, ldx, y, ldy, bias, self_coef, d4);
+                     n_split, scratch, xs, ldx, y, ldy, bias, self_coef, d4);
   return launched("spmm_fixup");
 }

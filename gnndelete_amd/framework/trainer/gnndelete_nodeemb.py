@@ -3,7 +3,7 @@
 GNNDeleteNodeClassificationTrainer :498-657).
 
 Two execution paths behind the same API:
-  * fused path (default for --loss_fct mse_mean / mse_sum on GCN / GAT / GIN): the whole
+  * fused path (default for --loss_fct mse_mean / mse_sum on GCN / GAT / GIN / GraphSAGE): the whole
     iteration - frozen-backbone forward, Del, Deleted-Edge-Consistency + Neighborhood-Influence
     losses, hand-derived backward, Adam - is gnndelete_amd.engine.NodeembEngine, one hipGraph
     replay per epoch, no per-step host sync;
@@ -169,9 +169,9 @@ class _EmbeddingUnlearner:
 
     def _can_fuse(self, model, loss_name):
         from ...engine import NodeembEngine  # noqa: F401
-        from ...nn import GATConv, GCNConv, GINConv
+        from ...nn import GATConv, GCNConv, GINConv, SAGEConv
         conv2 = getattr(model, 'conv2', None)
-        return loss_name in ('mse_mean', 'mse_sum') and isinstance(conv2, (GCNConv, GATConv, GINConv)) and \
+        return loss_name in ('mse_mean', 'mse_sum') and isinstance(conv2, (GCNConv, GATConv, GINConv, SAGEConv)) and \
             not (isinstance(conv2, GINConv) and conv2.nn.out_features > conv2.nn.in_features)
 
     def _unlearn(self, model, data, optimizer, args, edge_key, loss_name, loss_type, select_best):

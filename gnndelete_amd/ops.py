@@ -19,19 +19,22 @@ def _f32_rows(t):
     return t
 
 
-def _spmm_raw(rowptr, col, val, x, bias, self_coef, n_rows, plan=None, out=None):
-    """y = self_coef * x + A x + bias.  With a SplitPlan (and a float4-able width) the
-    load-balanced kernel is used, otherwise the one-wave-per-row kernel."""
+def _spmm_raw(rowptr, col, val, x, bias, self_coef, n_rows, plan=None, out=None, x_self=None):
+    """y = self_coef * x_self + A x + bias (x_self = x unless given; same row pitch).  With a SplitPlan
+    (and a float4-able width) the load-balanced kernel is used, otherwise the one-wave-per-row kernel."""
     d = x.shape[1]
+    if x_self is not None:
+        assert plan is not None and x_self.stride(0) == x.stride(0) and x_self.shape[1] == d
     y = out if out is not None else torch.empty(n_rows, d, dtype=torch.float32, device=x.device)
     if plan is not None and d % 4 == 0 and d <= 1024 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
         scratch = plan.scratch(d, x.device)
         check(_lib.lib().gd_spmm_csr_balanced_f32(ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split,
                                                   ptr(col), ptr(val), ptr(x), x.stride(0), ptr(y), y.stride(0),
-                                                  ptr(bias), float(self_coef), ptr(scratch), d, int(col.shape[0]),
+                                                  ptr(bias), float(self_coef), ptr(x_self), ptr(scratch), d, int(col.shape[0]),
                                                   max(int(x.shape[0]), int(y.shape[0])), stream_ptr(x.device)),
               'gd_spmm_csr_balanced_f32')
         return y
+    assert x_self is None, 'x_self needs the balanced kernel (d % 4 == 0, 16-byte aligned rows)'
     check(_lib.lib().gd_spmm_csr_f32(ptr(rowptr), ptr(col), ptr(val), ptr(x), x.stride(0), ptr(y), y.stride(0),
                                      ptr(bias), float(self_coef), n_rows, d, stream_ptr(x.device)),
           'gd_spmm_csr_f32')

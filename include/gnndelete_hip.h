@@ -65,6 +65,9 @@ int gd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
  * `scratch`.  split[4*i..] = {row, first_slot, n_slots, 0} lists the rows cut into several
  * items; their partials are added in slot order by a second kernel (no atomics: deterministic).
  * nnz = length of col/val (index loads are clamped to it instead of being predicated).
+ * x_self (optional, same pitch ldx): the matrix the self_coef term is read from, y[i] += self_coef *
+ * x_self[i,:]; NULL = x itself (GIN's (1+eps) x_i).  With another matrix (or other columns of the
+ * same buffer) and self_coef = 1 it is SAGEConv's root path, out = mean_j(x_j W_l) + b + x_i W_r.
  * x_rows = an upper bound on the number of rows of x AND of y (every col id and every item row
  * is < x_rows); when both matrices are smaller than 4 GiB the kernel uses 32-bit row offsets
  * (pass 0 if unknown: 64-bit addressing).
@@ -72,7 +75,8 @@ int gd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
 int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
                              const int32_t* col, const float* val, const float* x, int64_t ldx,
                              float* y, int64_t ldy, const float* bias, float self_coef,
-                             float* scratch, int32_t d, int32_t nnz, int32_t x_rows, void* stream);
+                             const float* x_self, float* scratch, int32_t d, int32_t nnz, int32_t x_rows,
+                             void* stream);
 
 /* Per-relation mean aggregation of R-GCN ("typed SpMM") over a relation-major CSR:
  *   rowptr[(r*n_rows + i) .. +1] delimit the in-edges of type r into node i;
