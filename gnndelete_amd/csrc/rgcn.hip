@@ -1,0 +1,108 @@
+// R-GCN message passing without the [R, N, d] per-relation aggregate (PyG RGCNConv, aggr='mean',
+// framework/models/rgcn.py:16-38):
+//
+//     y[i,:] += sum_r ( sum_{e in seg(i,r)} w_e x[col_e,:] ) @ W_r          (W_r dense or block-diagonal)
+//
+// The typed graph is node-major: the in-edges of node i are sorted by relation, `seg_*` lists the
+// (node, relation) runs.  One wave per node: it walks the node's runs, accumulates the weighted sum of
+// the neighbour rows of a run in registers (lane l owns features l and l + 64), parks the 128-float
+// aggregate in LDS and applies the relation's transform from there - for a block-diagonal weight every
+// output feature only reads its own block of the aggregate (32 multiply-adds instead of 128).  The
+// [R, N, d] tensor the reference path materialises (4.9 GB per layer at ogbl-biokg size) is never formed,
+// and the 1.6 MB of relation weights stay in L2.
+//
+// With w_e = 1 / |seg| this is the forward; on the transposed graph with w_e = 1 / |seg(target, r)| and
+// `trans` = 1 (the run's aggregate multiplies W_r^T) it is the input gradient.
+#include "common.h"
+
+namespace gd {
+
+__global__ __launch_bounds__(256) void rgcn_conv_kernel(
+    const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_rel,
+    const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ x, int64_t ldx,
+    int32_t d_in, const float* __restrict__ weight, int32_t n_blocks, int32_t ib, int32_t ob, int32_t trans,
+    float* __restrict__ y, int64_t ldy, int32_t d_out, int32_t n_nodes) {
+  __shared__ float agg[4][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* m = agg[wave];
+  // this direction's block geometry: the aggregate has `kb` features per block, the output `nb`
+  const int kb = trans ? ob : ib, nb = trans ? ib : ob;
+  for (int i = blockIdx.x * 4 + wave; i < n_nodes; i += gridDim.x * 4) {
+    const int s0 = node_ptr[i], s1 = node_ptr[i + 1];
+    if (s0 == s1) continue;
+    float o0 = 0.f, o1 = 0.f;
+    for (int s = s0; s < s1; ++s) {
+      const int e0 = seg_ptr[s], e1 = seg_ptr[s + 1], r = seg_rel[s];
+      // ---- weighted sum of the run's neighbour rows (4 rows in flight)
+      float a0 = 0.f, a1 = 0.f;
+      int e = e0;
+      for (; e + 4 <= e1; e += 4) {
+        float v0[4], v1[4], we[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* xr = x + (int64_t)col[e + u] * ldx;
+          we[u] = w[e + u];
+          v0[u] = lane < d_in ? xr[lane] : 0.f;
+          v1[u] = lane + 64 < d_in ? xr[lane + 64] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a0 = fmaf(we[u], v0[u], a0); a1 = fmaf(we[u], v1[u], a1); }
+      }
+      for (; e < e1; ++e) {
+        const float* xr = x + (int64_t)col[e] * ldx;
+        const float we = w[e];
+        if (lane < d_in) a0 = fmaf(we, xr[lane], a0);
+        if (lane + 64 < d_in) a1 = fmaf(we, xr[lane + 64], a1);
+      }
+      m[lane] = a0;
+      m[lane + 64] = a1;
+      // (same wave wrote and reads: LDS operations of one wave complete in order)
+      // ---- transform: output feature o lives in block o / nb and reads that block of the aggregate
+      const float* wr = weight + (int64_t)r * n_blocks * ib * ob;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int o = lane + 64 * h;
+        if (o < d_out) {
+          const int b = o / nb, ol = o - b * nb;
+          const float* mb = m + b * kb;
+          const float* wb = wr + (int64_t)b * ib * ob;
+          float acc = 0.f;
+          if (!trans) {
+            for (int k = 0; k < kb; ++k) acc = fmaf(mb[k], wb[k * ob + ol], acc);     // W[b][k][ol]
+          } else {
+            for (int k = 0; k < kb; ++k) acc = fmaf(mb[k], wb[ol * ob + k], acc);     // W[b][ol][k]
+          }
+          if (h == 0) o0 += acc; else o1 += acc;
+        }
+      }
+    }
+    float* yr = y + (int64_t)i * ldy;
+    if (lane < d_out) yr[lane] += o0;
+    if (lane + 64 < d_out) yr[lane + 64] += o1;
+  }
+}
+
+}  // namespace gd
+
+extern "C" int gd_rgcn_conv_f32(const int32_t* node_ptr, const int32_t* seg_ptr, const int32_t* seg_rel,
+                                const int32_t* col, const float* w, const float* x, int64_t ldx, int32_t d_in,
+                                const float* weight, int32_t n_blocks, int32_t trans, float* y, int64_t ldy,
+                                int32_t d_out, int32_t n_nodes, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(node_ptr && seg_ptr && seg_rel && col && w && x && weight && y, GD_E_NULL, "gd_rgcn_conv_f32: null pointer");
+  GD_REQUIRE(n_nodes >= 0 && d_in > 0 && d_out > 0 && d_in <= 128 && d_out <= 128 && ldx >= d_in && ldy >= d_out,
+             GD_E_DIM, "gd_rgcn_conv_f32: feature widths must be in [1, 128] (d_in=%d d_out=%d)", d_in, d_out);
+  GD_REQUIRE(n_blocks >= 1, GD_E_DIM, "gd_rgcn_conv_f32: n_blocks < 1");
+  // the relation weight is [n_blocks, ib, ob] with (ib, ob) the block of the FORWARD direction
+  const int din_f = trans ? d_out : d_in, dout_f = trans ? d_in : d_out;
+  GD_REQUIRE(din_f % n_blocks == 0 && dout_f % n_blocks == 0, GD_E_DIM,
+             "gd_rgcn_conv_f32: feature widths must be multiples of n_blocks");
+  GD_REQUIRE(x != y, GD_E_DIM, "gd_rgcn_conv_f32: x and y must not alias");
+  if (n_nodes == 0) return GD_OK;
+  int grid = (n_nodes + 3) / 4;
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(rgcn_conv_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, node_ptr, seg_ptr, seg_rel, col,
+                     w, x, ldx, d_in, weight, n_blocks, din_f / n_blocks, dout_f / n_blocks, trans, y, ldy, d_out,
+                     n_nodes);
+  return launched("rgcn_conv");
+}

@@ -180,3 +180,38 @@ def build_typed_csr(edge_index, edge_type, num_nodes, num_relations):
     col_t = vrow[order_t].to(torch.int32)
     inv_t = (1.0 / counts.clamp(min=1).to(torch.float32))[vrow[order_t]]
     return rowptr.to(torch.int32), col, rowptr_t.to(torch.int32), col_t, inv_t
+
+
+class TypedNodeCSR:
+    """Node-major typed graph for the fused R-GCN conv (gd_rgcn_conv_f32): the in-edges of a node are
+    sorted by relation and grouped into (node, relation) runs.  `fwd` aggregates sources into targets
+    with w = 1 / |run| (PyG RGCNConv aggr='mean' per relation); `bwd` is the transposed graph whose
+    edges carry the weight of the forward run they belong to (input gradient)."""
+
+    def __init__(self, edge_index, edge_type, num_nodes, num_relations):
+        n, r = int(num_nodes), int(num_relations)
+        src, dst, et = edge_index[0].long(), edge_index[1].long(), edge_type.long()
+        if src.numel() >= 2 ** 31:
+            raise ValueError('graph too large for int32 CSR indices')
+        self.n, self.num_relations = n, r
+        run_f = dst * r + et
+        order = torch.argsort(run_f * n + src)
+        self.fwd, w_sorted = self._runs(run_f[order], src[order], r, n, None)
+        w_edge = torch.empty_like(w_sorted)
+        w_edge[order] = w_sorted                                   # weight of every edge in input order
+        run_b = src * r + et
+        order_b = torch.argsort(run_b * n + dst)
+        self.bwd, _ = self._runs(run_b[order_b], dst[order_b], r, n, w_edge[order_b])
+
+    @staticmethod
+    def _runs(run_sorted, col_sorted, r, n, w):
+        dev = run_sorted.device
+        runs, counts = torch.unique_consecutive(run_sorted, return_counts=True)
+        seg_ptr = torch.zeros(runs.numel() + 1, dtype=torch.int64, device=dev)
+        seg_ptr[1:] = torch.cumsum(counts, 0)
+        node_ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        node_ptr[1:] = torch.cumsum(torch.bincount(runs // r, minlength=n), 0)
+        if w is None:
+            w = torch.repeat_interleave(1.0 / counts.to(torch.float32), counts)
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        return (i32(node_ptr), i32(seg_ptr), i32(runs % r), i32(col_sorted), w.to(torch.float32).contiguous()), w

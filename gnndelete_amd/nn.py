@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .graph import build_typed_csr, graph_for
+from .graph import TypedNodeCSR, build_typed_csr, graph_for
 
 
 def _glorot(*shape):
@@ -121,6 +121,7 @@ class RGCNConv(nn.Module):
         self.root = _glorot(in_channels, out_channels)
         self.bias = nn.Parameter(torch.zeros(out_channels))
         self._typed = None
+        self._typed_nodes = None
 
     def _typed_csr(self, edge_index, edge_type, n):
         c = self._typed
@@ -129,8 +130,24 @@ class RGCNConv(nn.Module):
             self._typed = c
         return c[3]
 
+    def _typed_node_csr(self, edge_index, edge_type, n):
+        c = self._typed_nodes
+        if c is None or c[0] is not edge_index or c[1] is not edge_type or c[2] != n:
+            c = (edge_index, edge_type, n, TypedNodeCSR(edge_index, edge_type, n, self.num_relations))
+            self._typed_nodes = c
+        return c[3]
+
     def forward(self, x, edge_index, edge_type):
         n = x.shape[0]
+        # Relation weights that need no gradient - evaluation, or a conv the *Delete wrapper marked
+        # frozen (framework/models/deletion.py sets the same plain `requires_grad = False` attribute
+        # upstream does, rgcn.py / deletion.py:145-163) - take the fused kernel: no [R, n, d] tensor.
+        frozen = (not torch.is_grad_enabled()) or getattr(self, 'requires_grad', True) is False \
+            or not self.weight.requires_grad
+        if frozen and self.in_channels <= 128 and self.out_channels <= 128:
+            tg = self._typed_node_csr(edge_index, edge_type, n)
+            nb = 1 if self.num_blocks is None else self.num_blocks
+            return ops.rgcn_conv_frozen(x, tg, self.weight, self.root, self.bias, nb)
         typed = self._typed_csr(edge_index, edge_type, n)
         m = ops.rgcn_mean(x, typed, self.num_relations, n)                  # [R, n, in]
         if self.num_blocks is None:

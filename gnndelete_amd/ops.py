@@ -277,6 +277,42 @@ def rgcn_mean(x, typed, num_rel, n):
     return _RgcnMean.apply(x, typed, num_rel, n)
 
 
+class _RgcnConvFrozen(torch.autograd.Function):
+    """y = sum_r mean_{j in N_r(i)} x_j W_r + x_i root + bias with CONSTANT relation weights (frozen
+    backbone / evaluation): gd_rgcn_conv_f32 forms no [R, n, d] tensor; backward = input gradient only."""
+
+    @staticmethod
+    def forward(ctx, x, tg, weight, root, bias, n_blocks):
+        x = _f32_rows(x)
+        weight = weight.detach().contiguous()
+        y = torch.addmm(bias.detach(), x, root.detach()) if bias is not None else x @ root.detach()
+        node_ptr, seg_ptr, seg_rel, col, w = tg.fwd
+        if col.numel():
+            check(_lib.lib().gd_rgcn_conv_f32(ptr(node_ptr), ptr(seg_ptr), ptr(seg_rel), ptr(col), ptr(w), ptr(x),
+                                              x.stride(0), x.shape[1], ptr(weight), n_blocks, 0, ptr(y), y.stride(0),
+                                              y.shape[1], tg.n, stream_ptr(x.device)), 'gd_rgcn_conv_f32')
+        ctx.tg, ctx.n_blocks = tg, n_blocks
+        ctx.save_for_backward(weight, root.detach())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, root = ctx.saved_tensors
+        dy = _f32_rows(dy)
+        dx = dy @ root.t()
+        node_ptr, seg_ptr, seg_rel, col, w = ctx.tg.bwd
+        if col.numel():
+            check(_lib.lib().gd_rgcn_conv_f32(ptr(node_ptr), ptr(seg_ptr), ptr(seg_rel), ptr(col), ptr(w), ptr(dy),
+                                              dy.stride(0), dy.shape[1], ptr(weight), ctx.n_blocks, 1, ptr(dx),
+                                              dx.stride(0), dx.shape[1], ctx.tg.n, stream_ptr(dy.device)),
+                  'gd_rgcn_conv_f32')
+        return dx, None, None, None, None, None
+
+
+def rgcn_conv_frozen(x, tg, weight, root, bias, n_blocks):
+    return _RgcnConvFrozen.apply(x, tg, weight, root, bias, n_blocks)
+
+
 # ------------------------------------------------------------------------------ decoders
 class _EdgeDot(torch.autograd.Function):
     @staticmethod

@@ -137,6 +137,19 @@ int gd_row_dots_f32(const float* h, int64_t ldh, int32_t n, int32_t d, const flo
 int gd_segment_sum_f32(const int32_t* rowptr, const int32_t* perm, const float* x, int32_t n, float* out,
                        void* stream);
 
+/* Fused R-GCN message passing (PyG RGCNConv aggr='mean', framework/models/rgcn.py:16-38) for constant
+ * relation weights - no [R, N, d] per-relation aggregate is formed:
+ *     y[i,:] += sum over the (i, r) runs of node i:  ( sum_{e in run} w[e] * x[col[e],:] ) @ W_r
+ * Node-major typed graph: node_ptr[n+1] indexes the runs of a node, seg_ptr[S+1] the edges of a run,
+ * seg_rel[S] its relation; col/w per edge (forward: w = 1/|run|).  weight = [R, n_blocks, ib, ob]
+ * (n_blocks = 1: dense [R, d_in, d_out]).  trans != 0 multiplies by W_r^T instead (input gradient on the
+ * transposed graph; then d_in is the forward d_out and vice versa).  y must hold the root/bias term (or
+ * zeros) on entry; d_in, d_out <= 128.  Replaces the per-relation masked propagate + einsum loop. */
+int gd_rgcn_conv_f32(const int32_t* node_ptr, const int32_t* seg_ptr, const int32_t* seg_rel,
+                     const int32_t* col, const float* w, const float* x, int64_t ldx, int32_t d_in,
+                     const float* weight, int32_t n_blocks, int32_t trans,
+                     float* y, int64_t ldy, int32_t d_out, int32_t n_nodes, void* stream);
+
 /* ---------------------------------------------------------------- Del operator --------- */
 
 /* Row-subset GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
