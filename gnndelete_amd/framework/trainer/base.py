@@ -18,6 +18,7 @@ from sklearn.metrics import accuracy_score, f1_score
 from ..evaluation import verification_error
 from ..graph_utils import negative_sampling
 from ..metrics import batched_average_precision, batched_roc_auc
+from ..training_args import is_large
 from ..utils import get_link_labels
 from ._log import fmt, wandb_log
 
@@ -162,7 +163,7 @@ class Trainer:
         if ckpt == 'best':
             state = torch.load(os.path.join(self.args.checkpoint_dir, 'model_best.pt'), map_location='cpu')
             model.load_state_dict(state['model_state'])
-        pred_all = 'ogbl' not in self.args.dataset
+        pred_all = not is_large(self.args.dataset)       # N x N logits only for the small graphs (base.py:314-317)
         loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, logit_all_pair, test_log = self.eval(model, data, 'test', pred_all)
         self.logit_all_pair = logit_all_pair
         self.trainer_log.update({
@@ -230,7 +231,7 @@ class NodeClassificationTrainer(Trainer):
         if ckpt == 'best':
             state = torch.load(os.path.join(self.args.checkpoint_dir, 'model_best.pt'), map_location='cpu')
             model.load_state_dict(state['model_state'])
-        loss, dt_acc, dt_f1, test_log = self.eval(model, data, 'test', 'ogbl' not in self.args.dataset)
+        loss, dt_acc, dt_f1, test_log = self.eval(model, data, 'test', not is_large(self.args.dataset))
         self.trainer_log.update({'dt_loss': loss, 'dt_acc': dt_acc, 'dt_f1': dt_f1})
         if model_retrain is not None:
             self.trainer_log['ve'] = verification_error(model, model_retrain).cpu().item()

@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 from ..graph_utils import negative_sampling
 from ._log import wandb_log
+from ..training_args import is_large
 from .base import NodeClassificationTrainer, Trainer, _require_gpu, device
 
 # ----------------------------------------------------------------------------- loss zoo
@@ -242,7 +243,7 @@ class _EmbeddingUnlearner:
 class GNNDeleteNodeembTrainer(_EmbeddingUnlearner, Trainer):
 
     def train(self, model, data, optimizer, args, logits_ori=None, attack_model_all=None, attack_model_sub=None):
-        if 'ogbl' in self.args.dataset and getattr(args, 'minibatch', False):
+        if is_large(self.args.dataset) and getattr(args, 'minibatch', False):
             return self.train_minibatch(model, data, optimizer, args, logits_ori, attack_model_all, attack_model_sub)
         return self.train_fullbatch(model, data, optimizer, args, logits_ori, attack_model_all, attack_model_sub)
 
