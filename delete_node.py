@@ -22,10 +22,16 @@ from gnndelete_amd.framework.utils import seed_everything
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
 
 
-def main():
+def main(feature_only=False):
+    """feature_only: delete_node_feature.py - the Df nodes keep their edges in the graph structure used
+    for evaluation bookkeeping but their feature rows are zeroed (reference delete_node_feature.py:35,
+    76-85 vs delete_node.py)."""
     args = parse_args()
-    base = 'checkpoint_node'
+    base = 'checkpoint_node_feature' if feature_only else 'checkpoint_node'
     original_path = os.path.join(base, args.dataset, args.gnn, 'original', str(args.random_seed))
+    if feature_only and not os.path.exists(os.path.join(original_path, 'model_best.pt')):
+        # train_node.py writes the original model under checkpoint_node/
+        original_path = os.path.join('checkpoint_node', args.dataset, args.gnn, 'original', str(args.random_seed))
     seed_everything(args.random_seed)
     tail = '-'.join(str(i) for i in [args.df, args.df_size, args.random_seed])
     variant = '-'.join(str(i) for i in [args.loss_fct, args.loss_type, args.alpha, args.neg_sample_random])
@@ -43,6 +49,9 @@ def main():
     df_nodes = torch.randperm(n)[:df_size]
     gone = torch.zeros(n, dtype=torch.bool)
     gone[df_nodes] = True
+    if feature_only:
+        data.x[df_nodes] = 0
+        assert data.x[df_nodes].sum() == 0
     df_mask_edge = gone[data.edge_index[0]] | gone[data.edge_index[1]]
     df_edge = data.edge_index[:, df_mask_edge]
     data.directed_df_edge_index = df_edge[:, df_edge[0] < df_edge[1]]

@@ -116,6 +116,14 @@ def test_cli_node_deletion(tmp_path, monkeypatch, gnn):
     state = torch.load(os.path.join(out, 'model_final.pt'))['model_state']
     assert state['deletion2.deletion_weight'].shape == (4, 4)
     assert not torch.allclose(state['deletion1.deletion_weight'], torch.full((128, 128), 1e-3))
+    if gnn == 'gat':
+        # delete_node_feature.py: same flow, feature rows of the Df nodes zeroed, own checkpoint root
+        run([os.path.join(ROOT, 'delete_node_feature.py')] + common + ['--unlearning_model', 'gnndelete_nodeemb', '--df',
+                                                                       'in', '--df_size', '5'], cwd)
+        out = os.path.join(cwd, 'checkpoint_node_feature', 'synth-tiny', gnn, 'gnndelete_nodeemb-node_deletion',
+                           'mse_mean-both_layerwise-0.5-non_connected', 'in-5.0-42')
+        with open(os.path.join(out, 'trainer_log.json')) as f:
+            assert 'dt_acc' in json.load(f)
 
 
 def test_minibatch_trainer_runs(tmp_path, monkeypatch):
