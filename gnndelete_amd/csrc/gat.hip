@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void gat_items_fwd_kernel(
   int c = col[min(desc.y + lane, nnz - 1)];
   for (; i < i1; i += waves_per_xcd) {
     const int row = desc.x, slot = desc.w;
-    const int cnt = desc.z - desc.y;
+    const int cnt = __builtin_amdgcn_readfirstlane(desc.z - desc.y);   // same in every lane: scalar trip control
     const int c_cur = c;
     desc = items[min(i + waves_per_xcd, i1 - 1)];
     c = col[min(desc.y + lane, nnz - 1)];
@@ -241,22 +241,28 @@ __global__ __launch_bounds__(256) void gat_items_fwd_kernel(
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
     const int trips = (cnt + G - 1) / G;
+    // as in the SpMM (spmm.hip): whole trips past the end issue no gather (scalar branch); the last,
+    // partly filled trip re-reads the item's last neighbour with the weight of lane `cnt` (zero)
+    const int last4 = 4 * cnt - 4, end4 = 4 * cnt;
     for (int t0 = 0; t0 < trips; t0 += U) {
       float4 xv[U][VPL];
       float wj[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int j = (t0 + u) * G + g;
-        const int cj = __shfl(c_cur, j & 63);
-        const float wsh = __shfl(p_cur, j & 63);
-        const int c0 = __shfl(c_cur, 0);
-        wj[u] = j < cnt ? wsh : 0.f;
-        const int cs = j < cnt ? cj : c0;
-        const float4* xr = reinterpret_cast<const float4*>(h + (int64_t)cs * ldh);
+        if (t0 + u < trips) {
+          const int j4 = 4 * ((t0 + u) * G) + 4 * g;
+          const int cs = __builtin_amdgcn_ds_bpermute(min(j4, last4), c_cur);
+          wj[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(min(j4, end4), __float_as_int(p_cur)));
+          const float4* xr = reinterpret_cast<const float4*>(h + (int64_t)cs * ldh);
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          const int vec = li + v * LPR;
-          xv[u][v] = EXACT ? xr[vec] : xr[min(vec, d4 - 1)];
+          for (int v = 0; v < VPL; ++v) {
+            const int vec = li + v * LPR;
+            xv[u][v] = EXACT ? xr[vec] : xr[min(vec, d4 - 1)];
+          }
+        } else {
+          wj[u] = 0.f;
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) xv[u][v] = f4_zero();
         }
       }
 #pragma unroll
@@ -265,9 +271,7 @@ __global__ __launch_bounds__(256) void gat_items_fwd_kernel(
         for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
     }
 #pragma unroll
-    for (int v = 0; v < VPL; ++v)
-#pragma unroll
-      for (int off = LPR; off < kWave; off <<= 1) acc[v] = f4_add(acc[v], f4_shfl_xor(acc[v], off));
+    for (int v = 0; v < VPL; ++v) acc[v] = f4_group_sum<LPR>(acc[v]);
     if (lane == 0) {
       if (slot < 0) { rowmax[row] = m; rowsum[row] = ssum; }
       else { scratch_ms[2 * slot] = m; scratch_ms[2 * slot + 1] = ssum; }
@@ -351,25 +355,44 @@ __global__ __launch_bounds__(256) void gat_items_bwd_dalpha_kernel(
     if (!EXACT && vec >= d4) dyr[v] = f4_zero();
   }
   float tpart = 0.f;
-  const int trips = (cnt + G - 1) / G;
-  for (int it = 0; it < trips; ++it) {
-    const int j = it * G + g;
-    const int cj = __shfl(c, j & 63);
-    const float aj = __shfl(al, j & 63);
-    const int c0 = __shfl(c, 0);
-    const float4* hr = reinterpret_cast<const float4*>(h + (int64_t)(j < cnt ? cj : c0) * ldh);
-    float p = 0.f;
+  const int cnt_s = __builtin_amdgcn_readfirstlane(cnt);           // scalar trip control
+  const int trips = (cnt_s + G - 1) / G;
+  const int last4 = 4 * cnt_s - 4;
+  constexpr int U = 4;                                             // neighbour rows in flight per lane group
+  for (int t0 = 0; t0 < trips; t0 += U) {
+    float4 hv[U][VPL];
+    float aj[U];
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      const int vec = li + v * LPR;
-      const float4 hv = hr[EXACT ? vec : min(vec, d4 - 1)];
-      p = fmaf(dyr[v].x, hv.x, p); p = fmaf(dyr[v].y, hv.y, p); p = fmaf(dyr[v].z, hv.z, p); p = fmaf(dyr[v].w, hv.w, p);
+    for (int u = 0; u < U; ++u) {
+      if (t0 + u < trips) {
+        const int j4 = min(4 * ((t0 + u) * G) + 4 * g, last4);     // padded slots re-read the last neighbour
+        const int cj = __builtin_amdgcn_ds_bpermute(j4, c);
+        aj[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(j4, __float_as_int(al)));
+        const float4* hr = reinterpret_cast<const float4*>(h + (int64_t)cj * ldh);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int vec = li + v * LPR;
+          hv[u][v] = hr[EXACT ? vec : min(vec, d4 - 1)];
+        }
+      }
     }
 #pragma unroll
-    for (int off = 1; off < LPR; off <<= 1) p += __shfl_xor(p, off);
-    if (j < cnt && li == 0) {
-      de[start + j] = p;
-      tpart = fmaf(aj, p, tpart);
+    for (int u = 0; u < U; ++u) {
+      if (t0 + u < trips) {
+        const int j = (t0 + u) * G + g;
+        float p = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          p = fmaf(dyr[v].x, hv[u][v].x, p); p = fmaf(dyr[v].y, hv[u][v].y, p);
+          p = fmaf(dyr[v].z, hv[u][v].z, p); p = fmaf(dyr[v].w, hv[u][v].w, p);
+        }
+#pragma unroll
+        for (int off = 1; off < LPR; off <<= 1) p += __shfl_xor(p, off);
+        if (j < cnt && li == 0) {
+          de[start + j] = p;
+          tpart = fmaf(aj[u], p, tpart);
+        }
+      }
     }
   }
   tpart = wave_sum(tpart);
