@@ -462,6 +462,21 @@ __global__ __launch_bounds__(256) void row_dots_kernel(const float* __restrict__
   if (row < n && li == 0) { a1[row] = p1; a2[row] = p2; }
 }
 
+// y[i,:] += a[i] * u + b[i] * v : the part of d(lin_src output) that comes through the attention logits
+// (a_src = <h, att_src>, a_dst = <h, att_dst>), both rank-1 terms in one pass over y
+__global__ __launch_bounds__(256) void rank1_add2_kernel(float* __restrict__ y, int64_t ldy, int32_t n, int32_t d4,
+                                                         const float* __restrict__ a, const float* __restrict__ u,
+                                                         const float* __restrict__ b, const float* __restrict__ v) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)n * d4) return;
+  const int row = (int)(e / d4), vec = (int)(e % d4);
+  float4* yr = reinterpret_cast<float4*>(y + (int64_t)row * ldy) + vec;
+  float4 o = *yr;
+  o = f4_fma(a[row], reinterpret_cast<const float4*>(u)[vec], o);
+  o = f4_fma(b[row], reinterpret_cast<const float4*>(v)[vec], o);
+  *yr = o;
+}
+
 // out[i] = sum_{k in [rowptr[i], rowptr[i+1])} x[perm ? perm[k] : k]   (deterministic, one wave per row)
 __global__ __launch_bounds__(256) void segment_sum_kernel(const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ perm,
@@ -654,4 +669,17 @@ extern "C" int gd_segment_sum_f32(const int32_t* rowptr, const int32_t* perm, co
   if (n <= 0) return GD_OK;
   hipLaunchKernelGGL(segment_sum_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, rowptr, perm, x, n, out);
   return launched("segment_sum");
+}
+
+extern "C" int gd_rank1_add2_f32(float* y, int64_t ldy, int32_t n, int32_t d, const float* a, const float* u,
+                                 const float* b, const float* v, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(y && a && u && b && v, GD_E_NULL, "gd_rank1_add2_f32: null pointer");
+  GD_REQUIRE(n >= 0 && d > 0 && d % 4 == 0 && ldy % 4 == 0 && ldy >= d, GD_E_DIM, "gd_rank1_add2_f32: d must be a multiple of 4");
+  GD_REQUIRE(aligned16(y) && aligned16(u) && aligned16(v), GD_E_ALIGN, "gd_rank1_add2_f32: unaligned pointer");
+  if (n == 0) return GD_OK;
+  const int64_t total = (int64_t)n * (d / 4);
+  hipLaunchKernelGGL(rank1_add2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, ldy,
+                     n, d / 4, a, u, b, v);
+  return launched("rank1_add2");
 }

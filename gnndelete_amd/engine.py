@@ -313,7 +313,7 @@ class NodeembEngine:
         else:
             dt2, da_s, da_d = ops.gat_backward_raw(g, self._h2, self._a_src, self._a_dst, self._rowmax, self._rowsum,
                                                    self.dz2, c.negative_slope)
-            dt2.addcmul_(da_s[:, None], c.att_src.view(1, -1)).addcmul_(da_d[:, None], c.att_dst.view(1, -1))
+            ops.rank1_add2_(dt2, da_s, c.att_src, da_d, c.att_dst)
             w2 = c.lin_src.weight
         # dh[S1] = (dt2[S1] @ W2) * [z1[S1] > 0]   (W2 is [out, in] = [d_in, d_out] of this product; the
         # ReLU backward is applied in the GEMM epilogue so dh can outlive this iteration's z1)

@@ -205,12 +205,25 @@ def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope):
         ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split, ptr(g.col), ptr(a_src), ptr(a_dst), ptr(rowmax),
         ptr(rowsum), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(alpha), ptr(de), ptr(da_dst), ptr(t_row),
         ptr(scratch), float(slope), d, g.nnz, stream_ptr(dev)), 'gd_gat_edge_grads_balanced_f32')
-    perm = g.perm_t.long()
+    perm = getattr(g, '_perm_t_long', None)
+    if perm is None:
+        perm = g._perm_t_long = g.perm_t.long()                 # cached: the conversion is a kernel launch
     dh = _spmm_raw(g.rowptr_t, g.col_t, alpha[perm], dy, None, 0.0, n, g.plan_t)
     da_src = torch.empty(n, dtype=torch.float32, device=dev)
     check(_lib.lib().gd_segment_sum_f32(ptr(g.rowptr_t), ptr(g.perm_t), ptr(de), n, ptr(da_src), stream_ptr(dev)),
           'gd_segment_sum_f32')
     return dh, da_src, da_dst
+
+
+def rank1_add2_(y, a, u, b, v):
+    """y[i,:] += a[i] * u + b[i] * v, in place (raw, no autograd)."""
+    n, d = y.shape
+    u, v = u.reshape(-1).contiguous(), v.reshape(-1).contiguous()
+    if d % 4 or y.stride(0) % 4 or y.stride(1) != 1:
+        return y.addcmul_(a[:, None], u.view(1, -1)).addcmul_(b[:, None], v.view(1, -1))
+    check(_lib.lib().gd_rank1_add2_f32(ptr(y), y.stride(0), n, d, ptr(a), ptr(u), ptr(b), ptr(v),
+                                       stream_ptr(y.device)), 'gd_rank1_add2_f32')
+    return y
 
 
 def row_dots(h, v1, v2):

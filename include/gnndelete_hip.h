@@ -137,6 +137,12 @@ int gd_row_dots_f32(const float* h, int64_t ldh, int32_t n, int32_t d, const flo
 int gd_segment_sum_f32(const int32_t* rowptr, const int32_t* perm, const float* x, int32_t n, float* out,
                        void* stream);
 
+/* y[i,:] += a[i] * u[:] + b[i] * v[:]  (d % 4 == 0): the gradient that reaches GATConv's linear output
+ * through the attention logits alpha_src = <h, att_src>, alpha_dst = <h, att_dst> (gat.py:11-12 /
+ * PyG GATConv), both rank-1 terms in one pass. */
+int gd_rank1_add2_f32(float* y, int64_t ldy, int32_t n, int32_t d, const float* a, const float* u,
+                      const float* b, const float* v, void* stream);
+
 /* Fused R-GCN message passing (PyG RGCNConv aggr='mean', framework/models/rgcn.py:16-38) for constant
  * relation weights - no [R, N, d] per-relation aggregate is formed:
  *     y[i,:] += sum over the (i, r) runs of node i:  ( sum_{e in run} w[e] * x[col[e],:] ) @ W_r
