@@ -58,6 +58,24 @@ __device__ __forceinline__ float xor16_sum(float v) {
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// Sum over the LPR consecutive lanes of a lane group (LPR a power of two), result in every lane of the
+// group, on the VALU only: DPP quad permutes / row mirrors inside a 16-lane row, permlane swaps above it.
+// Same pairing tree as an xor butterfly (pairs, quads, eights, ...), so the result is bit-identical to it.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int LPR>
+__device__ __forceinline__ float lanes_sum(float v) {
+  if (LPR >= 2) v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+  if (LPR >= 4) v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+  if (LPR >= 8) v = dpp_add<0x141>(v);    // row_half_mirror: the other quad of the 8
+  if (LPR >= 16) v = dpp_add<0x140>(v);   // row_mirror: the other half of the 16
+  if (LPR >= 32) v = xor16_sum(v);
+  if (LPR >= 64) v = xor32_sum(v);
+  return v;
+}
+
 // acc[l] += acc[l ^ off] for off = LPR, 2 LPR, ... < 64 (the sum over the 64 / LPR lane groups)
 template <int LPR>
 __device__ __forceinline__ float4 f4_group_sum(float4 a) {

@@ -386,8 +386,7 @@ __global__ __launch_bounds__(256) void gat_items_bwd_dalpha_kernel(
           p = fmaf(dyr[v].x, hv[u][v].x, p); p = fmaf(dyr[v].y, hv[u][v].y, p);
           p = fmaf(dyr[v].z, hv[u][v].z, p); p = fmaf(dyr[v].w, hv[u][v].w, p);
         }
-#pragma unroll
-        for (int off = 1; off < LPR; off <<= 1) p += __shfl_xor(p, off);
+        p = lanes_sum<LPR>(p);
         if (j < cnt && li == 0) {
           de[start + j] = p;
           tpart = fmaf(aj[u], p, tpart);
@@ -457,8 +456,8 @@ __global__ __launch_bounds__(256) void row_dots_kernel(const float* __restrict__
       p2 = fmaf(hv.x, x2.x, p2); p2 = fmaf(hv.y, x2.y, p2); p2 = fmaf(hv.z, x2.z, p2); p2 = fmaf(hv.w, x2.w, p2);
     }
   }
-#pragma unroll
-  for (int off = 1; off < LPR; off <<= 1) { p1 += __shfl_xor(p1, off); p2 += __shfl_xor(p2, off); }
+  p1 = lanes_sum<LPR>(p1);
+  p2 = lanes_sum<LPR>(p2);
   if (row < n && li == 0) { a1[row] = p1; a2[row] = p2; }
 }
 
