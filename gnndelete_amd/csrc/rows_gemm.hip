@@ -213,11 +213,25 @@ __global__ __launch_bounds__(256) void rows_gemm_scalar_kernel(
 // while tile t feeds the matrix cores); its 4 waves split the TA x TB output tiles and read their
 // MFMA operands straight out of the row-major tiles (lane -> consecutive column: conflict-free).
 // HBM bytes S (d_a + d_b) 4 and flops 2 S d_a d_b are balanced at d = 128 (ridge ~20 flop/B).
-template <int TA, int TB>
+//
+// LOSS: the upstream gradient is not read but FORMED while it is fetched, from the folded row-target MSE
+// terms of that layer (loss.hip): g = coef_u (z - tbar_u) for a row with loss slot u, 0 otherwise
+// (+ g_add).  The loss kernel, its [S, d] gradient write and this kernel's read of it disappear; the
+// two loss sums (cnt_u |z - tbar_u|^2 per kind) fall out of the same fetch as per-block partials.
+struct WgradLoss {
+  const int32_t* slot;     // [n_sel]: loss slot of selected row s, or -1
+  const float* tm;         // [n_slots, d_b] mean targets (compact)
+  const float* coef;       // [n_slots] gradient scale 2 w c
+  const float* cnt_signed; // [n_slots] term count, NI terms stored negative (kind folded into the sign)
+  float* partials;         // [2 * n_blocks] per-block (DEC, NI) sums of cnt |z - tbar|^2
+};
+
+template <int TA, int TB, bool LOSS>
 __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
     const float* __restrict__ a, int64_t ld_a, const int32_t* __restrict__ a_idx, const float* __restrict__ g,
     int64_t ld_g, const int32_t* __restrict__ g_idx, const float* __restrict__ relu_mask,
-    const float* __restrict__ g_add, int32_t n_sel, int32_t rows_per_block, float* __restrict__ partials) {
+    const float* __restrict__ g_add, int32_t n_sel, int32_t rows_per_block, float* __restrict__ partials,
+    WgradLoss loss) {
   constexpr int DA = 32 * TA, DB = 32 * TB, KT = 32;
   constexpr int TILES = TA * TB, TPW = (TILES + 3) / 4;
   constexpr int FA = DA / 4, FB = DB / 4;            // float4 per row
@@ -225,9 +239,12 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
   __shared__ __attribute__((aligned(16))) float sa[2][KT * DA];
   __shared__ __attribute__((aligned(16))) float sg[2][KT * DB];
   __shared__ int32_t sia[kWgradMaxRows], sig[kWgradMaxRows];   // this block's gather lists
+  __shared__ int32_t sls[LOSS ? kWgradMaxRows : 1];            // and loss slots
+  __shared__ float lred[2][4];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int c_lo = lane & 31, khalf = lane >> 5;
+  float ls0 = 0.f, ls1 = 0.f;
 
   f32x16 acc[TPW];
 #pragma unroll
@@ -243,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
   for (int i = tid; i < s_end - s_begin; i += 256) {
     sia[i] = a_idx ? a_idx[s_begin + i] : s_begin + i;
     sig[i] = g_idx ? g_idx[s_begin + i] : s_begin + i;
+    if (LOSS) sls[i] = loss.slot[s_begin + i];
   }
   __syncthreads();
 
@@ -264,8 +282,24 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
       const int f = tid + 256 * i, r = f / FB, c4 = f % FB, ss = s0 + r;
       if (ss < s_end) {
         const int64_t row = sig[ss - s_begin];
-        float4 v = reinterpret_cast<const float4*>(g + row * ld_g)[c4];
-        if (relu_mask) {
+        float4 v;
+        if (LOSS) {
+          const int u = sls[ss - s_begin];
+          v = f4_zero();
+          if (u >= 0) {
+            const float4 zv = reinterpret_cast<const float4*>(g + row * ld_g)[c4];
+            const float4 tv = reinterpret_cast<const float4*>(loss.tm + (int64_t)u * DB)[c4];
+            const float cf = loss.coef[u], cn = loss.cnt_signed[u];
+            const float4 df = make_float4(zv.x - tv.x, zv.y - tv.y, zv.z - tv.z, zv.w - tv.w);
+            float sq = df.x * df.x;
+            sq = fmaf(df.y, df.y, sq); sq = fmaf(df.z, df.z, sq); sq = fmaf(df.w, df.w, sq);
+            if (cn >= 0.f) ls0 = fmaf(cn, sq, ls0); else ls1 = fmaf(-cn, sq, ls1);
+            v = make_float4(cf * df.x, cf * df.y, cf * df.z, cf * df.w);
+          }
+        } else {
+          v = reinterpret_cast<const float4*>(g + row * ld_g)[c4];
+        }
+        if (!LOSS && relu_mask) {
           const float4 m = reinterpret_cast<const float4*>(relu_mask + row * ld_g)[c4];
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
           v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
@@ -321,6 +355,16 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
     for (int r = 0; r < 16; ++r) {
       const int rr = (r & 3) + 8 * (r >> 2) + 4 * khalf;
       dst[(int64_t)(i0 + rr) * DB + j0 + c_lo] = acc[q][r];
+    }
+  }
+  if (LOSS) {
+    ls0 = wave_sum(ls0);
+    ls1 = wave_sum(ls1);
+    if (lane == 0) { lred[0][wave] = ls0; lred[1][wave] = ls1; }
+    __syncthreads();
+    if (tid == 0) {
+      loss.partials[2 * blockIdx.x + 0] = (lred[0][0] + lred[0][1]) + (lred[0][2] + lred[0][3]);
+      loss.partials[2 * blockIdx.x + 1] = (lred[1][0] + lred[1][1]) + (lred[1][2] + lred[1][3]);
     }
   }
 }
@@ -523,8 +567,8 @@ namespace gd {
 struct AdamArgs { float* param; float* m; float* v; const int32_t* iter; double lr, beta1, beta2, eps; };
 }
 
-static int wgrad_impl(const float* a, int64_t ld_a, const int32_t* a_idx, const float* g, int64_t ld_g,
-                      const int32_t* g_idx, const float* relu_mask, const float* g_add, int32_t n_sel, int32_t d_a, int32_t d_b, float* dw,
+static int wgrad_impl(const gd::WgradLoss* loss, const float* a, int64_t ld_a, const int32_t* a_idx, const float* g,
+                      int64_t ld_g, const int32_t* g_idx, const float* relu_mask, const float* g_add, int32_t n_sel, int32_t d_a, int32_t d_b, float* dw,
                       int32_t accumulate, float* partials, const gd::AdamArgs* adam, void* stream) {
   using namespace gd;
   GD_REQUIRE(dw && partials, GD_E_NULL, "gd_rows_gemm_wgrad_f32: null output");
@@ -541,9 +585,16 @@ static int wgrad_impl(const float* a, int64_t ld_a, const int32_t* a_idx, const 
                          aligned16(a) && aligned16(g) && ld_a % 4 == 0 && ld_g % 4 == 0 &&
                          (!relu_mask || aligned16(relu_mask)) && (!g_add || aligned16(g_add));
     if (mfma_ok) {
+    const WgradLoss no_loss{nullptr, nullptr, nullptr, nullptr, nullptr};
 #define GD_WG_CASE(TA, TB)                                                                                        \
-  hipLaunchKernelGGL((rows_wgrad_mfma_kernel<TA, TB>), dim3(nb), dim3(256), 0, s, a, ld_a, a_idx, g, ld_g, g_idx, \
-                     relu_mask, g_add, n_sel, rpb, partials)
+  do {                                                                                                            \
+    if (loss)                                                                                                     \
+      hipLaunchKernelGGL((rows_wgrad_mfma_kernel<TA, TB, true>), dim3(nb), dim3(256), 0, s, a, ld_a, a_idx, g,     \
+                         ld_g, g_idx, relu_mask, g_add, n_sel, rpb, partials, *loss);                             \
+    else                                                                                                          \
+      hipLaunchKernelGGL((rows_wgrad_mfma_kernel<TA, TB, false>), dim3(nb), dim3(256), 0, s, a, ld_a, a_idx, g,    \
+                         ld_g, g_idx, relu_mask, g_add, n_sel, rpb, partials, no_loss);                           \
+  } while (0)
       switch (ta * 8 + tb) {
         case 1 * 8 + 1: GD_WG_CASE(1, 1); break;
         case 1 * 8 + 2: GD_WG_CASE(1, 2); break;
@@ -557,6 +608,7 @@ static int wgrad_impl(const float* a, int64_t ld_a, const int32_t* a_idx, const 
       }
 #undef GD_WG_CASE
     } else {
+      GD_REQUIRE(!loss, GD_E_DIM, "gd_rows_gemm_wgrad_loss_f32: the fused loss form needs widths in {32,64,128}");
       hipLaunchKernelGGL(rows_wgrad_scalar_kernel, dim3(nb), dim3(256), 0, s, a, ld_a, a_idx, g, ld_g, g_idx,
                          relu_mask, g_add, n_sel, d_a, d_b, rpb, partials);
     }
@@ -586,8 +638,8 @@ extern "C" int gd_rows_gemm_wgrad_f32(const float* a, int64_t ld_a, const int32_
                                       const int32_t* g_idx, const float* relu_mask, const float* g_add,
                                       int32_t n_sel, int32_t d_a, int32_t d_b, float* dw, int32_t accumulate,
                                       float* partials, void* stream) {
-  return wgrad_impl(a, ld_a, a_idx, g, ld_g, g_idx, relu_mask, g_add, n_sel, d_a, d_b, dw, accumulate, partials,
-                    nullptr, stream);
+  return wgrad_impl(nullptr, a, ld_a, a_idx, g, ld_g, g_idx, relu_mask, g_add, n_sel, d_a, d_b, dw, accumulate,
+                    partials, nullptr, stream);
 }
 
 extern "C" int gd_rows_gemm_wgrad_adam_f32(const float* a, int64_t ld_a, const int32_t* a_idx, const float* g,
@@ -598,6 +650,29 @@ extern "C" int gd_rows_gemm_wgrad_adam_f32(const float* a, int64_t ld_a, const i
                                            double lr, double beta1, double beta2, double eps, void* stream) {
   GD_REQUIRE(param && exp_avg && exp_avg_sq && iter, GD_E_NULL, "gd_rows_gemm_wgrad_adam_f32: null optimizer state");
   const gd::AdamArgs adam{param, exp_avg, exp_avg_sq, iter, lr, beta1, beta2, eps};
-  return wgrad_impl(a, ld_a, a_idx, g, ld_g, g_idx, relu_mask, g_add, n_sel, d_a, d_b, dw, accumulate, partials,
-                    &adam, stream);
+  return wgrad_impl(nullptr, a, ld_a, a_idx, g, ld_g, g_idx, relu_mask, g_add, n_sel, d_a, d_b, dw, accumulate,
+                    partials, &adam, stream);
+}
+
+extern "C" int32_t gd_rows_gemm_wgrad_blocks(int32_t n_sel) {
+  int nb, rpb;
+  gd::wgrad_geometry(n_sel, &nb, &rpb);
+  return n_sel > 0 ? nb : 0;
+}
+
+extern "C" int gd_rows_gemm_wgrad_loss_f32(const float* a, int64_t ld_a, const int32_t* a_idx, const float* z,
+                                           int64_t ld_z, const int32_t* z_idx, const int32_t* loss_slot,
+                                           const float* tm, const float* coef, const float* cnt_signed,
+                                           const float* g_add, int32_t n_sel, int32_t d_a, int32_t d_b, float* dw,
+                                           int32_t accumulate, float* partials, float* loss_partials, float* param,
+                                           float* exp_avg, float* exp_avg_sq, const int32_t* iter, double lr,
+                                           double beta1, double beta2, double eps, void* stream) {
+  GD_REQUIRE(n_sel == 0 || (loss_slot && tm && coef && cnt_signed), GD_E_NULL, "gd_rows_gemm_wgrad_loss_f32: null loss terms");
+  GD_REQUIRE(loss_partials, GD_E_NULL, "gd_rows_gemm_wgrad_loss_f32: null loss_partials");
+  GD_REQUIRE(!param || (exp_avg && exp_avg_sq && iter), GD_E_NULL, "gd_rows_gemm_wgrad_loss_f32: null optimizer state");
+  GD_REQUIRE(n_sel == 0 || gd::aligned16(tm), GD_E_ALIGN, "gd_rows_gemm_wgrad_loss_f32: unaligned targets");
+  const gd::WgradLoss loss{loss_slot, tm, coef, cnt_signed, loss_partials};
+  const gd::AdamArgs adam{param, exp_avg, exp_avg_sq, iter, lr, beta1, beta2, eps};
+  return wgrad_impl(&loss, a, ld_a, a_idx, z, ld_z, z_idx, nullptr, g_add, n_sel, d_a, d_b, dw, accumulate, partials,
+                    param ? &adam : nullptr, stream);
 }

@@ -20,6 +20,8 @@ HIP kernels - no autograd tape - laid out once over static buffers and captured 
 
 Per-step loss sums are appended to a device-side history without a host sync.
 """
+import os
+
 import torch
 
 from . import _lib, ops
@@ -222,7 +224,22 @@ class NodeembEngine:
         self.steps_done = 0
         self._graph = None
         self._use_graph = use_graph
-        self._side = torch.cuda.Stream(device=dev)
+        # layer-1 loss folded into the W_D1 weight-gradient fetch (see _wgrad1): needs the folded loss form on
+        # both layers, MFMA-able widths, a loss type whose layer-1 gradient feeds W_D1, every loss row inside S1
+        self._fuse_loss1 = False
+        t1 = self.t1
+        if (t1.folded and self.t2.folded and loss_type in ('both_layerwise', 'both_all', 'only1') and self.s1 > 0
+                and self.h in (32, 64, 128) and t1.n_rows > 0 and os.environ.get('GD_NO_FUSED_LOSS1') != '1'):
+            pos = torch.searchsorted(self.idx1, t1.row_idx)
+            inside = (pos < self.s1) & (self.idx1[pos.clamp(max=self.s1 - 1)] == t1.row_idx)
+            if bool(inside.all()):
+                slot = torch.full((self.s1,), -1, dtype=torch.int32, device=dev)
+                slot[pos] = torch.arange(t1.n_rows, dtype=torch.int32, device=dev)
+                self._slot1 = slot
+                self._cnt_signed1 = torch.where(t1.kind == 1, -t1.cnt, t1.cnt).contiguous()
+                self._lp1_blocks = _lib.lib().gd_rows_gemm_wgrad_blocks(self.s1)
+                self._lp1 = torch.zeros(2 * max(1, self._lp1_blocks), **f32)
+                self._fuse_loss1 = True
         self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat', SAGEConv: 'sage'}[type(conv2)]
         gmode = {'gcn': 'gcn', 'gin': 'sum', 'gat': 'gat', 'sage': 'mean'}[self._mode]
         self.graph = graph_for(edge_index, n, gmode)
@@ -295,7 +312,7 @@ class NodeembEngine:
             _, self._rowmax, self._rowsum = ops.gat_forward_raw(self.graph, h2, self._a_src, self._a_dst, c.bias,
                                                                 c.negative_slope, out=self.z2)
 
-    def _conv2_backward_to_s1(self, join=None):
+    def _conv2_backward_to_s1(self):
         """dh[S1] = d loss2 / d z1 (post-Del, pre-ReLU) restricted to the S1 rows (all that Del-1 needs)."""
         c = self.model.conv2
         g = self.graph
@@ -317,8 +334,6 @@ class NodeembEngine:
             w2 = c.lin_src.weight
         # dh[S1] = (dt2[S1] @ W2) * [z1[S1] > 0]   (W2 is [out, in] = [d_in, d_out] of this product; the
         # ReLU backward is applied in the GEMM epilogue so dh can outlive this iteration's z1)
-        if join is not None:
-            torch.cuda.current_stream().wait_stream(join)      # the side branch may still read last step's dh
         ops.rows_gemm(dt2, self.idx1, w2, trans_w=False, out=self.dh, gate_bits=self.z1_pos)
 
     def _spmm(self, transposed, val, x, y, bias, self_coef, x_self=None):
@@ -346,11 +361,26 @@ class NodeembEngine:
               'gd_rows_gemm_wgrad_f32')
 
     # ------------------------------------------------------------------ one iteration
+    def _wgrad1(self, accumulate, g_add):
+        """g1 (+)= xs1^T (dz1 + g_add) followed by Adam on W_D1.  With the fused form dz1 = coef (z1 - tbar)
+        is formed inside the kernel's fetch from the folded layer-1 loss terms (no loss kernel, no dz1
+        buffer traffic) and the layer-1 loss sums come out as per-block partials for the finalize kernel."""
+        if not self._fuse_loss1:
+            self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, self.g1, accumulate, self.ws1, adam=self.adam1,
+                        g_add=g_add)
+            return
+        a = self.adam1
+        a.applied += 1
+        check(_lib.lib().gd_rows_gemm_wgrad_loss_f32(
+            ptr(self.xs1), self.xs1.stride(0), None, ptr(self.z1), self.z1.stride(0), ptr(self.idx1),
+            ptr(self._slot1), ptr(self.t1.tm), ptr(self.t1.coef), ptr(self._cnt_signed1), ptr(g_add), self.s1, self.h,
+            self.h, ptr(self.g1), int(accumulate), ptr(self.ws1), ptr(self._lp1), ptr(a.param), ptr(a.m), ptr(a.v),
+            ptr(a.iter_ctr), a.lr, a.betas[0], a.betas[1], a.eps, stream_ptr(self.x.device)),
+            'gd_rows_gemm_wgrad_loss_f32')
+
     def _iteration(self):
-        """One training iteration.  The layer-1 loss (and, for the layer-wise types, the W_D1
-        gradient + Adam step) only depend on z1, so they run on a side stream concurrently with the
-        layer-2 forward (conv2, Del-2, layer-2 loss): memory-bound and MFMA-bound kernels overlap
-        and fill each other's tails.  Inside the hipGraph this is a fork/join of two branches.
+        """One training iteration, a single dependent chain of launches (every kernel here fills the chip on
+        its own: running the layer-1 loss branch on a second stream measured within 1 % of this).
 
         W_D1 receives gradient from the layer-1 loss (dz1 rows) and, through conv2, from the layer-2
         loss (dh rows, already ReLU-gated).  Both are products with the same loop-invariant operand
@@ -361,8 +391,6 @@ class NodeembEngine:
                           left in .grad by the PREVIOUS one (zero_grad only after loss-1's step,
                           :232-262), i.e. dh is consumed one iteration late (zeros at iteration 0)."""
         lt = self.loss_type
-        main = torch.cuda.current_stream()
-        side = self._side
         with torch.no_grad():
             # ---- forward, layer 1
             if self.cache_layer1:
@@ -375,54 +403,48 @@ class NodeembEngine:
                 self.sums.zero_()
             s1 = None if fused_fin else self.sums[0:2]
             s2 = None if fused_fin else self.sums[2:4]
-            # ---- fork: layer-1 loss branch
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
+            # ---- layer-1 loss (+ its W_D1 step for the layer-wise types)
+            if not self._fuse_loss1:
                 self.t1.launch(self.z1, self.dz1, s1)
-                if lt == 'both_layerwise':
-                    self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, self.g1, False, self.ws1, adam=self.adam1,
-                                g_add=self.dh)
-                elif lt == 'only1':
-                    self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, self.g1, False, self.ws1, adam=self.adam1)
-            # ---- main: forward layer 2 + its loss
+            if lt == 'both_layerwise':
+                self._wgrad1(False, self.dh)
+            elif lt == 'only1':
+                self._wgrad1(False, None)
+            # ---- forward layer 2 + its loss
             self._conv2_forward()
             ops.rows_gemm(self.z2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
             self.t2.launch(self.z2, self.dz2, s2)
-            # ---- backward + update (joins the side branch before dh / dz1 / W_D1 state are touched)
+            # ---- backward + update
             if lt == 'both_layerwise':
-                self._layer2_backward(join=side)                 # leaves dh for the next iteration
+                self._layer2_backward()                          # leaves dh for the next iteration
                 self.adam2.apply(self.g2)
             elif lt == 'both_all':
-                self._layer2_backward(g2_accumulate=True, join=side)
-                self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, self.g1, True, self.ws1, adam=self.adam1,
-                            g_add=self.dh)
+                self._layer2_backward(g2_accumulate=True)
+                self._wgrad1(True, self.dh)
                 self.adam2.apply(self.g2)
             elif lt == 'only2_layerwise':
                 self._layer2_backward(to_w1=False)
                 self.adam2.apply(self.g2)
-                main.wait_stream(side)
             elif lt == 'only2_all':
-                self._layer2_backward(join=side)
+                self._layer2_backward()
                 self._wgrad(self.xs1, self.dh, self.idx1, self.s1, self.g1, False, self.ws1, adam=self.adam1)
                 self.adam2.apply(self.g2)
-            else:  # only1
-                main.wait_stream(side)
             # ---- loss sums -> history ring, advance the iteration counter (Adam's step number)
+            p1, n1 = (self._lp1, self._lp1_blocks) if self._fuse_loss1 else (self.t1.partials, self.t1.n_partial_blocks())
             check(_lib.lib().gd_loss_finalize_f32(
-                ptr(self.t1.partials) if fused_fin else None, self.t1.n_partial_blocks() if fused_fin else 0,
+                ptr(p1) if fused_fin else None, n1 if fused_fin else 0,
                 ptr(self.t2.partials) if fused_fin else None, self.t2.n_partial_blocks() if fused_fin else 0,
                 None if fused_fin else ptr(self.sums), ptr(self.hist), self.hist.shape[0], ptr(self.hist_pos),
                 ptr(self.iter_ctr), stream_ptr(self.x.device)), 'gd_loss_finalize_f32')
 
-    def _layer2_backward(self, to_w1=True, g2_accumulate=False, join=None):
-        """g2 (+)= dW_D2; with to_w1 also dh[S1] = d loss2 / d z1[S1].  `join`: the side stream whose
-        work must be finished before dh is overwritten."""
+    def _layer2_backward(self, to_w1=True, g2_accumulate=False):
+        """g2 (+)= dW_D2; with to_w1 also dh[S1] = d loss2 / d z1[S1] (ReLU-gated)."""
         self._wgrad(self.xs2, self.dz2, self.idx2, self.s2, self.g2, g2_accumulate, self.ws2)
         if not to_w1:
             return
         # dz2 -> dp2 in place (Del-2 input gradient on the masked rows, identity elsewhere)
         ops.rows_gemm(self.dz2, self.idx2, self.wd2, trans_w=True, out=self.dz2)
-        self._conv2_backward_to_s1(join=join)
+        self._conv2_backward_to_s1()
 
     # ------------------------------------------------------------------ public
     def step(self):

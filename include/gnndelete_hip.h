@@ -216,6 +216,25 @@ int gd_rows_gemm_wgrad_adam_f32(const float* a, int64_t ld_a, const int32_t* a_i
                                 float* param, float* exp_avg, float* exp_avg_sq, const int32_t* iter,
                                 double lr, double beta1, double beta2, double eps, void* stream);
 
+/* Weight gradient whose upstream gradient is FORMED while it is fetched, from the folded DEC + NI
+ * row-target terms of that layer (see gd_rowtarget_mse_f32): for selected row s with loss slot
+ * u = loss_slot[s] >= 0,  g_s = coef[u] * (z[z_idx[s],:] - tm[u,:]),  else 0;  then  + g_add.
+ *     dW (+)= sum_s a[ia(s),:]^T g_s        loss_partials[2b], [2b+1] = per-block sums of
+ *     cnt |z - tm|^2 over the DEC / NI slots (cnt_signed < 0 marks an NI slot),
+ * b < gd_rows_gemm_wgrad_blocks(n_sel); reduce them with gd_loss_finalize_f32.  Replaces
+ * gd_rowtarget_mse_f32 + gd_rows_gemm_wgrad_adam_f32 for a layer whose loss gradient feeds nothing
+ * but its own Del weight (layer 1 with the backbone frozen): the [S, d] gradient is never written.
+ * param != NULL applies Adam as gd_rows_gemm_wgrad_adam_f32 does.  Needs d_a, d_b in {32, 64, 128}. */
+int32_t gd_rows_gemm_wgrad_blocks(int32_t n_sel);
+int gd_rows_gemm_wgrad_loss_f32(const float* a, int64_t ld_a, const int32_t* a_idx,
+                                const float* z, int64_t ld_z, const int32_t* z_idx,
+                                const int32_t* loss_slot, const float* tm, const float* coef,
+                                const float* cnt_signed, const float* g_add,
+                                int32_t n_sel, int32_t d_a, int32_t d_b, float* dw, int32_t accumulate,
+                                float* partials, float* loss_partials,
+                                float* param, float* exp_avg, float* exp_avg_sq, const int32_t* iter,
+                                double lr, double beta1, double beta2, double eps, void* stream);
+
 /* ---------------------------------------------------------------- losses --------------- */
 
 /* Fused Deleted-Edge-Consistency + Neighborhood-Influence MSE terms of one layer, value and
