@@ -26,12 +26,13 @@ constexpr int kWgradMaxRows = 1024;   // rows of the reduction dimension one wgr
 constexpr int kGemmThreads = 512;   // 8 waves share one LDS weight image; 2 blocks per CU
 
 // MODE 0: plain, 1: also emit the packed sign pattern of the output, 2: gate the output by such a pattern
-template <int NT, int MODE>
+// SEL: rows may come from a second buffer (in_alt where sel[r] != 0); only instantiated for MODE 0
+template <int NT, int MODE, bool SEL = false>
 __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
     const float* in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel,
     const float* __restrict__ w, int32_t d_in, int32_t trans_w, const float* __restrict__ bias, int32_t relu_in,
     float* out, int64_t ld_out, float* __restrict__ save_in, const uint32_t* __restrict__ gate_bits,
-    uint32_t* __restrict__ sign_out) {
+    uint32_t* __restrict__ sign_out, const float* in_alt, const uint8_t* __restrict__ sel) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   constexpr int d_out = 32 * NT;
   constexpr int kWaves = kGemmThreads / 64;
@@ -69,21 +70,23 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
     const int s_ = min(tile_ * 32 + r_lo, n_sel - 1);
     return idx ? idx[s_] : s_;
   };
+  // row r is read from in_alt instead of in where sel[r] != 0 (a matrix whose rows live in two buffers)
+  auto base_of = [&](int32_t r) -> const float* { return (SEL && sel[r]) ? in_alt : in; };
   int tile = blockIdx.x * kWaves + wave;
   if (tile >= n_tiles) return;
   int32_t row_cur = row_of(tile);
   int32_t row_nxt = row_of(min(tile + stride, n_tiles - 1));
   float4 a_next[4];
   {
-    const float4* src0 = reinterpret_cast<const float4*>(in + (int64_t)row_cur * ld_in) + khalf * 4;
+    const float4* src0 = reinterpret_cast<const float4*>(base_of(row_cur) + (int64_t)row_cur * ld_in) + khalf * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) a_next[i] = src0[i];
   }
   for (; tile < n_tiles; tile += stride) {
     const int s_a = tile * 32 + r_lo;
     const bool live = s_a < n_sel;
-    const float4* src = reinterpret_cast<const float4*>(in + (int64_t)row_cur * ld_in) + khalf * 4;
-    const float4* src_n = reinterpret_cast<const float4*>(in + (int64_t)row_nxt * ld_in) + khalf * 4;
+    const float4* src = reinterpret_cast<const float4*>(base_of(row_cur) + (int64_t)row_cur * ld_in) + khalf * 4;
+    const float4* src_n = reinterpret_cast<const float4*>(base_of(row_nxt) + (int64_t)row_nxt * ld_in) + khalf * 4;
     float4* sav = save_in ? reinterpret_cast<float4*>(save_in + (int64_t)s_a * d_in) + khalf * 4 : nullptr;
 
     f32x16 acc[NT];
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256) void rows_gemm_scalar_kernel(
     const float* in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel,
     const float* __restrict__ w, int32_t d_in, int32_t d_out, int32_t trans_w, const float* __restrict__ bias,
     int32_t relu_in, float* out, int64_t ld_out, float* __restrict__ save_in, const uint32_t* __restrict__ gate_bits,
-    uint32_t* __restrict__ sign_out) {
+    uint32_t* __restrict__ sign_out, const float* in_alt, const uint8_t* __restrict__ sel) {
   constexpr int kMaxPerLane = 16;  // d_in <= 1024
   const int lane = threadIdx.x & 63;
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void rows_gemm_scalar_kernel(
 #pragma unroll
   for (int q = 0; q < kMaxPerLane; ++q) {
     const int k = lane + q * kWave;
-    float v = k < d_in ? in[row * ld_in + k] : 0.f;
+    float v = k < d_in ? ((sel && sel[row]) ? in_alt : in)[row * ld_in + k] : 0.f;
     if (save_in && k < d_in) save_in[(int64_t)s * d_in + k] = v;
     xr[q] = relu_in ? fmaxf(v, 0.f) : v;
   }
@@ -491,8 +494,10 @@ static inline void wgrad_geometry(int32_t n_sel, int* n_blocks, int* rows_per_bl
 static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w,
                           int32_t d_in, int32_t d_out, int32_t trans_w, const float* bias, int32_t relu_in,
                           const uint32_t* gate_bits, uint32_t* sign_out, float* out, int64_t ld_out,
-                          float* save_in, void* stream) {
+                          float* save_in, void* stream, const float* in_alt = nullptr, const uint8_t* sel = nullptr) {
   using namespace gd;
+  GD_REQUIRE(!sel || (in_alt && aligned16(in_alt) && in_alt != out && !gate_bits && !sign_out), GD_E_NULL,
+             "gd_rows_gemm_select_f32: bad in_alt");
   GD_REQUIRE(in && w && out, GD_E_NULL, "gd_rows_gemm_f32: null pointer");
   GD_REQUIRE(n_sel >= 0 && d_in > 0 && d_out > 0 && ld_in >= d_in && ld_out >= d_out, GD_E_DIM,
              "gd_rows_gemm_f32: bad dims n_sel=%d d_in=%d d_out=%d", n_sel, d_in, d_out);
@@ -510,11 +515,15 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
     if (grid > 512) grid = 512;
 #define GD_RG_LAUNCH(NT, MODE)                                                                                    \
   hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT, MODE>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in, idx,   \
-                     n_sel, w, d_in, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out)
+                     n_sel, w, d_in, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out, in_alt, sel)
 #define GD_RG_CASE(NT)                                                                                            \
   do {                                                                                                            \
     if (gate_bits) GD_RG_LAUNCH(NT, 2);                                                                           \
     else if (sign_out) GD_RG_LAUNCH(NT, 1);                                                                       \
+    else if (sel)                                                                                                 \
+      hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT, 0, true>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in,  \
+                         idx, n_sel, w, d_in, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out,  \
+                         in_alt, sel);                                                                            \
     else GD_RG_LAUNCH(NT, 0);                                                                                     \
   } while (0)
     switch (d_out / 32) {
@@ -529,7 +538,7 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
   }
   GD_REQUIRE(d_in <= 1024, GD_E_DIM, "gd_rows_gemm_f32: fallback path needs d_in <= 1024 (got %d)", d_in);
   hipLaunchKernelGGL(rows_gemm_scalar_kernel, dim3((n_sel + 3) / 4), dim3(256), 0, s, in, ld_in, idx, n_sel, w, d_in,
-                     d_out, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out);
+                     d_out, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out, in_alt, sel);
   return launched("rows_gemm_scalar");
 }
 
@@ -538,6 +547,15 @@ extern "C" int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* i
                                 float* out, int64_t ld_out, float* save_in, void* stream) {
   return rows_gemm_impl(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, bias, relu_in, nullptr, nullptr, out, ld_out,
                         save_in, stream);
+}
+
+extern "C" int gd_rows_gemm_select_f32(const float* in, const float* in_alt, const uint8_t* sel, int64_t ld_in,
+                                       const int32_t* idx, int32_t n_sel, const float* w, int32_t d_in, int32_t d_out,
+                                       int32_t trans_w, const float* bias, int32_t relu_in, float* out, int64_t ld_out,
+                                       void* stream) {
+  GD_REQUIRE(sel, GD_E_NULL, "gd_rows_gemm_select_f32: null selector");
+  return rows_gemm_impl(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, bias, relu_in, nullptr, nullptr, out, ld_out,
+                        nullptr, stream, in_alt, sel);
 }
 
 extern "C" int gd_rows_gemm_signs_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel,

@@ -149,6 +149,16 @@ class _Adam:
         return {'exp_avg': self.m.clone(), 'exp_avg_sq': self.v.clone(), 'step': int(self.step)}
 
 
+def _rows_inside(terms, idx, n_sel):
+    """Are all loss rows of `terms` (folded form) members of the sorted Del row list idx?"""
+    if not terms.folded or n_sel == 0:
+        return False
+    if terms.n_rows == 0:
+        return True
+    pos = torch.searchsorted(idx, terms.row_idx)
+    return bool(((pos < n_sel) & (idx[pos.clamp(max=n_sel - 1)] == terms.row_idx)).all())
+
+
 class NodeembEngine:
     """One object per unlearning request (fixed graph, fixed Df, fixed negatives)."""
 
@@ -201,7 +211,22 @@ class NodeembEngine:
         self.z1 = torch.empty(n, self.h, **f32)
         self.z2 = torch.empty(n, self.o, **f32)
         self.xs1 = torch.empty(max(1, self.s1), self.h, **f32)       # p1[S1] (input rows of Del-1)
-        self.xs2 = torch.empty(max(1, self.s2), self.o, **f32)
+        # Del-2 out of place: conv2 writes p2, Del-2 writes z2[S2] from p2[S2] and the weight gradient gathers its
+        # operand from p2 - no [S2, O] copy of the Del input per step.  z2 rows outside S2 are then never
+        # formed, which training only tolerates when every layer-2 loss row lies in S2 (always so for the
+        # reference's masks); otherwise the in-place form with its saved input is used.
+        self._split2 = _rows_inside(self.t2, self.idx2, self.s2) and os.environ.get('GD_NO_SPLIT') != '1'
+        self.p2 = torch.empty(n, self.o, **f32) if self._split2 else self.z2
+        self.xs2 = None if self._split2 else torch.empty(max(1, self.s2), self.o, **f32)
+        # Same for layer 1 (not with the cached layer-1 output, which is a fixed buffer already): conv1 writes
+        # pre1, Del-1 writes z1[S1] from pre1[S1]; conv2's Linear reads row r from z1 if r is in S1, else from
+        # pre1 (gd_rows_gemm_select_f32).  Upstream clones the whole [N, H] matrix for this (deletion.py:24).
+        self._split1 = (not cache_layer1 and _rows_inside(self.t1, self.idx1, self.s1)
+                        and os.environ.get('GD_NO_SPLIT') != '1')
+        self.pre1 = torch.empty(n, self.h, **f32) if self._split1 else self.z1
+        self._sel1 = m1.to(torch.uint8).contiguous() if self._split1 else None
+        if self._split1:
+            self.xs1 = None
         self.dz1 = torch.zeros(n, self.h, **f32)                     # only loss rows are ever written
         if isinstance(conv2, SAGEConv):
             # [ dt2 = A_mean^T dp2 | dp2 ]: the two halves of conv2's input gradient operand side by side, so
@@ -266,51 +291,61 @@ class NodeembEngine:
             return ops.rows_gemm(x, None, weight, trans_w=True, relu_in=relu_in)
         return torch.nn.functional.linear(torch.relu(x) if relu_in else x, weight)
 
+    def _linear_relu_z1(self, weight):
+        """relu(z1) @ weight^T where z1 = Del-1 output on the S1 rows and conv1 output elsewhere."""
+        if not self._split1:
+            return self._linear(self.z1, weight, relu_in=True)
+        out_f, in_f = weight.shape
+        if in_f % 32 == 0 and out_f % 32 == 0 and out_f <= 128 and in_f * out_f * 4 <= 64 * 1024:
+            return ops.rows_gemm_select(self.pre1, self.z1, self._sel1, weight, trans_w=True, relu_in=True)
+        z = torch.where(self._sel1.bool()[:, None], self.z1, self.pre1)
+        return torch.nn.functional.linear(torch.relu(z), weight)
+
     def _conv1_forward(self):
         """Frozen layer 1, recomputed every step exactly as upstream does, written into z1."""
         c = self.model.conv1
         g = self.graph
         if self._mode == 'gcn':
-            self._spmm(False, g.val, self._linear(self.x, c.lin.weight), self.z1, c.bias, 0.0)
+            self._spmm(False, g.val, self._linear(self.x, c.lin.weight), self.pre1, c.bias, 0.0)
         elif self._mode == 'gin':
             lin = c.nn
             if lin.out_features <= lin.in_features:
-                self._spmm(False, None, self._linear(self.x, lin.weight), self.z1, lin.bias, 1.0 + c.eps)
+                self._spmm(False, None, self._linear(self.x, lin.weight), self.pre1, lin.bias, 1.0 + c.eps)
             else:
                 agg = torch.empty_like(self.x)
                 self._spmm(False, None, self.x, agg, None, 1.0 + c.eps)
-                self.z1.copy_(torch.nn.functional.linear(agg, lin.weight, lin.bias))
+                self.pre1.copy_(torch.nn.functional.linear(agg, lin.weight, lin.bias))
         elif self._mode == 'sage':
             # out_i = mean_j (x_j W_l^T) + b_l + x_i W_r^T  (transform first, then aggregate at width H)
             t_l = self._linear(self.x, c.lin_l.weight)
             t_r = self._linear(self.x, c.lin_r.weight)
-            self._spmm(False, g.val, t_l, self.z1, c.lin_l.bias, 1.0, x_self=t_r)
+            self._spmm(False, g.val, t_l, self.pre1, c.lin_l.bias, 1.0, x_self=t_r)
         else:
             h1 = self._linear(self.x, c.lin_src.weight)
             a_src, a_dst = ops.row_dots(h1, c.att_src, c.att_dst)
-            ops.gat_forward_raw(g, h1, a_src, a_dst, c.bias, c.negative_slope, out=self.z1)
+            ops.gat_forward_raw(g, h1, a_src, a_dst, c.bias, c.negative_slope, out=self.pre1)
 
     def _conv2_forward(self):
         c = self.model.conv2
         if self._mode == 'gcn':
-            t2 = self._linear(self.z1, c.lin.weight, relu_in=True)
-            self._spmm(False, self.graph.val, t2, self.z2, c.bias, 0.0)
+            t2 = self._linear_relu_z1(c.lin.weight)
+            self._spmm(False, self.graph.val, t2, self.p2, c.bias, 0.0)
         elif self._mode == 'gin':
             lin = c.nn
             if lin.out_features <= lin.in_features:
-                t2 = self._linear(self.z1, lin.weight, relu_in=True)
-                self._spmm(False, None, t2, self.z2, lin.bias, 1.0 + c.eps)
+                t2 = self._linear_relu_z1(lin.weight)
+                self._spmm(False, None, t2, self.p2, lin.bias, 1.0 + c.eps)
             else:
                 raise NotImplementedError('GIN layer that widens its input is not on the fused path')
         elif self._mode == 'sage':
-            t2 = self._linear(self.z1, self._w2cat, relu_in=True)              # [N, 2*O] = (t2_l | t2_r)
-            self._spmm(False, self.graph.val, t2[:, :self.o], self.z2, c.lin_l.bias, 1.0, x_self=t2[:, self.o:])
+            t2 = self._linear_relu_z1(self._w2cat)              # [N, 2*O] = (t2_l | t2_r)
+            self._spmm(False, self.graph.val, t2[:, :self.o], self.p2, c.lin_l.bias, 1.0, x_self=t2[:, self.o:])
         else:   # gat
-            h2 = self._linear(self.z1, c.lin_src.weight, relu_in=True)
+            h2 = self._linear_relu_z1(c.lin_src.weight)
             self._h2 = h2
             self._a_src, self._a_dst = ops.row_dots(h2, c.att_src, c.att_dst)
             _, self._rowmax, self._rowsum = ops.gat_forward_raw(self.graph, h2, self._a_src, self._a_dst, c.bias,
-                                                                c.negative_slope, out=self.z2)
+                                                                c.negative_slope, out=self.p2)
 
     def _conv2_backward_to_s1(self):
         """dh[S1] = d loss2 / d z1 (post-Del, pre-ReLU) restricted to the S1 rows (all that Del-1 needs)."""
@@ -343,19 +378,19 @@ class NodeembEngine:
         else:
             ops._spmm_raw(g.rowptr, g.col, val, x, bias, self_coef, self.n, g.plan, out=y, x_self=x_self)
 
-    def _wgrad(self, a_compact, g, g_idx, n_sel, out, accumulate, ws, adam=None, g_add=None):
+    def _wgrad(self, a_compact, g, g_idx, n_sel, out, accumulate, ws, adam=None, g_add=None, a_idx=None):
         """out (+)= a^T (g + g_add) over the selected rows; with `adam` the optimizer update of that Del
         weight is applied inside the split-K reduction (one launch less)."""
         d_a, d_b = a_compact.shape[1], g.shape[1]
         if adam is not None:
             adam.applied += 1
             check(_lib.lib().gd_rows_gemm_wgrad_adam_f32(
-                ptr(a_compact), a_compact.stride(0), None, ptr(g), g.stride(0), ptr(g_idx), None, ptr(g_add), n_sel,
+                ptr(a_compact), a_compact.stride(0), ptr(a_idx), ptr(g), g.stride(0), ptr(g_idx), None, ptr(g_add), n_sel,
                 d_a, d_b, ptr(out), int(accumulate), ptr(ws), ptr(adam.param), ptr(adam.m), ptr(adam.v),
                 ptr(adam.iter_ctr), adam.lr, adam.betas[0], adam.betas[1], adam.eps, stream_ptr(g.device)),
                 'gd_rows_gemm_wgrad_adam_f32')
             return
-        check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(a_compact), a_compact.stride(0), None, ptr(g), g.stride(0),
+        check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(a_compact), a_compact.stride(0), ptr(a_idx), ptr(g), g.stride(0),
                                                 ptr(g_idx), None, ptr(g_add), n_sel, d_a, d_b, ptr(out),
                                                 int(accumulate), ptr(ws), stream_ptr(g.device)),
               'gd_rows_gemm_wgrad_f32')
@@ -365,14 +400,15 @@ class NodeembEngine:
         """g1 (+)= xs1^T (dz1 + g_add) followed by Adam on W_D1.  With the fused form dz1 = coef (z1 - tbar)
         is formed inside the kernel's fetch from the folded layer-1 loss terms (no loss kernel, no dz1
         buffer traffic) and the layer-1 loss sums come out as per-block partials for the finalize kernel."""
+        a1, a1_idx = (self.pre1, self.idx1) if self._split1 else (self.xs1, None)
         if not self._fuse_loss1:
-            self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, self.g1, accumulate, self.ws1, adam=self.adam1,
-                        g_add=g_add)
+            self._wgrad(a1, self.dz1, self.idx1, self.s1, self.g1, accumulate, self.ws1, adam=self.adam1,
+                        g_add=g_add, a_idx=a1_idx)
             return
         a = self.adam1
         a.applied += 1
         check(_lib.lib().gd_rows_gemm_wgrad_loss_f32(
-            ptr(self.xs1), self.xs1.stride(0), None, ptr(self.z1), self.z1.stride(0), ptr(self.idx1),
+            ptr(a1), a1.stride(0), ptr(a1_idx), ptr(self.z1), self.z1.stride(0), ptr(self.idx1),
             ptr(self._slot1), ptr(self.t1.tm), ptr(self.t1.coef), ptr(self._cnt_signed1), ptr(g_add), self.s1, self.h,
             self.h, ptr(self.g1), int(accumulate), ptr(self.ws1), ptr(self._lp1), ptr(a.param), ptr(a.m), ptr(a.v),
             ptr(a.iter_ctr), a.lr, a.betas[0], a.betas[1], a.eps, stream_ptr(self.x.device)),
@@ -397,7 +433,7 @@ class NodeembEngine:
                 ops.rows_gemm(self.p1, self.idx1, self.wd1, out=self.z1, sign_bits=self.z1_pos)   # other rows stay = p1
             else:
                 self._conv1_forward()
-                ops.rows_gemm(self.z1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1, sign_bits=self.z1_pos)
+                ops.rows_gemm(self.pre1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1, sign_bits=self.z1_pos)
             fused_fin = self.t1.folded and self.t2.folded       # partials reduced by the finalize kernel
             if not fused_fin:
                 self.sums.zero_()
@@ -412,7 +448,7 @@ class NodeembEngine:
                 self._wgrad1(False, None)
             # ---- forward layer 2 + its loss
             self._conv2_forward()
-            ops.rows_gemm(self.z2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
+            ops.rows_gemm(self.p2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
             self.t2.launch(self.z2, self.dz2, s2)
             # ---- backward + update
             if lt == 'both_layerwise':
@@ -427,7 +463,8 @@ class NodeembEngine:
                 self.adam2.apply(self.g2)
             elif lt == 'only2_all':
                 self._layer2_backward()
-                self._wgrad(self.xs1, self.dh, self.idx1, self.s1, self.g1, False, self.ws1, adam=self.adam1)
+                a1, a1_idx = (self.pre1, self.idx1) if self._split1 else (self.xs1, None)
+                self._wgrad(a1, self.dh, self.idx1, self.s1, self.g1, False, self.ws1, adam=self.adam1, a_idx=a1_idx)
                 self.adam2.apply(self.g2)
             # ---- loss sums -> history ring, advance the iteration counter (Adam's step number)
             p1, n1 = (self._lp1, self._lp1_blocks) if self._fuse_loss1 else (self.t1.partials, self.t1.n_partial_blocks())
@@ -439,7 +476,10 @@ class NodeembEngine:
 
     def _layer2_backward(self, to_w1=True, g2_accumulate=False):
         """g2 (+)= dW_D2; with to_w1 also dh[S1] = d loss2 / d z1[S1] (ReLU-gated)."""
-        self._wgrad(self.xs2, self.dz2, self.idx2, self.s2, self.g2, g2_accumulate, self.ws2)
+        if self._split2:
+            self._wgrad(self.p2, self.dz2, self.idx2, self.s2, self.g2, g2_accumulate, self.ws2, a_idx=self.idx2)
+        else:
+            self._wgrad(self.xs2, self.dz2, self.idx2, self.s2, self.g2, g2_accumulate, self.ws2)
         if not to_w1:
             return
         # dz2 -> dp2 in place (Del-2 input gradient on the masked rows, identity elsewhere)

@@ -101,6 +101,21 @@ def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, sa
     return out
 
 
+def rows_gemm_select(inp, inp_alt, sel, w, trans_w=False, bias=None, relu_in=False, out=None):
+    """Dense rows_gemm over a matrix split across two buffers: row r comes from inp_alt where sel[r] (uint8)."""
+    inp, inp_alt = _f32_rows(inp), _f32_rows(inp_alt)
+    assert inp.shape == inp_alt.shape and inp.stride(0) == inp_alt.stride(0) and sel.dtype == torch.uint8
+    n, d_in = inp.shape
+    d_out = w.shape[0] if trans_w else w.shape[1]
+    if out is None:
+        out = torch.empty(n, d_out, dtype=torch.float32, device=inp.device)
+    w = w.contiguous()
+    check(_lib.lib().gd_rows_gemm_select_f32(ptr(inp), ptr(inp_alt), ptr(sel), inp.stride(0), None, n, ptr(w), d_in,
+                                             d_out, int(trans_w), ptr(bias), int(relu_in), ptr(out), out.stride(0),
+                                             stream_ptr(inp.device)), 'gd_rows_gemm_select_f32')
+    return out
+
+
 def rows_gemm_wgrad(a, a_idx, g, g_idx, n_sel, relu_mask=None, out=None, accumulate=False, g_add=None):
     """dW[d_a, d_b] (+)= sum_s a[a_idx[s]]^T (mask(g) + g_add)[g_idx[s]] - raw call."""
     a, g = _f32_rows(a), _f32_rows(g)

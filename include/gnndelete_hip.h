@@ -173,6 +173,14 @@ int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t
                      const float* bias, int32_t relu_in,
                      float* out, int64_t ld_out, float* save_in, void* stream);
 
+/* gd_rows_gemm_f32 over a matrix whose rows live in two buffers of the same shape: row r is read from
+ * in_alt where sel[r] != 0 and from in otherwise (e.g. z1 = Del-1 output on the S_Df rows, conv1 output
+ * elsewhere: deletion.py:17-29 clones the whole matrix to get this; here neither copy is made). */
+int gd_rows_gemm_select_f32(const float* in, const float* in_alt, const uint8_t* sel, int64_t ld_in,
+                            const int32_t* idx, int32_t n_sel, const float* w, int32_t d_in, int32_t d_out,
+                            int32_t trans_w, const float* bias, int32_t relu_in,
+                            float* out, int64_t ld_out, void* stream);
+
 /* gd_rows_gemm_f32 that also emits the sign pattern of what it wrote, packed one bit per output
  * feature: sign_bits is compact [n_sel, ceil(d_out/32)] words, bit b of word k of entry s is set
  * iff out[idx[s], 32k + b] > 0.  With W = deletion_weight this is the ReLU gate of F.relu(x1)
