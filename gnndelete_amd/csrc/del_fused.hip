@@ -1,0 +1,214 @@
+// Last-layer Del operator, its loss and its input gradient in one pass over the S_Df rows:
+//
+//     z  = p[idx,:] @ W_D                         DeletionLayer.forward (deletion.py:17-29)
+//     dz = coef_u (z - tbar_u)                    folded DEC + NI MSE terms of the layer (loss.hip), 0 without a slot
+//     dp[idx,:] = dz @ W_D^T                      what autograd sends back through the Del operator
+//
+// z itself has no other consumer during training (it is the model output), so it is never written: per
+// row the kernel reads p and tbar and writes dz (for the weight gradient) and dp (for conv2's backward) -
+// 4 row-streams instead of the 10 of the separate Del / loss / Del-backward kernels.
+//
+// Same mapping as rows_gemm.hip (transposed product, weight image in LDS, sample rows straight from global
+// memory); the image rows are padded by one float (pitch D + 1) so that reads along either axis are
+// conflict-free AND every LDS address is one per-lane base plus a compile-time offset.  The second product needs no layout change: after the first one a lane
+// holds, for its own sample j, the features i = 32t + (r&3) + 8(r>>2) + 4kh in acc[t][r]; using exactly that
+// feature as MFMA k slot (r, kh) of the second product - both operands agree on the permutation - the
+// accumulator registers ARE its "B" operand, and its "A" operand W_D[c][i] comes out of the same LDS image
+// read along the other axis.
+#include "common.h"
+
+namespace gd {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct DelLoss {
+  const int32_t* slot;      // [n_sel] loss slot of selected row s, or -1
+  const float* tm;          // [n_slots, d]
+  const float* coef;        // [n_slots]
+  const float* cnt_signed;  // [n_slots] (NI slots negative)
+  float* partials;          // [2 * gridDim.x]
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __restrict__ p, int64_t ld_p,
+                                                              const int32_t* __restrict__ idx, int32_t n_sel,
+                                                              const float* __restrict__ w, DelLoss loss,
+                                                              float* __restrict__ dz, int64_t ld_dz,
+                                                              float* __restrict__ dp, int64_t ld_dp) {
+  constexpr int D = 32 * NT;
+  constexpr int P = D + 1;                                       // image pitch
+  extern __shared__ __attribute__((aligned(16))) float wl[];     // wl[k * P + n] = W_D[k][n]
+  __shared__ float lred[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 31, kh = lane >> 5;
+  for (int e = tid; e < D * D; e += 256) {
+    const int k = e / D, n = e % D;
+    wl[k * P + n] = w[e];
+  }
+  __syncthreads();
+
+  const float* w_fwd = wl + kh * (D / 2) * P + lo;               // per-lane bases of the two read patterns
+  const float* w_bwd = wl + lo * P + 4 * kh;
+  float ls0 = 0.f, ls1 = 0.f;
+  const int n_tiles = (n_sel + 31) >> 5;
+  // Operands of one tile: sample row index, loss slot, this lane's half of the p row, its target runs.
+  // The next tile's operands are requested before the current tile's 2 x NT x D/2 MFMAs are issued
+  // (plain arrays, copied element-wise: keeps everything in registers).
+  int32_t n_row;
+  int n_u;
+  bool n_live;
+  float n_cf, n_cn;
+  float4 n_pa[D / 8], n_tv[NT * 4];
+  auto fetch = [&](int tile_) {
+    const int s_ = tile_ * 32 + lo;
+    n_live = s_ < n_sel;
+    const int sc = min(s_, n_sel - 1);
+    n_row = idx[sc];
+    n_u = n_live ? loss.slot[sc] : -1;
+    const float4* src = reinterpret_cast<const float4*>(p + (int64_t)n_row * ld_p + kh * (D / 2));
+#pragma unroll
+    for (int c4 = 0; c4 < D / 8; ++c4) n_pa[c4] = src[c4];
+    const int uc = max(n_u, 0);
+    n_cf = loss.coef[uc];
+    n_cn = loss.cnt_signed[uc];
+    const float* trow = loss.tm + (int64_t)uc * D + 4 * kh;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) n_tv[t * 4 + q] = *reinterpret_cast<const float4*>(trow + 32 * t + 8 * q);
+  };
+  const int stride = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  if (tile < n_tiles) fetch(tile);
+  for (; tile < n_tiles; tile += stride) {
+    // the weight fragments a lane reads from LDS are the same for every tile; left alone the compiler hoists
+    // all 2 NT D/2 of them out of this loop and spills - keep them as loads inside the loop
+    asm volatile("" ::: "memory");
+    const int s = tile * 32 + lo;
+    const bool live = n_live;
+    const int32_t row = n_row;
+    const int u = n_u;
+    const float c_cf = n_cf, c_cn = n_cn;
+    float4 c_pa[D / 8], c_tv[NT * 4];
+#pragma unroll
+    for (int c4 = 0; c4 < D / 8; ++c4) c_pa[c4] = n_pa[c4];
+#pragma unroll
+    for (int q = 0; q < NT * 4; ++q) c_tv[q] = n_tv[q];
+    if (tile + stride < n_tiles) fetch(tile + stride);
+    // ---- z^T tile = W_D^T x^T : lane (sample lo, half kh) feeds features [kh*D/2, kh*D/2 + D/2) of its row
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < D / 8; ++c4) {
+      const float4 a4 = c_pa[c4];
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* wk = w_fwd + (4 * c4 + e) * P;              // W_D[kh*D/2 + 4c4 + e][lo + 32t]
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[32 * t], av[e], acc[t], 0, 0, 0);
+      }
+    }
+    // ---- loss gradient in place: acc[t][r] (feature 32t + (r&3) + 8(r>>2) + 4kh of sample lo) -> dz
+    if (u >= 0) {
+      const float cf = c_cf, cn = c_cn;
+      float* drow = dz + (int64_t)s * ld_dz + 4 * kh;
+      float sq = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 tv = c_tv[t * 4 + q];
+          const float4 df = make_float4(acc[t][4 * q] - tv.x, acc[t][4 * q + 1] - tv.y, acc[t][4 * q + 2] - tv.z,
+                                        acc[t][4 * q + 3] - tv.w);
+          sq = fmaf(df.x, df.x, sq); sq = fmaf(df.y, df.y, sq); sq = fmaf(df.z, df.z, sq); sq = fmaf(df.w, df.w, sq);
+          const float4 g4 = make_float4(cf * df.x, cf * df.y, cf * df.z, cf * df.w);
+          acc[t][4 * q] = g4.x; acc[t][4 * q + 1] = g4.y; acc[t][4 * q + 2] = g4.z; acc[t][4 * q + 3] = g4.w;
+          *reinterpret_cast<float4*>(drow + 32 * t + 8 * q) = g4;
+        }
+      if (cn >= 0.f) ls0 = fmaf(cn, sq, ls0); else ls1 = fmaf(-cn, sq, ls1);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      if (live) {
+        float* drow = dz + (int64_t)s * ld_dz + 4 * kh;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(drow + 32 * t + 8 * q) = f4_zero();
+      }
+    }
+    // ---- dp^T tile = W_D dz^T : k slot (kk, kh) of feature tile t <-> feature i = 32t + (kk&3) + 8(kk>>2) + 4kh
+    f32x16 dacc[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dacc[c][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int i0 = 32 * t + (kk & 3) + 8 * (kk >> 2);                        // + 4 kh folded into w_bwd
+#pragma unroll
+        for (int c = 0; c < NT; ++c)                                              // W_D[32c + lo][i0 + 4kh]
+          dacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w_bwd[32 * c * P + i0], acc[t][kk], dacc[c], 0, 0, 0);
+      }
+    if (live) {
+      float* orow = dp + (int64_t)row * ld_dp + 4 * kh;
+#pragma unroll
+      for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(orow + 32 * c + 8 * q) =
+              make_float4(dacc[c][4 * q], dacc[c][4 * q + 1], dacc[c][4 * q + 2], dacc[c][4 * q + 3]);
+    }
+  }
+  ls0 = wave_sum(ls0);
+  ls1 = wave_sum(ls1);
+  if (lane == 0) { lred[0][wave] = ls0; lred[1][wave] = ls1; }
+  __syncthreads();
+  if (tid == 0) {
+    loss.partials[2 * blockIdx.x + 0] = (lred[0][0] + lred[0][1]) + (lred[0][2] + lred[0][3]);
+    loss.partials[2 * blockIdx.x + 1] = (lred[1][0] + lred[1][1]) + (lred[1][2] + lred[1][3]);
+  }
+}
+
+static inline int del_fused_grid(int32_t n_sel) {
+  const int n_tiles = (n_sel + 31) / 32;
+  int grid = (n_tiles + 3) / 4;
+  if (grid > 1024) grid = 1024;
+  return grid < 1 ? 1 : grid;
+}
+
+}  // namespace gd
+
+extern "C" int32_t gd_del_loss_bwd_blocks(int32_t n_sel) { return n_sel > 0 ? gd::del_fused_grid(n_sel) : 0; }
+
+extern "C" int gd_del_loss_bwd_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w,
+                                   int32_t d, const int32_t* loss_slot, const float* tm, const float* coef,
+                                   const float* cnt_signed, float* dz, int64_t ld_dz, float* dp, int64_t ld_dp,
+                                   float* loss_partials, void* stream) {
+  using namespace gd;
+  if (n_sel == 0) return GD_OK;
+  GD_REQUIRE(p && idx && w && loss_slot && tm && coef && cnt_signed && dz && dp && loss_partials, GD_E_NULL,
+             "gd_del_loss_bwd_f32: null pointer");
+  GD_REQUIRE(d == 32 || d == 64, GD_E_DIM, "gd_del_loss_bwd_f32: d=%d must be 32 or 64", d);
+  GD_REQUIRE(ld_p >= d && ld_dz >= d && ld_dp >= d && ld_p % 4 == 0 && ld_dz % 4 == 0 && ld_dp % 4 == 0, GD_E_DIM,
+             "gd_del_loss_bwd_f32: bad row strides");
+  GD_REQUIRE(aligned16(p) && aligned16(tm) && aligned16(dz) && aligned16(dp), GD_E_ALIGN, "gd_del_loss_bwd_f32: unaligned");
+  GD_REQUIRE(p != dp && p != dz && dz != dp, GD_E_DIM, "gd_del_loss_bwd_f32: buffers must not alias");
+  hipStream_t s = (hipStream_t)stream;
+  const DelLoss loss{loss_slot, tm, coef, cnt_signed, loss_partials};
+  const dim3 grid(del_fused_grid(n_sel));
+  const size_t lds = (size_t)d * (d + 1) * sizeof(float);
+  switch (d / 32) {
+    case 1: hipLaunchKernelGGL((del_loss_bwd_kernel<1>), grid, dim3(256), lds, s, p, ld_p, idx, n_sel, w, loss, dz, ld_dz, dp, ld_dp); break;
+    default: hipLaunchKernelGGL((del_loss_bwd_kernel<2>), grid, dim3(256), lds, s, p, ld_p, idx, n_sel, w, loss, dz, ld_dz, dp, ld_dp); break;
+  }
+  return launched("del_loss_bwd");
+}

@@ -159,6 +159,15 @@ def _rows_inside(terms, idx, n_sel):
     return bool(((pos < n_sel) & (idx[pos.clamp(max=n_sel - 1)] == terms.row_idx)).all())
 
 
+def _loss_slots(terms, idx, n_sel, device):
+    """(slot[n_sel] int32: position of each Del row in the folded loss rows or -1, cnt with NI negative)."""
+    slot = torch.full((n_sel,), -1, dtype=torch.int32, device=device)
+    if terms.n_rows:
+        pos = torch.searchsorted(idx, terms.row_idx)
+        slot[pos] = torch.arange(terms.n_rows, dtype=torch.int32, device=device)
+    return slot, torch.where(terms.kind == 1, -terms.cnt, terms.cnt).contiguous()
+
+
 class NodeembEngine:
     """One object per unlearning request (fixed graph, fixed Df, fixed negatives)."""
 
@@ -218,6 +227,14 @@ class NodeembEngine:
         self._split2 = _rows_inside(self.t2, self.idx2, self.s2) and os.environ.get('GD_NO_SPLIT') != '1'
         self.p2 = torch.empty(n, self.o, **f32) if self._split2 else self.z2
         self.xs2 = None if self._split2 else torch.empty(max(1, self.s2), self.o, **f32)
+        # ... and with that, Del-2 forward + layer-2 loss + Del-2 input gradient are ONE kernel (csrc/del_fused.hip)
+        self._fuse_l2 = (self._split2 and self.t1.folded and self.o in (32, 64) and self.t2.n_rows > 0
+                         and os.environ.get('GD_NO_FUSED_L2') != '1')
+        if self._fuse_l2:
+            self._slot2, self._cnt_signed2 = _loss_slots(self.t2, self.idx2, self.s2, dev)
+            self._lp2_blocks = _lib.lib().gd_del_loss_bwd_blocks(self.s2)
+            self._lp2 = torch.zeros(2 * max(1, self._lp2_blocks), **f32)
+            self.dz2c = torch.zeros(self.s2, self.o, **f32)          # dz2 on the S2 rows (compact)
         # Same for layer 1 (not with the cached layer-1 output, which is a fixed buffer already): conv1 writes
         # pre1, Del-1 writes z1[S1] from pre1[S1]; conv2's Linear reads row r from z1 if r is in S1, else from
         # pre1 (gd_rows_gemm_select_f32).  Upstream clones the whole [N, H] matrix for this (deletion.py:24).
@@ -448,8 +465,14 @@ class NodeembEngine:
                 self._wgrad1(False, None)
             # ---- forward layer 2 + its loss
             self._conv2_forward()
-            ops.rows_gemm(self.p2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
-            self.t2.launch(self.z2, self.dz2, s2)
+            if self._fuse_l2:
+                check(_lib.lib().gd_del_loss_bwd_f32(
+                    ptr(self.p2), self.p2.stride(0), ptr(self.idx2), self.s2, ptr(self.wd2), self.o, ptr(self._slot2),
+                    ptr(self.t2.tm), ptr(self.t2.coef), ptr(self._cnt_signed2), ptr(self.dz2c), self.dz2c.stride(0),
+                    ptr(self.dz2), self.dz2.stride(0), ptr(self._lp2), stream_ptr(self.x.device)), 'gd_del_loss_bwd_f32')
+            else:
+                ops.rows_gemm(self.p2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
+                self.t2.launch(self.z2, self.dz2, s2)
             # ---- backward + update
             if lt == 'both_layerwise':
                 self._layer2_backward()                          # leaves dh for the next iteration
@@ -468,22 +491,26 @@ class NodeembEngine:
                 self.adam2.apply(self.g2)
             # ---- loss sums -> history ring, advance the iteration counter (Adam's step number)
             p1, n1 = (self._lp1, self._lp1_blocks) if self._fuse_loss1 else (self.t1.partials, self.t1.n_partial_blocks())
+            p2, n2 = (self._lp2, self._lp2_blocks) if self._fuse_l2 else (self.t2.partials, self.t2.n_partial_blocks())
             check(_lib.lib().gd_loss_finalize_f32(
                 ptr(p1) if fused_fin else None, n1 if fused_fin else 0,
-                ptr(self.t2.partials) if fused_fin else None, self.t2.n_partial_blocks() if fused_fin else 0,
+                ptr(p2) if fused_fin else None, n2 if fused_fin else 0,
                 None if fused_fin else ptr(self.sums), ptr(self.hist), self.hist.shape[0], ptr(self.hist_pos),
                 ptr(self.iter_ctr), stream_ptr(self.x.device)), 'gd_loss_finalize_f32')
 
     def _layer2_backward(self, to_w1=True, g2_accumulate=False):
         """g2 (+)= dW_D2; with to_w1 also dh[S1] = d loss2 / d z1[S1] (ReLU-gated)."""
-        if self._split2:
+        if self._fuse_l2:          # dz2 (compact) and dp2 (in self.dz2) were produced by the fused Del-2 kernel
+            self._wgrad(self.p2, self.dz2c, None, self.s2, self.g2, g2_accumulate, self.ws2, a_idx=self.idx2)
+        elif self._split2:
             self._wgrad(self.p2, self.dz2, self.idx2, self.s2, self.g2, g2_accumulate, self.ws2, a_idx=self.idx2)
         else:
             self._wgrad(self.xs2, self.dz2, self.idx2, self.s2, self.g2, g2_accumulate, self.ws2)
         if not to_w1:
             return
-        # dz2 -> dp2 in place (Del-2 input gradient on the masked rows, identity elsewhere)
-        ops.rows_gemm(self.dz2, self.idx2, self.wd2, trans_w=True, out=self.dz2)
+        if not self._fuse_l2:
+            # dz2 -> dp2 in place (Del-2 input gradient on the masked rows, identity elsewhere)
+            ops.rows_gemm(self.dz2, self.idx2, self.wd2, trans_w=True, out=self.dz2)
         self._conv2_backward_to_s1()
 
     # ------------------------------------------------------------------ public

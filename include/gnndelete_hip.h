@@ -243,6 +243,17 @@ int gd_rows_gemm_wgrad_loss_f32(const float* a, int64_t ld_a, const int32_t* a_i
                                 float* param, float* exp_avg, float* exp_avg_sq, const int32_t* iter,
                                 double lr, double beta1, double beta2, double eps, void* stream);
 
+/* Last-layer Del operator + its folded DEC/NI loss + its input gradient in one pass over the S_Df rows
+ * (deletion.py:17-29 forward, gnndelete_nodeemb.py:196-210 loss, autograd's matmul backward):
+ *     z = p[idx[s],:] @ W_D ;  dz[s,:] = coef[u] (z - tm[u,:]) (u = loss_slot[s] >= 0, else 0) ;
+ *     dp[idx[s],:] = dz[s,:] @ W_D^T ;  loss_partials = per-block (DEC, NI) sums of cnt |z - tm|^2
+ * for b < gd_del_loss_bwd_blocks(n_sel).  z is not written (no other consumer during training); dz is
+ * compact [n_sel, d] for gd_rows_gemm_wgrad_f32.  d in {32, 64}; p, dz, dp must not alias. */
+int32_t gd_del_loss_bwd_blocks(int32_t n_sel);
+int gd_del_loss_bwd_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w, int32_t d,
+                        const int32_t* loss_slot, const float* tm, const float* coef, const float* cnt_signed,
+                        float* dz, int64_t ld_dz, float* dp, int64_t ld_dp, float* loss_partials, void* stream);
+
 /* ---------------------------------------------------------------- losses --------------- */
 
 /* Fused Deleted-Edge-Consistency + Neighborhood-Influence MSE terms of one layer, value and

@@ -505,3 +505,47 @@ def test_rgcn_conv_fused_matches_oracle(n, m, R, din, dout, nb):
     got.backward(up.float().cuda())
     assert rel_l2(got.detach().cpu(), want.detach()) < TOL
     assert rel_l2(xg.grad.cpu(), xr.grad) < TOL
+
+
+@pytest.mark.parametrize('n,d,frac,loss_frac', [(500, 64, 0.6, 0.8), (300, 32, 1.0, 1.0), (4000, 64, 0.9, 0.5), (70, 64, 0.3, 0.0)])
+def test_del_loss_bwd_fused_matches_separate_steps(n, d, frac, loss_frac):
+    """Fused last-layer kernel (Del forward + folded MSE terms + Del input gradient) vs the same three steps in
+    float64: dz on the Del rows, dp scattered to the full matrix, the two loss sums; rows with no loss slot."""
+    from gnndelete_amd import _lib
+    from gnndelete_amd._lib import ptr, check
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(n + d)
+    p = torch.randn(n, d, generator=g)
+    w = torch.randn(d, d, generator=g) * 0.2
+    mask = torch.rand(n, generator=g) < frac
+    idx = mask.nonzero().flatten()
+    s = idx.numel()
+    has = torch.rand(s, generator=g) < loss_frac
+    slot = torch.full((s,), -1, dtype=torch.int32)
+    n_slots = int(has.sum())
+    slot[has] = torch.arange(n_slots, dtype=torch.int32)[torch.randperm(n_slots, generator=g)]
+    tm = torch.randn(max(n_slots, 1), d, generator=g)
+    coef = torch.rand(max(n_slots, 1), generator=g) + 0.1
+    cnt = (torch.randint(1, 4, (max(n_slots, 1),), generator=g).float()) * torch.where(torch.rand(max(n_slots, 1), generator=g) < 0.5, -1.0, 1.0)
+    z = p.double()[idx] @ w.double()
+    dz_want = torch.zeros(s, d, dtype=torch.float64)
+    sl = slot[has].long()
+    df = z[has] - tm.double()[sl]
+    dz_want[has] = coef.double()[sl][:, None] * df
+    dp_want = torch.zeros(n, d, dtype=torch.float64)
+    dp_want[idx] = dz_want @ w.double().t()
+    sq = (df * df).sum(1) * cnt.double()[sl].abs()
+    want_s = [float(sq[cnt[sl] >= 0].sum()), float(sq[cnt[sl] < 0].sum())]
+
+    nb = L.gd_del_loss_bwd_blocks(s)
+    dz = torch.full((max(s, 1), d), 7.0, device='cuda')
+    dp = torch.zeros(n, d, device='cuda')
+    parts = torch.zeros(2 * max(nb, 1), device='cuda')
+    dev = lambda t_: t_.cuda()
+    args = [dev(p), dev(idx.int()), dev(w), dev(slot), dev(tm), dev(coef), dev(cnt)]
+    check(L.gd_del_loss_bwd_f32(ptr(args[0]), d, ptr(args[1]), s, ptr(args[2]), d, ptr(args[3]), ptr(args[4]), ptr(args[5]),
+                                ptr(args[6]), ptr(dz), d, ptr(dp), d, ptr(parts), torch.cuda.current_stream().cuda_stream))
+    assert rel_l2(dz.cpu()[:s], dz_want) < TOL or float(dz_want.abs().max()) == 0
+    assert rel_l2(dp.cpu(), dp_want) < TOL or float(dp_want.abs().max()) == 0
+    got_s = parts.view(-1, 2).double().sum(0).cpu()
+    np.testing.assert_allclose(got_s.numpy(), want_s, rtol=1e-5, atol=1e-7)
