@@ -209,6 +209,7 @@ def test_sage_engine_matches_oracle_training(loss_type, use_graph):
         z1o, z2o = m.get_original_embeddings(dev['x'], E[:, dev['dr_mask']], return_all_emb=True)
     eng = NodeembEngine(m, dev['x'], E[:, dev['sdf_mask']].contiguous(), z1o, z2o, E[:, dev['df_mask']],
                         t(rest['neg']).cuda(), ni1, ni2, loss_type=loss_type, alpha=0.4, lr=0.01, use_graph=use_graph)
+    assert eng._fuse_l2 and eng._split1          # H = 128, O = 64: every fused stage is on
     for _ in range(6):
         eng.step()
     hist = eng.loss_history().numpy()
@@ -216,3 +217,26 @@ def test_sage_engine_matches_oracle_training(loss_type, use_graph):
         np.testing.assert_allclose(hist[:, col], [l[key] for l in logs], rtol=1e-4, atol=1e-8, err_msg=key)
     assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), mo.deletion1.deletion_weight.detach()) < 1e-4
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
+
+
+@pytest.mark.parametrize('knob', ['GD_NO_SPLIT', 'GD_NO_FUSED_LOSS1', 'GD_NO_FUSED_L2'])
+@pytest.mark.parametrize('gnn,loss_type', [('gat', 'both_layerwise'), ('gcn', 'both_all')])
+def test_unfused_fallback_stages_reproduce_reference_trajectory(monkeypatch, knob, gnn, loss_type):
+    """The engine falls back stage by stage to the unfused kernels (in-place Del with its saved input, the
+    stand-alone loss kernels, separate Del-2 backward) when a fused form does not apply; each fallback is forced
+    here and must give the reference trajectory as well."""
+    monkeypatch.setenv(knob, '1')
+    eng, m, rest = make_engine(gnn, loss_type, True)
+    assert not getattr(eng, {'GD_NO_SPLIT': '_split2', 'GD_NO_FUSED_LOSS1': '_fuse_loss1', 'GD_NO_FUSED_L2': '_fuse_l2'}[knob])
+    for _ in range(int(rest['epochs'])):
+        eng.step()
+    hist = eng.loss_history().numpy()
+    for col, key in enumerate(['train_loss', 'loss_r', 'loss_l']):
+        np.testing.assert_allclose(hist[:, col], rest[key], rtol=1e-4, atol=1e-8, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), rest['final_w1']) < 1e-4
+    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < 1e-4
+
+
+def test_fused_stages_are_active_on_the_reference_masks():
+    eng, _, _ = make_engine('gcn', 'both_all', True)
+    assert eng._split1 and eng._split2 and eng._fuse_loss1
