@@ -41,9 +41,12 @@ def parse():
     p.add_argument('--no_graph', action='store_true')
     p.add_argument('--no_cached_rate', action='store_true')
     p.add_argument('--probe_partition', action='store_true', help=argparse.SUPPRESS)   # child-process self test
-    p.add_argument('--parallel', default='partition', choices=['partition', 'replicas'],
-                   help='N>1: row-partition ONE request over the GPUs (RCCL all-gather + all-reduce, strong '
-                        'scaling) or run N independent requests (no exchange, weak scaling)')
+    p.add_argument('--parallel', default='auto', choices=['auto', 'partition', 'replicas'],
+                   help='N>1: "replicas" = every GPU serves its own unlearning request (independent units, no '
+                        'data-path collective, weak scaling); "partition" = ONE request row-partitioned over the GPUs '
+                        '(RCCL halo all-to-all + all-reduce per step, strong scaling) for graphs that outgrow one GPU; '
+                        '"auto" = replicas when the request fits one GPU (it does for every BASELINE config: the '
+                        'collab-shaped request needs < 2 GB of 288 GB), else partition')
     return p.parse_args()
 
 
@@ -229,6 +232,8 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     # GD_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a one-GPU box (all ranks on cuda:0)
     backend = os.environ.get('GD_BENCH_BACKEND', 'nccl')
+    if args.parallel == 'auto':
+        args.parallel = 'replicas'          # every BASELINE workload fits one MI355X many times over
     mode, note, probe_ok = ('single' if world == 1 else args.parallel), None, 1
     force_probe = os.environ.get('GD_BENCH_FORCE_PROBE') == '1'          # lets the gloo test exercise the probe
     if world > 1 and mode == 'partition' and (backend == 'nccl' or force_probe) and not args.probe_partition:
