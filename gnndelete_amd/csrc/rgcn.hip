@@ -57,28 +57,38 @@ __global__ __launch_bounds__(256) void rgcn_conv_kernel(
       m[lane] = a0;
       m[lane + 64] = a1;
       // (same wave wrote and reads: LDS operations of one wave complete in order)
-      // ---- transform: output feature o lives in block o / nb and reads that block of the aggregate
+      // ---- transform: this lane owns the ADJACENT output features 2*lane, 2*lane + 1 (same block, nb is
+      // even), so one aggregate read and one 8-byte weight read feed two multiply-adds
       const float* wr = weight + (int64_t)r * n_blocks * ib * ob;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int o = lane + 64 * h;
-        if (o < d_out) {
-          const int b = o / nb, ol = o - b * nb;
-          const float* mb = m + b * kb;
-          const float* wb = wr + (int64_t)b * ib * ob;
-          float acc = 0.f;
-          if (!trans) {
-            for (int k = 0; k < kb; ++k) acc = fmaf(mb[k], wb[k * ob + ol], acc);     // W[b][k][ol]
-          } else {
-            for (int k = 0; k < kb; ++k) acc = fmaf(mb[k], wb[ol * ob + k], acc);     // W[b][ol][k]
+      const int o = 2 * lane;
+      if (o < d_out) {
+        const int b = o / nb, ol = o - b * nb;
+        const float* mb = m + b * kb;
+        const float* wb = wr + (int64_t)b * ib * ob;
+        float acc0 = 0.f, acc1 = 0.f;
+        if (!trans) {
+          for (int k = 0; k < kb; ++k) {                         // W[b][k][ol], W[b][k][ol + 1]
+            const float2 wv = *reinterpret_cast<const float2*>(wb + k * ob + ol);
+            acc0 = fmaf(mb[k], wv.x, acc0);
+            acc1 = fmaf(mb[k], wv.y, acc1);
           }
-          if (h == 0) o0 += acc; else o1 += acc;
+        } else {
+          for (int k = 0; k < kb; ++k) {                         // W[b][ol][k], W[b][ol + 1][k]
+            acc0 = fmaf(mb[k], wb[ol * ob + k], acc0);
+            acc1 = fmaf(mb[k], wb[(ol + 1) * ob + k], acc1);
+          }
         }
+        o0 += acc0;
+        o1 += acc1;
       }
     }
     float* yr = y + (int64_t)i * ldy;
-    if (lane < d_out) yr[lane] += o0;
-    if (lane + 64 < d_out) yr[lane + 64] += o1;
+    if (2 * lane < d_out) {
+      float2 cur = *reinterpret_cast<float2*>(yr + 2 * lane);
+      cur.x += o0;
+      cur.y += o1;
+      *reinterpret_cast<float2*>(yr + 2 * lane) = cur;
+    }
   }
 }
 
@@ -97,6 +107,9 @@ extern "C" int gd_rgcn_conv_f32(const int32_t* node_ptr, const int32_t* seg_ptr,
   const int din_f = trans ? d_out : d_in, dout_f = trans ? d_in : d_out;
   GD_REQUIRE(din_f % n_blocks == 0 && dout_f % n_blocks == 0, GD_E_DIM,
              "gd_rgcn_conv_f32: feature widths must be multiples of n_blocks");
+  GD_REQUIRE((din_f / n_blocks) % 2 == 0 && (dout_f / n_blocks) % 2 == 0 && ldy % 2 == 0 &&
+                 (reinterpret_cast<uintptr_t>(y) & 7u) == 0 && (reinterpret_cast<uintptr_t>(weight) & 7u) == 0,
+             GD_E_DIM, "gd_rgcn_conv_f32: block sizes and ldy must be even, y / weight 8-byte aligned");
   GD_REQUIRE(x != y, GD_E_DIM, "gd_rgcn_conv_f32: x and y must not alias");
   if (n_nodes == 0) return GD_OK;
   int grid = (n_nodes + 3) / 4;

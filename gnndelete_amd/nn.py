@@ -144,9 +144,10 @@ class RGCNConv(nn.Module):
         # upstream does, rgcn.py / deletion.py:145-163) - take the fused kernel: no [R, n, d] tensor.
         frozen = (not torch.is_grad_enabled()) or getattr(self, 'requires_grad', True) is False \
             or not self.weight.requires_grad
-        if frozen and self.in_channels <= 128 and self.out_channels <= 128:
+        nb = 1 if self.num_blocks is None else self.num_blocks
+        even = (self.in_channels // nb) % 2 == 0 and (self.out_channels // nb) % 2 == 0
+        if frozen and even and self.in_channels <= 128 and self.out_channels <= 128:
             tg = self._typed_node_csr(edge_index, edge_type, n)
-            nb = 1 if self.num_blocks is None else self.num_blocks
             return ops.rgcn_conv_frozen(x, tg, self.weight, self.root, self.bias, nb)
         typed = self._typed_csr(edge_index, edge_type, n)
         m = ops.rgcn_mean(x, typed, self.num_relations, n)                  # [R, n, in]
