@@ -82,6 +82,9 @@ def lib():
                 f'{LIB_PATH} is missing: the HIP extension is not built. Run '
                 '`python -c "import __graft_entry__ as g; g.build()"` (or `make -C gnndelete_amd/csrc`). '
                 'There is no CPU fallback.')
+        # torch first: its bundled HIP runtime must be the one in the process before this library (linked
+        # against libamdhip64) is mapped, or the two end up on different runtime instances
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)
