@@ -14,6 +14,7 @@ What each piece follows (paths relative to /root/reference):
   LOSSES                   framework/trainer/gnndelete_nodeemb.py:19-97
   nodeemb_terms / epoch    framework/trainer/gnndelete_nodeemb.py:169-299
   edgeprob_terms/fullbatch framework/trainer/gnndelete.py:174-193, 211-258
+  original_fullbatch       framework/trainer/base.py:75-142
   eval_linkpred            framework/trainer/base.py:229-305
   negative_sampling_kg     framework/utils.py:46-58
 
@@ -277,6 +278,25 @@ def nodeemb_fullbatch(model, data, epochs, loss_type='both_layerwise', alpha=0.5
         model.train()
         logs.append(nodeemb_epoch(model, fwd, targets, opt, loss_type, alpha, fct))
     return logs, targets
+
+
+def original_fullbatch(model, data, epochs, lr, neg_edge):
+    """Original-model training, Trainer.train_fullbatch (framework/trainer/base.py:75-142) without
+    evaluation: BCE-with-logits over all training edges (label 1) and the injected negatives (label 0),
+    one Adam over every parameter, zero_grad after the step.  -> per-epoch train_loss."""
+    E = data['train_pos_edge_index']
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    label = torch.cat([torch.ones(E.shape[1]), torch.zeros(neg_edge.shape[1])])
+    losses = []
+    for _ in range(epochs):
+        model.train()
+        z = model(data['x'], E)
+        loss = F.binary_cross_entropy_with_logits(model.decode(z, E, neg_edge), label)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss))
+    return losses
 
 
 # ----------------------------------------------------------------------------

@@ -407,6 +407,44 @@ def golden_edgeprob_trajectories(D, TE, A):
         np.savez_compressed(os.path.join(HERE, f'traj_edgeprob_{gnn}.npz'), **out)
 
 
+def golden_original_training(B, A):
+    """The real original-model loop Trainer.train_fullbatch (framework/trainer/base.py:75-142) on the
+    reference's own GCN / GAT / GIN (framework/models/{gcn,gat,gin}.py): BCE-with-logits link prediction on
+    the whole training graph with per-epoch negatives (the stub returns the same injected set), Adam."""
+    models = {'gcn': importlib.import_module('framework.models.gcn').GCN,
+              'gat': importlib.import_module('framework.models.gat').GAT,
+              'gin': importlib.import_module('framework.models.gin').GIN}
+    for gnn, cls in models.items():
+        g = synth_graph(90, 340, 10, seed=29)
+        E = g['train']
+        und, _ = pyg.to_undirected(E, [torch.ones(E.shape[1], dtype=torch.int32)], g['num_nodes'])
+        gen = torch.Generator().manual_seed(4)
+        neg = torch.randint(0, g['num_nodes'], (2, und.shape[1]), generator=gen)
+        d = Bag(x=g['x'], num_nodes=g['num_nodes'], train_pos_edge_index=und, edge_index=und,
+                dtrain_mask=torch.ones(und.shape[1], dtype=torch.bool), dr_mask=torch.ones(und.shape[1], dtype=torch.bool),
+                val_pos_edge_index=g['val_pos'], val_neg_edge_index=g['val_neg'],
+                test_pos_edge_index=g['test_pos'], test_neg_edge_index=g['test_neg'])
+        args = make_args(A, ['--gnn', gnn, '--unlearning_model', 'original', '--in_dim', '10', '--hidden_dim', '32',
+                             '--out_dim', '16', '--dataset', 'Cora', '--checkpoint_dir', tempfile.mkdtemp(), '--lr', '0.01'])
+        args.epochs, args.valid_freq = 6, 1            # parse_args forces 2000 / 500 for `original`
+        torch.manual_seed(12)
+        model = cls(args)
+        init = state_np(model)
+        opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+        STATE['neg'], STATE['wandb'] = neg, []
+        torch.manual_seed(79)
+        B.Trainer(args).train_fullbatch(model, d, opt, args)
+        steps = [w for w in STATE['wandb'] if 'train_loss' in w]
+        vals = [w for w in STATE['wandb'] if 'val_loss' in w]
+        out = dict(init)
+        out.update(data_np(d, neg))
+        out.update({f'final::{k}': np_(v) for k, v in model.state_dict().items()})
+        out.update(train_loss=np.array([s['train_loss'] for s in steps]),
+                   val_loss=np.array([v['val_loss'] for v in vals]), val_dt_auc=np.array([v['val_dt_auc'] for v in vals]),
+                   lr=np.float64(args.lr), epochs=np.int64(6), eval_seed=np.int64(79))
+        np.savez_compressed(os.path.join(HERE, f'orig_{gnn}.npz'), **out)
+
+
 def golden_gcn_layerwise_crash(D, T, A):
     """record that upstream GCNDelete + both_layerwise raises."""
     g = synth_graph(40, 120, 6, seed=31)
@@ -569,11 +607,15 @@ def main():
     if sys.argv[1:] == ['edgeprob']:            # add these fixtures without rewriting the others
         golden_edgeprob_trajectories(D, TE, A)
         return
+    if sys.argv[1:] == ['original']:
+        golden_original_training(B, A)
+        return
     golden_del_layer(D)
     golden_losses(T)
     golden_wiring(D, A)
     golden_trajectories(D, T, A)
     golden_edgeprob_trajectories(D, TE, A)
+    golden_original_training(B, A)
     crash = golden_gcn_layerwise_crash(D, T, A)
     golden_parse_args(A)
     golden_eval(D, T, A)

@@ -109,6 +109,26 @@ def test_edgeprob_trajectory_matches_reference_loop(gnn):
     assert rel_l2(m.deletion2.deletion_weight.detach(), rest['final_w2']) < 1e-5
 
 
+@pytest.mark.parametrize('gnn', ['gcn', 'gat', 'gin'])
+def test_original_training_matches_reference_loop(gnn):
+    """Trainer.train_fullbatch (base.py:75-142) on the reference's own GCN / GAT / GIN: per-epoch BCE loss and
+    every trained parameter after 6 Adam steps."""
+    fx = load_golden(f'orig_{gnn}.npz')
+    state, data, rest = split_fixture(fx)
+    i, h, o = {'gcn': lambda s_: (s_['conv1.lin.weight'].shape[1], s_['conv1.lin.weight'].shape[0], s_['conv2.lin.weight'].shape[0]),
+               'gat': lambda s_: (s_['conv1.lin_src.weight'].shape[1], s_['conv1.lin_src.weight'].shape[0], s_['conv2.lin_src.weight'].shape[0]),
+               'gin': lambda s_: (s_['conv1.nn.weight'].shape[1], s_['conv1.nn.weight'].shape[0], s_['conv2.nn.weight'].shape[0])}[gnn](state)
+    m = R.TwoLayer(gnn, i, h, o)
+    missing = m.load_state_dict(state, strict=False)
+    assert not [k for k in missing.missing_keys if 'lin_dst' not in k]
+    losses = R.original_fullbatch(m, data, int(rest['epochs']), float(rest['lr']), t(rest['neg']))
+    np.testing.assert_allclose(losses, rest['train_loss'], rtol=2e-5)
+    final = {k[len('final::'):]: v for k, v in fx.items() if k.startswith('final::')}
+    for k, v in m.state_dict().items():
+        if k in final:
+            assert rel_l2(v, final[k]) < 1e-5, k
+
+
 def test_eval_matches_reference():
     fx = load_golden('eval.npz')
     state, data, rest = split_fixture(fx)
