@@ -445,6 +445,66 @@ def golden_original_training(B, A):
         np.savez_compressed(os.path.join(HERE, f'orig_{gnn}.npz'), **out)
 
 
+def golden_nodecls_trajectory(D, T, A):
+    """The real node-unlearning loop GNNDeleteNodeClassificationTrainer.train (gnndelete_nodeemb.py:498-657):
+    layer-wise DEC + NI losses over data.edge_index, two Adams, accuracy / micro-F1 evaluation
+    (NodeClassificationTrainer.eval, base.py:754-790).  GATDelete: upstream's GCNDelete crashes here (F5)."""
+    g = synth_graph(100, 380, 10, seed=33)
+    n = g['num_nodes']
+    gen = torch.Generator().manual_seed(9)
+    E = g['train']
+    und, _ = pyg.to_undirected(E, [torch.ones(E.shape[1], dtype=torch.int32)], n)
+    # node deletion as delete_node.py:66-110 sets it up: Df = every edge touching the deleted nodes
+    df_nodes = torch.randperm(n, generator=gen)[:6]
+    gone = torch.zeros(n, dtype=torch.bool)
+    gone[df_nodes] = True
+    df_mask = gone[und[0]] | gone[und[1]]
+    df_edge = und[:, df_mask]
+    seeds = df_edge.flatten().unique()
+    _, e2, m2 = pyg.k_hop_subgraph(seeds, 2, und, n)
+    _, e1, _ = pyg.k_hop_subgraph(seeds, 1, und, n)
+    s1 = torch.zeros(n, dtype=torch.bool)
+    s2 = torch.zeros(n, dtype=torch.bool)
+    s1[e1.flatten().unique()] = True
+    s2[e2.flatten().unique()] = True
+    y = torch.randint(0, 4, (n,), generator=gen)
+    perm = torch.randperm(n, generator=gen)
+    tr, va, te = (torch.zeros(n, dtype=torch.bool) for _ in range(3))
+    tr[perm[:60]] = True
+    va[perm[60:80]] = True
+    te[perm[80:]] = True
+    neg = torch.randint(0, n, (2, int(df_mask.sum())), generator=gen)
+    d = Bag(x=g['x'], num_nodes=n, edge_index=und, y=y, train_mask=tr, val_mask=va, test_mask=te,
+            df_mask=df_mask, dr_mask=~df_mask, dtrain_mask=~df_mask, sdf_mask=m2, sdf_node_1hop_mask=s1,
+            sdf_node_2hop_mask=s2, directed_df_edge_index=df_edge[:, df_edge[0] < df_edge[1]])
+    args = make_args(A, ['--gnn', 'gat', '--unlearning_model', 'gnndelete_nodeemb', '--in_dim', '10', '--hidden_dim', '32',
+                         '--out_dim', '4', '--epochs', '6', '--valid_freq', '3', '--dataset', 'DBLP', '--lr', '0.01',
+                         '--alpha', '0.4', '--checkpoint_dir', tempfile.mkdtemp()])
+    torch.manual_seed(6)
+    model = D.GATDelete(args, s1, s2)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if n_.endswith('bias'):
+                p.copy_(torch.randn_like(p) * 0.1)
+    init = state_np(model)
+    model.to = lambda *a, **k: model
+    opt = [torch.optim.Adam(model.deletion1.parameters(), lr=args.lr),
+           torch.optim.Adam(model.deletion2.parameters(), lr=args.lr)]
+    STATE['neg'], STATE['wandb'] = neg, []
+    T.GNNDeleteNodeClassificationTrainer(args).train(model, d, opt, args)
+    steps = [w for w in STATE['wandb'] if 'Epoch' in w]
+    vals = [w for w in STATE['wandb'] if 'val_loss' in w]
+    out = dict(init)
+    out.update(data_np(d, neg))
+    out.update(train_loss=np.array([s['train_loss'] for s in steps]), loss_r=np.array([s['loss_r'] for s in steps]),
+               loss_l=np.array([s['loss_l'] for s in steps]),
+               final_w1=np_(model.deletion1.deletion_weight), final_w2=np_(model.deletion2.deletion_weight),
+               val_loss=np.array([v['val_loss'] for v in vals]), val_dt_acc=np.array([v['val_dt_acc'] for v in vals]),
+               val_dt_f1=np.array([v['val_dt_f1'] for v in vals]),
+               lr=np.float64(args.lr), alpha=np.float64(args.alpha), epochs=np.int64(6))
+    np.savez_compressed(os.path.join(HERE, 'traj_nodecls_gat.npz'), **out)
+
+
 def golden_gcn_layerwise_crash(D, T, A):
     """record that upstream GCNDelete + both_layerwise raises."""
     g = synth_graph(40, 120, 6, seed=31)
@@ -610,12 +670,16 @@ def main():
     if sys.argv[1:] == ['original']:
         golden_original_training(B, A)
         return
+    if sys.argv[1:] == ['nodecls']:
+        golden_nodecls_trajectory(D, T, A)
+        return
     golden_del_layer(D)
     golden_losses(T)
     golden_wiring(D, A)
     golden_trajectories(D, T, A)
     golden_edgeprob_trajectories(D, TE, A)
     golden_original_training(B, A)
+    golden_nodecls_trajectory(D, T, A)
     crash = golden_gcn_layerwise_crash(D, T, A)
     golden_parse_args(A)
     golden_eval(D, T, A)

@@ -208,3 +208,31 @@ def test_original_trainer_reproduces_reference_training(tmp_path, monkeypatch, g
     for k, v in m.state_dict().items():
         if k in final:
             assert rel_l2(v.cpu(), final[k]) < 1e-4, k
+
+
+def test_node_unlearning_trainer_reproduces_reference_trajectory(tmp_path, monkeypatch):
+    """GNNDeleteNodeClassificationTrainer (delete_node.py's trainer) on the HIP path against the reference's real
+    loop (gnndelete_nodeemb.py:498-657) incl. its accuracy / micro-F1 evaluation; out_dim = 4 classes, so the
+    last-layer Del takes the generic-width kernels."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework.data import Data
+    from gnndelete_amd.framework.trainer import gnndelete_nodeemb as TN
+    fx = load_golden('traj_nodecls_gat.npz')
+    state, data, rest = split_fixture(fx)
+    m = hip_model('gat', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    neg = t(rest['neg']).cuda()
+    monkeypatch.setattr(TN, 'negative_sampling', lambda *a, **k: neg)
+    epochs = int(rest['epochs'])
+    args = SimpleNamespace(unlearning_model='gnndelete_nodeemb', dataset='DBLP', checkpoint_dir=str(tmp_path),
+                           eval_on_cpu=False, epochs=epochs, valid_freq=3, lr=float(rest['lr']), alpha=float(rest['alpha']),
+                           loss_fct='mse_mean', loss_type='both_layerwise', gnn='gat')
+    opt = [torch.optim.Adam(m.deletion1.parameters(), lr=args.lr), torch.optim.Adam(m.deletion2.parameters(), lr=args.lr)]
+    tr = TN.GNNDeleteNodeClassificationTrainer(args)
+    tr.train(m, Data(data), opt, args)
+    assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), rest['final_w1']) < 1e-4
+    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < 1e-4
+    vals = [r for r in tr.trainer_log['log'] if 'val_dt_acc' in r]
+    np.testing.assert_allclose([v['val_dt_acc'] for v in vals], rest['val_dt_acc'], atol=1e-9)
+    np.testing.assert_allclose([v['val_loss'] for v in vals], rest['val_loss'], rtol=1e-4)
+    tl = [r for r in tr.trainer_log['log'] if 'train_loss' in r]
+    np.testing.assert_allclose([r['train_loss'] for r in tl], rest['train_loss'][[2, 5]], rtol=1e-4)

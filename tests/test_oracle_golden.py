@@ -129,6 +129,21 @@ def test_original_training_matches_reference_loop(gnn):
             assert rel_l2(v, final[k]) < 1e-5, k
 
 
+def test_node_unlearning_trajectory_matches_reference_loop():
+    """GNNDeleteNodeClassificationTrainer.train (gnndelete_nodeemb.py:498-657): the layer-wise rule over
+    data.edge_index - the oracle's nodeemb loop reproduces its losses and final Del weights."""
+    fx = load_golden('traj_nodecls_gat.npz')
+    state, data, rest = split_fixture(fx)
+    data['train_pos_edge_index'] = data['edge_index']
+    m = oracle_model('gat', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    logs, _ = R.nodeemb_fullbatch(m, data, int(rest['epochs']), 'both_layerwise', float(rest['alpha']), 'mse_mean',
+                                  float(rest['lr']), neg_edge=t(rest['neg']))
+    for key in ['train_loss', 'loss_r', 'loss_l']:
+        np.testing.assert_allclose(np.array([l[key] for l in logs]), rest[key], rtol=2e-5, atol=1e-9, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach(), rest['final_w1']) < 1e-5
+    assert rel_l2(m.deletion2.deletion_weight.detach(), rest['final_w2']) < 1e-5
+
+
 def test_eval_matches_reference():
     fx = load_golden('eval.npz')
     state, data, rest = split_fixture(fx)
