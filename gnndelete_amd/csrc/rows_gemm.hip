@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void rows_gemm_scalar_kernel(
 // while tile t feeds the matrix cores); its 4 waves split the TA x TB output tiles and read their
 // MFMA operands straight out of the row-major tiles (lane -> consecutive column: conflict-free).
 // HBM bytes S (d_a + d_b) 4 and flops 2 S d_a d_b are balanced at d = 128 (ridge ~20 flop/B).
+// NW = waves per block (they split the TA x TB output tiles).
 //
 // LOSS: the upstream gradient is not read but FORMED while it is fetched, from the folded row-target MSE
 // terms of that layer (loss.hip): g = coef_u (z - tbar_u) for a row with loss slot u, 0 otherwise
@@ -229,21 +230,22 @@ struct WgradLoss {
   float* partials;         // [2 * n_blocks] per-block (DEC, NI) sums of cnt |z - tbar|^2
 };
 
-template <int TA, int TB, bool LOSS>
-__global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
+template <int TA, int TB, bool LOSS, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void rows_wgrad_mfma_kernel(
     const float* __restrict__ a, int64_t ld_a, const int32_t* __restrict__ a_idx, const float* __restrict__ g,
     int64_t ld_g, const int32_t* __restrict__ g_idx, const float* __restrict__ relu_mask,
     const float* __restrict__ g_add, int32_t n_sel, int32_t rows_per_block, float* __restrict__ partials,
     WgradLoss loss) {
   constexpr int DA = 32 * TA, DB = 32 * TB, KT = 32;
-  constexpr int TILES = TA * TB, TPW = (TILES + 3) / 4;
+  constexpr int TILES = TA * TB, TPW = (TILES + NW - 1) / NW;
+  constexpr int NTH = 64 * NW;
   constexpr int FA = DA / 4, FB = DB / 4;            // float4 per row
-  constexpr int LA = KT * FA / 256, LB = KT * FB / 256;  // float4 loads per thread per tile (TA, TB)
+  constexpr int LA = (KT * FA + NTH - 1) / NTH, LB = (KT * FB + NTH - 1) / NTH;  // float4 loads per thread per tile
   __shared__ __attribute__((aligned(16))) float sa[2][KT * DA];
   __shared__ __attribute__((aligned(16))) float sg[2][KT * DB];
   __shared__ int32_t sia[kWgradMaxRows], sig[kWgradMaxRows];   // this block's gather lists
   __shared__ int32_t sls[LOSS ? kWgradMaxRows : 1];            // and loss slots
-  __shared__ float lred[2][4];
+  __shared__ float lred[2][NW];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int c_lo = lane & 31, khalf = lane >> 5;
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
   const int n_tiles = (s_end - s_begin + KT - 1) / KT;
 
   // stage the row indices once so the per-tile row loads do not wait on an index load
-  for (int i = tid; i < s_end - s_begin; i += 256) {
+  for (int i = tid; i < s_end - s_begin; i += NTH) {
     sia[i] = a_idx ? a_idx[s_begin + i] : s_begin + i;
     sig[i] = g_idx ? g_idx[s_begin + i] : s_begin + i;
     if (LOSS) sls[i] = loss.slot[s_begin + i];
@@ -272,8 +274,8 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
     const int s0 = s_begin + tile * KT;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-      const int f = tid + 256 * i, r = f / FA, c4 = f % FA, ss = s0 + r;
-      if (ss < s_end) {
+      const int f = tid + NTH * i, r = f / FA, c4 = f % FA, ss = s0 + r;
+      if (ss < s_end && f < KT * FA) {
         const int64_t row = sia[ss - s_begin];
         ra[i] = reinterpret_cast<const float4*>(a + row * ld_a)[c4];
       } else {
@@ -282,8 +284,8 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-      const int f = tid + 256 * i, r = f / FB, c4 = f % FB, ss = s0 + r;
-      if (ss < s_end) {
+      const int f = tid + NTH * i, r = f / FB, c4 = f % FB, ss = s0 + r;
+      if (ss < s_end && f < KT * FB) {
         const int64_t row = sig[ss - s_begin];
         float4 v;
         if (LOSS) {
@@ -316,9 +318,11 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < LA; ++i) reinterpret_cast<float4*>(sa[buf])[tid + 256 * i] = ra[i];
+    for (int i = 0; i < LA; ++i)
+      if (tid + NTH * i < KT * FA) reinterpret_cast<float4*>(sa[buf])[tid + NTH * i] = ra[i];
 #pragma unroll
-    for (int i = 0; i < LB; ++i) reinterpret_cast<float4*>(sg[buf])[tid + 256 * i] = rg[i];
+    for (int i = 0; i < LB; ++i)
+      if (tid + NTH * i < KT * FB) reinterpret_cast<float4*>(sg[buf])[tid + NTH * i] = rg[i];
   };
 
   if (n_tiles > 0) {
@@ -336,8 +340,8 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
       const int k = 2 * kk + khalf;
 #pragma unroll
       for (int q = 0; q < TPW; ++q) {
-        const int id = wave + 4 * q;
-        if (TILES % 4 == 0 || id < TILES) {
+        const int id = wave + NW * q;
+        if (TILES % NW == 0 || id < TILES) {
           const float av = pa[k * DA + (id / TB) * 32 + c_lo];
           const float gv = pg[k * DB + (id % TB) * 32 + c_lo];
           acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gv, acc[q], 0, 0, 0);
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
   float* dst = partials + (int64_t)blockIdx.x * DA * DB;
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
-    const int id = wave + 4 * q;
+    const int id = wave + NW * q;
     if (id >= TILES) continue;
     const int i0 = (id / TB) * 32, j0 = (id % TB) * 32;
 #pragma unroll
@@ -366,8 +370,11 @@ __global__ __launch_bounds__(256, 2) void rows_wgrad_mfma_kernel(
     if (lane == 0) { lred[0][wave] = ls0; lred[1][wave] = ls1; }
     __syncthreads();
     if (tid == 0) {
-      loss.partials[2 * blockIdx.x + 0] = (lred[0][0] + lred[0][1]) + (lred[0][2] + lred[0][3]);
-      loss.partials[2 * blockIdx.x + 1] = (lred[1][0] + lred[1][1]) + (lred[1][2] + lred[1][3]);
+      float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) { p0 += lred[0][q]; p1 += lred[1][q]; }
+      loss.partials[2 * blockIdx.x + 0] = p0;
+      loss.partials[2 * blockIdx.x + 1] = p1;
     }
   }
 }
@@ -604,6 +611,16 @@ static int wgrad_impl(const gd::WgradLoss* loss, const float* a, int64_t ld_a, c
                          (!relu_mask || aligned16(relu_mask)) && (!g_add || aligned16(g_add));
     if (mfma_ok) {
     const WgradLoss no_loss{nullptr, nullptr, nullptr, nullptr, nullptr};
+    // 128 x 128: 8 waves share the LDS tiles (2 output tiles each, 4 waves / SIMD at 2 blocks per CU) - measured
+    // +3 % on the whole step over 4 waves with 4 tiles each; the smaller shapes keep 4 waves
+    if (ta == 4 && tb == 4) {
+      if (loss)
+        hipLaunchKernelGGL((rows_wgrad_mfma_kernel<4, 4, true, 8>), dim3(nb), dim3(512), 0, s, a, ld_a, a_idx, g, ld_g,
+                           g_idx, relu_mask, g_add, n_sel, rpb, partials, *loss);
+      else
+        hipLaunchKernelGGL((rows_wgrad_mfma_kernel<4, 4, false, 8>), dim3(nb), dim3(512), 0, s, a, ld_a, a_idx, g, ld_g,
+                           g_idx, relu_mask, g_add, n_sel, rpb, partials, no_loss);
+    } else
 #define GD_WG_CASE(TA, TB)                                                                                        \
   do {                                                                                                            \
     if (loss)                                                                                                     \
