@@ -476,19 +476,23 @@ class NodeembEngine:
             # ---- backward + update
             if lt == 'both_layerwise':
                 self._layer2_backward()                          # leaves dh for the next iteration
-                self.adam2.apply(self.g2)
+                if not self._fuse_l2:
+                    self.adam2.apply(self.g2)
             elif lt == 'both_all':
                 self._layer2_backward(g2_accumulate=True)
                 self._wgrad1(True, self.dh)
-                self.adam2.apply(self.g2)
+                if not self._fuse_l2:
+                    self.adam2.apply(self.g2)
             elif lt == 'only2_layerwise':
                 self._layer2_backward(to_w1=False)
-                self.adam2.apply(self.g2)
+                if not self._fuse_l2:
+                    self.adam2.apply(self.g2)
             elif lt == 'only2_all':
                 self._layer2_backward()
                 a1, a1_idx = (self.pre1, self.idx1) if self._split1 else (self.xs1, None)
                 self._wgrad(a1, self.dh, self.idx1, self.s1, self.g1, False, self.ws1, adam=self.adam1, a_idx=a1_idx)
-                self.adam2.apply(self.g2)
+                if not self._fuse_l2:
+                    self.adam2.apply(self.g2)
             # ---- loss sums -> history ring, advance the iteration counter (Adam's step number)
             p1, n1 = (self._lp1, self._lp1_blocks) if self._fuse_loss1 else (self.t1.partials, self.t1.n_partial_blocks())
             p2, n2 = (self._lp2, self._lp2_blocks) if self._fuse_l2 else (self.t2.partials, self.t2.n_partial_blocks())
@@ -500,8 +504,10 @@ class NodeembEngine:
 
     def _layer2_backward(self, to_w1=True, g2_accumulate=False):
         """g2 (+)= dW_D2; with to_w1 also dh[S1] = d loss2 / d z1[S1] (ReLU-gated)."""
-        if self._fuse_l2:          # dz2 (compact) and dp2 (in self.dz2) were produced by the fused Del-2 kernel
-            self._wgrad(self.p2, self.dz2c, None, self.s2, self.g2, g2_accumulate, self.ws2, a_idx=self.idx2)
+        if self._fuse_l2:          # dz2 (compact) and dp2 (in self.dz2) were produced by the fused Del-2 kernel,
+            # so nothing reads W_D2 any more this iteration: its Adam step rides on the split-K reduction
+            self._wgrad(self.p2, self.dz2c, None, self.s2, self.g2, g2_accumulate, self.ws2, a_idx=self.idx2,
+                        adam=self.adam2)
         elif self._split2:
             self._wgrad(self.p2, self.dz2, self.idx2, self.s2, self.g2, g2_accumulate, self.ws2, a_idx=self.idx2)
         else:
