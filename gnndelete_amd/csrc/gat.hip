@@ -490,6 +490,50 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const int32_t* __restr
   if (lane == 0) out[row] = s;
 }
 
+// Edge quantities of the GAT backward moved to the transposed (source-major) edge order in one pass:
+//   alpha_t[k] = alpha[perm[k]]                 (the weights of the transposed SpMM that forms dh)
+//   da_src[j]  = sum_{k in row j} de[perm[k]]   (gradient of the source attention logit)
+// 8 lanes per source row (8 rows per wave; the typical row has ~8 out-edges), rows with more than 256
+// out-edges are redone by the whole wave.  Fixed summation order per row (deterministic).
+__global__ __launch_bounds__(256) void gat_transpose_edge_kernel(const int32_t* __restrict__ rowptr_t,
+                                                                 const int32_t* __restrict__ perm,
+                                                                 const float* __restrict__ alpha,
+                                                                 const float* __restrict__ de, int32_t n,
+                                                                 float* __restrict__ alpha_t,
+                                                                 float* __restrict__ da_src) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 3, li = lane & 7;
+  const int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+  const int r = base + g;
+  int start = 0, end = 0;
+  if (r < n) { start = rowptr_t[r]; end = rowptr_t[r + 1]; }
+  const bool heavy = end - start > 256;
+  float s = 0.f;
+  if (!heavy)
+    for (int k = start + li; k < end; k += 8) {
+      const int p = perm[k];
+      alpha_t[k] = alpha[p];
+      s += de[p];
+    }
+  s = lanes_sum<8>(s);
+  if (r < n && !heavy && li == 0) da_src[r] = s;
+  unsigned long long todo = __ballot(heavy && li == 0);
+  while (todo) {
+    const int g2 = (__ffsll((long long)todo) - 1) >> 3;
+    todo &= todo - 1;
+    const int r2 = base + g2;
+    const int s2 = rowptr_t[r2], e2 = rowptr_t[r2 + 1];
+    float t = 0.f;
+    for (int k = s2 + lane; k < e2; k += kWave) {
+      const int p = perm[k];
+      alpha_t[k] = alpha[p];
+      t += de[p];
+    }
+    t = wave_sum(t);
+    if (lane == 0) da_src[r2] = t;
+  }
+}
+
 #define GD_GAT_DISPATCH(KERNEL, ...)                                                         \
   do {                                                                                       \
     const int lpr = lanes_per_row(d4);                                                       \
@@ -681,4 +725,14 @@ extern "C" int gd_rank1_add2_f32(float* y, int64_t ldy, int32_t n, int32_t d, co
   hipLaunchKernelGGL(rank1_add2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, ldy,
                      n, d / 4, a, u, b, v);
   return launched("rank1_add2");
+}
+
+extern "C" int gd_gat_transpose_edges_f32(const int32_t* rowptr_t, const int32_t* perm, const float* alpha,
+                                          const float* de, int32_t n, float* alpha_t, float* da_src, void* stream) {
+  using namespace gd;
+  if (n <= 0) return GD_OK;
+  GD_REQUIRE(rowptr_t && perm && alpha && de && alpha_t && da_src, GD_E_NULL, "gd_gat_transpose_edges_f32: null pointer");
+  hipLaunchKernelGGL(gat_transpose_edge_kernel, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, rowptr_t, perm,
+                     alpha, de, n, alpha_t, da_src);
+  return launched("gat_transpose_edges");
 }

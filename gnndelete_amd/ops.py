@@ -220,13 +220,11 @@ def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope):
         ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split, ptr(g.col), ptr(a_src), ptr(a_dst), ptr(rowmax),
         ptr(rowsum), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(alpha), ptr(de), ptr(da_dst), ptr(t_row),
         ptr(scratch), float(slope), d, g.nnz, stream_ptr(dev)), 'gd_gat_edge_grads_balanced_f32')
-    perm = getattr(g, '_perm_t_long', None)
-    if perm is None:
-        perm = g._perm_t_long = g.perm_t.long()                 # cached: the conversion is a kernel launch
-    dh = _spmm_raw(g.rowptr_t, g.col_t, alpha[perm], dy, None, 0.0, n, g.plan_t)
+    alpha_t = torch.empty_like(alpha)
     da_src = torch.empty(n, dtype=torch.float32, device=dev)
-    check(_lib.lib().gd_segment_sum_f32(ptr(g.rowptr_t), ptr(g.perm_t), ptr(de), n, ptr(da_src), stream_ptr(dev)),
-          'gd_segment_sum_f32')
+    check(_lib.lib().gd_gat_transpose_edges_f32(ptr(g.rowptr_t), ptr(g.perm_t), ptr(alpha), ptr(de), n, ptr(alpha_t),
+                                                ptr(da_src), stream_ptr(dev)), 'gd_gat_transpose_edges_f32')
+    dh = _spmm_raw(g.rowptr_t, g.col_t, alpha_t, dy, None, 0.0, n, g.plan_t)
     return dh, da_src, da_dst
 
 

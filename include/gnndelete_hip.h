@@ -143,6 +143,13 @@ int gd_segment_sum_f32(const int32_t* rowptr, const int32_t* perm, const float* 
 int gd_rank1_add2_f32(float* y, int64_t ldy, int32_t n, int32_t d, const float* a, const float* u,
                       const float* b, const float* v, void* stream);
 
+/* GAT backward, edge quantities moved to the transposed (source-major) edge order in one pass:
+ * alpha_t[k] = alpha[perm[k]] (weights of the transposed SpMM that forms dh) and
+ * da_src[j] = sum_{k in source row j} de[perm[k]] (gradient of alpha_src); perm = position of
+ * transposed edge k in the forward CSR. */
+int gd_gat_transpose_edges_f32(const int32_t* rowptr_t, const int32_t* perm, const float* alpha, const float* de,
+                               int32_t n, float* alpha_t, float* da_src, void* stream);
+
 /* Fused R-GCN message passing (PyG RGCNConv aggr='mean', framework/models/rgcn.py:16-38) for constant
  * relation weights - no [R, N, d] per-relation aggregate is formed:
  *     y[i,:] += sum over the (i, r) runs of node i:  ( sum_{e in run} w[e] * x[col[e],:] ) @ W_r
