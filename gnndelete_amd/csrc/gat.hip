@@ -354,20 +354,19 @@ __global__ __launch_bounds__(256) void gat_items_bwd_dalpha_kernel(
     dyr[v] = reinterpret_cast<const float4*>(dy + (int64_t)row * lddy)[EXACT ? vec : min(vec, d4 - 1)];
     if (!EXACT && vec >= d4) dyr[v] = f4_zero();
   }
-  float tpart = 0.f;
+  __shared__ float pbuf[4][kWave];
+  float* pw = pbuf[threadIdx.x >> 6];
   const int cnt_s = __builtin_amdgcn_readfirstlane(cnt);           // scalar trip control
   const int trips = (cnt_s + G - 1) / G;
   const int last4 = 4 * cnt_s - 4;
   constexpr int U = 4;                                             // neighbour rows in flight per lane group
   for (int t0 = 0; t0 < trips; t0 += U) {
     float4 hv[U][VPL];
-    float aj[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (t0 + u < trips) {
         const int j4 = min(4 * ((t0 + u) * G) + 4 * g, last4);     // padded slots re-read the last neighbour
         const int cj = __builtin_amdgcn_ds_bpermute(j4, c);
-        aj[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(j4, __float_as_int(al)));
         const float4* hr = reinterpret_cast<const float4*>(h + (int64_t)cj * ldh);
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
@@ -387,13 +386,15 @@ __global__ __launch_bounds__(256) void gat_items_bwd_dalpha_kernel(
           p = fmaf(dyr[v].z, hv[u][v].z, p); p = fmaf(dyr[v].w, hv[u][v].w, p);
         }
         p = lanes_sum<LPR>(p);
-        if (j < cnt && li == 0) {
-          de[start + j] = p;
-          tpart = fmaf(aj[u], p, tpart);
-        }
+        if (j < cnt && li == 0) pw[j] = p;                          // edge j's <dy_i, h_j>, parked per edge
       }
     }
   }
+  // one coalesced store of the item's edge values and the attention-weighted sum, edge per lane
+  // (LDS operations of one wave complete in order: no barrier needed)
+  const float pj = lane < cnt ? pw[lane] : 0.f;
+  if (lane < cnt) de[start + lane] = pj;
+  float tpart = al * pj;
   tpart = wave_sum(tpart);
   if (lane == 0) {
     if (slot < 0) t_row[row] = tpart; else scratch_t[slot] = tpart;
