@@ -72,6 +72,24 @@ def _features(n, f, style, community, gen):
     return x / x.sum(1, keepdim=True).clamp(min=1e-12)
 
 
+def split_linkpred(x, edges, n, gen, val_ratio=0.05, test_ratio=0.05):
+    """The reference's split recipe (prepare_dataset.py:31-136 train_test_split_edges_no_neg_adj_mask,
+    :205-214 IN / OUT masks) on unique ``row < col`` edges: randperm, test then validation edges first,
+    negatives that avoid the positives, Df candidates inside / outside the 2-hop enclosing subgraph of
+    the test edges.  -> (data, {'in': mask, 'out': mask})"""
+    m = edges.shape[1]
+    n_v, n_t = int(math.floor(val_ratio * m)), int(math.floor(test_ratio * m))
+    perm = torch.randperm(m, generator=gen)
+    edges = edges[:, perm]
+    test_pos, val_pos, train = edges[:, :n_t], edges[:, n_t:n_t + n_v], edges[:, n_t + n_v:]
+    data = Data(x=x, num_nodes=n, num_features=int(x.shape[1]) if x.dim() == 2 else 0, train_pos_edge_index=train,
+                test_pos_edge_index=test_pos, val_pos_edge_index=val_pos,
+                test_neg_edge_index=negative_sampling(test_pos, n, n_t, generator=gen),
+                val_neg_edge_index=negative_sampling(val_pos, n, n_v, generator=gen))
+    _, _, _, local = k_hop_subgraph(test_pos.flatten().unique(), 2, train, num_nodes=n)
+    return data, {'in': local, 'out': ~local}
+
+
 def make_linkpred_dataset(name='synth-collab', seed=42, val_ratio=0.05, test_ratio=0.05, shape=None):
     """-> (data, df_masks) where data has x, num_nodes, train_pos_edge_index (directed row<col),
     {val,test}_{pos,neg}_edge_index and df_masks = {'in': mask, 'out': mask} over the train edges
@@ -80,16 +98,7 @@ def make_linkpred_dataset(name='synth-collab', seed=42, val_ratio=0.05, test_rat
     gen = torch.Generator().manual_seed(seed)
     edges, community = dcsbm_edges(n, m, seed)
     x = _features(n, f, style, community, gen)
-    n_v, n_t = int(math.floor(val_ratio * m)), int(math.floor(test_ratio * m))
-    perm = torch.randperm(m, generator=gen)
-    edges = edges[:, perm]
-    test_pos, val_pos, train = edges[:, :n_t], edges[:, n_t:n_t + n_v], edges[:, n_t + n_v:]
-    data = Data(x=x, num_nodes=n, num_features=f, train_pos_edge_index=train,
-                test_pos_edge_index=test_pos, val_pos_edge_index=val_pos,
-                test_neg_edge_index=negative_sampling(test_pos, n, n_t, generator=gen),
-                val_neg_edge_index=negative_sampling(val_pos, n, n_v, generator=gen))
-    _, _, _, local = k_hop_subgraph(test_pos.flatten().unique(), 2, train, num_nodes=n)
-    return data, {'in': local, 'out': ~local}
+    return split_linkpred(x, edges, n, gen, val_ratio, test_ratio)
 
 
 # name -> (num_nodes, num_relations, unique triples)

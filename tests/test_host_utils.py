@@ -1,5 +1,7 @@
 """Host-side preprocessing of gnndelete_amd.framework vs the oracle and vs what the reference's
 delete_gnn.main() produced (tests/golden/prep_*.npz).  Bit-exact (integer / boolean work)."""
+import os
+
 import pytest
 import torch
 
@@ -89,3 +91,58 @@ def test_labels_and_data_bag():
     assert 'foo' in d and d.to('cpu') is d
     assert R.df_size_from_arg(2.5, 1000) == resolve_df_size(2.5, 1000) == 25
     assert resolve_df_size(100, 1000) == 100
+
+
+def test_raw_readers_and_prepare_dataset_on_files_in_the_upstream_layouts(tmp_path):
+    """prepare_dataset.py on raw files laid out like the reference's downloads (CitationFull .npz,
+    ogbl-collab csv.gz): self loops and duplicate / reversed edges collapse to unique row<col pairs, features
+    are binarised and row-normalised, and the result goes through the reference's split recipe."""
+    import gzip
+    import subprocess
+    import sys
+    import numpy as np
+    import scipy.sparse as sp
+    import torch
+    from gnndelete_amd.framework.raw_readers import load_raw
+    rng = np.random.default_rng(0)
+    n, f = 120, 30
+    a = sp.random(n, n, density=0.05, random_state=1, format='csr')
+    a = a + a.T + sp.eye(n)                                   # symmetric with self loops, like the raw files
+    a = sp.csr_matrix(a)
+    x = sp.random(n, f, density=0.2, random_state=2, format='csr')
+    raw = tmp_path / 'data' / 'DBLP' / 'raw'
+    raw.mkdir(parents=True)
+    np.savez(raw / 'dblp.npz', adj_data=a.data, adj_indices=a.indices, adj_indptr=a.indptr, adj_shape=a.shape,
+             attr_data=x.data, attr_indices=x.indices, attr_indptr=x.indptr, attr_shape=x.shape,
+             labels=rng.integers(0, 4, n))
+    xr, edges, y = load_raw('DBLP', str(tmp_path / 'data'))
+    dense = np.asarray(a.todense()) != 0
+    np.fill_diagonal(dense, False)
+    want = torch.from_numpy(np.stack(np.nonzero(np.triu(dense, 1))))
+    assert torch.equal(edges, want) and y.shape == (n,)
+    xd = (np.asarray(x.todense()) > 0).astype(np.float32)
+    np.testing.assert_allclose(xr.numpy(), xd / np.maximum(xd.sum(1, keepdims=True), 1), rtol=1e-6)
+
+    craw = tmp_path / 'data' / 'ogbl_collab' / 'raw'
+    craw.mkdir(parents=True)
+    e = rng.integers(0, n, (400, 2))
+    with gzip.open(craw / 'edge.csv.gz', 'wt') as fh:
+        fh.write('\n'.join(f'{u},{v}' for u, v in e))
+    feat = rng.standard_normal((n, 8)).astype(np.float32)
+    with gzip.open(craw / 'node-feat.csv.gz', 'wt') as fh:
+        fh.write('\n'.join(','.join(repr(float(v)) for v in row) for row in feat))
+    xc, ec, _ = load_raw('ogbl-collab', str(tmp_path / 'data'))
+    keys = {(min(u, v), max(u, v)) for u, v in e.tolist() if u != v}
+    assert ec.shape[1] == len(keys) and bool((ec[0] < ec[1]).all()) and xc.shape == (n, 8)
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'prepare_dataset.py'), '--dataset', 'DBLP', '--data_dir',
+                        str(tmp_path / 'data'), '--seeds', '42'], capture_output=True, text=True,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0, r.stderr[-800:]
+    d = torch.load(tmp_path / 'data' / 'DBLP' / 'd_42.pt')
+    m = edges.shape[1]
+    assert d['train_pos_edge_index'].shape[1] == m - 2 * int(0.05 * m) and d['val_pos_edge_index'].shape[1] == int(0.05 * m)
+    r = subprocess.run([sys.executable, os.path.join(root, 'prepare_dataset.py'), '--dataset', 'PubMed', '--data_dir',
+                        str(tmp_path / 'data')], capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode != 0 and 'no raw files' in r.stderr + r.stdout
