@@ -3,8 +3,8 @@ factories (get_model / get_trainer), registry names and class names (framework/_
 Registry entries whose upstream implementation is outside the hot path (competing baselines,
 membership-inference attack, the unfinished graph_eraser / missing graph_editor) are not built;
 asking for one raises NotImplementedError naming it."""
-from .models import (GAT, GCN, GIN, RGCN, SAGE, GATDelete, GCNDelete, GINDelete, RGCNDelete,  # noqa: F401
-                     SAGEDelete)
+from .models import (GAT, GCN, GIN, RGAT, RGCN, SAGE, GATDelete, GCNDelete, GINDelete, RGATDelete,  # noqa: F401
+                     RGCNDelete, SAGEDelete)
 from .trainer.base import NodeClassificationTrainer, Trainer
 from .trainer.gnndelete_nodeemb import GNNDeleteNodeClassificationTrainer, GNNDeleteNodeembTrainer
 
@@ -37,9 +37,10 @@ def _lazy_trainers():
 
 def get_model(args, mask_1hop=None, mask_2hop=None, num_nodes=None, num_edge_type=None):
     if 'gnndelete' in args.unlearning_model:
-        model_mapping = {'gcn': GCNDelete, 'gat': GATDelete, 'gin': GINDelete, 'rgcn': RGCNDelete, 'sage': SAGEDelete}
+        model_mapping = {'gcn': GCNDelete, 'gat': GATDelete, 'gin': GINDelete, 'rgcn': RGCNDelete, 'rgat': RGATDelete,
+                         'sage': SAGEDelete}
     else:
-        model_mapping = {'gcn': GCN, 'gat': GAT, 'gin': GIN, 'rgcn': RGCN, 'sage': SAGE}
+        model_mapping = {'gcn': GCN, 'gat': GAT, 'gin': GIN, 'rgcn': RGCN, 'rgat': RGAT, 'sage': SAGE}
     if args.gnn not in model_mapping:
         raise NotImplementedError(f"gnn '{args.gnn}' is outside the hot-path scope of this build (have: "
                                   f"{sorted(model_mapping)})")

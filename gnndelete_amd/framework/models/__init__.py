@@ -1,5 +1,6 @@
-from .backbones import GAT, GCN, GIN, RGCN, SAGE
-from .deletion import DeletionLayer, DeletionLayerKG, GATDelete, GCNDelete, GINDelete, RGCNDelete, SAGEDelete
+from .backbones import GAT, GCN, GIN, RGAT, RGCN, SAGE
+from .deletion import (DeletionLayer, DeletionLayerKG, GATDelete, GCNDelete, GINDelete, RGATDelete, RGCNDelete,
+                       SAGEDelete)
 
-__all__ = ['GCN', 'GAT', 'GIN', 'RGCN', 'DeletionLayer', 'DeletionLayerKG', 'GCNDelete', 'GATDelete',
-           'GINDelete', 'RGCNDelete', 'SAGE', 'SAGEDelete']
+__all__ = ['GCN', 'GAT', 'GIN', 'RGCN', 'RGAT', 'DeletionLayer', 'DeletionLayerKG', 'GCNDelete', 'GATDelete',
+           'GINDelete', 'RGCNDelete', 'RGATDelete', 'SAGE', 'SAGEDelete']

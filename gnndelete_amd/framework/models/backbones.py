@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...nn import GATConv, GCNConv, GINConv, RGCNConv, SAGEConv
+from ...nn import GATConv, GCNConv, GINConv, RGATConv, RGCNConv, SAGEConv
 
 
 class _Homogeneous(nn.Module):
@@ -79,3 +79,19 @@ class RGCN(nn.Module):
 
     def decode(self, z, edge_index, edge_type):
         return ops.edge_dot(z, edge_index[0], edge_index[1], self.W, edge_type)
+
+
+class RGAT(RGCN):
+    """nn.Embedding -> RGATConv x2 + DistMult decoder (framework/models/rgat.py:353-391)."""
+
+    def __init__(self, args, num_nodes, num_edge_type, **kwargs):
+        nn.Module.__init__(self)
+        self.args = args
+        self.num_edge_type = num_edge_type
+        self.node_emb = nn.Embedding(num_nodes, args.in_dim)
+        blocks = 4 if num_edge_type > 20 else None
+        self.conv1 = RGATConv(args.in_dim, args.hidden_dim, num_edge_type * 2, num_blocks=blocks)
+        self.conv2 = RGATConv(args.hidden_dim, args.out_dim, num_edge_type * 2, num_blocks=blocks)
+        self.relu = nn.ReLU()
+        self.W = nn.Parameter(torch.empty(num_edge_type, args.out_dim))
+        nn.init.xavier_uniform_(self.W, gain=nn.init.calculate_gain('relu'))

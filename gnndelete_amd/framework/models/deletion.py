@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from .backbones import GAT, GCN, GIN, RGCN, SAGE
+from .backbones import GAT, GCN, GIN, RGAT, RGCN, SAGE
 
 
 class _RowList:
@@ -59,7 +59,7 @@ DeletionLayerKG = DeletionLayer
 
 
 def _with_deletion(base):
-    relational = base is RGCN
+    relational = base in (RGCN, RGAT)
 
     class _Delete(base):
         def __init__(self, args, *pos, mask_1hop=None, mask_2hop=None, **kwargs):
@@ -113,4 +113,5 @@ GCNDelete = _with_deletion(GCN)
 GATDelete = _with_deletion(GAT)
 GINDelete = _with_deletion(GIN)
 RGCNDelete = _with_deletion(RGCN)
+RGATDelete = _with_deletion(RGAT)
 SAGEDelete = _with_deletion(SAGE)

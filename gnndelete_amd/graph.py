@@ -196,6 +196,7 @@ class TypedNodeCSR:
         self.n, self.num_relations = n, r
         run_f = dst * r + et
         order = torch.argsort(run_f * n + src)
+        self.fwd_order = order                                     # fwd edge k = input edge fwd_order[k]
         self.fwd, w_sorted = self._runs(run_f[order], src[order], r, n, None)
         w_edge = torch.empty_like(w_sorted)
         w_edge[order] = w_sorted                                   # weight of every edge in input order

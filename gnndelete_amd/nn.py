@@ -160,3 +160,73 @@ class RGCNConv(nn.Module):
 
 
 FastRGCNConv = RGCNConv
+
+
+class RGATConv(nn.Module):
+    """The reference's RGATConv (framework/models/rgat.py:24-351) in the configuration the reference builds
+    (rgat.py:361-366): heads = dim = 1, additive self-attention, softmax across relations, no `mod`, no edge
+    features.  Parameter names / shapes as upstream registers them (w, l1, b1, l2, b2 are only read by the `mod`
+    variants but are part of every checkpoint).
+
+    The attention logit of an edge (j -> i, r) is  leaky_relu(x_i W_r q + x_j W_r k) = A[i, r] + B[j, r]  with
+    A = x (W q)^T, B = x (W k)^T two [N, R] tables (one small GEMM each) instead of two per-edge transforms;
+    the aggregation  y_i = sum_e alpha_e x_j W_r  is the typed conv kernel with alpha as edge weights under
+    no_grad (evaluation), and a per-relation autograd loop otherwise (training runs on sampled subgraphs)."""
+
+    def __init__(self, in_channels, out_channels, num_relations, num_blocks=None, negative_slope=0.2):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_relations, self.num_blocks, self.negative_slope = num_relations, num_blocks, negative_slope
+        self.q = _glorot(out_channels, 1)
+        self.k = _glorot(out_channels, 1)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        if num_blocks is None:
+            self.weight = _glorot(num_relations, in_channels, out_channels)
+        else:
+            assert in_channels % num_blocks == 0 and out_channels % num_blocks == 0
+            self.weight = _glorot(num_relations, num_blocks, in_channels // num_blocks, out_channels // num_blocks)
+        self.w = nn.Parameter(torch.ones(out_channels))
+        self.l1 = nn.Parameter(torch.ones(1, out_channels))
+        self.b1 = nn.Parameter(torch.zeros(1, out_channels))
+        self.l2 = nn.Parameter(torch.full((out_channels, out_channels), 1.0 / out_channels))
+        self.b2 = nn.Parameter(torch.zeros(1, out_channels))
+        self._typed_nodes = None
+
+    def _typed_node_csr(self, edge_index, edge_type, n):
+        c = self._typed_nodes
+        if c is None or c[0] is not edge_index or c[1] is not edge_type or c[2] != n:
+            c = (edge_index, edge_type, n, TypedNodeCSR(edge_index, edge_type, n, self.num_relations))
+            self._typed_nodes = c
+        return c[3]
+
+    def _relation_vectors(self, v):
+        """W_r v for every relation: [R, in]."""
+        if self.num_blocks is None:
+            return (self.weight @ v).squeeze(-1)
+        vb = v.view(self.num_blocks, -1)
+        return torch.einsum('rbio,bo->rbi', self.weight, vb).reshape(self.num_relations, self.in_channels)
+
+    def forward(self, x, edge_index, edge_type):
+        n = x.shape[0]
+        src, dst, et = edge_index[0], edge_index[1], edge_type
+        a = x @ self._relation_vectors(self.q).t()                      # [N, R]
+        b = x @ self._relation_vectors(self.k).t()
+        e = F.leaky_relu(a[dst, et] + b[src, et], self.negative_slope)
+        m = torch.full((n,), float('-inf'), dtype=e.dtype, device=e.device).index_reduce_(0, dst, e.detach(), 'amax')
+        ex = torch.exp(e - m[dst])
+        alpha = ex / (torch.zeros(n, dtype=e.dtype, device=e.device).index_add_(0, dst, ex)[dst] + 1e-16)
+        nb = 1 if self.num_blocks is None else self.num_blocks
+        even = (self.in_channels // nb) % 2 == 0 and (self.out_channels // nb) % 2 == 0
+        if not torch.is_grad_enabled() and even and self.in_channels <= 128 and self.out_channels <= 128:
+            tg = self._typed_node_csr(edge_index, edge_type, n)
+            return ops.rgat_aggregate_nograd(x, tg, alpha, self.weight, self.bias, nb, self.out_channels)
+        out = torch.zeros(n, self.out_channels, dtype=x.dtype, device=x.device)
+        for r in torch.unique(et).tolist():
+            sel = (et == r).nonzero().flatten()
+            xj = x[src[sel]]
+            if self.num_blocks is None:
+                msg = xj @ self.weight[r]
+            else:
+                msg = torch.einsum('ebi,bio->ebo', xj.view(sel.numel(), nb, -1), self.weight[r]).reshape(sel.numel(), -1)
+            out = out.index_add(0, dst[sel], alpha[sel, None] * msg)
+        return out + self.bias

@@ -335,6 +335,23 @@ class _RgcnConvFrozen(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+def rgat_aggregate_nograd(x, tg, alpha, weight, bias, n_blocks, out_dim):
+    """y_i = sum_e alpha_e (x_j W_r) + bias for RGATConv under no_grad: the typed conv kernel with the attention
+    coefficients as per-edge weights (alpha in input edge order)."""
+    x = _f32_rows(x)
+    n = x.shape[0]
+    y = (bias.detach().to(torch.float32).expand(n, out_dim).contiguous() if bias is not None
+         else torch.zeros(n, out_dim, dtype=torch.float32, device=x.device))
+    node_ptr, seg_ptr, seg_rel, col, _ = tg.fwd
+    if col.numel():
+        w = alpha.detach().to(torch.float32)[tg.fwd_order].contiguous()
+        weight = weight.detach().contiguous()
+        check(_lib.lib().gd_rgcn_conv_f32(ptr(node_ptr), ptr(seg_ptr), ptr(seg_rel), ptr(col), ptr(w), ptr(x),
+                                          x.stride(0), x.shape[1], ptr(weight), n_blocks, 0, ptr(y), y.stride(0),
+                                          out_dim, n, stream_ptr(x.device)), 'gd_rgcn_conv_f32')
+    return y
+
+
 def rgcn_conv_frozen(x, tg, weight, root, bias, n_blocks):
     return _RgcnConvFrozen.apply(x, tg, weight, root, bias, n_blocks)
 

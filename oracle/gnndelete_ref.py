@@ -68,16 +68,20 @@ def _make_convs(gnn, in_dim, hidden, out_dim, num_edge_type=None):
         nb = 4 if num_edge_type > 20 else None          # rgcn.py:17-22
         return (pyg.RGCNConv(in_dim, hidden, 2 * num_edge_type, nb),
                 pyg.RGCNConv(hidden, out_dim, 2 * num_edge_type, nb))
+    if gnn == 'rgat':
+        nb = 4 if num_edge_type > 20 else None          # rgat.py:361-366
+        return (pyg.RGATConv(in_dim, hidden, 2 * num_edge_type, nb),
+                pyg.RGATConv(hidden, out_dim, 2 * num_edge_type, nb))
     raise NotImplementedError(gnn)
 
 
 class TwoLayer(nn.Module):
-    """The reference's 2-layer backbones; ``gnn`` in {gcn, gat, gin, rgcn}."""
+    """The reference's 2-layer backbones; ``gnn`` in {gcn, gat, gin, rgcn, rgat} (+ sage)."""
 
     def __init__(self, gnn, in_dim, hidden, out_dim, num_nodes=None, num_edge_type=None):
         super().__init__()
         self.gnn = gnn
-        self.relational = gnn == 'rgcn'
+        self.relational = gnn in ('rgcn', 'rgat')
         if self.relational:
             self.num_edge_type = num_edge_type
             self.node_emb = nn.Embedding(num_nodes, in_dim)

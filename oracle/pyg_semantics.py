@@ -176,6 +176,31 @@ def rgcn_conv(x, edge_index, edge_type, weight, root, bias, num_blocks=None):
     return out + bias if bias is not None else out
 
 
+def rgat_conv(x, edge_index, edge_type, weight, q, k, bias, num_blocks=None, negative_slope=0.2):
+    """The reference's RGATConv (framework/models/rgat.py:24-351, itself torch_geometric's) in the only
+    configuration the reference instantiates (rgat.py:361-366): heads = dim = 1, additive self-attention,
+    across-relation softmax, mod = None, no edge features.  Per edge e = (j -> i, type r):
+        out_i = x_i W_r, out_j = x_j W_r  (W_r dense [in,out] or block-diagonal [nb, in/nb, out/nb], :188-206)
+        alpha_e = softmax over ALL in-edges of i of leaky_relu(out_i q + out_j k)   (:208, :226-241)
+        y_i = sum_e alpha_e out_j + bias                                            (:322-323, :330-337)"""
+    n = x.shape[0]
+    src, dst = edge_index[0], edge_index[1]
+    if num_blocks is not None:
+        w = weight[edge_type]                                           # [E, nb, in/nb, out/nb]
+        xi = x[dst].view(-1, num_blocks, w.shape[2])
+        xj = x[src].view(-1, num_blocks, w.shape[2])
+        outi = torch.einsum('ebi,ebio->ebo', xi, w).reshape(src.shape[0], -1)
+        outj = torch.einsum('ebi,ebio->ebo', xj, w).reshape(src.shape[0], -1)
+    else:
+        w = weight[edge_type]                                           # [E, in, out]
+        outi = torch.bmm(x[dst].unsqueeze(1), w).squeeze(1)
+        outj = torch.bmm(x[src].unsqueeze(1), w).squeeze(1)
+    e = F.leaky_relu((outi @ q + outj @ k).squeeze(-1), negative_slope)
+    alpha = segment_softmax(e, dst, n)
+    out = scatter_rows(alpha[:, None] * outj, dst, n)
+    return out + bias if bias is not None else out
+
+
 # ----------------------------------------------------------------------------
 # nn.Module wrappers with PyG's parameter names (state_dict keys are part of the
 # checkpoint contract: delete_gnn.py:206-207 loads model_best.pt with strict=False)
@@ -258,3 +283,28 @@ class RGCNConv(nn.Module):
 
 
 FastRGCNConv = RGCNConv
+
+
+class RGATConv(nn.Module):
+    """keys as the reference's RGATConv registers them (rgat.py:96-149): q, k [out,1], bias [out], weight
+    [R,in,out] or [R,nb,in/nb,out/nb], and w, l1, b1, l2, b2, which only the `mod` variants read."""
+    def __init__(self, in_dim, out_dim, num_relations, num_blocks=None, negative_slope=0.2):
+        super().__init__()
+        self.num_blocks, self.negative_slope = num_blocks, negative_slope
+        self.q = nn.Parameter(glorot_(torch.empty(out_dim, 1)))
+        self.k = nn.Parameter(glorot_(torch.empty(out_dim, 1)))
+        self.bias = nn.Parameter(torch.zeros(out_dim))
+        if num_blocks is None:
+            self.weight = nn.Parameter(glorot_(torch.empty(num_relations, in_dim, out_dim)))
+        else:
+            self.weight = nn.Parameter(glorot_(torch.empty(
+                num_relations, num_blocks, in_dim // num_blocks, out_dim // num_blocks)))
+        self.w = nn.Parameter(torch.ones(out_dim))
+        self.l1 = nn.Parameter(torch.ones(1, out_dim))
+        self.b1 = nn.Parameter(torch.zeros(1, out_dim))
+        self.l2 = nn.Parameter(torch.full((out_dim, out_dim), 1.0 / out_dim))
+        self.b2 = nn.Parameter(torch.zeros(1, out_dim))
+
+    def forward(self, x, edge_index, edge_type):
+        return rgat_conv(x, edge_index, edge_type, self.weight, self.q, self.k, self.bias, self.num_blocks,
+                         self.negative_slope)

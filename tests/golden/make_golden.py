@@ -112,16 +112,53 @@ class FakeDataset:
         return 'SynthDataset()'
 
 
+class _MessagePassing(nn.Module):
+    """Just enough of torch_geometric's MessagePassing for the reference's own RGATConv (rgat.py:24-351) to
+    run: gather x_i / x_j along the edges (flow source -> target), call message(), sum per target, update()."""
+
+    def __init__(self, aggr='add', node_dim=0, **kwargs):
+        super().__init__()
+        assert aggr == 'add' and node_dim == 0
+
+    def propagate(self, edge_index, size=None, **kwargs):
+        x = kwargs['x']
+        src, dst = edge_index[0], edge_index[1]
+        msg = self.message(x_i=x[dst], x_j=x[src], edge_type=kwargs.get('edge_type'), edge_attr=kwargs.get('edge_attr'),
+                           index=dst, ptr=None, size_i=x.shape[0])
+        out = torch.zeros((x.shape[0],) + tuple(msg.shape[1:]), dtype=msg.dtype)
+        out.index_add_(0, dst, msg)
+        return self.update(out)
+
+
+def _pyg_softmax(src, index, ptr=None, num_nodes=None):
+    n = int(num_nodes) if num_nodes is not None else int(index.max()) + 1
+    flat = src.reshape(src.shape[0], -1)
+    cols = [pyg.segment_softmax(flat[:, c], index, n) for c in range(flat.shape[1])]
+    return torch.stack(cols, 1).reshape(src.shape)
+
+
+def _glorot(t):
+    if t is not None:
+        pyg.glorot_(t.data)
+
+
+def _fill(v):
+    def f(t):
+        if t is not None:
+            t.data.fill_(v)
+    return f
+
+
 def install_stubs():
     _mod('torch_geometric')
     _mod('torch_geometric.nn', GCNConv=pyg.GCNConv, GATConv=pyg.GATConv, GINConv=pyg.GINConv,
          RGCNConv=pyg.RGCNConv, FastRGCNConv=pyg.RGCNConv)
-    _mod('torch_geometric.nn.conv', MessagePassing=nn.Module)
+    _mod('torch_geometric.nn.conv', MessagePassing=_MessagePassing)
     _mod('torch_geometric.nn.dense')
     _mod('torch_geometric.nn.dense.linear', Linear=nn.Linear)
-    _mod('torch_geometric.nn.inits', glorot=None, ones=None, zeros=None)
+    _mod('torch_geometric.nn.inits', glorot=_glorot, ones=_fill(1.0), zeros=_fill(0.0))
     _mod('torch_geometric.typing', Adj=object, OptTensor=object, Size=object, OptPairTensor=object)
-    _mod('torch_geometric.utils', softmax=None, negative_sampling=_neg_stub, k_hop_subgraph=_khop_stub,
+    _mod('torch_geometric.utils', softmax=_pyg_softmax, negative_sampling=_neg_stub, k_hop_subgraph=_khop_stub,
          to_undirected=_to_undirected_stub, is_undirected=_is_undirected_stub, to_networkx=None)
     _mod('torch_geometric.loader', GraphSAINTRandomWalkSampler=None)
     _mod('torch_geometric.data', DataLoader=None, Data=Bag)
@@ -505,6 +542,44 @@ def golden_nodecls_trajectory(D, T, A):
     np.savez_compressed(os.path.join(HERE, 'traj_nodecls_gat.npz'), **out)
 
 
+def golden_rgat(D, A):
+    """The reference's own RGAT / RGATConv / RGATDelete (framework/models/rgat.py, deletion.py:165-193) under a
+    minimal MessagePassing: dense relation weights (3 relation types) and the block-diagonal branch the
+    reference takes above 20 types (rgat.py:361-363)."""
+    rgat_mod = importlib.import_module('framework.models.rgat')
+    for tag, R, hidden, out_dim in [('dense', 3, 32, 16), ('blocks', 21, 32, 16)]:
+        g = synth_graph(60, 220, 12, seed=14 + R, relations=R)
+        E = g['train']
+        ei = torch.cat([E, E.flip(0)], 1)
+        et = torch.cat([g['train_type'], g['train_type'] + R])
+        args = make_args(A, ['--gnn', 'rgat', '--dataset', 'WordNet18', '--in_dim', '12', '--hidden_dim', str(hidden),
+                             '--out_dim', str(out_dim)])
+        m1 = torch.rand(60, generator=torch.Generator().manual_seed(3)) < 0.4
+        m2 = torch.rand(60, generator=torch.Generator().manual_seed(4)) < 0.7
+        torch.manual_seed(8)
+        model = D.RGATDelete(args, 60, R, m1, m2)
+        with torch.no_grad():
+            for n_, p in model.named_parameters():
+                if n_.endswith('bias'):
+                    p.copy_(torch.randn_like(p) * 0.1)
+                if 'deletion_weight' in n_:
+                    p.copy_(torch.eye(p.shape[0]) * 0.5 + torch.randn_like(p) * 0.05)
+                if n_.endswith('.l2'):
+                    p.zero_()                       # upstream never initialises l2 (rgat.py:165): unused, keep it finite
+        x = torch.arange(60)
+        z1, z2 = model(x, ei, et, return_all_emb=True)
+        o1, o2 = model.get_original_embeddings(x, ei, et, return_all_emb=True)
+        score = model.decode(z2, E, g['train_type'])
+        loss = (z2 ** 2).mean() + (z1 ** 2).mean()
+        loss.backward()
+        out = dict(state_np(model))
+        out.update(edge_index=np_(ei), edge_type=np_(et), x=np_(x), dec_edge=np_(E), dec_type=np_(g['train_type']),
+                   score=np_(score), num_edge_type=np.int64(R), mask1=np_(m1), mask2=np_(m2), z1=np_(z1), z2=np_(z2),
+                   o1=np_(o1), o2=np_(o2), gw1=np_(model.deletion1.deletion_weight.grad),
+                   gw2=np_(model.deletion2.deletion_weight.grad))
+        np.savez_compressed(os.path.join(HERE, f'wiring_rgat_{tag}.npz'), **out)
+
+
 def golden_gcn_layerwise_crash(D, T, A):
     """record that upstream GCNDelete + both_layerwise raises."""
     g = synth_graph(40, 120, 6, seed=31)
@@ -673,6 +748,9 @@ def main():
     if sys.argv[1:] == ['nodecls']:
         golden_nodecls_trajectory(D, T, A)
         return
+    if sys.argv[1:] == ['rgat']:
+        golden_rgat(D, A)
+        return
     golden_del_layer(D)
     golden_losses(T)
     golden_wiring(D, A)
@@ -680,6 +758,7 @@ def main():
     golden_edgeprob_trajectories(D, TE, A)
     golden_original_training(B, A)
     golden_nodecls_trajectory(D, T, A)
+    golden_rgat(D, A)
     crash = golden_gcn_layerwise_crash(D, T, A)
     golden_parse_args(A)
     golden_eval(D, T, A)

@@ -36,6 +36,8 @@ def test_factories_and_registry():
     a.unlearning_model, a.gnn = 'original', 'gat'
     assert type(get_model(a)).__name__ == 'GAT'
     a.gnn = 'rgat'
+    assert type(get_model(a, num_nodes=5, num_edge_type=3)).__name__ == 'RGAT'
+    a.gnn = 'gcn2'
     with pytest.raises(NotImplementedError):
         get_model(a)
     a.gnn, a.unlearning_model = 'gcn', 'graph_eraser'

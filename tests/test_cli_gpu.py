@@ -77,18 +77,19 @@ def test_cli_pipeline(tmp_path, gnn, method, loss_type):
     assert not torch.allclose(state['deletion2.deletion_weight'], torch.full_like(state['deletion2.deletion_weight'], 1e-3))
 
 
-def test_cli_pipeline_knowledge_graph(tmp_path, monkeypatch):
-    """R-GCN on a synthetic KG: original training, then Del training on random-walk batches."""
+@pytest.mark.parametrize('gnn', ['rgcn', 'rgat'])
+def test_cli_pipeline_knowledge_graph(tmp_path, monkeypatch, gnn):
+    """R-GCN / R-GAT on a synthetic KG: original training, then Del training on random-walk batches."""
     cwd = str(tmp_path)
     monkeypatch.setenv('GNNDELETE_FORCE_EPOCHS', '3')
     monkeypatch.setenv('GNNDELETE_FORCE_VALID_FREQ', '3')
     monkeypatch.setenv('GNNDELETE_FORCE_NUM_STEPS', '4')
     run([os.path.join(ROOT, 'prepare_dataset.py'), '--dataset', 'synth-kg-tiny', '--seeds', '42'], cwd)
-    common = ['--dataset', 'synth-kg-tiny', '--gnn', 'rgcn', '--random_seed', '42', '--in_dim', '32', '--hidden_dim', '32',
+    common = ['--dataset', 'synth-kg-tiny', '--gnn', gnn, '--random_seed', '42', '--in_dim', '32', '--hidden_dim', '32',
               '--out_dim', '16']
     run([os.path.join(ROOT, 'train_gnn.py')] + common, cwd)
     run([os.path.join(ROOT, 'delete_gnn.py')] + common + ['--unlearning_model', 'gnndelete', '--df', 'in', '--df_size', '5'], cwd)
-    out = os.path.join(cwd, 'checkpoint', 'synth-kg-tiny', 'rgcn', 'gnndelete', 'mse_mean-both_layerwise-0.5-non_connected',
+    out = os.path.join(cwd, 'checkpoint', 'synth-kg-tiny', gnn, 'gnndelete', 'mse_mean-both_layerwise-0.5-non_connected',
                        'in-5.0-42')
     with open(os.path.join(out, 'trainer_log.json')) as f:
         log = json.load(f)

@@ -43,6 +43,30 @@ def test_rgcn_delete_matches_reference_golden():
     assert rel_l2(s.detach().cpu(), rest['score']) < TOL
 
 
+@pytest.mark.parametrize('tag', ['dense', 'blocks'])
+def test_rgat_delete_matches_reference_golden(tag):
+    """RGATConv on the HIP side (attention logits from two [N, R] tables, typed conv kernel with alpha as edge
+    weights under no_grad, per-relation autograd loop otherwise) against the reference's own RGAT code."""
+    fx = load_golden(f'wiring_rgat_{tag}.npz')
+    state, _, rest = split_fixture(fx)
+    r = int(rest['num_edge_type'])
+    m = hip_model('rgat', state, t(rest['mask1']), t(rest['mask2']), num_nodes=state['node_emb.weight'].shape[0],
+                  num_edge_type=r)
+    x, ei, et = t(rest['x']).cuda(), t(rest['edge_index']).cuda(), t(rest['edge_type']).cuda()
+    z1, z2 = m(x, ei, et, return_all_emb=True)
+    o1, o2 = m.get_original_embeddings(x, ei, et, return_all_emb=True)
+    for got, key in [(z1, 'z1'), (z2, 'z2'), (o1, 'o1'), (o2, 'o2')]:
+        assert rel_l2(got.detach().cpu(), rest[key]) < TOL, key
+    s = m.decode(z2, t(rest['dec_edge']).cuda(), t(rest['dec_type']).cuda())
+    assert rel_l2(s.detach().cpu(), rest['score']) < TOL
+    ((z2 ** 2).mean() + (z1 ** 2).mean()).backward()
+    assert rel_l2(m.deletion1.deletion_weight.grad.cpu(), rest['gw1']) < TOL
+    assert rel_l2(m.deletion2.deletion_weight.grad.cpu(), rest['gw2']) < TOL
+    with torch.no_grad():                                   # evaluation path: fused typed kernel
+        e1, e2 = m(x, ei, et, return_all_emb=True)
+    assert rel_l2(e1.cpu(), rest['z1']) < TOL and rel_l2(e2.cpu(), rest['z2']) < TOL
+
+
 @pytest.mark.parametrize('gnn', ['gcn', 'gat', 'gin'])
 def test_del_weight_gradients_match_oracle(gnn):
     fx = load_golden(f'wiring_{gnn}.npz')

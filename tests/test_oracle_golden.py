@@ -72,6 +72,28 @@ def test_rgcn_wiring_matches_reference():
     assert rel_l2(s.detach(), rest['score']) < TOL
 
 
+@pytest.mark.parametrize('tag', ['dense', 'blocks'])
+def test_rgat_wiring_matches_reference(tag):
+    """The reference's own RGATConv / RGAT / RGATDelete code (rgat.py, deletion.py:165-193) run under a minimal
+    MessagePassing vs the oracle's restatement of its default configuration: embeddings with and without Del,
+    DistMult scores and the Del-weight gradients; dense and block-diagonal relation weights."""
+    fx = load_golden(f'wiring_rgat_{tag}.npz')
+    state, _, rest = split_fixture(fx)
+    R_ = int(rest['num_edge_type'])
+    m = oracle_model('rgat', state, t(rest['mask1']), t(rest['mask2']),
+                     num_nodes=state['node_emb.weight'].shape[0], num_edge_type=R_)
+    x, ei, et = t(rest['x']), t(rest['edge_index']), t(rest['edge_type'])
+    z1, z2 = m(x, ei, et, return_all_emb=True)
+    o1, o2 = m.get_original_embeddings(x, ei, et, return_all_emb=True)
+    for got, key in [(z1, 'z1'), (z2, 'z2'), (o1, 'o1'), (o2, 'o2')]:
+        assert rel_l2(got.detach(), rest[key]) < TOL, key
+    s = m.decode(z2, t(rest['dec_edge']), t(rest['dec_type']))
+    assert rel_l2(s.detach(), rest['score']) < TOL
+    ((z2 ** 2).mean() + (z1 ** 2).mean()).backward()
+    assert rel_l2(m.deletion1.deletion_weight.grad, rest['gw1']) < TOL
+    assert rel_l2(m.deletion2.deletion_weight.grad, rest['gw2']) < TOL
+
+
 TRAJ = [('gat', 'both_layerwise'), ('gat', 'both_all'), ('gat', 'only2_layerwise'), ('gat', 'only2_all'),
         ('gat', 'only1'), ('gin', 'both_layerwise'), ('gcn', 'both_all'), ('gcn', 'only2_layerwise'),
         ('gcn', 'only1')]
