@@ -191,9 +191,9 @@ def cpu_baseline(args, data, model_state, neg, iters):
 
 def recorded_traffic(n, nnz, d):
     """HBM bytes per launch of the dominant kernel from the committed PMC run (separate rocprofv3
-    --pmc passes, gfx950 correction applied: profiles/r01_d_spmm_traffic.json); None when the
+    --pmc passes, gfx950 correction applied: profiles/r01_e_spmm_traffic.json); None when the
     workload differs from the one that was profiled."""
-    path = os.path.join(ROOT, 'profiles', 'r01_d_spmm_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_e_spmm_traffic.json')
     try:
         with open(path) as f:
             rec = json.load(f)
@@ -329,7 +329,7 @@ def main():
             'roofline': {'kernel': 'spmm_persist_kernel<32,1,true,true> (layer-1 CSR SpMM, d=128)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': recorded_traffic(data.num_nodes, eng.graph.nnz, 128) if world == 1 else None,
-                         'traffic_unit': 'bytes/launch (PMC, profiles/r01_d_spmm_traffic.json)', 'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6},
+                         'traffic_unit': 'bytes/launch (PMC, profiles/r01_e_spmm_traffic.json)', 'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6},
             'final_loss': float(losses[-1, 0]) if len(losses) else None,
         }
         if note:
