@@ -313,6 +313,7 @@ def main():
     if rank == 0:
         kdur, kbytes = time_dominant_kernel(eng)
         achieved = kbytes / kdur / 1e9
+        traffic = recorded_traffic(data.num_nodes, eng.graph.nnz, 128) if world == 1 else None
         out = {
             'metric': 'Del-op train iters/sec', 'value': units / dt, 'unit': 'iters/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
@@ -326,9 +327,12 @@ def main():
                        'S1': int(data.sdf_node_1hop_mask.sum()), 'S2': int(data.sdf_node_2hop_mask.sum()), 'hip_graph': not args.no_graph,
                        'parallelism': 'single' if world == 1 else (f'row-partition x{world} (RCCL halo all-to-all + all-reduce)'
                                                                   if partitioned else f'replicas x{world}')},
-            'roofline': {'kernel': 'spmm_persist_kernel<32,1,true,true> (layer-1 CSR SpMM, d=128)', 'bound': 'hbm',
+            'roofline': {'kernel': 'spmm_persist_kernel<32,1,4,true,true> (layer-1 CSR SpMM, d=128)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': recorded_traffic(data.num_nodes, eng.graph.nnz, 128) if world == 1 else None,
+                         'traffic': traffic,
+                         # the recorded L2-miss (fabric) bytes over this run's launch duration: how close the kernel
+                         # runs to the ~6.3 TB/s a streaming copy achieves on this part (MI355X_MICROARCH.md)
+                         'traffic_gbs': traffic / kdur / 1e9 if traffic else None,
                          'traffic_unit': 'bytes/launch (PMC, profiles/r01_e_spmm_traffic.json)', 'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6},
             'final_loss': float(losses[-1, 0]) if len(losses) else None,
         }

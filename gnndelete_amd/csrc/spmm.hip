@@ -103,7 +103,12 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(const int32_t* __restrict
 // ADDR32: byte offsets of x rows fit 32 bits and (row id, row pitch in bytes) fit 24 bits, so a row
 // address is ONE full-rate v_mul_u32_u24 instead of a 64-bit multiply (three quarter-rate integer
 // multiplies per gathered row made the kernel issue-bound, not memory-bound, once the rows hit in L2).
-template <int LPR, int VPL, bool EXACT, bool ADDR32>
+// Latency structure (what the kernel is actually bound by - a wave spends its life waiting on memory, so the
+// number of DEPENDENT round trips per visited row is the cost): the item descriptor is fetched two visits
+// ahead and the item's (col, val) one visit ahead, the self row is requested together with the gathers and the
+// bias lives in registers, so a row costs ONE round trip (its gathers) instead of three (descriptor -> indices,
+// gathers, then self / bias behind them).
+template <int LPR, int VPL, int U, bool EXACT, bool ADDR32>
 __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restrict__ items, int32_t n_items,
                                                            const int32_t* __restrict__ col,
                                                            const float* __restrict__ val,
@@ -113,97 +118,136 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
                                                            const float* __restrict__ xs,
                                                            float* __restrict__ scratch, int32_t d4, int32_t nnz) {
   constexpr int G = kWave / LPR;
-  constexpr int U = (kWave / G) >= 4 ? 4 : (kWave / G);
   constexpr int kXcd = 8;
   const int lane = threadIdx.x & 63;
   const int g = lane / LPR, li = lane % LPR;
   const int xcd = blockIdx.x % kXcd;
-  const int waves_per_xcd = (gridDim.x / kXcd) * 4;
+  const int stride = (gridDim.x / kXcd) * 4;                        // waves per XCD
   const int wx = (blockIdx.x / kXcd) * 4 + (threadIdx.x >> 6);
   const int per = (n_items + kXcd - 1) / kXcd;
   const int i0 = xcd * per, i1 = min(n_items, i0 + per);
   int i = i0 + wx;
   if (i >= i1) return;
 
+  // per-lane constants: byte offset of this lane's vectors inside a row, its slice of the bias
+  uint32_t lo[VPL];
+  float4 bv[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int vec = EXACT ? li + v * LPR : min(li + v * LPR, d4 - 1);
+    lo[v] = 16u * (uint32_t)vec;
+    bv[v] = bias ? reinterpret_cast<const float4*>(bias)[vec] : f4_zero();
+  }
   const uint32_t pitch_b = (uint32_t)ldx * 4u;
-  int4 desc = items[i];
-  int kk = min(desc.y + lane, nnz - 1);
+  const char* xb = reinterpret_cast<const char*>(x);
+
+  // Descriptors are wave-uniform: ONE lane fetches them (a 64-lane load of one address would still occupy the
+  // texture addresser like a full gather) and they are kept in SGPRs, so the trip structure and the
+  // epilogue's addressing are scalar work.
+  struct Desc { int row, start, end, slot; };
+  auto uniform = [](const int4& v) {
+    Desc d;
+    d.row = __builtin_amdgcn_readfirstlane(v.x);
+    d.start = __builtin_amdgcn_readfirstlane(v.y);
+    d.end = __builtin_amdgcn_readfirstlane(v.z);
+    d.slot = __builtin_amdgcn_readfirstlane(v.w);
+    return d;
+  };
+  int4 dv = make_int4(0, 0, 0, 0), dv1 = dv;
+  if (lane == 0) {
+    dv = items[i];
+    dv1 = items[min(i + stride, i1 - 1)];
+  }
+  Desc d0 = uniform(dv), d1 = uniform(dv1);
+  int kk = min(d0.start + lane, nnz - 1);
   int c = col[kk];
   float w = val ? val[kk] : 1.0f;
-  for (; i < i1; i += waves_per_xcd) {
-    const int row = desc.x, slot = desc.w;
-    // the descriptor is the same in every lane: keep the edge count in an SGPR so that the trip
-    // structure below is scalar control flow
-    const int cnt = __builtin_amdgcn_readfirstlane(desc.z - desc.y);
+  for (; i < i1; i += stride) {
+    const int row = d0.row, slot = d0.slot, cnt = d0.end - d0.start;
     const int c_cur = c;
     const float w_cur = lane < cnt ? w : 0.f;
-    // prefetch the next visit (clamped, branch-free)
-    desc = items[min(i + waves_per_xcd, i1 - 1)];
-    kk = min(desc.y + lane, nnz - 1);
+    // prefetch (clamped, branch-free): descriptor of the visit after next, indices of the next visit
+    if (lane == 0) dv = items[min(i + 2 * stride, i1 - 1)];
+    kk = min(d1.start + lane, nnz - 1);
     c = col[kk];
     w = val ? val[kk] : 1.0f;
+    const bool whole = slot < 0, self = whole && self_coef != 0.0f;
+    float4 sv[VPL];
+    if (self) {
+      const char* sb = reinterpret_cast<const char*>(xs + (int64_t)row * ldx);
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) sv[v] = *reinterpret_cast<const float4*>(sb + lo[v]);
+    }
 
     float4 acc[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
     const int trips = (cnt + G - 1) / G;
     // Slot j of the item (j = trip * G + g) is fetched from lane j of (c_cur, w_cur) through the LDS
-    // crossbar (byte-addressed ds_bpermute, everything kept pre-multiplied by 4).  The gathers are
-    // what this kernel is bound by - a wave64 x 16-byte load occupies the CU's texture addresser for
-    // 16 cycles whether or not its rows are useful - so a trip past the end of the item is skipped
-    // by a SCALAR branch (no load issued at all); only the last, partly filled trip pads: its extra
-    // lane groups re-read the item's last neighbour (cached) and take weight 0 from lane `cnt`.
+    // crossbar (byte-addressed ds_bpermute, everything kept pre-multiplied by 4).  A wave64 x 16-byte load
+    // occupies the CU's texture addresser for 16 cycles whether or not its rows are useful, so trips past
+    // the end of the item are never issued (scalar trip control); only the last, partly filled trip pads:
+    // its extra lane groups re-read the item's last neighbour (cached) and take weight 0 from lane `cnt`.
     const int last4 = 4 * cnt - 4, end4 = 4 * cnt;
-    for (int t0 = 0; t0 < trips; t0 += U) {
+    auto fetch = [&](int t, float4(&xv)[VPL], float& wj) {
+      const int j4 = 4 * (t * G) + 4 * g;
+      const int cs = __builtin_amdgcn_ds_bpermute(min(j4, last4), c_cur);
+      wj = __int_as_float(__builtin_amdgcn_ds_bpermute(min(j4, end4), __float_as_int(w_cur)));
+      if (ADDR32) {   // row byte offset by one full-rate 24-bit multiply, 32-bit offset on a scalar base
+        const uint32_t ro = __umul24((uint32_t)cs, pitch_b);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) xv[v] = *reinterpret_cast<const float4*>(xb + (ro + lo[v]));
+      } else {
+        const char* xr = reinterpret_cast<const char*>(x + (int64_t)cs * ldx);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) xv[v] = *reinterpret_cast<const float4*>(xr + lo[v]);
+      }
+    };
+    int t0 = 0;
+    for (; t0 + U <= trips; t0 += U) {
       float4 xv[U][VPL];
       float wj[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (t0 + u < trips) {
-          const int j4 = 4 * ((t0 + u) * G) + 4 * g;
-          const int cs = __builtin_amdgcn_ds_bpermute(min(j4, last4), c_cur);
-          wj[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(min(j4, end4), __float_as_int(w_cur)));
-          const float4* xr;
-          if (ADDR32)   // row byte offset by one full-rate 24-bit multiply
-            xr = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + __umul24((uint32_t)cs, pitch_b));
-          else
-            xr = reinterpret_cast<const float4*>(x + (int64_t)cs * ldx);
-#pragma unroll
-          for (int v = 0; v < VPL; ++v) {
-            const int vec = li + v * LPR;
-            xv[u][v] = EXACT ? xr[vec] : xr[min(vec, d4 - 1)];
-          }
-        } else {
-          wj[u] = 0.f;
-#pragma unroll
-          for (int v = 0; v < VPL; ++v) xv[u][v] = f4_zero();
-        }
-      }
+      for (int u = 0; u < U; ++u) fetch(t0 + u, xv[u], wj[u]);
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
     }
+    if (U > 1) {
+      const int rem = trips - t0;
+      if (rem > 0) {
+        float4 xv[U - 1 > 0 ? U - 1 : 1][VPL];
+        float wj[U - 1 > 0 ? U - 1 : 1];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+          if (u < rem) fetch(t0 + u, xv[u], wj[u]);
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+          if (u < rem) {
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
+          }
+      }
+    }
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_group_sum<LPR>(acc[v]);
     if (g == 0) {
+      char* ob = whole ? reinterpret_cast<char*>(y + (int64_t)row * ldy)
+                       : reinterpret_cast<char*>(scratch + (int64_t)slot * d4 * 4);
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
-        const int vec = li + v * LPR;
-        if (!EXACT && vec >= d4) continue;
+        if (!EXACT && li + v * LPR >= d4) continue;
         float4 o = acc[v];
-        if (slot < 0) {
-          if (self_coef != 0.0f) o = f4_fma(self_coef, reinterpret_cast<const float4*>(xs + (int64_t)row * ldx)[vec], o);
-          if (bias) o = f4_add(o, reinterpret_cast<const float4*>(bias)[vec]);
-          if (ADDR32)
-            reinterpret_cast<float4*>(reinterpret_cast<char*>(y) + __umul24((uint32_t)row, (uint32_t)ldy * 4u))[vec] = o;
-          else
-            reinterpret_cast<float4*>(y + (int64_t)row * ldy)[vec] = o;
-        } else {
-          reinterpret_cast<float4*>(scratch + (int64_t)slot * d4 * 4)[vec] = o;
+        if (whole) {
+          if (self) o = f4_fma(self_coef, sv[v], o);
+          if (bias) o = f4_add(o, bv[v]);
         }
+        *reinterpret_cast<float4*>(ob + lo[v]) = o;
       }
     }
+    d0 = d1;
+    d1 = uniform(dv);
   }
 }
 
@@ -354,11 +398,11 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   const int d4 = d / 4;
   const float* xs = x_self ? x_self : x;            // rows of the self / residual term (same pitch as x)
   GD_REQUIRE(aligned16(xs) && xs != y, GD_E_ALIGN, "gd_spmm_csr_balanced_f32: bad x_self");
-  // grid: a few visits per wave (4 x the resident set of 256 CUs x 8 blocks measured best), a
+  // grid: a few visits per wave (8 x the resident set of 256 CUs x 8 blocks measured best), a
   // multiple of the 8 XCDs
   int nblk = (n_items + 3) / 4;
   const char* cap_env = getenv("GD_SPMM_GRID_CAP");                 // tuning knob (blocks)
-  const int cap = cap_env ? atoi(cap_env) : 8192;
+  const int cap = cap_env ? atoi(cap_env) : 16384;
   if (nblk > cap) nblk = cap;
   nblk = (nblk + 7) / 8 * 8;
   const dim3 grid(nblk), block(256);
@@ -366,9 +410,9 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   // 24-bit fast addressing needs: row ids < 2^24, row pitches in bytes < 2^24, x and y smaller than 4 GiB
   const bool addr32 = x_rows > 0 && x_rows <= (1 << 24) && ldx * 4 < (1 << 24) && ldy * 4 < (1 << 24) &&
                       (int64_t)x_rows * ldx * 4 < (1ll << 32) && (int64_t)x_rows * ldy * 4 < (1ll << 32);
-#define GD_ITEMS_LAUNCH(LPR, VPL, EXACT, A32)                                                                      \
-  hipLaunchKernelGGL((spmm_persist_kernel<LPR, VPL, EXACT, A32>), grid, block, 0, s, it, n_items, col, val, x, ldx, \
-                     y, ldy, bias, self_coef, xs, scratch, d4, nnz)
+#define GD_ITEMS_LAUNCH(LPR, VPL, EXACT, A32)                                                                        \
+  hipLaunchKernelGGL((spmm_persist_kernel<LPR, VPL, ((64 / (64 / LPR)) >= 4 ? 4 : (64 / (64 / LPR))), EXACT, A32>), \
+                     grid, block, 0, s, it, n_items, col, val, x, ldx, y, ldy, bias, self_coef, xs, scratch, d4, nnz)
 #define GD_ITEMS_CASE(LPR, VPL)                                                                                    \
   do {                                                                                                             \
     if (d4 == LPR * VPL) {                                                                                         \
