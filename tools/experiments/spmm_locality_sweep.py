@@ -22,7 +22,7 @@ for W in WS:
     else:
         src = ei[0]
         off = torch.randint(-W, W + 1, src.shape, device='cuda', generator=g0)
-        dst = (src + off).clamp_(0, n - 1)
+        dst = (src + off) % n            # wrap (clamping would pile the ends up into two mega-hubs)
         e = torch.stack([src, dst])
     g = build_csr(e.contiguous(), n, 'gcn')
     for _ in range(5): ops._spmm_raw(g.rowptr, g.col, g.val, x, None, 0.0, n, g.plan, out=y)
