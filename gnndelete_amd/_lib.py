@@ -7,7 +7,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libgnndelete_hip.so')
+# GNNDELETE_HIP_LIB points at another build of the same ABI (A/B measurements); there is still no fallback
+LIB_PATH = os.environ.get('GNNDELETE_HIP_LIB') or os.path.join(_HERE, 'lib', 'libgnndelete_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'gnndelete_hip.h')
 
 _i32, _i64, _f32, _f64, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
@@ -16,6 +17,8 @@ _i32, _i64, _f32, _f64, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, cty
 PROTOTYPES = {
     'gd_abi_version': (ctypes.c_int, []),
     'gd_last_error_string': (ctypes.c_char_p, []),
+    'gd_csr_from_coo_workspace': (_i64, [_i32, _i64]),
+    'gd_csr_from_coo': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i64, _p]),
     'gd_gcn_norm_f32': (ctypes.c_int, [_p, _p, _i32, _p, _p]),
     'gd_spmm_csr_f32': (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _f32, _i32, _i32, _p]),
     'gd_spmm_csr_balanced_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _f32, _p, _p, _i32,

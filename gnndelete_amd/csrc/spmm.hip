@@ -105,9 +105,10 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(const int32_t* __restrict
 // multiplies per gathered row made the kernel issue-bound, not memory-bound, once the rows hit in L2).
 // Latency structure (what the kernel is actually bound by - a wave spends its life waiting on memory, so the
 // number of DEPENDENT round trips per visited row is the cost): the item descriptor is fetched two visits
-// ahead and the item's (col, val) one visit ahead, the self row is requested together with the gathers and the
-// bias lives in registers, so a row costs ONE round trip (its gathers) instead of three (descriptor -> indices,
-// gathers, then self / bias behind them).
+// ahead and the item's (col, val) one visit ahead and the bias is requested together with the gathers (as the
+// accumulators' initial value), so a GCN row costs ONE round trip (its gathers) instead of three (descriptor ->
+// indices, gathers, then the bias behind them); only a self / residual row (GIN, GraphSAGE) is still fetched
+// in the epilogue - holding it across the gathers costs the registers that decide 8 vs 7 waves per SIMD.
 template <int LPR, int VPL, int U, bool EXACT, bool ADDR32>
 __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restrict__ items, int32_t n_items,
                                                            const int32_t* __restrict__ col,
@@ -131,13 +132,9 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
 
   // per-lane constants: byte offset of this lane's vectors inside a row, its slice of the bias
   uint32_t lo[VPL];
-  float4 bv[VPL];
 #pragma unroll
-  for (int v = 0; v < VPL; ++v) {
-    const int vec = EXACT ? li + v * LPR : min(li + v * LPR, d4 - 1);
-    lo[v] = 16u * (uint32_t)vec;
-    bv[v] = bias ? reinterpret_cast<const float4*>(bias)[vec] : f4_zero();
-  }
+  for (int v = 0; v < VPL; ++v) lo[v] = 16u * (uint32_t)(EXACT ? li + v * LPR : min(li + v * LPR, d4 - 1));
+  const char* bb = reinterpret_cast<const char*>(bias);
   const uint32_t pitch_b = (uint32_t)ldx * 4u;
   const char* xb = reinterpret_cast<const char*>(x);
 
@@ -172,16 +169,15 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
     c = col[kk];
     w = val ? val[kk] : 1.0f;
     const bool whole = slot < 0, self = whole && self_coef != 0.0f;
-    float4 sv[VPL];
-    if (self) {
-      const char* sb = reinterpret_cast<const char*>(xs + (int64_t)row * ldx);
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) sv[v] = *reinterpret_cast<const float4*>(sb + lo[v]);
-    }
-
+    // the accumulators of lane group 0 start from the bias (requested with the gathers: no round trip of its
+    // own, no registers held across rows); the pieces of a split row get theirs in the fix-up
     float4 acc[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
+    if (bias && whole && g == 0) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) acc[v] = *reinterpret_cast<const float4*>(bb + lo[v]);
+    }
     const int trips = (cnt + G - 1) / G;
     // Slot j of the item (j = trip * G + g) is fetched from lane j of (c_cur, w_cur) through the LDS
     // crossbar (byte-addressed ds_bpermute, everything kept pre-multiplied by 4).  A wave64 x 16-byte load
@@ -235,14 +231,12 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
     if (g == 0) {
       char* ob = whole ? reinterpret_cast<char*>(y + (int64_t)row * ldy)
                        : reinterpret_cast<char*>(scratch + (int64_t)slot * d4 * 4);
+      const char* sb = reinterpret_cast<const char*>(xs + (int64_t)row * ldx);
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
         if (!EXACT && li + v * LPR >= d4) continue;
         float4 o = acc[v];
-        if (whole) {
-          if (self) o = f4_fma(self_coef, sv[v], o);
-          if (bias) o = f4_add(o, bv[v]);
-        }
+        if (self) o = f4_fma(self_coef, *reinterpret_cast<const float4*>(sb + lo[v]), o);
         *reinterpret_cast<float4*>(ob + lo[v]) = o;
       }
     }
@@ -398,11 +392,11 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   const int d4 = d / 4;
   const float* xs = x_self ? x_self : x;            // rows of the self / residual term (same pitch as x)
   GD_REQUIRE(aligned16(xs) && xs != y, GD_E_ALIGN, "gd_spmm_csr_balanced_f32: bad x_self");
-  // grid: a few visits per wave (8 x the resident set of 256 CUs x 8 blocks measured best), a
+  // grid: a few visits per wave (4 x the resident set of 256 CUs x 8 blocks measured best), a
   // multiple of the 8 XCDs
   int nblk = (n_items + 3) / 4;
   const char* cap_env = getenv("GD_SPMM_GRID_CAP");                 // tuning knob (blocks)
-  const int cap = cap_env ? atoi(cap_env) : 16384;
+  const int cap = cap_env ? atoi(cap_env) : 8192;
   if (nblk > cap) nblk = cap;
   nblk = (nblk + 7) / 8 * 8;
   const dim3 grid(nblk), block(256);

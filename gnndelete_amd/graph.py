@@ -81,7 +81,31 @@ class CSRGraph:
         return self.col.device
 
 
+def csr_from_coo(src, dst, n):
+    """gd_csr_from_coo on device tensors: -> (rowptr int32 [n+1], col int32 [E], order int32 [E])."""
+    src, dst = src.long().contiguous(), dst.long().contiguous()
+    dev, e = src.device, int(src.numel())
+    L = _lib.lib()
+    nbytes = int(L.gd_csr_from_coo_workspace(n, e))
+    if nbytes < 0:
+        raise ValueError('graph too large for int32 CSR indices')
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(e, dtype=torch.int32, device=dev)
+    order = torch.empty(e, dtype=torch.int32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.check(L.gd_csr_from_coo(_lib.ptr(src), _lib.ptr(dst), e, n, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(order),
+                                 _lib.ptr(status), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev)), 'gd_csr_from_coo')
+    if int(status):
+        raise IndexError(f'edge_index has endpoints outside [0, {n})')
+    return rowptr, col, order
+
+
 def _sorted_csr(src, dst, n):
+    if src.is_cuda:
+        rowptr, col, order = csr_from_coo(src, dst, n)
+        return rowptr, col, order.long()
+    # host-side layout only (CPU tests of the partition plan); no compute runs on these
     key = dst * n + src
     order = torch.argsort(key)
     counts = torch.bincount(dst, minlength=n)

@@ -44,6 +44,21 @@ const char* gd_last_error_string(void);
 
 /* ---------------------------------------------------------------- message passing ----- */
 
+/* COO -> CSR over TARGET rows, sources of a row ascending, multi-edges kept, ties in input order (stable).
+ *   src, dst  [n_edges] int64 device arrays: the two rows of the reference's edge_index (flow source -> target)
+ *   rowptr    [n_nodes + 1], col [n_edges] int32 out;  order [n_edges] int32 out or NULL: input position of
+ *             the edge stored in CSR slot k
+ *   status    device int32 out: 0, or 1 if any endpoint was outside [0, n_nodes) (outputs then undefined;
+ *             the caller reads it when it next synchronises - no host sync in here)
+ *   workspace >= gd_csr_from_coo_workspace(n_nodes, n_edges) bytes, 256-byte aligned
+ * Replaces what torch_geometric re-derives from edge_index inside every conv call (framework/models/gcn.py:16-22,
+ * gat.py:16-22, gin.py:26-34) and the sort + coalesce of to_undirected in the Df preprocessing
+ * (delete_gnn.py:175-182).  Integer only: bit-exact, independent of the order the edges arrive in. */
+int64_t gd_csr_from_coo_workspace(int32_t n_nodes, int64_t n_edges);
+int gd_csr_from_coo(const int64_t* src, const int64_t* dst, int64_t n_edges, int32_t n_nodes, int32_t* rowptr,
+                    int32_t* col, int32_t* order, int32_t* status, void* workspace, int64_t workspace_bytes,
+                    void* stream);
+
 /* GCN symmetric normalisation on a CSR that already contains exactly one self loop per node:
  *   val[k] = deg[i]^-1/2 * deg[col[k]]^-1/2,  deg[i] = rowptr[i+1]-rowptr[i]  (k in row i)
  * Replaces torch_geometric gcn_norm inside GCNConv.forward (framework/models/gcn.py:16,19). */

@@ -549,3 +549,44 @@ def test_del_loss_bwd_fused_matches_separate_steps(n, d, frac, loss_frac):
     assert rel_l2(dp.cpu(), dp_want) < TOL or float(dp_want.abs().max()) == 0
     got_s = parts.view(-1, 2).double().sum(0).cpu()
     np.testing.assert_allclose(got_s.numpy(), want_s, rtol=1e-5, atol=1e-7)
+
+
+def _csr_reference(src, dst, n):
+    """numpy restatement: rows = targets, sources ascending, ties in input order (stable)."""
+    key = dst.astype(np.int64) * n + src.astype(np.int64)
+    order = np.argsort(key, kind='stable')
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, dst + 1, 1)
+    return np.cumsum(rowptr), src[order], order
+
+
+@pytest.mark.parametrize('n,m', [(1, 0), (1, 5), (7, 0), (50, 400), (1000, 20000), (235868, 2000000)])
+def test_csr_from_coo_is_bit_exact(n, m):
+    """gd_csr_from_coo (P1 layout step) against a stable numpy sort: multi-edges, self loops, isolated
+    rows, both arrival orders give the same CSR."""
+    from gnndelete_amd.graph import csr_from_coo
+    rng = np.random.default_rng(n + m)
+    src = rng.integers(0, n, m)
+    dst = rng.integers(0, max(1, n - n // 5), m)          # the last fifth of the rows stays empty
+    if m >= 100:
+        src[:50], dst[:50] = src[50:100], dst[50:100]      # duplicates
+    rp, col, order = csr_from_coo(torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda(), n)
+    want_rp, want_col, want_order = _csr_reference(src, dst, n)
+    assert rp.dtype == col.dtype == order.dtype == torch.int32
+    assert np.array_equal(rp.cpu().numpy(), want_rp)
+    assert np.array_equal(col.cpu().numpy(), want_col)
+    assert np.array_equal(order.cpu().numpy(), want_order)
+    if m:
+        perm = rng.permutation(m)                          # arrival order must not matter for (rowptr, col)
+        rp2, col2, _ = csr_from_coo(torch.from_numpy(src[perm]).cuda(), torch.from_numpy(dst[perm]).cuda(), n)
+        assert torch.equal(rp2, rp) and torch.equal(col2, col)
+
+
+def test_csr_from_coo_rejects_out_of_range_endpoints():
+    from gnndelete_amd.graph import csr_from_coo
+    src = torch.tensor([0, 1, 9], device='cuda')
+    dst = torch.tensor([1, 2, 0], device='cuda')
+    with pytest.raises(IndexError):
+        csr_from_coo(src, dst, 5)
+    with pytest.raises(IndexError):
+        csr_from_coo(torch.tensor([0, -1], device='cuda'), torch.tensor([1, 2], device='cuda'), 5)
