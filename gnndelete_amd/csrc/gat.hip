@@ -203,8 +203,14 @@ __global__ __launch_bounds__(256) void gat_bwd_col_kernel(const int32_t* __restr
 // (m_p = max score, s_p = sum exp(e - m_p), acc_p = sum exp(e - m_p) h_j); pieces of one row are
 // merged flash-attention style:  M = max m_p,  S = sum s_p e^(m_p-M),  y = sum acc_p e^(m_p-M) / S.
 // The row statistics (M, S) are all the backward needs to rebuild the attention weights.
-template <int LPR, int VPL, bool EXACT>
-__global__ __launch_bounds__(256) void gat_items_fwd_kernel(
+// Latency structure as in spmm.hip: a wave's cost per visited item is the number of DEPENDENT round trips.
+// Descriptors are fetched two visits ahead (by one lane, kept in SGPRs) and the item's column indices one visit
+// ahead; the gathers of the first batch need only those indices, so they are ISSUED before the attention logits
+// a_src[col] / a_dst[row] are waited for, and the local softmax (max, exp, sum) is computed while the rows are
+// in flight; the bias is requested with the gathers.  One round trip per item (was: descriptor -> indices ->
+// logits -> gathers -> bias).
+template <int LPR, int VPL, bool EXACT, bool ADDR32>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 1 ? ((ADDR32 || LPR >= 16) ? 8 : 7) : 2))) void gat_items_fwd_kernel(
     const int4* __restrict__ items, int32_t n_items, const int32_t* __restrict__ col,
     const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ h, int64_t ldh,
     float* __restrict__ y, int64_t ldy, const float* __restrict__ bias, float* __restrict__ rowmax,
@@ -216,82 +222,145 @@ __global__ __launch_bounds__(256) void gat_items_fwd_kernel(
   const int lane = threadIdx.x & 63;
   const int g = lane / LPR, li = lane % LPR;
   const int xcd = blockIdx.x % kXcd;
-  const int waves_per_xcd = (gridDim.x / kXcd) * 4;
+  const int stride = (gridDim.x / kXcd) * 4;                        // waves per XCD
   const int wx = (blockIdx.x / kXcd) * 4 + (threadIdx.x >> 6);
   const int per = (n_items + kXcd - 1) / kXcd;
   const int i0 = xcd * per, i1 = min(n_items, i0 + per);
   int i = i0 + wx;
   if (i >= i1) return;
 
-  int4 desc = items[i];
-  int c = col[min(desc.y + lane, nnz - 1)];
-  for (; i < i1; i += waves_per_xcd) {
-    const int row = desc.x, slot = desc.w;
-    const int cnt = __builtin_amdgcn_readfirstlane(desc.z - desc.y);   // same in every lane: scalar trip control
-    const int c_cur = c;
-    desc = items[min(i + waves_per_xcd, i1 - 1)];
-    c = col[min(desc.y + lane, nnz - 1)];
+  uint32_t lo[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) lo[v] = 16u * (uint32_t)(EXACT ? li + v * LPR : min(li + v * LPR, d4 - 1));
+  const char* bb = reinterpret_cast<const char*>(bias);
+  const char* hb = reinterpret_cast<const char*>(h);
+  const uint32_t pitch_b = (uint32_t)ldh * 4u;
 
-    const float e = lane < cnt ? leaky(a_src[c_cur] + a_dst[row], slope) : -INFINITY;
-    const float m = wave_max(e);
-    const float p_cur = lane < cnt ? expf(e - m) : 0.f;
-    const float ssum = wave_sum(p_cur);
+  struct Desc { int row, start, end, slot; };
+  auto uniform = [](const int4& v) {
+    Desc d;
+    d.row = __builtin_amdgcn_readfirstlane(v.x);
+    d.start = __builtin_amdgcn_readfirstlane(v.y);
+    d.end = __builtin_amdgcn_readfirstlane(v.z);
+    d.slot = __builtin_amdgcn_readfirstlane(v.w);
+    return d;
+  };
+  int4 dv = make_int4(0, 0, 0, 0), dv1 = dv;
+  if (lane == 0) {
+    dv = items[i];
+    dv1 = items[min(i + stride, i1 - 1)];
+  }
+  Desc d0 = uniform(dv), d1 = uniform(dv1);
+  int c = col[min(d0.start + lane, nnz - 1)];
+  for (; i < i1; i += stride) {
+    const int row = d0.row, slot = d0.slot, cnt = d0.end - d0.start;
+    const bool whole = slot < 0;
+    const int c_cur = c;
+    // ---- prefetch: descriptor of the visit after next, indices of the next visit
+    if (lane == 0) dv = items[min(i + 2 * stride, i1 - 1)];
+    c = col[min(d1.start + lane, nnz - 1)];
+    // ---- this item's logits (lanes past its end never load), requested now, consumed behind the gathers
+    float as = 0.f;
+    if (lane < cnt) as = a_src[c_cur];
+    const float ad = a_dst[row];
 
     float4 acc[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
+    const bool with_bias = bias && whole && g == 0;
+    if (with_bias) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) acc[v] = *reinterpret_cast<const float4*>(bb + lo[v]);
+    }
     const int trips = (cnt + G - 1) / G;
     // as in the SpMM (spmm.hip): whole trips past the end issue no gather (scalar branch); the last,
     // partly filled trip re-reads the item's last neighbour with the weight of lane `cnt` (zero)
     const int last4 = 4 * cnt - 4, end4 = 4 * cnt;
-    for (int t0 = 0; t0 < trips; t0 += U) {
+    auto gather = [&](int t, float4(&xv)[VPL]) {
+      const int j4 = 4 * (t * G) + 4 * g;
+      const int cs = __builtin_amdgcn_ds_bpermute(min(j4, last4), c_cur);
+      if (ADDR32) {   // one full-rate 24-bit multiply, 32-bit offset on the scalar base (see spmm.hip)
+        const uint32_t ro = __umul24((uint32_t)cs, pitch_b);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) xv[v] = *reinterpret_cast<const float4*>(hb + (ro + lo[v]));
+      } else {
+        const char* xr = reinterpret_cast<const char*>(h + (int64_t)cs * ldh);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) xv[v] = *reinterpret_cast<const float4*>(xr + lo[v]);
+      }
+    };
+    float m = 0.f, ssum = 0.f, p_cur = 0.f;
+    bool have_p = false;
+    // local softmax of the item; lane group 0 starts from bias * (sum + eps): after the 1 / (sum + eps) of the
+    // epilogue that is the bias
+    auto softmax = [&]() {
+      if (have_p) return;
+      have_p = true;
+      const float e = lane < cnt ? leaky(as + ad, slope) : -INFINITY;
+      m = wave_max(e);
+      p_cur = lane < cnt ? expf(e - m) : 0.f;
+      ssum = wave_sum(p_cur);
+      if (with_bias) {
+        const float sden = ssum + 1e-16f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) { acc[v].x *= sden; acc[v].y *= sden; acc[v].z *= sden; acc[v].w *= sden; }
+      }
+    };
+    auto weight = [&](int t) {
+      const int j4 = 4 * (t * G) + 4 * g;
+      return __int_as_float(__builtin_amdgcn_ds_bpermute(min(j4, end4), __float_as_int(p_cur)));
+    };
+    int t0 = 0;
+    for (; t0 + U <= trips; t0 += U) {
       float4 xv[U][VPL];
-      float wj[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) gather(t0 + u, xv[u]);
+      softmax();
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (t0 + u < trips) {
-          const int j4 = 4 * ((t0 + u) * G) + 4 * g;
-          const int cs = __builtin_amdgcn_ds_bpermute(min(j4, last4), c_cur);
-          wj[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(min(j4, end4), __float_as_int(p_cur)));
-          const float4* xr = reinterpret_cast<const float4*>(h + (int64_t)cs * ldh);
+        const float wj = weight(t0 + u);
 #pragma unroll
-          for (int v = 0; v < VPL; ++v) {
-            const int vec = li + v * LPR;
-            xv[u][v] = EXACT ? xr[vec] : xr[min(vec, d4 - 1)];
-          }
-        } else {
-          wj[u] = 0.f;
-#pragma unroll
-          for (int v = 0; v < VPL; ++v) xv[u][v] = f4_zero();
-        }
+        for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj, xv[u][v], acc[v]);
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
     }
+    if (U > 1) {
+      const int rem = trips - t0;
+      if (rem > 0) {
+        float4 xv[U - 1 > 0 ? U - 1 : 1][VPL];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+          if (u < rem) gather(t0 + u, xv[u]);
+        softmax();
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+          if (u < rem) {
+            const float wj = weight(t0 + u);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj, xv[u][v], acc[v]);
+          }
+      }
+    }
+    softmax();                                                  // items without edges
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_group_sum<LPR>(acc[v]);
     if (lane == 0) {
-      if (slot < 0) { rowmax[row] = m; rowsum[row] = ssum; }
+      if (whole) { rowmax[row] = m; rowsum[row] = ssum; }
       else { scratch_ms[2 * slot] = m; scratch_ms[2 * slot + 1] = ssum; }
     }
     if (g == 0) {
-      const float inv = 1.0f / (ssum + 1e-16f);
+      const float inv = whole ? 1.0f / (ssum + 1e-16f) : 1.0f;
+      char* ob = whole ? reinterpret_cast<char*>(y + (int64_t)row * ldy)
+                       : reinterpret_cast<char*>(scratch + (int64_t)slot * d4 * 4);
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
-        const int vec = li + v * LPR;
-        if (!EXACT && vec >= d4) continue;
+        if (!EXACT && li + v * LPR >= d4) continue;
         float4 o = acc[v];
-        if (slot < 0) {
-          o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
-          if (bias) o = f4_add(o, reinterpret_cast<const float4*>(bias)[vec]);
-          reinterpret_cast<float4*>(y + (int64_t)row * ldy)[vec] = o;
-        } else {
-          reinterpret_cast<float4*>(scratch + (int64_t)slot * d4 * 4)[vec] = o;
-        }
+        o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+        *reinterpret_cast<float4*>(ob + lo[v]) = o;
       }
     }
+    d0 = d1;
+    d1 = uniform(dv);
   }
 }
 
@@ -326,78 +395,130 @@ __global__ __launch_bounds__(256) void gat_fixup_fwd_kernel(const int4* __restri
 
 // backward pass 1 (target-major pieces): alpha_k, d_alpha_k = <dy_i, h_j> (stored in de),
 // per-piece T = sum alpha d_alpha -> t[row] (whole rows) or a scratch slot (split rows)
+// Same visit structure as the forward (persistent XCD windows, descriptors two visits ahead through one lane,
+// indices one visit ahead): the neighbour rows are requested from the indices alone, the attention weights
+// (logits, row statistics) and the dy row arrive behind them.
 template <int LPR, int VPL, bool EXACT>
 __global__ __launch_bounds__(256) void gat_items_bwd_dalpha_kernel(
     const int4* __restrict__ items, int32_t n_items, const int32_t* __restrict__ col,
     const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ rowmax,
     const float* __restrict__ rowsum, const float* __restrict__ h, int64_t ldh, const float* __restrict__ dy,
     int64_t lddy, float* __restrict__ alpha, float* __restrict__ de, float* __restrict__ t_row,
-    float* __restrict__ scratch_t, float slope, int32_t d4, int32_t nnz) {
+    float* __restrict__ da_dst, float* __restrict__ scratch_t, float slope, int32_t d4, int32_t nnz) {
   constexpr int G = kWave / LPR;
+  constexpr int U = 4;                                             // neighbour rows in flight per lane group
+  constexpr int kXcd = 8;
   const int lane = threadIdx.x & 63;
   const int g = lane / LPR, li = lane % LPR;
-  const int bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
-  const int item = bid * 4 + (threadIdx.x >> 6);
-  if (item >= n_items) return;
-  const int4 desc = items[item];
-  const int row = desc.x, start = desc.y, slot = desc.w;
-  const int cnt = desc.z - start;
-  const int c = col[min(start + lane, nnz - 1)];
-  const float e = leaky(a_src[c] + a_dst[row], slope);
-  const float al = lane < cnt ? expf(e - rowmax[row]) / (rowsum[row] + 1e-16f) : 0.f;
-  if (lane < cnt) alpha[start + lane] = al;
-
-  float4 dyr[VPL];
-#pragma unroll
-  for (int v = 0; v < VPL; ++v) {
-    const int vec = li + v * LPR;
-    dyr[v] = reinterpret_cast<const float4*>(dy + (int64_t)row * lddy)[EXACT ? vec : min(vec, d4 - 1)];
-    if (!EXACT && vec >= d4) dyr[v] = f4_zero();
-  }
+  const int xcd = blockIdx.x % kXcd;
+  const int stride = (gridDim.x / kXcd) * 4;                        // waves per XCD
+  const int wx = (blockIdx.x / kXcd) * 4 + (threadIdx.x >> 6);
+  const int per = (n_items + kXcd - 1) / kXcd;
+  const int i0 = xcd * per, i1 = min(n_items, i0 + per);
+  int i = i0 + wx;
+  if (i >= i1) return;
   __shared__ float pbuf[4][kWave];
   float* pw = pbuf[threadIdx.x >> 6];
-  const int cnt_s = __builtin_amdgcn_readfirstlane(cnt);           // scalar trip control
-  const int trips = (cnt_s + G - 1) / G;
-  const int last4 = 4 * cnt_s - 4;
-  constexpr int U = 4;                                             // neighbour rows in flight per lane group
-  for (int t0 = 0; t0 < trips; t0 += U) {
-    float4 hv[U][VPL];
+
+  uint32_t lo[VPL];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (t0 + u < trips) {
-        const int j4 = min(4 * ((t0 + u) * G) + 4 * g, last4);     // padded slots re-read the last neighbour
-        const int cj = __builtin_amdgcn_ds_bpermute(j4, c);
-        const float4* hr = reinterpret_cast<const float4*>(h + (int64_t)cj * ldh);
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          const int vec = li + v * LPR;
-          hv[u][v] = hr[EXACT ? vec : min(vec, d4 - 1)];
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (t0 + u < trips) {
-        const int j = (t0 + u) * G + g;
-        float p = 0.f;
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          p = fmaf(dyr[v].x, hv[u][v].x, p); p = fmaf(dyr[v].y, hv[u][v].y, p);
-          p = fmaf(dyr[v].z, hv[u][v].z, p); p = fmaf(dyr[v].w, hv[u][v].w, p);
-        }
-        p = lanes_sum<LPR>(p);
-        if (j < cnt && li == 0) pw[j] = p;                          // edge j's <dy_i, h_j>, parked per edge
-      }
-    }
-  }
-  // one coalesced store of the item's edge values and the attention-weighted sum, edge per lane
-  // (LDS operations of one wave complete in order: no barrier needed)
-  const float pj = lane < cnt ? pw[lane] : 0.f;
-  if (lane < cnt) de[start + lane] = pj;
-  float tpart = al * pj;
-  tpart = wave_sum(tpart);
+  for (int v = 0; v < VPL; ++v) lo[v] = 16u * (uint32_t)(EXACT ? li + v * LPR : min(li + v * LPR, d4 - 1));
+
+  struct Desc { int row, start, end, slot; };
+  auto uniform = [](const int4& v) {
+    Desc d;
+    d.row = __builtin_amdgcn_readfirstlane(v.x);
+    d.start = __builtin_amdgcn_readfirstlane(v.y);
+    d.end = __builtin_amdgcn_readfirstlane(v.z);
+    d.slot = __builtin_amdgcn_readfirstlane(v.w);
+    return d;
+  };
+  int4 dv = make_int4(0, 0, 0, 0), dv1 = dv;
   if (lane == 0) {
-    if (slot < 0) t_row[row] = tpart; else scratch_t[slot] = tpart;
+    dv = items[i];
+    dv1 = items[min(i + stride, i1 - 1)];
+  }
+  Desc d0 = uniform(dv), d1 = uniform(dv1);
+  int c_next = col[min(d0.start + lane, nnz - 1)];
+  for (; i < i1; i += stride) {
+    const int row = d0.row, start = d0.start, slot = d0.slot, cnt = d0.end - d0.start;
+    const int c = c_next;
+    if (lane == 0) dv = items[min(i + 2 * stride, i1 - 1)];
+    c_next = col[min(d1.start + lane, nnz - 1)];
+    // weights of the item's edges and the dy row: requested now, consumed behind the first gathers
+    float as = 0.f;
+    if (lane < cnt) as = a_src[c];
+    const float ad = a_dst[row], rm = rowmax[row], rs = rowsum[row];
+    float4 dyr[VPL];
+    const char* dyb = reinterpret_cast<const char*>(dy + (int64_t)row * lddy);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      dyr[v] = *reinterpret_cast<const float4*>(dyb + lo[v]);
+      if (!EXACT && li + v * LPR >= d4) dyr[v] = f4_zero();
+    }
+    const int trips = (cnt + G - 1) / G;
+    const int last4 = 4 * cnt - 4;
+    auto gather = [&](int t, float4(&hv)[VPL]) {
+      const int j4 = min(4 * (t * G) + 4 * g, last4);              // padded slots re-read the last neighbour
+      const int cj = __builtin_amdgcn_ds_bpermute(j4, c);
+      const char* hr = reinterpret_cast<const char*>(h + (int64_t)cj * ldh);
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) hv[v] = *reinterpret_cast<const float4*>(hr + lo[v]);
+    };
+    auto dot = [&](int t, const float4(&hv)[VPL]) {
+      const int j = t * G + g;
+      float p = 0.f;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        p = fmaf(dyr[v].x, hv[v].x, p); p = fmaf(dyr[v].y, hv[v].y, p);
+        p = fmaf(dyr[v].z, hv[v].z, p); p = fmaf(dyr[v].w, hv[v].w, p);
+      }
+      p = lanes_sum<LPR>(p);
+      if (j < cnt && li == 0) pw[j] = p;                            // edge j's <dy_i, h_j>, parked per edge
+    };
+    int t0 = 0;
+    for (; t0 + U <= trips; t0 += U) {
+      float4 hv[U][VPL];
+#pragma unroll
+      for (int u = 0; u < U; ++u) gather(t0 + u, hv[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) dot(t0 + u, hv[u]);
+    }
+    {
+      const int rem = trips - t0;
+      if (rem > 0) {
+        float4 hv[U - 1][VPL];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+          if (u < rem) gather(t0 + u, hv[u]);
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+          if (u < rem) dot(t0 + u, hv[u]);
+      }
+    }
+    const float e = leaky(as + ad, slope);
+    const float al = lane < cnt ? expf(e - rm) / (rs + 1e-16f) : 0.f;
+    if (lane < cnt) alpha[start + lane] = al;
+    // one coalesced store of the item's edge values and the attention-weighted sum, edge per lane
+    // (LDS operations of one wave complete in order: no barrier needed)
+    const float pj = lane < cnt ? pw[lane] : 0.f;
+    float tpart = al * pj;
+    tpart = wave_sum(tpart);
+    if (slot < 0) {
+      // the item is the whole row: t_i = sum_j alpha_ij <dy_i, h_j> is complete, so the score gradient
+      // de_ij = alpha_ij (<dy_i, h_j> - t_i) leaky'(s_ij) and da_dst_i = sum_j de_ij are finished here
+      float v = lane < cnt ? al * (pj - tpart) * (as + ad > 0.f ? 1.0f : slope) : 0.f;
+      if (lane < cnt) de[start + lane] = v;
+      v = wave_sum(v);
+      if (lane == 0) { t_row[row] = tpart; da_dst[row] = v; }
+    } else {
+      // a piece of a split row: park <dy_i, h_j> and the partial t; gat_items_bwd_de_kernel finishes the
+      // pieces once the row's t is summed
+      if (lane < cnt) de[start + lane] = pj;
+      if (lane == 0) scratch_t[slot] = tpart;
+    }
+    d0 = d1;
+    d1 = uniform(dv);
   }
 }
 
@@ -415,24 +536,29 @@ __global__ __launch_bounds__(256) void scalar_fixup_kernel(const int4* __restric
 __global__ __launch_bounds__(256) void gat_items_bwd_de_kernel(
     const int4* __restrict__ items, int32_t n_items, const int32_t* __restrict__ col,
     const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ alpha,
-    const float* __restrict__ t_row, float* __restrict__ de, float* __restrict__ da_dst,
-    float* __restrict__ scratch_d, float slope, int32_t nnz) {
+    const float* __restrict__ t_row, float* __restrict__ de, float* __restrict__ scratch_d, float slope, int32_t nnz) {
+  // Only the pieces of split rows are left for this pass (whole rows were finished by
+  // gat_items_bwd_dalpha_kernel): a wave looks at kPer consecutive descriptors and skips the whole rows.
+  constexpr int kPer = 4;
   const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= n_items) return;
-  const int4 desc = items[item];
-  const int row = desc.x, start = desc.y, slot = desc.w;
-  const int cnt = desc.z - start;
-  float v = 0.f;
-  if (lane < cnt) {
-    const int k = start + lane;
-    const float s = a_src[col[k]] + a_dst[row];
-    v = alpha[k] * (de[k] - t_row[row]) * (s > 0.f ? 1.0f : slope);
-    de[k] = v;
-  }
-  v = wave_sum(v);
-  if (lane == 0) {
-    if (slot < 0) da_dst[row] = v; else scratch_d[slot] = v;
+  const int first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kPer;
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const int item = first + q;
+    if (item >= n_items) return;
+    const int4 desc = items[item];
+    const int row = desc.x, start = desc.y, slot = desc.w;
+    if (slot < 0) continue;
+    const int cnt = desc.z - start;
+    float v = 0.f;
+    if (lane < cnt) {
+      const int k = start + lane;
+      const float s = a_src[col[k]] + a_dst[row];
+      v = alpha[k] * (de[k] - t_row[row]) * (s > 0.f ? 1.0f : slope);
+      de[k] = v;
+    }
+    v = wave_sum(v);
+    if (lane == 0) scratch_d[slot] = v;
   }
 }
 
@@ -611,6 +737,27 @@ extern "C" int gd_gat_aggregate_bwd_f32(const int32_t* rowptr, const int32_t* co
     }                                                                                                          \
     (void)ex;                                                                                                  \
   } while (0)
+#define GD_A32_TRUE , true
+#define GD_A32_FALSE , false
+#define GD_GAT_ITEMS_T(KERNEL, TAIL, ...)                                                                              \
+  do {                                                                                                         \
+    const int lpr = lanes_per_row(d4);                                                                         \
+    const bool ex = (lpr == 64) ? (d4 == 64 || d4 == 256) : (d4 == lpr);                                        \
+    switch (lpr) {                                                                                             \
+      case 1: hipLaunchKernelGGL((KERNEL<1, 1, true TAIL>), grid, dim3(256), 0, s, __VA_ARGS__); break;             \
+      case 2: hipLaunchKernelGGL((KERNEL<2, 1, true TAIL>), grid, dim3(256), 0, s, __VA_ARGS__); break;             \
+      case 4: hipLaunchKernelGGL((KERNEL<4, 1, true TAIL>), grid, dim3(256), 0, s, __VA_ARGS__); break;             \
+      case 8: hipLaunchKernelGGL((KERNEL<8, 1, true TAIL>), grid, dim3(256), 0, s, __VA_ARGS__); break;             \
+      case 16: hipLaunchKernelGGL((KERNEL<16, 1, true TAIL>), grid, dim3(256), 0, s, __VA_ARGS__); break;           \
+      case 32: hipLaunchKernelGGL((KERNEL<32, 1, true TAIL>), grid, dim3(256), 0, s, __VA_ARGS__); break;           \
+      default:                                                                                                 \
+        if (d4 == 64) hipLaunchKernelGGL((KERNEL<64, 1, true TAIL>), grid, dim3(256), 0, s, __VA_ARGS__);           \
+        else if (d4 < 64) hipLaunchKernelGGL((KERNEL<64, 1, false TAIL>), grid, dim3(256), 0, s, __VA_ARGS__);      \
+        else if (d4 == 256) hipLaunchKernelGGL((KERNEL<64, 4, true TAIL>), grid, dim3(256), 0, s, __VA_ARGS__);     \
+        else hipLaunchKernelGGL((KERNEL<64, 4, false TAIL>), grid, dim3(256), 0, s, __VA_ARGS__);                   \
+    }                                                                                                          \
+    (void)ex;                                                                                                  \
+  } while (0)
 
 extern "C" int64_t gd_gat_balanced_scratch(int32_t n_slots, int32_t d) { return (int64_t)n_slots * (d + 4) + 4; }
 
@@ -618,7 +765,7 @@ extern "C" int gd_gat_aggregate_balanced_f32(const int32_t* items, int32_t n_ite
                                              int32_t n_split, int32_t n_slots, const int32_t* col, const float* a_src,
                                              const float* a_dst, const float* h, int64_t ldh, float* y, int64_t ldy,
                                              const float* bias, float* rowmax, float* rowsum, float* scratch,
-                                             float slope, int32_t d, int32_t nnz, void* stream) {
+                                             float slope, int32_t d, int32_t nnz, int32_t h_rows, void* stream) {
   using namespace gd;
   GD_REQUIRE(items && col && a_src && a_dst && h && y && rowmax && rowsum, GD_E_NULL,
              "gd_gat_aggregate_balanced_f32: null pointer");
@@ -636,8 +783,14 @@ extern "C" int gd_gat_aggregate_balanced_f32(const int32_t* items, int32_t n_ite
   const dim3 grid(nblk);
   float* scratch_ms = scratch ? scratch + (int64_t)n_slots * d : nullptr;
   const int4* it = reinterpret_cast<const int4*>(items);
-  GD_GAT_ITEMS(gat_items_fwd_kernel, it, n_items, col, a_src, a_dst, h, ldh, y, ldy, bias, rowmax, rowsum, scratch,
-               scratch_ms, slope, d4, nnz);
+  // 24-bit fast addressing (see spmm.hip): row ids and the row pitch in bytes below 2^24, h smaller than 4 GiB
+  const bool addr32 = h_rows > 0 && h_rows <= (1 << 24) && ldh * 4 < (1 << 24) && (int64_t)h_rows * ldh * 4 < (1ll << 32);
+  if (addr32)
+    GD_GAT_ITEMS_T(gat_items_fwd_kernel, GD_A32_TRUE, it, n_items, col, a_src, a_dst, h, ldh, y, ldy, bias, rowmax, rowsum,
+                   scratch, scratch_ms, slope, d4, nnz);
+  else
+    GD_GAT_ITEMS_T(gat_items_fwd_kernel, GD_A32_FALSE, it, n_items, col, a_src, a_dst, h, ldh, y, ldy, bias, rowmax, rowsum,
+                   scratch, scratch_ms, slope, d4, nnz);
   int rc = launched("gat_items_fwd");
   if (rc || n_split == 0) return rc;
   hipLaunchKernelGGL(gat_fixup_fwd_kernel, dim3((n_split + 3) / 4), dim3(256), 0, s,
@@ -661,21 +814,24 @@ extern "C" int gd_gat_edge_grads_balanced_f32(const int32_t* items, int32_t n_it
   if (n_items == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
   const int d4 = d / 4;
-  const dim3 grid(((n_items + 3) / 4 + 7) / 8 * 8);
+  int nblk = (n_items + 3) / 4;
+  if (nblk > 8192) nblk = 8192;                         // persistent visits, as the forward
+  const dim3 grid((nblk + 7) / 8 * 8);
   const int4* it = reinterpret_cast<const int4*>(items);
   const int4* sp = reinterpret_cast<const int4*>(split);
   GD_GAT_ITEMS(gat_items_bwd_dalpha_kernel, it, n_items, col, a_src, a_dst, rowmax, rowsum, h, ldh, dy, lddy, alpha, de,
-               t_row, scratch, slope, d4, nnz);
+               t_row, da_dst, scratch, slope, d4, nnz);
   int rc = launched("gat_items_bwd_dalpha");
   if (rc) return rc;
   if (n_split) {
     hipLaunchKernelGGL(scalar_fixup_kernel, dim3((n_split + 255) / 256), dim3(256), 0, s, sp, n_split, scratch, t_row);
     if ((rc = launched("gat_fixup_t"))) return rc;
   }
-  hipLaunchKernelGGL(gat_items_bwd_de_kernel, dim3((n_items + 3) / 4), dim3(256), 0, s, it, n_items, col, a_src, a_dst,
-                     alpha, t_row, de, da_dst, scratch, slope, nnz);
-  if ((rc = launched("gat_items_bwd_de"))) return rc;
   if (n_split) {
+    // only the pieces of split rows are left (whole rows exit at once)
+    hipLaunchKernelGGL(gat_items_bwd_de_kernel, dim3((n_items + 15) / 16), dim3(256), 0, s, it, n_items, col, a_src,
+                       a_dst, alpha, t_row, de, scratch, slope, nnz);
+    if ((rc = launched("gat_items_bwd_de"))) return rc;
     hipLaunchKernelGGL(scalar_fixup_kernel, dim3((n_split + 255) / 256), dim3(256), 0, s, sp, n_split, scratch, da_dst);
     rc = launched("gat_fixup_dadst");
   }

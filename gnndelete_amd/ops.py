@@ -187,7 +187,7 @@ def gat_forward_raw(graph, h, a_src, a_dst, bias, slope, out=None):
         check(_lib.lib().gd_gat_aggregate_balanced_f32(
             ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split, plan.n_slots, ptr(graph.col), ptr(a_src),
             ptr(a_dst), ptr(h), h.stride(0), ptr(y), y.stride(0), ptr(bias), ptr(rowmax), ptr(rowsum), ptr(scratch),
-            float(slope), d, graph.nnz, stream_ptr(h.device)), 'gd_gat_aggregate_balanced_f32')
+            float(slope), d, graph.nnz, int(h.shape[0]), stream_ptr(h.device)), 'gd_gat_aggregate_balanced_f32')
         return y, rowmax, rowsum
     alpha = torch.empty(graph.nnz, dtype=torch.float32, device=h.device)
     check(_lib.lib().gd_gat_aggregate_f32(ptr(graph.rowptr), ptr(graph.col), ptr(a_src), ptr(a_dst), ptr(h),

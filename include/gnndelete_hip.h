@@ -135,7 +135,7 @@ int gd_gat_aggregate_balanced_f32(const int32_t* items, int32_t n_items, const i
                                   int32_t n_slots, const int32_t* col, const float* a_src, const float* a_dst,
                                   const float* h, int64_t ldh, float* y, int64_t ldy, const float* bias,
                                   float* rowmax, float* rowsum, float* scratch, float slope,
-                                  int32_t d, int32_t nnz, void* stream);
+                                  int32_t d, int32_t nnz, int32_t h_rows /* rows of h, 0 = unknown */, void* stream);
 int gd_gat_edge_grads_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
                                    const int32_t* col, const float* a_src, const float* a_dst,
                                    const float* rowmax, const float* rowsum, const float* h, int64_t ldh,
