@@ -81,6 +81,52 @@ class CSRGraph:
         return self.col.device
 
 
+class CappedCSR:
+    """A CSR whose rows have at most CAP in-edges, for gd_agg_gemm_f32: every heavier (hub) row h is replaced by
+    ONE edge of weight 1 to an extra operand row n + h, which `aggregate_hubs` fills with the hub's weighted
+    neighbour sum (the balanced SpMM over the hub rows only).  The operand therefore has n + n_hub rows."""
+
+    CAP = 64       # heaviest row the fused kernel walks itself (one wave; 256 measured the same: fewer hub rows, longer tail)
+
+    def __init__(self, rowptr, col, val, n, cap=None):
+        dev = rowptr.device
+        rp = rowptr.long()
+        deg = rp[1:] - rp[:-1]
+        hub_mask = deg > (self.CAP if cap is None else cap)
+        self.hub = hub_mask.nonzero().flatten()
+        self.n, self.n_hub = n, int(self.hub.numel())
+        edge_row = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+        keep = ~hub_mask[edge_row]
+        new_deg = torch.where(hub_mask, torch.ones_like(deg), deg)
+        rpc = torch.zeros(n + 1, dtype=torch.long, device=dev)
+        rpc[1:] = torch.cumsum(new_deg, 0)
+        nnz_c = int(rpc[-1])
+        colc = torch.empty(nnz_c, dtype=torch.int32, device=dev)
+        valc = torch.ones(nnz_c, dtype=torch.float32, device=dev)
+        k = torch.arange(col.numel(), device=dev)[keep]
+        pos = rpc[edge_row[keep]] + (k - rp[edge_row[keep]])
+        colc[pos] = col[keep]
+        if val is not None:
+            valc[pos] = val[keep]
+        colc[rpc[self.hub]] = (n + torch.arange(self.n_hub, device=dev)).to(torch.int32)
+        self.rowptr, self.col = rpc.to(torch.int32), colc
+        self.val = valc
+        # the hub rows' own edges as a small CSR (rows 0 .. n_hub - 1) + its balanced plan
+        if self.n_hub:
+            rph = torch.zeros(self.n_hub + 1, dtype=torch.long, device=dev)
+            rph[1:] = torch.cumsum(deg[self.hub], 0)
+            self.rowptr_h = rph.to(torch.int32)
+            self.col_h = col[~keep].contiguous()
+            self.val_h = val[~keep].contiguous() if val is not None else None
+            self.plan_h = SplitPlan(self.rowptr_h)
+
+    def operand(self, x):
+        """x [n, d] -> a [n + n_hub, d] buffer whose first n rows are x (the hub rows are filled per call)."""
+        buf = torch.empty(self.n + self.n_hub, x.shape[1], dtype=torch.float32, device=x.device)
+        buf[:self.n] = x
+        return buf
+
+
 def csr_from_coo(src, dst, n):
     """gd_csr_from_coo on device tensors: -> (rowptr int32 [n+1], col int32 [E], order int32 [E])."""
     src, dst = src.long().contiguous(), dst.long().contiguous()

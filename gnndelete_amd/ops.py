@@ -391,6 +391,30 @@ def edge_dot(z, e0, e1, rel=None, etype=None):
     return _EdgeDot.apply(z, rel, e0, e1, etype)
 
 
+def aggregate_hubs(capped, x_ext):
+    """Fill the extra operand rows x_ext[n:] with the hub rows' weighted neighbour sums (balanced SpMM)."""
+    if capped.n_hub:
+        _spmm_raw(capped.rowptr_h, capped.col_h, capped.val_h, x_ext, None, 0.0, capped.n_hub, capped.plan_h,
+                  out=x_ext[capped.n:])
+
+
+def agg_gemm(capped, x_ext, w, bias=None, rows=None, gate_bits=None, out=None, w_out_in=True):
+    """out[r] = (sum_k val[k] x_ext[col[k]]) @ (w^T if w_out_in else w) (+ bias / gated) for r in rows (all rows of
+    the capped CSR when rows is None) - gd_agg_gemm_f32, raw call.  x_ext = capped.operand(x) after
+    aggregate_hubs.  Output rows are indexed by row id."""
+    d_in = x_ext.shape[1]
+    d_out = w.shape[0] if w_out_in else w.shape[1]
+    n_rows = capped.n if rows is None else int(rows.shape[0])
+    if out is None:
+        out = torch.empty(capped.n, d_out, dtype=torch.float32, device=x_ext.device)
+    w = w.contiguous()
+    check(_lib.lib().gd_agg_gemm_f32(ptr(capped.rowptr), ptr(capped.col), ptr(capped.val), ptr(x_ext), x_ext.stride(0),
+                                     int(x_ext.shape[0]), ptr(rows), n_rows, ptr(w), d_in, d_out, 1 if w_out_in else 0,
+                                     ptr(bias), ptr(gate_bits), ptr(out), out.stride(0), int(capped.col.shape[0]),
+                                     stream_ptr(x_ext.device)), 'gd_agg_gemm_f32')
+    return out
+
+
 # ------------------------------------------------------------------------------ edge-probability NI term
 class _PairsSigmoidMse(torch.autograd.Function):
     """mean over the included pairs i > j of (sigmoid(z[nodes[i]] . z[nodes[j]]) - target[i, j])^2,

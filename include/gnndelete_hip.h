@@ -59,6 +59,22 @@ int gd_csr_from_coo(const int64_t* src, const int64_t* dst, int64_t n_edges, int
                     int32_t* col, int32_t* order, int32_t* status, void* workspace, int64_t workspace_bytes,
                     void* stream);
 
+/* Aggregate-then-transform in one kernel:  y[r,:] = (sum_{k in row r} val[k] x[col[k],:]) @ W (+ bias), r in rows.
+ *   rowptr/col/val  CSR over target rows (val required: ones for a plain sum); a row is walked by one wave, so rows above a few hundred
+ *                   in-edges should be pre-aggregated by gd_spmm_csr_balanced_f32 into extra rows of x and given one edge
+ *   x [x_rows, d_in], d_in in {64, 128}; rows [n_rows] int32 row ids or NULL for 0..n_rows-1
+ *   w: w_out_in = 1 -> [d_out, d_in] (a Linear weight, y = agg @ w^T), 0 -> [d_in, d_out]; d_out in {64, 128}
+ *   bias [d_out] or NULL;  gate_bits [n_rows, d_out/32] or NULL: zero the outputs whose bit is clear (packed
+ *   [z > 0] of gd_rows_gemm_signs_f32, indexed by position in `rows`) - exclusive with bias
+ * By linearity this is GCNConv / GINConv with in_dim <= out_dim (framework/models/gcn.py:11-24, gin.py:26-34:
+ * propagate(lin(x)) = lin(propagate(x))) and, on the transposed CSR with the gate, relu's and conv2's backward
+ * into the S1 rows (framework/models/deletion.py:66-68).  The gather-bound aggregation and the MFMA-bound
+ * transform overlap inside the CUs; the aggregated rows never reach HBM. */
+int gd_agg_gemm_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t ldx,
+                    int32_t x_rows, const int32_t* rows, int32_t n_rows, const float* w, int32_t d_in, int32_t d_out,
+                    int32_t w_out_in, const float* bias, const uint32_t* gate_bits, float* y, int64_t ldy,
+                    int32_t nnz /* length of col */, void* stream);
+
 /* GCN symmetric normalisation on a CSR that already contains exactly one self loop per node:
  *   val[k] = deg[i]^-1/2 * deg[col[k]]^-1/2,  deg[i] = rowptr[i+1]-rowptr[i]  (k in row i)
  * Replaces torch_geometric gcn_norm inside GCNConv.forward (framework/models/gcn.py:16,19). */

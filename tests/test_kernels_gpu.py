@@ -590,3 +590,46 @@ def test_csr_from_coo_rejects_out_of_range_endpoints():
         csr_from_coo(src, dst, 5)
     with pytest.raises(IndexError):
         csr_from_coo(torch.tensor([0, -1], device='cuda'), torch.tensor([1, 2], device='cuda'), 5)
+
+
+@pytest.mark.parametrize('n,m,d_in,d_out,hub', [(300, 3000, 128, 128, 150), (300, 3000, 64, 128, 0), (130, 900, 128, 64, 100),
+                                                (1000, 9000, 64, 64, 400), (17, 40, 128, 128, 0), (5000, 60000, 128, 128, 900)])
+def test_agg_gemm_matches_dense_closed_form(n, m, d_in, d_out, hub):
+    """gd_agg_gemm_f32: (A x) W^T + b in one kernel, hub rows (> 64 in-edges) through the pre-aggregated extra
+    operand rows; also a row subset with the packed ReLU gate (the layer-2 input-gradient form)."""
+    from gnndelete_amd import ops
+    from gnndelete_amd.graph import build_csr, CappedCSR
+    ei = random_graph(n, m, seed=n + d_in, isolate=3)
+    if hub:
+        src = torch.randperm(n)[:hub]
+        ei = torch.cat([ei, torch.stack([src, torch.full_like(src, 5)]), torch.stack([torch.full_like(src, 5), src])], 1)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, d_in, generator=g)
+    w = torch.randn(d_out, d_in, generator=g) / d_in ** 0.5
+    b = torch.randn(d_out, generator=g)
+    gr = build_csr(ei.cuda(), n, 'gcn')
+    a = torch.zeros(n, n, dtype=torch.float64)
+    rp, col, val = gr.rowptr.cpu().long(), gr.col.cpu().long(), gr.val.cpu().double()
+    for i in range(n):
+        a[i].index_add_(0, col[rp[i]:rp[i + 1]], val[rp[i]:rp[i + 1]])
+    want = a @ x.double() @ w.double().t() + b.double()
+    cap = CappedCSR(gr.rowptr, gr.col, gr.val, n, cap=64 if n % 2 else 256)      # both: hub rows / long rows walked in segments
+    assert cap.n_hub == int(((rp[1:] - rp[:-1]) > (64 if n % 2 else 256)).sum())
+    xe = cap.operand(x.cuda())
+    ops.aggregate_hubs(cap, xe)
+    y = ops.agg_gemm(cap, xe, w.cuda(), bias=b.cuda())
+    assert rel_l2(y.cpu(), want) < TOL
+    # subset of rows + gate bits, weight given as [d_in, d_out]
+    rows = torch.randperm(n, generator=g)[: max(1, n // 3)].sort().values.int()
+    gate = torch.randint(0, 2, (rows.numel(), d_out), generator=g).bool()
+    bits = torch.zeros(rows.numel(), d_out // 32, dtype=torch.int64)
+    for f in range(d_out):
+        bits[:, f // 32] |= gate[:, f].long() << (f % 32)
+    bits = bits.to(torch.int32) if d_out < 32 else (bits & 0xFFFFFFFF).to(torch.int64).to(torch.int32)
+    out = torch.zeros(n, d_out, device='cuda')
+    ops.agg_gemm(cap, xe, w.t().contiguous().cuda(), rows=rows.cuda(), gate_bits=bits.cuda(), out=out, w_out_in=False)
+    want_g = (a @ x.double() @ w.double().t())[rows.long()] * gate.double()
+    assert rel_l2(out.cpu()[rows.long()], want_g) < TOL
+    untouched = torch.ones(n, dtype=torch.bool)
+    untouched[rows.long()] = False
+    assert float(out.cpu()[untouched].abs().max()) == 0.0 if untouched.any() else True

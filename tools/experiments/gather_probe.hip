@@ -14,6 +14,8 @@ __device__ __forceinline__ uint32_t mix(uint32_t a) {
 template <int U>
 __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
                                                      int deg, int window, int rows_per_wave) {
+  extern __shared__ float occupancy_ballast[];     // dynamic LDS only limits the resident blocks per CU
+  if (rows_per_wave < 0) occupancy_ballast[threadIdx.x] = 0.f;
   const int lane = threadIdx.x & 63, g = lane >> 5, li = lane & 31;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int xcd = blockIdx.x & 7;
@@ -49,6 +51,29 @@ int main(int argc, char** argv) {
   hipMalloc(&x, (size_t)n * d * 4); hipMalloc(&y, (size_t)n * d * 4);
   hipMemset(x, 0, (size_t)n * d * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  if (argc > 1) {
+    // occupancy study: how the gather rate holds up with few resident waves per CU and deep unrolling
+    // (what a kernel that also keeps a 64 KB weight image in LDS could afford)
+    const int deg = 16;
+    for (int w : {64, 117000}) for (int lds_kb : {0, 40, 64}) for (int U : {4, 8}) {
+      const int grid = 2048;
+      const size_t lds = (size_t)lds_kb * 1024;
+      auto launch = [&]() {
+        if (U == 4) hipLaunchKernelGGL(gather_kernel<4>, dim3(grid), dim3(256), lds, 0, x, y, n, deg, w, 0);
+        else hipLaunchKernelGGL(gather_kernel<8>, dim3(grid), dim3(256), lds, 0, x, y, n, deg, w, 0);
+      };
+      for (int i = 0; i < 3; ++i) launch();
+      hipEventRecord(e0);
+      for (int i = 0; i < 20; ++i) launch();
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      const double us = ms / 20 * 1e3, gathered = (double)n * deg * 512;
+      const int blocks_per_cu = lds_kb ? (160 / lds_kb < 8 ? 160 / lds_kb : 8) : 8;
+      printf("deg=%d window=%d lds=%dKB (%d waves/CU) U=%d: %.1f us  gather %.1f TB/s\n", deg, w, lds_kb,
+             blocks_per_cu * 4, U, us, gathered / us / 1e6);
+    }
+    return 0;
+  }
   const int degs[] = {8, 16};
   const int windows[] = {64, 4096, 117000};
   const int grids[] = {2048, 8192, 16384};
