@@ -548,6 +548,39 @@ class NodeembEngine:
             self._graph.replay()
         self.steps_done += 1
 
+    def run(self, n_steps, unroll=4):
+        """n_steps iterations, `unroll` of them per graph launch where possible (a replay boundary costs ~8 us of
+        launch latency that a kernel boundary inside a graph does not); the remainder goes step by step.  Same
+        iterations, same order."""
+        if not self._use_graph or unroll <= 1:
+            for _ in range(n_steps):
+                self.step()
+            return
+        if n_steps >= unroll:
+            self.prepare_unrolled(unroll)
+            while n_steps >= unroll:
+                self._graph_k[1].replay()
+                self.steps_done += unroll
+                n_steps -= unroll
+        for _ in range(n_steps):
+            self.step()
+
+    def prepare_unrolled(self, unroll):
+        """Capture the `unroll`-iteration graph now (nothing is executed, no state changes)."""
+        if not self._use_graph or unroll <= 1:
+            return
+        if self._graph is None:
+            self._capture()                               # warms the libraries up on scratch state first
+        if getattr(self, '_graph_k', None) is None or self._graph_k[0] != unroll:
+            saved = [t.clone() for t in self._mutable_state()]
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(unroll):
+                    self._iteration()
+            for t, sv in zip(self._mutable_state(), saved):
+                t.copy_(sv)
+            self._graph_k = (unroll, graph)
+
     def _mutable_state(self):
         return [self.wd1.data, self.wd2.data, self.g1, self.g2, self.adam1.m, self.adam1.v, self.iter_ctr,
                 self.adam2.m, self.adam2.v, self.hist, self.hist_pos, self.dz1, self.dz2, self.dh]

@@ -280,3 +280,18 @@ def test_fused_layer1_kernel_matches_oracle_training(monkeypatch, use_graph):
         np.testing.assert_allclose(hist[:, col], [l[key] for l in logs], rtol=1e-4, atol=1e-8, err_msg=key)
     assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), mo.deletion1.deletion_weight.detach()) < 1e-4
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
+
+
+def test_unrolled_graph_runs_the_same_iterations():
+    """engine.run(n, unroll=k) - k iterations per hipGraph launch plus a step-by-step remainder - must leave exactly
+    the state that n single steps leave (bit-identical: same kernels, same order)."""
+    a, ma, rest = make_engine('gcn', 'both_all', True)
+    b, mb, _ = make_engine('gcn', 'both_all', True)
+    n = int(rest['epochs'])
+    for _ in range(n):
+        a.step()
+    b.run(n, unroll=3)
+    assert a.steps_done == b.steps_done == n
+    assert torch.equal(a.loss_history(), b.loss_history())
+    assert torch.equal(ma.deletion1.deletion_weight, mb.deletion1.deletion_weight)
+    assert torch.equal(ma.deletion2.deletion_weight, mb.deletion2.deletion_weight)
