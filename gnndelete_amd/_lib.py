@@ -20,7 +20,7 @@ PROTOTYPES = {
     'gd_csr_from_coo_workspace': (_i64, [_i32, _i64]),
     'gd_csr_from_coo': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i64, _p]),
     'gd_agg_gemm_f32': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p, _i64, _i32,
-                                       _p]),
+                                       _p, _p, _i32, _i32, _p]),
     'gd_gcn_norm_f32': (ctypes.c_int, [_p, _p, _i32, _p, _p]),
     'gd_spmm_csr_f32': (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _f32, _i32, _i32, _p]),
     'gd_spmm_csr_balanced_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _f32, _p, _p, _i32,

@@ -411,8 +411,22 @@ def agg_gemm(capped, x_ext, w, bias=None, rows=None, gate_bits=None, out=None, w
     check(_lib.lib().gd_agg_gemm_f32(ptr(capped.rowptr), ptr(capped.col), ptr(capped.val), ptr(x_ext), x_ext.stride(0),
                                      int(x_ext.shape[0]), ptr(rows), n_rows, ptr(w), d_in, d_out, 1 if w_out_in else 0,
                                      ptr(bias), ptr(gate_bits), ptr(out), out.stride(0), int(capped.col.shape[0]),
-                                     stream_ptr(x_ext.device)), 'gd_agg_gemm_f32')
+                                     None, None, 0, 0, stream_ptr(x_ext.device)), 'gd_agg_gemm_f32')
     return out
+
+
+def agg_gemm_items(graph, x, w, bias, out_ext, transposed=False):
+    """out_ext[:n] = (A x) @ w^T + bias over the work items of the balanced SpMM (gd_agg_gemm_f32, work-item form):
+    out_ext has graph.n + plan.n_slots rows, the extra ones hold the hub rows' piece products."""
+    plan = graph.plan_t if transposed else graph.plan
+    col, val = (graph.col_t, graph.val_t) if transposed else (graph.col, graph.val)
+    assert out_ext.shape[0] >= graph.n + plan.n_slots and val is not None
+    w = w.contiguous()
+    check(_lib.lib().gd_agg_gemm_f32(None, ptr(col), ptr(val), ptr(x), x.stride(0), int(x.shape[0]), None, plan.n_items,
+                                     ptr(w), x.shape[1], w.shape[0], 1, ptr(bias), None, ptr(out_ext), out_ext.stride(0),
+                                     int(col.shape[0]), ptr(plan.items), ptr(plan.split), plan.n_split, graph.n,
+                                     stream_ptr(x.device)), 'gd_agg_gemm_f32')
+    return out_ext[:graph.n]
 
 
 # ------------------------------------------------------------------------------ edge-probability NI term

@@ -73,7 +73,12 @@ int gd_csr_from_coo(const int64_t* src, const int64_t* dst, int64_t n_edges, int
 int gd_agg_gemm_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t ldx,
                     int32_t x_rows, const int32_t* rows, int32_t n_rows, const float* w, int32_t d_in, int32_t d_out,
                     int32_t w_out_in, const float* bias, const uint32_t* gate_bits, float* y, int64_t ldy,
-                    int32_t nnz /* length of col */, void* stream);
+                    int32_t nnz /* length of col */,
+                    const int32_t* items /* NULL, or the [n_rows, 4] work items {row, start, end, slot} of
+                                            gd_spmm_csr_balanced_f32 instead of rowptr / rows: a piece (slot >= 0) writes its
+                                            un-biased product to row piece_base + slot of y, which must have those rows */,
+                    const int32_t* split, int32_t n_split /* the items' split rows: summed (+ bias) by a fix-up */,
+                    int32_t piece_base, void* stream);
 
 /* GCN symmetric normalisation on a CSR that already contains exactly one self loop per node:
  *   val[k] = deg[i]^-1/2 * deg[col[k]]^-1/2,  deg[i] = rowptr[i+1]-rowptr[i]  (k in row i)

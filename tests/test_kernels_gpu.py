@@ -619,6 +619,10 @@ def test_agg_gemm_matches_dense_closed_form(n, m, d_in, d_out, hub):
     ops.aggregate_hubs(cap, xe)
     y = ops.agg_gemm(cap, xe, w.cuda(), bias=b.cuda())
     assert rel_l2(y.cpu(), want) < TOL
+    # work-item form: the balanced SpMM's items, hub pieces summed by the fix-up, no operand copy
+    y_ext = torch.full((n + gr.plan.n_slots, d_out), float('nan'), device='cuda')
+    y2 = ops.agg_gemm_items(gr, x.cuda(), w.cuda(), b.cuda(), y_ext)
+    assert rel_l2(y2.cpu(), want) < TOL
     # subset of rows + gate bits, weight given as [d_in, d_out]
     rows = torch.randperm(n, generator=g)[: max(1, n // 3)].sort().values.int()
     gate = torch.randint(0, 2, (rows.numel(), d_out), generator=g).bool()

@@ -39,6 +39,9 @@ us_fused = timed(lambda: (ops.aggregate_hubs(cap, xe), ops.agg_gemm(cap, xe, w1,
 us_hub = timed(lambda: ops.aggregate_hubs(cap, xe))
 print(f'layer 1 (128 -> 128): transform + aggregate {us_sep:.1f} us; fused {us_fused:.1f} us (hub pre-aggregation {us_hub:.1f} us, '
       f'{cap.n_hub} hub rows); rel diff {((y - ref).norm() / ref.norm()).item():.2e}', flush=True)
+y_ext = torch.empty(n + g.plan.n_slots, 128, device=dev)
+us_items = timed(lambda: ops.agg_gemm_items(g, x, w1, b1, y_ext))
+print(f'layer 1 fused, work-item form (pieces + fix-up, no operand copy): {us_items:.1f} us; rel diff {((y_ext[:n] - ref).norm() / ref.norm()).item():.2e}', flush=True)
 # backward shape: (A^T dp2)[S1] W2 gated, d_in = 64 -> 128 on the S1 rows
 capt = CappedCSR(g.rowptr_t, g.col_t, g.val_t, n)
 dp = torch.randn(n, 64, device=dev); w2 = torch.randn(64, 128, device=dev) / 8; idx1 = eng.idx1
