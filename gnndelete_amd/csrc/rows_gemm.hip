@@ -25,14 +25,19 @@ constexpr int kWgradMaxRows = 1024;   // rows of the reduction dimension one wgr
 
 constexpr int kGemmThreads = 512;   // 8 waves share one LDS weight image; 2 blocks per CU
 
-// MODE 0: plain, 1: also emit the packed sign pattern of the output, 2: gate the output by such a pattern
-// SEL: rows may come from a second buffer (in_alt where sel[r] != 0); only instantiated for MODE 0
+// optional: o1[row] = <out[row,:], u1>, o2[row] = <out[row,:], u2> from the epilogue (GAT's attention logits,
+// which otherwise cost a second pass over the rows just written)
+struct RowDots { const float* u1; const float* u2; float* o1; float* o2; };
+
+// MODE 0: plain, 1: also emit the packed sign pattern of the output, 2: gate the output by such a pattern,
+// 3: plain + the two row dot products of RowDots
+// SEL: rows may come from a second buffer (in_alt where sel[r] != 0); only instantiated for MODE 0 and 3
 template <int NT, int MODE, bool SEL = false>
 __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
     const float* in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel,
     const float* __restrict__ w, int32_t d_in, int32_t trans_w, const float* __restrict__ bias, int32_t relu_in,
     float* out, int64_t ld_out, float* __restrict__ save_in, const uint32_t* __restrict__ gate_bits,
-    uint32_t* __restrict__ sign_out, const float* in_alt, const uint8_t* __restrict__ sel) {
+    uint32_t* __restrict__ sign_out, const float* in_alt, const uint8_t* __restrict__ sel, RowDots dots) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   constexpr int d_out = 32 * NT;
   constexpr int kWaves = kGemmThreads / 64;
@@ -139,6 +144,10 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
     // (feature 32t + 8q + 4 khalf + c sits in acc[t][4q + c]; bit b of word t of a row's packed
     //  sign / gate mask is feature 32t + b, so this lane owns bits 8q + 4 khalf + c of each word)
     float* dst = out + (int64_t)row_cur * ld_out + 4 * khalf;
+    constexpr bool want_dots = MODE == 3;
+    // (the u vectors are the same for every tile: without the clobber LICM keeps all of them in registers)
+    if (want_dots) asm volatile("" ::: "memory");
+    float dot1 = 0.f, dot2 = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       uint32_t pos = 0;
@@ -147,6 +156,13 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
         float4 v = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
         const int n0 = 32 * t + 8 * q;
         if (bias) v = f4_add(v, *reinterpret_cast<const float4*>(bias + n0 + 4 * khalf));
+        if (want_dots) {
+          asm volatile("" ::: "memory");      // one pair of u loads in flight, not all 8 NT of them
+          const float4 p1 = *reinterpret_cast<const float4*>(dots.u1 + n0 + 4 * khalf);
+          const float4 p2 = *reinterpret_cast<const float4*>(dots.u2 + n0 + 4 * khalf);
+          dot1 = fmaf(v.x, p1.x, dot1); dot1 = fmaf(v.y, p1.y, dot1); dot1 = fmaf(v.z, p1.z, dot1); dot1 = fmaf(v.w, p1.w, dot1);
+          dot2 = fmaf(v.x, p2.x, dot2); dot2 = fmaf(v.y, p2.y, dot2); dot2 = fmaf(v.z, p2.z, dot2); dot2 = fmaf(v.w, p2.w, dot2);
+        }
         if (MODE == 2) {   // ReLU backward: pass the gradient where the forward activation input was > 0
           const uint32_t m = gate_w[t] >> (8 * q + 4 * khalf);
           v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f;
@@ -161,6 +177,11 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
         pos |= (uint32_t)__shfl_xor((int)pos, 32);
         if (live && khalf == 0) sign_out[(int64_t)s_a * NT + t] = pos;
       }
+    }
+    if (want_dots) {       // the two half-row lanes of a sample add their halves (all lanes shuffle)
+      dot1 += __shfl_xor(dot1, 32);
+      dot2 += __shfl_xor(dot2, 32);
+      if (live && khalf == 0) { dots.o1[row_cur] = dot1; dots.o2[row_cur] = dot2; }
     }
     row_cur = row_nxt;
     // row index of the tile after next: its first loads are only issued at the end of the next tile
@@ -501,7 +522,8 @@ static inline void wgrad_geometry(int32_t n_sel, int* n_blocks, int* rows_per_bl
 static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w,
                           int32_t d_in, int32_t d_out, int32_t trans_w, const float* bias, int32_t relu_in,
                           const uint32_t* gate_bits, uint32_t* sign_out, float* out, int64_t ld_out,
-                          float* save_in, void* stream, const float* in_alt = nullptr, const uint8_t* sel = nullptr) {
+                          float* save_in, void* stream, const float* in_alt = nullptr, const uint8_t* sel = nullptr,
+                          gd::RowDots dots = gd::RowDots{nullptr, nullptr, nullptr, nullptr}) {
   using namespace gd;
   GD_REQUIRE(!sel || (in_alt && aligned16(in_alt) && in_alt != out && !gate_bits && !sign_out), GD_E_NULL,
              "gd_rows_gemm_select_f32: bad in_alt");
@@ -522,15 +544,20 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
     if (grid > 512) grid = 512;
 #define GD_RG_LAUNCH(NT, MODE)                                                                                    \
   hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT, MODE>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in, idx,   \
-                     n_sel, w, d_in, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out, in_alt, sel)
+                     n_sel, w, d_in, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out, in_alt, sel, dots)
 #define GD_RG_CASE(NT)                                                                                            \
   do {                                                                                                            \
     if (gate_bits) GD_RG_LAUNCH(NT, 2);                                                                           \
     else if (sign_out) GD_RG_LAUNCH(NT, 1);                                                                       \
+    else if (dots.u1 && sel)                                                                                      \
+      hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT, 3, true>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in,  \
+                         idx, n_sel, w, d_in, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out,  \
+                         in_alt, sel, dots);                                                                      \
+    else if (dots.u1) GD_RG_LAUNCH(NT, 3);                                                                        \
     else if (sel)                                                                                                 \
       hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT, 0, true>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in,  \
                          idx, n_sel, w, d_in, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out,  \
-                         in_alt, sel);                                                                            \
+                         in_alt, sel, dots);                                                                      \
     else GD_RG_LAUNCH(NT, 0);                                                                                     \
   } while (0)
     switch (d_out / 32) {
@@ -543,6 +570,8 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
 #undef GD_RG_CASE
     return launched("rows_gemm_mfma");
   }
+  GD_REQUIRE(!dots.u1, GD_E_DIM, "gd_rows_gemm_dots_f32: needs the MFMA path (d_in, d_out multiples of 32, d_out <= 128, "
+             "weight <= 64 KB, 16-byte aligned rows)");
   GD_REQUIRE(d_in <= 1024, GD_E_DIM, "gd_rows_gemm_f32: fallback path needs d_in <= 1024 (got %d)", d_in);
   hipLaunchKernelGGL(rows_gemm_scalar_kernel, dim3((n_sel + 3) / 4), dim3(256), 0, s, in, ld_in, idx, n_sel, w, d_in,
                      d_out, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out, in_alt, sel);
@@ -563,6 +592,18 @@ extern "C" int gd_rows_gemm_select_f32(const float* in, const float* in_alt, con
   GD_REQUIRE(sel, GD_E_NULL, "gd_rows_gemm_select_f32: null selector");
   return rows_gemm_impl(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, bias, relu_in, nullptr, nullptr, out, ld_out,
                         nullptr, stream, in_alt, sel);
+}
+
+extern "C" int gd_rows_gemm_dots_f32(const float* in, const float* in_alt, const uint8_t* sel, int64_t ld_in,
+                                     const float* w, int32_t d_in, int32_t d_out, int32_t trans_w, const float* bias,
+                                     int32_t relu_in, float* out, int64_t ld_out, int32_t n_rows, const float* u1,
+                                     const float* u2, float* o1, float* o2, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(u1 && u2 && o1 && o2 && aligned16(u1) && aligned16(u2), GD_E_NULL,
+             "gd_rows_gemm_dots_f32: u1 / u2 (16-byte aligned) and o1 / o2 are required");
+  GD_REQUIRE(in != out, GD_E_DIM, "gd_rows_gemm_dots_f32: in and out must not alias");
+  return rows_gemm_impl(in, ld_in, nullptr, n_rows, w, d_in, d_out, trans_w, bias, relu_in, nullptr, nullptr, out, ld_out,
+                        nullptr, stream, sel ? in_alt : nullptr, sel, RowDots{u1, u2, o1, o2});
 }
 
 extern "C" int gd_rows_gemm_signs_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel,

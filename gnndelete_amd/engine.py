@@ -283,6 +283,7 @@ class NodeembEngine:
                 self._lp1 = torch.zeros(2 * max(1, self._lp1_blocks), **f32)
                 self._fuse_loss1 = True
         self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat', SAGEConv: 'sage'}[type(conv2)]
+        self._gat_dots = os.environ.get('GD_NO_GAT_DOTS') != '1'      # attention logits from the GEMM epilogue
         gmode = {'gcn': 'gcn', 'gin': 'sum', 'gat': 'gat', 'sage': 'mean'}[self._mode]
         self.graph = graph_for(edge_index, n, gmode)
         if self._mode == 'sage':
@@ -354,8 +355,12 @@ class NodeembEngine:
             t_r = self._linear(self.x, c.lin_r.weight)
             self._spmm(False, g.val, t_l, self.pre1, c.lin_l.bias, 1.0, x_self=t_r)
         else:
-            h1 = self._linear(self.x, c.lin_src.weight)
-            a_src, a_dst = ops.row_dots(h1, c.att_src, c.att_dst)
+            wsrc = c.lin_src.weight
+            if self._gat_dots and ops.rows_gemm_dots_ok(wsrc.shape[1], wsrc.shape[0]):
+                h1, a_src, a_dst = ops.rows_gemm_dots(self.x, wsrc, c.att_src, c.att_dst)   # logits from the epilogue
+            else:
+                h1 = self._linear(self.x, wsrc)
+                a_src, a_dst = ops.row_dots(h1, c.att_src, c.att_dst)
             ops.gat_forward_raw(g, h1, a_src, a_dst, c.bias, c.negative_slope, out=self.pre1)
 
     def _conv2_forward(self):
@@ -374,9 +379,14 @@ class NodeembEngine:
             t2 = self._linear_relu_z1(self._w2cat)              # [N, 2*O] = (t2_l | t2_r)
             self._spmm(False, self.graph.val, t2[:, :self.o], self.p2, c.lin_l.bias, 1.0, x_self=t2[:, self.o:])
         else:   # gat
-            h2 = self._linear_relu_z1(c.lin_src.weight)
+            wsrc = c.lin_src.weight
+            if self._gat_dots and self._split1 and ops.rows_gemm_dots_ok(wsrc.shape[1], wsrc.shape[0]):
+                h2, self._a_src, self._a_dst = ops.rows_gemm_dots(self.pre1, wsrc, c.att_src, c.att_dst, inp_alt=self.z1,
+                                                                  sel=self._sel1, relu_in=True)
+            else:
+                h2 = self._linear_relu_z1(wsrc)
+                self._a_src, self._a_dst = ops.row_dots(h2, c.att_src, c.att_dst)
             self._h2 = h2
-            self._a_src, self._a_dst = ops.row_dots(h2, c.att_src, c.att_dst)
             _, self._rowmax, self._rowsum = ops.gat_forward_raw(self.graph, h2, self._a_src, self._a_dst, c.bias,
                                                                 c.negative_slope, out=self.p2)
 

@@ -116,6 +116,34 @@ def rows_gemm_select(inp, inp_alt, sel, w, trans_w=False, bias=None, relu_in=Fal
     return out
 
 
+def rows_gemm_dots_ok(d_in, d_out):
+    """Whether fusing the row dots into the GEMM epilogue pays (the engine's choice; the entry itself takes 128 too)."""
+    # d_out <= 64: the 128-wide variant runs out of registers (spills: measured 7 % slower than the separate pass)
+    return d_in % 32 == 0 and d_out % 32 == 0 and d_out <= 64 and d_in * d_out * 4 <= 64 * 1024
+
+
+def rows_gemm_dots(inp, w, u1, u2, inp_alt=None, sel=None, relu_in=False, out=None):
+    """out = act(inp or inp_alt) @ w^T (w [d_out, d_in]) and, from the same pass, a1 = out @ u1, a2 = out @ u2
+    (gd_rows_gemm_dots_f32; MFMA widths only - see rows_gemm_dots_ok)."""
+    inp = _f32_rows(inp)
+    n, d_in = inp.shape
+    d_out = w.shape[0]
+    assert d_in % 32 == 0 and d_out % 32 == 0 and d_out <= 128 and d_in * d_out * 4 <= 64 * 1024 and w.shape[1] == d_in
+    if inp_alt is not None:
+        inp_alt = _f32_rows(inp_alt)
+        assert inp_alt.shape == inp.shape and inp_alt.stride(0) == inp.stride(0) and sel.dtype == torch.uint8
+    if out is None:
+        out = torch.empty(n, d_out, dtype=torch.float32, device=inp.device)
+    a1 = torch.empty(n, dtype=torch.float32, device=inp.device)
+    a2 = torch.empty(n, dtype=torch.float32, device=inp.device)
+    w = w.contiguous()
+    u1, u2 = u1.reshape(-1).contiguous(), u2.reshape(-1).contiguous()
+    check(_lib.lib().gd_rows_gemm_dots_f32(ptr(inp), ptr(inp_alt), ptr(sel), inp.stride(0), ptr(w), d_in, d_out, 1, None,
+                                           int(relu_in), ptr(out), out.stride(0), n, ptr(u1), ptr(u2), ptr(a1), ptr(a2),
+                                           stream_ptr(inp.device)), 'gd_rows_gemm_dots_f32')
+    return out, a1, a2
+
+
 def rows_gemm_wgrad(a, a_idx, g, g_idx, n_sel, relu_mask=None, out=None, accumulate=False, g_add=None):
     """dW[d_a, d_b] (+)= sum_s a[a_idx[s]]^T (mask(g) + g_add)[g_idx[s]] - raw call."""
     a, g = _f32_rows(a), _f32_rows(g)

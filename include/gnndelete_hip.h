@@ -224,6 +224,15 @@ int gd_rows_gemm_select_f32(const float* in, const float* in_alt, const uint8_t*
                             int32_t trans_w, const float* bias, int32_t relu_in,
                             float* out, int64_t ld_out, void* stream);
 
+/* Dense out = act(in or in_alt) @ W (+ bias) as gd_rows_gemm_select_f32 (sel / in_alt may be NULL), plus the two
+ * row dot products o1[r] = <out[r,:], u1>, o2[r] = <out[r,:], u2> from the epilogue: GATConv's lin_src followed by
+ * (x_src * att_src).sum(-1), (x_dst * att_dst).sum(-1) (framework/models/gat.py:11-12) without re-reading the rows
+ * just written.  MFMA path only (d_in, d_out multiples of 32, d_out <= 128, weight <= 64 KB). */
+int gd_rows_gemm_dots_f32(const float* in, const float* in_alt, const uint8_t* sel, int64_t ld_in, const float* w,
+                          int32_t d_in, int32_t d_out, int32_t trans_w, const float* bias, int32_t relu_in, float* out,
+                          int64_t ld_out, int32_t n_rows, const float* u1, const float* u2, float* o1, float* o2,
+                          void* stream);
+
 /* gd_rows_gemm_f32 that also emits the sign pattern of what it wrote, packed one bit per output
  * feature: sign_bits is compact [n_sel, ceil(d_out/32)] words, bit b of word k of entry s is set
  * iff out[idx[s], 32k + b] > 0.  With W = deletion_weight this is the ReLU gate of F.relu(x1)

@@ -637,3 +637,26 @@ def test_agg_gemm_matches_dense_closed_form(n, m, d_in, d_out, hub):
     untouched = torch.ones(n, dtype=torch.bool)
     untouched[rows.long()] = False
     assert float(out.cpu()[untouched].abs().max()) == 0.0 if untouched.any() else True
+
+
+@pytest.mark.parametrize('n,d_in,d_out,select', [(500, 128, 64, False), (500, 128, 64, True), (77, 64, 32, True),
+                                                 (300, 128, 128, False), (1, 32, 64, False)])
+def test_rows_gemm_dots_matches_fp64(n, d_in, d_out, select):
+    """gd_rows_gemm_dots_f32: h = act(x or x_alt) W^T and the two row dots <h, u1>, <h, u2> from its epilogue
+    (GATConv lin_src + attention logits, framework/models/gat.py:11-12)."""
+    from gnndelete_amd import ops
+    g = torch.Generator().manual_seed(n + d_out)
+    x = torch.randn(n, d_in, generator=g)
+    xa = torch.randn(n, d_in, generator=g)
+    sel = (torch.rand(n, generator=g) < 0.4).to(torch.uint8)
+    w = torch.randn(d_out, d_in, generator=g) / d_in ** 0.5
+    u1, u2 = torch.randn(d_out, generator=g), torch.randn(1, 1, d_out, generator=g)
+    src = torch.where(sel.bool()[:, None], xa, x) if select else x
+    if select:
+        src = src.clamp(min=0)
+    want = src.double() @ w.double().t()
+    h, a1, a2 = ops.rows_gemm_dots(x.cuda(), w.cuda(), u1.cuda(), u2.cuda(), inp_alt=xa.cuda() if select else None,
+                                   sel=sel.cuda() if select else None, relu_in=select)
+    assert rel_l2(h.cpu(), want) < TOL
+    assert rel_l2(a1.cpu(), want @ u1.double()) < TOL
+    assert rel_l2(a2.cpu(), want @ u2.double().reshape(-1)) < TOL
