@@ -99,13 +99,30 @@ class Trainer:
         mask = data.dtrain_mask if hasattr(data, 'dtrain_mask') else data.dr_mask
         return data.train_pos_edge_index[:, mask]
 
-    def _ensure_df_subsets(self, n_dr, k):
-        """500 random Dr subsets of size |Df|, drawn once with torch.randperm and reused."""
-        if len(self.df_pos_edge) == 0:
+    # above this many Dr edges the 500 subsets are drawn on the device (see _ensure_df_subsets)
+    FAST_SUBSETS_ABOVE = 1 << 18
+
+    def _ensure_df_subsets(self, n_dr, k, dev=None):
+        """500 random Dr subsets of size |Df|, drawn once and reused (base.py:263-268 upstream).
+
+        Up to FAST_SUBSETS_ABOVE Dr edges they are drawn exactly as upstream does - 500 x torch.randperm(n_dr) on
+        the host generator, kept as boolean masks in `self.df_pos_edge` - so the same seed gives the same subsets
+        (tests/test_cli_gpu.py pins them against the reference).  Beyond that (ogbl-size graphs: 2 M Dr edges make
+        those 500 host permutations 19 s of a 27 s unlearning request, and the masks 1 GB) the subsets come from
+        torch.randperm on the device, seeded from the host generator: the same statistic - the mean over 500
+        uniformly random |Df|-subsets of Dr - from a different random stream, kept as an index matrix only."""
+        if len(self.df_pos_edge) > 0:
+            return
+        if n_dr <= self.FAST_SUBSETS_ABOVE or dev is None or dev.type != 'cuda':
             for _ in range(500):
                 chosen = torch.zeros(n_dr, dtype=torch.bool)
                 chosen[torch.randperm(n_dr)[:k]] = True
                 self.df_pos_edge.append(chosen)
+            return
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,))))
+        self._df_subset_index = torch.stack([torch.randperm(n_dr, device=dev, generator=gen)[:k] for _ in range(500)])
+        self.df_pos_edge = [None] * 500          # placeholders: only the count is used on this path
 
     @torch.no_grad()
     def eval(self, model, data, stage='val', pred_all=False):
@@ -131,7 +148,7 @@ class Trainer:
 
         if len(df_logit) > 0:
             dr_edges = data.train_pos_edge_index[:, data.dr_mask]
-            self._ensure_df_subsets(dr_edges.shape[1], len(df_logit))
+            self._ensure_df_subsets(dr_edges.shape[1], len(df_logit), z.device)
             # one decode over all of Dr instead of 500 decodes of subsets (same scores), then the 500
             # resampled AUC / AUP as ONE batched sort on the device: Df labelled 0, Dr labelled 1
             k = len(df_logit)

@@ -83,7 +83,15 @@ class KGTrainer(Trainer):
             dr_edges, dr_types = data.train_pos_edge_index[:, half], data.train_edge_type[half]
             k = len(df_logit)
             dr_score = model.decode(z, dr_edges, dr_types).sigmoid()
-            picks = torch.stack([torch.randperm(dr_edges.shape[1])[:k].sort().values for _ in range(500)])
+            n_dr = dr_edges.shape[1]
+            if n_dr <= self.FAST_SUBSETS_ABOVE:
+                # upstream's 500 fresh host permutations per evaluation (base.py:530-539)
+                picks = torch.stack([torch.randperm(n_dr)[:k].sort().values for _ in range(500)])
+            else:
+                # ogbl-biokg size: the same statistic from device-side permutations (see Trainer._ensure_df_subsets)
+                gen = torch.Generator(device=dr_score.device)
+                gen.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,))))
+                picks = torch.stack([torch.randperm(n_dr, device=dr_score.device, generator=gen)[:k] for _ in range(500)])
             df_score = torch.tensor(df_logit, dtype=dr_score.dtype, device=dr_score.device)
             scores = torch.cat([df_score[None].expand(500, k), dr_score[picks.to(dr_score.device)]], dim=1)
             labels = torch.cat([torch.zeros(k), torch.ones(k)]).to(dr_score.device)

@@ -237,3 +237,28 @@ def test_node_unlearning_trainer_reproduces_reference_trajectory(tmp_path, monke
     np.testing.assert_allclose([v['val_loss'] for v in vals], rest['val_loss'], rtol=1e-4)
     tl = [r for r in tr.trainer_log['log'] if 'train_loss' in r]
     np.testing.assert_allclose([r['train_loss'] for r in tl], rest['train_loss'][[2, 5]], rtol=1e-4)
+
+
+def test_large_graph_df_subsets_are_drawn_on_the_device(monkeypatch):
+    """Above Trainer.FAST_SUBSETS_ABOVE Dr edges the 500 resampled Dr subsets come from device-side permutations
+    (same statistic, different random stream - upstream's 500 host permutations are 19 s per request at ogbl-collab
+    size): every subset has |Df| distinct in-range edges, the subsets differ, and the seed reproduces them."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework.trainer.base import Trainer
+    monkeypatch.setattr(Trainer, 'FAST_SUBSETS_ABOVE', 1000)
+    dev = torch.device('cuda')
+
+    def draw(seed):
+        torch.manual_seed(seed)
+        tr = Trainer.__new__(Trainer)
+        tr.df_pos_edge = []
+        tr._ensure_df_subsets(5000, 37, dev)
+        return tr
+
+    a, b, c = draw(3), draw(3), draw(4)
+    idx = a._df_subset_index
+    assert idx.shape == (500, 37) and idx.is_cuda and len(a.df_pos_edge) == 500
+    assert int(idx.min()) >= 0 and int(idx.max()) < 5000
+    assert all(len(set(r.tolist())) == 37 for r in idx[:20])
+    assert not torch.equal(idx[0], idx[1])
+    assert torch.equal(idx, b._df_subset_index) and not torch.equal(idx, c._df_subset_index)
