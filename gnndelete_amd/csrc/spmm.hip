@@ -178,6 +178,15 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
 #pragma unroll
       for (int v = 0; v < VPL; ++v) acc[v] = *reinterpret_cast<const float4*>(bb + lo[v]);
     }
+    // likewise a self / residual row with coefficient 1 (GraphSAGE's root term, GIN with eps = 0) is the
+    // initial value of lane group 1's accumulators; any other coefficient (or a row as wide as the wave, where
+    // there is no second group) is applied in the epilogue, one more round trip
+    const bool self_in_acc = self && G >= 2 && self_coef == 1.0f;
+    if (self_in_acc && g == 1) {
+      const char* sb0 = reinterpret_cast<const char*>(xs + (int64_t)row * ldx);
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) acc[v] = *reinterpret_cast<const float4*>(sb0 + lo[v]);
+    }
     const int trips = (cnt + G - 1) / G;
     // Slot j of the item (j = trip * G + g) is fetched from lane j of (c_cur, w_cur) through the LDS
     // crossbar (byte-addressed ds_bpermute, everything kept pre-multiplied by 4).  A wave64 x 16-byte load
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
       for (int v = 0; v < VPL; ++v) {
         if (!EXACT && li + v * LPR >= d4) continue;
         float4 o = acc[v];
-        if (self) o = f4_fma(self_coef, *reinterpret_cast<const float4*>(sb + lo[v]), o);
+        if (self && !self_in_acc) o = f4_fma(self_coef, *reinterpret_cast<const float4*>(sb + lo[v]), o);
         *reinterpret_cast<float4*>(ob + lo[v]) = o;
       }
     }
