@@ -433,16 +433,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int v = threadIdx.x & 15, slice = threadIdx.x >> 4;
   const int e4 = blockIdx.x * 16 + v;                     // float4 index
   const int n4 = n_elem >> 2;
-  float4 s0 = f4_zero(), s1 = f4_zero();
+  // same association as wgrad_reduce_adam_kernel (the two must agree bit for bit)
+  float4 s0 = f4_zero(), s1 = f4_zero(), s2 = f4_zero(), s3 = f4_zero();
   if (e4 < n4) {
     int b = slice;
-    for (; b + 16 < n_part; b += 32) {
-      s0 = f4_add(s0, reinterpret_cast<const float4*>(partials + (int64_t)b * n_elem)[e4]);
-      s1 = f4_add(s1, reinterpret_cast<const float4*>(partials + (int64_t)(b + 16) * n_elem)[e4]);
+    for (; b + 48 < n_part; b += 64) {
+      const float4 p0 = reinterpret_cast<const float4*>(partials + (int64_t)b * n_elem)[e4];
+      const float4 p1 = reinterpret_cast<const float4*>(partials + (int64_t)(b + 16) * n_elem)[e4];
+      const float4 p2 = reinterpret_cast<const float4*>(partials + (int64_t)(b + 32) * n_elem)[e4];
+      const float4 p3 = reinterpret_cast<const float4*>(partials + (int64_t)(b + 48) * n_elem)[e4];
+      s0 = f4_add(s0, p0); s1 = f4_add(s1, p1); s2 = f4_add(s2, p2); s3 = f4_add(s3, p3);
     }
-    if (b < n_part) s0 = f4_add(s0, reinterpret_cast<const float4*>(partials + (int64_t)b * n_elem)[e4]);
+    for (; b < n_part; b += 16) s0 = f4_add(s0, reinterpret_cast<const float4*>(partials + (int64_t)b * n_elem)[e4]);
   }
-  red[slice][v] = f4_add(s0, s1);
+  red[slice][v] = f4_add(f4_add(s0, s1), f4_add(s2, s3));
   __syncthreads();
   if (slice == 0 && e4 < n4) {
     float4 t = accumulate ? reinterpret_cast<float4*>(dw)[e4] : f4_zero();
@@ -464,16 +468,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_adam_kernel(const float* __r
   const int vv = threadIdx.x & 15, slice = threadIdx.x >> 4;
   const int e4 = blockIdx.x * 16 + vv;
   const int n4 = n_elem >> 2;
-  float4 s0 = f4_zero(), s1 = f4_zero();
+  // four partial rows in flight per thread (fixed association: s0 + s1 + s2 + s3 of the slice, then the slices)
+  float4 s0 = f4_zero(), s1 = f4_zero(), s2 = f4_zero(), s3 = f4_zero();
   if (e4 < n4) {
     int b = slice;
-    for (; b + 16 < n_part; b += 32) {
-      s0 = f4_add(s0, reinterpret_cast<const float4*>(partials + (int64_t)b * n_elem)[e4]);
-      s1 = f4_add(s1, reinterpret_cast<const float4*>(partials + (int64_t)(b + 16) * n_elem)[e4]);
+    for (; b + 48 < n_part; b += 64) {
+      const float4 p0 = reinterpret_cast<const float4*>(partials + (int64_t)b * n_elem)[e4];
+      const float4 p1 = reinterpret_cast<const float4*>(partials + (int64_t)(b + 16) * n_elem)[e4];
+      const float4 p2 = reinterpret_cast<const float4*>(partials + (int64_t)(b + 32) * n_elem)[e4];
+      const float4 p3 = reinterpret_cast<const float4*>(partials + (int64_t)(b + 48) * n_elem)[e4];
+      s0 = f4_add(s0, p0); s1 = f4_add(s1, p1); s2 = f4_add(s2, p2); s3 = f4_add(s3, p3);
     }
-    if (b < n_part) s0 = f4_add(s0, reinterpret_cast<const float4*>(partials + (int64_t)b * n_elem)[e4]);
+    for (; b < n_part; b += 16) s0 = f4_add(s0, reinterpret_cast<const float4*>(partials + (int64_t)b * n_elem)[e4]);
   }
-  red[slice][vv] = f4_add(s0, s1);
+  red[slice][vv] = f4_add(f4_add(s0, s1), f4_add(s2, s3));
   __syncthreads();
   if (slice == 0 && e4 < n4) {
     float4 t4 = accumulate ? reinterpret_cast<float4*>(dw)[e4] : f4_zero();
