@@ -267,7 +267,14 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int4* __restrict_
   const int row = sp.x, slot0 = sp.y, n = sp.z;
   for (int vec = lane; vec < d4; vec += kWave) {
     float4 o = f4_zero();
-    for (int s = 0; s < n; ++s) o = f4_add(o, reinterpret_cast<const float4*>(scratch + (int64_t)(slot0 + s) * d4 * 4)[vec]);
+    const float4* sp4 = reinterpret_cast<const float4*>(scratch + (int64_t)slot0 * d4 * 4) + vec;
+    int s = 0;
+    for (; s + 4 <= n; s += 4) {          // four pieces in flight, added in slot order (same sum as one by one)
+      const float4 p0 = sp4[(int64_t)s * d4], p1 = sp4[(int64_t)(s + 1) * d4], p2 = sp4[(int64_t)(s + 2) * d4],
+                   p3 = sp4[(int64_t)(s + 3) * d4];
+      o = f4_add(f4_add(f4_add(f4_add(o, p0), p1), p2), p3);
+    }
+    for (; s < n; ++s) o = f4_add(o, sp4[(int64_t)s * d4]);
     if (self_coef != 0.0f) o = f4_fma(self_coef, reinterpret_cast<const float4*>(x + (int64_t)row * ldx)[vec], o);
     if (bias) o = f4_add(o, reinterpret_cast<const float4*>(bias)[vec]);
     reinterpret_cast<float4*>(y + (int64_t)row * ldy)[vec] = o;
