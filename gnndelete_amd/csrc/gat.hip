@@ -375,16 +375,45 @@ __global__ __launch_bounds__(256) void gat_fixup_fwd_kernel(const int4* __restri
   if (i >= n_split) return;
   const int4 sp = split[i];
   const int row = sp.x, slot0 = sp.y, n = sp.z;
-  float mx = -INFINITY;
-  for (int s = 0; s < n; ++s) mx = fmaxf(mx, scratch_ms[2 * (slot0 + s)]);
-  float tot = 0.f;
-  for (int s = 0; s < n; ++s) tot += scratch_ms[2 * (slot0 + s) + 1] * expf(scratch_ms[2 * (slot0 + s)] - mx);
+  float mx, tot;
+  float f_lane = 0.f;                         // n <= 64: lane s holds piece s's rescale factor e^(m_s - M)
+  if (n <= kWave) {
+    // the pieces' (max, sum) pairs with one load per lane instead of three dependent passes over them
+    float m_s = -INFINITY, s_s = 0.f;
+    if (lane < n) {
+      const float2 ms = reinterpret_cast<const float2*>(scratch_ms)[slot0 + lane];
+      m_s = ms.x;
+      s_s = ms.y;
+    }
+    mx = wave_max(m_s);
+    f_lane = lane < n ? expf(m_s - mx) : 0.f;
+    tot = wave_sum(s_s * f_lane);
+  } else {
+    mx = -INFINITY;
+    for (int s = 0; s < n; ++s) mx = fmaxf(mx, scratch_ms[2 * (slot0 + s)]);
+    tot = 0.f;
+    for (int s = 0; s < n; ++s) tot += scratch_ms[2 * (slot0 + s) + 1] * expf(scratch_ms[2 * (slot0 + s)] - mx);
+  }
   const float inv = 1.0f / (tot + 1e-16f);
   for (int vec = lane; vec < d4; vec += kWave) {
     float4 o = f4_zero();
-    for (int s = 0; s < n; ++s) {
-      const float f = expf(scratch_ms[2 * (slot0 + s)] - mx);
-      o = f4_fma(f, reinterpret_cast<const float4*>(scratch + (int64_t)(slot0 + s) * d4 * 4)[vec], o);
+    const float4* sp4 = reinterpret_cast<const float4*>(scratch + (int64_t)slot0 * d4 * 4) + vec;
+    if (n <= kWave) {
+      int s = 0;
+      for (; s + 4 <= n; s += 4) {              // four pieces in flight, accumulated in slot order
+        const float4 p0 = sp4[(int64_t)s * d4], p1 = sp4[(int64_t)(s + 1) * d4], p2 = sp4[(int64_t)(s + 2) * d4],
+                     p3 = sp4[(int64_t)(s + 3) * d4];
+        o = f4_fma(__shfl(f_lane, s), p0, o);
+        o = f4_fma(__shfl(f_lane, s + 1), p1, o);
+        o = f4_fma(__shfl(f_lane, s + 2), p2, o);
+        o = f4_fma(__shfl(f_lane, s + 3), p3, o);
+      }
+      for (; s < n; ++s) o = f4_fma(__shfl(f_lane, s), sp4[(int64_t)s * d4], o);
+    } else {
+      for (int s = 0; s < n; ++s) {
+        const float f = expf(scratch_ms[2 * (slot0 + s)] - mx);
+        o = f4_fma(f, sp4[(int64_t)s * d4], o);
+      }
     }
     o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
     if (bias) o = f4_add(o, reinterpret_cast<const float4*>(bias)[vec]);
