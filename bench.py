@@ -185,9 +185,44 @@ def cpu_baseline(args, data, model_state, neg, iters):
     for _ in range(iters):
         R.nodeemb_epoch(m, fwd, targets, opt, args.loss_type, 0.5, R.LOSSES['mse_mean'])
     dt = time.perf_counter() - t0
-    return {'value': iters / dt, 'unit': 'iters/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{iters} full-graph iterations of the same request after 1 warm-up '
-                      f'({dt / iters:.2f} s each, torch CPU, {threads} of {os.cpu_count()} host threads - the fastest setting)'}
+    rec = {'value': iters / dt, 'unit': 'iters/s', 'cores': threads, 'kind': 'port',
+           'sample': f'{iters} full-graph iterations of the same request after 1 warm-up '
+                     f'({dt / iters:.2f} s each, torch CPU, {threads} of {os.cpu_count()} host threads - the fastest setting)'}
+    return rec, m, iters + 1
+
+
+def post_delete_parity(args, data, model, state, neg, ni1, ni2, device, cpu_model, n_iters):
+    """The metric's second half ("+ post-delete AUC"; north_star: AUC within +-0.002, affected-node embeddings
+    within 1e-4 rel-L2 on identical seeds): the HIP engine runs the SAME `n_iters` iterations the CPU oracle just
+    ran, from the same state with the same negatives; both models then embed the graph on the retained edges
+    (evaluation semantics of framework/trainer/base.py:238-249) and score the test edges."""
+    from gnndelete_amd.framework.metrics import batched_roc_auc
+    model.load_state_dict(state)
+    eng = make_engine(args, data, model, neg, ni1, ni2, device)
+    for _ in range(n_iters):
+        eng.step()
+    E = data.train_pos_edge_index
+    e_dr = E[:, data.dr_mask]
+    with torch.no_grad():
+        r1, r2 = cpu_model(data.x, e_dr, return_all_emb=True)
+        h1, h2 = model(data.x.to(device), e_dr.to(device).contiguous(), return_all_emb=True)
+
+    def rel(a, b):
+        return float((a.double().cpu() - b.double()).norm() / b.double().norm())
+
+    def auc(z, pos, neg_e):
+        ei = torch.cat([pos, neg_e], 1).to(z.device)
+        score = (z[ei[0]] * z[ei[1]]).sum(-1).sigmoid()
+        label = torch.cat([torch.ones(pos.shape[1]), torch.zeros(neg_e.shape[1])]).to(z.device)
+        return float(batched_roc_auc(score, label)[0])
+    m1, m2 = data.sdf_node_1hop_mask, data.sdf_node_2hop_mask
+    a_hip = auc(h2, data.test_pos_edge_index, data.test_neg_edge_index)
+    a_cpu = auc(r2, data.test_pos_edge_index, data.test_neg_edge_index)
+    return {'iterations': n_iters, 'test_auc_hip': a_hip, 'test_auc_cpu_oracle': a_cpu, 'abs_diff': abs(a_hip - a_cpu),
+            'tolerance': 0.002, 'z1_affected_rel_l2': rel(h1[m1.to(device)], r1[m1]),
+            'z2_affected_rel_l2': rel(h2[m2.to(device)], r2[m2]), 'embedding_tolerance': 1e-4,
+            'note': 'random-init backbone (no checkpoints offline): the AUC value itself is that of an untrained model; '
+                    'what is measured is HIP vs CPU oracle on identical state, negatives and iteration count'}
 
 
 def recorded_traffic(n, nnz, d):
@@ -365,8 +400,9 @@ def main():
             out.setdefault('extras', {})['roofline_del_gemm'] = time_del_gemm(eng)
         if not args.no_cpu_baseline and world == 1:
             cpu_data = data.clone().cpu() if hasattr(data, 'clone') else data
-            out['cpu_baseline'] = cpu_baseline(args, cpu_data, state, neg, args.cpu_baseline_iters)
+            out['cpu_baseline'], cpu_model, n_cpu = cpu_baseline(args, cpu_data, state, neg, args.cpu_baseline_iters)
             out['speedup_vs_cpu'] = out['value'] / out['cpu_baseline']['value']
+            out['post_delete_auc'] = post_delete_parity(args, cpu_data, model, state, neg, ni1, ni2, device, cpu_model, n_cpu)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
