@@ -7,13 +7,16 @@
 // only makes them time-share the CUs' wave slots.  Here every wave alternates between the
 // two phases on its own 16-row tile, so while some waves of a CU wait for gathered rows others feed the MFMA
 // pipe; the aggregated tile never leaves the CU (registers -> 8 KB of LDS -> MFMA operand registers).
+// Measured (DESIGN.md sections 7 and 9): layer 1 in 187 us against 205 us apart - not max(gather, MFMA), because
+// the gather path slows down with the clock once the matrix cores are busy.
 //
-//   phase A  the wave walks its tile's rows; a row of d_in floats is covered by LPR = d_in/4 lanes x float4, so
-//            G = 64/LPR neighbours are gathered per load instruction.  The loads of the NEXT batch (up to U
-//            instructions, possibly of the next row) are issued before the current batch is consumed: few waves
-//            per CU (the 64 KB weight image limits them to NW) but 2U loads in flight per wave, which the
-//            gather probe shows is enough (tools/experiments/gather_probe.hip: 8 waves/CU x 8 loads reach the
-//            rate of 32 waves/CU).  Row sums are reduced over the lane groups and written to the wave's tile.
+//   phase A  row-set walk: the G = 64 / LPR lane groups (LPR = d_in / 4 lanes x float4 cover a row) take G
+//            consecutive rows of the tile, one row each, and advance together - no reduction across groups, each
+//            group writes its own LDS row.  Batches of U = 8 gather instructions, all unconditional (padded trips
+//            re-read a cached row with weight 0) so that the s_waitcnt in front of a batch's consumer can leave
+//            the next batch in flight; two batches rotate.  Few waves per CU (the 64 KB weight image limits them
+//            to NW) but up to 16 loads in flight per wave, which the gather probe shows is enough
+//            (tools/experiments/gather_probe.hip: 8 waves/CU x 8 loads reach the rate of 32 waves/CU).
 //   phase B  D^T[feat][sample] = W[feat][k] . X^T[k][sample] with v_mfma_f32_16x16x4_f32: lane (n = l % 16,
 //            q = l / 16) holds sample n's features k in [KQ q, KQ q + KQ) (8 or 4 ds_read_b128 from the tile,
 //            conflict-free with the +4 pitch) and, per output tile, the weight image pre-permuted so that its
