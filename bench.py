@@ -396,6 +396,22 @@ def main():
                 ceng.step()
             torch.cuda.synchronize()
             out['extras'] = {'iters_per_s_with_loop_invariant_layer1_cached': args.steps / (time.perf_counter() - t1)}
+            # informational only: the step restricted to the rows the request can influence (identical results,
+            # DESIGN.md section 2), without and with the layer-1 cache - the latter is what the trainer runs
+            for key, cached in (('iters_per_s_affected_rows_only', False), ('iters_per_s_trainer_default', True)):
+                model.load_state_dict(state)
+                reng = NodeembEngine(*eng_args, loss_type=args.loss_type, alpha=0.5, lr=1e-3, cache_layer1=cached,
+                                     affected_rows_only=True)
+                if not getattr(reng, '_rows_only', False):
+                    continue
+                for _ in range(args.warmup):
+                    reng.step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                reng.run(args.steps, unroll=args.unroll)
+                torch.cuda.synchronize()
+                out['extras'][key] = args.steps / (time.perf_counter() - t1)
+            out['extras']['affected_rows'] = {'S2': int(data.sdf_node_2hop_mask.sum()), 'of': data.num_nodes}
         if world == 1 and hasattr(eng, 'idx1'):
             out.setdefault('extras', {})['roofline_del_gemm'] = time_del_gemm(eng)
         if not args.no_cpu_baseline and world == 1:

@@ -173,7 +173,7 @@ class NodeembEngine:
 
     def __init__(self, model, x, edge_index, z1_ori, z2_ori, pos_edge, neg_edge, ni_mask1, ni_mask2,
                  loss_type='both_layerwise', alpha=0.5, lr=1e-3, reduction='mean', mask_1hop=None, mask_2hop=None,
-                 use_graph=True, history=4096, reorder=True, cache_layer1=False):
+                 use_graph=True, history=4096, reorder=True, cache_layer1=False, affected_rows_only=False):
         assert loss_type in LOSS_TYPES, loss_type
         conv1, conv2 = model.conv1, model.conv2
         if not isinstance(conv2, (GCNConv, GINConv, GATConv, SAGEConv)):
@@ -293,6 +293,36 @@ class NodeembEngine:
         # Optional: the frozen layer-1 output p1 = conv1(x) is loop-invariant (fixed x, edges and
         # weights), so it can be computed once.  OFF by default: upstream recomputes it every epoch and
         # the benchmark's `value` is measured that way; the trainer turns it on (identical results).
+        # Affected rows only (GCN): the training graph holds the S_Df edges plus self loops, so a row outside the
+        # 2-hop set S2 neither reads nor feeds a row inside it and no loss term sees it - its transforms and
+        # aggregates influence nothing the iteration produces.  With this option every N-row kernel runs on the S2
+        # rows (the transposed aggregation on S1): identical Del weights and losses, cost proportional to the
+        # affected subgraph instead of the graph.  OFF by default (upstream computes every row and the benchmark's
+        # `value` is measured that way); the trainer turns it on.  Verified closed under the graph first.
+        self._rows_only = False
+        if affected_rows_only and self._mode == 'gcn' and self._split2 and self.s2 > 0:
+            g = self.graph
+            in2 = torch.zeros(n, dtype=torch.bool, device=dev)
+            in2[self.idx2.long()] = True
+            in1_rows = torch.zeros(n, dtype=torch.bool, device=dev)
+            in1_rows[self.idx1.long()] = True
+            deg = (g.rowptr[1:] - g.rowptr[:-1]).long()
+            erow = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+            closed = bool(in2[g.col.long()[in2[erow]]].all()) and bool(in2[self.idx1.long()].all())
+            deg_t = (g.rowptr_t[1:] - g.rowptr_t[:-1]).long()
+            erow_t = torch.repeat_interleave(torch.arange(n, device=dev), deg_t)
+            closed = closed and bool(in2[g.col_t.long()[in1_rows[erow_t]]].all())
+            if closed:
+                from .graph import SplitPlan
+                self._plan2 = SplitPlan(g.rowptr, rows=self.idx2)
+                self._plan_t1 = SplitPlan(g.rowptr_t, rows=self.idx1)
+                self._t1buf = torch.zeros(n, self.h, **f32)
+                self._t2buf = torch.zeros(n, self.o, **f32)
+                self._dt2buf = torch.zeros(n, self.o, **f32)
+                if self._split1:
+                    self.pre1.zero_()
+                self.p2.zero_()
+                self._rows_only = True
         self.cache_layer1 = cache_layer1
         # GCN layer 1 as ONE kernel, (A x) W1^T + b1 (= A (x W1^T) + b1 by linearity): the gather-bound
         # aggregation and the MFMA-bound transform share the CUs instead of following each other
@@ -339,6 +369,9 @@ class NodeembEngine:
         g = self.graph
         if self._mode == 'gcn' and self._fused_l1:
             ops.agg_gemm_items(g, self.x, c.lin.weight, c.bias, self._pre1_ext)
+        elif self._mode == 'gcn' and self._rows_only and self._split1:
+            ops.rows_gemm(self.x, self.idx2, c.lin.weight, trans_w=True, out=self._t1buf)
+            self._spmm(False, g.val, self._t1buf, self.pre1, c.bias, 0.0, plan=self._plan2)
         elif self._mode == 'gcn':
             self._spmm(False, g.val, self._linear(self.x, c.lin.weight), self.pre1, c.bias, 0.0)
         elif self._mode == 'gin':
@@ -365,7 +398,14 @@ class NodeembEngine:
 
     def _conv2_forward(self):
         c = self.model.conv2
-        if self._mode == 'gcn':
+        if self._mode == 'gcn' and self._rows_only:
+            if self._split1:
+                t2 = ops.rows_gemm_select(self.pre1, self.z1, self._sel1, c.lin.weight, trans_w=True, relu_in=True,
+                                          out=self._t2buf, idx=self.idx2)
+            else:       # layer 1 cached: z1 holds conv1's output with the Del'd rows written over it
+                t2 = ops.rows_gemm(self.z1, self.idx2, c.lin.weight, trans_w=True, relu_in=True, out=self._t2buf)
+            self._spmm(False, self.graph.val, t2, self.p2, c.bias, 0.0, plan=self._plan2)
+        elif self._mode == 'gcn':
             t2 = self._linear_relu_z1(c.lin.weight)
             self._spmm(False, self.graph.val, t2, self.p2, c.bias, 0.0)
         elif self._mode == 'gin':
@@ -399,7 +439,11 @@ class NodeembEngine:
             dt2, w2 = self.dcat, self._w2cat
         elif self._mode in ('gcn', 'gin'):
             dt2 = torch.empty(self.n, self.o, dtype=torch.float32, device=self.x.device)
-            if self._mode == 'gcn':
+            if self._mode == 'gcn' and self._rows_only:
+                dt2 = self._dt2buf
+                self._spmm(True, g.val_t, self.dz2, dt2, None, 0.0, plan=self._plan_t1)
+                w2 = c.lin.weight
+            elif self._mode == 'gcn':
                 self._spmm(True, g.val_t, self.dz2, dt2, None, 0.0)
                 w2 = c.lin.weight
             else:
@@ -414,12 +458,12 @@ class NodeembEngine:
         # ReLU backward is applied in the GEMM epilogue so dh can outlive this iteration's z1)
         ops.rows_gemm(dt2, self.idx1, w2, trans_w=False, out=self.dh, gate_bits=self.z1_pos)
 
-    def _spmm(self, transposed, val, x, y, bias, self_coef, x_self=None):
+    def _spmm(self, transposed, val, x, y, bias, self_coef, x_self=None, plan=None):
         g = self.graph
         if transposed:
-            ops._spmm_raw(g.rowptr_t, g.col_t, val, x, bias, self_coef, self.n, g.plan_t, out=y, x_self=x_self)
+            ops._spmm_raw(g.rowptr_t, g.col_t, val, x, bias, self_coef, self.n, plan or g.plan_t, out=y, x_self=x_self)
         else:
-            ops._spmm_raw(g.rowptr, g.col, val, x, bias, self_coef, self.n, g.plan, out=y, x_self=x_self)
+            ops._spmm_raw(g.rowptr, g.col, val, x, bias, self_coef, self.n, plan or g.plan, out=y, x_self=x_self)
 
     def _wgrad(self, a_compact, g, g_idx, n_sel, out, accumulate, ws, adam=None, g_add=None, a_idx=None):
         """out (+)= a^T (g + g_add) over the selected rows; with `adam` the optimizer update of that Del

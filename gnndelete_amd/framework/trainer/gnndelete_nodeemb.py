@@ -197,7 +197,8 @@ class _EmbeddingUnlearner:
                                    loss_type=loss_type, alpha=self.args.alpha, lr=lr,
                                    reduction='mean' if loss_name == 'mse_mean' else 'sum',
                                    history=max(16, args.epochs),
-                                   cache_layer1=not getattr(args, 'no_layer1_cache', False))
+                                   cache_layer1=not getattr(args, 'no_layer1_cache', False),
+                                   affected_rows_only=not getattr(args, 'all_rows', False))
             engine.adam1.betas = engine.adam2.betas = betas
             engine.adam1.eps = engine.adam2.eps = eps
         loss_fct = get_loss_fct(loss_name)

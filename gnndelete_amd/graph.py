@@ -21,28 +21,34 @@ class SplitPlan:
     """Work items of the load-balanced SpMM (gd_spmm_csr_balanced_f32): every CSR row is cut
     into pieces of at most CHUNK in-edges so that hub rows are spread over many waves."""
 
-    def __init__(self, rowptr, chunk=CHUNK, row_range=None):
+    def __init__(self, rowptr, chunk=CHUNK, row_range=None, rows=None):
         """row_range=(lo, hi) keeps only the rows lo <= i < hi (a rank's share of a 1-D
-        row partition); item rows stay global ids."""
+        row partition); rows = a sorted list of row ids keeps only those (the rows an unlearning request
+        can influence); item rows stay global ids."""
         dev = rowptr.device
-        lo, hi = (0, rowptr.numel() - 1) if row_range is None else row_range
-        rp = rowptr.long()[lo:hi + 1]
-        n = rp.numel() - 1
-        deg = rp[1:] - rp[:-1]
+        rpl = rowptr.long()
+        if rows is not None:
+            ids = rows.long()
+        else:
+            lo, hi = (0, rowptr.numel() - 1) if row_range is None else row_range
+            ids = torch.arange(lo, hi, device=dev)
+        r_start, r_end = rpl[ids], rpl[ids + 1]
+        n = ids.numel()
+        deg = r_end - r_start
         pieces = torch.clamp((deg + chunk - 1) // chunk, min=1)
         first = torch.cumsum(pieces, 0) - pieces
         row = torch.repeat_interleave(torch.arange(n, device=dev), pieces)
         k = torch.arange(row.numel(), device=dev) - first[row]
-        start = rp[row] + k * chunk
-        end = torch.minimum(rp[row + 1], start + chunk)
+        start = r_start[row] + k * chunk
+        end = torch.minimum(r_end[row], start + chunk)
         is_split = pieces[row] > 1
         slot = torch.where(is_split, torch.cumsum(is_split, 0) - 1, torch.full_like(row, -1))
-        self.items = torch.stack([row + lo, start, end, slot], 1).to(torch.int32).contiguous()
+        self.items = torch.stack([ids[row], start, end, slot], 1).to(torch.int32).contiguous()
         self.n_items = int(row.numel())
         srows = (pieces > 1).nonzero().flatten()
         split_pieces = torch.where(pieces > 1, pieces, torch.zeros_like(pieces))
         slot0 = (torch.cumsum(split_pieces, 0) - split_pieces)[srows]
-        self.split = torch.stack([srows + lo, slot0, pieces[srows], torch.zeros_like(srows)], 1).to(torch.int32).contiguous()
+        self.split = torch.stack([ids[srows], slot0, pieces[srows], torch.zeros_like(srows)], 1).to(torch.int32).contiguous()
         self.n_split = int(srows.numel())
         self.n_slots = int(split_pieces.sum())
         self._scratch = {}

@@ -101,8 +101,9 @@ def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, sa
     return out
 
 
-def rows_gemm_select(inp, inp_alt, sel, w, trans_w=False, bias=None, relu_in=False, out=None):
-    """Dense rows_gemm over a matrix split across two buffers: row r comes from inp_alt where sel[r] (uint8)."""
+def rows_gemm_select(inp, inp_alt, sel, w, trans_w=False, bias=None, relu_in=False, out=None, idx=None):
+    """rows_gemm over a matrix split across two buffers: row r comes from inp_alt where sel[r] (uint8); all rows,
+    or the rows listed in idx (int32, written to the same rows of out)."""
     inp, inp_alt = _f32_rows(inp), _f32_rows(inp_alt)
     assert inp.shape == inp_alt.shape and inp.stride(0) == inp_alt.stride(0) and sel.dtype == torch.uint8
     n, d_in = inp.shape
@@ -110,7 +111,9 @@ def rows_gemm_select(inp, inp_alt, sel, w, trans_w=False, bias=None, relu_in=Fal
     if out is None:
         out = torch.empty(n, d_out, dtype=torch.float32, device=inp.device)
     w = w.contiguous()
-    check(_lib.lib().gd_rows_gemm_select_f32(ptr(inp), ptr(inp_alt), ptr(sel), inp.stride(0), None, n, ptr(w), d_in,
+    if idx is not None:
+        n = int(idx.shape[0])
+    check(_lib.lib().gd_rows_gemm_select_f32(ptr(inp), ptr(inp_alt), ptr(sel), inp.stride(0), ptr(idx), n, ptr(w), d_in,
                                              d_out, int(trans_w), ptr(bias), int(relu_in), ptr(out), out.stride(0),
                                              stream_ptr(inp.device)), 'gd_rows_gemm_select_f32')
     return out

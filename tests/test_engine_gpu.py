@@ -332,3 +332,33 @@ def test_gat_engine_at_kernel_native_widths_matches_oracle_training(loss_type):
         np.testing.assert_allclose(hist[:, col], [l[key] for l in logs], rtol=1e-4, atol=1e-8, err_msg=key)
     assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), mo.deletion1.deletion_weight.detach()) < 1e-4
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
+
+
+@pytest.mark.parametrize('cache_layer1', [False, True])
+@pytest.mark.parametrize('loss_type', ['both_all', 'only2_layerwise'])
+def test_affected_rows_only_reproduces_reference_trajectory(loss_type, cache_layer1):
+    """affected_rows_only=True: every N-row kernel of the GCN step runs on the S2 rows only (S1 for the transposed
+    aggregation) - rows outside cannot influence any loss term - and the trajectory recorded from the reference's
+    real loop is reproduced exactly as with all rows."""
+    from gnndelete_amd.engine import NodeembEngine
+    from oracle import gnndelete_ref as R
+    fx = load_golden(f'traj_gcn_{loss_type}.npz')
+    state, data, rest = split_fixture(fx)
+    m = hip_model('gcn', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    E = dev['train_pos_edge_index']
+    ni1, ni2 = R.non_df_masks(data['x'].shape[0], data['directed_df_edge_index'], data['sdf_node_1hop_mask'],
+                              data['sdf_node_2hop_mask'])
+    with torch.no_grad():
+        z1o, z2o = m.get_original_embeddings(dev['x'], E[:, dev['dr_mask']], return_all_emb=True)
+    eng = NodeembEngine(m, dev['x'], E[:, dev['sdf_mask']].contiguous(), z1o, z2o, E[:, dev['df_mask']],
+                        t(rest['neg']).cuda(), ni1, ni2, loss_type=loss_type, alpha=float(rest['alpha']),
+                        lr=float(rest['lr']), cache_layer1=cache_layer1, affected_rows_only=True)
+    assert eng._rows_only and eng.s2 < eng.n
+    for _ in range(int(rest['epochs'])):
+        eng.step()
+    hist = eng.loss_history().numpy()
+    for col, key in enumerate(['train_loss', 'loss_r', 'loss_l']):
+        np.testing.assert_allclose(hist[:, col], rest[key], rtol=1e-4, atol=1e-8, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), rest['final_w1']) < 1e-4
+    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < 1e-4
