@@ -335,16 +335,16 @@ def test_gat_engine_at_kernel_native_widths_matches_oracle_training(loss_type):
 
 
 @pytest.mark.parametrize('cache_layer1', [False, True])
-@pytest.mark.parametrize('loss_type', ['both_all', 'only2_layerwise'])
-def test_affected_rows_only_reproduces_reference_trajectory(loss_type, cache_layer1):
+@pytest.mark.parametrize('gnn,loss_type', [('gcn', 'both_all'), ('gcn', 'only2_layerwise')])
+def test_affected_rows_only_reproduces_reference_trajectory(gnn, loss_type, cache_layer1):
     """affected_rows_only=True: every N-row kernel of the GCN step runs on the S2 rows only (S1 for the transposed
     aggregation) - rows outside cannot influence any loss term - and the trajectory recorded from the reference's
     real loop is reproduced exactly as with all rows."""
     from gnndelete_amd.engine import NodeembEngine
     from oracle import gnndelete_ref as R
-    fx = load_golden(f'traj_gcn_{loss_type}.npz')
+    fx = load_golden(f'traj_{gnn}_{loss_type}.npz')
     state, data, rest = split_fixture(fx)
-    m = hip_model('gcn', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    m = hip_model(gnn, state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
     dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
     E = dev['train_pos_edge_index']
     ni1, ni2 = R.non_df_masks(data['x'].shape[0], data['directed_df_edge_index'], data['sdf_node_1hop_mask'],
@@ -362,3 +362,37 @@ def test_affected_rows_only_reproduces_reference_trajectory(loss_type, cache_lay
         np.testing.assert_allclose(hist[:, col], rest[key], rtol=1e-4, atol=1e-8, err_msg=key)
     assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), rest['final_w1']) < 1e-4
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < 1e-4
+
+
+@pytest.mark.parametrize('cache_layer1', [False, True])
+def test_gin_affected_rows_only_matches_oracle_training(cache_layer1):
+    """GIN with affected_rows_only on a request at kernel-native widths (128 -> 128 -> 64; the golden GIN fixture
+    widens its input, which takes the aggregate-first path the option does not cover): trajectory against autograd
+    on the CPU oracle with the reference's update rules."""
+    from gnndelete_amd.engine import NodeembEngine
+    from oracle import gnndelete_ref as R
+    fx = load_golden('traj_gin_both_layerwise.npz')
+    _, data, rest = split_fixture(fx)
+    n = data['x'].shape[0]
+    torch.manual_seed(9)
+    data = dict(data, x=torch.randn(n, 128) * 0.3)
+    mo = R.TwoLayerDelete('gin', 128, 128, 64, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    state = {k: v.clone() for k, v in mo.state_dict().items()}
+    m = hip_model('gin', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    logs, _ = R.nodeemb_fullbatch(mo, data, 6, 'both_layerwise', 0.4, 'mse_mean', 0.01, neg_edge=t(rest['neg']))
+    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    E = dev['train_pos_edge_index']
+    ni1, ni2 = R.non_df_masks(n, data['directed_df_edge_index'], data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    with torch.no_grad():
+        z1o, z2o = m.get_original_embeddings(dev['x'], E[:, dev['dr_mask']], return_all_emb=True)
+    eng = NodeembEngine(m, dev['x'], E[:, dev['sdf_mask']].contiguous(), z1o, z2o, E[:, dev['df_mask']],
+                        t(rest['neg']).cuda(), ni1, ni2, loss_type='both_layerwise', alpha=0.4, lr=0.01,
+                        cache_layer1=cache_layer1, affected_rows_only=True)
+    assert eng._rows_only
+    for _ in range(6):
+        eng.step()
+    hist = eng.loss_history().numpy()
+    for col, key in enumerate(['train_loss', 'loss_r', 'loss_l']):
+        np.testing.assert_allclose(hist[:, col], [l[key] for l in logs], rtol=1e-4, atol=1e-8, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), mo.deletion1.deletion_weight.detach()) < 1e-4
+    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
