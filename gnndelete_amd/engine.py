@@ -293,7 +293,7 @@ class NodeembEngine:
         # Optional: the frozen layer-1 output p1 = conv1(x) is loop-invariant (fixed x, edges and
         # weights), so it can be computed once.  OFF by default: upstream recomputes it every epoch and
         # the benchmark's `value` is measured that way; the trainer turns it on (identical results).
-        # Affected rows only (GCN, GIN): the training graph holds the S_Df edges plus self loops, so a row outside the
+        # Affected rows only (GCN, GIN; GAT: its aggregation kernels): the training graph holds the S_Df edges plus self loops, so a row outside the
         # 2-hop set S2 neither reads nor feeds a row inside it and no loss term sees it - its transforms and
         # aggregates influence nothing the iteration produces.  With this option every N-row kernel runs on the S2
         # rows (the transposed aggregation on S1): identical Del weights and losses, cost proportional to the
@@ -301,7 +301,7 @@ class NodeembEngine:
         # `value` is measured that way); the trainer turns it on.  Verified closed under the graph first.
         self._rows_only = False
         gin_ok = self._mode == 'gin' and conv1.nn.out_features <= conv1.nn.in_features and conv2.nn.out_features <= conv2.nn.in_features
-        if affected_rows_only and (self._mode == 'gcn' or gin_ok) and self._split2 and self.s2 > 0:
+        if affected_rows_only and (self._mode in ('gcn', 'gat') or gin_ok) and self._split2 and self.s2 > 0:
             g = self.graph
             in2 = torch.zeros(n, dtype=torch.bool, device=dev)
             in2[self.idx2.long()] = True
@@ -399,7 +399,8 @@ class NodeembEngine:
             else:
                 h1 = self._linear(self.x, wsrc)
                 a_src, a_dst = ops.row_dots(h1, c.att_src, c.att_dst)
-            ops.gat_forward_raw(g, h1, a_src, a_dst, c.bias, c.negative_slope, out=self.pre1)
+            ops.gat_forward_raw(g, h1, a_src, a_dst, c.bias, c.negative_slope, out=self.pre1,
+                                plan=self._plan2 if (self._rows_only and self._split1) else None)
 
     def _conv2_forward(self):
         c = self.model.conv2
@@ -441,7 +442,8 @@ class NodeembEngine:
                 self._a_src, self._a_dst = ops.row_dots(h2, c.att_src, c.att_dst)
             self._h2 = h2
             _, self._rowmax, self._rowsum = ops.gat_forward_raw(self.graph, h2, self._a_src, self._a_dst, c.bias,
-                                                                c.negative_slope, out=self.p2)
+                                                                c.negative_slope, out=self.p2,
+                                                                plan=self._plan2 if self._rows_only else None)
 
     def _conv2_backward_to_s1(self):
         """dh[S1] = d loss2 / d z1 (post-Del, pre-ReLU) restricted to the S1 rows (all that Del-1 needs)."""
@@ -468,7 +470,9 @@ class NodeembEngine:
                 w2 = c.nn.weight
         else:
             dt2, da_s, da_d = ops.gat_backward_raw(g, self._h2, self._a_src, self._a_dst, self._rowmax, self._rowsum,
-                                                   self.dz2, c.negative_slope)
+                                                   self.dz2, c.negative_slope,
+                                                   plan=self._plan2 if self._rows_only else None,
+                                                   plan_t=self._plan_t1 if self._rows_only else None)
             ops.rank1_add2_(dt2, da_s, c.att_src, da_d, c.att_dst)
             w2 = c.lin_src.weight
         # dh[S1] = (dt2[S1] @ W2) * [z1[S1] > 0]   (W2 is [out, in] = [d_in, d_out] of this product; the

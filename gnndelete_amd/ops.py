@@ -205,12 +205,12 @@ def _pow2(d):
     return d >= 4 and (d & (d - 1)) == 0 and d <= 1024
 
 
-def gat_forward_raw(graph, h, a_src, a_dst, bias, slope, out=None):
+def gat_forward_raw(graph, h, a_src, a_dst, bias, slope, out=None, plan=None):
     """Fused edge-softmax aggregation; returns (y, rowmax, rowsum) - balanced kernels when the
     width allows, else the one-wave-per-row kernel (then rowmax is the saved alpha, rowsum None)."""
     n, d = graph.n, h.shape[1]
     y = out if out is not None else torch.empty(n, d, dtype=torch.float32, device=h.device)
-    plan = graph.plan
+    plan = plan or graph.plan               # a plan over a row subset: only those rows of y / rowmax / rowsum are written
     if _pow2(d) and h.stride(0) % 4 == 0:
         rowmax = torch.empty(n, dtype=torch.float32, device=h.device)
         rowsum = torch.empty(n, dtype=torch.float32, device=h.device)
@@ -227,8 +227,9 @@ def gat_forward_raw(graph, h, a_src, a_dst, bias, slope, out=None):
     return y, alpha, None
 
 
-def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope):
-    """-> (dh message path, da_src, da_dst)."""
+def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope, plan=None, plan_t=None):
+    """-> (dh message path, da_src, da_dst).  plan / plan_t: work items of a row subset for the target-major edge
+    gradients and the source-major aggregation (rows outside are not produced)."""
     g = graph
     n, d = g.n, h.shape[1]
     dev = h.device
@@ -243,8 +244,12 @@ def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope):
             ptr(a_dst), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(dh), dh.stride(0), ptr(da_src), ptr(da_dst),
             ptr(de), float(slope), n, d, stream_ptr(dev)), 'gd_gat_aggregate_bwd_f32')
         return dh, da_src, da_dst
-    plan = g.plan
-    alpha = torch.empty(g.nnz, dtype=torch.float32, device=dev)
+    subset = plan is not None
+    plan = plan or g.plan
+    # (edges of rows outside a subset are never computed: keep them finite for the transposition pass)
+    alpha = (torch.zeros if subset else torch.empty)(g.nnz, dtype=torch.float32, device=dev)
+    if subset:
+        de.zero_()
     t_row = torch.empty(n, dtype=torch.float32, device=dev)
     scratch = plan.scratch_flat('gat_bwd', max(4, plan.n_slots), dev)
     check(_lib.lib().gd_gat_edge_grads_balanced_f32(
@@ -255,7 +260,7 @@ def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope):
     da_src = torch.empty(n, dtype=torch.float32, device=dev)
     check(_lib.lib().gd_gat_transpose_edges_f32(ptr(g.rowptr_t), ptr(g.perm_t), ptr(alpha), ptr(de), n, ptr(alpha_t),
                                                 ptr(da_src), stream_ptr(dev)), 'gd_gat_transpose_edges_f32')
-    dh = _spmm_raw(g.rowptr_t, g.col_t, alpha_t, dy, None, 0.0, n, g.plan_t)
+    dh = _spmm_raw(g.rowptr_t, g.col_t, alpha_t, dy, None, 0.0, n, plan_t or g.plan_t)
     return dh, da_src, da_dst
 
 

@@ -335,7 +335,8 @@ def test_gat_engine_at_kernel_native_widths_matches_oracle_training(loss_type):
 
 
 @pytest.mark.parametrize('cache_layer1', [False, True])
-@pytest.mark.parametrize('gnn,loss_type', [('gcn', 'both_all'), ('gcn', 'only2_layerwise')])
+@pytest.mark.parametrize('gnn,loss_type', [('gcn', 'both_all'), ('gcn', 'only2_layerwise'), ('gat', 'both_layerwise'),
+                                           ('gat', 'both_all')])
 def test_affected_rows_only_reproduces_reference_trajectory(gnn, loss_type, cache_layer1):
     """affected_rows_only=True: every N-row kernel of the GCN step runs on the S2 rows only (S1 for the transposed
     aggregation) - rows outside cannot influence any loss term - and the trajectory recorded from the reference's
