@@ -70,3 +70,12 @@ def test_cpu_tensors_are_rejected_by_the_ops():
     from gnndelete_amd import _lib, ops
     with pytest.raises(_lib.GnnDeleteHipError):
         ops.rows_gemm(torch.zeros(4, 32), None, torch.zeros(32, 32))
+
+
+def test_csr_from_coo_rejects_sizes_outside_the_int32_range():
+    """Argument validation of gd_csr_from_coo_workspace needs no GPU: edge counts the int32 CSR cannot index."""
+    from gnndelete_amd import _lib
+    L = _lib.lib()
+    assert L.gd_csr_from_coo_workspace(10, 2 ** 31) == -1
+    assert L.gd_csr_from_coo_workspace(-1, 5) == -1
+    assert L.gd_csr_from_coo_workspace(10, 0) == 256
