@@ -397,3 +397,43 @@ def test_gin_affected_rows_only_matches_oracle_training(cache_layer1):
         np.testing.assert_allclose(hist[:, col], [l[key] for l in logs], rtol=1e-4, atol=1e-8, err_msg=key)
     assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), mo.deletion1.deletion_weight.detach()) < 1e-4
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
+
+
+@pytest.mark.parametrize('cache_layer1', [False, True])
+def test_sage_affected_rows_only_matches_oracle_training(cache_layer1, loss_type='both_layerwise', use_graph=True):
+    """GraphSAGE (BASELINE.json config 3; not in the reference, so the oracle restatement is the
+    yardstick): the fused step - stacked [W_l; W_r] product, mean SpMM with the root term in its
+    epilogue, (A^T dp2 | dp2) x [W_l; W_r] input gradient - against autograd on the CPU oracle with
+    the reference's update rules, on the graph / request of a golden fixture."""
+    from gnndelete_amd.engine import NodeembEngine
+    from oracle import gnndelete_ref as R
+    fx = load_golden('traj_gcn_both_all.npz')
+    _, data, rest = split_fixture(fx)
+    n, f = data['x'].shape
+    torch.manual_seed(11)
+    mo = R.TwoLayerDelete('sage', f, 128, 64, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    with torch.no_grad():
+        for name, p in mo.named_parameters():
+            if name.endswith('bias'):
+                p.copy_(torch.randn_like(p) * 0.1)
+    state = {k: v.clone() for k, v in mo.state_dict().items()}
+    m = hip_model('sage', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    logs, _ = R.nodeemb_fullbatch(mo, data, 6, loss_type, 0.4, 'mse_mean', 0.01, neg_edge=t(rest['neg']))
+
+    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    E = dev['train_pos_edge_index']
+    ni1, ni2 = R.non_df_masks(n, data['directed_df_edge_index'], data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    with torch.no_grad():
+        z1o, z2o = m.get_original_embeddings(dev['x'], E[:, dev['dr_mask']], return_all_emb=True)
+    eng = NodeembEngine(m, dev['x'], E[:, dev['sdf_mask']].contiguous(), z1o, z2o, E[:, dev['df_mask']],
+                        t(rest['neg']).cuda(), ni1, ni2, loss_type=loss_type, alpha=0.4, lr=0.01, use_graph=use_graph, cache_layer1=cache_layer1,
+                        affected_rows_only=True)
+    assert eng._rows_only
+    for _ in range(6):
+        eng.step()
+    hist = eng.loss_history().numpy()
+    for col, key in enumerate(['train_loss', 'loss_r', 'loss_l']):
+        np.testing.assert_allclose(hist[:, col], [l[key] for l in logs], rtol=1e-4, atol=1e-8, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), mo.deletion1.deletion_weight.detach()) < 1e-4
+    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
+
