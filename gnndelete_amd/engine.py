@@ -348,6 +348,11 @@ class NodeembEngine:
                     self.xs1.copy_(self.p1[self.idx1.long()])
 
     # ------------------------------------------------------------------ pieces
+    @staticmethod
+    def _mfma_weight(weight):
+        out_f, in_f = weight.shape
+        return in_f % 32 == 0 and out_f % 32 == 0 and out_f <= 128 and in_f * out_f * 4 <= 64 * 1024
+
     def _linear(self, x, weight, relu_in=False):
         """x @ weight^T: the MFMA row kernel when the weight fits its LDS image, else rocBLAS."""
         out_f, in_f = weight.shape
@@ -371,12 +376,12 @@ class NodeembEngine:
         g = self.graph
         if self._mode == 'gcn' and self._fused_l1:
             ops.agg_gemm_items(g, self.x, c.lin.weight, c.bias, self._pre1_ext)
-        elif self._mode == 'gcn' and self._rows_only and self._split1:
+        elif self._mode == 'gcn' and self._rows_only and self._split1 and self._mfma_weight(c.lin.weight):
             ops.rows_gemm(self.x, self.idx2, c.lin.weight, trans_w=True, out=self._t1buf)
             self._spmm(False, g.val, self._t1buf, self.pre1, c.bias, 0.0, plan=self._plan2)
         elif self._mode == 'gcn':
             self._spmm(False, g.val, self._linear(self.x, c.lin.weight), self.pre1, c.bias, 0.0)
-        elif self._mode == 'gin' and self._rows_only and self._split1:
+        elif self._mode == 'gin' and self._rows_only and self._split1 and self._mfma_weight(c.nn.weight):
             lin = c.nn
             ops.rows_gemm(self.x, self.idx2, lin.weight, trans_w=True, out=self._t1buf)
             self._spmm(False, None, self._t1buf, self.pre1, lin.bias, 1.0 + c.eps, plan=self._plan2)
@@ -388,7 +393,7 @@ class NodeembEngine:
                 agg = torch.empty_like(self.x)
                 self._spmm(False, None, self.x, agg, None, 1.0 + c.eps)
                 self.pre1.copy_(torch.nn.functional.linear(agg, lin.weight, lin.bias))
-        elif self._mode == 'sage' and self._rows_only and self._split1:
+        elif self._mode == 'sage' and self._rows_only and self._split1 and self._mfma_weight(c.lin_l.weight):
             ops.rows_gemm(self.x, self.idx2, c.lin_l.weight, trans_w=True, out=self._t1buf)
             ops.rows_gemm(self.x, self.idx2, c.lin_r.weight, trans_w=True, out=self._t1rbuf)
             self._spmm(False, g.val, self._t1buf, self.pre1, c.lin_l.bias, 1.0, x_self=self._t1rbuf, plan=self._plan2)
