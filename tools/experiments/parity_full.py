@@ -27,7 +27,8 @@ for _ in range(epochs):
 t_cpu = time.time() - t0
 from gnndelete_amd.engine import NodeembEngine
 hip = model.to(dev)
-eng = NodeembEngine(hip, data.x.to(dev), e_sdf.to(dev).contiguous(), z1o.to(dev), z2o.to(dev), E[:, data.df_mask].to(dev), neg.to(dev), ni1, ni2, loss_type=args.loss_type, alpha=0.5, lr=lr)
+eng = NodeembEngine(hip, data.x.to(dev), e_sdf.to(dev).contiguous(), z1o.to(dev), z2o.to(dev), E[:, data.df_mask].to(dev), neg.to(dev), ni1, ni2, loss_type=args.loss_type, alpha=0.5, lr=lr,
+                    cache_layer1=os.environ.get('TRAINER_DEFAULTS') == '1', affected_rows_only=os.environ.get('TRAINER_DEFAULTS') == '1')
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(epochs): eng.step()
 torch.cuda.synchronize(); t_gpu = time.time() - t0
