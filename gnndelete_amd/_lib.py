@@ -42,7 +42,8 @@ PROTOTYPES = {
     'gd_rows_gemm_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _i64, _p, _p]),
     'gd_rows_gemm_wgrad_workspace': (_i64, [_i32, _i32, _i32]),
     'gd_rows_gemm_select_f32': (ctypes.c_int, [_p, _p, _p, _i64, _p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _i64, _p]),
-    'gd_rows_gemm_dots_f32': (ctypes.c_int, [_p, _p, _p, _i64, _p, _i32, _i32, _i32, _p, _i32, _p, _i64, _i32, _p, _p, _p, _p, _p]),
+    'gd_rows_gemm_dots_f32': (ctypes.c_int, [_p, _p, _p, _i64, _p, _i32, _i32, _i32, _p, _i32, _p, _i64, _p, _i32, _p, _p, _p, _p,
+                                             _p]),
     'gd_rows_gemm_signs_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _i64, _p, _p, _p]),
     'gd_rows_gemm_gated_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _i64, _p]),
     'gd_rows_gemm_wgrad_f32': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p]),

@@ -604,13 +604,13 @@ extern "C" int gd_rows_gemm_select_f32(const float* in, const float* in_alt, con
 
 extern "C" int gd_rows_gemm_dots_f32(const float* in, const float* in_alt, const uint8_t* sel, int64_t ld_in,
                                      const float* w, int32_t d_in, int32_t d_out, int32_t trans_w, const float* bias,
-                                     int32_t relu_in, float* out, int64_t ld_out, int32_t n_rows, const float* u1,
-                                     const float* u2, float* o1, float* o2, void* stream) {
+                                     int32_t relu_in, float* out, int64_t ld_out, const int32_t* idx, int32_t n_rows,
+                                     const float* u1, const float* u2, float* o1, float* o2, void* stream) {
   using namespace gd;
   GD_REQUIRE(u1 && u2 && o1 && o2 && aligned16(u1) && aligned16(u2), GD_E_NULL,
              "gd_rows_gemm_dots_f32: u1 / u2 (16-byte aligned) and o1 / o2 are required");
   GD_REQUIRE(in != out, GD_E_DIM, "gd_rows_gemm_dots_f32: in and out must not alias");
-  return rows_gemm_impl(in, ld_in, nullptr, n_rows, w, d_in, d_out, trans_w, bias, relu_in, nullptr, nullptr, out, ld_out,
+  return rows_gemm_impl(in, ld_in, idx, n_rows, w, d_in, d_out, trans_w, bias, relu_in, nullptr, nullptr, out, ld_out,
                         nullptr, stream, sel ? in_alt : nullptr, sel, RowDots{u1, u2, o1, o2});
 }
 

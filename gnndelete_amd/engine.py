@@ -321,6 +321,7 @@ class NodeembEngine:
                 self._t1rbuf = torch.zeros(n, self.h, **f32) if self._mode == 'sage' else None
                 self._t2buf = torch.zeros(n, self.o * (2 if self._mode == 'sage' else 1), **f32)
                 self._dt2buf = torch.zeros(n, self.o, **f32)
+                self._adots = torch.zeros(2, n, **f32)                     # GAT logits of a row subset
                 if self._split1:
                     self.pre1.zero_()
                 self.p2.zero_()
@@ -404,7 +405,10 @@ class NodeembEngine:
             self._spmm(False, g.val, t_l, self.pre1, c.lin_l.bias, 1.0, x_self=t_r)
         else:
             wsrc = c.lin_src.weight
-            if self._gat_dots and ops.rows_gemm_dots_ok(wsrc.shape[1], wsrc.shape[0]):
+            if self._rows_only and self._split1 and self._mfma_weight(wsrc):
+                h1 = ops.rows_gemm(self.x, self.idx2, wsrc, trans_w=True, out=self._t1buf)       # rows outside stay 0
+                a_src, a_dst = ops.row_dots(h1, c.att_src, c.att_dst)
+            elif self._gat_dots and ops.rows_gemm_dots_ok(wsrc.shape[1], wsrc.shape[0]):
                 h1, a_src, a_dst = ops.rows_gemm_dots(self.x, wsrc, c.att_src, c.att_dst)   # logits from the epilogue
             else:
                 h1 = self._linear(self.x, wsrc)
@@ -453,8 +457,11 @@ class NodeembEngine:
         else:   # gat
             wsrc = c.lin_src.weight
             if self._gat_dots and self._split1 and ops.rows_gemm_dots_ok(wsrc.shape[1], wsrc.shape[0]):
-                h2, self._a_src, self._a_dst = ops.rows_gemm_dots(self.pre1, wsrc, c.att_src, c.att_dst, inp_alt=self.z1,
-                                                                  sel=self._sel1, relu_in=True)
+                ro = self._rows_only
+                h2, self._a_src, self._a_dst = ops.rows_gemm_dots(
+                    self.pre1, wsrc, c.att_src, c.att_dst, inp_alt=self.z1, sel=self._sel1, relu_in=True,
+                    out=self._t2buf if ro else None, idx=self.idx2 if ro else None,
+                    dots_out=(self._adots[0], self._adots[1]) if ro else None)
             else:
                 h2 = self._linear_relu_z1(wsrc)
                 self._a_src, self._a_dst = ops.row_dots(h2, c.att_src, c.att_dst)

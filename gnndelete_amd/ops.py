@@ -125,7 +125,7 @@ def rows_gemm_dots_ok(d_in, d_out):
     return d_in % 32 == 0 and d_out % 32 == 0 and d_out <= 64 and d_in * d_out * 4 <= 64 * 1024
 
 
-def rows_gemm_dots(inp, w, u1, u2, inp_alt=None, sel=None, relu_in=False, out=None):
+def rows_gemm_dots(inp, w, u1, u2, inp_alt=None, sel=None, relu_in=False, out=None, idx=None, dots_out=None):
     """out = act(inp or inp_alt) @ w^T (w [d_out, d_in]) and, from the same pass, a1 = out @ u1, a2 = out @ u2
     (gd_rows_gemm_dots_f32; MFMA widths only - see rows_gemm_dots_ok)."""
     inp = _f32_rows(inp)
@@ -137,13 +137,17 @@ def rows_gemm_dots(inp, w, u1, u2, inp_alt=None, sel=None, relu_in=False, out=No
         assert inp_alt.shape == inp.shape and inp_alt.stride(0) == inp.stride(0) and sel.dtype == torch.uint8
     if out is None:
         out = torch.empty(n, d_out, dtype=torch.float32, device=inp.device)
-    a1 = torch.empty(n, dtype=torch.float32, device=inp.device)
-    a2 = torch.empty(n, dtype=torch.float32, device=inp.device)
+    if dots_out is not None:                      # caller-owned (e.g. zero-initialised, for a row subset)
+        a1, a2 = dots_out
+    else:
+        a1 = torch.empty(n, dtype=torch.float32, device=inp.device)
+        a2 = torch.empty(n, dtype=torch.float32, device=inp.device)
     w = w.contiguous()
     u1, u2 = u1.reshape(-1).contiguous(), u2.reshape(-1).contiguous()
+    n_rows = n if idx is None else int(idx.shape[0])
     check(_lib.lib().gd_rows_gemm_dots_f32(ptr(inp), ptr(inp_alt), ptr(sel), inp.stride(0), ptr(w), d_in, d_out, 1, None,
-                                           int(relu_in), ptr(out), out.stride(0), n, ptr(u1), ptr(u2), ptr(a1), ptr(a2),
-                                           stream_ptr(inp.device)), 'gd_rows_gemm_dots_f32')
+                                           int(relu_in), ptr(out), out.stride(0), ptr(idx), n_rows, ptr(u1), ptr(u2),
+                                           ptr(a1), ptr(a2), stream_ptr(inp.device)), 'gd_rows_gemm_dots_f32')
     return out, a1, a2
 
 

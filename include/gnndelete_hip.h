@@ -230,8 +230,9 @@ int gd_rows_gemm_select_f32(const float* in, const float* in_alt, const uint8_t*
  * just written.  MFMA path only (d_in, d_out multiples of 32, d_out <= 128, weight <= 64 KB). */
 int gd_rows_gemm_dots_f32(const float* in, const float* in_alt, const uint8_t* sel, int64_t ld_in, const float* w,
                           int32_t d_in, int32_t d_out, int32_t trans_w, const float* bias, int32_t relu_in, float* out,
-                          int64_t ld_out, int32_t n_rows, const float* u1, const float* u2, float* o1, float* o2,
-                          void* stream);
+                          int64_t ld_out, const int32_t* idx /* NULL = rows 0 .. n_rows-1, else the n_rows listed rows:
+                          out / o1 / o2 are written at those row ids */, int32_t n_rows, const float* u1, const float* u2,
+                          float* o1, float* o2, void* stream);
 
 /* gd_rows_gemm_f32 that also emits the sign pattern of what it wrote, packed one bit per output
  * feature: sign_bits is compact [n_sel, ceil(d_out/32)] words, bit b of word k of entry s is set

@@ -437,3 +437,43 @@ def test_sage_affected_rows_only_matches_oracle_training(cache_layer1, loss_type
     assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), mo.deletion1.deletion_weight.detach()) < 1e-4
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
 
+
+
+@pytest.mark.parametrize('cache_layer1', [False, True])
+def test_gat_affected_rows_only_at_native_widths_matches_oracle_training(cache_layer1, loss_type='both_layerwise'):
+    """GAT at H = 128, O = 64 (the widths of the bench; the golden fixtures are 32 / 16): every fused stage is on,
+    including the attention logits taken from the epilogue of the layer-2 GEMM; trajectory against autograd on
+    the CPU oracle with the reference's update rules."""
+    from gnndelete_amd.engine import NodeembEngine
+    from oracle import gnndelete_ref as R
+    fx = load_golden('traj_gat_both_layerwise.npz')
+    _, data, rest = split_fixture(fx)
+    n = data['x'].shape[0]
+    torch.manual_seed(3)
+    f = 64
+    data = dict(data, x=torch.randn(n, f) * 0.3)      # an input width the row-subset GEMM has
+    mo = R.TwoLayerDelete('gat', f, 128, 64, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    with torch.no_grad():
+        for name, p in mo.named_parameters():
+            if name.endswith('bias'):
+                p.copy_(torch.randn_like(p) * 0.1)
+    state = {k: v.clone() for k, v in mo.state_dict().items()}
+    m = hip_model('gat', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    logs, _ = R.nodeemb_fullbatch(mo, data, 6, loss_type, 0.4, 'mse_mean', 0.01, neg_edge=t(rest['neg']))
+
+    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    E = dev['train_pos_edge_index']
+    ni1, ni2 = R.non_df_masks(n, data['directed_df_edge_index'], data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    with torch.no_grad():
+        z1o, z2o = m.get_original_embeddings(dev['x'], E[:, dev['dr_mask']], return_all_emb=True)
+    eng = NodeembEngine(m, dev['x'], E[:, dev['sdf_mask']].contiguous(), z1o, z2o, E[:, dev['df_mask']],
+                        t(rest['neg']).cuda(), ni1, ni2, loss_type=loss_type, alpha=0.4, lr=0.01, use_graph=True, cache_layer1=cache_layer1,
+                        affected_rows_only=True)
+    assert eng._rows_only and eng._gat_dots
+    for _ in range(6):
+        eng.step()
+    hist = eng.loss_history().numpy()
+    for col, key in enumerate(['train_loss', 'loss_r', 'loss_l']):
+        np.testing.assert_allclose(hist[:, col], [l[key] for l in logs], rtol=1e-4, atol=1e-8, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), mo.deletion1.deletion_weight.detach()) < 1e-4
+    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
