@@ -24,7 +24,7 @@ PROTOTYPES = {
     'gd_gcn_norm_f32': (ctypes.c_int, [_p, _p, _i32, _p, _p]),
     'gd_spmm_csr_f32': (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _f32, _i32, _i32, _p]),
     'gd_spmm_csr_balanced_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _f32, _p, _p, _i32,
-                                                _i32, _i32, _p]),
+                                                _i32, _i32, _p, _p]),
     'gd_rgcn_conv_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _i32, _i32, _p, _i64, _i32, _i32, _p]),
     'gd_rgcn_mean_f32': (ctypes.c_int, [_p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p]),
     'gd_gat_aggregate_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _f32, _i32, _i32, _p]),

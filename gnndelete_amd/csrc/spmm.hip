@@ -109,15 +109,17 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(const int32_t* __restrict
 // accumulators' initial value), so a GCN row costs ONE round trip (its gathers) instead of three (descriptor ->
 // indices, gathers, then the bias behind them); only a self / residual row (GIN, GraphSAGE) is still fetched
 // in the epilogue - holding it across the gathers costs the registers that decide 8 vs 7 waves per SIMD.
+// xcd_bounds (optional, 9 ints): XCD k sweeps the items [xcd_bounds[k], xcd_bounds[k+1]) instead of an equal eighth -
+// the host balances the ranges by bytes moved (a self-loop-only row costs two row transfers, a 64-edge piece 65),
+// so that no XCD's fabric link idles while another still has a third of its traffic to go.
 template <int LPR, int VPL, int U, bool EXACT, bool ADDR32>
-__global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restrict__ items, int32_t n_items,
-                                                           const int32_t* __restrict__ col,
-                                                           const float* __restrict__ val,
-                                                           const float* __restrict__ x, int64_t ldx,
-                                                           float* __restrict__ y, int64_t ldy,
-                                                           const float* __restrict__ bias, float self_coef,
-                                                           const float* __restrict__ xs,
-                                                           float* __restrict__ scratch, int32_t d4, int32_t nnz) {
+__device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items, int32_t n_items,
+                                                  const int32_t* __restrict__ xcd_bounds,
+                                                  const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                  const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                                  int64_t ldy, const float* __restrict__ bias, float self_coef,
+                                                  const float* __restrict__ xs, float* __restrict__ scratch, int32_t d4,
+                                                  int32_t nnz) {
   constexpr int G = kWave / LPR;
   constexpr int kXcd = 8;
   const int lane = threadIdx.x & 63;
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
   const int stride = (gridDim.x / kXcd) * 4;                        // waves per XCD
   const int wx = (blockIdx.x / kXcd) * 4 + (threadIdx.x >> 6);
   const int per = (n_items + kXcd - 1) / kXcd;
-  const int i0 = xcd * per, i1 = min(n_items, i0 + per);
+  const int i0 = xcd_bounds ? xcd_bounds[xcd] : xcd * per;
+  const int i1 = xcd_bounds ? xcd_bounds[xcd + 1] : min(n_items, i0 + per);
   int i = i0 + wx;
   if (i >= i1) return;
 
@@ -252,6 +255,20 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
     d0 = d1;
     d1 = uniform(dv);
   }
+}
+
+template <int LPR, int VPL, int U, bool EXACT, bool ADDR32>
+__global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restrict__ items, int32_t n_items,
+                                                           const int32_t* __restrict__ xcd_bounds,
+                                                           const int32_t* __restrict__ col,
+                                                           const float* __restrict__ val,
+                                                           const float* __restrict__ x, int64_t ldx,
+                                                           float* __restrict__ y, int64_t ldy,
+                                                           const float* __restrict__ bias, float self_coef,
+                                                           const float* __restrict__ xs,
+                                                           float* __restrict__ scratch, int32_t d4, int32_t nnz) {
+  spmm_persist_body<LPR, VPL, U, EXACT, ADDR32>(items, n_items, xcd_bounds, col, val, x, ldx, y, ldy, bias, self_coef, xs,
+                                                scratch, d4, nnz);
 }
 
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int4* __restrict__ split, int32_t n_split,
@@ -393,7 +410,8 @@ extern "C" int gd_rgcn_mean_f32(const int32_t* rowptr, const int32_t* col, const
 extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
                                         const int32_t* col, const float* val, const float* x, int64_t ldx, float* y,
                                         int64_t ldy, const float* bias, float self_coef, const float* x_self,
-                                        float* scratch, int32_t d, int32_t nnz, int32_t x_rows, void* stream) {
+                                        float* scratch, int32_t d, int32_t nnz, int32_t x_rows,
+                                        const int32_t* xcd_bounds, void* stream) {
   using namespace gd;
   GD_REQUIRE(items && col && x && y, GD_E_NULL, "gd_spmm_csr_balanced_f32: null pointer");
   GD_REQUIRE(n_split == 0 || (split && scratch), GD_E_NULL, "gd_spmm_csr_balanced_f32: split rows need scratch");
@@ -411,8 +429,11 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   // grid: a few visits per wave (4 x the resident set of 256 CUs x 8 blocks measured best), a
   // multiple of the 8 XCDs
   int nblk = (n_items + 3) / 4;
-  const char* cap_env = getenv("GD_SPMM_GRID_CAP");                 // tuning knob (blocks)
-  const int cap = cap_env ? atoi(cap_env) : 8192;
+  static const int cap = [] {                                       // tuning knob (blocks), read once per process
+    const char* e = getenv("GD_SPMM_GRID_CAP");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 8192;
+  }();
   if (nblk > cap) nblk = cap;
   nblk = (nblk + 7) / 8 * 8;
   const dim3 grid(nblk), block(256);
@@ -422,7 +443,8 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
                       (int64_t)x_rows * ldx * 4 < (1ll << 32) && (int64_t)x_rows * ldy * 4 < (1ll << 32);
 #define GD_ITEMS_LAUNCH(LPR, VPL, EXACT, A32)                                                                        \
   hipLaunchKernelGGL((spmm_persist_kernel<LPR, VPL, ((64 / (64 / LPR)) >= 4 ? 4 : (64 / (64 / LPR))), EXACT, A32>), \
-                     grid, block, 0, s, it, n_items, col, val, x, ldx, y, ldy, bias, self_coef, xs, scratch, d4, nnz)
+                     grid, block, 0, s, it, n_items, xcd_bounds, col, val, x, ldx, y, ldy, bias, self_coef, xs, scratch, \
+                     d4, nnz)
 #define GD_ITEMS_CASE(LPR, VPL)                                                                                    \
   do {                                                                                                             \
     if (d4 == LPR * VPL) {                                                                                         \

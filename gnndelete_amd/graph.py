@@ -52,6 +52,29 @@ class SplitPlan:
         self.n_split = int(srows.numel())
         self.n_slots = int(split_pieces.sum())
         self._scratch = {}
+        self._edges_per_item = (end - start)
+        self._bounds = {}
+        for d in (64, 128):          # the path's widths, ahead of any hipGraph capture (the tables are built lazily)
+            self.xcd_bounds(d)
+
+    def xcd_bounds(self, d):
+        """Item range of each of the 8 XCDs for a width-d SpMM (int32 [9] on the device, None for small plans),
+        balanced by what an item costs its XCD: its in-edges (one feature row each) plus a fixed per-visit overhead
+        worth about 6 KB of row traffic (measured with per-XCD time stamps on the bench graph,
+        tools/experiments/spmm_lab.hip: a wave's visit is one dependent memory round trip however short the row).
+        With equal item counts the XCD that gets the rows outside S_Df (self loop only) is done in half the time and
+        its CUs and fabric link idle while the others still have a third of their traffic to go."""
+        if self.n_items < 8 * 1024:
+            return None
+        a = int(min(48, max(8, 1536 // max(int(d), 1))))
+        b = self._bounds.get(a)
+        if b is None:
+            cost = torch.cumsum((self._edges_per_item + a).double(), 0)
+            dev = cost.device
+            cuts = torch.searchsorted(cost, cost[-1] * torch.arange(1, 8, device=dev, dtype=torch.float64) / 8)
+            b = torch.cat([cuts.new_zeros(1), cuts, cuts.new_full((1,), self.n_items)]).to(torch.int32).contiguous()
+            self._bounds[a] = b
+        return b
 
     def scratch_flat(self, tag, n_floats, device):
         """Named flat work buffers (e.g. the GAT kernels' merge scratch), kept per plan."""

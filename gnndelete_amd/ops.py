@@ -31,7 +31,8 @@ def _spmm_raw(rowptr, col, val, x, bias, self_coef, n_rows, plan=None, out=None,
         check(_lib.lib().gd_spmm_csr_balanced_f32(ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split,
                                                   ptr(col), ptr(val), ptr(x), x.stride(0), ptr(y), y.stride(0),
                                                   ptr(bias), float(self_coef), ptr(x_self), ptr(scratch), d, int(col.shape[0]),
-                                                  max(int(x.shape[0]), int(y.shape[0])), stream_ptr(x.device)),
+                                                  max(int(x.shape[0]), int(y.shape[0])), ptr(plan.xcd_bounds(d)),
+                                                  stream_ptr(x.device)),
               'gd_spmm_csr_balanced_f32')
         return y
     assert x_self is None, 'x_self needs the balanced kernel (d % 4 == 0, 16-byte aligned rows)'

@@ -107,12 +107,14 @@ int gd_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
  * x_rows = an upper bound on the number of rows of x AND of y (every col id and every item row
  * is < x_rows); when both matrices are smaller than 4 GiB the kernel uses 32-bit row offsets
  * (pass 0 if unknown: 64-bit addressing).
+ * xcd_bounds (optional, 9 ascending item indices, [0] = 0, [8] = n_items): the item range each of the 8 XCDs
+ * sweeps; NULL = equal eighths.  A placement hint only (balances the bytes each XCD's L2 moves), never results.
  * Same arithmetic, same call sites as gd_spmm_csr_f32. */
 int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
                              const int32_t* col, const float* val, const float* x, int64_t ldx,
                              float* y, int64_t ldy, const float* bias, float self_coef,
                              const float* x_self, float* scratch, int32_t d, int32_t nnz, int32_t x_rows,
-                             void* stream);
+                             const int32_t* xcd_bounds, void* stream);
 
 /* Per-relation mean aggregation of R-GCN ("typed SpMM") over a relation-major CSR:
  *   rowptr[(r*n_rows + i) .. +1] delimit the in-edges of type r into node i;
