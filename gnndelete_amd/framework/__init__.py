@@ -14,7 +14,6 @@ _OUT_OF_SCOPE = ['gradient_ascent', 'descent_to_delete', 'approx_retrain', 'grap
 trainer_mapping = {
     'original': Trainer,
     'original_node': NodeClassificationTrainer,
-    'retrain': Trainer,                       # retrain = original training on Dr (dtrain_mask)
     'gnndelete_nodeemb': GNNDeleteNodeembTrainer,
 }
 
@@ -25,10 +24,12 @@ def _lazy_trainers():
     from .trainer.gnndelete import GNNDeleteTrainer
     for key in ('gnndelete', 'gnndelete_mse', 'gnndelete_kld', 'gnndelete_cosine'):
         trainer_mapping.setdefault(key, GNNDeleteTrainer)
+    from .trainer.retrain import KGRetrainTrainer, RetrainTrainer
+    trainer_mapping.setdefault('retrain', RetrainTrainer)
     try:
         from .trainer.kg import KGGNNDeleteNodeembTrainer, KGTrainer
         kg_trainer_mapping.setdefault('original', KGTrainer)
-        kg_trainer_mapping.setdefault('retrain', KGTrainer)
+        kg_trainer_mapping.setdefault('retrain', KGRetrainTrainer)
         kg_trainer_mapping.setdefault('gnndelete', KGGNNDeleteNodeembTrainer)
         kg_trainer_mapping.setdefault('gnndelete_nodeemb', KGGNNDeleteNodeembTrainer)
     except ImportError:

@@ -72,14 +72,23 @@ def _features(n, f, style, community, gen):
     return x / x.sum(1, keepdim=True).clamp(min=1e-12)
 
 
-def split_linkpred(x, edges, n, gen, val_ratio=0.05, test_ratio=0.05):
+def split_linkpred(x, edges, n, gen, val_ratio=0.05, test_ratio=0.05, two_hop_degree=None):
     """The reference's split recipe (prepare_dataset.py:31-136 train_test_split_edges_no_neg_adj_mask,
     :205-214 IN / OUT masks) on unique ``row < col`` edges: randperm, test then validation edges first,
     negatives that avoid the positives, Df candidates inside / outside the 2-hop enclosing subgraph of
-    the test edges.  -> (data, {'in': mask, 'out': mask})"""
+    the test edges.  two_hop_degree (per edge, optional): edges whose two-hop degree is below 50 are drawn first,
+    so that they make up the test / validation sets - what upstream does for ogbl-* (:54-64, :186-189).
+    -> (data, {'in': mask, 'out': mask})"""
     m = edges.shape[1]
     n_v, n_t = int(math.floor(val_ratio * m)), int(math.floor(test_ratio * m))
-    perm = torch.randperm(m, generator=gen)
+    if two_hop_degree is not None:
+        low_mask = two_hop_degree < 50
+        low, high = low_mask.nonzero().flatten(), (~low_mask).nonzero().flatten()
+        low = low[torch.randperm(low.shape[0], generator=gen)]
+        high = high[torch.randperm(high.shape[0], generator=gen)]
+        perm = torch.cat([low, high])
+    else:
+        perm = torch.randperm(m, generator=gen)
     edges = edges[:, perm]
     test_pos, val_pos, train = edges[:, :n_t], edges[:, n_t:n_t + n_v], edges[:, n_t + n_v:]
     data = Data(x=x, num_nodes=n, num_features=int(x.shape[1]) if x.dim() == 2 else 0, train_pos_edge_index=train,
@@ -120,18 +129,28 @@ def make_kg_dataset(name='synth-kg-tiny', seed=42, val_ratio=0.05, test_ratio=0.
     m = edges.shape[1]
     w = 1.0 / torch.arange(1, r + 1, dtype=torch.float64)
     rel = torch.searchsorted(torch.cumsum(w / w.sum(), 0), torch.rand(m, generator=gen, dtype=torch.float64)).clamp(max=r - 1)
-    perm = torch.randperm(m, generator=gen)
-    edges, rel = edges[:, perm], rel[perm]
-    n_v, n_t = int(math.floor(val_ratio * m)), int(math.floor(test_ratio * m))
     state = torch.get_rng_state()
     torch.manual_seed(seed)
-    data = Data(x=torch.arange(n), num_nodes=n, num_features=0,
-                train_pos_edge_index=edges[:, n_t + n_v:], train_edge_type=rel[n_t + n_v:],
-                test_pos_edge_index=edges[:, :n_t], test_edge_type=rel[:n_t],
-                val_pos_edge_index=edges[:, n_t:n_t + n_v], val_edge_type=rel[n_t:n_t + n_v])
+    data, masks = split_kg(torch.arange(n), edges, rel, n, val_ratio, test_ratio)
+    torch.set_rng_state(state)
+    return data, masks
+
+
+def split_kg(x, edges, edge_type, n, val_ratio=0.05, test_ratio=0.05):
+    """The KG branch of train_test_split_edges_no_neg_adj_mask (prepare_dataset.py:31-136, kg=True) on directed
+    triples: the edges are permuted with torch.randperm on the GLOBAL generator, test then validation triples are
+    taken first - and the relation types are sliced WITHOUT the permutation, exactly as upstream does (:79, :104,
+    :119; pinned by tests/golden/split.npz) - negatives by per-relation head shuffling (framework/utils.py:46-58,
+    test first, then validation), Df candidates inside / outside the 2-hop enclosing subgraph of the test triples."""
+    m = edges.shape[1]
+    n_v, n_t = int(math.floor(val_ratio * m)), int(math.floor(test_ratio * m))
+    edges = edges[:, torch.randperm(m)]
+    data = Data(x=x, num_nodes=n, num_features=0,
+                train_pos_edge_index=edges[:, n_t + n_v:], train_edge_type=edge_type[n_t + n_v:],
+                test_pos_edge_index=edges[:, :n_t], test_edge_type=edge_type[:n_t],
+                val_pos_edge_index=edges[:, n_t:n_t + n_v], val_edge_type=edge_type[n_t:n_t + n_v])
     data.test_neg_edge_index = negative_sampling_kg(data.test_pos_edge_index, data.test_edge_type)
     data.val_neg_edge_index = negative_sampling_kg(data.val_pos_edge_index, data.val_edge_type)
-    torch.set_rng_state(state)
     _, _, _, local = k_hop_subgraph(data.test_pos_edge_index.flatten().unique(), 2, data.train_pos_edge_index, num_nodes=n)
     return data, {'in': local, 'out': ~local}
 

@@ -14,7 +14,8 @@ from ..metrics import batched_average_precision, batched_roc_auc
 from ..utils import get_link_labels, negative_sampling_kg
 from .base import Trainer, _require_gpu, device
 from .gnndelete_nodeemb import _four_terms, _non_df_masks, get_loss_fct
-from .sampler import RandomWalkSubgraphSampler
+from . import sampler as _sampler
+from ._log import wandb_log
 
 
 class KGTrainer(Trainer):
@@ -24,7 +25,7 @@ class KGTrainer(Trainer):
         _require_gpu()
         model = model.to(device)
         data = data.to('cpu')
-        loader = RandomWalkSubgraphSampler(data, batch_size=128, walk_length=2, num_steps=args.num_steps)
+        loader = _sampler.make_sampler(data, 128, args.num_steps)
         best_metric, best_epoch = 0, 0
         start = time.time()
         for epoch in range(args.epochs):
@@ -132,9 +133,10 @@ class KGGNNDeleteNodeembTrainer(KGTrainer):
         model = model.to(device)
         data = data.to('cpu')
         _non_df_masks(data)
-        loader = RandomWalkSubgraphSampler(data, batch_size=args.batch_size, walk_length=2, num_steps=args.num_steps)
+        loader = _sampler.make_sampler(data, args.batch_size, args.num_steps)
         best_metric = 0
         alpha = self.args.alpha
+        self.trainer_log['steps'] = []
         for epoch in range(args.epochs):
             model.train()
             last = None
@@ -160,6 +162,9 @@ class KGGNNDeleteNodeembTrainer(KGTrainer):
                 optimizer[1].step()
                 optimizer[1].zero_grad()
                 last = (loss1 + loss2, r1 + r2, l1 + l2)
+                step_log = {'Epoch': epoch, 'train_loss': last[0].item(), 'loss_r': last[1].item(), 'loss_l': last[2].item()}
+                wandb_log(step_log)
+                self.trainer_log['steps'].append(step_log)
             if (epoch + 1) % self.args.valid_freq == 0 and last is not None:
                 valid_loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, _, valid_log = self.eval(model, data, 'val')
                 valid_log['epoch'] = epoch

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from ..graph_utils import negative_sampling
+from ._log import wandb_log
 from .base import _require_gpu, device
 
 
@@ -43,26 +44,54 @@ class RandomWalkSubgraphSampler:
             visited.append(cur)
         return torch.cat(visited).unique()
 
-    def __iter__(self):
+    def subgraph(self, nodes):
+        """The batch for one (sorted, unique) node set - what GraphSAINTSampler.__getitem__ + saint_subgraph hand
+        the loop [PyG-mem]: induced edges in (source, target) order with relabelled endpoints, node-sized
+        tensors sliced by the node ids, edge-sized ones by the kept edges, the rest passed through."""
         from ..data import Data
         d = self.data
         n_edges = d.edge_index.shape[1]
+        member = torch.zeros(self.n, dtype=torch.bool)
+        member[nodes] = True
+        keep = self.order[(member[d.edge_index[0]] & member[d.edge_index[1]])[self.order]]
+        relabel = torch.full((self.n,), -1, dtype=torch.long)
+        relabel[nodes] = torch.arange(nodes.numel())
+        batch = Data(num_nodes=int(nodes.numel()), edge_index=relabel[d.edge_index[:, keep]])
+        for key, val in d.items():
+            if key in ('edge_index', 'num_nodes'):
+                continue
+            if torch.is_tensor(val) and val.dim() >= 1 and val.shape[0] == self.n:
+                batch[key] = val[nodes]
+            elif torch.is_tensor(val) and val.dim() >= 1 and val.shape[0] == n_edges:
+                batch[key] = val[keep]
+            else:
+                batch[key] = val
+        return batch
+
+    def node_sets(self):
         for _ in range(self.num_steps):
-            nodes = self._walk()
-            member = torch.zeros(self.n, dtype=torch.bool)
-            member[nodes] = True
-            emask = member[d.edge_index[0]] & member[d.edge_index[1]]
-            relabel = torch.full((self.n,), -1, dtype=torch.long)
-            relabel[nodes] = torch.arange(nodes.numel())
-            batch = Data(num_nodes=int(nodes.numel()), edge_index=relabel[d.edge_index[:, emask]], node_id=nodes)
-            for key, val in d.items():
-                if not torch.is_tensor(val) or key in ('edge_index', 'node_id'):
-                    continue
-                if val.dim() >= 1 and val.shape[0] == self.n:
-                    batch[key] = val[nodes]
-                elif val.dim() == 1 and val.shape[0] == n_edges:
-                    batch[key] = val[emask]
-            yield batch
+            yield self._walk()
+
+    def __iter__(self):
+        for nodes in self.node_sets():
+            yield self.subgraph(nodes)
+
+
+class FixedNodeSets(RandomWalkSubgraphSampler):
+    """The same batches every epoch from a given list of node sets (parity tests inject the node sets the
+    reference's loop was run on; the random-walk stream itself cannot be matched)."""
+
+    def __init__(self, data, node_sets):
+        super().__init__(data, batch_size=0, num_steps=len(node_sets))
+        self._sets = [torch.as_tensor(s, dtype=torch.long).unique() for s in node_sets]
+
+    def node_sets(self):
+        return iter(self._sets)
+
+
+def make_sampler(data, batch_size, num_steps, walk_length=2):
+    """Sampler factory of the mini-batch loops (a seam for tests: monkeypatch to inject FixedNodeSets)."""
+    return RandomWalkSubgraphSampler(data, batch_size=batch_size, walk_length=walk_length, num_steps=num_steps)
 
 
 def train_minibatch(trainer, model, data, optimizer, args):
@@ -75,9 +104,10 @@ def train_minibatch(trainer, model, data, optimizer, args):
     _non_df_masks(data)
     data.edge_index = data.train_pos_edge_index
     data.node_id = torch.arange(data.x.shape[0])
-    loader = RandomWalkSubgraphSampler(data, batch_size=args.batch_size, walk_length=2, num_steps=args.num_steps)
+    loader = make_sampler(data, args.batch_size, args.num_steps)
     model = model.to(device)
     best_metric = 0
+    trainer.trainer_log['steps'] = []
     for epoch in range(args.epochs):
         model.train()
         sums = {'loss': 0.0, 'loss_l': 0.0, 'loss_r': 0.0}
@@ -100,9 +130,13 @@ def train_minibatch(trainer, model, data, optimizer, args):
             loss2.backward(retain_graph=True)
             optimizer[1].step()
             optimizer[1].zero_grad()
-            sums['loss'] += (loss1 + loss2).item()
-            sums['loss_l'] += (l1 + l2).item()
-            sums['loss_r'] += (r1 + r2).item()
+            step_log = {'Epoch': epoch, 'train_loss': (loss1 + loss2).item(), 'train_loss_l': (l1 + l2).item(),
+                        'train_loss_r': (r1 + r2).item()}
+            wandb_log(step_log)
+            trainer.trainer_log['steps'].append(step_log)
+            sums['loss'] += step_log['train_loss']
+            sums['loss_l'] += step_log['train_loss_l']
+            sums['loss_r'] += step_log['train_loss_r']
             steps += 1
         if (epoch + 1) % args.valid_freq == 0:
             valid_loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, _, valid_log = trainer.eval(model, data, 'val')

@@ -17,6 +17,12 @@ What each piece follows (paths relative to /root/reference):
   original_fullbatch       framework/trainer/base.py:75-142
   eval_linkpred            framework/trainer/base.py:229-305
   negative_sampling_kg     framework/utils.py:46-58
+  nodeemb_minibatch        framework/trainer/gnndelete_nodeemb.py:352-443 (GraphSAINT batches injected)
+  kg_nodeemb_minibatch     framework/trainer/gnndelete_nodeemb.py:734-800
+  eval_kg                  framework/trainer/base.py:495-567
+  retrain_fullbatch        framework/trainer/retrain.py:57-131
+  verification_error       framework/evaluation.py:63-81
+  split_edges              prepare_dataset.py:31-136 (+ IN / OUT masks :205-214)
 
 Build semantics: the backbone is truly frozen - conv1
 runs under no_grad for every architecture (upstream does so for GAT/GIN/RGCN; for GCN
@@ -401,6 +407,184 @@ def negative_sampling_kg(edge_index, edge_type, generator=None):
         heads = out[0, sel]
         perm = torch.randperm(heads.shape[0], generator=generator)
         out[0, sel] = heads[perm]
+    return out
+
+
+# ----------------------------------------------------------------------------
+# mini-batch loops on injected GraphSAINT batches
+# ----------------------------------------------------------------------------
+def _layerwise_step(optimizer, alpha, r1, r2, l1, l2):
+    """The update both mini-batch loops share (gnndelete_nodeemb.py:433-443, 788-798): step + zero_grad per layer;
+    loss2's gradient w.r.t. W_D1 (through conv2) stays in W_D1.grad and is consumed by the NEXT batch's step."""
+    loss1 = alpha * r1 + (1 - alpha) * l1
+    loss1.backward(retain_graph=True)
+    optimizer[0].step()
+    optimizer[0].zero_grad()
+    loss2 = alpha * r2 + (1 - alpha) * l2
+    loss2.backward(retain_graph=True)
+    optimizer[1].step()
+    optimizer[1].zero_grad()
+    return loss1 + loss2
+
+
+def nodeemb_minibatch(model, data, node_sets, negs, epochs, alpha, lr):
+    """GNNDeleteNodeembTrainer.train_minibatch (gnndelete_nodeemb.py:352-443) without validation: per batch the
+    original embeddings on ALL batch edges (Df included, :399-400), Del forward on the batch's S_Df edges with the
+    batch's node masks, plain MSE (:357), negatives per batch (``negs``, consumed in order), layer-wise update.
+    -> per-step dicts(train_loss, train_loss_l, train_loss_r)."""
+    d = dict(data)
+    d['sdf_node_1hop_mask_non_df_mask'], d['sdf_node_2hop_mask_non_df_mask'] = non_df_masks(
+        d['x'].shape[0], d['directed_df_edge_index'], d['sdf_node_1hop_mask'], d['sdf_node_2hop_mask'])
+    d['edge_index'] = d['train_pos_edge_index']
+    opt = make_optimizer(model, 'both_layerwise', lr)
+    fct = nn.MSELoss()
+    negs = iter(negs)
+    logs = []
+    for _ in range(epochs):
+        model.train()
+        for nodes in node_sets:
+            b = pyg.saint_subgraph(d, nodes)
+            with torch.no_grad():
+                z1o, z2o = model.get_original_embeddings(b['x'], b['edge_index'], return_all_emb=True)
+            z1, z2 = model(b['x'], b['edge_index'][:, b['sdf_mask']], None, b['sdf_node_1hop_mask'], b['sdf_node_2hop_mask'],
+                           return_all_emb=True)
+            pos = b['edge_index'][:, b['df_mask']]
+            neg = next(negs)
+            assert neg.shape[1] == pos.shape[1]
+            r1, r2, l1, l2 = nodeemb_terms(z1, z2, z1o, z2o, pos, neg, b['sdf_node_1hop_mask_non_df_mask'],
+                                           b['sdf_node_2hop_mask_non_df_mask'], fct)
+            loss = _layerwise_step(opt, alpha, r1, r2, l1, l2)
+            logs.append(dict(train_loss=float(loss), train_loss_l=float(l1 + l2), train_loss_r=float(r1 + r2)))
+    return logs
+
+
+def kg_nodeemb_minibatch(model, data, node_sets, num_edge_type, epochs, alpha, lr, loss_fct='mse_mean'):
+    """KGGNNDeleteNodeembTrainer.train (gnndelete_nodeemb.py:734-800) without validation: message passing on the
+    batch's Dr edges with the S_Df-minus-Df node masks as the Del masks (:749-751), DEC on the forward-direction Df
+    triples only (:761) against per-relation head-shuffled negatives drawn from the GLOBAL torch RNG (:766-768),
+    NI on the same node masks, layer-wise update.  -> per-step dicts(train_loss, loss_r, loss_l)."""
+    d = dict(data)
+    d['sdf_node_1hop_mask_non_df_mask'], d['sdf_node_2hop_mask_non_df_mask'] = non_df_masks(
+        d['x'].shape[0], d['directed_df_edge_index'], d['sdf_node_1hop_mask'], d['sdf_node_2hop_mask'])
+    opt = make_optimizer(model, 'both_layerwise', lr)
+    fct = LOSSES[loss_fct]
+    logs = []
+    for _ in range(epochs):
+        model.train()
+        for nodes in node_sets:
+            b = pyg.saint_subgraph(d, nodes)
+            ei, et = b['edge_index'][:, b['dr_mask']], b['edge_type'][b['dr_mask']]
+            m1, m2 = b['sdf_node_1hop_mask_non_df_mask'], b['sdf_node_2hop_mask_non_df_mask']
+            z1, z2 = model(b['x'], ei, et, m1, m2, return_all_emb=True)
+            with torch.no_grad():
+                z1o, z2o = model.get_original_embeddings(b['x'], ei, et, return_all_emb=True)
+            pos, pt = b['edge_index'][:, b['df_mask']], b['edge_type'][b['df_mask']]
+            fw = pt < num_edge_type
+            dec, dec_t = pos[:, fw], pt[fw]
+            neg = negative_sampling_kg(dec, dec_t)
+            r1, r2, l1, l2 = nodeemb_terms(z1, z2, z1o, z2o, dec, neg, m1, m2, fct)
+            loss = _layerwise_step(opt, alpha, r1, r2, l1, l2)
+            logs.append(dict(train_loss=float(loss), loss_r=float(r1 + r2), loss_l=float(l1 + l2)))
+    return logs
+
+
+def eval_kg(model, data, stage, unlearning_model='gnndelete_nodeemb'):
+    """KGTrainer.eval (base.py:495-567): full-graph message passing on Dr, DistMult scores WITHOUT sigmoid for the
+    Dt loss / AUC / AUP, sigmoid scores of the directed Df triples, and 500 FRESH Dr subsets per call
+    (torch.randperm on the global RNG, :530-539) for the Df-vs-Dr AUC / AUP (Df labelled 0, Dr labelled 1)."""
+    from sklearn.metrics import roc_auc_score, average_precision_score
+    model.eval()
+    with torch.no_grad():
+        pos, neg, et = data[f'{stage}_pos_edge_index'], data[f'{stage}_neg_edge_index'], data[f'{stage}_edge_type']
+        z = model(data['x'], data['edge_index'][:, data['dr_mask']], data['edge_type'][data['dr_mask']])
+        logits = model.decode(z, torch.cat([pos, neg], -1), torch.cat([et, et], -1))
+        label = torch.zeros(pos.shape[1] + neg.shape[1])
+        label[:pos.shape[1]] = 1.0
+        loss = F.binary_cross_entropy_with_logits(logits, label).item()
+        dt_auc = roc_auc_score(label.numpy(), logits.numpy())
+        dt_aup = average_precision_score(label.numpy(), logits.numpy())
+        if unlearning_model == 'original':
+            df_logit = []
+        else:
+            df_logit = model.decode(z, data['directed_df_edge_index'], data['directed_df_edge_type']).sigmoid().tolist()
+        half = data['dr_mask'][:data['dr_mask'].shape[0] // 2]
+        if df_logit:
+            dr_e, dr_t = data['train_pos_edge_index'][:, half], data['train_edge_type'][half]
+            aucs, aups = [], []
+            lab = [0] * len(df_logit) + [1] * len(df_logit)
+            for _ in range(500):
+                m = torch.zeros(dr_e.shape[1], dtype=torch.bool)
+                m[torch.randperm(dr_e.shape[1])[:len(df_logit)]] = True
+                pl = model.decode(z, dr_e[:, m], dr_t[m]).sigmoid().tolist()
+                aucs.append(roc_auc_score(lab, df_logit + pl))
+                aups.append(average_precision_score(lab, df_logit + pl))
+            df_auc, df_aup = float(np.mean(aucs)), float(np.mean(aups))
+        else:
+            df_auc = df_aup = float('nan')
+    return {'loss': loss, 'dt_auc': dt_auc, 'dt_aup': dt_aup, 'df_auc': df_auc, 'df_aup': df_aup, 'df_logit': df_logit}
+
+
+# ----------------------------------------------------------------------------
+# retrain baseline (retrain.py:57-131), verification error (evaluation.py:63-81)
+# ----------------------------------------------------------------------------
+def retrain_fullbatch(model, data, epochs, lr, negs):
+    """RetrainTrainer.train_fullbatch without validation: BCE-with-logits link prediction on the Dr edges only,
+    fresh negatives per epoch (``negs``, consumed in order), one Adam over every parameter, zero_grad after the
+    step.  -> per-epoch train_loss."""
+    E = data['train_pos_edge_index'][:, data['dr_mask']]
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    losses = []
+    for ep in range(epochs):
+        model.train()
+        neg = negs[ep]
+        z = model(data['x'], E)
+        label = torch.cat([torch.ones(E.shape[1]), torch.zeros(neg.shape[1])])
+        loss = F.binary_cross_entropy_with_logits(model.decode(z, E, neg), label)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss))
+    return losses
+
+
+def verification_error(model1, model2):
+    """Sum over the parameters both models have (by name) of the L2 norm of their difference."""
+    p1, p2 = dict(model1.named_parameters()), dict(model2.named_parameters())
+    diff = torch.tensor(0.0)
+    with torch.no_grad():
+        for n in set(p1) & set(p2):
+            diff += torch.norm(p1[n] - p2[n])
+    return float(diff)
+
+
+# ----------------------------------------------------------------------------
+# dataset split (prepare_dataset.py:31-136) and Df candidate masks (:205-214)
+# ----------------------------------------------------------------------------
+def split_edges(edge_index, num_nodes, val_ratio=0.05, test_ratio=0.1, two_hop_degree=None, kg=False, edge_type=None):
+    """train_test_split_edges_no_neg_adj_mask: keep ``row < col`` (not for KGs), permute with torch.randperm on the
+    GLOBAL RNG (low-two-hop-degree edges first when ``two_hop_degree`` is given, :54-64), TEST edges first, then
+    validation, the rest is training.  Upstream slices the KG edge TYPES without applying the permutation
+    (:79, :104, :119) - reproduced.  Negatives are sampled by the caller.  -> dict."""
+    row, col = edge_index
+    if not kg:
+        m = row < col
+        row, col = row[m], col[m]
+    n_v, n_t = int(math.floor(val_ratio * row.shape[0])), int(math.floor(test_ratio * row.shape[0]))
+    if two_hop_degree is not None:
+        low_mask = two_hop_degree < 50
+        low, high = low_mask.nonzero().squeeze(), (~low_mask).nonzero().squeeze()
+        low = low[torch.randperm(low.shape[0])]
+        high = high[torch.randperm(high.shape[0])]
+        perm = torch.cat([low, high])
+    else:
+        perm = torch.randperm(row.shape[0])
+    row, col = row[perm], col[perm]
+    out = {'train': torch.stack([row[n_v + n_t:], col[n_v + n_t:]]), 'test': torch.stack([row[:n_t], col[:n_t]]),
+           'val': torch.stack([row[n_t:n_t + n_v], col[n_t:n_t + n_v]])}
+    if kg:
+        out.update(train_type=edge_type[n_v + n_t:], test_type=edge_type[:n_t], val_type=edge_type[n_t:n_t + n_v])
+    _, _, local = pyg.k_hop_subgraph(out['test'].flatten().unique(), 2, out['train'], num_nodes)
+    out['in_mask'] = local
     return out
 
 

@@ -94,6 +94,34 @@ def to_undirected(edge_index, attrs, num_nodes):
     return coalesce(both, [torch.cat([a, a]) for a in attrs], num_nodes)
 
 
+def saint_subgraph(data, node_idx, num_nodes=None):
+    """One batch of torch_geometric's GraphSAINTSampler for the (sorted, unique) node set ``node_idx`` [PyG-mem]:
+    the induced subgraph in the adjacency's (row, col) order - SparseTensor(row=edge_index[0], col=edge_index[1],
+    value=arange(E)).saint_subgraph - with endpoints relabelled to positions in ``node_idx``; tensors whose first
+    dimension is N are sliced by ``node_idx``, those whose first dimension is E by the kept edges, the rest are
+    passed through.  ``data`` is a dict; -> dict with num_nodes = len(node_idx)."""
+    ei = data['edge_index']
+    n = int(data['num_nodes'] if num_nodes is None else num_nodes)
+    e = ei.shape[1]
+    member = torch.zeros(n, dtype=torch.bool)
+    member[node_idx] = True
+    order = torch.argsort(ei[0] * n + ei[1], stable=True)
+    keep = order[(member[ei[0]] & member[ei[1]])[order]]
+    relabel = torch.full((n,), -1, dtype=torch.long)
+    relabel[node_idx] = torch.arange(node_idx.numel())
+    out = {'num_nodes': int(node_idx.numel()), 'edge_index': relabel[ei[:, keep]]}
+    for k, v in data.items():
+        if k in ('edge_index', 'num_nodes'):
+            continue
+        if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n:
+            out[k] = v[node_idx]
+        elif torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == e:
+            out[k] = v[keep]
+        else:
+            out[k] = v
+    return out
+
+
 def is_undirected(edge_index, num_nodes):
     a, _ = coalesce(edge_index, [], num_nodes)
     b, _ = coalesce(edge_index.flip(0), [], num_nodes)

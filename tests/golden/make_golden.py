@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import pyg_semantics as pyg  # noqa: E402
 
-STATE = {'neg': None, 'wandb': []}
+STATE = {'neg': None, 'wandb': [], 'neg_gen': None, 'neg_log': [], 'batches': []}
 
 
 # --------------------------------------------------------------------------- stubs
@@ -52,9 +52,56 @@ def _mod(name, **attrs):
 
 
 def _neg_stub(edge_index=None, num_nodes=None, num_neg_samples=None, **kw):
+    if STATE.get('neg_gen') is not None:
+        # mini-batch loops draw fresh negatives per batch: drawn here from a seeded generator and RECORDED, so the
+        # fixture holds every set the reference's loop consumed, in order
+        neg = torch.randint(0, int(num_nodes), (2, int(num_neg_samples)), generator=STATE['neg_gen'])
+        STATE['neg_log'].append(neg.clone())
+        return neg
     neg = STATE['neg']
     assert neg is not None and neg.shape[1] == int(num_neg_samples), (neg.shape, num_neg_samples)
     return neg.clone()
+
+
+def saint_batch(data, node_idx):
+    """What torch_geometric's GraphSAINTSampler hands the loop for one sampled node set [PyG-mem]: the induced
+    subgraph in the adjacency's (row, col) order with relabelled endpoints, node-sized tensors sliced by the
+    (sorted) node ids, edge-sized tensors by the kept edges, everything else passed through."""
+    n, ei = int(data['num_nodes']), data['edge_index']
+    e = ei.shape[1]
+    member = torch.zeros(n, dtype=torch.bool)
+    member[node_idx] = True
+    order = torch.argsort(ei[0] * n + ei[1], stable=True)          # SparseTensor(row, col, value=arange(E)) order
+    keep = order[(member[ei[0]] & member[ei[1]])[order]]
+    relabel = torch.full((n,), -1, dtype=torch.long)
+    relabel[node_idx] = torch.arange(node_idx.numel())
+    b = Bag(num_nodes=int(node_idx.numel()), edge_index=relabel[ei[:, keep]])
+    for k, v in data.items():
+        if k in ('edge_index', 'num_nodes'):
+            continue
+        if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n:
+            b[k] = v[node_idx]
+        elif torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == e:
+            b[k] = v[keep]
+        else:
+            b[k] = v
+    return b
+
+
+class _SaintStub:
+    """GraphSAINTRandomWalkSampler with INJECTED node sets (STATE['batches']): the sampler's random stream cannot
+    be reproduced without torch_sparse, the loop that consumes its batches can."""
+
+    def __init__(self, data, batch_size=None, walk_length=None, num_steps=None, **kw):
+        self.data = data
+        assert num_steps == len(STATE['batches']), (num_steps, len(STATE['batches']))
+
+    def __len__(self):
+        return len(STATE['batches'])
+
+    def __iter__(self):
+        for nodes in STATE['batches']:
+            yield saint_batch(self.data, nodes)
 
 
 def _khop_stub(node_idx, num_hops, edge_index, relabel_nodes=False, num_nodes=None, **kw):
@@ -160,7 +207,7 @@ def install_stubs():
     _mod('torch_geometric.typing', Adj=object, OptTensor=object, Size=object, OptPairTensor=object)
     _mod('torch_geometric.utils', softmax=_pyg_softmax, negative_sampling=_neg_stub, k_hop_subgraph=_khop_stub,
          to_undirected=_to_undirected_stub, is_undirected=_is_undirected_stub, to_networkx=None)
-    _mod('torch_geometric.loader', GraphSAINTRandomWalkSampler=None)
+    _mod('torch_geometric.loader', GraphSAINTRandomWalkSampler=_SaintStub)
     _mod('torch_geometric.data', DataLoader=None, Data=Bag)
     _mod('torch_geometric.seed', seed_everything=_seed_everything)
     _mod('torch_scatter', scatter_add=None)
@@ -169,6 +216,11 @@ def install_stubs():
          watch=lambda *a, **k: None)
     _mod('ogb')
     _mod('ogb.graphproppred', Evaluator=None)
+    _mod('ogb.linkproppred', PygLinkPropPredDataset=None)
+    _mod('torch_geometric.transforms', NormalizeFeatures=None)
+    _mod('torch_geometric.datasets', CitationFull=None, Coauthor=None, Flickr=None, RelLinkPredDataset=None,
+         WordNet18=None, WordNet18RR=None)
+    sys.modules['torch_geometric.utils'].train_test_split_edges = None
     _mod('train_mi', MLPAttacker=None)
     for name, path in [('framework', f'{REF}/framework'), ('framework.trainer', f'{REF}/framework/trainer')]:
         pkg = types.ModuleType(name)
@@ -580,6 +632,263 @@ def golden_rgat(D, A):
         np.savez_compressed(os.path.join(HERE, f'wiring_rgat_{tag}.npz'), **out)
 
 
+
+def _node_sets(n, k, size, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randperm(n, generator=g)[:size].sort().values for _ in range(k)]
+
+
+def golden_minibatch(D, T, A):
+    """The real GraphSAINT mini-batch loop GNNDeleteNodeembTrainer.train_minibatch
+    (gnndelete_nodeemb.py:352-495) on injected batches: original embeddings on ALL batch edges, Del forward
+    on the batch's S_Df edges with per-batch masks, fresh negatives per batch (recorded), layer-wise update with
+    zero_grad right after each step.  GATDelete: upstream's GCNDelete crashes in this loop too."""
+    g = synth_graph(140, 620, 10, seed=61)
+    d, _ = prepare_deletion(g, 24, seed=9)
+    model, _ = build_ref_model(D, A, 'gat', d, 10, seed=7)
+    with torch.no_grad():
+        model.deletion1.deletion_weight.fill_(1 / 1000)
+        model.deletion2.deletion_weight.fill_(1 / 1000)
+    init = state_np(model)
+    model.to = lambda *a, **k: model
+    args = make_args(A, ['--gnn', 'gat', '--unlearning_model', 'gnndelete_nodeemb', '--epochs', '3', '--valid_freq', '3',
+                         '--checkpoint_dir', tempfile.mkdtemp(), '--dataset', 'Cora', '--lr', '0.01', '--alpha', '0.4',
+                         '--batch_size', '40', '--num_steps', '3'])
+    opt = [torch.optim.Adam(model.deletion1.parameters(), lr=args.lr),
+           torch.optim.Adam(model.deletion2.parameters(), lr=args.lr)]
+    STATE['batches'] = _node_sets(140, 3, 90, seed=3)
+    STATE['neg_gen'], STATE['neg_log'], STATE['wandb'] = torch.Generator().manual_seed(17), [], []
+    torch.manual_seed(80)
+    try:
+        T.GNNDeleteNodeembTrainer(args).train_minibatch(model, d, opt, args)
+    finally:
+        STATE['neg_gen'] = None
+    steps = [w for w in STATE['wandb'] if 'Epoch' in w]
+    vals = [w for w in STATE['wandb'] if 'val_loss' in w]
+    out = dict(init)
+    d2 = Bag({k: v for k, v in d.items() if k not in ('node_id',) and not k.endswith('_non_df_mask')})
+    out.update(data_np(d2, torch.zeros(2, 0, dtype=torch.long)))
+    for i, b in enumerate(STATE['batches']):
+        out[f'batch::{i}'] = np_(b)
+    for i, ng in enumerate(STATE['neg_log']):
+        out[f'negs::{i}'] = np_(ng)
+    out.update(n_batches=np.int64(len(STATE['batches'])), n_negs=np.int64(len(STATE['neg_log'])),
+               train_loss=np.array([s_['train_loss'] for s_ in steps]),
+               train_loss_l=np.array([s_['train_loss_l'] for s_ in steps]),
+               train_loss_r=np.array([s_['train_loss_r'] for s_ in steps]),
+               final_w1=np_(model.deletion1.deletion_weight), final_w2=np_(model.deletion2.deletion_weight),
+               val_dt_auc=np.array([v['val_dt_auc'] for v in vals]), val_df_auc=np.array([v['val_df_auc'] for v in vals]),
+               lr=np.float64(args.lr), alpha=np.float64(args.alpha), epochs=np.int64(3), eval_seed=np.int64(80))
+    np.savez_compressed(os.path.join(HERE, 'traj_minibatch_gat.npz'), **out)
+
+
+def kg_request(n, m, R, seed, df_count):
+    """delete_gnn.py:85-171 (KG branch) on a synthetic relational graph: directed training triples, Df by index,
+    k-hop masks on the directed list, reverse edges with type + R appended, masks repeat(2)."""
+    g = synth_graph(n, m, 4, seed=seed, relations=R)
+    gen = torch.Generator().manual_seed(seed + 1)
+    E, et = g['train'], g['train_type']
+    df_idx = torch.randperm(E.shape[1], generator=gen)[:df_count]
+    df_mask = torch.zeros(E.shape[1], dtype=torch.bool)
+    df_mask[df_idx] = True
+    seeds = E[:, df_mask].flatten().unique()
+    _, e2, m2 = pyg.k_hop_subgraph(seeds, 2, E, n)
+    _, e1, _ = pyg.k_hop_subgraph(seeds, 1, E, n)
+    s1 = torch.zeros(n, dtype=torch.bool)
+    s2 = torch.zeros(n, dtype=torch.bool)
+    s1[e1.flatten().unique()] = True
+    s2[e2.flatten().unique()] = True
+    nv = g['val_pos'].shape[1]
+    d = Bag(x=torch.arange(n), num_nodes=n, train_pos_edge_index=E, train_edge_type=et,
+            edge_index=torch.cat([E, E.flip(0)], 1), edge_type=torch.cat([et, et + R]),
+            df_mask=df_mask.repeat(2), dr_mask=(~df_mask).repeat(2), sdf_mask=m2.repeat(2),
+            sdf_node_1hop_mask=s1, sdf_node_2hop_mask=s2,
+            directed_df_edge_index=E[:, df_mask], directed_df_edge_type=et[df_mask],
+            val_pos_edge_index=g['val_pos'], val_neg_edge_index=g['val_neg'],
+            val_edge_type=torch.randint(0, R, (nv,), generator=gen),
+            test_pos_edge_index=g['test_pos'], test_neg_edge_index=g['test_neg'],
+            test_edge_type=torch.randint(0, R, (g['test_pos'].shape[1],), generator=gen))
+    return d
+
+
+def golden_kg(D, T, A, B):
+    """KGGNNDeleteNodeembTrainer.train (gnndelete_nodeemb.py:659-846) on injected batches with RGCNDelete at
+    R = 21 relation types (> 20, so RGCNConv takes its block-diagonal branch, rgcn.py:17-22), negatives from the
+    reference's own negative_sampling_kg under a recorded seed; and KGTrainer.eval (base.py:495-567: DistMult
+    scores without sigmoid for Dt, 500 fresh Dr subsets for Df) on the model it leaves behind."""
+    R, n = 21, 150
+    d = kg_request(n, 900, R, seed=71, df_count=40)
+    args = make_args(A, ['--gnn', 'rgcn', '--unlearning_model', 'gnndelete_nodeemb', '--dataset', 'WordNet18',
+                         '--in_dim', '32', '--hidden_dim', '32', '--out_dim', '16', '--checkpoint_dir', tempfile.mkdtemp(),
+                         '--alpha', '0.4'])
+    args.epochs, args.valid_freq, args.batch_size, args.num_steps, args.lr, args.num_edge_type = 2, 2, 30, 3, 0.01, R
+    torch.manual_seed(15)
+    model = D.RGCNDelete(args, n, R, d['sdf_node_1hop_mask'], d['sdf_node_2hop_mask'])
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if n_.endswith('bias'):
+                p.copy_(torch.randn_like(p) * 0.1)
+    init = state_np(model)
+    model.to = lambda *a, **k: model
+    opt = [torch.optim.Adam(model.deletion1.parameters(), lr=args.lr),
+           torch.optim.Adam(model.deletion2.parameters(), lr=args.lr)]
+    STATE['batches'] = _node_sets(n, 3, 110, seed=5)
+    STATE['wandb'] = []
+    torch.manual_seed(81)                     # negative_sampling_kg and the 500 Dr subsets of eval draw from this stream
+    trainer = T.KGGNNDeleteNodeembTrainer(args)
+    trainer.train(model, d, opt, args)
+    steps = [w for w in STATE['wandb'] if 'Epoch' in w]
+    vals = [w for w in STATE['wandb'] if 'val_loss' in w]
+    out = dict(init)
+    d2 = Bag({k: v for k, v in d.items() if not k.endswith('_non_df_mask')})
+    out.update(data_np(d2, torch.zeros(2, 0, dtype=torch.long)))
+    for i, b in enumerate(STATE['batches']):
+        out[f'batch::{i}'] = np_(b)
+    out.update(n_batches=np.int64(3), num_edge_type=np.int64(R),
+               train_loss=np.array([s_['train_loss'] for s_ in steps]), loss_r=np.array([s_['loss_r'] for s_ in steps]),
+               loss_l=np.array([s_['loss_l'] for s_ in steps]),
+               final_w1=np_(model.deletion1.deletion_weight), final_w2=np_(model.deletion2.deletion_weight),
+               val_loss=np.array([v['val_loss'] for v in vals]), val_dt_auc=np.array([v['val_dt_auc'] for v in vals]),
+               val_dt_aup=np.array([v['val_dt_aup'] for v in vals]), val_df_auc=np.array([v['val_df_auc'] for v in vals]),
+               val_df_aup=np.array([v['val_df_aup'] for v in vals]),
+               lr=np.float64(args.lr), alpha=np.float64(args.alpha), epochs=np.int64(2), seed=np.int64(81))
+    np.savez_compressed(os.path.join(HERE, 'traj_kg_rgcn.npz'), **out)
+    # ---- KGTrainer.eval on the trained model, own seed
+    torch.manual_seed(82)
+    loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, _, log = B.KGTrainer.eval(trainer, model, d, 'test')
+    ev = dict(state_np(model))
+    ev.update(data_np(d2, torch.zeros(2, 0, dtype=torch.long)))
+    ev.update(num_edge_type=np.int64(R), eval_seed=np.int64(82), test_loss=np.float64(loss), test_dt_auc=np.float64(dt_auc),
+              test_dt_aup=np.float64(dt_aup), test_df_auc=np.float64(df_auc), test_df_aup=np.float64(df_aup),
+              test_df_logit=np.array(df_logit))
+    np.savez_compressed(os.path.join(HERE, 'eval_kg.npz'), **ev)
+
+
+def golden_retrain(A):
+    """RetrainTrainer.train_fullbatch (framework/trainer/retrain.py:39-131): BCE link prediction on Dr only with
+    per-epoch negatives (recorded), Adam on every parameter, Trainer.eval for model selection; plus
+    verification_error (framework/evaluation.py:63-81) between the retrained and a second model."""
+    RT = importlib.import_module('framework.trainer.retrain')
+    EV = importlib.import_module('framework.evaluation')
+    GCN = importlib.import_module('framework.models.gcn').GCN
+    g = synth_graph(90, 340, 10, seed=43)
+    d, _ = prepare_deletion(g, 12, seed=10)
+    args = make_args(A, ['--gnn', 'gcn', '--unlearning_model', 'retrain', '--in_dim', '10', '--hidden_dim', '32',
+                         '--out_dim', '16', '--dataset', 'Cora', '--checkpoint_dir', tempfile.mkdtemp(), '--lr', '0.01'])
+    args.epochs, args.valid_freq = 5, 5
+    torch.manual_seed(13)
+    model = GCN(args)
+    other = GCN(args)
+    init = state_np(model)
+    model.to = lambda *a, **k: model
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    STATE['neg_gen'], STATE['neg_log'], STATE['wandb'] = torch.Generator().manual_seed(19), [], []
+    torch.manual_seed(83)
+    try:
+        RT.RetrainTrainer(args).train_fullbatch(model, d, opt, args)
+    finally:
+        STATE['neg_gen'] = None
+    steps = [w for w in STATE['wandb'] if 'Epoch' in w]
+    vals = [w for w in STATE['wandb'] if 'val_loss' in w]
+    out = dict(init)
+    out.update(data_np(d, torch.zeros(2, 0, dtype=torch.long)))
+    out.update({f'final::{k}': np_(v) for k, v in model.state_dict().items()})
+    out.update({f'other::{k}': np_(v) for k, v in other.state_dict().items()})
+    for i, ng in enumerate(STATE['neg_log']):
+        out[f'negs::{i}'] = np_(ng)
+    out.update(n_negs=np.int64(len(STATE['neg_log'])), train_loss=np.array([s_['train_loss'] for s_ in steps]),
+               val_loss=np.array([v['val_loss'] for v in vals]), val_dt_auc=np.array([v['val_dt_auc'] for v in vals]),
+               val_df_auc=np.array([v['val_df_auc'] for v in vals]),
+               ve=np.float64(EV.verification_error(model, other)),
+               lr=np.float64(args.lr), epochs=np.int64(5), eval_seed=np.int64(83))
+    np.savez_compressed(os.path.join(HERE, 'retrain_gcn.npz'), **out)
+
+
+def golden_split():
+    """train_test_split_edges_no_neg_adj_mask (prepare_dataset.py:31-136) and the IN / OUT candidate masks
+    (:205-214) run from the reference's own module: plain, with the two-hop-degree ordering the ogbl-* datasets
+    get (:186-189), and the KG branch (edge types sliced WITHOUT the permutation, as upstream does)."""
+    old_cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp())
+    sys.path.insert(0, REF)
+    try:
+        P = importlib.import_module('prepare_dataset')
+    finally:
+        sys.path.remove(REF)
+        os.chdir(old_cwd)
+    out = {}
+    for tag, n, m, kg, deg in [('plain', 80, 300, False, False), ('degree', 90, 360, False, True), ('kg', 70, 260, True, False)]:
+        g = synth_graph(n, m, 3, seed=91 + n, relations=5 if kg else 0)
+        gen = torch.Generator().manual_seed(n)
+        E = torch.cat([g['train'], g['val_pos'], g['test_pos']], 1)
+        if kg:
+            ei = E[:, torch.randperm(E.shape[1], generator=gen)]
+            et = torch.randint(0, 5, (ei.shape[1],), generator=gen)
+        else:
+            both = torch.cat([E, E.flip(0)], 1)
+            ei = both[:, torch.randperm(both.shape[1], generator=gen)]
+            et = None
+        n_dir = int((ei[0] < ei[1]).sum()) if not kg else ei.shape[1]
+        thd = torch.randint(10, 100, (n_dir,), generator=gen) if deg else None
+        data = Bag(num_nodes=n, edge_index=ei.clone(), edge_attr=None, edge_type=et)
+        STATE['neg_gen'], STATE['neg_log'] = torch.Generator().manual_seed(23), []
+        torch.manual_seed(500 + n)
+        try:
+            res = P.train_test_split_edges_no_neg_adj_mask(data, test_ratio=0.05, two_hop_degree=thd, kg=kg)
+        finally:
+            STATE['neg_gen'] = None
+        _, _, _, local = sys.modules['torch_geometric.utils'].k_hop_subgraph(
+            res['test_pos_edge_index'].flatten().unique(), 2, res['train_pos_edge_index'], num_nodes=n)
+        out.update({f'{tag}::edge_index': np_(ei), f'{tag}::num_nodes': np.int64(n), f'{tag}::seed': np.int64(500 + n),
+                    f'{tag}::train': np_(res['train_pos_edge_index']), f'{tag}::val': np_(res['val_pos_edge_index']),
+                    f'{tag}::test': np_(res['test_pos_edge_index']), f'{tag}::in_mask': np_(local)})
+        if thd is not None:
+            out[f'{tag}::two_hop_degree'] = np_(thd)
+        if kg:
+            out.update({f'{tag}::edge_type': np_(et), f'{tag}::train_type': np_(res['train_edge_type']),
+                        f'{tag}::val_type': np_(res['val_edge_type']), f'{tag}::test_type': np_(res['test_edge_type']),
+                        f'{tag}::val_neg': np_(res['val_neg_edge_index']), f'{tag}::test_neg': np_(res['test_neg_edge_index'])})
+    np.savez_compressed(os.path.join(HERE, 'split.npz'), **out)
+
+
+def golden_wide_trajectories(D, T, A):
+    """train_fullbatch at the widths the fused HIP stages are built for (in 32 -> hidden 128 -> out 64), so that the
+    reference-loop fixtures drive the MFMA row kernels and the fused loss / Del stages, not the generic fallbacks."""
+    for gnn, loss_type in [('gcn', 'both_all'), ('gat', 'both_layerwise')]:
+        g = synth_graph(160, 700, 32, seed=25)
+        d, neg = prepare_deletion(g, 20, seed=11)
+        model, _ = build_ref_model(D, A, gnn, d, 32, seed=14, hidden=128, out=64)
+        with torch.no_grad():
+            model.deletion1.deletion_weight.fill_(1 / 1000)
+            model.deletion2.deletion_weight.fill_(1 / 1000)
+        init = state_np(model)
+        model.to = lambda *a, **k: model
+        args = make_args(A, ['--gnn', gnn, '--unlearning_model', 'gnndelete_nodeemb', '--epochs', '5', '--valid_freq', '5',
+                             '--loss_type', loss_type, '--checkpoint_dir', tempfile.mkdtemp(), '--dataset', 'Cora',
+                             '--lr', '0.01', '--alpha', '0.4'])
+        if 'layerwise' in loss_type:
+            opt = [torch.optim.Adam(model.deletion1.parameters(), lr=args.lr),
+                   torch.optim.Adam(model.deletion2.parameters(), lr=args.lr)]
+        else:
+            opt = torch.optim.Adam([{'params': [p for n_, p in model.named_parameters() if 'del' in n_],
+                                     'weight_decay': 0.0}], lr=args.lr)
+        STATE['neg'], STATE['wandb'] = neg, []
+        torch.manual_seed(84)
+        T.GNNDeleteNodeembTrainer(args).train_fullbatch(model, d, opt, args)
+        steps = [w for w in STATE['wandb'] if 'Epoch' in w]
+        vals = [w for w in STATE['wandb'] if 'val_loss' in w]
+        out = dict(init)
+        out.update(data_np(d, neg))
+        out.update(train_loss=np.array([s_['train_loss'] for s_ in steps]), loss_r=np.array([s_['loss_r'] for s_ in steps]),
+                   loss_l=np.array([s_['loss_l'] for s_ in steps]),
+                   final_w1=np_(model.deletion1.deletion_weight), final_w2=np_(model.deletion2.deletion_weight),
+                   val_dt_auc=np.array([v['val_dt_auc'] for v in vals]), val_df_auc=np.array([v['val_df_auc'] for v in vals]),
+                   val_loss=np.array([v['val_loss'] for v in vals]),
+                   val_df_logit_mean=np.array([v['val_df_logit_mean'] for v in vals]),
+                   lr=np.float64(args.lr), alpha=np.float64(args.alpha), epochs=np.int64(5), eval_seed=np.int64(84))
+        np.savez_compressed(os.path.join(HERE, f'traj_wide_{gnn}_{loss_type}.npz'), **out)
+
+
 def golden_gcn_layerwise_crash(D, T, A):
     """record that upstream GCNDelete + both_layerwise raises."""
     g = synth_graph(40, 120, 6, seed=31)
@@ -736,6 +1045,17 @@ def golden_prep(D):
             np.savez_compressed(os.path.join(HERE, f'prep_{gnn}_{df}.npz'), **out)
 
 
+def write_manifest(crash):
+    path = os.path.join(HERE, 'MANIFEST.json')
+    if crash is None:                                            # keep the recorded upstream error text
+        with open(path) as f:
+            crash = json.load(f).get('gcn_both_layerwise_upstream_error')
+    with open(path, 'w') as f:
+        json.dump({'generated_by': 'tests/golden/make_golden.py', 'reference': REF, 'torch': torch.__version__,
+                   'gcn_both_layerwise_upstream_error': crash,
+                   'files': sorted(x for x in os.listdir(HERE) if x.endswith(('.npz', '.json')))}, f, indent=1)
+
+
 def main():
     torch.set_num_threads(4)
     D, T, TE, A, U, B = load_reference()
@@ -751,6 +1071,14 @@ def main():
     if sys.argv[1:] == ['rgat']:
         golden_rgat(D, A)
         return
+    if sys.argv[1:] == ['round2']:              # the fixtures added in round 2 (+ the manifest)
+        golden_minibatch(D, T, A)
+        golden_kg(D, T, A, B)
+        golden_retrain(A)
+        golden_split()
+        golden_wide_trajectories(D, T, A)
+        write_manifest(None)
+        return
     golden_del_layer(D)
     golden_losses(T)
     golden_wiring(D, A)
@@ -759,17 +1087,17 @@ def main():
     golden_original_training(B, A)
     golden_nodecls_trajectory(D, T, A)
     golden_rgat(D, A)
+    golden_minibatch(D, T, A)
+    golden_kg(D, T, A, B)
+    golden_retrain(A)
+    golden_split()
+    golden_wide_trajectories(D, T, A)
     crash = golden_gcn_layerwise_crash(D, T, A)
     golden_parse_args(A)
     golden_eval(D, T, A)
     golden_neg_kg(U)
     golden_prep(D)
-    with open(os.path.join(HERE, 'MANIFEST.json'), 'w') as f:
-        json.dump({'generated_by': 'tests/golden/make_golden.py', 'reference': REF,
-                   'torch': torch.__version__,
-                   'gcn_both_layerwise_upstream_error': crash,
-                   'files': sorted(x for x in os.listdir(HERE) if x.endswith(('.npz', '.json')))},
-                  f, indent=1)
+    write_manifest(crash)
     print('golden vectors written to', HERE)
 
 

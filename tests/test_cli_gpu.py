@@ -262,3 +262,146 @@ def test_large_graph_df_subsets_are_drawn_on_the_device(monkeypatch):
     assert all(len(set(r.tolist())) == 37 for r in idx[:20])
     assert not torch.equal(idx[0], idx[1])
     assert torch.equal(idx, b._df_subset_index) and not torch.equal(idx, c._df_subset_index)
+
+
+# ----------------------------------------------------------------------------- round-2 fixtures (injected batches)
+def _lists(fx, prefix, count_key):
+    return [t(fx[f'{prefix}::{i}']) for i in range(int(fx[count_key]))]
+
+
+def test_minibatch_trainer_reproduces_reference_trajectory(tmp_path, monkeypatch):
+    """The GraphSAINT mini-batch loop (gnndelete_nodeemb.py:352-495) on the HIP path, on the node sets and negatives
+    the reference's real loop consumed: per-step losses, final Del weights (the W_D1 gradient that loss2 leaves
+    behind for the next batch included), validation AUCs."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework.data import Data
+    from gnndelete_amd.framework.trainer import gnndelete_nodeemb as TN
+    from gnndelete_amd.framework.trainer import sampler as S
+    fx = load_golden('traj_minibatch_gat.npz')
+    state, data, rest = split_fixture(fx)
+    m = hip_model('gat', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    sets, negs = _lists(fx, 'batch', 'n_batches'), iter(_lists(fx, 'negs', 'n_negs'))
+    monkeypatch.setattr(S, 'make_sampler', lambda d, batch_size, num_steps, walk_length=2: S.FixedNodeSets(d, sets))
+    monkeypatch.setattr(S, 'negative_sampling', lambda ei, n, k: next(negs).to(ei.device))
+    epochs = int(rest['epochs'])
+    args = SimpleNamespace(unlearning_model='gnndelete_nodeemb', dataset='ogbl-synth', checkpoint_dir=str(tmp_path),
+                           eval_on_cpu=False, epochs=epochs, valid_freq=epochs, lr=float(rest['lr']),
+                           alpha=float(rest['alpha']), loss_fct='mse_mean', loss_type='both_layerwise', gnn='gat',
+                           batch_size=40, num_steps=len(sets), minibatch=True)
+    opt = [torch.optim.Adam(m.deletion1.parameters(), lr=args.lr), torch.optim.Adam(m.deletion2.parameters(), lr=args.lr)]
+    tr = TN.GNNDeleteNodeembTrainer(args)
+    torch.manual_seed(int(rest['eval_seed']))
+    tr.train(m, Data(data), opt, args)
+    steps = tr.trainer_log['steps']
+    assert len(steps) == len(rest['train_loss'])
+    for key in ['train_loss', 'train_loss_l', 'train_loss_r']:
+        np.testing.assert_allclose([s_[key] for s_ in steps], rest[key], rtol=1e-4, atol=1e-8, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), rest['final_w1']) < 1e-4
+    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < 1e-4
+    vals = [r for r in tr.trainer_log['log'] if 'val_dt_auc' in r]
+    assert abs(vals[-1]['val_dt_auc'] - float(rest['val_dt_auc'][-1])) < 2e-3
+    assert abs(vals[-1]['val_df_auc'] - float(rest['val_df_auc'][-1])) < 2e-3
+
+
+def _kg_fixture(name):
+    from gnndelete_amd.framework.data import Data
+    fx = load_golden(name)
+    state, data, rest = split_fixture(fx)
+    R_ = int(rest['num_edge_type'])
+    m = hip_model('rgcn', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'], num_nodes=data['num_nodes'],
+                  num_edge_type=R_)
+    return fx, m, Data(data), rest, R_
+
+
+def test_kg_trainer_reproduces_reference_trajectory(tmp_path, monkeypatch):
+    """KGGNNDeleteNodeembTrainer.train (gnndelete_nodeemb.py:659-846) on the HIP path (typed conv kernels, 21
+    relation types -> block-diagonal weights) on the reference's batches; negative_sampling_kg and the 500 Dr
+    subsets of the closing validation re-draw the reference's random stream from the recorded seed."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework.trainer import kg as TK
+    from gnndelete_amd.framework.trainer import sampler as S
+    fx, m, data, rest, R_ = _kg_fixture('traj_kg_rgcn.npz')
+    sets = _lists(fx, 'batch', 'n_batches')
+    monkeypatch.setattr(S, 'make_sampler', lambda d, batch_size, num_steps, walk_length=2: S.FixedNodeSets(d, sets))
+    epochs = int(rest['epochs'])
+    args = SimpleNamespace(unlearning_model='gnndelete_nodeemb', dataset='WordNet18', checkpoint_dir=str(tmp_path),
+                           eval_on_cpu=False, epochs=epochs, valid_freq=epochs, lr=float(rest['lr']), alpha=float(rest['alpha']),
+                           loss_fct='mse_mean', loss_type='both_layerwise', gnn='rgcn', batch_size=30, num_steps=len(sets),
+                           num_edge_type=R_)
+    opt = [torch.optim.Adam(m.deletion1.parameters(), lr=args.lr), torch.optim.Adam(m.deletion2.parameters(), lr=args.lr)]
+    tr = TK.KGGNNDeleteNodeembTrainer(args)
+    torch.manual_seed(int(rest['seed']))
+    tr.train(m, data, opt, args)
+    steps = tr.trainer_log['steps']
+    assert len(steps) == len(rest['train_loss'])
+    for key in ['train_loss', 'loss_r', 'loss_l']:
+        np.testing.assert_allclose([s_[key] for s_ in steps], rest[key], rtol=1e-4, atol=1e-8, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), rest['final_w1']) < 1e-4
+    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < 1e-4
+    vals = [r for r in tr.trainer_log['log'] if 'val_dt_auc' in r]
+    assert abs(vals[-1]['val_loss'] - float(rest['val_loss'][-1])) < 1e-4
+    assert abs(vals[-1]['val_dt_auc'] - float(rest['val_dt_auc'][-1])) < 2e-3
+    assert abs(vals[-1]['val_df_auc'] - float(rest['val_df_auc'][-1])) < 2e-3
+
+
+def test_kg_eval_matches_reference_golden(tmp_path):
+    """KGTrainer.eval (base.py:495-567) on the HIP path: DistMult scores without sigmoid for the Dt loss / AUC / AUP,
+    500 fresh host permutations for the Df-vs-Dr statistics (same seed -> same subsets as upstream)."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework.trainer import kg as TK
+    fx, m, data, rest, R_ = _kg_fixture('eval_kg.npz')
+    args = SimpleNamespace(unlearning_model='gnndelete_nodeemb', dataset='WordNet18', checkpoint_dir=str(tmp_path),
+                           eval_on_cpu=False, num_edge_type=R_)
+    tr = TK.KGTrainer(args)
+    torch.manual_seed(int(rest['eval_seed']))
+    loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, _, log = tr.eval(m, data, 'test')
+    assert abs(loss - float(rest['test_loss'])) < 1e-4
+    assert abs(dt_auc - float(rest['test_dt_auc'])) < 2e-3 and abs(dt_aup - float(rest['test_dt_aup'])) < 2e-3
+    assert abs(df_auc - float(rest['test_df_auc'])) < 2e-3 and abs(df_aup - float(rest['test_df_aup'])) < 2e-3
+    np.testing.assert_allclose(np.array(df_logit), rest['test_df_logit'], rtol=1e-4)
+
+
+def test_retrain_trainer_reproduces_reference(tmp_path, monkeypatch):
+    """RetrainTrainer (retrain.py:39-131) on the HIP convs: Dr-only message passing / positives / negative count,
+    model selection on dt_auc + df_auc; and Trainer.test's verification error against a second model
+    (evaluation.py:63-81)."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework import get_model, get_trainer
+    from gnndelete_amd.framework.data import Data
+    from gnndelete_amd.framework.evaluation import verification_error
+    from gnndelete_amd.framework.trainer import retrain as TR
+    fx = load_golden('retrain_gcn.npz')
+    state, data, rest = split_fixture(fx)
+    w1, w2 = state['conv1.lin.weight'], state['conv2.lin.weight']
+    epochs = int(rest['epochs'])
+    args = SimpleNamespace(unlearning_model='retrain', gnn='gcn', dataset='Cora', checkpoint_dir=str(tmp_path),
+                           in_dim=w1.shape[1], hidden_dim=w1.shape[0], out_dim=w2.shape[0], eval_on_cpu=False, epochs=epochs,
+                           valid_freq=epochs, lr=float(rest['lr']))
+    m = get_model(args)
+    m.load_state_dict(state)
+    negs = iter(_lists(fx, 'negs', 'n_negs'))
+    n_dr = int(data['dr_mask'].sum())
+
+    def fake_neg(edge_index, num_nodes, num_neg_samples):
+        assert edge_index.shape[1] == n_dr and num_neg_samples == n_dr          # Dr only
+        return next(negs).to(edge_index.device)
+    monkeypatch.setattr(TR, 'negative_sampling', fake_neg)
+    tr = get_trainer(args)
+    assert isinstance(tr, TR.RetrainTrainer)
+    opt = torch.optim.Adam(m.parameters(), lr=args.lr)
+    torch.manual_seed(int(rest['eval_seed']))
+    d = Data(data)
+    d.dtrain_mask = d.dr_mask
+    tr.train(m, d, opt, args)
+    np.testing.assert_allclose([s_['train_loss'] for s_ in tr.trainer_log['steps']], rest['train_loss'], rtol=1e-4)
+    final = {k[len('final::'):]: v for k, v in fx.items() if k.startswith('final::')}
+    for k, v in m.state_dict().items():
+        assert rel_l2(v.cpu(), final[k]) < 1e-4, k
+    vals = [r for r in tr.trainer_log['log'] if 'val_dt_auc' in r]
+    assert abs(vals[-1]['val_dt_auc'] - float(rest['val_dt_auc'][-1])) < 2e-3
+    assert abs(vals[-1]['val_df_auc'] - float(rest['val_df_auc'][-1])) < 2e-3
+    assert os.path.exists(os.path.join(str(tmp_path), 'model_best.pt'))
+    other = get_model(args)
+    other.load_state_dict({k[len('other::'):]: t(v) for k, v in fx.items() if k.startswith('other::')})
+    ve = float(verification_error(m, other.cuda()))
+    assert abs(ve - float(rest['ve'])) < 1e-3 * float(rest['ve'])

@@ -146,3 +146,31 @@ def test_raw_readers_and_prepare_dataset_on_files_in_the_upstream_layouts(tmp_pa
     r = subprocess.run([sys.executable, os.path.join(root, 'prepare_dataset.py'), '--dataset', 'PubMed', '--data_dir',
                         str(tmp_path / 'data')], capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=root))
     assert r.returncode != 0 and 'no raw files' in r.stderr + r.stdout
+
+
+@pytest.mark.parametrize('tag', ['plain', 'degree', 'kg'])
+def test_dataset_split_reproduces_reference(tag):
+    """synth.split_linkpred / split_kg vs train_test_split_edges_no_neg_adj_mask run from the reference's own
+    prepare_dataset.py (tests/golden/split.npz): train / validation / test positives, the KG type slicing and
+    negatives, and the IN candidate mask of :205-214.  (Non-KG negatives come from torch_geometric's
+    negative_sampling upstream - a different sampler with the same contract, checked separately.)"""
+    from gnndelete_amd.framework.synth import split_kg, split_linkpred
+    fx = load_golden('split.npz')
+    ei, n, seed = t(fx[f'{tag}::edge_index']), int(fx[f'{tag}::num_nodes']), int(fx[f'{tag}::seed'])
+    if tag == 'kg':
+        torch.manual_seed(seed)
+        data, masks = split_kg(torch.arange(n), ei, t(fx[f'{tag}::edge_type']), n, 0.05, 0.05)
+        for k, f in [('train_edge_type', 'train_type'), ('val_edge_type', 'val_type'), ('test_edge_type', 'test_type'),
+                     ('val_neg_edge_index', 'val_neg'), ('test_neg_edge_index', 'test_neg')]:
+            assert torch.equal(data[k], t(fx[f'{tag}::{f}'])), k
+    else:
+        thd = t(fx[f'{tag}::two_hop_degree']) if f'{tag}::two_hop_degree' in fx else None
+        gen = torch.Generator().manual_seed(seed)
+        data, masks = split_linkpred(torch.zeros(n, 1), ei[:, ei[0] < ei[1]], n, gen, 0.05, 0.05, two_hop_degree=thd)
+        for stage in ('val', 'test'):
+            neg, pos = data[f'{stage}_neg_edge_index'], data[f'{stage}_pos_edge_index']
+            assert neg.shape == pos.shape and bool((neg[0] != neg[1]).all())
+    assert torch.equal(data.train_pos_edge_index, t(fx[f'{tag}::train']))
+    assert torch.equal(data.val_pos_edge_index, t(fx[f'{tag}::val']))
+    assert torch.equal(data.test_pos_edge_index, t(fx[f'{tag}::test']))
+    assert torch.equal(masks['in'], t(fx[f'{tag}::in_mask'])) and torch.equal(masks['out'], ~t(fx[f'{tag}::in_mask']))

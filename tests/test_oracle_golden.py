@@ -223,3 +223,110 @@ def test_preprocessing_matches_reference_main(name):
     assert torch.equal(s1, t(fx['out::sdf_node_1hop_mask']))
     assert torch.equal(s2, t(fx['out::sdf_node_2hop_mask']))
     assert torch.equal(E[:, df], t(fx['out::directed_df_edge_index']))
+
+
+# ----------------------------------------------------------------------------- round-2 fixtures
+def _fixture_lists(fx, prefix, count_key):
+    return [t(fx[f'{prefix}::{i}']) for i in range(int(fx[count_key]))]
+
+
+@pytest.mark.parametrize('gnn,loss_type', [('gcn', 'both_all'), ('gat', 'both_layerwise')])
+def test_wide_trajectory_matches_reference_loop(gnn, loss_type):
+    """train_fullbatch at widths 32 -> 128 -> 64 (the widths the fused HIP stages exist for)."""
+    fx = load_golden(f'traj_wide_{gnn}_{loss_type}.npz')
+    state, data, rest = split_fixture(fx)
+    m = oracle_model(gnn, state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    logs, _ = R.nodeemb_fullbatch(m, data, int(rest['epochs']), loss_type, float(rest['alpha']), 'mse_mean',
+                                  float(rest['lr']), neg_edge=t(rest['neg']))
+    for key in ['train_loss', 'loss_r', 'loss_l']:
+        np.testing.assert_allclose(np.array([l[key] for l in logs]), rest[key], rtol=5e-5, atol=1e-9, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach(), rest['final_w1']) < 2e-5
+    assert rel_l2(m.deletion2.deletion_weight.detach(), rest['final_w2']) < 2e-5
+
+
+def test_minibatch_trajectory_matches_reference_loop():
+    """GNNDeleteNodeembTrainer.train_minibatch (gnndelete_nodeemb.py:352-495) on the injected GraphSAINT batches:
+    per-step losses and the final Del weights (the carry-over of loss2's W_D1 gradient across batches included)."""
+    fx = load_golden('traj_minibatch_gat.npz')
+    state, data, rest = split_fixture(fx)
+    m = oracle_model('gat', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    logs = R.nodeemb_minibatch(m, data, _fixture_lists(fx, 'batch', 'n_batches'), _fixture_lists(fx, 'negs', 'n_negs'),
+                               int(rest['epochs']), float(rest['alpha']), float(rest['lr']))
+    assert len(logs) == len(rest['train_loss'])
+    for key in ['train_loss', 'train_loss_l', 'train_loss_r']:
+        np.testing.assert_allclose(np.array([l[key] for l in logs]), rest[key], rtol=2e-5, atol=1e-9, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach(), rest['final_w1']) < 1e-5
+    assert rel_l2(m.deletion2.deletion_weight.detach(), rest['final_w2']) < 1e-5
+
+
+def test_kg_trajectory_matches_reference_loop():
+    """KGGNNDeleteNodeembTrainer.train (gnndelete_nodeemb.py:659-846) with RGCNDelete at 21 relation types
+    (block-diagonal weights): per-step losses and final Del weights, negatives re-drawn from the recorded seed."""
+    fx = load_golden('traj_kg_rgcn.npz')
+    state, data, rest = split_fixture(fx)
+    R_ = int(rest['num_edge_type'])
+    m = oracle_model('rgcn', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'], num_nodes=data['num_nodes'],
+                     num_edge_type=R_)
+    torch.manual_seed(int(rest['seed']))
+    logs = R.kg_nodeemb_minibatch(m, data, _fixture_lists(fx, 'batch', 'n_batches'), R_, int(rest['epochs']),
+                                  float(rest['alpha']), float(rest['lr']))
+    for key in ['train_loss', 'loss_r', 'loss_l']:
+        np.testing.assert_allclose(np.array([l[key] for l in logs]), rest[key], rtol=5e-5, atol=1e-9, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach(), rest['final_w1']) < 2e-5
+    assert rel_l2(m.deletion2.deletion_weight.detach(), rest['final_w2']) < 2e-5
+    # the validation at the end of the loop continues the same RNG stream (500 fresh Dr subsets)
+    ev = R.eval_kg(m, data, 'val')
+    assert abs(ev['dt_auc'] - float(rest['val_dt_auc'][-1])) < 1e-6
+    assert abs(ev['df_auc'] - float(rest['val_df_auc'][-1])) < 1e-6
+    assert abs(ev['loss'] - float(rest['val_loss'][-1])) < 1e-5
+
+
+def test_kg_eval_matches_reference():
+    """KGTrainer.eval (base.py:495-567): DistMult without sigmoid for Dt, 500 fresh Dr subsets for Df."""
+    fx = load_golden('eval_kg.npz')
+    state, data, rest = split_fixture(fx)
+    R_ = int(rest['num_edge_type'])
+    m = oracle_model('rgcn', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'], num_nodes=data['num_nodes'],
+                     num_edge_type=R_)
+    torch.manual_seed(int(rest['eval_seed']))
+    ev = R.eval_kg(m, data, 'test')
+    assert abs(ev['loss'] - float(rest['test_loss'])) < 1e-5
+    for k in ['dt_auc', 'dt_aup', 'df_auc', 'df_aup']:
+        assert abs(ev[k] - float(rest[f'test_{k}'])) < 1e-6, k
+    np.testing.assert_allclose(np.array(ev['df_logit']), rest['test_df_logit'], rtol=1e-5)
+
+
+def test_retrain_matches_reference_loop():
+    """RetrainTrainer.train_fullbatch (retrain.py:39-131) and verification_error (evaluation.py:63-81)."""
+    fx = load_golden('retrain_gcn.npz')
+    state, data, rest = split_fixture(fx)
+    w1, w2 = state['conv1.lin.weight'], state['conv2.lin.weight']
+    m = R.TwoLayer('gcn', w1.shape[1], w1.shape[0], w2.shape[0])
+    m.load_state_dict(state)
+    losses = R.retrain_fullbatch(m, data, int(rest['epochs']), float(rest['lr']), _fixture_lists(fx, 'negs', 'n_negs'))
+    np.testing.assert_allclose(losses, rest['train_loss'], rtol=2e-5)
+    final = {k[len('final::'):]: v for k, v in fx.items() if k.startswith('final::')}
+    for k, v in m.state_dict().items():
+        assert rel_l2(v, final[k]) < 1e-5, k
+    other = R.TwoLayer('gcn', w1.shape[1], w1.shape[0], w2.shape[0])
+    other.load_state_dict({k[len('other::'):]: t(v) for k, v in fx.items() if k.startswith('other::')})
+    assert abs(R.verification_error(m, other) - float(rest['ve'])) < 1e-4 * float(rest['ve'])
+
+
+@pytest.mark.parametrize('tag', ['plain', 'degree', 'kg'])
+def test_split_matches_reference(tag):
+    """train_test_split_edges_no_neg_adj_mask (prepare_dataset.py:31-136) + the IN candidate mask (:205-214)."""
+    fx = load_golden('split.npz')
+    kg = tag == 'kg'
+    torch.manual_seed(int(fx[f'{tag}::seed']))
+    thd = t(fx[f'{tag}::two_hop_degree']) if f'{tag}::two_hop_degree' in fx else None
+    out = R.split_edges(t(fx[f'{tag}::edge_index']), int(fx[f'{tag}::num_nodes']), test_ratio=0.05, two_hop_degree=thd,
+                        kg=kg, edge_type=t(fx[f'{tag}::edge_type']) if kg else None)
+    for k in ['train', 'val', 'test', 'in_mask']:
+        assert torch.equal(out[k], t(fx[f'{tag}::{k}'])), k
+    if kg:
+        for k in ['train_type', 'val_type', 'test_type']:
+            assert torch.equal(out[k], t(fx[f'{tag}::{k}'])), k
+        # negatives: the reference's negative_sampling_kg continues the same RNG stream (test first, then val)
+        assert torch.equal(R.negative_sampling_kg(out['test'], out['test_type']), t(fx[f'{tag}::test_neg']))
+        assert torch.equal(R.negative_sampling_kg(out['val'], out['val_type']), t(fx[f'{tag}::val_neg']))
