@@ -399,16 +399,21 @@ __global__ __launch_bounds__(256) void gat_fixup_fwd_kernel(const int4* __restri
     float4 o = f4_zero();
     const float4* sp4 = reinterpret_cast<const float4*>(scratch + (int64_t)slot0 * d4 * 4) + vec;
     if (n <= kWave) {
+      // piece s's factor lives in lane s.  Only the lanes with vec < d4 are inside this loop, and the LDS crossbar
+      // (__shfl = ds_bpermute) returns 0 for a source lane that is masked off - a hub row with more pieces than
+      // d/4 lanes lost its tail (found by tests/test_full_size_gpu.py on a degree-1884 row at d = 64).  v_readlane
+      // reads the register of ANY lane; s is wave-uniform.
+      auto factor = [&](int s_) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f_lane), s_)); };
       int s = 0;
       for (; s + 4 <= n; s += 4) {              // four pieces in flight, accumulated in slot order
         const float4 p0 = sp4[(int64_t)s * d4], p1 = sp4[(int64_t)(s + 1) * d4], p2 = sp4[(int64_t)(s + 2) * d4],
                      p3 = sp4[(int64_t)(s + 3) * d4];
-        o = f4_fma(__shfl(f_lane, s), p0, o);
-        o = f4_fma(__shfl(f_lane, s + 1), p1, o);
-        o = f4_fma(__shfl(f_lane, s + 2), p2, o);
-        o = f4_fma(__shfl(f_lane, s + 3), p3, o);
+        o = f4_fma(factor(s), p0, o);
+        o = f4_fma(factor(s + 1), p1, o);
+        o = f4_fma(factor(s + 2), p2, o);
+        o = f4_fma(factor(s + 3), p3, o);
       }
-      for (; s < n; ++s) o = f4_fma(__shfl(f_lane, s), sp4[(int64_t)s * d4], o);
+      for (; s < n; ++s) o = f4_fma(factor(s), sp4[(int64_t)s * d4], o);
     } else {
       for (int s = 0; s < n; ++s) {
         const float f = expf(scratch_ms[2 * (slot0 + s)] - mx);

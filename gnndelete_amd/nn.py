@@ -105,6 +105,12 @@ class SAGEConv(nn.Module):
         return agg + self.lin_r(x)
 
 
+def _tensor_key(*tensors):
+    """Cache key of device tensors that also changes when one of them is edited IN PLACE (storage address, shape
+    and torch's version counter) - an identity check alone would hand back a stale CSR after `edge_index[...] = ...`."""
+    return tuple((t.data_ptr(), tuple(t.shape), t._version) for t in tensors)
+
+
 class RGCNConv(nn.Module):
     """aggr='mean', root_weight, bias; dense [R, in, out] or block-diagonal
     [R, num_blocks, in/nb, out/nb] relation weights."""
@@ -124,18 +130,19 @@ class RGCNConv(nn.Module):
         self._typed_nodes = None
 
     def _typed_csr(self, edge_index, edge_type, n):
-        c = self._typed
-        if c is None or c[0] is not edge_index or c[1] is not edge_type or c[2] != n:
-            c = (edge_index, edge_type, n, build_typed_csr(edge_index, edge_type, n, self.num_relations))
+        c, key = self._typed, (_tensor_key(edge_index, edge_type), n)
+        if c is None or c[0] != key:
+            # the entry keeps the key tensors alive, so their storage cannot be recycled for another edge list
+            c = (key, build_typed_csr(edge_index, edge_type, n, self.num_relations), edge_index, edge_type)
             self._typed = c
-        return c[3]
+        return c[1]
 
     def _typed_node_csr(self, edge_index, edge_type, n):
-        c = self._typed_nodes
-        if c is None or c[0] is not edge_index or c[1] is not edge_type or c[2] != n:
-            c = (edge_index, edge_type, n, TypedNodeCSR(edge_index, edge_type, n, self.num_relations))
+        c, key = self._typed_nodes, (_tensor_key(edge_index, edge_type), n)
+        if c is None or c[0] != key:
+            c = (key, TypedNodeCSR(edge_index, edge_type, n, self.num_relations), edge_index, edge_type)
             self._typed_nodes = c
-        return c[3]
+        return c[1]
 
     def forward(self, x, edge_index, edge_type):
         n = x.shape[0]
@@ -193,11 +200,11 @@ class RGATConv(nn.Module):
         self._typed_nodes = None
 
     def _typed_node_csr(self, edge_index, edge_type, n):
-        c = self._typed_nodes
-        if c is None or c[0] is not edge_index or c[1] is not edge_type or c[2] != n:
-            c = (edge_index, edge_type, n, TypedNodeCSR(edge_index, edge_type, n, self.num_relations))
+        c, key = self._typed_nodes, (_tensor_key(edge_index, edge_type), n)
+        if c is None or c[0] != key:
+            c = (key, TypedNodeCSR(edge_index, edge_type, n, self.num_relations), edge_index, edge_type)
             self._typed_nodes = c
-        return c[3]
+        return c[1]
 
     def _relation_vectors(self, v):
         """W_r v for every relation: [R, in]."""

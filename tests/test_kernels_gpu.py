@@ -660,3 +660,41 @@ def test_rows_gemm_dots_matches_fp64(n, d_in, d_out, select):
     assert rel_l2(h.cpu(), want) < TOL
     assert rel_l2(a1.cpu(), want @ u1.double()) < TOL
     assert rel_l2(a2.cpu(), want @ u2.double().reshape(-1)) < TOL
+
+
+@pytest.mark.parametrize('d,hub_degree', [(64, 1500), (16, 700), (128, 2500), (64, 5000)])
+def test_gat_hub_row_with_more_pieces_than_feature_lanes(d, hub_degree):
+    """A hub row is cut into pieces of 64 in-edges that the fix-up merges flash-attention style.  With more pieces
+    than d/4 (the lanes that carry features in the fix-up) the merge used to drop the tail pieces' rescale factors
+    (LDS-crossbar shuffle from masked-off lanes reads 0); > 64 pieces take the serial branch.  Forward and backward
+    of the balanced GAT kernels on a graph with one such hub vs the fp64 oracle."""
+    from gnndelete_amd import ops
+    from gnndelete_amd.graph import build_csr
+    from oracle import pyg_semantics as pyg
+    n = hub_degree + 200
+    g = torch.Generator().manual_seed(d + hub_degree)
+    hub = 17
+    src = torch.randperm(n, generator=g)[:hub_degree]
+    ei = torch.cat([torch.stack([src, torch.full_like(src, hub)]), torch.randint(0, n, (2, 3 * n), generator=g)], 1)
+    ei = ei[:, ei[0] != ei[1]]
+    ei = torch.unique(ei[0] * n + ei[1])
+    ei = torch.stack([ei // n, ei % n])
+    x = torch.randn(n, 12, generator=g, dtype=torch.float64)
+    w = torch.randn(d, 12, generator=g, dtype=torch.float64) * 0.3
+    a_s, a_d = (torch.randn(1, 1, d, generator=g, dtype=torch.float64) for _ in range(2))
+    b = torch.randn(d, generator=g, dtype=torch.float64)
+    up = torch.randn(n, d, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    want = pyg.gat_conv(xr, ei, w, a_s, a_d, b)
+    want.backward(up)
+    gr = build_csr(ei.cuda(), n, 'gat')
+    assert int(gr.plan.split[:, 2].max()) > d // 4, 'the hub must be cut into more pieces than feature lanes'
+    xg = x.float().cuda().requires_grad_(True)
+    h = xg @ w.float().cuda().t()
+    out = ops.gat_aggregate(h, (h * a_s.float().cuda().view(1, -1)).sum(-1), (h * a_d.float().cuda().view(1, -1)).sum(-1),
+                            gr, b.float().cuda())
+    err = (out.detach().cpu().double() - want.detach()).norm(dim=1) / want.detach().norm(dim=1)
+    assert float(err[hub]) < 1e-5, float(err[hub])
+    assert rel_l2(out.detach().cpu(), want.detach()) < TOL
+    out.backward(up.float().cuda())
+    assert rel_l2(xg.grad.cpu(), xr.grad) < 5e-5

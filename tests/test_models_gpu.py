@@ -149,3 +149,26 @@ def test_sage_extension_matches_oracle_forward_and_gradients():
     o1, o2 = hip.get_original_embeddings(x.cuda(), ei.cuda(), return_all_emb=True)
     q1, q2 = ref.get_original_embeddings(x, ei, return_all_emb=True)
     assert rel_l2(o2.detach().cpu(), q2.detach()) < TOL
+
+
+def test_typed_csr_cache_sees_in_place_edits():
+    """The R-GCN / R-GAT convs cache their relation-typed CSR per (edge_index, edge_type); editing either tensor IN
+    PLACE must rebuild it (keyed on storage address + torch's version counter, not on object identity alone)."""
+    from gnndelete_amd.nn import RGCNConv
+    from oracle import pyg_semantics as pyg
+    torch.manual_seed(0)
+    n, r = 50, 3
+    conv = RGCNConv(8, 8, r).cuda()
+    x = torch.randn(n, 8).cuda()
+    ei = torch.randint(0, n, (2, 200)).cuda()
+    et = torch.randint(0, r, (200,)).cuda()
+
+    def ref():
+        return pyg.rgcn_conv(x.cpu(), ei.cpu(), et.cpu(), conv.weight.detach().cpu(), conv.root.detach().cpu(),
+                             conv.bias.detach().cpu())
+    with torch.no_grad():
+        assert rel_l2(conv(x, ei, et).cpu(), ref()) < TOL
+        ei[0, :50] = torch.randint(0, n, (50,)).cuda()          # same tensor object, new content
+        assert rel_l2(conv(x, ei, et).cpu(), ref()) < TOL
+        et[:50] = (et[:50] + 1) % r
+        assert rel_l2(conv(x, ei, et).cpu(), ref()) < TOL
