@@ -6,8 +6,8 @@
 // Both use v_mfma_f32_32x32x2_f32 (exact fp32 = a k-ordered fmaf chain, 64 FLOP/clk/SIMD: the
 // Del GEMM at d=128 has intensity d/4 = 32 flop/B and sits on the compute side of the ridge).
 //
-// forward kernel: the [d_in, d_out] weight lives in LDS for the life of the block (XOR-swizzled
-// columns so the straight fill, the transposed fill and the reads are bank-conflict free); every wave owns
+// forward kernel: the [d_in, d_out] weight lives in LDS for the life of the block, interleaved by output tile
+// (wl[k][r][t] = W(k, 32 t + r): the NT operands of a k step are one 16-byte read per lane); every wave owns
 // one 32-row tile at a time and feeds its A operand STRAIGHT from global memory: lane l holds
 // row (l&31) and loads 64 contiguous bytes per 32-wide k chunk = k-slots {32kc + 16(l>>5) + j},
 // i.e. the k index of each MFMA step is permuted (both operands agree), which turns the gather
@@ -45,20 +45,22 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
-  // ---- weight image: wl[k][n] = W[k][n] or W[n][k]
-  const int n_w = d_in * d_out;
-  // (column index XOR-swizzled with k inside each 32-wide group: conflict-free for the
-  //  straight fill, the transposed fill and the fragment reads, with no padding)
-  if (!trans_w) {
-    for (int e = tid; e < n_w; e += kGemmThreads) {
-      const int k = e / d_out, n = e % d_out;
-      wl[k * d_out + ((n & ~31) | ((n ^ k) & 31))] = w[e];
-    }
-  } else {
-    for (int e = tid; e < n_w; e += kGemmThreads) {
-      const int k = e % d_in, n = e / d_in;
-      wl[k * d_out + ((n & ~31) | ((n ^ k) & 31))] = w[e];
-    }
+  // ---- weight image, interleaved by output tile: wl[(k * 32 + r) * NTP + t] = W(k, 32 t + r), so that the NT weight
+  // operands one k step needs are ONE 16 / 8-byte LDS read per lane (conflict-free: consecutive lanes, consecutive
+  // 16 bytes) instead of NT 4-byte reads - a third of the LDS instructions per MFMA of the row-major image.
+  // Fill: one (k, r) pair per thread and step, its NT weights leave as one vector store.  With [k][n] weights
+  // (trans_w = 0) the loads are coalesced as well; with [n][k] weights they are strided (slow fill: callers with
+  // constant weights hand over a pre-transposed copy, see engine.py).
+  constexpr int NTP = NT == 3 ? 4 : NT;
+  for (int e = tid; e < d_in * 32; e += kGemmThreads) {
+    const int k = e >> 5, r = e & 31;
+    float v[NTP];
+#pragma unroll
+    for (int t = 0; t < NTP; ++t)
+      v[t] = t < NT ? (trans_w ? w[(int64_t)(32 * t + r) * d_in + k] : w[(int64_t)k * d_out + 32 * t + r]) : 0.f;
+    if (NTP == 4) *reinterpret_cast<float4*>(wl + e * 4) = make_float4(v[0], v[1], v[2], v[3 % NTP]);
+    else if (NTP == 2) *reinterpret_cast<float2*>(wl + e * 2) = make_float2(v[0], v[1 % NTP]);
+    else wl[e] = v[0];
   }
   __syncthreads();
 
@@ -128,13 +130,23 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
         const int k0 = kc * 32 + khalf * 16 + i * 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const float* wk = wl + (k0 + s) * d_out + ((r_lo ^ (k0 + s)) & 31);
+          const float* wk = wl + ((k0 + s) * 32 + r_lo) * NTP;
+          float wv[NTP];
+          if (NTP == 4) {
+            const float4 f = *reinterpret_cast<const float4*>(wk);
+            wv[0] = f.x; wv[1 % NTP] = f.y; wv[2 % NTP] = f.z; wv[3 % NTP] = f.w;
+          } else if (NTP == 2) {
+            const float2 f = *reinterpret_cast<const float2*>(wk);
+            wv[0] = f.x; wv[1 % NTP] = f.y;
+          } else {
+            wv[0] = wk[0];
+          }
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             // transposed product: the weight is the MFMA "A" operand (D rows = output features),
             // the sample row the "B" operand (D cols = samples), so every lane ends up holding
             // 4-float runs of ITS OWN output row -> float4 stores, no index reload
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[t * 32], av[s], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t], av[s], acc[t], 0, 0, 0);
           }
         }
       }
@@ -290,51 +302,68 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void rows_wgrad_mfma_kern
   }
   __syncthreads();
 
-  float4 ra[LA], rg[LB];
+  // The operand loads of tile t+1 are ISSUED before tile t feeds the matrix cores and only COMBINED (loss gradient,
+  // ReLU mask, g_add) after it, in finish(): nothing between the two may touch the loaded registers, or the
+  // compiler has to drain the loads before the MFMA loop and their whole latency is exposed once per tile
+  // (measured: 74 us with two raw operands, 106 us when the loss terms were formed inside the fetch).
+  float4 ra[LA], rg[LB], rt[LB], rx[LB];      // a rows | g (or z) rows | folded targets (LOSS) or ReLU mask | g_add
+  float rcf[LB], rcn[LB];
   auto fetch = [&](int tile) {
     const int s0 = s_begin + tile * KT;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int f = tid + NTH * i, r = f / FA, c4 = f % FA, ss = s0 + r;
-      if (ss < s_end && f < KT * FA) {
-        const int64_t row = sia[ss - s_begin];
-        ra[i] = reinterpret_cast<const float4*>(a + row * ld_a)[c4];
-      } else {
-        ra[i] = f4_zero();
-      }
+      ra[i] = f4_zero();
+      if (ss < s_end && f < KT * FA) ra[i] = reinterpret_cast<const float4*>(a + (int64_t)sia[ss - s_begin] * ld_a)[c4];
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
       const int f = tid + NTH * i, r = f / FB, c4 = f % FB, ss = s0 + r;
+      rg[i] = f4_zero();
+      rx[i] = f4_zero();
+      rt[i] = LOSS ? f4_zero() : make_float4(1.f, 1.f, 1.f, 1.f);      // (a mask of ones = no mask)
+      rcf[i] = 0.f;
+      rcn[i] = 0.f;
       if (ss < s_end && f < KT * FB) {
         const int64_t row = sig[ss - s_begin];
-        float4 v;
         if (LOSS) {
-          const int u = sls[ss - s_begin];
-          v = f4_zero();
-          if (u >= 0) {
-            const float4 zv = reinterpret_cast<const float4*>(g + row * ld_g)[c4];
-            const float4 tv = reinterpret_cast<const float4*>(loss.tm + (int64_t)u * DB)[c4];
-            const float cf = loss.coef[u], cn = loss.cnt_signed[u];
-            const float4 df = make_float4(zv.x - tv.x, zv.y - tv.y, zv.z - tv.z, zv.w - tv.w);
-            float sq = df.x * df.x;
-            sq = fmaf(df.y, df.y, sq); sq = fmaf(df.z, df.z, sq); sq = fmaf(df.w, df.w, sq);
-            if (cn >= 0.f) ls0 = fmaf(cn, sq, ls0); else ls1 = fmaf(-cn, sq, ls1);
-            v = make_float4(cf * df.x, cf * df.y, cf * df.z, cf * df.w);
-          }
+          // branch-free: a row without loss terms (slot -1) reads slot 0's target with coefficient and count 0
+          const int u = sls[ss - s_begin], uu = max(u, 0);
+          rg[i] = reinterpret_cast<const float4*>(g + row * ld_g)[c4];
+          rt[i] = reinterpret_cast<const float4*>(loss.tm + (int64_t)uu * DB)[c4];
+          rcf[i] = u >= 0 ? loss.coef[uu] : 0.f;
+          rcn[i] = u >= 0 ? loss.cnt_signed[uu] : 0.f;
         } else {
-          v = reinterpret_cast<const float4*>(g + row * ld_g)[c4];
+          rg[i] = reinterpret_cast<const float4*>(g + row * ld_g)[c4];
+          if (relu_mask) rt[i] = reinterpret_cast<const float4*>(relu_mask + row * ld_g)[c4];
         }
-        if (!LOSS && relu_mask) {
-          const float4 m = reinterpret_cast<const float4*>(relu_mask + row * ld_g)[c4];
+        if (g_add) rx[i] = reinterpret_cast<const float4*>(g_add + row * ld_g)[c4];
+      }
+    }
+  };
+  // rg <- the upstream gradient rows of the fetched tile (same arithmetic, same order as before the split)
+  auto finish = [&]() {
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      float4 v;
+      if (LOSS) {
+        const float4 zv = rg[i], tv = rt[i];
+        const float cf = rcf[i], cn = rcn[i];
+        const float4 df = make_float4(zv.x - tv.x, zv.y - tv.y, zv.z - tv.z, zv.w - tv.w);
+        float sq = df.x * df.x;
+        sq = fmaf(df.y, df.y, sq); sq = fmaf(df.z, df.z, sq); sq = fmaf(df.w, df.w, sq);
+        if (cn >= 0.f) ls0 = fmaf(cn, sq, ls0); else ls1 = fmaf(-cn, sq, ls1);
+        v = make_float4(cf * df.x, cf * df.y, cf * df.z, cf * df.w);
+      } else {
+        v = rg[i];
+        if (relu_mask) {
+          const float4 m = rt[i];
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
           v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
-        if (g_add) v = f4_add(v, reinterpret_cast<const float4*>(g_add + row * ld_g)[c4]);
-        rg[i] = v;
-      } else {
-        rg[i] = f4_zero();
       }
+      if (g_add) v = f4_add(v, rx[i]);
+      rg[i] = v;
     }
   };
   auto stash = [&](int buf) {
@@ -348,6 +377,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void rows_wgrad_mfma_kern
 
   if (n_tiles > 0) {
     fetch(0);
+    finish();
     stash(0);
   }
   __syncthreads();
@@ -369,7 +399,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void rows_wgrad_mfma_kern
         }
       }
     }
-    if (tile + 1 < n_tiles) stash(cur ^ 1);
+    if (tile + 1 < n_tiles) {
+      finish();
+      stash(cur ^ 1);
+    }
     __syncthreads();
   }
 
@@ -542,7 +575,7 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
   GD_REQUIRE(!(gate_bits && sign_out), GD_E_DIM, "gd_rows_gemm_f32: gate and sign output are exclusive");
   if (n_sel == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = (size_t)d_in * d_out * sizeof(float);
+  const size_t lds = (size_t)d_in * 32 * (d_out / 32 == 3 ? 4 : d_out / 32) * sizeof(float);   // NT = 3 is padded to 4
   const bool mfma_ok = (d_out % 32 == 0) && d_out <= 128 && (d_in % 32 == 0) && lds <= 64 * 1024 && aligned16(in) &&
                        (ld_in % 4 == 0) && (!save_in || aligned16(save_in)) && aligned16(out) && (ld_out % 4 == 0) &&
                        (!bias || aligned16(bias));

@@ -358,7 +358,7 @@ class NodeembEngine:
         """x @ weight^T: the MFMA row kernel when the weight fits its LDS image, else rocBLAS."""
         out_f, in_f = weight.shape
         if in_f % 32 == 0 and out_f % 32 == 0 and out_f <= 128 and in_f * out_f * 4 <= 64 * 1024:
-            return ops.rows_gemm(x, None, weight, trans_w=True, relu_in=relu_in)
+            return ops.rows_gemm(x, None, weight, trans_w=True, const_w=True, relu_in=relu_in)
         return torch.nn.functional.linear(torch.relu(x) if relu_in else x, weight)
 
     def _linear_relu_z1(self, weight):
@@ -367,7 +367,7 @@ class NodeembEngine:
             return self._linear(self.z1, weight, relu_in=True)
         out_f, in_f = weight.shape
         if in_f % 32 == 0 and out_f % 32 == 0 and out_f <= 128 and in_f * out_f * 4 <= 64 * 1024:
-            return ops.rows_gemm_select(self.pre1, self.z1, self._sel1, weight, trans_w=True, relu_in=True)
+            return ops.rows_gemm_select(self.pre1, self.z1, self._sel1, weight, trans_w=True, const_w=True, relu_in=True)
         z = torch.where(self._sel1.bool()[:, None], self.z1, self.pre1)
         return torch.nn.functional.linear(torch.relu(z), weight)
 
@@ -378,13 +378,13 @@ class NodeembEngine:
         if self._mode == 'gcn' and self._fused_l1:
             ops.agg_gemm_items(g, self.x, c.lin.weight, c.bias, self._pre1_ext)
         elif self._mode == 'gcn' and self._rows_only and self._split1 and self._mfma_weight(c.lin.weight):
-            ops.rows_gemm(self.x, self.idx2, c.lin.weight, trans_w=True, out=self._t1buf)
+            ops.rows_gemm(self.x, self.idx2, c.lin.weight, trans_w=True, const_w=True, out=self._t1buf)
             self._spmm(False, g.val, self._t1buf, self.pre1, c.bias, 0.0, plan=self._plan2)
         elif self._mode == 'gcn':
             self._spmm(False, g.val, self._linear(self.x, c.lin.weight), self.pre1, c.bias, 0.0)
         elif self._mode == 'gin' and self._rows_only and self._split1 and self._mfma_weight(c.nn.weight):
             lin = c.nn
-            ops.rows_gemm(self.x, self.idx2, lin.weight, trans_w=True, out=self._t1buf)
+            ops.rows_gemm(self.x, self.idx2, lin.weight, trans_w=True, const_w=True, out=self._t1buf)
             self._spmm(False, None, self._t1buf, self.pre1, lin.bias, 1.0 + c.eps, plan=self._plan2)
         elif self._mode == 'gin':
             lin = c.nn
@@ -395,8 +395,8 @@ class NodeembEngine:
                 self._spmm(False, None, self.x, agg, None, 1.0 + c.eps)
                 self.pre1.copy_(torch.nn.functional.linear(agg, lin.weight, lin.bias))
         elif self._mode == 'sage' and self._rows_only and self._split1 and self._mfma_weight(c.lin_l.weight):
-            ops.rows_gemm(self.x, self.idx2, c.lin_l.weight, trans_w=True, out=self._t1buf)
-            ops.rows_gemm(self.x, self.idx2, c.lin_r.weight, trans_w=True, out=self._t1rbuf)
+            ops.rows_gemm(self.x, self.idx2, c.lin_l.weight, trans_w=True, const_w=True, out=self._t1buf)
+            ops.rows_gemm(self.x, self.idx2, c.lin_r.weight, trans_w=True, const_w=True, out=self._t1rbuf)
             self._spmm(False, g.val, self._t1buf, self.pre1, c.lin_l.bias, 1.0, x_self=self._t1rbuf, plan=self._plan2)
         elif self._mode == 'sage':
             # out_i = mean_j (x_j W_l^T) + b_l + x_i W_r^T  (transform first, then aggregate at width H)
@@ -406,10 +406,10 @@ class NodeembEngine:
         else:
             wsrc = c.lin_src.weight
             if self._rows_only and self._split1 and self._mfma_weight(wsrc):
-                h1 = ops.rows_gemm(self.x, self.idx2, wsrc, trans_w=True, out=self._t1buf)       # rows outside stay 0
+                h1 = ops.rows_gemm(self.x, self.idx2, wsrc, trans_w=True, const_w=True, out=self._t1buf)       # rows outside stay 0
                 a_src, a_dst = ops.row_dots(h1, c.att_src, c.att_dst)
             elif self._gat_dots and ops.rows_gemm_dots_ok(wsrc.shape[1], wsrc.shape[0]):
-                h1, a_src, a_dst = ops.rows_gemm_dots(self.x, wsrc, c.att_src, c.att_dst)   # logits from the epilogue
+                h1, a_src, a_dst = ops.rows_gemm_dots(self.x, wsrc, c.att_src, c.att_dst, const_w=True)   # logits from the epilogue
             else:
                 h1 = self._linear(self.x, wsrc)
                 a_src, a_dst = ops.row_dots(h1, c.att_src, c.att_dst)
@@ -420,10 +420,10 @@ class NodeembEngine:
         c = self.model.conv2
         if self._mode == 'gcn' and self._rows_only:
             if self._split1:
-                t2 = ops.rows_gemm_select(self.pre1, self.z1, self._sel1, c.lin.weight, trans_w=True, relu_in=True,
+                t2 = ops.rows_gemm_select(self.pre1, self.z1, self._sel1, c.lin.weight, trans_w=True, const_w=True, relu_in=True,
                                           out=self._t2buf, idx=self.idx2)
             else:       # layer 1 cached: z1 holds conv1's output with the Del'd rows written over it
-                t2 = ops.rows_gemm(self.z1, self.idx2, c.lin.weight, trans_w=True, relu_in=True, out=self._t2buf)
+                t2 = ops.rows_gemm(self.z1, self.idx2, c.lin.weight, trans_w=True, const_w=True, relu_in=True, out=self._t2buf)
             self._spmm(False, self.graph.val, t2, self.p2, c.bias, 0.0, plan=self._plan2)
         elif self._mode == 'gcn':
             t2 = self._linear_relu_z1(c.lin.weight)
@@ -431,10 +431,10 @@ class NodeembEngine:
         elif self._mode == 'gin' and self._rows_only:
             lin = c.nn
             if self._split1:
-                t2 = ops.rows_gemm_select(self.pre1, self.z1, self._sel1, lin.weight, trans_w=True, relu_in=True,
+                t2 = ops.rows_gemm_select(self.pre1, self.z1, self._sel1, lin.weight, trans_w=True, const_w=True, relu_in=True,
                                           out=self._t2buf, idx=self.idx2)
             else:
-                t2 = ops.rows_gemm(self.z1, self.idx2, lin.weight, trans_w=True, relu_in=True, out=self._t2buf)
+                t2 = ops.rows_gemm(self.z1, self.idx2, lin.weight, trans_w=True, const_w=True, relu_in=True, out=self._t2buf)
             self._spmm(False, None, t2, self.p2, lin.bias, 1.0 + c.eps, plan=self._plan2)
         elif self._mode == 'gin':
             lin = c.nn
@@ -445,10 +445,10 @@ class NodeembEngine:
                 raise NotImplementedError('GIN layer that widens its input is not on the fused path')
         elif self._mode == 'sage' and self._rows_only:
             if self._split1:
-                t2 = ops.rows_gemm_select(self.pre1, self.z1, self._sel1, self._w2cat, trans_w=True, relu_in=True,
+                t2 = ops.rows_gemm_select(self.pre1, self.z1, self._sel1, self._w2cat, trans_w=True, const_w=True, relu_in=True,
                                           out=self._t2buf, idx=self.idx2)
             else:
-                t2 = ops.rows_gemm(self.z1, self.idx2, self._w2cat, trans_w=True, relu_in=True, out=self._t2buf)
+                t2 = ops.rows_gemm(self.z1, self.idx2, self._w2cat, trans_w=True, const_w=True, relu_in=True, out=self._t2buf)
             self._spmm(False, self.graph.val, t2[:, :self.o], self.p2, c.lin_l.bias, 1.0, x_self=t2[:, self.o:],
                        plan=self._plan2)
         elif self._mode == 'sage':
@@ -459,7 +459,7 @@ class NodeembEngine:
             if self._gat_dots and self._split1 and ops.rows_gemm_dots_ok(wsrc.shape[1], wsrc.shape[0]):
                 ro = self._rows_only
                 h2, self._a_src, self._a_dst = ops.rows_gemm_dots(
-                    self.pre1, wsrc, c.att_src, c.att_dst, inp_alt=self.z1, sel=self._sel1, relu_in=True,
+                    self.pre1, wsrc, c.att_src, c.att_dst, inp_alt=self.z1, sel=self._sel1, relu_in=True, const_w=True,
                     out=self._t2buf if ro else None, idx=self.idx2 if ro else None,
                     dots_out=(self._adots[0], self._adots[1]) if ro else None)
             else:

@@ -68,12 +68,35 @@ def spmm(x, graph, bias=None, self_coef=0.0):
 
 
 # ------------------------------------------------------------------------------ Del operator
+_WT_CACHE = {}
+
+
+def _const_weight(w, trans_w):
+    """-> (weight, trans_w) for a weight the caller declares constant (frozen backbone): an [out, in] weight is replaced
+    by a cached [in, out] copy so that the row kernels fill their LDS weight image with coalesced loads (the [n][k]
+    fill is strided).  Keyed on storage address + shape + torch's version counter: an in-place update of the weight
+    (an optimizer step) invalidates the copy; the entry keeps the weight alive so the address cannot be recycled."""
+    if not trans_w:
+        return w, trans_w
+    key = (w.data_ptr(), tuple(w.shape), w._version)
+    hit = _WT_CACHE.get(key)
+    if hit is None:
+        if len(_WT_CACHE) >= 64:
+            _WT_CACHE.clear()
+        hit = (w.detach().t().contiguous(), w)
+        _WT_CACHE[key] = hit
+    return hit[0], False
+
+
 def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, save_in=None, gate_bits=None,
-              sign_bits=None):
+              sign_bits=None, const_w=False):
     """out[idx] = act(inp[idx]) @ (w or w^T) - raw call (no autograd).
     sign_bits (int32 [n_sel, ceil(d_out/32)], written): packed [out > 0] of the rows just produced;
-    gate_bits (same layout, read): zero the product where the bit is clear (ReLU backward in the epilogue)."""
+    gate_bits (same layout, read): zero the product where the bit is clear (ReLU backward in the epilogue);
+    const_w: the weight is constant across calls (see _const_weight)."""
     inp = _f32_rows(inp)
+    if const_w:
+        w, trans_w = _const_weight(w, trans_w)
     n_sel = inp.shape[0] if idx is None else int(idx.shape[0])
     d_in = inp.shape[1]
     d_out = w.shape[0] if trans_w else w.shape[1]
@@ -102,10 +125,12 @@ def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, sa
     return out
 
 
-def rows_gemm_select(inp, inp_alt, sel, w, trans_w=False, bias=None, relu_in=False, out=None, idx=None):
+def rows_gemm_select(inp, inp_alt, sel, w, trans_w=False, bias=None, relu_in=False, out=None, idx=None, const_w=False):
     """rows_gemm over a matrix split across two buffers: row r comes from inp_alt where sel[r] (uint8); all rows,
     or the rows listed in idx (int32, written to the same rows of out)."""
     inp, inp_alt = _f32_rows(inp), _f32_rows(inp_alt)
+    if const_w:
+        w, trans_w = _const_weight(w, trans_w)
     assert inp.shape == inp_alt.shape and inp.stride(0) == inp_alt.stride(0) and sel.dtype == torch.uint8
     n, d_in = inp.shape
     d_out = w.shape[0] if trans_w else w.shape[1]
@@ -126,7 +151,8 @@ def rows_gemm_dots_ok(d_in, d_out):
     return d_in % 32 == 0 and d_out % 32 == 0 and d_out <= 64 and d_in * d_out * 4 <= 64 * 1024
 
 
-def rows_gemm_dots(inp, w, u1, u2, inp_alt=None, sel=None, relu_in=False, out=None, idx=None, dots_out=None):
+def rows_gemm_dots(inp, w, u1, u2, inp_alt=None, sel=None, relu_in=False, out=None, idx=None, dots_out=None,
+                   const_w=False):
     """out = act(inp or inp_alt) @ w^T (w [d_out, d_in]) and, from the same pass, a1 = out @ u1, a2 = out @ u2
     (gd_rows_gemm_dots_f32; MFMA widths only - see rows_gemm_dots_ok)."""
     inp = _f32_rows(inp)
@@ -143,10 +169,10 @@ def rows_gemm_dots(inp, w, u1, u2, inp_alt=None, sel=None, relu_in=False, out=No
     else:
         a1 = torch.empty(n, dtype=torch.float32, device=inp.device)
         a2 = torch.empty(n, dtype=torch.float32, device=inp.device)
-    w = w.contiguous()
+    w, trans = _const_weight(w, True) if const_w else (w.contiguous(), True)
     u1, u2 = u1.reshape(-1).contiguous(), u2.reshape(-1).contiguous()
     n_rows = n if idx is None else int(idx.shape[0])
-    check(_lib.lib().gd_rows_gemm_dots_f32(ptr(inp), ptr(inp_alt), ptr(sel), inp.stride(0), ptr(w), d_in, d_out, 1, None,
+    check(_lib.lib().gd_rows_gemm_dots_f32(ptr(inp), ptr(inp_alt), ptr(sel), inp.stride(0), ptr(w), d_in, d_out, int(trans), None,
                                            int(relu_in), ptr(out), out.stride(0), ptr(idx), n_rows, ptr(u1), ptr(u2),
                                            ptr(a1), ptr(a2), stream_ptr(inp.device)), 'gd_rows_gemm_dots_f32')
     return out, a1, a2
