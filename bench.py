@@ -46,11 +46,10 @@ def parse():
     p.add_argument('--no_cached_rate', action='store_true')
     p.add_argument('--probe_partition', action='store_true', help=argparse.SUPPRESS)   # child-process self test
     p.add_argument('--parallel', default='auto', choices=['auto', 'partition', 'replicas'],
-                   help='N>1: "replicas" = every GPU serves its own unlearning request (independent units, no '
-                        'data-path collective, weak scaling); "partition" = ONE request row-partitioned over the GPUs '
-                        '(RCCL halo all-to-all + all-reduce per step, strong scaling) for graphs that outgrow one GPU; '
-                        '"auto" = replicas when the request fits one GPU (it does for every BASELINE config: the '
-                        'collab-shaped request needs < 2 GB of 288 GB), else partition')
+                   help='N>1: "partition" (= "auto") = ONE request row-partitioned over the GPUs (RCCL halo all-to-all + '
+                        'all-reduce per step, strong scaling: what north_star asks to be measured; the independent-'
+                        'replicas rate of the same GPUs is reported next to it under extras); "replicas" = every GPU '
+                        'serves its own unlearning request (no data-path collective, weak scaling) as the headline')
     return p.parse_args()
 
 
@@ -117,6 +116,27 @@ def make_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1, group
         return PartitionedNodeembEngine(*common, rank, world, loss_type=args.loss_type, alpha=0.5, lr=1e-3,
                                         use_graph=not args.no_graph, group=group)
     return NodeembEngine(*common, loss_type=args.loss_type, alpha=0.5, lr=1e-3, use_graph=not args.no_graph)
+
+
+def replicas_rate(args, model, state, device, world, barrier):
+    """Informational (extras): every rank serves the WHOLE request on its own GPU at the same time, no data-path
+    collective - requests x iterations all ranks complete per second (max over ranks of the wall time)."""
+    import torch.distributed as dist
+    from gnndelete_amd.engine import NodeembEngine
+    model.load_state_dict(state)
+    eng = NodeembEngine(*eng_args, loss_type=args.loss_type, alpha=0.5, lr=1e-3, use_graph=not args.no_graph)
+    if args.unroll > 1 and not args.no_graph:
+        eng.prepare_unrolled(args.unroll)
+    for _ in range(args.warmup):
+        eng.step()
+    barrier()
+    t0 = time.perf_counter()
+    eng.run(args.steps, unroll=args.unroll)
+    torch.cuda.synchronize()
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return world * args.steps / float(t)
 
 
 def spmm_algorithmic_bytes(n, nnz, d):
@@ -327,7 +347,7 @@ def probe_partition_in_child(args, rank):
     env = dict(os.environ, MASTER_PORT=str(int(os.environ.get('MASTER_PORT', '29500')) + 23))
     env.pop('TORCHELASTIC_USE_AGENT_STORE', None)      # the children's rank 0 hosts its own rendezvous store
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(args.gpus), '--probe_partition', '--workload',
-           'synth-dblp', '--df', 'out', '--df_size', '2.5', '--gnn', args.gnn, '--loss_type', args.loss_type]
+           'synth-small', '--df', 'in', '--df_size', '5', '--gnn', args.gnn, '--loss_type', args.loss_type]
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
         if r.returncode == 0:
@@ -347,7 +367,7 @@ def main():
     # GD_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a one-GPU box (all ranks on cuda:0)
     backend = os.environ.get('GD_BENCH_BACKEND', 'nccl')
     if args.parallel == 'auto':
-        args.parallel = 'replicas'          # every BASELINE workload fits one MI355X many times over
+        args.parallel = 'partition'         # north_star: the 1-D partitioned step is what the scaling curve measures
     mode, note, probe_ok = ('single' if world == 1 else args.parallel), None, 1
     force_probe = os.environ.get('GD_BENCH_FORCE_PROBE') == '1'          # lets the gloo test exercise the probe
     if world > 1 and mode == 'partition' and (backend == 'nccl' or force_probe) and not args.probe_partition:
@@ -436,6 +456,7 @@ def main():
 
     partitioned = mode == 'partition'
     units = args.steps if partitioned else world * args.steps      # iterations of whole requests
+    rep_rate = replicas_rate(args, model, state, device, world, barrier) if (partitioned and world > 1) else None
     if rank == 0:
         kdur, kbytes = time_dominant_kernel(eng)
         achieved = kbytes / kdur / 1e9
@@ -468,6 +489,8 @@ def main():
         }
         if note:
             out['config']['partition_fallback'] = note
+        if partitioned:
+            out['config']['halo'] = eng.halo_report()
         if world == 1 and not args.no_cached_rate:
             # informational only (never `value`): the same step with the loop-invariant frozen layer-1
             # output computed once, which is how the trainer runs by default
@@ -498,6 +521,8 @@ def main():
                 torch.cuda.synchronize()
                 out['extras'][key] = args.steps / (time.perf_counter() - t1)
             out['extras']['affected_rows'] = {'S2': int(data.sdf_node_2hop_mask.sum()), 'of': data.num_nodes}
+        if rep_rate is not None:
+            out.setdefault('extras', {})['iters_per_s_independent_replicas'] = rep_rate
         if world == 1 and hasattr(eng, 'idx1'):
             out.setdefault('extras', {})['roofline_del_gemm'] = time_del_gemm(eng)
             out['extras']['roofline_wgrad'] = time_wgrad(eng)

@@ -3,8 +3,8 @@
 
   all_gather_rows   every rank owns one equal-sized block of rows of an [n_pad, d] matrix and
                     needs all of it for the next SpMM (t2 forward, dz2 backward);
-  exchange_rows     the sparse form of the same exchange: every rank sends each peer only the
-                    rows that peer's SpMM actually gathers (all-to-all with per-pair row lists);
+  halo_plan /       the sparse form of the same exchange: every rank sends each peer only the
+  exchange_rows     rows that peer's SpMM actually gathers (all-to-all with per-pair row lists);
   all_reduce_sum    one packed fp32 buffer per step: the partial Del-weight gradients
                     (128^2 + 128^2 + 64^2 floats) and the four loss sums.
 """
@@ -35,40 +35,52 @@ def all_reduce_sum(buf, world, group=None):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
 
 
-def halo_lists(rowptr, col, n, rank, world, chunk):
-    """Per-pair row lists of a 1-D row partition: rank q's SpMM over its rows [q*chunk, ..) gathers
-    the source rows unique(col[rowptr[lo_q]:rowptr[hi_q]]); the part of that set owned by another
-    rank p is what p must send to q.  Every rank holds the whole (small) graph structure, so both
-    sides of every pair derive the same sorted list without communicating.
-    -> (send_rows, in_splits, recv_rows, out_splits) for `rank` (global row ids, int64)."""
+class HaloPlan:
+    """One rank's side of a sparse row exchange: send_rows (global ids, grouped by destination rank, sorted inside a
+    group), in_splits (rows sent to each rank), recv_rows / out_splits likewise for what it receives."""
+
+    def __init__(self, send_rows, in_splits, recv_rows, out_splits, pair_counts):
+        self.send_rows, self.in_splits = send_rows, in_splits
+        self.recv_rows, self.out_splits = recv_rows, out_splits
+        self.n_send, self.n_recv = int(sum(in_splits)), int(sum(out_splits))
+        self.pair_counts = pair_counts              # [world][world]: rows rank p sends to rank q at [q][p]
+
+
+def halo_plan(rowptr, col, n, rank, world, chunk, row_mask=None):
+    """Per-pair row lists of a 1-D row partition, for all ranks at once ON THE DEVICE: rank q aggregates the rows
+    [q*chunk, ..) (only those with row_mask set, if given) and gathers the source rows col[k] of their CSR entries;
+    a gathered row owned by another rank p is a row p sends to q.  The distinct (q, p, row) triples are one
+    torch.unique over the cross-rank CSR entries; their order (q, then p, then row id) is the order both ends use,
+    so no list is ever communicated - every rank holds the replicated graph structure.  One device->host transfer:
+    the [world, world] count matrix (the split sizes all_to_all_single wants as Python ints)."""
     dev = col.device
-    send, recv = [[] for _ in range(world)], [[] for _ in range(world)]
-    for q in range(world):
-        lo_q, hi_q = min(n, q * chunk), min(n, (q + 1) * chunk)
-        a, b = int(rowptr[lo_q]), int(rowptr[hi_q])
-        needed = torch.unique(col[a:b].long())
-        owner = needed // chunk
-        if q == rank:
-            for p in range(world):
-                if p != rank:
-                    recv[p] = needed[owner == p]
-        else:
-            send[q] = needed[owner == rank]
-    empty = torch.empty(0, dtype=torch.long, device=dev)
-    send = [s if torch.is_tensor(s) else empty for s in send]
-    recv = [r if torch.is_tensor(r) else empty for r in recv]
-    return (torch.cat(send), [int(s.numel()) for s in send], torch.cat(recv), [int(r.numel()) for r in recv])
+    deg = (rowptr[1:] - rowptr[:-1]).long()
+    tgt = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+    src = col.long()
+    q, p = tgt // chunk, src // chunk
+    cross = q != p
+    if row_mask is not None:
+        cross &= row_mask.to(dev)[tgt]
+    key = torch.unique((q[cross] * world + p[cross]) * n + src[cross])
+    pair, rows = key // n, key % n
+    counts = torch.bincount(pair, minlength=world * world).view(world, world).tolist()      # the one host sync
+    recv_sel = (pair // world) == rank                 # what this rank receives: ordered by sender p, then row
+    send_sel = (pair % world) == rank                  # what it sends: ordered by receiver q, then row
+    return HaloPlan(rows[send_sel].contiguous(), [counts[qq][rank] for qq in range(world)],
+                    rows[recv_sel].contiguous(), [counts[rank][pp] for pp in range(world)], counts)
 
 
-def exchange_rows(send_buf, recv_buf, in_splits, out_splits, world, group=None):
-    """recv_buf <- all-to-all of send_buf along dim 0 (rows per peer: in_splits sent, out_splits
-    received).  Backends without device all-to-all (gloo + GPU tensors in the tests) stage
-    through the host."""
+def exchange_rows(send_buf, recv_buf, plan, world, group=None):
+    """recv_buf[:n_recv] <- all-to-all of send_buf[:n_send] along dim 0 with the plan's per-peer row counts.
+    RCCL ("nccl") moves device buffers directly and any failure propagates - a silent detour through the host would
+    turn a broken transport into a 100x slowdown.  gloo (the CPU-side test backend) has no device all-to-all: there,
+    and only there, the buffers are staged through the host."""
     if world == 1:
         return
-    try:
-        dist.all_to_all_single(recv_buf, send_buf, out_splits, in_splits, group=group)
-    except (RuntimeError, NotImplementedError):
-        host = torch.empty(recv_buf.shape, dtype=recv_buf.dtype)
-        dist.all_to_all_single(host, send_buf.cpu(), out_splits, in_splits, group=group)
-        recv_buf.copy_(host)
+    send, recv = send_buf[:plan.n_send], recv_buf[:plan.n_recv]
+    if dist.get_backend(group) == 'gloo' and send.is_cuda:
+        host = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(host, send.cpu(), plan.out_splits, plan.in_splits, group=group)
+        recv.copy_(host)
+        return
+    dist.all_to_all_single(recv, send, plan.out_splits, plan.in_splits, group=group)

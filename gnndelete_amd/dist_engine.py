@@ -1,49 +1,50 @@
 """Row-partitioned Del-training step for N GPUs of one node (one process per GPU, RCCL over xGMI).
 
-north_star: "graphs that outgrow one GPU are 1-D partitioned across the 8 GPUs with RCCL exchange
-of the aggregates and of the Del-operator gradients".  The partition used here is by TARGET rows
-(contiguous equal blocks of the engine's locality order), which turns the exchange of partial
-aggregates into an all-gather of the layer input instead of an all-reduce of [N, d] partial sums
-(half the bytes, and the per-row summation order - hence the result - stays that of one GPU):
+north_star: "graphs that outgrow one GPU are 1-D partitioned across the 8 GPUs with RCCL exchange of the aggregates
+and of the Del-operator gradients".  The partition is by TARGET rows - contiguous equal blocks of the engine's
+locality order - which turns the exchange of partial aggregates ([N, d] all-reduce) into an exchange of the layer
+INPUT rows a rank's aggregation gathers from other ranks (the halo): fewer bytes, and every row keeps the
+summation order it has on one GPU.
 
-  every rank   t1 = x W1^T for ALL rows (the input is static and replicated; recomputing 7.7 GF
-               is cheaper than gathering 121 MB over xGMI)
-  own rows     z1 = A t1 + b1, Del-1, t2 = relu(z1) W2^T
-  exchange 1   t2 rows                  [N, out] fp32 (see "exchange" below)
-  own rows     z2 = A t2 + b2, Del-2, DEC + NI losses, dW_D2 partial, dz2 <- dz2 W_D2^T
-  exchange 2   dz2 rows                 [N, out] fp32
-  own rows     dt2 = A^T dz2, dh = dt2 W2, dW_D1 partials
-  exchange 3   all-reduce of ONE packed buffer: dW_D1 (loss-1 part), dW_D1 (loss-2 part), dW_D2,
-               4 loss sums  (~144 KiB)
-  every rank   the --loss_type bookkeeping + Adam, identically (replicated Del weights)
+Same fused stages as the single-GPU step (engine.NodeembEngine), cut into four hipGraph
+segments by the three collectives; the halo pack / unpack copies are part of the graphs:
 
-Exchange 1/2 are sparse by default (`exchange='halo'`): a rank sends each peer only the rows
-that peer's SpMM gathers (all-to-all with per-pair sorted row lists that both sides derive from
-the replicated CSR); with the locality order most gathers are rank-local, so this is a fraction
-of the dense all-gather (`exchange='allgather'`), which matters most at N=2 where a pair shares
-a single xGMI link.
+  A  t1 = x W1^T on the rows this rank's layer-1 aggregation reads (own + halo: the input is replicated and
+     recomputing a halo row costs 33 kflop, sending it 512 B)  ->  pre1 = conv1 on OWN rows  ->  Del-1 (+ ReLU sign
+     bits)  ->  [layer-wise types] partial dW_D1 with the layer-1 loss formed in the fetch  ->  t2 = relu(.) W2^T
+     on own rows  ->  pack the t2 rows other ranks gather
+  >> all-to-all #1: t2 halo rows ([*, out] fp32, per-pair sorted row lists both sides derive from the replicated CSR)
+  B  unpack  ->  p2 = conv2 aggregation on own rows  ->  Del-2 + layer-2 loss + Del-2 input gradient (one kernel)
+     ->  partial dW_D2  ->  pack the dp2 rows other ranks' transposed aggregation gathers
+  >> all-to-all #2: dp2 halo rows
+  C  unpack  ->  dt2 = A^T dp2 on the own S1 rows  ->  dh[S1] = (dt2 W2) gated by the sign bits  ->  [both_all /
+     only2_all] partial dW_D1  ->  loss partial sums  ->  one packed buffer
+  >> all-reduce: [dW_D1 | dW_D2 | 4 loss sums]  (128^2 + 64^2 + 4 floats = 80 KiB)
+  D  the --loss_type gradient bookkeeping + Adam on both Del weights, identically on every rank;
+     loss history, iteration counter.
 
-The four compute segments are captured as hipGraphs; the three collectives are issued between
-the replays.  GCN and GIN backbones (GAT's backward would need the per-edge attention of remote
-rows)."""
+GCN, GIN and GraphSAGE backbones (GAT's message gradient needs the attention statistics of remote targets; not
+built).  The fused single-GPU configuration is required: folded DEC + NI terms, every loss row inside its Del row
+list (always so for the reference's masks), MFMA widths."""
 import torch
+import torch.distributed as dist
 
 from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
-from .collectives import all_gather_rows, all_reduce_sum, exchange_rows, halo_lists, row_blocks
-from .engine import LOSS_TYPES, _Adam, _LayerTerms, _loss_coefficients
+from .collectives import all_reduce_sum, exchange_rows, halo_plan, row_blocks
+from .engine import LOSS_TYPES, _Adam, _LayerTerms, _loss_coefficients, _loss_slots, _rows_inside
 from .graph import SplitPlan, graph_for
-from .nn import GCNConv, GINConv
+from .nn import GCNConv, GINConv, SAGEConv
 
 
 class PartitionedNodeembEngine:
     def __init__(self, model, x, edge_index, z1_ori, z2_ori, pos_edge, neg_edge, ni_mask1, ni_mask2, rank, world,
                  loss_type='both_layerwise', alpha=0.5, lr=1e-3, reduction='mean', use_graph=True, history=4096,
-                 reorder=True, group=None, exchange='halo'):
+                 reorder=True, group=None):
         assert loss_type in LOSS_TYPES, loss_type
-        conv2 = model.conv2
-        if not isinstance(conv2, (GCNConv, GINConv)):
-            raise NotImplementedError('PartitionedNodeembEngine supports GCN and GIN backbones')
+        conv1, conv2 = model.conv1, model.conv2
+        if not isinstance(conv2, (GCNConv, GINConv, SAGEConv)):
+            raise NotImplementedError('PartitionedNodeembEngine supports GCN, GIN and GraphSAGE backbones')
         dev = x.device
         if dev.type != 'cuda':
             raise _lib.GnnDeleteHipError('PartitionedNodeembEngine needs CUDA(HIP) tensors (no CPU fallback)')
@@ -64,184 +65,270 @@ class PartitionedNodeembEngine:
             m1, m2, ni_mask1, ni_mask2 = m1[perm], m2[perm], ni_mask1[perm], ni_mask2[perm]
             pos_edge, neg_edge = inv[pos_edge], inv[neg_edge]
         self.x = x
-        self.chunk, self.n_pad = row_blocks(n, world)
+        self.chunk, _ = row_blocks(n, world)
         self.lo = lo = min(n, rank * self.chunk)
         self.hi = hi = min(n, lo + self.chunk)
         self.wd1, self.wd2 = model.deletion1.deletion_weight, model.deletion2.deletion_weight
         self.h, self.o = self.wd1.shape[0], self.wd2.shape[0]
+        self._mode = {GCNConv: 'gcn', GINConv: 'gin', SAGEConv: 'sage'}[type(conv2)]
+        if self.h not in (32, 64, 128) or self.o not in (32, 64) or x.shape[1] % 32 or x.shape[1] * self.h * 4 > 65536:
+            raise NotImplementedError('partitioned step: widths must suit the fused kernels (in % 32 == 0, hidden in '
+                                      '{32, 64, 128}, out in {32, 64})')
+        if self._mode == 'gin' and conv2.nn.out_features > conv2.nn.in_features:
+            raise NotImplementedError('partitioned step: a second GIN layer that widens its input')
+        # a first GIN layer that widens aggregates BEFORE its Linear (fewer gathered bytes); x is replicated, so that
+        # aggregation needs no halo at all
+        self._gin_agg_first = self._mode == 'gin' and conv1.nn.out_features > conv1.nn.in_features
 
         def local(mask):
             idx = mask.nonzero().flatten()
             return idx[(idx >= lo) & (idx < hi)].to(torch.int32)
         self.idx1, self.idx2 = local(m1), local(m2)
         self.s1, self.s2 = int(self.idx1.numel()), int(self.idx2.numel())
+        self.own = torch.arange(lo, hi, dtype=torch.int32, device=dev)
         z1_ori, z2_ori = ops._f32_rows(z1_ori), ops._f32_rows(z2_ori)
         coef_r, coef_l = _loss_coefficients(loss_type, alpha)
         self.t1 = _LayerTerms(pos_edge, neg_edge, ni_mask1, z1_ori, coef_r, coef_l, reduction, (lo, hi))
         self.t2 = _LayerTerms(pos_edge, neg_edge, ni_mask2, z2_ori, coef_r, coef_l, reduction, (lo, hi))
-        # constants of the folded losses are per-rank partial sums too: reduce them once
-        k = torch.tensor(self.t1.k_const + self.t2.k_const, dtype=torch.float64, device=dev)
+        ok = torch.tensor([int(self.t1.folded and self.t2.folded
+                               and (self.t1.n_rows == 0 or _rows_inside(self.t1, self.idx1, self.s1))
+                               and (self.t2.n_rows == 0 or _rows_inside(self.t2, self.idx2, self.s2)))],
+                          dtype=torch.float64, device=dev)
+        # constants of the folded losses are per-rank partial sums: reduce them (and the feasibility flag) once
+        k = torch.cat([torch.tensor(self.t1.k_const + self.t2.k_const, dtype=torch.float64, device=dev), ok])
         all_reduce_sum(k, world, group)
-        self.k_const = k.tolist()
-
-        self._mode = 'gcn' if isinstance(conv2, GCNConv) else 'gin'
-        self.graph = g = graph_for(edge_index, n, 'gcn' if self._mode == 'gcn' else 'sum')
-        self.plan = SplitPlan(g.rowptr, row_range=(lo, hi))
-        self.plan_t = SplitPlan(g.rowptr_t, row_range=(lo, hi))
-
+        if int(round(float(k[4]))) != world:
+            raise NotImplementedError('partitioned step: a loss row lies outside its Del row list on some rank')
+        self.k_const = k[:4].tolist()
         f32 = dict(dtype=torch.float32, device=dev)
-        self.z1 = torch.zeros(self.n_pad, self.h, **f32)
-        self.z2 = torch.zeros(self.n_pad, self.o, **f32)
-        self.t2_full = torch.zeros(self.n_pad, self.o, **f32)
-        self.dz1 = torch.zeros(self.n_pad, self.h, **f32)
-        self.dz2 = torch.zeros(self.n_pad, self.o, **f32)        # all-gathered in place (own block written)
-        self.dt2 = torch.zeros(self.n_pad, self.o, **f32)
-        self.dh = torch.zeros(self.n_pad, self.h, **f32)
-        self.xs1 = torch.empty(max(1, self.s1), self.h, **f32)
-        self.xs2 = torch.empty(max(1, self.s2), self.o, **f32)
+
+        def slots(terms, idx, n_sel):
+            if terms.n_rows == 0:
+                return (torch.full((max(n_sel, 1),), -1, dtype=torch.int32, device=dev), torch.zeros(1, **f32))
+            return _loss_slots(terms, idx, n_sel, dev)
+        self._slot1, self._cnt_signed1 = slots(self.t1, self.idx1, self.s1)
+        self._slot2, self._cnt_signed2 = slots(self.t2, self.idx2, self.s2)
+        self._tm1 = self.t1.tm if self.t1.n_rows else torch.zeros(1, self.h, **f32)
+        self._tm2 = self.t2.tm if self.t2.n_rows else torch.zeros(1, self.o, **f32)
+        self._coef1 = self.t1.coef if self.t1.n_rows else torch.zeros(1, **f32)
+        self._coef2 = self.t2.coef if self.t2.n_rows else torch.zeros(1, **f32)
+
+        gmode = {'gcn': 'gcn', 'gin': 'sum', 'sage': 'mean'}[self._mode]
+        self.graph = g = graph_for(edge_index, n, gmode)
+        self.plan = SplitPlan(g.rowptr, row_range=(lo, hi))                    # forward aggregations: own rows
+        self.plan_t = SplitPlan(g.rowptr_t, rows=self.idx1) if self.s1 else None   # transposed: own S1 rows only
+        # ---- halo lists (device-side, one host transfer of the [world, world] count matrix each)
+        own_mask = torch.zeros(n, dtype=torch.bool, device=dev)
+        own_mask[lo:hi] = True
+        s1_mask = m1.clone()
+        self.halo_f = halo_plan(g.rowptr, g.col, n, rank, world, self.chunk, None)
+        self.halo_b = halo_plan(g.rowptr_t, g.col_t, n, rank, world, self.chunk, s1_mask)
+        self.need1 = torch.unique(torch.cat([self.own.long(), self.halo_f.recv_rows])).to(torch.int32)
+        self.send_f = torch.zeros(max(1, self.halo_f.n_send), self.o, **f32)
+        self.recv_f = torch.zeros(max(1, self.halo_f.n_recv), self.o, **f32)
+        self.send_b = torch.zeros(max(1, self.halo_b.n_send), self.o, **f32)
+        self.recv_b = torch.zeros(max(1, self.halo_b.n_recv), self.o, **f32)
+
+        w_o = 2 * self.o if self._mode == 'sage' else self.o
+        self.t1buf = torch.zeros(n, self.h, **f32)                  # x W1^T on the rows need1 (others never read)
+        self.t1rbuf = torch.zeros(n, self.h, **f32) if self._mode == 'sage' else None
+        self.aggbuf = torch.zeros(n, x.shape[1], **f32) if self._gin_agg_first else None
+        self.pre1 = torch.zeros(n, self.h, **f32)
+        self.z1 = torch.zeros(n, self.h, **f32)
+        self.t2buf = torch.zeros(n, w_o, **f32)                     # (t2_l | t2_r) for GraphSAGE
+        self.p2 = torch.zeros(n, self.o, **f32)
+        if self._mode == 'sage':
+            self.dcat = torch.zeros(n, 2 * self.o, **f32)           # [ dt2 | dp2 ]
+            self.dz2 = self.dcat[:, self.o:]
+            self._w2cat = torch.cat([conv2.lin_l.weight.detach(), conv2.lin_r.weight.detach()], 0).contiguous()
+        else:
+            self.dz2 = torch.zeros(n, self.o, **f32)
+            self.dt2 = torch.zeros(n, self.o, **f32)
+        self.dz2c = torch.zeros(max(1, self.s2), self.o, **f32)
+        self.dh = torch.zeros(n, self.h, **f32)
+        self.z1_pos = torch.zeros(max(1, self.s1), (self.h + 31) // 32, dtype=torch.int32, device=dev)
+        self._sel1 = m1.to(torch.uint8).contiguous()
         hh, oo = self.h * self.h, self.o * self.o
-        self.pack = torch.zeros(2 * hh + oo + 4, **f32)          # [dW1 loss-1 | dW1 loss-2 | dW2 | sums]
-        self.p_a = self.pack[:hh].view(self.h, self.h)
-        self.p_b = self.pack[hh:2 * hh].view(self.h, self.h)
-        self.p_c = self.pack[2 * hh:2 * hh + oo].view(self.o, self.o)
-        self.p_sums = self.pack[2 * hh + oo:]
-        self.g1 = torch.zeros_like(self.wd1)
+        self.pack = torch.zeros(hh + oo + 4, **f32)                 # [dW_D1 | dW_D2 | r1 l1 r2 l2]
+        self.p_g1 = self.pack[:hh].view(self.h, self.h)
+        self.p_g2 = self.pack[hh:hh + oo].view(self.o, self.o)
+        self.p_sums = self.pack[hh + oo:]
+        self.g1 = torch.zeros_like(self.wd1)                        # the .grad of W_D1 / W_D2 (replicated)
         self.g2 = torch.zeros_like(self.wd2)
         self.ws1 = torch.empty(max(1, _lib.lib().gd_rows_gemm_wgrad_workspace(self.s1, self.h, self.h)), **f32)
         self.ws2 = torch.empty(max(1, _lib.lib().gd_rows_gemm_wgrad_workspace(self.s2, self.o, self.o)), **f32)
-        self.adam1, self.adam2 = _Adam(self.wd1, lr), _Adam(self.wd2, lr)
+        self._lp1_blocks = _lib.lib().gd_rows_gemm_wgrad_blocks(self.s1)
+        self._lp1 = torch.zeros(2 * max(1, self._lp1_blocks), **f32)
+        self._lp2_blocks = _lib.lib().gd_del_loss_bwd_blocks(self.s2)
+        self._lp2 = torch.zeros(2 * max(1, self._lp2_blocks), **f32)
+        self.iter_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.adam1, self.adam2 = _Adam(self.wd1, lr, iter_ctr=self.iter_ctr), _Adam(self.wd2, lr, iter_ctr=self.iter_ctr)
         self.hist = torch.zeros(history, 4, **f32)
-        self.hist_pos = torch.zeros(1, dtype=torch.long, device=dev)
+        self.hist_pos = torch.zeros(1, dtype=torch.int32, device=dev)
         self.steps_done = 0
         self._use_graph = use_graph
         self._graphs = None
-        self.needs_b = loss_type in ('both_all', 'both_layerwise', 'only2_all')
-        self.needs_a = loss_type in ('both_all', 'both_layerwise', 'only1')
-        # sparse exchange: only the rows a peer's SpMM gathers travel (with the locality order that
-        # is a fraction of a full all-gather); 'allgather' keeps the dense collective
-        assert exchange in ('halo', 'allgather')
-        self.exchange = exchange if world > 1 else 'allgather'
-        if self.exchange == 'halo':
-            self.halo_f = halo_lists(g.rowptr, g.col, n, rank, world, self.chunk)
-            self.halo_b = halo_lists(g.rowptr_t, g.col_t, n, rank, world, self.chunk)
-            self.recv_f = torch.empty(sum(self.halo_f[3]), self.o, **f32)
-            self.recv_b = torch.empty(sum(self.halo_b[3]), self.o, **f32)
+        self.uses_l1 = loss_type in ('both_all', 'both_layerwise', 'only1')
+        self.needs_l2_to_w1 = loss_type in ('both_all', 'both_layerwise', 'only2_all')
 
-    # ------------------------------------------------------------------ helpers
-    def _linear(self, x, weight, relu_in=False, out=None):
-        out_f, in_f = weight.shape
-        if x.shape[0] == 0:
-            return out if out is not None else x.new_zeros(0, out_f)
-        if in_f % 32 == 0 and out_f % 32 == 0 and out_f <= 128 and in_f * out_f * 4 <= 64 * 1024:
-            return ops.rows_gemm(x, None, weight, trans_w=True, relu_in=relu_in, out=out)
-        res = torch.nn.functional.linear(torch.relu(x) if relu_in else x, weight)
-        if out is not None:
-            out.copy_(res)
-            return out
-        return res
-
-    def _spmm_own_rows(self, transposed, val, x, y, bias, self_coef):
+    # ------------------------------------------------------------------ pieces
+    def _spmm(self, transposed, val, x, y, bias, self_coef, x_self=None):
         g = self.graph
         if transposed:
-            ops._spmm_raw(g.rowptr_t, g.col_t, val, x, bias, self_coef, self.n, self.plan_t, out=y)
+            ops._spmm_raw(g.rowptr_t, g.col_t, val, x, bias, self_coef, self.n, self.plan_t, out=y, x_self=x_self)
         else:
-            ops._spmm_raw(g.rowptr, g.col, val, x, bias, self_coef, self.n, self.plan, out=y)
+            ops._spmm_raw(g.rowptr, g.col, val, x, bias, self_coef, self.n, self.plan, out=y, x_self=x_self)
 
-    def _wgrad(self, a_compact, g, g_idx, n_sel, relu_mask, out, ws):
-        check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(a_compact), a_compact.stride(0), None, ptr(g), g.stride(0),
-                                                ptr(g_idx), ptr(relu_mask), None, n_sel, a_compact.shape[1], g.shape[1],
-                                                ptr(out), 0, ptr(ws), stream_ptr(g.device)), 'gd_rows_gemm_wgrad_f32')
+    def _wgrad1_partial(self, with_loss, g_add):
+        """p_g1 = pre1[S1]^T (layer-1 loss gradient and / or g_add) over the OWN S1 rows; the layer-1 loss sums
+        come out as per-block partials (no optimizer update here: the gradient is still a partial sum)."""
+        if self.s1 == 0:
+            self.p_g1.zero_()
+            self._lp1.zero_()
+            return
+        if with_loss:
+            check(_lib.lib().gd_rows_gemm_wgrad_loss_f32(
+                ptr(self.pre1), self.pre1.stride(0), ptr(self.idx1), ptr(self.z1), self.z1.stride(0), ptr(self.idx1),
+                ptr(self._slot1), ptr(self._tm1), ptr(self._coef1), ptr(self._cnt_signed1), ptr(g_add), self.s1, self.h,
+                self.h, ptr(self.p_g1), 0, ptr(self.ws1), ptr(self._lp1), None, None, None, None, 0.0, 0.0, 0.0, 0.0,
+                stream_ptr(self.x.device)), 'gd_rows_gemm_wgrad_loss_f32')
+        else:
+            check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(self.pre1), self.pre1.stride(0), ptr(self.idx1), ptr(g_add),
+                                                    g_add.stride(0), ptr(self.idx1), None, None, self.s1, self.h, self.h,
+                                                    ptr(self.p_g1), 0, ptr(self.ws1), stream_ptr(self.x.device)),
+                  'gd_rows_gemm_wgrad_f32')
 
-    def _weights(self):
-        c1, c2 = self.model.conv1, self.model.conv2
-        if self._mode == 'gcn':
-            return c1.lin.weight, c1.bias, c2.lin.weight, c2.bias, 0.0
-        return c1.nn.weight, c1.nn.bias, c2.nn.weight, c2.nn.bias, 1.0 + c2.eps
+    def _layer1_loss_only(self):
+        """Loss sums of layer 1 when its gradient feeds no optimizer step (only2_*): the weight-gradient kernel's
+        fetch is still the cheapest place to form them, its product is discarded."""
+        self._wgrad1_partial(True, None)
+        self.p_g1.zero_()
 
     # ------------------------------------------------------------------ the four segments
-    def _seg_forward1(self):
-        w1, b1, w2, b2, sc = self._weights()
-        val = self.graph.val
-        lo, hi = self.lo, self.hi
-        t1 = self._linear(self.x, w1)                                   # all rows (replicated)
-        self._spmm_own_rows(False, val, t1, self.z1, b1, sc)
-        ops.rows_gemm(self.z1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1)
-        self._linear(self.z1[lo:hi], w2, relu_in=True, out=self.t2_full[lo:hi])
-
-    def _seg_forward2_backward1(self):
-        w1, b1, w2, b2, sc = self._weights()
-        self._spmm_own_rows(False, self.graph.val, self.t2_full, self.z2, b2, sc)
-        ops.rows_gemm(self.z2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
-        self.p_sums.zero_()
-        self.t1.launch(self.z1, self.dz1, self.p_sums[0:2])
-        self.t2.launch(self.z2, self.dz2, self.p_sums[2:4])
-        if self.loss_type != 'only1':
-            self._wgrad(self.xs2, self.dz2, self.idx2, self.s2, None, self.p_c, self.ws2)
-            if self.needs_b:
-                ops.rows_gemm(self.dz2, self.idx2, self.wd2, trans_w=True, out=self.dz2)
-
-    def _seg_backward2(self):
-        w1, b1, w2, b2, sc = self._weights()
-        if self.needs_a:
-            self._wgrad(self.xs1, self.dz1, self.idx1, self.s1, None, self.p_a, self.ws1)
-        if self.needs_b:
-            self._spmm_own_rows(True, self.graph.val_t, self.dz2, self.dt2, None, sc)
-            ops.rows_gemm(self.dt2, self.idx1, w2, trans_w=False, out=self.dh)
-            self._wgrad(self.xs1, self.dh, self.idx1, self.s1, self.z1, self.p_b, self.ws1)
-
-    def _seg_update(self):
-        lt = self.loss_type
-        self.hist.index_copy_(0, self.hist_pos, self.p_sums[None])
-        self.hist_pos.add_(1).remainder_(self.hist.shape[0])
-        if lt == 'both_layerwise':
-            self.g1.add_(self.p_a)
-            self.adam1.apply(self.g1)
-            self.g1.copy_(self.p_b)
-            self.g2.copy_(self.p_c)
-            self.adam2.apply(self.g2)
-        elif lt == 'both_all':
-            self.g1.add_(self.p_a).add_(self.p_b)
-            self.g2.add_(self.p_c)
-            self.adam1.apply(self.g1)
-            self.adam2.apply(self.g2)
-        elif lt == 'only2_layerwise':
-            self.g2.copy_(self.p_c)
-            self.adam2.apply(self.g2)
-        elif lt == 'only2_all':
-            self.g1.copy_(self.p_b)
-            self.g2.copy_(self.p_c)
-            self.adam1.apply(self.g1)
-            self.adam2.apply(self.g2)
+    def _seg_a(self):
+        c1, c2 = self.model.conv1, self.model.conv2
+        g, lt = self.graph, self.loss_type
+        if self._mode == 'gcn':
+            ops.rows_gemm(self.x, self.need1, c1.lin.weight, trans_w=True, const_w=True, out=self.t1buf)
+            self._spmm(False, g.val, self.t1buf, self.pre1, c1.bias, 0.0)
+            w2 = c2.lin.weight
+        elif self._mode == 'gin':
+            if self._gin_agg_first:
+                self._spmm(False, None, self.x, self.aggbuf, None, 1.0 + c1.eps)
+                ops.rows_gemm(self.aggbuf, self.own, c1.nn.weight, trans_w=True, const_w=True, bias=c1.nn.bias, out=self.pre1)
+            else:
+                ops.rows_gemm(self.x, self.need1, c1.nn.weight, trans_w=True, const_w=True, out=self.t1buf)
+                self._spmm(False, None, self.t1buf, self.pre1, c1.nn.bias, 1.0 + c1.eps)
+            w2 = c2.nn.weight
         else:
-            self.g1.copy_(self.p_a)
+            ops.rows_gemm(self.x, self.need1, c1.lin_l.weight, trans_w=True, const_w=True, out=self.t1buf)
+            ops.rows_gemm(self.x, self.own, c1.lin_r.weight, trans_w=True, const_w=True, out=self.t1rbuf)
+            self._spmm(False, g.val, self.t1buf, self.pre1, c1.lin_l.bias, 1.0, x_self=self.t1rbuf)
+            w2 = self._w2cat
+        if self.s1:
+            ops.rows_gemm(self.pre1, self.idx1, self.wd1, out=self.z1, sign_bits=self.z1_pos)
+        if lt == 'both_layerwise':
+            self._wgrad1_partial(True, self.dh)          # dh = the PREVIOUS iteration's layer-2 gradient (SURVEY F6)
+        elif lt == 'only1':
+            self._wgrad1_partial(True, None)
+        elif lt in ('only2_layerwise', 'only2_all'):
+            self._layer1_loss_only()
+        if lt != 'only1':
+            ops.rows_gemm_select(self.pre1, self.z1, self._sel1, w2, trans_w=True, const_w=True, relu_in=True,
+                                 out=self.t2buf, idx=self.own)
+            if self.halo_f.n_send:
+                torch.index_select(self.t2buf[:, :self.o], 0, self.halo_f.send_rows, out=self.send_f)
+
+    def _seg_b(self):
+        c2 = self.model.conv2
+        g, lt = self.graph, self.loss_type
+        if lt == 'only1':
+            self._lp2.zero_()
+            self.p_g2.zero_()
+            return
+        if self.halo_f.n_recv:
+            self.t2buf[:, :self.o].index_copy_(0, self.halo_f.recv_rows, self.recv_f)
+        if self._mode == 'gcn':
+            self._spmm(False, g.val, self.t2buf, self.p2, c2.bias, 0.0)
+        elif self._mode == 'gin':
+            self._spmm(False, None, self.t2buf, self.p2, c2.nn.bias, 1.0 + c2.eps)
+        else:
+            self._spmm(False, g.val, self.t2buf[:, :self.o], self.p2, c2.lin_l.bias, 1.0, x_self=self.t2buf[:, self.o:])
+        if self.s2:
+            check(_lib.lib().gd_del_loss_bwd_f32(
+                ptr(self.p2), self.p2.stride(0), ptr(self.idx2), self.s2, ptr(self.wd2), self.o, ptr(self._slot2),
+                ptr(self._tm2), ptr(self._coef2), ptr(self._cnt_signed2), ptr(self.dz2c), self.dz2c.stride(0),
+                ptr(self.dz2), self.dz2.stride(0), ptr(self._lp2), stream_ptr(self.x.device)), 'gd_del_loss_bwd_f32')
+            check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(self.p2), self.p2.stride(0), ptr(self.idx2), ptr(self.dz2c),
+                                                    self.dz2c.stride(0), None, None, None, self.s2, self.o, self.o,
+                                                    ptr(self.p_g2), 0, ptr(self.ws2), stream_ptr(self.x.device)),
+                  'gd_rows_gemm_wgrad_f32')
+        else:
+            self._lp2.zero_()
+            self.p_g2.zero_()
+        if self.needs_l2_to_w1 and self.halo_b.n_send:
+            torch.index_select(self.dz2, 0, self.halo_b.send_rows, out=self.send_b)
+
+    def _seg_c(self):
+        c2 = self.model.conv2
+        g, lt = self.graph, self.loss_type
+        if self.needs_l2_to_w1:
+            if self.halo_b.n_recv:
+                self.dz2.index_copy_(0, self.halo_b.recv_rows, self.recv_b)
+            if self.s1:
+                if self._mode == 'sage':
+                    self._spmm(True, g.val_t, self.dz2, self.dcat[:, :self.o], None, 0.0)
+                    dt2, w2 = self.dcat, self._w2cat
+                elif self._mode == 'gcn':
+                    self._spmm(True, g.val_t, self.dz2, self.dt2, None, 0.0)
+                    dt2, w2 = self.dt2, c2.lin.weight
+                else:
+                    self._spmm(True, None, self.dz2, self.dt2, None, 1.0 + c2.eps)
+                    dt2, w2 = self.dt2, c2.nn.weight
+                ops.rows_gemm(dt2, self.idx1, w2, trans_w=False, out=self.dh, gate_bits=self.z1_pos)
+            if lt == 'both_all':
+                self._wgrad1_partial(True, self.dh)
+            elif lt == 'only2_all':
+                lp1 = self._lp1.clone()
+                self._wgrad1_partial(False, self.dh) if self.s1 else self.p_g1.zero_()
+                self._lp1.copy_(lp1)
+        # loss partial sums of this rank -> the tail of the packed buffer
+        self.p_sums[0:2] = self._lp1.view(-1, 2)[:max(self._lp1_blocks, 1)].sum(0)
+        self.p_sums[2:4] = self._lp2.view(-1, 2)[:max(self._lp2_blocks, 1)].sum(0)
+
+    def _seg_d(self):
+        lt = self.loss_type
+        if lt == 'both_all':                        # upstream never zeroes these gradients
+            self.g1.add_(self.p_g1)
+            self.g2.add_(self.p_g2)
+        else:
+            self.g1.copy_(self.p_g1)
+            self.g2.copy_(self.p_g2)
+        if lt in ('both_all', 'both_layerwise', 'only2_all', 'only1'):
             self.adam1.apply(self.g1)
+        if lt != 'only1':
+            self.adam2.apply(self.g2)
+        check(_lib.lib().gd_loss_finalize_f32(None, 0, None, 0, ptr(self.p_sums), ptr(self.hist), self.hist.shape[0],
+                                              ptr(self.hist_pos), ptr(self.iter_ctr), stream_ptr(self.x.device)),
+              'gd_loss_finalize_f32')
 
     def _segments(self):
-        return [self._seg_forward1, self._seg_forward2_backward1, self._seg_backward2, self._seg_update]
-
-    def _halo(self, full, lists, recv_buf):
-        send_rows, in_splits, recv_rows, out_splits = lists
-        exchange_rows(full.index_select(0, send_rows), recv_buf, in_splits, out_splits, self.world, self.group)
-        full.index_copy_(0, recv_rows, recv_buf)
+        return [self._seg_a, self._seg_b, self._seg_c, self._seg_d]
 
     def _exchange(self, after_segment):
-        if after_segment == 0:
-            if self.exchange == 'halo':
-                self._halo(self.t2_full, self.halo_f, self.recv_f)
-            else:
-                all_gather_rows(self.t2_full, self.rank, self.world, self.chunk, self.group)
-        elif after_segment == 1 and self.needs_b:
-            if self.exchange == 'halo':
-                self._halo(self.dz2, self.halo_b, self.recv_b)
-            else:
-                all_gather_rows(self.dz2, self.rank, self.world, self.chunk, self.group)
+        if self.world == 1:
+            return
+        if after_segment == 0 and self.loss_type != 'only1':
+            exchange_rows(self.send_f, self.recv_f, self.halo_f, self.world, self.group)
+        elif after_segment == 1 and self.needs_l2_to_w1:
+            exchange_rows(self.send_b, self.recv_b, self.halo_b, self.world, self.group)
         elif after_segment == 2:
             all_reduce_sum(self.pack, self.world, self.group)
 
     # ------------------------------------------------------------------ public
     def _mutable_state(self):
-        return [self.wd1.data, self.wd2.data, self.g1, self.g2, self.adam1.m, self.adam1.v, self.adam1.step,
-                self.adam2.m, self.adam2.v, self.adam2.step, self.hist, self.hist_pos]
+        return [self.wd1.data, self.wd2.data, self.g1, self.g2, self.adam1.m, self.adam1.v, self.adam2.m, self.adam2.v,
+                self.iter_ctr, self.hist, self.hist_pos, self.dh]
 
     def _run_eager(self):
         with torch.no_grad():
@@ -251,6 +338,7 @@ class PartitionedNodeembEngine:
 
     def _capture(self):
         saved = [t.clone() for t in self._mutable_state()]
+        applied = (self.adam1.applied, self.adam2.applied)
         self._run_eager()                                  # warm-up incl. the collectives (all ranks)
         torch.cuda.synchronize()
         graphs = []
@@ -263,6 +351,7 @@ class PartitionedNodeembEngine:
                 graphs.append(g)
         for t, s in zip(self._mutable_state(), saved):
             t.copy_(s)
+        self.adam1.applied, self.adam2.applied = applied
         self._graphs = graphs
 
     def step(self):
@@ -275,6 +364,14 @@ class PartitionedNodeembEngine:
                 g.replay()
                 self._exchange(i)
         self.steps_done += 1
+
+    def halo_report(self):
+        """Bytes this rank receives per step in the two row exchanges, and what the dense all-gather would move."""
+        row = 4 * self.o
+        return {'recv_rows_forward': self.halo_f.n_recv, 'recv_rows_backward': self.halo_b.n_recv,
+                'recv_bytes_per_step': row * (self.halo_f.n_recv + self.halo_b.n_recv),
+                'allgather_bytes_per_step': 2 * row * (self.n - (self.hi - self.lo)),
+                'layer1_rows_recomputed': int(self.need1.numel()) - (self.hi - self.lo)}
 
     def loss_history(self):
         k = min(self.steps_done, self.hist.shape[0])

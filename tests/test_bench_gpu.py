@@ -1,0 +1,48 @@
+"""bench.py's contract on the GPU box: the one-GPU line, and the N > 1 launch exactly as the driver starts it
+(torch.distributed.run, one process per rank) - here with both ranks on the box's single GPU over gloo
+(GD_BENCH_BACKEND=gloo; RCCL refuses two ranks on one device), which runs the same partitioned step, halo exchanges
+and replicas leg as an RCCL run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ['--workload', 'synth-small', '--steps', '8', '--warmup', '2', '--pretrain_epochs', '3', '--no_cpu_baseline',
+         '--no_cached_rate']
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + SMALL + ['--cpu_baseline_iters', '2'], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d['n_gpus'] == 1 and d['scaling'] == 'weak' and d['steps'] == 8 and d['warmup'] == 2 and d['value'] > 0
+    assert d['unit'] == 'iters/s' and d['dtype'] == 'f32' and d['vs_baseline'] is None
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(d['roofline'])
+    assert {'roofline_del_gemm', 'roofline_wgrad', 'roofline_spmm_d64'} <= set(d['extras'])
+
+
+@pytest.mark.parametrize('probe', ['0', '1'])
+def test_bench_two_ranks_run_the_partitioned_step(probe):
+    env = dict(os.environ, GD_BENCH_BACKEND='gloo', GD_BENCH_FORCE_PROBE=probe, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(29611 + int(probe)), os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + SMALL
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong', d
+    assert 'partition_fallback' not in d['config'], d['config']
+    assert 'row-partition' in d['config']['parallelism']
+    assert d['config']['halo']['recv_bytes_per_step'] > 0
+    assert d['extras']['iters_per_s_independent_replicas'] > 0
+    assert d['value'] > 0 and abs(d['value'] - d['steps'] / (d['ms_per_step'] * d['steps'] / 1e3)) < 1e-6 * d['value']

@@ -25,7 +25,10 @@ def test_partitioned_step_algebra_and_collectives_over_gloo(world):
 
 
 @pytest.mark.gpu
-def test_partitioned_engine_matches_single_gpu_engine():
-    """Two ranks sharing cuda:0 over gloo (the box has one GPU): the real HIP engine."""
-    out = launch('gpu', 2, timeout=900)
-    assert out.count('partitioned == single') == 3
+@pytest.mark.parametrize('world', [2, 3])
+def test_partitioned_engine_matches_single_gpu_engine(world):
+    """Ranks sharing cuda:0 over gloo (the box has one GPU): the real partitioned HIP engine (fused stages, halo
+    exchanges packed / unpacked inside the hipGraph segments) vs the single-GPU engine, GCN / GIN / GraphSAGE, every
+    --loss_type."""
+    out = launch('gpu', world, timeout=900)
+    assert out.count('partitioned == single') == 7
