@@ -190,6 +190,57 @@ __global__ __launch_bounds__(256) void edge_dot_kernel(const float* __restrict__
   if (li == 0 && m < n_edges) out[m] = p;
 }
 
+// Decoder backward (input gradient): dz[v,:] = sum over the decoded edges m incident to v of
+//     dout[m] * z[other endpoint of m,:]  (* rel[etype[m],:] for DistMult)
+// over a node-major incidence list (inc_ptr[n+1], inc[k] = 2 m + side; side 0: v = e0[m], the other endpoint is
+// e1[m]).  One lane group per node, its incidences summed in list order: no atomics, the same bits every run
+// (autograd's two index_add_ calls add with atomics in arrival order).  Nodes without decoded edges get zeros.
+template <int LPR, bool DISTMULT>
+__global__ __launch_bounds__(256) void edge_dot_bwd_kernel(const float* __restrict__ z, int64_t ld_z, int32_t d4,
+                                                           const int64_t* __restrict__ e0, const int64_t* __restrict__ e1,
+                                                           const float* __restrict__ rel, int64_t ld_rel,
+                                                           const int64_t* __restrict__ etype,
+                                                           const float* __restrict__ dout,
+                                                           const int64_t* __restrict__ inc_ptr,
+                                                           const int64_t* __restrict__ inc, int64_t n_nodes,
+                                                           float* __restrict__ dz, int64_t ld_dz) {
+  constexpr int G = kWave / LPR;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR, li = lane % LPR;
+  const int64_t v = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G + g;
+  if (v >= n_nodes) return;
+  const int64_t k0 = inc_ptr[v], k1 = inc_ptr[v + 1];
+  for (int vec = li; vec < d4; vec += LPR) {
+    float4 acc = f4_zero();
+    int64_t k = k0;
+    for (; k + 2 <= k1; k += 2) {                    // two incidences in flight, added in list order
+      const int64_t c0 = inc[k], c1 = inc[k + 1];
+      const int64_t m0 = c0 >> 1, m1 = c1 >> 1;
+      const int64_t o0 = (c0 & 1) ? e0[m0] : e1[m0], o1 = (c1 & 1) ? e0[m1] : e1[m1];
+      float4 a0 = reinterpret_cast<const float4*>(z + o0 * ld_z)[vec], a1 = reinterpret_cast<const float4*>(z + o1 * ld_z)[vec];
+      const float w0 = dout[m0], w1 = dout[m1];
+      if (DISTMULT) {
+        const float4 r0 = reinterpret_cast<const float4*>(rel + etype[m0] * ld_rel)[vec];
+        const float4 r1 = reinterpret_cast<const float4*>(rel + etype[m1] * ld_rel)[vec];
+        a0.x *= r0.x; a0.y *= r0.y; a0.z *= r0.z; a0.w *= r0.w;
+        a1.x *= r1.x; a1.y *= r1.y; a1.z *= r1.z; a1.w *= r1.w;
+      }
+      acc = f4_fma(w0, a0, acc);
+      acc = f4_fma(w1, a1, acc);
+    }
+    if (k < k1) {
+      const int64_t c0 = inc[k], m0 = c0 >> 1, o0 = (c0 & 1) ? e0[m0] : e1[m0];
+      float4 a0 = reinterpret_cast<const float4*>(z + o0 * ld_z)[vec];
+      if (DISTMULT) {
+        const float4 r0 = reinterpret_cast<const float4*>(rel + etype[m0] * ld_rel)[vec];
+        a0.x *= r0.x; a0.y *= r0.y; a0.z *= r0.z; a0.w *= r0.w;
+      }
+      acc = f4_fma(dout[m0], a0, acc);
+    }
+    reinterpret_cast<float4*>(dz + v * ld_dz)[vec] = acc;
+  }
+}
+
 template <bool DISTMULT>
 __global__ __launch_bounds__(256) void edge_dot_scalar_kernel(const float* __restrict__ z, int64_t ld_z, int32_t d,
                                                               const int64_t* __restrict__ e0,
@@ -427,4 +478,39 @@ extern "C" int gd_adam_f32(float* param, const float* grad, float* exp_avg, floa
   }
   hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, s, step);
   return launched("adam_bump");
+}
+
+extern "C" int gd_edge_dot_bwd_f32(const float* z, int64_t ld_z, int32_t d, const int64_t* e0, const int64_t* e1,
+                                   const float* rel, int64_t ld_rel, const int64_t* etype, const float* dout,
+                                   const int64_t* inc_ptr, const int64_t* inc, int64_t n_nodes, float* dz, int64_t ld_dz,
+                                   void* stream) {
+  using namespace gd;
+  if (n_nodes == 0) return GD_OK;
+  GD_REQUIRE(z && e0 && e1 && dout && inc_ptr && inc && dz, GD_E_NULL, "gd_edge_dot_bwd_f32: null pointer");
+  GD_REQUIRE((rel == nullptr) == (etype == nullptr), GD_E_NULL, "gd_edge_dot_bwd_f32: rel and etype go together");
+  GD_REQUIRE(d > 0 && d % 4 == 0 && d <= 1024 && ld_z >= d && ld_dz >= d && ld_z % 4 == 0 && ld_dz % 4 == 0 &&
+                 (!rel || ld_rel % 4 == 0), GD_E_DIM, "gd_edge_dot_bwd_f32: d=%d must be a multiple of 4 with 16-byte rows", d);
+  GD_REQUIRE(aligned16(z) && aligned16(dz) && (!rel || aligned16(rel)) && z != dz, GD_E_ALIGN,
+             "gd_edge_dot_bwd_f32: unaligned or aliasing pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int d4 = d / 4;
+  const int lpr = lanes_per_row(d4);
+  const int64_t per_block = 4 * (kWave / lpr);
+  const dim3 grid((unsigned)((n_nodes + per_block - 1) / per_block));
+#define GD_DOTB_CASE(LPR)                                                                                              \
+  do {                                                                                                                 \
+    if (rel) hipLaunchKernelGGL((edge_dot_bwd_kernel<LPR, true>), grid, dim3(256), 0, s, z, ld_z, d4, e0, e1, rel, ld_rel, etype, dout, inc_ptr, inc, n_nodes, dz, ld_dz); \
+    else hipLaunchKernelGGL((edge_dot_bwd_kernel<LPR, false>), grid, dim3(256), 0, s, z, ld_z, d4, e0, e1, rel, ld_rel, etype, dout, inc_ptr, inc, n_nodes, dz, ld_dz);    \
+  } while (0)
+  switch (lpr) {
+    case 1: GD_DOTB_CASE(1); break;
+    case 2: GD_DOTB_CASE(2); break;
+    case 4: GD_DOTB_CASE(4); break;
+    case 8: GD_DOTB_CASE(8); break;
+    case 16: GD_DOTB_CASE(16); break;
+    case 32: GD_DOTB_CASE(32); break;
+    default: GD_DOTB_CASE(64); break;
+  }
+#undef GD_DOTB_CASE
+  return launched("edge_dot_bwd");
 }

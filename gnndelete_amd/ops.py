@@ -442,15 +442,31 @@ class _EdgeDot(torch.autograd.Function):
     def backward(ctx, dout):
         z, rel, e0, e1, etype = ctx.saved_tensors
         dz = drel = None
-        a, b = z[e0], z[e1]
-        r = rel[etype] if rel is not None else None
-        g = dout[:, None]
+        dout = dout.contiguous().float()
         if ctx.needs_input_grad[0]:
-            dz = torch.zeros_like(z)
-            dz.index_add_(0, e0, g * (b * r if r is not None else b))
-            dz.index_add_(0, e1, g * (a * r if r is not None else a))
+            n, d = z.shape
+            if d % 4 == 0 and z.stride(0) % 4 == 0 and (rel is None or rel.stride(0) % 4 == 0):
+                # node-major incidence list of the decoded edges (one stable sort), then one deterministic kernel
+                m = e0.shape[0]
+                ends = torch.cat([e0, e1])
+                order = torch.argsort(ends, stable=True)
+                inc = (order % m) * 2 + (order >= m).long()
+                inc_ptr = torch.zeros(n + 1, dtype=torch.long, device=z.device)
+                inc_ptr[1:] = torch.cumsum(torch.bincount(ends, minlength=n), 0)
+                dz = torch.empty(n, d, dtype=torch.float32, device=z.device)
+                check(_lib.lib().gd_edge_dot_bwd_f32(ptr(z), z.stride(0), d, ptr(e0), ptr(e1), ptr(rel),
+                                                     rel.stride(0) if rel is not None else 0, ptr(etype), ptr(dout),
+                                                     ptr(inc_ptr), ptr(inc), n, ptr(dz), dz.stride(0), stream_ptr(z.device)),
+                      'gd_edge_dot_bwd_f32')
+            else:
+                a, b = z[e0], z[e1]
+                r = rel[etype] if rel is not None else None
+                g = dout[:, None]
+                dz = torch.zeros_like(z)
+                dz.index_add_(0, e0, g * (b * r if r is not None else b))
+                dz.index_add_(0, e1, g * (a * r if r is not None else a))
         if rel is not None and ctx.needs_input_grad[1]:
-            drel = torch.zeros_like(rel).index_add_(0, etype, g * a * b)
+            drel = torch.zeros_like(rel).index_add_(0, etype, dout[:, None] * z[e0] * z[e1])
         return dz, drel, None, None, None
 
 
