@@ -355,10 +355,14 @@ class NodeembEngine:
         return in_f % 32 == 0 and out_f % 32 == 0 and out_f <= 128 and in_f * out_f * 4 <= 64 * 1024
 
     def _linear(self, x, weight, relu_in=False):
-        """x @ weight^T: the MFMA row kernel when the weight fits its LDS image, else rocBLAS."""
+        """x @ weight^T on the matrix-core kernels: the whole-weight-in-LDS row kernel when the weight fits its 64 KB
+        image, else the K-tiled kernel (wide bag-of-words inputs: the padded copy of x is made once)."""
         out_f, in_f = weight.shape
         if in_f % 32 == 0 and out_f % 32 == 0 and out_f <= 128 and in_f * out_f * 4 <= 64 * 1024:
             return ops.rows_gemm(x, None, weight, trans_w=True, const_w=True, relu_in=relu_in)
+        if ops.mfma_out_width(out_f):
+            xin = torch.relu(x) if relu_in else x
+            return ops.gemm_wide(xin, ops._const_weight(weight, True)[0], const_x=not relu_in)
         return torch.nn.functional.linear(torch.relu(x) if relu_in else x, weight)
 
     def _linear_relu_z1(self, weight):
@@ -393,7 +397,7 @@ class NodeembEngine:
             else:
                 agg = torch.empty_like(self.x)
                 self._spmm(False, None, self.x, agg, None, 1.0 + c.eps)
-                self.pre1.copy_(torch.nn.functional.linear(agg, lin.weight, lin.bias))
+                ops.rows_gemm(agg, None, lin.weight, trans_w=True, const_w=True, bias=lin.bias, out=self.pre1)
         elif self._mode == 'sage' and self._rows_only and self._split1 and self._mfma_weight(c.lin_l.weight):
             ops.rows_gemm(self.x, self.idx2, c.lin_l.weight, trans_w=True, const_w=True, out=self._t1buf)
             ops.rows_gemm(self.x, self.idx2, c.lin_r.weight, trans_w=True, const_w=True, out=self._t1rbuf)

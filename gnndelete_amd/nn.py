@@ -6,8 +6,9 @@ load unchanged (delete_gnn.py:206-207, strict=False).
 Semantics follow the torch_geometric convs the reference instantiates
 (framework/models/gcn.py:11-12, gat.py:11-12, gin.py:11-12, rgcn.py:17-22); they are pinned by
 the dense known-answer tests of the oracle and by HIP-vs-oracle parity tests.  The dense
-feature transforms (x @ W^T) are plain library GEMMs (torch.matmul -> rocBLAS/hipBLASLt); the
-sparse aggregation, attention softmax and typed mean run in libgnndelete_hip.so."""
+feature transforms (x @ W^T, their input and weight gradients) run on the fp32 matrix-core kernels of
+libgnndelete_hip.so too (ops.dense: whole-weight-in-LDS row kernel, K-tiled kernel for the wide
+bag-of-words inputs), like the sparse aggregation, attention softmax and typed mean."""
 import math
 
 import torch
@@ -31,8 +32,8 @@ class _Weight(nn.Module):
         super().__init__()
         self.weight = _glorot(out_dim, in_dim)
 
-    def forward(self, x):
-        return F.linear(x, self.weight)
+    def forward(self, x, const_x=False):
+        return ops.dense(x, self.weight, None, const_x)
 
 
 class GCNConv(nn.Module):
@@ -44,7 +45,7 @@ class GCNConv(nn.Module):
 
     def forward(self, x, edge_index):
         g = graph_for(edge_index, x.shape[0], 'gcn')
-        return ops.spmm(self.lin(x), g, self.bias)
+        return ops.spmm(self.lin(x, const_x=not x.requires_grad), g, self.bias)
 
 
 class GATConv(nn.Module):
@@ -62,7 +63,7 @@ class GATConv(nn.Module):
 
     def forward(self, x, edge_index):
         g = graph_for(edge_index, x.shape[0], 'gat')
-        h = self.lin_src(x)
+        h = self.lin_src(x, const_x=not x.requires_grad)
         a_src = (h * self.att_src.view(1, -1)).sum(-1)
         a_dst = (h * self.att_dst.view(1, -1)).sum(-1)
         return ops.gat_aggregate(h, a_src, a_dst, g, self.bias, self.negative_slope)
@@ -81,8 +82,9 @@ class GINConv(nn.Module):
     def forward(self, x, edge_index):
         g = graph_for(edge_index, x.shape[0], 'sum')
         if isinstance(self.nn, nn.Linear) and self.nn.out_features <= self.nn.in_features:
-            return ops.spmm(F.linear(x, self.nn.weight), g, self.nn.bias, 1.0 + self.eps)
-        return self.nn(ops.spmm(x, g, None, 1.0 + self.eps))
+            return ops.spmm(ops.dense(x, self.nn.weight, None, not x.requires_grad), g, self.nn.bias, 1.0 + self.eps)
+        agg = ops.spmm(x, g, None, 1.0 + self.eps)
+        return ops.dense(agg, self.nn.weight, self.nn.bias) if isinstance(self.nn, nn.Linear) else self.nn(agg)
 
 
 class SAGEConv(nn.Module):
@@ -98,11 +100,12 @@ class SAGEConv(nn.Module):
 
     def forward(self, x, edge_index):
         g = graph_for(edge_index, x.shape[0], 'mean')
+        const = not x.requires_grad
         if self.out_channels <= self.in_channels:
-            agg = ops.spmm(F.linear(x, self.lin_l.weight), g, self.lin_l.bias)
+            agg = ops.spmm(ops.dense(x, self.lin_l.weight, None, const), g, self.lin_l.bias)
         else:
-            agg = self.lin_l(ops.spmm(x, g))
-        return agg + self.lin_r(x)
+            agg = ops.dense(ops.spmm(x, g), self.lin_l.weight, self.lin_l.bias)
+        return agg + ops.dense(x, self.lin_r.weight, None, const)
 
 
 def _tensor_key(*tensors):
@@ -163,7 +166,7 @@ class RGCNConv(nn.Module):
         else:
             mb = m.view(self.num_relations, n, self.num_blocks, -1)
             out = torch.einsum('rnbi,rbio->nbo', mb, self.weight).reshape(n, self.out_channels)
-        return out + x @ self.root + self.bias
+        return out + ops.dense(x, self.root.t(), self.bias)
 
 
 FastRGCNConv = RGCNConv

@@ -178,6 +178,128 @@ def rows_gemm_dots(inp, w, u1, u2, inp_alt=None, sel=None, relu_in=False, out=No
     return out, a1, a2
 
 
+_PAD_CACHE = {}
+
+
+def _cached(tag, t, build):
+    """build(t) cached per tensor content identity (storage address, shape, strides, torch's version counter); the
+    entry keeps `t` alive so the address cannot be recycled.  For operands that stay constant across calls (the
+    node features, frozen weights): padded / transposed copies are made once."""
+    key = (tag, t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version)
+    hit = _PAD_CACHE.get(key)
+    if hit is None:
+        if len(_PAD_CACHE) >= 8:
+            _PAD_CACHE.clear()
+        hit = (build(t), t)
+        _PAD_CACHE[key] = hit
+    return hit[0]
+
+
+def _pad_cols32(t):
+    k = t.shape[1]
+    kp = (k + 31) // 32 * 32
+    if kp == k and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and t.stride(1) == 1:
+        return t
+    out = torch.zeros(t.shape[0], kp, dtype=torch.float32, device=t.device)
+    out[:, :k] = t
+    return out
+
+
+def mfma_out_width(n):
+    return n % 32 == 0 and 32 <= n <= 128
+
+
+def gemm_wide(x, w_kn, bias=None, idx=None, out=None, const_x=False):
+    """out[rows] = x[rows] @ w_kn (+ bias) with a reduction dimension of any width (gd_gemm_f32): x [M, K], w_kn [K, N]
+    (the transpose of a torch Linear weight), N in {32, 64, 96, 128}.  K is zero-padded to a multiple of 32 (x: a
+    padded copy, cached when const_x says the matrix does not change between calls - the node features)."""
+    assert mfma_out_width(w_kn.shape[1]) and w_kn.shape[0] == x.shape[1]
+    x = _f32_rows(x)
+    xp = _cached('padx', x, _pad_cols32) if const_x else _pad_cols32(x)
+    k = xp.shape[1]
+    if w_kn.shape[0] != k or not w_kn.is_contiguous():
+        wp = torch.zeros(k, w_kn.shape[1], dtype=torch.float32, device=x.device)
+        wp[:w_kn.shape[0]] = w_kn
+        w_kn = wp
+    n = w_kn.shape[1]
+    n_rows = x.shape[0] if idx is None else int(idx.shape[0])
+    if out is None:
+        out = torch.empty(x.shape[0], n, dtype=torch.float32, device=x.device)
+    ws_n = _lib.lib().gd_gemm_f32_workspace(n_rows, k, n)
+    ws = torch.empty(max(int(ws_n), 4), dtype=torch.float32, device=x.device)
+    check(_lib.lib().gd_gemm_f32(ptr(xp), xp.stride(0), ptr(idx), n_rows, ptr(w_kn), k, n, ptr(bias), ptr(out), out.stride(0),
+                                 ptr(ws), stream_ptr(x.device)), 'gd_gemm_f32')
+    return out
+
+
+def _small_weight(d_in, d_out):
+    """Does [d_in, d_out] fit the whole-weight-in-LDS row kernel (rows_gemm_mfma_kernel)?"""
+    return d_in % 32 == 0 and mfma_out_width(d_out) and d_in * 32 * (4 if d_out == 96 else d_out // 32) * 4 <= 64 * 1024
+
+
+class _Dense(torch.autograd.Function):
+    """y = x @ weight^T (+ bias), weight [out, in] as torch.nn.Linear / torch_geometric's Linear store it
+    (framework/models/gcn.py:11-12 ...): every product on the HIP matrix-core kernels where the widths allow -
+    forward (whole weight in LDS for in <= 128, K-tiled for wider inputs), input gradient, weight gradient (row
+    reduction kernel; for a wide input the K-tiled kernel on a cached x^T) - and torch's matmul otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, const_x):
+        x = _f32_rows(x)
+        out_f, in_f = weight.shape
+        ctx.const_x = const_x
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        w = weight.detach()
+        b = bias.detach().contiguous() if bias is not None else None
+        if _small_weight(in_f, out_f) and x.stride(0) % 4 == 0:
+            return rows_gemm(x, None, w, trans_w=True, bias=b)
+        if mfma_out_width(out_f):
+            return gemm_wide(x, _cached('wT', w, lambda t: t.t().contiguous()), b, const_x=const_x)
+        if in_f <= 1024:
+            return rows_gemm(x, None, w, trans_w=True, bias=b)            # any widths: the one-wave-per-row kernel
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = _f32_rows(dy)
+        out_f, in_f = weight.shape
+        dx = dw = db = None
+        w = weight.detach()
+        if ctx.needs_input_grad[0]:
+            if _small_weight(out_f, in_f) or (out_f <= 1024 and in_f <= 1024):
+                dx = rows_gemm(dy, None, w, trans_w=False)                  # dy [*, out] @ W [out, in]
+            else:
+                dx = dy @ w
+        if ctx.needs_input_grad[1]:
+            m = x.shape[0]
+            if out_f % 32 == 0 and in_f % 32 == 0 and out_f <= 128 and in_f <= 128 and out_f != 96 and in_f != 96:
+                dw = rows_gemm_wgrad(dy, None, x, None, m)                  # dy^T x  [out, in]
+            elif mfma_out_width(out_f) and m >= 32:
+                # dW^T [in, out] = x^T dy: the K-tiled kernel with the ROWS of x as the reduction dimension
+                def transpose_pad(t):
+                    mp = (t.shape[0] + 31) // 32 * 32
+                    xt = torch.zeros(t.shape[1], mp, dtype=torch.float32, device=t.device)
+                    xt[:, :t.shape[0]] = t.t()
+                    return xt
+                xt = _cached('xT', x, transpose_pad) if ctx.const_x else transpose_pad(x)
+                dyp = torch.zeros(xt.shape[1], out_f, dtype=torch.float32, device=dy.device)
+                dyp[:m] = dy
+                dw = gemm_wide(xt, dyp).t()
+            else:
+                dw = dy.t() @ x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db, None
+
+
+def dense(x, weight, bias=None, const_x=False):
+    """torch.nn.functional.linear on the HIP kernels (see _Dense); const_x: x is the same matrix on every call (the
+    node features) - padded / transposed copies of it are cached."""
+    return _Dense.apply(x, weight, bias, const_x)
+
+
 def rows_gemm_wgrad(a, a_idx, g, g_idx, n_sel, relu_mask=None, out=None, accumulate=False, g_add=None):
     """dW[d_a, d_b] (+)= sum_s a[a_idx[s]]^T (mask(g) + g_add)[g_idx[s]] - raw call."""
     a, g = _f32_rows(a), _f32_rows(g)
@@ -378,7 +500,9 @@ class _RgcnConvFrozen(torch.autograd.Function):
     def forward(ctx, x, tg, weight, root, bias, n_blocks):
         x = _f32_rows(x)
         weight = weight.detach().contiguous()
-        y = torch.addmm(bias.detach(), x, root.detach()) if bias is not None else x @ root.detach()
+        # root is [in, out]: the row kernel takes it as is (any widths up to 1024: MFMA where they allow)
+        y = rows_gemm(x, None, root.detach(), trans_w=False, bias=bias.detach() if bias is not None else None) \
+            if x.shape[1] <= 1024 else (torch.addmm(bias.detach(), x, root.detach()) if bias is not None else x @ root.detach())
         node_ptr, seg_ptr, seg_rel, col, w = tg.fwd
         if col.numel():
             check(_lib.lib().gd_rgcn_conv_f32(ptr(node_ptr), ptr(seg_ptr), ptr(seg_rel), ptr(col), ptr(w), ptr(x),
@@ -392,7 +516,7 @@ class _RgcnConvFrozen(torch.autograd.Function):
     def backward(ctx, dy):
         weight, root = ctx.saved_tensors
         dy = _f32_rows(dy)
-        dx = dy @ root.t()
+        dx = rows_gemm(dy, None, root, trans_w=True) if dy.shape[1] <= 1024 else dy @ root.t()
         node_ptr, seg_ptr, seg_rel, col, w = ctx.tg.bwd
         if col.numel():
             check(_lib.lib().gd_rgcn_conv_f32(ptr(node_ptr), ptr(seg_ptr), ptr(seg_rel), ptr(col), ptr(w), ptr(dy),

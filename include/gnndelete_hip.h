@@ -350,6 +350,17 @@ int gd_loss_finalize_f32(const float* partials1, int32_t n1, const float* partia
                          const float* extra_sums, float* hist, int32_t capacity, int32_t* pos, int32_t* iter,
                          void* stream);
 
+/* Dense transform with a reduction dimension of any width: out[row(s), :] = in[row(s), :] @ W (+ bias), s < n_rows,
+ * row(s) = idx[s] or s; in [*, k] with k % 32 == 0 (zero-pad the columns of `in` and the rows of W), W [k, n] row-major
+ * (= the TRANSPOSE of a torch Linear weight), n in {32, 64, 96, 128}.  The layer-1 transform x W1^T of the wide
+ * bag-of-words inputs (framework/models/gcn.py:11-12, gat.py / gin.py alike; F = 1,639 / 8,710) - W is streamed
+ * through LDS in 32-row chunks and the k range is split over several blocks per row group; `workspace` holds
+ * gd_gemm_f32_workspace(n_rows, k, n) floats for their partial products (may be NULL when that is 0), which are
+ * added in split order: deterministic.  Replaces torch's matmul -> rocBLAS on the path. */
+int64_t gd_gemm_f32_workspace(int32_t n_rows, int32_t k, int32_t n);
+int gd_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_rows, const float* w, int32_t k,
+                int32_t n, const float* bias, float* out, int64_t ld_out, float* workspace, void* stream);
+
 /* Link decoders.  dot: out[m] = <z[e0[m]], z[e1[m]]>  (framework/models/gcn.py:26-36);
  * distmult: out[m] = sum_c z[e0[m],c] * rel[etype[m],c] * z[e1[m],c]  (rgcn.py:40-47). */
 int gd_edge_dot_f32(const float* z, int64_t ld_z, int32_t d, const int64_t* e0, const int64_t* e1,

@@ -747,3 +747,52 @@ def test_loss_zoo_on_the_device_matches_reference_golden(name):
     v.backward()
     assert rel_l2(v.detach().cpu(), fx[f'{name}::value']) < 1e-5
     assert rel_l2(a.grad.cpu(), fx[f'{name}::grad']) < 1e-4
+
+
+@pytest.mark.parametrize('m,k,n', [(300, 1639, 128), (1000, 96, 64), (77, 8710, 128), (2500, 333, 96), (64, 32, 32),
+                                   (5000, 1664, 64)])
+def test_gemm_wide_matches_fp64(m, k, n):
+    """gd_gemm_f32 (K-tiled MFMA GEMM, W streamed through LDS in 32-row chunks, deterministic split-K): any reduction
+    width (zero-padded to 32), every supported output width, with bias, on all rows and on a gathered row subset."""
+    from gnndelete_amd import ops
+    g = torch.Generator().manual_seed(m + k)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(k, n, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g)
+    want = x.double() @ w.double() + b.double()
+    got = ops.gemm_wide(x.cuda(), w.cuda(), b.cuda())
+    assert rel_l2(got.cpu(), want) < TOL
+    assert torch.equal(got, ops.gemm_wide(x.cuda(), w.cuda(), b.cuda()))          # split-K partials added in fixed order
+    idx = torch.randperm(m, generator=g)[:max(1, m // 3)].sort().values.to(torch.int32)
+    out = torch.full((m, n), -7.0).cuda()
+    ops.gemm_wide(x.cuda(), w.cuda(), None, idx=idx.cuda(), out=out)
+    assert rel_l2(out.cpu()[idx.long()], (x.double() @ w.double())[idx.long()]) < TOL
+    rest = torch.ones(m, dtype=torch.bool)
+    rest[idx.long()] = False
+    assert bool((out.cpu()[rest] == -7.0).all())
+
+
+@pytest.mark.parametrize('m,in_f,out_f,bias', [(400, 1639, 128, False), (400, 128, 64, True), (90, 20, 4, True),
+                                              (700, 200, 96, True), (50, 1639, 6, False)])
+def test_dense_autograd_matches_fp64(m, in_f, out_f, bias):
+    """ops.dense = torch.nn.functional.linear on the HIP kernels: forward, input gradient and weight gradient (for a
+    wide input: the K-tiled kernel on a cached x^T) against fp64 autograd."""
+    from gnndelete_amd import ops
+    g = torch.Generator().manual_seed(in_f + out_f)
+    x = torch.randn(m, in_f, generator=g)
+    w = torch.randn(out_f, in_f, generator=g) / in_f ** 0.5
+    b = torch.randn(out_f, generator=g) if bias else None
+    up = torch.randn(m, out_f, generator=g)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True) if bias else None
+    torch.nn.functional.linear(xd, wd, bd).backward(up.double())
+    for const_x in (False, True):
+        xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+        bg = b.cuda().requires_grad_(True) if bias else None
+        y = ops.dense(xg, wg, bg, const_x)
+        assert rel_l2(y.detach().cpu(), torch.nn.functional.linear(x.double(), w.double(), b.double() if bias else None)) < TOL
+        y.backward(up.cuda())
+        assert rel_l2(xg.grad.cpu(), xd.grad) < TOL
+        assert rel_l2(wg.grad.cpu(), wd.grad) < TOL
+        if bias:
+            assert rel_l2(bg.grad.cpu(), bd.grad) < TOL
