@@ -27,7 +27,7 @@ import torch
 from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
 from .graph import graph_for
-from .nn import GATConv, GCNConv, GINConv, SAGEConv
+from .nn import GATConv, GCNConv, GINConv, RGCNConv, SAGEConv
 
 LOSS_TYPES = ('both_all', 'both_layerwise', 'only2_layerwise', 'only2_all', 'only1')
 
@@ -173,11 +173,22 @@ class NodeembEngine:
 
     def __init__(self, model, x, edge_index, z1_ori, z2_ori, pos_edge, neg_edge, ni_mask1, ni_mask2,
                  loss_type='both_layerwise', alpha=0.5, lr=1e-3, reduction='mean', mask_1hop=None, mask_2hop=None,
-                 use_graph=True, history=4096, reorder=True, cache_layer1=False, affected_rows_only=False):
+                 use_graph=True, history=4096, reorder=True, cache_layer1=False, affected_rows_only=False,
+                 edge_type=None):
+        """edge_type (R-GCN only): relation type per column of edge_index (reverse edges included, as
+        delete_gnn.py:158-171 builds them); x is then the entity id vector the embedding table is indexed with."""
         assert loss_type in LOSS_TYPES, loss_type
         conv1, conv2 = model.conv1, model.conv2
-        if not isinstance(conv2, (GCNConv, GINConv, GATConv, SAGEConv)):
+        if not isinstance(conv2, (GCNConv, GINConv, GATConv, SAGEConv, RGCNConv)):
             raise NotImplementedError(f'NodeembEngine: unsupported conv {type(conv2).__name__}')
+        if isinstance(conv2, RGCNConv):
+            assert edge_type is not None, 'R-GCN needs edge_type'
+            nb = conv2.num_blocks or 1
+            if any((c.in_channels // (c.num_blocks or 1)) % 2 or (c.out_channels // (c.num_blocks or 1)) % 2
+                   or c.in_channels > 128 or c.out_channels > 128 for c in (conv1, conv2)):
+                raise NotImplementedError('NodeembEngine: R-GCN widths outside the typed conv kernel (<= 128, even blocks)')
+            reorder = cache_layer1 = affected_rows_only = False
+            x = model.node_emb.weight.detach()[x.to(model.node_emb.weight.device)]      # frozen embedding lookup, once
         dev = x.device
         if dev.type != 'cuda':
             raise _lib.GnnDeleteHipError('NodeembEngine needs CUDA(HIP) tensors (no CPU fallback)')
@@ -282,10 +293,17 @@ class NodeembEngine:
                 self._lp1_blocks = _lib.lib().gd_rows_gemm_wgrad_blocks(self.s1)
                 self._lp1 = torch.zeros(2 * max(1, self._lp1_blocks), **f32)
                 self._fuse_loss1 = True
-        self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat', SAGEConv: 'sage'}[type(conv2)]
+        self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat', SAGEConv: 'sage', RGCNConv: 'rgcn'}[type(conv2)]
         self._gat_dots = os.environ.get('GD_NO_GAT_DOTS') != '1'      # attention logits from the GEMM epilogue
-        gmode = {'gcn': 'gcn', 'gin': 'sum', 'gat': 'gat', 'sage': 'mean'}[self._mode]
-        self.graph = graph_for(edge_index, n, gmode)
+        if self._mode == 'rgcn':
+            from .graph import TypedNodeCSR
+            self.typed = TypedNodeCSR(edge_index, edge_type.to(dev), n, conv2.num_relations)
+            self.graph = None
+            self._hbuf = torch.zeros(n, self.h, **f32)                # relu(z1) as the typed conv reads it
+            self._dxbuf = torch.zeros(n, self.h, **f32)               # conv2's input gradient
+        else:
+            gmode = {'gcn': 'gcn', 'gin': 'sum', 'gat': 'gat', 'sage': 'mean'}[self._mode]
+            self.graph = graph_for(edge_index, n, gmode)
         if self._mode == 'sage':
             # frozen: [W_l ; W_r] of conv2 stacked once -> one GEMM gives (t2_l | t2_r), and its transpose
             # side gives dh from (dt2 | dp2)
@@ -379,7 +397,9 @@ class NodeembEngine:
         """Frozen layer 1, recomputed every step exactly as upstream does, written into z1."""
         c = self.model.conv1
         g = self.graph
-        if self._mode == 'gcn' and self._fused_l1:
+        if self._mode == 'rgcn':
+            self._rgcn_conv(c, self.x, self.pre1, 0)
+        elif self._mode == 'gcn' and self._fused_l1:
             ops.agg_gemm_items(g, self.x, c.lin.weight, c.bias, self._pre1_ext)
         elif self._mode == 'gcn' and self._rows_only and self._split1 and self._mfma_weight(c.lin.weight):
             ops.rows_gemm(self.x, self.idx2, c.lin.weight, trans_w=True, const_w=True, out=self._t1buf)
@@ -420,9 +440,29 @@ class NodeembEngine:
             ops.gat_forward_raw(g, h1, a_src, a_dst, c.bias, c.negative_slope, out=self.pre1,
                                 plan=self._plan2 if (self._rows_only and self._split1) else None)
 
+    def _rgcn_conv(self, conv, inp, out, trans):
+        """out = inp @ root (+ bias) + sum_r mean_{N_r} inp W_r (forward), or the input gradient with trans = 1:
+        out = inp @ root^T + the typed kernel on the transposed graph with W_r^T.  Raw kernel calls, no tape."""
+        tg = self.typed
+        nb = conv.num_blocks or 1
+        ops.rows_gemm(inp, None, conv.root.detach(), trans_w=bool(trans), bias=None if trans else conv.bias.detach(), out=out)
+        node_ptr, seg_ptr, seg_rel, col, w = tg.bwd if trans else tg.fwd
+        if col.numel():
+            weight = conv.weight.detach().contiguous()
+            check(_lib.lib().gd_rgcn_conv_f32(ptr(node_ptr), ptr(seg_ptr), ptr(seg_rel), ptr(col), ptr(w), ptr(inp),
+                                              inp.stride(0), inp.shape[1], ptr(weight), nb, int(trans), ptr(out), out.stride(0),
+                                              out.shape[1], tg.n, stream_ptr(inp.device)), 'gd_rgcn_conv_f32')
+
     def _conv2_forward(self):
         c = self.model.conv2
-        if self._mode == 'gcn' and self._rows_only:
+        if self._mode == 'rgcn':
+            if self._split1:
+                torch.where(self._sel1.bool()[:, None], self.z1, self.pre1, out=self._hbuf)
+                self._hbuf.clamp_(min=0)
+            else:
+                torch.clamp(self.z1, min=0, out=self._hbuf)
+            self._rgcn_conv(c, self._hbuf, self.p2, 0)
+        elif self._mode == 'gcn' and self._rows_only:
             if self._split1:
                 t2 = ops.rows_gemm_select(self.pre1, self.z1, self._sel1, c.lin.weight, trans_w=True, const_w=True, relu_in=True,
                                           out=self._t2buf, idx=self.idx2)
@@ -478,6 +518,11 @@ class NodeembEngine:
         """dh[S1] = d loss2 / d z1 (post-Del, pre-ReLU) restricted to the S1 rows (all that Del-1 needs)."""
         c = self.model.conv2
         g = self.graph
+        if self._mode == 'rgcn':
+            self._rgcn_conv(c, self.dz2, self._dxbuf, 1)
+            # dh[S1] = dx[S1] * [z1[S1] > 0]  (ReLU backward from the packed sign bits of the Del-1 output)
+            ops.gate_rows(self._dxbuf, self.idx1, self.z1_pos, self.dh)
+            return
         if self._mode == 'sage':
             self._spmm(True, g.val_t, self.dz2, self.dcat[:, :self.o], None, 0.0,
                        plan=self._plan_t1 if self._rows_only else None)

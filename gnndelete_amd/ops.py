@@ -125,6 +125,20 @@ def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, sa
     return out
 
 
+def gate_rows(src, idx, sign_bits, out):
+    """out[idx[s], :] = src[idx[s], :] where bit c of sign_bits[s] is set, else 0 (ReLU backward from the packed
+    [z > 0] pattern the Del-1 kernel emitted).  Plain tensor ops on static buffers (graph-capturable)."""
+    n_sel, d = int(idx.shape[0]), src.shape[1]
+    if n_sel == 0:
+        return out
+    words = (d + 31) // 32
+    shifts = torch.arange(32, device=src.device, dtype=torch.int32)
+    bits = ((sign_bits[:n_sel, :words, None] >> shifts) & 1).reshape(n_sel, words * 32)[:, :d]
+    rows = idx.long()
+    out[rows] = src[rows] * bits.to(src.dtype)
+    return out
+
+
 def rows_gemm_select(inp, inp_alt, sel, w, trans_w=False, bias=None, relu_in=False, out=None, idx=None, const_w=False):
     """rows_gemm over a matrix split across two buffers: row r comes from inp_alt where sel[r] (uint8); all rows,
     or the rows listed in idx (int32, written to the same rows of out)."""
