@@ -31,7 +31,8 @@ def parse():
     p.add_argument('--steps', type=int, default=200)
     p.add_argument('--warmup', type=int, default=20)
     p.add_argument('--workload', default='synth-collab')
-    p.add_argument('--gnn', default='gcn', choices=['gcn', 'gat', 'gin', 'sage'])
+    p.add_argument('--gnn', default='gcn', choices=['gcn', 'gat', 'gin', 'sage', 'rgcn'],
+                   help="'rgcn' = BASELINE config 4: --workload synth-biokg (51 relation types), full-graph fused Del step")
     p.add_argument('--df', default='in')
     p.add_argument('--df_size', type=float, default=5.0)
     p.add_argument('--loss_type', default='both_layerwise')
@@ -62,6 +63,8 @@ def build_request(args, device):
     from gnndelete_amd.framework.synth import make_linkpred_dataset
     from gnndelete_amd.framework.utils import seed_everything
 
+    if args.gnn == 'rgcn':
+        return build_kg_request(args)
     data, df_masks = make_linkpred_dataset(args.workload, seed=args.seed)
     seed_everything(args.seed)
     size = resolve_df_size(args.df_size, data.train_pos_edge_index.shape[1])
@@ -74,6 +77,116 @@ def build_request(args, device):
     keep[data.directed_df_edge_index.flatten().unique()] = False
     ni1, ni2 = data.sdf_node_1hop_mask & keep, data.sdf_node_2hop_mask & keep
     return data, model, neg, ni1, ni2
+
+
+def build_kg_request(args):
+    """BASELINE config 4: knowledge-graph unlearning request (delete_gnn.py:85-171, relational branch) on the synthetic
+    ogbl-biokg stand-in, R-GCN with block-diagonal relation weights; Del masks = S_Df minus the Df endpoints, DEC on
+    the forward-direction Df triples against head-shuffled negatives (gnndelete_nodeemb.py:749-768)."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework.data import prepare_edge_deletion, resolve_df_size
+    from gnndelete_amd.framework.models import RGCNDelete
+    from gnndelete_amd.framework.synth import KG_SHAPES, make_kg_dataset
+    from gnndelete_amd.framework.utils import negative_sampling_kg, seed_everything
+    data, df_masks = make_kg_dataset(args.workload, seed=args.seed)
+    nr = KG_SHAPES[args.workload][1]
+    seed_everything(args.seed)
+    size = resolve_df_size(args.df_size, data.train_pos_edge_index.shape[1])
+    prepare_edge_deletion(data, df_masks[args.df], size, True, nr)
+    keep = torch.ones(data.num_nodes, dtype=torch.bool)
+    keep[data.directed_df_edge_index.flatten().unique()] = False
+    ni1, ni2 = data.sdf_node_1hop_mask & keep, data.sdf_node_2hop_mask & keep
+    model = RGCNDelete(SimpleNamespace(in_dim=128, hidden_dim=128, out_dim=64), data.num_nodes, nr, ni1, ni2)
+    pos, pt = data.edge_index[:, data.df_mask], data.edge_type[data.df_mask]
+    fw = pt < nr
+    data.kg_dec_edge, data.kg_num_edge_type = pos[:, fw].contiguous(), nr
+    neg = negative_sampling_kg(data.kg_dec_edge, pt[fw])
+    return data, model, neg, ni1, ni2
+
+
+def make_kg_engine(args, data, model, neg, ni1, ni2, device):
+    from gnndelete_amd.engine import NodeembEngine
+    model = model.to(device)
+    ei = data.edge_index[:, data.dr_mask].to(device).contiguous()
+    et = data.edge_type[data.dr_mask].to(device).contiguous()
+    x = data.x.to(device)
+    with torch.no_grad():
+        z1o, z2o = model.get_original_embeddings(x, ei, et, return_all_emb=True)
+    return NodeembEngine(model, x, ei, z1o, z2o, data.kg_dec_edge.to(device), neg.to(device), ni1, ni2,
+                         loss_type=args.loss_type, alpha=0.5, lr=1e-3, use_graph=not args.no_graph, edge_type=et)
+
+
+def time_typed_conv(eng):
+    """The typed conv kernel of layer 1 (128 -> 128, block-diagonal W_r): algorithmic bytes = the gathered neighbour
+    rows 4 nnz d + 8 nnz of (col, weight) + 8 bytes per (node, relation) run + N d read for the root term and N d
+    written, against the HBM peak (the [R, N, d] tensor of the reference path is never formed)."""
+    conv, tg = eng.model.conv1, eng.typed
+    nnz, runs, n, d = int(tg.fwd[3].numel()), int(tg.fwd[1].numel()) - 1, eng.n, eng.h
+    out = torch.empty(n, d, device=eng.x.device)
+    dur = _avg_seconds(lambda: eng._rgcn_conv(conv, eng.x, out, 0), reps=10)
+    nbytes = 4.0 * nnz * d + 8.0 * nnz + 8.0 * runs + 8.0 * n * d
+    return {'kernel': 'rows_gemm (root) + rgcn_conv_kernel (typed mean aggregation + block-diagonal transform, 128 -> 128)',
+            'bound': 'hbm', 'achieved': nbytes / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': nbytes / dur / 1e9 / HBM_PEAK_GBS,
+            'traffic': None, 'algorithmic_bytes': nbytes, 'avg_us': dur * 1e6, 'typed_edges': nnz, 'runs': runs}
+
+
+def kg_cpu_baseline(args, data, state, neg, ni1, ni2, iters):
+    from oracle import gnndelete_ref as R
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    nr = data.kg_num_edge_type
+    m = R.TwoLayerDelete('rgcn', 128, 128, 64, ni1, ni2, num_nodes=data.num_nodes, num_edge_type=nr)
+    m.load_state_dict(state, strict=False)
+    ei, et = data.edge_index[:, data.dr_mask], data.edge_type[data.dr_mask]
+    with torch.no_grad():
+        z1o, z2o = m.get_original_embeddings(data.x, ei, et, return_all_emb=True)
+    targets = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=data.kg_dec_edge, neg_edge=neg, ni_mask1=ni1, ni_mask2=ni2)
+    opt = R.make_optimizer(m, args.loss_type, 1e-3)
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        R.nodeemb_epoch(m, lambda: m(data.x, ei, et, return_all_emb=True), targets, opt, args.loss_type, 0.5, R.LOSSES['mse_mean'])
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {'value': 1.0 / med, 'unit': 'iters/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{iters} full-graph R-GCN iterations of the same request, median ({med:.1f} s; torch CPU, {threads} host threads)'}, m
+
+
+def kg_main(args, device):
+    """One GPU, BASELINE config 4 (`--workload synth-biokg --gnn rgcn`): ONE JSON line with the same contract."""
+    data, model, neg, ni1, ni2 = build_kg_request(args)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    eng = make_kg_engine(args, data, model, neg, ni1, ni2, device)
+    if args.unroll > 1 and not args.no_graph:
+        eng.prepare_unrolled(args.unroll)
+    for _ in range(args.warmup):
+        eng.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run(args.steps, unroll=args.unroll)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {'metric': 'Del-op train iters/sec', 'value': args.steps / dt, 'unit': 'iters/s', 'n_gpus': 1, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': f'{args.workload} R-GCN 2-layer ({data.kg_num_edge_type} relation types, block-diagonal weights), '
+                                  f'{args.df_size}% {args.df.upper()} triple deletion, full-graph fused Del step ({args.loss_type}, mse_mean)',
+                      'num_nodes': data.num_nodes, 'typed_edges_dr': int(data.dr_mask.sum()), 'df_triples': int(data.directed_df_edge_index.shape[1]),
+                      'S1': int(ni1.sum()), 'S2': int(ni2.sum()), 'hip_graph': not args.no_graph, 'parallelism': 'single'},
+           'roofline': time_typed_conv(eng), 'final_loss': float(eng.loss_history()[-1, 0])}
+    if not args.no_cpu_baseline:
+        iters = max(1, min(args.cpu_baseline_iters, 2))
+        cpu_data = data.clone().cpu() if hasattr(data, 'clone') else data
+        out['cpu_baseline'], ref = kg_cpu_baseline(args, cpu_data, state, neg, ni1, ni2, iters)
+        out['speedup_vs_cpu'] = out['value'] / out['cpu_baseline']['value']
+        model.load_state_dict(state)
+        eng2 = make_kg_engine(args, data, model, neg, ni1, ni2, device)
+        for _ in range(iters):
+            eng2.step()
+        rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm())
+        out['parity'] = {'iterations': iters, 'W_D1_rel_l2': rel(model.deletion1.deletion_weight.detach(), ref.deletion1.deletion_weight.detach()),
+                         'W_D2_rel_l2': rel(model.deletion2.deletion_weight.detach(), ref.deletion2.deletion_weight.detach())}
+    print(json.dumps(out))
 
 
 def train_backbone(model, data, device, epochs, lr=0.01):
@@ -398,6 +511,9 @@ def main():
             torch.cuda.synchronize()
             dist.barrier(group=ctl)
 
+    if args.gnn == 'rgcn':
+        assert world == 1, 'the KG line is a one-GPU line'
+        return kg_main(args, device)
     data, model, neg, ni1, ni2 = build_request(args, device)
     pretrain_loss = None
     if args.pretrain_epochs > 0 and not args.probe_partition:
