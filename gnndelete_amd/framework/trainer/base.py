@@ -59,9 +59,54 @@ class Trainer:
 
     # ------------------------------------------------------------------ original training
     def train(self, model, data, optimizer, args):
-        # Cora / PubMed / DBLP / CS full batch; the reference's mini-batch branch (ogbl-*, Physics)
-        # exists to fit a 16-32 GB GPU - one MI355X holds these graphs whole
+        # Cora / PubMed / DBLP / CS full batch; the reference's mini-batch branch (ogbl-*, Physics) exists to fit a
+        # 16-32 GB GPU - one MI355X holds these graphs whole, so it is taken only on request (--minibatch)
+        if is_large(self.args.dataset) and getattr(args, 'minibatch', False):
+            return self.train_minibatch(model, data, optimizer, args)
         return self.train_fullbatch(model, data, optimizer, args)
+
+    def train_minibatch(self, model, data, optimizer, args):
+        """base.py:144-227: per GraphSAINT batch, BCE link prediction on the batch's edges against one negative per
+        edge; best-validation-loss checkpoint."""
+        from . import sampler as _sampler
+        _require_gpu()
+        start = time.time()
+        best_valid_loss, best_epoch = 1000000, 0
+        model = model.to(device)
+        data = data.to('cpu')
+        data.edge_index = data.train_pos_edge_index
+        loader = _sampler.make_sampler(data, args.batch_size, args.num_steps)
+        self.trainer_log['steps'] = []
+        for epoch in range(args.epochs):
+            model.train()
+            epoch_loss, steps, z = 0.0, 0, None
+            for batch in loader:
+                edges = batch.edge_index.to(device).contiguous()
+                z = model(batch.x.to(device), edges)
+                neg = _sampler.negative_sampling(edges, z.size(0), edges.shape[1])
+                loss = F.binary_cross_entropy_with_logits(model.decode(z, edges, neg), get_link_labels(edges, neg))
+                loss.backward()
+                optimizer.step()
+                optimizer.zero_grad()
+                rec = {'epoch': epoch, 'step': steps, 'train_loss': loss.item()}
+                wandb_log(rec)
+                self.trainer_log['steps'].append(rec)
+                epoch_loss += rec['train_loss']
+                steps += 1
+            if (epoch + 1) % args.valid_freq == 0:
+                valid_loss, *_, valid_log = self.eval(model, data, 'val')
+                self._record({'epoch': epoch, 'train_loss': epoch_loss / max(steps - 1, 1)}, valid_log)
+                if valid_loss < best_valid_loss:
+                    best_valid_loss, best_epoch = valid_loss, epoch
+                    print(f'Save best checkpoint at epoch {epoch:04d}. Valid loss = {valid_loss:.4f}')
+                    torch.save({'model_state': model.state_dict(), 'optimizer_state': optimizer.state_dict()},
+                               os.path.join(args.checkpoint_dir, 'model_best.pt'))
+                    torch.save(z.detach(), os.path.join(args.checkpoint_dir, 'node_embeddings.pt'))
+                data = data.to('cpu')
+        self.trainer_log['training_time'] = time.time() - start
+        torch.save({'model_state': model.state_dict(), 'optimizer_state': optimizer.state_dict()},
+                   os.path.join(args.checkpoint_dir, 'model_final.pt'))
+        self.trainer_log['best_epoch'], self.trainer_log['best_valid_loss'] = best_epoch, best_valid_loss
 
     def train_fullbatch(self, model, data, optimizer, args):
         """BCE link prediction on all train edges vs fresh negatives each epoch (base.py:75-142)."""

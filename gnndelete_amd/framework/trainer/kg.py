@@ -28,12 +28,13 @@ class KGTrainer(Trainer):
         loader = _sampler.make_sampler(data, 128, args.num_steps)
         best_metric, best_epoch = 0, 0
         start = time.time()
+        self.trainer_log['steps'] = []
         for epoch in range(args.epochs):
             model.train()
             epoch_loss, steps = 0.0, 0
             for batch in loader:
                 batch = batch.to(device)
-                edge_index, edge_type = batch.edge_index, batch.edge_type
+                edge_index, edge_type = batch.edge_index.contiguous(), batch.edge_type.contiguous()
                 z = model(batch.x, edge_index, edge_type)
                 decoding = edge_type < args.num_edge_type
                 dec_index, dec_type = edge_index[:, decoding], edge_type[decoding]
@@ -43,11 +44,15 @@ class KGTrainer(Trainer):
                 loss.backward()
                 optimizer.step()
                 optimizer.zero_grad()
-                epoch_loss += loss.item()
+                rec = {'epoch': epoch, 'step': steps, 'train_loss': loss.item()}
+                wandb_log(rec)
+                self.trainer_log['steps'].append(rec)
+                epoch_loss += rec['train_loss']
                 steps += 1
             if (epoch + 1) % args.valid_freq == 0:
                 valid_loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, _, valid_log = self.eval(model, data, 'val')
                 self._record({'epoch': epoch, 'train_loss': epoch_loss / max(steps - 1, 1)}, valid_log)
+                data = data.to('cpu')
                 if dt_aup > best_metric:
                     best_metric, best_epoch = dt_aup, epoch
                     print(f'Save best checkpoint at epoch {epoch:04d}. Valid loss = {valid_loss:.4f}')

@@ -23,6 +23,8 @@ What each piece follows (paths relative to /root/reference):
   retrain_fullbatch        framework/trainer/retrain.py:57-131
   verification_error       framework/evaluation.py:63-81
   split_edges              prepare_dataset.py:31-136 (+ IN / OUT masks :205-214)
+  original_minibatch       framework/trainer/base.py:144-227 (GraphSAINT batches injected)
+  kg_original_minibatch    framework/trainer/base.py:394-493
 
 Build semantics: the backbone is truly frozen - conv1
 runs under no_grad for every architecture (upstream does so for GAT/GIN/RGCN; for GCN
@@ -486,6 +488,57 @@ def kg_nodeemb_minibatch(model, data, node_sets, num_edge_type, epochs, alpha, l
             loss = _layerwise_step(opt, alpha, r1, r2, l1, l2)
             logs.append(dict(train_loss=float(loss), loss_r=float(r1 + r2), loss_l=float(l1 + l2)))
     return logs
+
+
+def original_minibatch(model, data, node_sets, negs, epochs, lr):
+    """Trainer.train_minibatch (base.py:144-227) without validation: per batch BCE-with-logits link prediction on the
+    batch's edges against one negative per edge (``negs``, consumed in order), Adam on every parameter, zero_grad
+    after the step.  -> per-step train_loss."""
+    d = dict(data)
+    d['edge_index'] = d['train_pos_edge_index']
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    negs = iter(negs)
+    losses = []
+    for _ in range(epochs):
+        model.train()
+        for nodes in node_sets:
+            b = pyg.saint_subgraph(d, nodes)
+            ei = b['edge_index']
+            z = model(b['x'], ei)
+            neg = next(negs)
+            assert neg.shape[1] == ei.shape[1]
+            label = torch.cat([torch.ones(ei.shape[1]), torch.zeros(neg.shape[1])])
+            loss = F.binary_cross_entropy_with_logits(model.decode(z, ei, neg), label)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+    return losses
+
+
+def kg_original_minibatch(model, data, node_sets, num_edge_type, epochs, lr):
+    """KGTrainer.train (base.py:394-493) without validation: message passing on ALL batch edges (both directions),
+    DistMult scores of the forward-direction batch edges against per-relation head-shuffled negatives (global torch
+    RNG), BCE-with-logits, Adam on every parameter.  -> per-step train_loss."""
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    losses = []
+    for _ in range(epochs):
+        model.train()
+        for nodes in node_sets:
+            b = pyg.saint_subgraph(dict(data), nodes)
+            ei, et = b['edge_index'], b['edge_type']
+            z = model(b['x'], ei, et)
+            fw = et < num_edge_type
+            dec, dec_t = ei[:, fw], et[fw]
+            neg = negative_sampling_kg(dec, dec_t)
+            logits = torch.cat([model.decode(z, dec, dec_t), model.decode(z, neg, dec_t)], -1)
+            label = torch.cat([torch.ones(dec.shape[1]), torch.zeros(neg.shape[1])])
+            loss = F.binary_cross_entropy_with_logits(logits, label)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+    return losses
 
 
 def eval_kg(model, data, stage, unlearning_model='gnndelete_nodeemb'):

@@ -55,7 +55,8 @@ def _neg_stub(edge_index=None, num_nodes=None, num_neg_samples=None, **kw):
     if STATE.get('neg_gen') is not None:
         # mini-batch loops draw fresh negatives per batch: drawn here from a seeded generator and RECORDED, so the
         # fixture holds every set the reference's loop consumed, in order
-        neg = torch.randint(0, int(num_nodes), (2, int(num_neg_samples)), generator=STATE['neg_gen'])
+        k = int(edge_index.shape[1] if num_neg_samples is None else num_neg_samples)      # PyG default: one per edge
+        neg = torch.randint(0, int(num_nodes), (2, k), generator=STATE['neg_gen'])
         STATE['neg_log'].append(neg.clone())
         return neg
     neg = STATE['neg']
@@ -889,6 +890,79 @@ def golden_wide_trajectories(D, T, A):
         np.savez_compressed(os.path.join(HERE, f'traj_wide_{gnn}_{loss_type}.npz'), **out)
 
 
+def golden_original_minibatch(B, A):
+    """The original-model MINI-BATCH loops on injected GraphSAINT batches: Trainer.train_minibatch
+    (framework/trainer/base.py:144-227; the reference's own GCN, negatives = one per batch edge, recorded) and
+    KGTrainer.train (base.py:394-493; the reference's own RGCN at 21 relation types, DistMult decoder on the
+    forward-direction batch edges, negative_sampling_kg from a recorded seed, model selection on validation AUP)."""
+    GCN = importlib.import_module('framework.models.gcn').GCN
+    g = synth_graph(140, 620, 10, seed=63)
+    E = g['train']
+    und, _ = pyg.to_undirected(E, [torch.ones(E.shape[1], dtype=torch.int32)], g['num_nodes'])
+    d = Bag(x=g['x'], num_nodes=g['num_nodes'], train_pos_edge_index=und, edge_index=und,
+            dtrain_mask=torch.ones(und.shape[1], dtype=torch.bool), dr_mask=torch.ones(und.shape[1], dtype=torch.bool),
+            val_pos_edge_index=g['val_pos'], val_neg_edge_index=g['val_neg'],
+            test_pos_edge_index=g['test_pos'], test_neg_edge_index=g['test_neg'])
+    args = make_args(A, ['--gnn', 'gcn', '--unlearning_model', 'original', '--in_dim', '10', '--hidden_dim', '32',
+                         '--out_dim', '16', '--dataset', 'Cora', '--checkpoint_dir', tempfile.mkdtemp(), '--lr', '0.01'])
+    args.epochs, args.valid_freq, args.batch_size, args.num_steps = 2, 2, 40, 3
+    torch.manual_seed(21)
+    model = GCN(args)
+    init = state_np(model)
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    STATE['batches'] = _node_sets(140, 3, 90, seed=4)
+    STATE['neg_gen'], STATE['neg_log'], STATE['wandb'] = torch.Generator().manual_seed(29), [], []
+    torch.manual_seed(85)
+    try:
+        B.Trainer(args).train_minibatch(model, d, opt, args)
+    finally:
+        STATE['neg_gen'] = None
+    steps = [w for w in STATE['wandb'] if 'step' in w]
+    vals = [w for w in STATE['wandb'] if 'val_loss' in w]
+    out = dict(init)
+    out.update(data_np(d, torch.zeros(2, 0, dtype=torch.long)))
+    out.update({f'final::{k}': np_(v) for k, v in model.state_dict().items()})
+    for i, b in enumerate(STATE['batches']):
+        out[f'batch::{i}'] = np_(b)
+    for i, ng in enumerate(STATE['neg_log']):
+        out[f'negs::{i}'] = np_(ng)
+    out.update(n_batches=np.int64(3), n_negs=np.int64(len(STATE['neg_log'])), train_loss=np.array([s_['train_loss'] for s_ in steps]),
+               val_loss=np.array([v['val_loss'] for v in vals]), val_dt_auc=np.array([v['val_dt_auc'] for v in vals]),
+               lr=np.float64(args.lr), epochs=np.int64(2), eval_seed=np.int64(85))
+    np.savez_compressed(os.path.join(HERE, 'orig_minibatch_gcn.npz'), **out)
+
+    # ---- KGTrainer.train
+    RGCN = importlib.import_module('framework.models.rgcn').RGCN
+    R_, n = 21, 150
+    d = kg_request(n, 900, R_, seed=73, df_count=40)
+    d['dr_mask'] = torch.ones_like(d['dr_mask'])                  # original training: nothing is deleted yet
+    d['df_mask'] = torch.zeros_like(d['df_mask'])
+    args = make_args(A, ['--gnn', 'rgcn', '--unlearning_model', 'original', '--dataset', 'WordNet18', '--in_dim', '32',
+                         '--hidden_dim', '32', '--out_dim', '16', '--checkpoint_dir', tempfile.mkdtemp()])
+    args.epochs, args.valid_freq, args.num_steps, args.lr, args.num_edge_type = 2, 2, 3, 0.01, R_
+    torch.manual_seed(22)
+    model = RGCN(args, n, R_)
+    init = state_np(model)
+    model.to = lambda *a, **k: model
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    STATE['batches'] = _node_sets(n, 3, 110, seed=6)
+    STATE['wandb'] = []
+    torch.manual_seed(86)
+    B.KGTrainer(args).train(model, d, opt, args)
+    steps = [w for w in STATE['wandb'] if 'step' in w]
+    vals = [w for w in STATE['wandb'] if 'val_loss' in w]
+    out = dict(init)
+    d2 = Bag({k: v for k, v in d.items()})
+    out.update(data_np(d2, torch.zeros(2, 0, dtype=torch.long)))
+    out.update({f'final::{k}': np_(v) for k, v in model.state_dict().items()})
+    for i, b in enumerate(STATE['batches']):
+        out[f'batch::{i}'] = np_(b)
+    out.update(n_batches=np.int64(3), num_edge_type=np.int64(R_), train_loss=np.array([s_['train_loss'] for s_ in steps]),
+               val_loss=np.array([v['val_loss'] for v in vals]), val_dt_auc=np.array([v['val_dt_auc'] for v in vals]),
+               val_dt_aup=np.array([v['val_dt_aup'] for v in vals]), lr=np.float64(args.lr), epochs=np.int64(2), seed=np.int64(86))
+    np.savez_compressed(os.path.join(HERE, 'orig_kg_rgcn.npz'), **out)
+
+
 def golden_gcn_layerwise_crash(D, T, A):
     """record that upstream GCNDelete + both_layerwise raises."""
     g = synth_graph(40, 120, 6, seed=31)
@@ -1077,6 +1151,11 @@ def main():
         golden_retrain(A)
         golden_split()
         golden_wide_trajectories(D, T, A)
+        golden_original_minibatch(B, A)
+        write_manifest(None)
+        return
+    if sys.argv[1:] == ['orig_minibatch']:
+        golden_original_minibatch(B, A)
         write_manifest(None)
         return
     golden_del_layer(D)
@@ -1092,6 +1171,7 @@ def main():
     golden_retrain(A)
     golden_split()
     golden_wide_trajectories(D, T, A)
+    golden_original_minibatch(B, A)
     crash = golden_gcn_layerwise_crash(D, T, A)
     golden_parse_args(A)
     golden_eval(D, T, A)

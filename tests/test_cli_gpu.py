@@ -405,3 +405,61 @@ def test_retrain_trainer_reproduces_reference(tmp_path, monkeypatch):
     other.load_state_dict({k[len('other::'):]: t(v) for k, v in fx.items() if k.startswith('other::')})
     ve = float(verification_error(m, other.cuda()))
     assert abs(ve - float(rest['ve'])) < 1e-3 * float(rest['ve'])
+
+
+def test_original_minibatch_trainers_reproduce_reference(tmp_path, monkeypatch):
+    """Original-model MINI-BATCH training on the HIP convs (conv weight gradients through the kernels) on the batches
+    the reference's loops consumed: Trainer.train_minibatch (base.py:144-227, GCN) and KGTrainer.train
+    (base.py:394-493, RGCN with 21 relation types: per-relation autograd path, DistMult, negative_sampling_kg
+    re-drawn from the recorded seed)."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework import get_model
+    from gnndelete_amd.framework.data import Data
+    from gnndelete_amd.framework.trainer import base as TB
+    from gnndelete_amd.framework.trainer import kg as TK
+    from gnndelete_amd.framework.trainer import sampler as S
+    fx = load_golden('orig_minibatch_gcn.npz')
+    state, data, rest = split_fixture(fx)
+    w1, w2 = state['conv1.lin.weight'], state['conv2.lin.weight']
+    sets, negs = _lists(fx, 'batch', 'n_batches'), iter(_lists(fx, 'negs', 'n_negs'))
+    monkeypatch.setattr(S, 'make_sampler', lambda d, batch_size, num_steps, walk_length=2: S.FixedNodeSets(d, sets))
+    monkeypatch.setattr(S, 'negative_sampling', lambda ei, n, k: next(negs).to(ei.device))
+    epochs = int(rest['epochs'])
+    args = SimpleNamespace(unlearning_model='original', gnn='gcn', dataset='ogbl-synth', checkpoint_dir=str(tmp_path / 'a'),
+                           in_dim=w1.shape[1], hidden_dim=w1.shape[0], out_dim=w2.shape[0], eval_on_cpu=False, epochs=epochs,
+                           valid_freq=epochs, lr=float(rest['lr']), batch_size=40, num_steps=len(sets), minibatch=True)
+    m = get_model(args)
+    m.load_state_dict(state)
+    opt = torch.optim.Adam(m.parameters(), lr=args.lr)
+    tr = TB.Trainer(args)
+    torch.manual_seed(int(rest['eval_seed']))
+    tr.train(m, Data(data), opt, args)
+    np.testing.assert_allclose([s_['train_loss'] for s_ in tr.trainer_log['steps']], rest['train_loss'], rtol=1e-4)
+    final = {k[len('final::'):]: v for k, v in fx.items() if k.startswith('final::')}
+    for k, v in m.state_dict().items():
+        assert rel_l2(v.cpu(), final[k]) < 1e-4, k
+    vals = [r for r in tr.trainer_log['log'] if 'val_loss' in r]
+    assert abs(vals[-1]['val_loss'] - float(rest['val_loss'][-1])) < 1e-4
+
+    fx = load_golden('orig_kg_rgcn.npz')
+    state, data, rest = split_fixture(fx)
+    R_ = int(rest['num_edge_type'])
+    sets = _lists(fx, 'batch', 'n_batches')
+    monkeypatch.setattr(S, 'make_sampler', lambda d, batch_size, num_steps, walk_length=2: S.FixedNodeSets(d, sets))
+    epochs = int(rest['epochs'])
+    args = SimpleNamespace(unlearning_model='original', gnn='rgcn', dataset='WordNet18', checkpoint_dir=str(tmp_path / 'b'),
+                           in_dim=state['node_emb.weight'].shape[1], hidden_dim=state['conv1.root'].shape[1],
+                           out_dim=state['conv2.root'].shape[1], eval_on_cpu=False, epochs=epochs, valid_freq=epochs,
+                           lr=float(rest['lr']), num_steps=len(sets), num_edge_type=R_)
+    m = get_model(args, num_nodes=data['num_nodes'], num_edge_type=R_)
+    m.load_state_dict(state)
+    opt = torch.optim.Adam(m.parameters(), lr=args.lr)
+    tr = TK.KGTrainer(args)
+    torch.manual_seed(int(rest['seed']))
+    tr.train(m, Data(data), opt, args)
+    np.testing.assert_allclose([s_['train_loss'] for s_ in tr.trainer_log['steps']], rest['train_loss'], rtol=2e-4)
+    final = {k[len('final::'):]: v for k, v in fx.items() if k.startswith('final::')}
+    for k, v in m.state_dict().items():
+        assert rel_l2(v.cpu(), final[k]) < 2e-4, k
+    vals = [r for r in tr.trainer_log['log'] if 'val_dt_aup' in r]
+    assert abs(vals[-1]['val_dt_aup'] - float(rest['val_dt_aup'][-1])) < 2e-3

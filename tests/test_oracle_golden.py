@@ -330,3 +330,34 @@ def test_split_matches_reference(tag):
         # negatives: the reference's negative_sampling_kg continues the same RNG stream (test first, then val)
         assert torch.equal(R.negative_sampling_kg(out['test'], out['test_type']), t(fx[f'{tag}::test_neg']))
         assert torch.equal(R.negative_sampling_kg(out['val'], out['val_type']), t(fx[f'{tag}::val_neg']))
+
+
+def test_original_minibatch_training_matches_reference_loops():
+    """Trainer.train_minibatch (base.py:144-227) on the reference's own GCN and KGTrainer.train (base.py:394-493) on
+    its own RGCN (21 relation types), both on injected GraphSAINT batches."""
+    fx = load_golden('orig_minibatch_gcn.npz')
+    state, data, rest = split_fixture(fx)
+    w1, w2 = state['conv1.lin.weight'], state['conv2.lin.weight']
+    m = R.TwoLayer('gcn', w1.shape[1], w1.shape[0], w2.shape[0])
+    m.load_state_dict(state)
+    losses = R.original_minibatch(m, data, _fixture_lists(fx, 'batch', 'n_batches'), _fixture_lists(fx, 'negs', 'n_negs'),
+                                  int(rest['epochs']), float(rest['lr']))
+    np.testing.assert_allclose(losses, rest['train_loss'], rtol=2e-5)
+    final = {k[len('final::'):]: v for k, v in fx.items() if k.startswith('final::')}
+    for k, v in m.state_dict().items():
+        assert rel_l2(v, final[k]) < 1e-5, k
+
+    fx = load_golden('orig_kg_rgcn.npz')
+    state, data, rest = split_fixture(fx)
+    R_ = int(rest['num_edge_type'])
+    i, h, o = state['node_emb.weight'].shape[1], state['conv1.root'].shape[1], state['conv2.root'].shape[1]
+    m = R.TwoLayer('rgcn', i, h, o, num_nodes=data['num_nodes'], num_edge_type=R_)
+    m.load_state_dict(state)
+    torch.manual_seed(int(rest['seed']))
+    losses = R.kg_original_minibatch(m, data, _fixture_lists(fx, 'batch', 'n_batches'), R_, int(rest['epochs']), float(rest['lr']))
+    np.testing.assert_allclose(losses, rest['train_loss'], rtol=5e-5)
+    final = {k[len('final::'):]: v for k, v in fx.items() if k.startswith('final::')}
+    for k, v in m.state_dict().items():
+        assert rel_l2(v, final[k]) < 2e-5, k
+    ev = R.eval_kg(m, data, 'val', unlearning_model='original')
+    assert abs(ev['dt_aup'] - float(rest['val_dt_aup'][-1])) < 1e-6 and abs(ev['loss'] - float(rest['val_loss'][-1])) < 1e-4 * ev['loss']
