@@ -855,6 +855,10 @@ def golden_split():
 def golden_wide_trajectories(D, T, A):
     """train_fullbatch at the widths the fused HIP stages are built for (in 32 -> hidden 128 -> out 64), so that the
     reference-loop fixtures drive the MFMA row kernels and the fused loss / Del stages, not the generic fallbacks."""
+    # one thread: at these widths the host BLAS splits its reductions by thread count and timing, and the fixture
+    # would differ in the last bit from run to run
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
     for gnn, loss_type in [('gcn', 'both_all'), ('gat', 'both_layerwise')]:
         g = synth_graph(160, 700, 32, seed=25)
         d, neg = prepare_deletion(g, 20, seed=11)
@@ -888,6 +892,7 @@ def golden_wide_trajectories(D, T, A):
                    val_df_logit_mean=np.array([v['val_df_logit_mean'] for v in vals]),
                    lr=np.float64(args.lr), alpha=np.float64(args.alpha), epochs=np.int64(5), eval_seed=np.int64(84))
         np.savez_compressed(os.path.join(HERE, f'traj_wide_{gnn}_{loss_type}.npz'), **out)
+    torch.set_num_threads(threads)
 
 
 def golden_original_minibatch(B, A):
@@ -1153,6 +1158,9 @@ def main():
         golden_wide_trajectories(D, T, A)
         golden_original_minibatch(B, A)
         write_manifest(None)
+        return
+    if sys.argv[1:] == ['wide']:
+        golden_wide_trajectories(D, T, A)
         return
     if sys.argv[1:] == ['orig_minibatch']:
         golden_original_minibatch(B, A)
