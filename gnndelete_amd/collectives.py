@@ -70,6 +70,13 @@ def halo_plan(rowptr, col, n, rank, world, chunk, row_mask=None):
                     rows[recv_sel].contiguous(), [counts[rank][pp] for pp in range(world)], counts)
 
 
+def exchange_rows_reverse(send_buf, recv_buf, plan, world, group=None):
+    """The same exchange run backwards (gradient contributions for the rows a rank RECEIVED in the forward exchange
+    travel back to their owners): send_buf rows are ordered like plan.recv_rows, recv_buf like plan.send_rows."""
+    rev = HaloPlan(plan.recv_rows, plan.out_splits, plan.send_rows, plan.in_splits, plan.pair_counts)
+    exchange_rows(send_buf, recv_buf, rev, world, group)
+
+
 def exchange_rows(send_buf, recv_buf, plan, world, group=None):
     """recv_buf[:n_recv] <- all-to-all of send_buf[:n_send] along dim 0 with the plan's per-peer row counts.
     RCCL ("nccl") moves device buffers directly and any failure propagates - a silent detour through the host would

@@ -23,18 +23,21 @@ segments by the three collectives; the halo pack / unpack copies are part of the
   D  the --loss_type gradient bookkeeping (SURVEY F6) + Adam on both Del weights, identically on every rank;
      loss history, iteration counter.
 
-GCN, GIN and GraphSAGE backbones (GAT's message gradient needs the attention statistics of remote targets; not
-built).  The fused single-GPU configuration is required: folded DEC + NI terms, every loss row inside its Del row
+GCN, GIN, GraphSAGE and GAT backbones.  GAT keeps every softmax on the rank that owns the target row; its backward
+needs no second forward-direction exchange: a rank computes the attention gradients of its OWN target rows (it
+holds their halo h rows since the forward exchange), which yields partial message gradients for own AND halo source
+rows; the halo rows' partials travel back to their owners in the reverse all-to-all and are added there in rank
+order (deterministic).  The fused single-GPU configuration is required: folded DEC + NI terms, every loss row inside its Del row
 list (always so for the reference's masks), MFMA widths."""
 import torch
 import torch.distributed as dist
 
 from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
-from .collectives import all_reduce_sum, exchange_rows, halo_plan, row_blocks
+from .collectives import all_reduce_sum, exchange_rows, exchange_rows_reverse, halo_plan, row_blocks
 from .engine import LOSS_TYPES, _Adam, _LayerTerms, _loss_coefficients, _loss_slots, _rows_inside
 from .graph import SplitPlan, graph_for
-from .nn import GCNConv, GINConv, SAGEConv
+from .nn import GATConv, GCNConv, GINConv, SAGEConv
 
 
 class PartitionedNodeembEngine:
@@ -43,8 +46,8 @@ class PartitionedNodeembEngine:
                  reorder=True, group=None):
         assert loss_type in LOSS_TYPES, loss_type
         conv1, conv2 = model.conv1, model.conv2
-        if not isinstance(conv2, (GCNConv, GINConv, SAGEConv)):
-            raise NotImplementedError('PartitionedNodeembEngine supports GCN, GIN and GraphSAGE backbones')
+        if not isinstance(conv2, (GCNConv, GINConv, SAGEConv, GATConv)):
+            raise NotImplementedError('PartitionedNodeembEngine supports GCN, GIN, GraphSAGE and GAT backbones')
         dev = x.device
         if dev.type != 'cuda':
             raise _lib.GnnDeleteHipError('PartitionedNodeembEngine needs CUDA(HIP) tensors (no CPU fallback)')
@@ -70,7 +73,7 @@ class PartitionedNodeembEngine:
         self.hi = hi = min(n, lo + self.chunk)
         self.wd1, self.wd2 = model.deletion1.deletion_weight, model.deletion2.deletion_weight
         self.h, self.o = self.wd1.shape[0], self.wd2.shape[0]
-        self._mode = {GCNConv: 'gcn', GINConv: 'gin', SAGEConv: 'sage'}[type(conv2)]
+        self._mode = {GCNConv: 'gcn', GINConv: 'gin', SAGEConv: 'sage', GATConv: 'gat'}[type(conv2)]
         if self.h not in (32, 64, 128) or self.o not in (32, 64) or x.shape[1] % 32 or x.shape[1] * self.h * 4 > 65536:
             raise NotImplementedError('partitioned step: widths must suit the fused kernels (in % 32 == 0, hidden in '
                                       '{32, 64, 128}, out in {32, 64})')
@@ -113,7 +116,7 @@ class PartitionedNodeembEngine:
         self._coef1 = self.t1.coef if self.t1.n_rows else torch.zeros(1, **f32)
         self._coef2 = self.t2.coef if self.t2.n_rows else torch.zeros(1, **f32)
 
-        gmode = {'gcn': 'gcn', 'gin': 'sum', 'sage': 'mean'}[self._mode]
+        gmode = {'gcn': 'gcn', 'gin': 'sum', 'sage': 'mean', 'gat': 'gat'}[self._mode]
         self.graph = g = graph_for(edge_index, n, gmode)
         self.plan = SplitPlan(g.rowptr, row_range=(lo, hi))                    # forward aggregations: own rows
         self.plan_t = SplitPlan(g.rowptr_t, rows=self.idx1) if self.s1 else None   # transposed: own S1 rows only
@@ -122,8 +125,15 @@ class PartitionedNodeembEngine:
         own_mask[lo:hi] = True
         s1_mask = m1.clone()
         self.halo_f = halo_plan(g.rowptr, g.col, n, rank, world, self.chunk, None)
-        self.halo_b = halo_plan(g.rowptr_t, g.col_t, n, rank, world, self.chunk, s1_mask)
+        self.halo_b = halo_plan(g.rowptr_t, g.col_t, n, rank, world, self.chunk, s1_mask) if self._mode != 'gat' else None
         self.need1 = torch.unique(torch.cat([self.own.long(), self.halo_f.recv_rows])).to(torch.int32)
+        if self._mode == 'gat':
+            # transposed aggregation over own + halo SOURCE rows (partial message gradients from the own targets),
+            # and the buffers of the reverse exchange that carries the halo rows' partials home
+            self.plan_src = SplitPlan(g.rowptr_t, rows=self.need1)
+            self.rsend = torch.zeros(max(1, self.halo_f.n_recv), self.o, **f32)
+            self.rrecv = torch.zeros(max(1, self.halo_f.n_send), self.o, **f32)
+            self.halo_b = self.halo_f                       # (report only: the reverse exchange moves the same rows)
         self.send_f = torch.zeros(max(1, self.halo_f.n_send), self.o, **f32)
         self.recv_f = torch.zeros(max(1, self.halo_f.n_recv), self.o, **f32)
         self.send_b = torch.zeros(max(1, self.halo_b.n_send), self.o, **f32)
@@ -220,6 +230,11 @@ class PartitionedNodeembEngine:
                 ops.rows_gemm(self.x, self.need1, c1.nn.weight, trans_w=True, const_w=True, out=self.t1buf)
                 self._spmm(False, None, self.t1buf, self.pre1, c1.nn.bias, 1.0 + c1.eps)
             w2 = c2.nn.weight
+        elif self._mode == 'gat':
+            ops.rows_gemm(self.x, self.need1, c1.lin_src.weight, trans_w=True, const_w=True, out=self.t1buf)
+            a_s, a_d = ops.row_dots(self.t1buf, c1.att_src, c1.att_dst)
+            ops.gat_forward_raw(g, self.t1buf, a_s, a_d, c1.bias, c1.negative_slope, out=self.pre1, plan=self.plan)
+            w2 = c2.lin_src.weight
         else:
             ops.rows_gemm(self.x, self.need1, c1.lin_l.weight, trans_w=True, const_w=True, out=self.t1buf)
             ops.rows_gemm(self.x, self.own, c1.lin_r.weight, trans_w=True, const_w=True, out=self.t1rbuf)
@@ -252,6 +267,11 @@ class PartitionedNodeembEngine:
             self._spmm(False, g.val, self.t2buf, self.p2, c2.bias, 0.0)
         elif self._mode == 'gin':
             self._spmm(False, None, self.t2buf, self.p2, c2.nn.bias, 1.0 + c2.eps)
+        elif self._mode == 'gat':
+            a_s, a_d = ops.row_dots(self.t2buf, c2.att_src, c2.att_dst)          # own + halo rows hold h2
+            _, rowmax, rowsum = ops.gat_forward_raw(g, self.t2buf, a_s, a_d, c2.bias, c2.negative_slope, out=self.p2,
+                                                    plan=self.plan)
+            self._gat2 = (a_s, a_d, rowmax, rowsum)
         else:
             self._spmm(False, g.val, self.t2buf[:, :self.o], self.p2, c2.lin_l.bias, 1.0, x_self=self.t2buf[:, self.o:])
         if self.s2:
@@ -266,13 +286,44 @@ class PartitionedNodeembEngine:
         else:
             self._lp2.zero_()
             self.p_g2.zero_()
-        if self.needs_l2_to_w1 and self.halo_b.n_send:
+        if self.needs_l2_to_w1 and self._mode != 'gat' and self.halo_b.n_send:
             torch.index_select(self.dz2, 0, self.halo_b.send_rows, out=self.send_b)
+
+    def _seg_c_gat_edges(self):
+        """GAT only: attention gradients of the OWN target rows -> partial message gradients dt2 for own and halo
+        source rows (+ the rank-1 logit terms), halo rows packed for the reverse exchange."""
+        if not self.needs_l2_to_w1:
+            return
+        c2 = self.model.conv2
+        a_s, a_d, rowmax, rowsum = self._gat2
+        dt2, da_s, da_d = ops.gat_backward_raw(self.graph, self.t2buf, a_s, a_d, rowmax, rowsum, self.dz2, c2.negative_slope,
+                                               plan=self.plan, plan_t=self.plan_src)
+        rows = self.need1.long()
+        dt2[rows] += da_s[rows, None] * c2.att_src.detach().view(1, -1)
+        dt2[self.lo:self.hi] += da_d[self.lo:self.hi, None] * c2.att_dst.detach().view(1, -1)
+        self.dt2 = dt2
+        if self.halo_f.n_recv:
+            torch.index_select(dt2, 0, self.halo_f.recv_rows, out=self.rsend)
 
     def _seg_c(self):
         c2 = self.model.conv2
         g, lt = self.graph, self.loss_type
-        if self.needs_l2_to_w1:
+        if self.needs_l2_to_w1 and self._mode == 'gat':
+            # partial gradients of the rows this rank owns arrive grouped by sender: added in rank order
+            off = 0
+            for q, cnt in enumerate(self.halo_f.in_splits):
+                if cnt:
+                    self.dt2.index_add_(0, self.halo_f.send_rows[off:off + cnt], self.rrecv[off:off + cnt])
+                off += cnt
+            if self.s1:
+                ops.rows_gemm(self.dt2, self.idx1, c2.lin_src.weight, trans_w=False, out=self.dh, gate_bits=self.z1_pos)
+            if lt == 'both_all':
+                self._wgrad1_partial(True, self.dh)
+            elif lt == 'only2_all':
+                lp1 = self._lp1.clone()
+                self._wgrad1_partial(False, self.dh) if self.s1 else self.p_g1.zero_()
+                self._lp1.copy_(lp1)
+        elif self.needs_l2_to_w1:
             if self.halo_b.n_recv:
                 self.dz2.index_copy_(0, self.halo_b.recv_rows, self.recv_b)
             if self.s1:
@@ -313,16 +364,21 @@ class PartitionedNodeembEngine:
               'gd_loss_finalize_f32')
 
     def _segments(self):
+        if self._mode == 'gat':
+            return [self._seg_a, self._seg_b, self._seg_c_gat_edges, self._seg_c, self._seg_d]
         return [self._seg_a, self._seg_b, self._seg_c, self._seg_d]
 
     def _exchange(self, after_segment):
         if self.world == 1:
             return
+        gat = self._mode == 'gat'
         if after_segment == 0 and self.loss_type != 'only1':
             exchange_rows(self.send_f, self.recv_f, self.halo_f, self.world, self.group)
-        elif after_segment == 1 and self.needs_l2_to_w1:
+        elif after_segment == 1 and self.needs_l2_to_w1 and not gat:
             exchange_rows(self.send_b, self.recv_b, self.halo_b, self.world, self.group)
-        elif after_segment == 2:
+        elif after_segment == 2 and gat and self.needs_l2_to_w1:
+            exchange_rows_reverse(self.rsend, self.rrecv, self.halo_f, self.world, self.group)
+        elif after_segment == (3 if gat else 2):
             all_reduce_sum(self.pack, self.world, self.group)
 
     # ------------------------------------------------------------------ public

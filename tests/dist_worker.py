@@ -207,11 +207,12 @@ def gpu_checks(rank, world):
     from types import SimpleNamespace
     from gnndelete_amd.dist_engine import PartitionedNodeembEngine
     from gnndelete_amd.engine import NodeembEngine
-    from gnndelete_amd.framework.models import GCNDelete, GINDelete, SAGEDelete
+    from gnndelete_amd.framework.models import GATDelete, GCNDelete, GINDelete, SAGEDelete
     dev = torch.device('cuda', 0)
     data, neg, ni1, ni2, (f, h, o) = small_request(n=6000, m=30000, f=32, h=128, o=64)
     cases = [(GCNDelete, 'both_layerwise'), (GINDelete, 'both_all'), (GCNDelete, 'only2_all'), (SAGEDelete, 'both_layerwise'),
-             (SAGEDelete, 'both_all'), (GCNDelete, 'only1'), (GINDelete, 'only2_layerwise')]
+             (SAGEDelete, 'both_all'), (GCNDelete, 'only1'), (GINDelete, 'only2_layerwise'), (GATDelete, 'both_layerwise'),
+             (GATDelete, 'both_all')]
     for cls, lt in cases:
         results = []
         for partitioned in (False, True):

@@ -28,7 +28,7 @@ def test_partitioned_step_algebra_and_collectives_over_gloo(world):
 @pytest.mark.parametrize('world', [2, 3])
 def test_partitioned_engine_matches_single_gpu_engine(world):
     """Ranks sharing cuda:0 over gloo (the box has one GPU): the real partitioned HIP engine (fused stages, halo
-    exchanges packed / unpacked inside the hipGraph segments) vs the single-GPU engine, GCN / GIN / GraphSAGE, every
+    exchanges packed / unpacked inside the hipGraph segments) vs the single-GPU engine, GCN / GIN / GraphSAGE / GAT, every
     --loss_type."""
     out = launch('gpu', world, timeout=900)
-    assert out.count('partitioned == single') == 7
+    assert out.count('partitioned == single') == 9
