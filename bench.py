@@ -438,9 +438,9 @@ def post_delete_parity(args, data, model, state, neg, ni1, ni2, device, cpu_mode
 
 def recorded_traffic(n, nnz, d):
     """HBM bytes per launch of the dominant kernel from the committed PMC run (separate rocprofv3
-    --pmc passes, gfx950 correction applied: profiles/r02_a_spmm_traffic.json); None when the
+    --pmc passes, gfx950 correction applied: profiles/r02_d_spmm_traffic.json); None when the
     workload differs from the one that was profiled."""
-    path = os.path.join(ROOT, 'profiles', 'r02_a_spmm_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r02_d_spmm_traffic.json')
     try:
         with open(path) as f:
             rec = json.load(f)
@@ -600,7 +600,7 @@ def main():
                          # the recorded L2-miss (fabric) bytes over this run's launch duration: how close the kernel
                          # runs to the ~6.3 TB/s a streaming copy achieves on this part (MI355X_MICROARCH.md)
                          'traffic_gbs': traffic / kdur / 1e9 if traffic else None,
-                         'traffic_unit': 'bytes/launch (PMC, profiles/r02_a_spmm_traffic.json)', 'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6},
+                         'traffic_unit': 'bytes/launch (PMC, profiles/r02_d_spmm_traffic.json)', 'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6},
             'final_loss': float(losses[-1, 0]) if len(losses) else None,
         }
         if note:

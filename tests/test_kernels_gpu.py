@@ -750,10 +750,11 @@ def test_loss_zoo_on_the_device_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize('m,k,n', [(300, 1639, 128), (1000, 96, 64), (77, 8710, 128), (2500, 333, 96), (64, 32, 32),
-                                   (5000, 1664, 64)])
+                                   (5000, 1664, 64), (3000, 1433, 128), (17716, 1639, 128), (20000, 224, 64)])
 def test_gemm_wide_matches_fp64(m, k, n):
-    """gd_gemm_f32 (K-tiled MFMA GEMM, W streamed through LDS in 32-row chunks, deterministic split-K): any reduction
-    width (zero-padded to 32), every supported output width, with bias, on all rows and on a gathered row subset."""
+    """gd_gemm_f32 (K-tiled MFMA GEMM, W streamed through LDS in 32-row chunks, equal unit ranges per block whose
+    pieces are added in k order): any reduction width (zero-padded to 32), every supported output width, with bias, on
+    all rows and on a gathered row subset; ranges inside one row group, across groups, and whole groups per block."""
     from gnndelete_amd import ops
     g = torch.Generator().manual_seed(m + k)
     x = torch.randn(m, k, generator=g)
@@ -762,7 +763,7 @@ def test_gemm_wide_matches_fp64(m, k, n):
     want = x.double() @ w.double() + b.double()
     got = ops.gemm_wide(x.cuda(), w.cuda(), b.cuda())
     assert rel_l2(got.cpu(), want) < TOL
-    assert torch.equal(got, ops.gemm_wide(x.cuda(), w.cuda(), b.cuda()))          # split-K partials added in fixed order
+    assert torch.equal(got, ops.gemm_wide(x.cuda(), w.cuda(), b.cuda()))          # pieces added in fixed order
     idx = torch.randperm(m, generator=g)[:max(1, m // 3)].sort().values.to(torch.int32)
     out = torch.full((m, n), -7.0).cuda()
     ops.gemm_wide(x.cuda(), w.cuda(), None, idx=idx.cuda(), out=out)
