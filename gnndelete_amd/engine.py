@@ -301,6 +301,11 @@ class NodeembEngine:
             self.graph = None
             self._hbuf = torch.zeros(n, self.h, **f32)                # relu(z1) as the typed conv reads it
             self._dxbuf = torch.zeros(n, self.h, **f32)               # conv2's input gradient
+            # tile plans and packed relation weights are made here, outside any graph capture
+            for c_, din, dout, tr in ((conv1, self.x.shape[1], self.h, 0), (conv2, self.h, self.o, 0), (conv2, self.o, self.h, 1)):
+                if int(_lib.lib().gd_rgcn_tile_kl(din, dout, c_.num_blocks or 1, tr)) > 0 and os.environ.get('GD_RGCN_NODE_MAJOR') != '1':
+                    self.typed.tile_plan(bool(tr))
+                    ops.rgcn_packed_weight(c_.weight.detach(), c_.num_blocks or 1, din, dout, tr)
         else:
             gmode = {'gcn': 'gcn', 'gin': 'sum', 'gat': 'gat', 'sage': 'mean'}[self._mode]
             self.graph = graph_for(edge_index, n, gmode)
@@ -446,12 +451,7 @@ class NodeembEngine:
         tg = self.typed
         nb = conv.num_blocks or 1
         ops.rows_gemm(inp, None, conv.root.detach(), trans_w=bool(trans), bias=None if trans else conv.bias.detach(), out=out)
-        node_ptr, seg_ptr, seg_rel, col, w = tg.bwd if trans else tg.fwd
-        if col.numel():
-            weight = conv.weight.detach().contiguous()
-            check(_lib.lib().gd_rgcn_conv_f32(ptr(node_ptr), ptr(seg_ptr), ptr(seg_rel), ptr(col), ptr(w), ptr(inp),
-                                              inp.stride(0), inp.shape[1], ptr(weight), nb, int(trans), ptr(out), out.stride(0),
-                                              out.shape[1], tg.n, stream_ptr(inp.device)), 'gd_rgcn_conv_f32')
+        ops.rgcn_typed_accumulate(tg, inp, conv.weight.detach(), nb, int(trans), out)
 
     def _conv2_forward(self):
         c = self.model.conv2

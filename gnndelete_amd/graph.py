@@ -303,6 +303,62 @@ class TypedNodeCSR:
         order_b = torch.argsort(run_b * n + dst)
         self.bwd, _ = self._runs(run_b[order_b], dst[order_b], r, n, w_edge[order_b])
 
+    def tile_plan(self, trans=False):
+        """The (64-node tile, relation) regrouping gd_rgcn_tile_conv_f32 walks (include/gnndelete_hip.h): runs cut into
+        pieces of <= 16 edges, piece k of a run in pass k; steps = distinct (tile, relation, pass); edges re-sorted into
+        (step, row, source) order.  Built once per direction with sorts / uniques on the device."""
+        key = 'bwd' if trans else 'fwd'
+        cache = self.__dict__.setdefault('_tile_plans', {})
+        if key not in cache:
+            cache[key] = self._build_tile_plan(self.bwd if trans else self.fwd, self.n, self.num_relations)
+        return cache[key]
+
+    @staticmethod
+    def _build_tile_plan(arrays, n, r, cap=16, tile=64):
+        node_ptr, seg_ptr, seg_rel, col, w = arrays
+        dev = col.device
+        n_tiles = (n + tile - 1) // tile
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        e = int(col.numel())
+        if e == 0:
+            z = torch.zeros(1, dtype=torch.int32, device=dev)
+            return dict(n_tiles=n_tiles, tile_order=i32(torch.arange(n_tiles, device=dev)),
+                        tile_step_ptr=torch.zeros(n_tiles + 1, dtype=torch.int32, device=dev), step_rel=z, step_piece_ptr=z,
+                        step_mask=torch.zeros(1, dtype=torch.int64, device=dev), piece=torch.zeros(1, 2, dtype=torch.int32, device=dev),
+                        col=z, w=torch.zeros(1, dtype=torch.float32, device=dev), n_steps=0, n_pieces=0)
+        seg_len = (seg_ptr[1:] - seg_ptr[:-1]).long()
+        n_runs = int(seg_len.numel())
+        run_of_edge = torch.repeat_interleave(torch.arange(n_runs, device=dev), seg_len)
+        runs_per_node = (node_ptr[1:] - node_ptr[:-1]).long()
+        node_of_run = torch.repeat_interleave(torch.arange(n, device=dev), runs_per_node)
+        pos = torch.arange(e, device=dev) - seg_ptr.long()[run_of_edge]
+        passes = int((int(seg_len.max()) + cap - 1) // cap)
+        node = node_of_run[run_of_edge]
+        rel = seg_rel.long()[run_of_edge]
+        pkey = (((node // tile) * r + rel) * passes + pos // cap) * tile + node % tile     # (tile, rel, pass, row)
+        order = torch.argsort(pkey, stable=True)
+        pk_sorted = pkey[order]
+        piece_key, piece_len = torch.unique_consecutive(pk_sorted, return_counts=True)
+        piece_e0 = torch.cumsum(piece_len, 0) - piece_len
+        piece_row = piece_key % tile
+        skey = piece_key // tile
+        step_key, step_np = torch.unique_consecutive(skey, return_counts=True)
+        n_steps = int(step_key.numel())
+        step_piece_ptr = torch.zeros(n_steps + 1, dtype=torch.int64, device=dev)
+        step_piece_ptr[1:] = torch.cumsum(step_np, 0)
+        step_of_piece = torch.repeat_interleave(torch.arange(n_steps, device=dev), step_np)
+        step_mask = torch.zeros(n_steps, dtype=torch.int64, device=dev)
+        step_mask.scatter_add_(0, step_of_piece, torch.ones_like(piece_row) << piece_row)     # distinct rows: no carries
+        step_tile = step_key // (passes * r)
+        steps_per_tile = torch.bincount(step_tile, minlength=n_tiles)
+        tile_step_ptr = torch.zeros(n_tiles + 1, dtype=torch.int64, device=dev)
+        tile_step_ptr[1:] = torch.cumsum(steps_per_tile, 0)
+        piece = torch.stack([piece_e0, piece_row | (piece_len << 8)], 1)
+        return dict(n_tiles=n_tiles, tile_order=i32(torch.argsort(steps_per_tile, descending=True, stable=True)),
+                    tile_step_ptr=i32(tile_step_ptr), step_rel=i32((step_key // passes) % r), step_piece_ptr=i32(step_piece_ptr),
+                    step_mask=step_mask.contiguous(), piece=i32(piece), col=col[order].contiguous(), w=w[order].contiguous(),
+                    n_steps=n_steps, n_pieces=int(piece_key.numel()))
+
     @staticmethod
     def _runs(run_sorted, col_sorted, r, n, w):
         dev = run_sorted.device

@@ -2,6 +2,8 @@
 
 PyTorch only owns memory, streams and the autograd tape here; all arithmetic on the hot path is
 the HIP library's.  Every wrapper raises when handed CPU tensors - there is no fallback."""
+import os
+
 import torch
 
 from . import _lib
@@ -506,6 +508,57 @@ def rgcn_mean(x, typed, num_rel, n):
     return _RgcnMean.apply(x, typed, num_rel, n)
 
 
+_RGCN_PACK_CACHE = {}
+
+
+def rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans):
+    """The relation weights [R, n_blocks, ib, ob] in the MFMA lane order of gd_rgcn_tile_conv_f32 for one direction,
+    cached per (storage, shape, version): a frozen backbone packs once, an updated weight repacks."""
+    kl = int(_lib.lib().gd_rgcn_tile_kl(d_in, d_out, n_blocks, int(trans)))
+    assert kl > 0
+    key = (weight.data_ptr(), tuple(weight.shape), weight._version, int(trans))
+    hit = _RGCN_PACK_CACHE.get(key)
+    if hit is None:
+        if len(_RGCN_PACK_CACHE) >= 16:
+            _RGCN_PACK_CACHE.clear()
+        wc = weight.detach().contiguous()
+        packed = torch.empty(wc.shape[0] * 4 * (kl // 8) * 256, dtype=torch.float32, device=wc.device)
+        check(_lib.lib().gd_rgcn_pack_weight_f32(ptr(wc), wc.shape[0], n_blocks, d_in, d_out, int(trans), ptr(packed),
+                                                 stream_ptr(wc.device)), 'gd_rgcn_pack_weight_f32')
+        hit = (packed, weight)
+        _RGCN_PACK_CACHE[key] = hit
+    return hit[0]
+
+
+def rgcn_typed_accumulate(tg, x, weight, n_blocks, trans, y, edge_w=None):
+    """y += sum_r (weighted mean over the relation-r in-edges of x) @ W_r (trans: the input gradient on the transposed
+    graph with W_r^T) - raw, no autograd.  The (tile, relation) kernel where the widths allow, the node-major one
+    otherwise or when GD_RGCN_NODE_MAJOR=1; edge_w (per edge of tg.fwd, in its order) replaces the mean weights."""
+    d_in, d_out = x.shape[1], y.shape[1]
+    arrays = tg.bwd if trans else tg.fwd
+    if arrays[3].numel() == 0:
+        return y
+    tiled = (edge_w is None and x.stride(0) % 4 == 0 and y.stride(0) % 4 == 0 and os.environ.get('GD_RGCN_NODE_MAJOR') != '1'
+             and int(_lib.lib().gd_rgcn_tile_kl(d_in, d_out, n_blocks, int(trans))) > 0)
+    if tiled:
+        p = tg.tile_plan(bool(trans))
+        packed = rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans)
+        check(_lib.lib().gd_rgcn_tile_conv_f32(ptr(p['tile_order']), ptr(p['tile_step_ptr']), ptr(p['step_rel']),
+                                               ptr(p['step_piece_ptr']), ptr(p['step_mask']), ptr(p['piece']), ptr(p['col']),
+                                               ptr(p['w']), p['n_tiles'], ptr(x), x.stride(0), d_in, ptr(packed), n_blocks,
+                                               int(trans), ptr(y), y.stride(0), d_out, tg.n, stream_ptr(x.device)),
+              'gd_rgcn_tile_conv_f32')
+        return y
+    node_ptr, seg_ptr, seg_rel, col, w = arrays
+    if edge_w is not None:
+        w = edge_w
+    weight = weight.detach().contiguous()
+    check(_lib.lib().gd_rgcn_conv_f32(ptr(node_ptr), ptr(seg_ptr), ptr(seg_rel), ptr(col), ptr(w), ptr(x), x.stride(0), d_in,
+                                      ptr(weight), n_blocks, int(trans), ptr(y), y.stride(0), d_out, tg.n,
+                                      stream_ptr(x.device)), 'gd_rgcn_conv_f32')
+    return y
+
+
 class _RgcnConvFrozen(torch.autograd.Function):
     """y = sum_r mean_{j in N_r(i)} x_j W_r + x_i root + bias with CONSTANT relation weights (frozen
     backbone / evaluation): gd_rgcn_conv_f32 forms no [R, n, d] tensor; backward = input gradient only."""
@@ -517,11 +570,7 @@ class _RgcnConvFrozen(torch.autograd.Function):
         # root is [in, out]: the row kernel takes it as is (any widths up to 1024: MFMA where they allow)
         y = rows_gemm(x, None, root.detach(), trans_w=False, bias=bias.detach() if bias is not None else None) \
             if x.shape[1] <= 1024 else (torch.addmm(bias.detach(), x, root.detach()) if bias is not None else x @ root.detach())
-        node_ptr, seg_ptr, seg_rel, col, w = tg.fwd
-        if col.numel():
-            check(_lib.lib().gd_rgcn_conv_f32(ptr(node_ptr), ptr(seg_ptr), ptr(seg_rel), ptr(col), ptr(w), ptr(x),
-                                              x.stride(0), x.shape[1], ptr(weight), n_blocks, 0, ptr(y), y.stride(0),
-                                              y.shape[1], tg.n, stream_ptr(x.device)), 'gd_rgcn_conv_f32')
+        rgcn_typed_accumulate(tg, x, weight, n_blocks, 0, y)
         ctx.tg, ctx.n_blocks = tg, n_blocks
         ctx.save_for_backward(weight, root.detach())
         return y
@@ -531,12 +580,7 @@ class _RgcnConvFrozen(torch.autograd.Function):
         weight, root = ctx.saved_tensors
         dy = _f32_rows(dy)
         dx = rows_gemm(dy, None, root, trans_w=True) if dy.shape[1] <= 1024 else dy @ root.t()
-        node_ptr, seg_ptr, seg_rel, col, w = ctx.tg.bwd
-        if col.numel():
-            check(_lib.lib().gd_rgcn_conv_f32(ptr(node_ptr), ptr(seg_ptr), ptr(seg_rel), ptr(col), ptr(w), ptr(dy),
-                                              dy.stride(0), dy.shape[1], ptr(weight), ctx.n_blocks, 1, ptr(dx),
-                                              dx.stride(0), dx.shape[1], ctx.tg.n, stream_ptr(dy.device)),
-                  'gd_rgcn_conv_f32')
+        rgcn_typed_accumulate(ctx.tg, dy, weight, ctx.n_blocks, 1, dx)
         return dx, None, None, None, None, None
 
 

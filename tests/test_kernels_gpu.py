@@ -507,6 +507,51 @@ def test_rgcn_conv_fused_matches_oracle(n, m, R, din, dout, nb):
     assert rel_l2(xg.grad.cpu(), xr.grad) < TOL
 
 
+@pytest.mark.parametrize('n,m,R,din,dout,nb', [(200, 20000, 7, 128, 128, 4), (1000, 30000, 102, 128, 64, 4), (130, 9000, 5, 64, 64, 4),
+                                               (257, 5000, 9, 128, 128, None), (64, 4000, 3, 64, 128, None), (500, 100, 4, 128, 64, None)])
+def test_rgcn_tile_conv_matches_oracle_and_node_major(n, m, R, din, dout, nb, monkeypatch):
+    """gd_rgcn_tile_conv_f32 ((64-node tile, relation) steps, accumulators in MFMA registers): forward and input
+    gradient against the float64 oracle and against the node-major kernel; hub runs far beyond one 16-edge piece
+    (several passes of one relation), relations that occur in no tile, a last tile with fewer than 64 nodes, dense
+    and 4-block weights, every supported width pair; bit-reproducible."""
+    from gnndelete_amd import _lib, ops
+    from gnndelete_amd.graph import TypedNodeCSR
+    from oracle import pyg_semantics as pyg
+    g = torch.Generator().manual_seed(n + m + R)
+    ei = torch.randint(0, n, (2, m), generator=g)
+    et = torch.randint(0, max(1, R - 1), (m,), generator=g)
+    ei[1, :m // 5] = 5                                     # a hub: one node with m / 5 in-edges ...
+    et[:m // 10] = 2 % R                                   # ... half of them of one relation
+    ei[0, m // 5:m // 4] = 9                               # and a hub source (long runs in the transposed graph)
+    x = torch.randn(n, din, generator=g, dtype=torch.float64)
+    w = torch.randn((R, din, dout) if nb is None else (R, nb, din // nb, dout // nb), generator=g, dtype=torch.float64) * 0.2
+    root = torch.randn(din, dout, generator=g, dtype=torch.float64) * 0.2
+    bias = torch.randn(dout, generator=g, dtype=torch.float64)
+    up = torch.randn(n, dout, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    want = pyg.rgcn_conv(xr, ei, et, w, root, bias, nb)
+    want.backward(up)
+    nbk = 1 if nb is None else nb
+    assert _lib.lib().gd_rgcn_tile_kl(din, dout, nbk, 0) > 0 and _lib.lib().gd_rgcn_tile_kl(dout, din, nbk, 1) > 0
+    tg = TypedNodeCSR(ei.cuda(), et.cuda(), n, R)
+    plan = tg.tile_plan(False)
+    assert plan['n_pieces'] >= plan['n_steps'] > 0 and int(plan['piece'][:, 1].max()) >> 8 <= 16
+
+    def run():
+        xg = x.float().cuda().requires_grad_(True)
+        got = ops.rgcn_conv_frozen(xg, tg, w.float().cuda(), root.float().cuda(), bias.float().cuda(), nbk)
+        got.backward(up.float().cuda())
+        return got.detach(), xg.grad
+    got, dx = run()
+    assert rel_l2(got.cpu(), want.detach()) < TOL
+    assert rel_l2(dx.cpu(), xr.grad) < TOL
+    got2, dx2 = run()
+    assert torch.equal(got, got2) and torch.equal(dx, dx2)
+    monkeypatch.setenv('GD_RGCN_NODE_MAJOR', '1')
+    ref, dref = run()
+    assert rel_l2(got.cpu(), ref.cpu()) < 1e-5 and rel_l2(dx.cpu(), dref.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize('n,d,frac,loss_frac', [(500, 64, 0.6, 0.8), (300, 32, 1.0, 1.0), (4000, 64, 0.9, 0.5), (70, 64, 0.3, 0.0)])
 def test_del_loss_bwd_fused_matches_separate_steps(n, d, frac, loss_frac):
     """Fused last-layer kernel (Del forward + folded MSE terms + Del input gradient) vs the same three steps in
