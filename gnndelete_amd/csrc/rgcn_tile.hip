@@ -20,8 +20,13 @@
 //            fills half of the MFMA's output rows), pre-packed in the lane order of the MFMA A operand
 //            (gd_rgcn_pack_weight_f32: one coalesced 16-byte load per 4 k).
 //
+// Hubs: "one piece per node and step" serialises a node whose runs hold thousands of edges (ogbl-biokg's largest
+// entity: 10,423 in-edges, 1,895 of one relation = 119 passes).  The plan spreads such a node over up to 64 SLICE rows
+// of extra tiles (piece k of a run -> slice k mod V); a slice row is an ordinary row to this kernel except that its
+// outputs go to y_ext, and rgcn_hub_fixup_kernel adds a hub's slices to its row of y in slice order (deterministic).
+//
 // The A tile is double buffered: while MFMA(s) reads one buffer the same waves gather step s + 1 into the other -
-// one barrier per step; piece descriptors are fetched two steps ahead and edge (col, w) one step ahead, so a step's
+// one barrier per step; piece descriptors are fetched six steps ahead and edge (col, w) four steps ahead, so a step's
 // critical path is one memory round trip (the neighbour rows).  Padding rows without a run to zero costs matrix
 // work (a node holds 36 of the 102 relations: 35 % of the rows are live) - which is what keeps the accumulators in
 // registers: 78 GF per launch at biokg size, < 1 ms on the matrix cores, against 4.3 GB of gathered rows.
@@ -30,17 +35,25 @@
 namespace gd {
 
 using f32x16t = __attribute__((ext_vector_type(16))) float;
+constexpr int kRing = 256;                              // steps in the LDS ring (power of two)
+constexpr int kRingBytes = kRing * 16;
 
 template <int DIN, int OW, int KL>
 __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
     const int32_t* __restrict__ tile_order, const int32_t* __restrict__ tile_step_ptr, const int32_t* __restrict__ step_rel,
     const int32_t* __restrict__ step_piece_ptr, const uint64_t* __restrict__ step_mask, const int2* __restrict__ piece,
     const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ x, int64_t ldx,
-    const float* __restrict__ wpk, int32_t k0_stride, float* __restrict__ y, int64_t ldy, int32_t n_nodes) {
+    const float* __restrict__ wpk, int32_t k0_stride, float* __restrict__ y, int64_t ldy, int32_t n_nodes,
+    float* __restrict__ y_ext, int32_t n_pad) {
   constexpr int NW = 8, NT = NW * 64, PITCH = DIN + 4, LPR = DIN / 4, GPW = 64 / LPR, NG = NW * GPW, MAXR = 64 / NG;
   constexpr int J8 = KL / 8;
-  extern __shared__ __attribute__((aligned(16))) float a_lds_raw[];   // two A tiles of 64 rows x PITCH floats
+  extern __shared__ __attribute__((aligned(16))) float a_lds_raw[];   // two A tiles of 64 rows x PITCH floats + the step ring
   auto a_lds = [&](int b) -> float* { return a_lds_raw + b * (64 * PITCH); };
+  // per-step scalars (relation, first piece, row mask) of the next >= 128 steps: a ring in LDS refilled every 64 steps, so
+  // that no iteration waits for a scalar load from memory (three dependent ones per step otherwise: 0.7 of 1.5 ms)
+  uint64_t* const m_mask = reinterpret_cast<uint64_t*>(a_lds_raw + 2 * 64 * PITCH);
+  int32_t* const m_rel = reinterpret_cast<int32_t*>(m_mask + kRing);
+  int32_t* const m_pp = m_rel + kRing;
   const int tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
   const int s0 = tile_step_ptr[tile], s1 = tile_step_ptr[tile + 1];
   if (s0 == s1) return;
@@ -49,49 +62,75 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
   const int grp = wave * GPW + lane / LPR, gl = lane % LPR;
 
   for (int i = tid; i < 2 * 64 * PITCH / 4; i += NT) reinterpret_cast<float4*>(a_lds_raw)[i] = f4_zero();
+  auto ring_fill = [&](int first, int count) {            // steps [first, first + count) (+ the piece pointer one past the end)
+    for (int i = tid; i < count; i += NT) {
+      const int s = first + i;
+      if (s <= s1) {
+        m_pp[(s - s0) & (kRing - 1)] = step_piece_ptr[s];
+        if (s < s1) { m_rel[(s - s0) & (kRing - 1)] = step_rel[s]; m_mask[(s - s0) & (kRing - 1)] = step_mask[s]; }
+      }
+    }
+  };
+  ring_fill(s0, 192);
+  __syncthreads();
 
-  auto load_desc = [&](int s, int2* d) {
-    int p0 = 0, p1 = 0;
-    if (s < s1) { p0 = step_piece_ptr[s]; p1 = step_piece_ptr[s + 1]; }
-#pragma unroll
-    for (int j = 0; j < MAXR; ++j) {
-      const int pi = p0 + grp + NG * j;
-      d[j] = pi < p1 ? piece[pi] : make_int2(0, 0);
+  // Plan data per wave and step, one element per lane: the wave takes the pieces wave, wave + 8, wave + 16 ... of a step
+  // (8 at most: 64 rows); lane i < 8 holds the descriptor of its i-th piece, lane 8 i + t the edges t and t + 8 of that
+  // piece.  6 + 4 registers keep descriptors six and edges four steps ahead: the plan is a stream that is touched once
+  // (an HBM round trip per load), and with one-step prefetch that round trip was the iteration time (0.7 of 1.5 ms).
+  struct Cw { int ca, cb; float wa, wb; };
+  auto load_desc = [&](int s) -> int2 {
+    int2 d = make_int2(0, 0);
+    if (s < s1 && lane < 8) {
+      const int p0 = m_pp[(s - s0) & (kRing - 1)], p1 = m_pp[(s + 1 - s0) & (kRing - 1)];
+      const int pi = p0 + wave + 8 * lane;
+      if (pi < p1) d = piece[pi];
     }
+    return d;
   };
-  auto load_cw = [&](const int2* d, int* c, float* ww) {
-#pragma unroll
-    for (int j = 0; j < MAXR; ++j) {
-      const bool ok = gl < (d[j].y >> 8);
-      c[j] = ok ? col[d[j].x + gl] : 0;
-      ww[j] = ok ? w[d[j].x + gl] : 0.f;
-    }
+  auto load_cw = [&](int2 d) -> Cw {
+    const int e0 = __shfl(d.x, lane >> 3), len = __shfl(d.y, lane >> 3) >> 8, t = lane & 7;
+    Cw r = {0, 0, 0.f, 0.f};
+    if (t < len) { r.ca = col[e0 + t]; r.wa = w[e0 + t]; }
+    if (t + 8 < len) { r.cb = col[e0 + 8 + t]; r.wb = w[e0 + 8 + t]; }
+    return r;
   };
-  // weighted sums of step s's runs -> buf (rows of `dirty` that this step leaves empty are cleared)
-  auto gather = [&](int s, const int2* d, const int* c, const float* ww, float* buf, uint64_t dirty) -> uint64_t {
-    const uint64_t mask = step_mask[s];
+  // weighted sums of step s's runs -> buf (rows of `dirty` that this step leaves empty are cleared).  Round j: lane
+  // group g of the wave sums the wave's piece GPW j + g.  Every cross-lane read sits in wave-uniform control flow
+  // (ds_bpermute returns 0 for a source lane that is masked off).
+  auto gather = [&](int s, int2 d, Cw cw, float* buf, uint64_t dirty) -> uint64_t {
+    const uint64_t mask = m_mask[(s - s0) & (kRing - 1)];
     const uint64_t zm = dirty & ~mask;
 #pragma unroll
     for (int j = 0; j < MAXR; ++j)
       if ((zm >> (grp + NG * j)) & 1) *reinterpret_cast<float4*>(buf + (grp + NG * j) * PITCH + 4 * gl) = f4_zero();
+    const int g_in_wave = lane / LPR;
 #pragma unroll
     for (int j = 0; j < MAXR; ++j) {
-      const int len = d[j].y >> 8, row = d[j].y & 255;
-      if (len == 0) continue;
+      int rl = 0, kmax = 0;
+#pragma unroll
+      for (int g = 0; g < GPW; ++g) {
+        const int v = __builtin_amdgcn_readlane(d.y, GPW * j + g);
+        kmax = max(kmax, v >> 8);
+        rl = g_in_wave == g ? v : rl;
+      }
+      if (kmax == 0) continue;
+      const int len = rl >> 8, row = rl & 255, src0 = 8 * (GPW * j + g_in_wave);
       float4 acc = f4_zero();
-      for (int k = 0; k < len; k += 4) {
+      for (int k = 0; k < kmax; k += 4) {
         float4 v[4];
         float we[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int cc = __shfl(c[j], k + u, LPR);
-          we[u] = __shfl(ww[j], k + u, LPR);
+          const int src = src0 + ((k + u) & 7);
+          const int cc = k < 8 ? __shfl(cw.ca, src) : __shfl(cw.cb, src);
+          we[u] = k < 8 ? __shfl(cw.wa, src) : __shfl(cw.wb, src);
           v[u] = k + u < len ? *reinterpret_cast<const float4*>(x + (int64_t)cc * ldx + 4 * gl) : f4_zero();
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc = f4_fma(we[u], v[u], acc);
       }
-      *reinterpret_cast<float4*>(buf + row * PITCH + 4 * gl) = acc;
+      if (len > 0) *reinterpret_cast<float4*>(buf + row * PITCH + 4 * gl) = acc;
     }
     return mask;
   };
@@ -100,34 +139,39 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  int2 d0[MAXR], d1[MAXR], d2[MAXR];
-  int c0[MAXR], c1[MAXR];
-  float w0[MAXR], w1[MAXR];
-  load_desc(s0, d0);
-  load_desc(s0 + 1, d1);
-  load_cw(d0, c0, w0);
-  __syncthreads();                                        // zero fill done
+  constexpr int DQ = 6, CQ = 4;                           // descriptors of steps s+1 .. s+6, edges of steps s+1 .. s+4
+  int2 dq[DQ];
+  Cw cq[CQ];
+#pragma unroll
+  for (int i = 0; i < DQ; ++i) dq[i] = load_desc(s0 + i);
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) cq[i] = load_cw(dq[i]);
   uint64_t dirty[2] = {0, 0};
-  dirty[0] = gather(s0, d0, c0, w0, a_lds(0), 0);
-  load_cw(d1, c1, w1);
-  load_desc(s0 + 2, d2);
+  dirty[0] = gather(s0, dq[0], cq[0], a_lds(0), 0);
+  auto advance = [&](int s_new_desc) {                    // queues move up one step; issue the loads that refill them
+#pragma unroll
+    for (int i = 0; i + 1 < DQ; ++i) dq[i] = dq[i + 1];
+#pragma unroll
+    for (int i = 0; i + 1 < CQ; ++i) cq[i] = cq[i + 1];
+    cq[CQ - 1] = load_cw(dq[CQ - 1]);
+    dq[DQ - 1] = load_desc(s_new_desc);
+  };
+  advance(s0 + DQ);
   __syncthreads();
   int cur = 0;
   for (int s = s0; s < s1; ++s) {
     // this step's weight slice (arrives behind the gathers of the next step)
     constexpr bool kPrefetchW = J8 <= 4;                 // a dense 128-wide slice (64 registers) is read in the loop instead
-    const float4* wp = reinterpret_cast<const float4*>(wpk) + ((int64_t)(step_rel[s] * 4 + ot) * J8) * 64 + lane;
+    const float4* wp = reinterpret_cast<const float4*>(wpk) + ((int64_t)(m_rel[(s - s0) & (kRing - 1)] * 4 + ot) * J8) * 64 + lane;
     float4 wv[kPrefetchW ? J8 : 1];
     if (kPrefetchW) {
 #pragma unroll
       for (int jj = 0; jj < J8; ++jj) wv[jj] = wp[jj * 64];
     }
     if (s + 1 < s1) {
-#pragma unroll
-      for (int j = 0; j < MAXR; ++j) { d0[j] = d1[j]; c0[j] = c1[j]; w0[j] = w1[j]; d1[j] = d2[j]; }
-      load_cw(d1, c1, w1);                                // edges of step s + 2
-      load_desc(s + 3, d2);
-      dirty[cur ^ 1] = gather(s + 1, d0, c0, w0, a_lds(cur ^ 1), dirty[cur ^ 1]);
+      dirty[cur ^ 1] = gather(s + 1, dq[0], cq[0], a_lds(cur ^ 1), dirty[cur ^ 1]);
+      // refills go out AFTER the row gathers: loads return in order, a wait for the rows would wait for these too
+      advance(s + 1 + DQ);
     }
     const float* bsrc = a_lds(cur) + (rt * 32 + n_lo) * PITCH + ot * k0_stride + 4 * khalf;
 #pragma unroll
@@ -141,6 +185,7 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
     }
     __syncthreads();
     cur ^= 1;
+    if (((s + 1 - s0) & 63) == 0) ring_fill(s + 1 + 128, 64);   // slots of steps every wave has left behind
   }
   // D[i][j]: j = lane & 31 = node, output OW ot + 8 q + 4 khalf + c in acc[4 q + c] (rows >= OW are padding)
   const int node = tile * 64 + rt * 32 + n_lo;
@@ -152,7 +197,23 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
       v.x += acc[4 * q]; v.y += acc[4 * q + 1]; v.z += acc[4 * q + 2]; v.w += acc[4 * q + 3];
       *reinterpret_cast<float4*>(dst + 8 * q) = v;
     }
+  } else if (node >= n_pad) {                             // a hub's slice: its own row of y_ext, added up by the fix-up
+    float* dst = y_ext + (int64_t)(node - n_pad) * (4 * OW) + OW * ot + 4 * khalf;
+#pragma unroll
+    for (int q = 0; q < OW / 8; ++q)
+      *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
   }
+}
+
+// y[hub_node[h], :] += the hub's slice rows y_ext[hub_ptr[h] .. hub_ptr[h + 1]), in slice order
+__global__ __launch_bounds__(128) void rgcn_hub_fixup_kernel(const int32_t* __restrict__ hub_node, const int32_t* __restrict__ hub_ptr,
+                                                             const float* __restrict__ y_ext, int32_t d_out,
+                                                             float* __restrict__ y, int64_t ldy) {
+  const int h = blockIdx.x, f = threadIdx.x;
+  if (f >= d_out) return;
+  float acc = 0.f;
+  for (int v = hub_ptr[h]; v < hub_ptr[h + 1]; ++v) acc += y_ext[(int64_t)v * d_out + f];
+  y[(int64_t)hub_node[h] * ldy + f] += acc;
 }
 
 // packed[((r * 4 + t) * (kl / 8) + jj) * 64 + lane][c] = Wdir_r[t k0_stride + 8 jj + 4 (lane >> 5) + c][ow t + (lane & 31)]
@@ -221,7 +282,8 @@ extern "C" int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* t
                                      const int32_t* step_piece_ptr, const int64_t* step_mask, const int32_t* piece,
                                      const int32_t* col, const float* w, int32_t n_tiles, const float* x, int64_t ldx,
                                      int32_t d_in, const float* packed_w, int32_t n_blocks, int32_t trans, float* y, int64_t ldy,
-                                     int32_t d_out, int32_t n_nodes, void* stream) {
+                                     int32_t d_out, int32_t n_nodes, const int32_t* hub_node, const int32_t* hub_ptr,
+                                     int32_t n_hubs, float* y_ext, void* stream) {
   using namespace gd;
   GD_REQUIRE(tile_step_ptr && step_rel && step_piece_ptr && step_mask && piece && col && w && x && packed_w && y, GD_E_NULL,
              "gd_rgcn_tile_conv_f32: null pointer");
@@ -231,8 +293,11 @@ extern "C" int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* t
                  tile_geometry(d_in, d_out, n_blocks, din_f / n_blocks, dout_f / n_blocks, trans, &kl, &k0s),
              GD_E_DIM, "gd_rgcn_tile_conv_f32: widths / block structure not supported (d_in=%d d_out=%d blocks=%d); use gd_rgcn_conv_f32",
              d_in, d_out, n_blocks);
-  GD_REQUIRE(n_tiles == (n_nodes + 63) / 64 && ldx >= d_in && ldy >= d_out && ldx % 4 == 0 && ldy % 4 == 0, GD_E_DIM,
-             "gd_rgcn_tile_conv_f32: n_tiles must be ceil(n_nodes / 64), row pitches multiples of 4");
+  const int n_real = (n_nodes + 63) / 64;
+  GD_REQUIRE(n_tiles >= n_real && ldx >= d_in && ldy >= d_out && ldx % 4 == 0 && ldy % 4 == 0 && n_hubs >= 0, GD_E_DIM,
+             "gd_rgcn_tile_conv_f32: n_tiles must be at least ceil(n_nodes / 64), row pitches multiples of 4");
+  GD_REQUIRE(n_tiles == n_real || (n_hubs > 0 && hub_node && hub_ptr && y_ext && aligned16(y_ext)), GD_E_NULL,
+             "gd_rgcn_tile_conv_f32: slice tiles need hub_node / hub_ptr / y_ext");
   GD_REQUIRE(aligned16(x) && aligned16(y) && aligned16(packed_w) && x != y, GD_E_ALIGN, "gd_rgcn_tile_conv_f32: unaligned or aliasing pointer");
   if (n_tiles == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -240,13 +305,13 @@ extern "C" int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* t
   // two A tiles: 67.6 KB at d_in = 128 - above the 64 KB a launch gets without asking
 #define GD_RT_CASE(DIN, OW, KL)                                                                                               \
   do {                                                                                                                        \
-    constexpr int kLds = 2 * 64 * (DIN + 4) * 4;                                                                              \
+    constexpr int kLds = 2 * 64 * (DIN + 4) * 4 + kRingBytes;                                                                             \
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rgcn_tile_kernel<DIN, OW, KL>),        \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds);                      \
     if (attr != hipSuccess) return fail(-(int)attr, "gd_rgcn_tile_conv_f32: %s", hipGetErrorString(attr));                    \
     hipLaunchKernelGGL((rgcn_tile_kernel<DIN, OW, KL>), grid, dim3(512), kLds, s, tile_order, tile_step_ptr, step_rel,  \
                        step_piece_ptr, reinterpret_cast<const uint64_t*>(step_mask), reinterpret_cast<const int2*>(piece), col, \
-                       w, x, ldx, packed_w, k0s, y, ldy, n_nodes);                                                             \
+                       w, x, ldx, packed_w, k0s, y, ldy, n_nodes, y_ext, n_real * 64);                                         \
   } while (0)
   const int key = d_in * 1000000 + d_out * 1000 + kl;
   switch (key) {
@@ -261,5 +326,8 @@ extern "C" int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* t
     default: return fail(GD_E_DIM, "gd_rgcn_tile_conv_f32: no kernel for d_in=%d d_out=%d kl=%d", d_in, d_out, kl);
   }
 #undef GD_RT_CASE
-  return launched("rgcn_tile_conv");
+  int rc = launched("rgcn_tile_conv");
+  if (rc || n_tiles == n_real) return rc;
+  hipLaunchKernelGGL(rgcn_hub_fixup_kernel, dim3(n_hubs), dim3(128), 0, s, hub_node, hub_ptr, y_ext, d_out, y, ldy);
+  return launched("rgcn_hub_fixup");
 }

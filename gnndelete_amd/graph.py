@@ -9,6 +9,8 @@ Three aggregation flavours, matching what each torch_geometric conv does to the 
   'mean' edges as given, val = 1 / in-degree of the target (GraphSAGE mean aggregation)
 Rows are sorted by (target, source), so the per-row summation order is deterministic.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -314,50 +316,79 @@ class TypedNodeCSR:
         return cache[key]
 
     @staticmethod
-    def _build_tile_plan(arrays, n, r, cap=16, tile=64):
+    def _build_tile_plan(arrays, n, r, cap=16, tile=64, hub_steps=None):
+        """hub_steps: a node whose runs make more than this many pieces-in-sequence (sum over its relations of
+        ceil(|run| / cap)) is spread over V = 2^k <= 64 SLICE rows of extra tiles, piece k of a run to slice k mod V, so
+        that a slice walks about hub_steps / 2 steps."""
         node_ptr, seg_ptr, seg_rel, col, w = arrays
         dev = col.device
-        n_tiles = (n + tile - 1) // tile
+        if hub_steps is None:
+            hub_steps = int(os.environ.get('GD_RGCN_HUB_STEPS', 128))
+        n_real = (n + tile - 1) // tile
         i32 = lambda t: t.to(torch.int32).contiguous()
         e = int(col.numel())
+        z = torch.zeros(1, dtype=torch.int32, device=dev)
         if e == 0:
-            z = torch.zeros(1, dtype=torch.int32, device=dev)
-            return dict(n_tiles=n_tiles, tile_order=i32(torch.arange(n_tiles, device=dev)),
-                        tile_step_ptr=torch.zeros(n_tiles + 1, dtype=torch.int32, device=dev), step_rel=z, step_piece_ptr=z,
+            return dict(n_tiles=n_real, tile_order=i32(torch.arange(n_real, device=dev)),
+                        tile_step_ptr=torch.zeros(n_real + 1, dtype=torch.int32, device=dev), step_rel=z, step_piece_ptr=z,
                         step_mask=torch.zeros(1, dtype=torch.int64, device=dev), piece=torch.zeros(1, 2, dtype=torch.int32, device=dev),
-                        col=z, w=torch.zeros(1, dtype=torch.float32, device=dev), n_steps=0, n_pieces=0)
+                        col=z, w=torch.zeros(1, dtype=torch.float32, device=dev), n_steps=0, n_pieces=0, n_hubs=0,
+                        hub_node=z, hub_ptr=z, n_slice_rows=0)
         seg_len = (seg_ptr[1:] - seg_ptr[:-1]).long()
         n_runs = int(seg_len.numel())
         run_of_edge = torch.repeat_interleave(torch.arange(n_runs, device=dev), seg_len)
         runs_per_node = (node_ptr[1:] - node_ptr[:-1]).long()
         node_of_run = torch.repeat_interleave(torch.arange(n, device=dev), runs_per_node)
         pos = torch.arange(e, device=dev) - seg_ptr.long()[run_of_edge]
-        passes = int((int(seg_len.max()) + cap - 1) // cap)
+        pc = pos // cap                                                    # piece of the run this edge belongs to
         node = node_of_run[run_of_edge]
         rel = seg_rel.long()[run_of_edge]
-        pkey = (((node // tile) * r + rel) * passes + pos // cap) * tile + node % tile     # (tile, rel, pass, row)
+        # hubs -> slice rows
+        node_steps = torch.zeros(n, dtype=torch.int64, device=dev).scatter_add_(0, node_of_run, (seg_len + cap - 1) // cap)
+        hub_node = (node_steps > hub_steps).nonzero().flatten()
+        n_hubs = int(hub_node.numel())
+        n_pad = n_real * tile
+        row_id, passn = node, pc
+        n_slice = 0
+        hub_ptr = torch.zeros(n_hubs + 1, dtype=torch.int64, device=dev)
+        if n_hubs:
+            want = (2 * node_steps[hub_node] + hub_steps - 1) // hub_steps      # slices so that each walks ~hub_steps / 2
+            v = torch.ones_like(want)
+            while bool((v < want).any()):
+                v = torch.where(v < want, v * 2, v)
+            v = v.clamp(max=tile)
+            hub_ptr[1:] = torch.cumsum(v, 0)
+            n_slice = int(hub_ptr[-1])
+            hub_of_node = torch.full((n,), -1, dtype=torch.int64, device=dev)
+            hub_of_node[hub_node] = torch.arange(n_hubs, device=dev)
+            h = hub_of_node[node]
+            is_hub = h >= 0
+            hv = v[h.clamp(min=0)]
+            row_id = torch.where(is_hub, n_pad + hub_ptr[h.clamp(min=0)] + pc % hv, node)
+            passn = torch.where(is_hub, pc // hv, pc)
+        n_tiles = n_real + (n_slice + tile - 1) // tile
+        passes = int(passn.max()) + 1
+        pkey = (((row_id // tile) * r + rel) * passes + passn) * tile + row_id % tile     # (tile, rel, pass, row)
         order = torch.argsort(pkey, stable=True)
-        pk_sorted = pkey[order]
-        piece_key, piece_len = torch.unique_consecutive(pk_sorted, return_counts=True)
+        piece_key, piece_len = torch.unique_consecutive(pkey[order], return_counts=True)
         piece_e0 = torch.cumsum(piece_len, 0) - piece_len
         piece_row = piece_key % tile
-        skey = piece_key // tile
-        step_key, step_np = torch.unique_consecutive(skey, return_counts=True)
+        step_key, step_np = torch.unique_consecutive(piece_key // tile, return_counts=True)
         n_steps = int(step_key.numel())
         step_piece_ptr = torch.zeros(n_steps + 1, dtype=torch.int64, device=dev)
         step_piece_ptr[1:] = torch.cumsum(step_np, 0)
         step_of_piece = torch.repeat_interleave(torch.arange(n_steps, device=dev), step_np)
         step_mask = torch.zeros(n_steps, dtype=torch.int64, device=dev)
         step_mask.scatter_add_(0, step_of_piece, torch.ones_like(piece_row) << piece_row)     # distinct rows: no carries
-        step_tile = step_key // (passes * r)
-        steps_per_tile = torch.bincount(step_tile, minlength=n_tiles)
+        steps_per_tile = torch.bincount(step_key // (passes * r), minlength=n_tiles)
         tile_step_ptr = torch.zeros(n_tiles + 1, dtype=torch.int64, device=dev)
         tile_step_ptr[1:] = torch.cumsum(steps_per_tile, 0)
         piece = torch.stack([piece_e0, piece_row | (piece_len << 8)], 1)
         return dict(n_tiles=n_tiles, tile_order=i32(torch.argsort(steps_per_tile, descending=True, stable=True)),
                     tile_step_ptr=i32(tile_step_ptr), step_rel=i32((step_key // passes) % r), step_piece_ptr=i32(step_piece_ptr),
                     step_mask=step_mask.contiguous(), piece=i32(piece), col=col[order].contiguous(), w=w[order].contiguous(),
-                    n_steps=n_steps, n_pieces=int(piece_key.numel()))
+                    n_steps=n_steps, n_pieces=int(piece_key.numel()), n_hubs=n_hubs, hub_node=i32(hub_node) if n_hubs else z,
+                    hub_ptr=i32(hub_ptr), n_slice_rows=(n_tiles - n_real) * tile, max_steps=int(steps_per_tile.max()))
 
     @staticmethod
     def _runs(run_sorted, col_sorted, r, n, w):

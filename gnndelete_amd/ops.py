@@ -543,11 +543,18 @@ def rgcn_typed_accumulate(tg, x, weight, n_blocks, trans, y, edge_w=None):
     if tiled:
         p = tg.tile_plan(bool(trans))
         packed = rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans)
+        y_ext = None
+        if p['n_hubs']:
+            bufs = p.setdefault('_y_ext', {})
+            y_ext = bufs.get(d_out)
+            if y_ext is None:
+                y_ext = bufs[d_out] = torch.zeros(p['n_slice_rows'], d_out, dtype=torch.float32, device=x.device)
         check(_lib.lib().gd_rgcn_tile_conv_f32(ptr(p['tile_order']), ptr(p['tile_step_ptr']), ptr(p['step_rel']),
                                                ptr(p['step_piece_ptr']), ptr(p['step_mask']), ptr(p['piece']), ptr(p['col']),
                                                ptr(p['w']), p['n_tiles'], ptr(x), x.stride(0), d_in, ptr(packed), n_blocks,
-                                               int(trans), ptr(y), y.stride(0), d_out, tg.n, stream_ptr(x.device)),
-              'gd_rgcn_tile_conv_f32')
+                                               int(trans), ptr(y), y.stride(0), d_out, tg.n, ptr(p['hub_node']) if p['n_hubs'] else None,
+                                               ptr(p['hub_ptr']) if p['n_hubs'] else None, p['n_hubs'], ptr(y_ext),
+                                               stream_ptr(x.device)), 'gd_rgcn_tile_conv_f32')
         return y
     node_ptr, seg_ptr, seg_rel, col, w = arrays
     if edge_w is not None:

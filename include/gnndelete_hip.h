@@ -217,6 +217,10 @@ int gd_rgcn_conv_f32(const int32_t* node_ptr, const int32_t* seg_ptr, const int3
  *     piece[P][2]                  {first edge, (node % 64) | length << 8}, at most one piece per node and step
  *     col[E], w[E]                 source node and weight per edge, in (step, node % 64, source) order
  *     tile_order[n_tiles]          launch order of the tiles (most steps first) or NULL
+ * Hubs (nodes with so many pieces that their tile would run long after the others): their pieces may be moved to SLICE
+ * rows - row ids >= 64 ceil(n_nodes / 64) in extra tiles (n_tiles > ceil(n_nodes / 64)); slice row v writes row
+ * v - 64 ceil(n_nodes / 64) of y_ext [(n_tiles - ceil(n_nodes / 64)) * 64, d_out], and y[hub_node[h]] += the rows
+ * y_ext[hub_ptr[h] .. hub_ptr[h + 1]) in order afterwards.  n_hubs = 0 and NULLs when the plan has no slices.
  * y must hold the root / bias term (or zeros) on entry, as for gd_rgcn_conv_f32; relations are accumulated in
  * ascending order: bit-reproducible. */
 int32_t gd_rgcn_tile_kl(int32_t d_in, int32_t d_out, int32_t n_blocks, int32_t trans);
@@ -226,7 +230,8 @@ int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* tile_step_pt
                           const int32_t* step_piece_ptr, const int64_t* step_mask, const int32_t* piece,
                           const int32_t* col, const float* w, int32_t n_tiles, const float* x, int64_t ldx,
                           int32_t d_in, const float* packed_w, int32_t n_blocks, int32_t trans, float* y, int64_t ldy,
-                          int32_t d_out, int32_t n_nodes, void* stream);
+                          int32_t d_out, int32_t n_nodes, const int32_t* hub_node, const int32_t* hub_ptr, int32_t n_hubs,
+                          float* y_ext, void* stream);
 
 /* ---------------------------------------------------------------- Del operator --------- */
 
