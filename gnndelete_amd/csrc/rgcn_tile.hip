@@ -35,6 +35,7 @@
 namespace gd {
 
 using f32x16t = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 constexpr int kRing = 256;                              // steps in the LDS ring (power of two)
 constexpr int kRingBytes = kRing * 16;
 
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
     const int32_t* __restrict__ step_piece_ptr, const uint64_t* __restrict__ step_mask, const int2* __restrict__ piece,
     const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ x, int64_t ldx,
     const float* __restrict__ wpk, int32_t k0_stride, float* __restrict__ y, int64_t ldy, int32_t n_nodes,
-    float* __restrict__ y_ext, int32_t n_pad) {
+    float* __restrict__ y_ext, int32_t n_pad, int64_t n_x_bytes) {
   constexpr int NW = 8, NT = NW * 64, PITCH = DIN + 4, LPR = DIN / 4, GPW = 64 / LPR, NG = NW * GPW, MAXR = 64 / NG;
   constexpr int J8 = KL / 8;
   extern __shared__ __attribute__((aligned(16))) float a_lds_raw[];   // two A tiles of 64 rows x PITCH floats + the step ring
@@ -95,6 +96,14 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
     if (t + 8 < len) { r.cb = col[e0 + 8 + t]; r.wb = w[e0 + 8 + t]; }
     return r;
   };
+  // neighbour rows through a raw buffer descriptor: a slot beyond the run gets an out-of-range offset, for which the
+  // hardware returns zeros without touching memory (no branch around the load), 24 x 24-bit row offsets
+  const uint32_t row_bytes = (uint32_t)(ldx * 4);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (uint32_t)n_x_bytes, 0x00020000);
+  auto load_row = [&](uint32_t cc, bool valid) -> float4 {
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, valid ? __umul24(cc, row_bytes) + 16u * gl : 0xffffffffu, 0, 0);
+    return __builtin_bit_cast(float4, r);
+  };
   // weighted sums of step s's runs -> buf (rows of `dirty` that this step leaves empty are cleared).  Round j: lane
   // group g of the wave sums the wave's piece GPW j + g.  Every cross-lane read sits in wave-uniform control flow
   // (ds_bpermute returns 0 for a source lane that is masked off).
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
           const int src = src0 + ((k + u) & 7);
           const int cc = k < 8 ? __shfl(cw.ca, src) : __shfl(cw.cb, src);
           we[u] = k < 8 ? __shfl(cw.wa, src) : __shfl(cw.wb, src);
-          v[u] = k + u < len ? *reinterpret_cast<const float4*>(x + (int64_t)cc * ldx + 4 * gl) : f4_zero();
+          v[u] = load_row((uint32_t)cc, k + u < len);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc = f4_fma(we[u], v[u], acc);
@@ -299,6 +308,8 @@ extern "C" int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* t
   GD_REQUIRE(n_tiles == n_real || (n_hubs > 0 && hub_node && hub_ptr && y_ext && aligned16(y_ext)), GD_E_NULL,
              "gd_rgcn_tile_conv_f32: slice tiles need hub_node / hub_ptr / y_ext");
   GD_REQUIRE(aligned16(x) && aligned16(y) && aligned16(packed_w) && x != y, GD_E_ALIGN, "gd_rgcn_tile_conv_f32: unaligned or aliasing pointer");
+  GD_REQUIRE(n_nodes <= (1 << 24) && ldx * 4 < (1 << 24) && (int64_t)n_nodes * ldx * 4 < ((int64_t)1 << 32), GD_E_DIM,
+             "gd_rgcn_tile_conv_f32: x beyond 4 GB / 2^24 rows (24 x 24-bit row offsets); use gd_rgcn_conv_f32");
   if (n_tiles == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(n_tiles);
@@ -311,7 +322,7 @@ extern "C" int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* t
     if (attr != hipSuccess) return fail(-(int)attr, "gd_rgcn_tile_conv_f32: %s", hipGetErrorString(attr));                    \
     hipLaunchKernelGGL((rgcn_tile_kernel<DIN, OW, KL>), grid, dim3(512), kLds, s, tile_order, tile_step_ptr, step_rel,  \
                        step_piece_ptr, reinterpret_cast<const uint64_t*>(step_mask), reinterpret_cast<const int2*>(piece), col, \
-                       w, x, ldx, packed_w, k0s, y, ldy, n_nodes, y_ext, n_real * 64);                                         \
+                       w, x, ldx, packed_w, k0s, y, ldy, n_nodes, y_ext, n_real * 64, ((int64_t)(n_nodes - 1) * ldx + d_in) * 4);                                         \
   } while (0)
   const int key = d_in * 1000000 + d_out * 1000 + kl;
   switch (key) {
