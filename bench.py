@@ -125,9 +125,14 @@ def time_typed_conv(eng):
     out = torch.empty(n, d, device=eng.x.device)
     dur = _avg_seconds(lambda: eng._rgcn_conv(conv, eng.x, out, 0), reps=10)
     nbytes = 4.0 * nnz * d + 8.0 * nnz + 8.0 * runs + 8.0 * n * d
-    return {'kernel': 'rows_gemm (root) + rgcn_conv_kernel (typed mean aggregation + block-diagonal transform, 128 -> 128)',
+    tiled = os.environ.get('GD_RGCN_NODE_MAJOR') != '1'
+    plan = tg.tile_plan(False) if tiled else {}
+    return {'kernel': ('rows_gemm (root) + rgcn_tile_kernel<128,32,32> ((64-node tile, relation) steps: typed mean aggregation into an LDS '
+                       'tile, block-diagonal transform on v_mfma_f32_32x32x2_f32, 128 -> 128)') if tiled else
+                      'rows_gemm (root) + rgcn_conv_kernel (node-major typed mean aggregation + block-diagonal transform, 128 -> 128)',
             'bound': 'hbm', 'achieved': nbytes / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': nbytes / dur / 1e9 / HBM_PEAK_GBS,
-            'traffic': None, 'algorithmic_bytes': nbytes, 'avg_us': dur * 1e6, 'typed_edges': nnz, 'runs': runs}
+            'traffic': None, 'algorithmic_bytes': nbytes, 'avg_us': dur * 1e6, 'typed_edges': nnz, 'runs': runs,
+            'tile_plan': {k: plan[k] for k in ('n_tiles', 'n_steps', 'n_pieces', 'n_hubs', 'n_slice_rows', 'max_steps') if k in plan}}
 
 
 def kg_cpu_baseline(args, data, state, neg, ni1, ni2, iters):

@@ -641,6 +641,50 @@ def split_edges(edge_index, num_nodes, val_ratio=0.05, test_ratio=0.1, two_hop_d
     return out
 
 
+def process_kg_ogbl(split_edge, num_nodes_dict, rev_offset=51):
+    """The ogbl branch of process_kg (prepare_dataset.py:300-353): OGB hands out per-type local entity ids; the global id
+    is the local one plus the running offset of its type in num_nodes_dict order (:305-310, :326-333); validation / test
+    negatives = (head, FIRST corrupted tail as OGB stores it) (:337, :341); of the training triples, those between two
+    entity types are kept as they are, those inside one type only once (head < tail) and appended after the others
+    (:343-346); every training triple gets an inverse with relation + 51 (:351-355, the constant is upstream's).
+    -> dict with the fields of the Data object upstream pickles, plus the IN candidate mask (:383-393)."""
+    offset, cur = {}, 0
+    for key in num_nodes_dict:
+        offset[key] = cur
+        cur += num_nodes_dict[key]
+    n_entity = cur
+
+    def to_global(d):
+        head = [int(i) + offset[t] for i, t in zip(d['head'], d['head_type'])]
+        tail = [int(i) + offset[t] for i, t in zip(d['tail'], d['tail_type'])]
+        return head, tail
+
+    out = {}
+    for name, key in (('val', 'valid'), ('test', 'test')):
+        d = split_edge[key]
+        head, tail = to_global(d)
+        pos = torch.tensor([head, tail])
+        out[f'{name}_pos_edge_index'] = pos
+        out[f'{name}_edge_type'] = torch.as_tensor(np.asarray(d['relation']))
+        out[f'{name}_neg_edge_index'] = torch.stack([pos[0], torch.as_tensor(np.asarray(d['tail_neg']))[:, 0]])
+    d = split_edge['train']
+    head, tail = to_global(d)
+    directed, undirected = [], []
+    for h, t, r, ht, tt in zip(head, tail, d['relation'], d['head_type'], d['tail_type']):
+        if ht != tt:
+            directed.append((h, t, int(r)))
+        elif h < t:
+            undirected.append((h, t, int(r)))
+    uni = directed + undirected
+    train = torch.tensor([[u[0] for u in uni], [u[1] for u in uni]])
+    train_type = torch.tensor([u[2] for u in uni])
+    out.update(x=torch.arange(n_entity), train_pos_edge_index=train, train_edge_type=train_type,
+               edge_index=torch.cat([train, train.flip(0)], 1), edge_type=torch.cat([train_type, train_type + rev_offset]))
+    _, _, local = pyg.k_hop_subgraph(out['test_pos_edge_index'].flatten().unique(), 2, train, n_entity)
+    out['in_mask'] = local
+    return out
+
+
 def df_size_from_arg(df_size, num_train_edges):
     """delete_gnn.py:88-91."""
     return int(df_size) if df_size >= 100 else int(df_size / 100 * num_train_edges)

@@ -14,27 +14,31 @@ import os
 
 import torch
 
-from gnndelete_amd.framework.raw_readers import RAW_FILES, load_raw
+from gnndelete_amd.framework.raw_readers import RAW_FILES, load_raw, load_raw_kg
 from gnndelete_amd.framework.synth import KG_SHAPES, SHAPES, make_kg_dataset, make_linkpred_dataset, split_linkpred
 
 
 def main():
     p = argparse.ArgumentParser()
     p.add_argument('--dataset', default='synth-dblp',
-                   choices=sorted(SHAPES) + sorted(KG_SHAPES) + sorted(RAW_FILES) + ['ogbl-collab'])
+                   choices=sorted(SHAPES) + sorted(KG_SHAPES) + sorted(RAW_FILES) + ['ogbl-collab', 'ogbl-biokg'])
     p.add_argument('--data_dir', default='./data')
     p.add_argument('--seeds', type=int, nargs='+', default=[42, 21, 13, 87, 100])
     a = p.parse_args()
     out = os.path.join(a.data_dir, a.dataset)
     os.makedirs(out, exist_ok=True)
-    raw = None
-    if a.dataset not in SHAPES and a.dataset not in KG_SHAPES:
+    raw = raw_kg = None
+    if a.dataset == 'ogbl-biokg':
+        raw_kg = load_raw_kg(a.dataset, a.data_dir)              # OGB ships the split: the same for every seed (as upstream)
+    if a.dataset not in SHAPES and a.dataset not in KG_SHAPES and raw_kg is None:
         raw = load_raw(a.dataset, a.data_dir)
         if raw is None:
             raise SystemExit(f"no raw files for '{a.dataset}' under {a.data_dir} (nothing can be downloaded here); "
                              f"use one of the synthetic stand-ins: {sorted(SHAPES) + sorted(KG_SHAPES)}")
     for seed in a.seeds:
-        if raw is not None:
+        if raw_kg is not None:
+            data, df = raw_kg
+        elif raw is not None:
             x, edges, _ = raw
             data, df = split_linkpred(x, edges, x.shape[0], torch.Generator().manual_seed(seed))
         else:

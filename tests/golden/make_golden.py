@@ -852,6 +852,81 @@ def golden_split():
     np.savez_compressed(os.path.join(HERE, 'split.npz'), **out)
 
 
+class FakeOgbKG:
+    """Stands in for ogb.linkproppred.PygLinkPropPredDataset on a knowledge graph with typed entities: what
+    process_kg (prepare_dataset.py:300-353) reads from it."""
+
+    def __init__(self, root=None, name=None):
+        self.split, self.num_nodes_dict = STATE['ogb_split'], STATE['ogb_num_nodes']
+
+    def get_edge_split(self):
+        return {k: dict(v) for k, v in self.split.items()}
+
+    def __getitem__(self, i):
+        return Bag(num_nodes_dict=self.num_nodes_dict, num_nodes=sum(self.num_nodes_dict.values()))
+
+    def __repr__(self):
+        return 'FakeOgbKG()'
+
+
+def golden_process_kg():
+    """process_kg's ogbl branch (prepare_dataset.py:300-399) run from the reference's own module on a small split in
+    OGB's in-memory layout (per-type local entity ids, head_type / tail_type strings, 500 -> 4 corrupted tails):
+    global ids, same-type relations kept once (head < tail), inverse triples with relation + 51, first corrupted
+    tail as the negative, IN / OUT candidate masks from the 2-hop enclosing subgraph of the test triples."""
+    old_cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    sys.path.insert(0, REF)
+    try:
+        P = importlib.import_module('prepare_dataset')
+    finally:
+        sys.path.remove(REF)
+        os.chdir(old_cwd)
+    g = torch.Generator().manual_seed(77)
+    types = {'disease': 9, 'drug': 12, 'protein': 17}            # OGB's num_nodes_dict order (alphabetical)
+    names = list(types)
+    rel_types = [('drug', 'disease'), ('drug', 'protein'), ('protein', 'protein'), ('drug', 'drug'), ('disease', 'protein'),
+                 ('protein', 'protein')]                          # relation id -> (head type, tail type)
+
+    def triples(m, both_ways):
+        rel = torch.randint(0, len(rel_types), (m,), generator=g)
+        ht = [rel_types[r][0] for r in rel.tolist()]
+        tt = [rel_types[r][1] for r in rel.tolist()]
+        head = torch.tensor([int(torch.randint(0, types[a], (1,), generator=g)) for a in ht])
+        tail = torch.tensor([int(torch.randint(0, types[b], (1,), generator=g)) for b in tt])
+        if both_ways:                                            # same-type relations are stored in both directions
+            same = torch.tensor([a == b for a, b in zip(ht, tt)])
+            idx = same.nonzero().flatten().tolist()
+            head, tail = torch.cat([head, tail[idx]]), torch.cat([tail, head[idx]])
+            rel = torch.cat([rel, rel[idx]])
+            ht, tt = ht + [tt[i] for i in idx], tt + [ht[i] for i in idx]
+        return {'head': head.numpy(), 'relation': rel.numpy(), 'tail': tail.numpy(), 'head_type': ht, 'tail_type': tt}
+
+    split = {'train': triples(260, True), 'valid': triples(20, False), 'test': triples(24, False)}
+    for k in ('valid', 'test'):
+        m = len(split[k]['head'])
+        split[k]['head_neg'] = torch.randint(0, 9, (m, 4), generator=g)
+        split[k]['tail_neg'] = torch.randint(0, 38, (m, 4), generator=g)
+    STATE['ogb_split'], STATE['ogb_num_nodes'] = split, types
+    P.PygLinkPropPredDataset = FakeOgbKG
+    P.kg_datasets, P.seeds, P.data_dir = ['ogbl-fake'], [42], tmp
+    os.makedirs(os.path.join(tmp, 'ogbl-fake'), exist_ok=True)
+    P.process_kg()
+    with open(os.path.join(tmp, 'ogbl-fake', 'd_42.pkl'), 'rb') as f:
+        _, data = pickle.load(f)
+    df = torch.load(os.path.join(tmp, 'ogbl-fake', 'df_42.pt'))
+    out = {'types': np.array(names), 'type_count': np.array([types[t] for t in names])}
+    for k, d in split.items():
+        for name, v in d.items():
+            out[f'in::{k}::{name}'] = np.array(v) if isinstance(v, list) else np_(v) if torch.is_tensor(v) else np.asarray(v)
+    for k in ('x', 'edge_index', 'edge_type', 'train_pos_edge_index', 'train_edge_type', 'val_pos_edge_index', 'val_edge_type',
+              'val_neg_edge_index', 'test_pos_edge_index', 'test_edge_type', 'test_neg_edge_index'):
+        out[f'out::{k}'] = np_(data[k])
+    out['out::in_mask'], out['out::out_mask'] = np_(df['in']), np_(df['out'])
+    np.savez_compressed(os.path.join(HERE, 'process_kg.npz'), **out)
+
+
 def golden_wide_trajectories(D, T, A):
     """train_fullbatch at the widths the fused HIP stages are built for (in 32 -> hidden 128 -> out 64), so that the
     reference-loop fixtures drive the MFMA row kernels and the fused loss / Del stages, not the generic fallbacks."""
@@ -1161,6 +1236,10 @@ def main():
         return
     if sys.argv[1:] == ['wide']:
         golden_wide_trajectories(D, T, A)
+        return
+    if sys.argv[1:] == ['process_kg']:
+        golden_process_kg()
+        write_manifest(None)
         return
     if sys.argv[1:] == ['orig_minibatch']:
         golden_original_minibatch(B, A)

@@ -174,3 +174,37 @@ def test_dataset_split_reproduces_reference(tag):
     assert torch.equal(data.val_pos_edge_index, t(fx[f'{tag}::val']))
     assert torch.equal(data.test_pos_edge_index, t(fx[f'{tag}::test']))
     assert torch.equal(masks['in'], t(fx[f'{tag}::in_mask'])) and torch.equal(masks['out'], ~t(fx[f'{tag}::in_mask']))
+
+
+def test_ogbl_biokg_reader_reproduces_reference_process_kg(tmp_path):
+    """gnndelete_amd.framework.raw_readers: OGB's on-disk layout of ogbl-biokg (split/random/*.pt dicts with per-type
+    local ids, raw/num-node-dict.csv.gz) -> the Data fields and Df candidate masks the reference's process_kg pickles
+    (tests/golden/process_kg.npz, made by the reference's own function); prepare_dataset.py writes them."""
+    import gzip
+    import subprocess
+    import sys
+    from helpers import load_golden, t
+    from test_oracle_golden import _ogb_split
+    from gnndelete_amd.framework import raw_readers
+    from gnndelete_amd.framework.data import Data
+    fx = load_golden('process_kg.npz')
+    split, nodes = _ogb_split(fx)
+    root = tmp_path / 'ogbl_biokg'
+    (root / 'raw').mkdir(parents=True)
+    (root / 'split' / 'random').mkdir(parents=True)
+    with gzip.open(root / 'raw' / 'num-node-dict.csv.gz', 'wt') as f:
+        f.write(','.join(nodes) + '\n' + ','.join(str(v) for v in nodes.values()) + '\n')
+    for k, d in split.items():
+        torch.save(d, root / 'split' / 'random' / f'{k}.pt')
+    data, df = raw_readers.load_raw_kg('ogbl-biokg', str(tmp_path))
+    for k in ('x', 'edge_index', 'edge_type', 'train_pos_edge_index', 'train_edge_type', 'val_pos_edge_index', 'val_edge_type',
+              'val_neg_edge_index', 'test_pos_edge_index', 'test_edge_type', 'test_neg_edge_index'):
+        assert torch.equal(data[k], t(fx[f'out::{k}'])), k
+    assert torch.equal(df['in'], t(fx['out::in_mask'])) and torch.equal(df['out'], t(fx['out::out_mask']))
+    assert raw_readers.load_raw_kg('ogbl-biokg', str(tmp_path / 'nowhere')) is None
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(repo, 'prepare_dataset.py'), '--dataset', 'ogbl-biokg', '--data_dir', str(tmp_path),
+                    '--seeds', '42'], check=True, capture_output=True)
+    saved = Data.load(str(tmp_path / 'ogbl-biokg' / 'd_42.pt'))
+    assert torch.equal(saved.train_pos_edge_index, t(fx['out::train_pos_edge_index']))
+    assert torch.equal(torch.load(tmp_path / 'ogbl-biokg' / 'df_42.pt')['in'], t(fx['out::in_mask']))

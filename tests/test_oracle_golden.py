@@ -332,6 +332,27 @@ def test_split_matches_reference(tag):
         assert torch.equal(R.negative_sampling_kg(out['val'], out['val_type']), t(fx[f'{tag}::val_neg']))
 
 
+def _ogb_split(fx):
+    split = {}
+    for key in ('train', 'valid', 'test'):
+        d = {k.split('::')[2]: v for k, v in fx.items() if k.startswith(f'in::{key}::')}
+        d['head_type'], d['tail_type'] = [str(x) for x in d['head_type']], [str(x) for x in d['tail_type']]
+        split[key] = d
+    return split, {str(k): int(c) for k, c in zip(fx['types'], fx['type_count'])}
+
+
+def test_process_kg_matches_reference():
+    """process_kg's ogbl branch (prepare_dataset.py:300-399): global entity ids, one direction of same-type relations,
+    inverse triples, first corrupted tail as the negative, IN / OUT candidate masks."""
+    fx = load_golden('process_kg.npz')
+    split, nodes = _ogb_split(fx)
+    out = R.process_kg_ogbl(split, nodes)
+    for k in ('x', 'edge_index', 'edge_type', 'train_pos_edge_index', 'train_edge_type', 'val_pos_edge_index', 'val_edge_type',
+              'val_neg_edge_index', 'test_pos_edge_index', 'test_edge_type', 'test_neg_edge_index', 'in_mask'):
+        assert torch.equal(out[k].long() if out[k].dtype != torch.bool else out[k], t(fx[f'out::{k}'])), k
+    assert torch.equal(~out['in_mask'], t(fx['out::out_mask']))
+
+
 def test_original_minibatch_training_matches_reference_loops():
     """Trainer.train_minibatch (base.py:144-227) on the reference's own GCN and KGTrainer.train (base.py:394-493) on
     its own RGCN (21 relation types), both on injected GraphSAINT batches."""
