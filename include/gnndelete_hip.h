@@ -233,6 +233,13 @@ int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* tile_step_pt
                           int32_t d_out, int32_t n_nodes, const int32_t* hub_node, const int32_t* hub_ptr, int32_t n_hubs,
                           float* y_ext, void* stream);
 
+/* Random walks for GraphSAINT mini-batches (torch_geometric GraphSAINTRandomWalkSampler / torch_sparse random_walk as
+ * used at framework/trainer/gnndelete_nodeemb.py:379-381, :734-736): out[s * n_walks + w] = node of walker w after s
+ * steps (s = 0: start[w]); a step draws one out-neighbour of the current node uniformly from the CSR over SOURCE rows
+ * (rowptr / col), a node without out-edges keeps the walker.  The draw is a hash of (seed, w, s): reproducible. */
+int gd_random_walk(const int32_t* rowptr, const int32_t* col, int32_t n_nodes, const int64_t* start, int32_t n_walks,
+                   int32_t walk_length, uint64_t seed, int64_t* out, void* stream);
+
 /* ---------------------------------------------------------------- Del operator --------- */
 
 /* Row-subset GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
