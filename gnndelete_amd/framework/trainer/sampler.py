@@ -4,7 +4,11 @@ num_steps batches per epoch) and the mini-batch unlearning loop of gnndelete_nod
 
 Kept for iteration-level parity studies: upstream needs it because ogbl-* graphs do not fit its
 GPUs; here the full graph is a single batch (NodeembEngine).  The sampler's random stream
-cannot match PyG's (torch_sparse random_walk), so parity with upstream is statistical."""
+cannot match PyG's (torch_sparse random_walk), so parity with upstream is statistical.
+
+The sampler works where its data lives: on CPU tensors with torch ops (tests, injected node sets), on device tensors
+with the HIP random-walk kernel (gd_random_walk) and device-side unique / compaction - the mini-batch loops hand it
+the device copy, so a batch never touches the host (upstream samples on the CPU and uploads every batch)."""
 import os
 
 import torch
@@ -23,17 +27,22 @@ class RandomWalkSubgraphSampler:
         self.data, self.batch_size, self.walk_length, self.num_steps = data, batch_size, walk_length, num_steps
         self.gen = generator
         ei = data.edge_index
+        self.dev = ei.device
         self.n = int(data.num_nodes)
-        order = torch.argsort(ei[0] * self.n + ei[1])
+        order = torch.argsort(ei[0] * self.n + ei[1], stable=True)         # ties (multi-edges) in input order on every device
         self.src_sorted, self.dst_sorted, self.order = ei[0][order], ei[1][order], order
         counts = torch.bincount(self.src_sorted, minlength=self.n)
-        self.rowptr = torch.zeros(self.n + 1, dtype=torch.long)
+        self.rowptr = torch.zeros(self.n + 1, dtype=torch.long, device=self.dev)
         self.rowptr[1:] = torch.cumsum(counts, 0)
+        if self.dev.type == 'cuda':                              # int32 CSR over source rows for the walk kernel
+            self._rowptr32, self._col32 = self.rowptr.to(torch.int32), self.dst_sorted.to(torch.int32).contiguous()
 
     def __len__(self):
         return self.num_steps
 
     def _walk(self):
+        if self.dev.type == 'cuda':
+            return self._walk_device()
         cur = torch.randint(0, self.n, (self.batch_size,), generator=self.gen)
         visited = [cur]
         for _ in range(self.walk_length):
@@ -44,6 +53,19 @@ class RandomWalkSubgraphSampler:
             visited.append(cur)
         return torch.cat(visited).unique()
 
+    def _walk_device(self):
+        """Roots and the walk seed from torch's device generator (seed_everything controls them), the walks themselves
+        by gd_random_walk; the visited set by torch.unique on the device."""
+        from ... import _lib
+        from ..._lib import check, ptr, stream_ptr
+        start = torch.randint(0, self.n, (self.batch_size,), device=self.dev, generator=self.gen)
+        seed = int(torch.randint(0, 2 ** 62, (1,), device=self.dev, generator=self.gen))
+        out = torch.empty(self.walk_length + 1, self.batch_size, dtype=torch.long, device=self.dev)
+        check(_lib.lib().gd_random_walk(ptr(self._rowptr32), ptr(self._col32), self.n, ptr(start), self.batch_size,
+                                        self.walk_length, seed, ptr(out), stream_ptr(self.dev)), 'gd_random_walk')
+        self.last_walks = out
+        return out.flatten().unique()
+
     def subgraph(self, nodes):
         """The batch for one (sorted, unique) node set - what GraphSAINTSampler.__getitem__ + saint_subgraph hand
         the loop [PyG-mem]: induced edges in (source, target) order with relabelled endpoints, node-sized
@@ -51,11 +73,12 @@ class RandomWalkSubgraphSampler:
         from ..data import Data
         d = self.data
         n_edges = d.edge_index.shape[1]
-        member = torch.zeros(self.n, dtype=torch.bool)
+        nodes = nodes.to(self.dev)
+        member = torch.zeros(self.n, dtype=torch.bool, device=self.dev)
         member[nodes] = True
         keep = self.order[(member[d.edge_index[0]] & member[d.edge_index[1]])[self.order]]
-        relabel = torch.full((self.n,), -1, dtype=torch.long)
-        relabel[nodes] = torch.arange(nodes.numel())
+        relabel = torch.full((self.n,), -1, dtype=torch.long, device=self.dev)
+        relabel[nodes] = torch.arange(nodes.numel(), device=self.dev)
         batch = Data(num_nodes=int(nodes.numel()), edge_index=relabel[d.edge_index[:, keep]])
         for key, val in d.items():
             if key in ('edge_index', 'num_nodes'):
@@ -90,7 +113,10 @@ class FixedNodeSets(RandomWalkSubgraphSampler):
 
 
 def make_sampler(data, batch_size, num_steps, walk_length=2):
-    """Sampler factory of the mini-batch loops (a seam for tests: monkeypatch to inject FixedNodeSets)."""
+    """Sampler factory of the mini-batch loops (a seam for tests: monkeypatch to inject FixedNodeSets).  The loops keep
+    their Data on the host as upstream does; the sampler gets a device copy and cuts its batches there."""
+    if torch.cuda.is_available() and data.edge_index.device.type == 'cpu':
+        data = data.clone().to(device)
     return RandomWalkSubgraphSampler(data, batch_size=batch_size, walk_length=walk_length, num_steps=num_steps)
 
 

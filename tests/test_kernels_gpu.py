@@ -842,3 +842,55 @@ def test_dense_autograd_matches_fp64(m, in_f, out_f, bias):
         assert rel_l2(wg.grad.cpu(), wd.grad) < TOL
         if bias:
             assert rel_l2(bg.grad.cpu(), bd.grad) < TOL
+
+
+def test_random_walk_kernel_and_device_sampler():
+    """gd_random_walk (GraphSAINT's random walks on the device): every step goes to an out-neighbour of the previous node,
+    a node without out-edges keeps the walker, the draw is uniform over the neighbours (chi-square on a 6-neighbour hub),
+    the same seed gives the same walks and another seed different ones; the device sampler's induced subgraph equals
+    the host sampler's for the same node set, attribute slicing included."""
+    from gnndelete_amd.framework.data import Data
+    from gnndelete_amd.framework.trainer.sampler import RandomWalkSubgraphSampler, make_sampler
+    g = torch.Generator().manual_seed(5)
+    n, m = 400, 3000
+    ei = torch.randint(0, n - 10, (2, m), generator=g)                     # nodes n-10 .. n-1: no edges at all
+    ei = torch.cat([ei, torch.tensor([[7] * 6, [11, 12, 13, 14, 15, 16]])], 1)
+    ei = ei[:, ei[0] != 7] if False else ei
+    data = Data(num_nodes=n, edge_index=ei, x=torch.randn(n, 3, generator=g), edge_flag=torch.rand(ei.shape[1], generator=g) < 0.3,
+                note='kept')
+    dev_sampler = RandomWalkSubgraphSampler(data.clone().to('cuda'), batch_size=5000, walk_length=3, num_steps=2)
+    torch.manual_seed(123)
+    nodes = dev_sampler._walk()
+    walks = dev_sampler.last_walks.cpu()
+    assert walks.shape == (4, 5000) and torch.equal(nodes.cpu(), walks.flatten().unique())
+    adj = torch.zeros(n, n, dtype=torch.bool)
+    adj[ei[0], ei[1]] = True
+    has_out = adj.any(1)
+    for s in range(3):
+        a, b = walks[s], walks[s + 1]
+        assert bool((adj[a, b] | (~has_out[a] & (a == b))).all())
+    torch.manual_seed(123)
+    dev_sampler._walk()
+    assert torch.equal(dev_sampler.last_walks.cpu(), walks)
+    torch.manual_seed(124)
+    dev_sampler._walk()
+    assert not torch.equal(dev_sampler.last_walks.cpu(), walks)
+    # uniformity: 60,000 walkers on node 7's out-neighbours (its only out-edges are the 6 added ones, plus random ones)
+    from gnndelete_amd import _lib
+    from gnndelete_amd._lib import check, ptr
+    nb = ei[1][ei[0] == 7]
+    start = torch.full((60000,), 7, dtype=torch.long, device='cuda')
+    out = torch.empty(2, 60000, dtype=torch.long, device='cuda')
+    check(_lib.lib().gd_random_walk(ptr(dev_sampler._rowptr32), ptr(dev_sampler._col32), n, ptr(start), 60000, 1, 99, ptr(out), None), 'walk')
+    torch.cuda.synchronize()
+    cnt = torch.bincount(out[1].cpu(), minlength=n).double()
+    expect = torch.bincount(nb, minlength=n).double() / nb.numel() * 60000
+    chi2 = float((((cnt - expect) ** 2)[expect > 0] / expect[expect > 0]).sum())
+    assert float(cnt[expect == 0].sum()) == 0 and chi2 < 3 * int((expect > 0).sum()), chi2
+    # induced subgraph: device == host for the same node set
+    host = RandomWalkSubgraphSampler(data, batch_size=10, walk_length=2, num_steps=1)
+    hb, db = host.subgraph(nodes.cpu()), dev_sampler.subgraph(nodes)
+    assert db.edge_index.is_cuda and hb.note == db.note == 'kept' and hb.num_nodes == db.num_nodes
+    for k in ('edge_index', 'x', 'edge_flag'):
+        assert torch.equal(hb[k], db[k].cpu()), k
+    assert make_sampler(data, 10, 1).dev.type == 'cuda'
