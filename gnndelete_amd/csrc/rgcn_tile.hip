@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  constexpr int DQ = 6, CQ = 4;                           // descriptors of steps s+1 .. s+6, edges of steps s+1 .. s+4
+  constexpr int DQ = 2, CQ = 1;                           // descriptors of steps s+1, s+2, edges of step s+1 (DQ > CQ)
   int2 dq[DQ];
   Cw cq[CQ];
 #pragma unroll
