@@ -7,82 +7,82 @@
 // 16 KB = 55 GB of L2 reads per launch at ogbl-biokg size - it runs at L2 bandwidth (7.6 ms).  Here the work is
 // regrouped so that a weight is fetched once per (64-node tile, relation):
 //
-//   block  = one tile of 64 consecutive nodes, 8 waves: wave (rt, ot) owns the accumulators of the 32 nodes
-//            rt x the d_out / 4 outputs ot (one weight block of the reference's num_blocks = 4 configuration) in 16
-//            MFMA accumulator registers FOR THE WHOLE TILE - no [R, N, d] tensor, no atomics, no scatter;
-//            relations are added in ascending order (deterministic);
-//   step   = one relation present in the tile (a second, third ... step for runs longer than 16 edges): the waves
-//            first build the step's A tile in LDS - row = node, the weighted sum of that node's run, zero when the
-//            node has no edge of this relation - one lane group (d_in / 4 lanes x float4) per run, runs as int2
-//            {first edge, row | length << 8} "pieces", edges stored in (tile, relation, node) order;
-//   then     D[32 out][32 node] += W_r^T[out][k] A^T[k][32 node] on v_mfma_f32_32x32x2_f32: only the [KL x OW] block of
-//            the block-diagonal weight that feeds the wave's outputs (KL = 32 = one block's inputs; a 16-wide block
-//            fills half of the MFMA's output rows), pre-packed in the lane order of the MFMA A operand
-//            (gd_rgcn_pack_weight_f32: one coalesced 16-byte load per 4 k).
+//   block  = one tile of 64 consecutive nodes, 8 waves; the tile's outputs [64 x d_out] live in LDS for the whole tile -
+//            no [R, N, d] tensor, no atomics; relations are added in ascending order (deterministic);
+//   step   = one relation present in the tile (further steps for runs longer than 16 edges and beyond 32 runs): the waves
+//            first build the step's COMPACT A tile in LDS - row q = the weighted sum of the step's q-th run - one lane
+//            group (d_in / 4 lanes x float4) per run, runs as int2 {first edge, row | length << 8} "pieces", edges
+//            stored in (tile, relation, node) order; a row map remembers which node each compact row belongs to;
+//   then     D[out][run] += W_r^T[out][k] A^T[k][run] on v_mfma_f32_16x16x4_f32: wave (ot, ch) multiplies the [KL x OW]
+//            block of the block-diagonal weight that feeds its d_out / 4 outputs with the runs [16 ch, 16 ch + 16) and
+//            adds its 16 x 16 products to the runs' node rows of the accumulators (distinct rows within a step,
+//            disjoint (ot, ch) ranges: plain read-modify-write).  The weight block is pre-packed in the lane order of
+//            the MFMA A operand (gd_rgcn_pack_weight_f32: one coalesced 16-byte load per 4 k).
+//
+// Compact rows instead of one row per node: a node holds 36 of the 102 relations, so node-aligned rows would leave 65 %
+// of the MFMA columns empty (the first version of this kernel: 0.55 ms of matrix time per launch at biokg size);
+// steps with <= 16 runs keep half of the waves out of the product altogether.
 //
 // Hubs: "one piece per node and step" serialises a node whose runs hold thousands of edges (ogbl-biokg's largest
 // entity: 10,423 in-edges, 1,895 of one relation = 119 passes).  The plan spreads such a node over up to 64 SLICE rows
 // of extra tiles (piece k of a run -> slice k mod V); a slice row is an ordinary row to this kernel except that its
 // outputs go to y_ext, and rgcn_hub_fixup_kernel adds a hub's slices to its row of y in slice order (deterministic).
 //
-// The A tile is double buffered: while MFMA(s) reads one buffer the same waves gather step s + 1 into the other -
-// one barrier per step; piece descriptors are fetched six steps ahead and edge (col, w) four steps ahead, so a step's
-// critical path is one memory round trip (the neighbour rows).  Padding rows without a run to zero costs matrix
-// work (a node holds 36 of the 102 relations: 35 % of the rows are live) - which is what keeps the accumulators in
-// registers: 78 GF per launch at biokg size, < 1 ms on the matrix cores, against 4.3 GB of gathered rows.
+// The A tile is double buffered: while the MFMAs of step s read one buffer the same waves gather step s + 1 into the
+// other - one barrier per step; step scalars sit in an LDS ring, piece descriptors and edge (col, w) pairs are fetched
+// into registers a step ahead of their use.
 #include "common.h"
 
 namespace gd {
 
 using f32x16t = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using f32x4t = __attribute__((ext_vector_type(4))) float;
 constexpr int kRing = 256;                              // steps in the LDS ring (power of two)
-constexpr int kRingBytes = kRing * 16;
 
 template <int DIN, int OW, int KL>
 __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
     const int32_t* __restrict__ tile_order, const int32_t* __restrict__ tile_step_ptr, const int32_t* __restrict__ step_rel,
-    const int32_t* __restrict__ step_piece_ptr, const uint64_t* __restrict__ step_mask, const int2* __restrict__ piece,
+    const int32_t* __restrict__ step_piece_ptr, const int2* __restrict__ piece,
     const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ x, int64_t ldx,
     const float* __restrict__ wpk, int32_t k0_stride, float* __restrict__ y, int64_t ldy, int32_t n_nodes,
     float* __restrict__ y_ext, int32_t n_pad, int64_t n_x_bytes) {
-  constexpr int NW = 8, NT = NW * 64, PITCH = DIN + 4, LPR = DIN / 4, GPW = 64 / LPR, NG = NW * GPW, MAXR = 64 / NG;
-  constexpr int J8 = KL / 8;
-  extern __shared__ __attribute__((aligned(16))) float a_lds_raw[];   // two A tiles of 64 rows x PITCH floats + the step ring
-  auto a_lds = [&](int b) -> float* { return a_lds_raw + b * (64 * PITCH); };
-  // per-step scalars (relation, first piece, row mask) of the next >= 128 steps: a ring in LDS refilled every 64 steps, so
-  // that no iteration waits for a scalar load from memory (three dependent ones per step otherwise: 0.7 of 1.5 ms)
-  uint64_t* const m_mask = reinterpret_cast<uint64_t*>(a_lds_raw + 2 * 64 * PITCH);
-  int32_t* const m_rel = reinterpret_cast<int32_t*>(m_mask + kRing);
+  constexpr int NW = 8, NT = NW * 64, PITCH = DIN + 4, LPR = DIN / 4, GPW = 64 / LPR;
+  constexpr int PPW = 4, MAXR = PPW / GPW;                 // pieces per wave and step (a step holds <= 32), rounds to sum them
+  constexpr int DOUT = 4 * OW, OPITCH = DOUT + 4, NOH = OW / 16, NMM = KL / 16;
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  // LDS: two compact A tiles (32 pieces x PITCH), the tile's accumulators (64 nodes x OPITCH), the step ring, row maps
+  auto a_lds = [&](int b) -> float* { return lds_raw + b * (32 * PITCH); };
+  float* const acc_lds = lds_raw + 2 * 32 * PITCH;
+  int32_t* const m_rel = reinterpret_cast<int32_t*>(acc_lds + 64 * OPITCH);
   int32_t* const m_pp = m_rel + kRing;
+  int32_t* const rowmap = m_pp + kRing;                     // [2][32]: node row of the piece in compact row q
   const int tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
   const int s0 = tile_step_ptr[tile], s1 = tile_step_ptr[tile + 1];
   if (s0 == s1) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rt = wave >> 2, ot = wave & 3, n_lo = lane & 31, khalf = lane >> 5;
-  const int grp = wave * GPW + lane / LPR, gl = lane % LPR;
+  const int ot = wave & 3, ch = wave >> 2;                  // MFMA role: outputs [OW ot, OW ot + OW), pieces [16 ch, 16 ch + 16)
+  const int g_in_wave = lane / LPR, gl = lane % LPR;
 
-  for (int i = tid; i < 2 * 64 * PITCH / 4; i += NT) reinterpret_cast<float4*>(a_lds_raw)[i] = f4_zero();
+  for (int i = tid; i < 64 * OPITCH / 4; i += NT) reinterpret_cast<float4*>(acc_lds)[i] = f4_zero();
   auto ring_fill = [&](int first, int count) {            // steps [first, first + count) (+ the piece pointer one past the end)
     for (int i = tid; i < count; i += NT) {
       const int s = first + i;
       if (s <= s1) {
         m_pp[(s - s0) & (kRing - 1)] = step_piece_ptr[s];
-        if (s < s1) { m_rel[(s - s0) & (kRing - 1)] = step_rel[s]; m_mask[(s - s0) & (kRing - 1)] = step_mask[s]; }
+        if (s < s1) m_rel[(s - s0) & (kRing - 1)] = step_rel[s];
       }
     }
   };
   ring_fill(s0, 192);
   __syncthreads();
 
-  // Plan data per wave and step, one element per lane: the wave takes the pieces wave, wave + 8, wave + 16 ... of a step
-  // (8 at most: 64 rows); lane i < 8 holds the descriptor of its i-th piece, lane 8 i + t the edges t and t + 8 of that
-  // piece.  6 + 4 registers keep descriptors six and edges four steps ahead: the plan is a stream that is touched once
-  // (an HBM round trip per load), and with one-step prefetch that round trip was the iteration time (0.7 of 1.5 ms).
+  // Plan data per wave and step, one element per lane: the wave takes the pieces wave, wave + 8, wave + 16, wave + 24 of
+  // a step; lane i < 4 holds the descriptor of its i-th piece, lane 8 i + t the edges t and t + 8 of that piece.
   struct Cw { int ca, cb; float wa, wb; };
   auto load_desc = [&](int s) -> int2 {
     int2 d = make_int2(0, 0);
-    if (s < s1 && lane < 8) {
+    if (s < s1 && lane < PPW) {
       const int p0 = m_pp[(s - s0) & (kRing - 1)], p1 = m_pp[(s + 1 - s0) & (kRing - 1)];
       const int pi = p0 + wave + 8 * lane;
       if (pi < p1) d = piece[pi];
@@ -90,7 +90,8 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
     return d;
   };
   auto load_cw = [&](int2 d) -> Cw {
-    const int e0 = __shfl(d.x, lane >> 3), len = __shfl(d.y, lane >> 3) >> 8, t = lane & 7;
+    const int slot = (lane >> 3) & (PPW - 1);
+    const int e0 = __shfl(d.x, slot), len = lane < 8 * PPW ? __shfl(d.y, slot) >> 8 : 0, t = lane & 7;
     Cw r = {0, 0, 0.f, 0.f};
     if (t < len) { r.ca = col[e0 + t]; r.wa = w[e0 + t]; }
     if (t + 8 < len) { r.cb = col[e0 + 8 + t]; r.wb = w[e0 + 8 + t]; }
@@ -104,16 +105,10 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
     const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, valid ? __umul24(cc, row_bytes) + 16u * gl : 0xffffffffu, 0, 0);
     return __builtin_bit_cast(float4, r);
   };
-  // weighted sums of step s's runs -> buf (rows of `dirty` that this step leaves empty are cleared).  Round j: lane
-  // group g of the wave sums the wave's piece GPW j + g.  Every cross-lane read sits in wave-uniform control flow
-  // (ds_bpermute returns 0 for a source lane that is masked off).
-  auto gather = [&](int s, int2 d, Cw cw, float* buf, uint64_t dirty) -> uint64_t {
-    const uint64_t mask = m_mask[(s - s0) & (kRing - 1)];
-    const uint64_t zm = dirty & ~mask;
-#pragma unroll
-    for (int j = 0; j < MAXR; ++j)
-      if ((zm >> (grp + NG * j)) & 1) *reinterpret_cast<float4*>(buf + (grp + NG * j) * PITCH + 4 * gl) = f4_zero();
-    const int g_in_wave = lane / LPR;
+  // weighted sums of a step's runs -> the compact rows of buf (row q = the step's q-th piece; rows beyond the step's
+  // piece count keep stale data whose products are never added).  Round j: lane group g of the wave sums the wave's
+  // piece GPW j + g.  Every cross-lane read sits in wave-uniform control flow (ds_bpermute returns 0 for a masked lane).
+  auto gather = [&](int2 d, Cw cw, float* buf, int32_t* rmap) {
 #pragma unroll
     for (int j = 0; j < MAXR; ++j) {
       int rl = 0, kmax = 0;
@@ -124,7 +119,7 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
         rl = g_in_wave == g ? v : rl;
       }
       if (kmax == 0) continue;
-      const int len = rl >> 8, row = rl & 255, src0 = 8 * (GPW * j + g_in_wave);
+      const int len = rl >> 8, slot = GPW * j + g_in_wave, q = wave + 8 * slot, src0 = 8 * slot;
       float4 acc = f4_zero();
       for (int k = 0; k < kmax; k += 4) {
         float4 v[4];
@@ -139,78 +134,83 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc = f4_fma(we[u], v[u], acc);
       }
-      if (len > 0) *reinterpret_cast<float4*>(buf + row * PITCH + 4 * gl) = acc;
+      if (len > 0) {
+        *reinterpret_cast<float4*>(buf + q * PITCH + 4 * gl) = acc;
+        if (gl == 0) rmap[q] = rl & 255;
+      }
     }
-    return mask;
   };
 
-  f32x16t acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-  constexpr int DQ = 2, CQ = 1;                           // descriptors of steps s+1, s+2, edges of step s+1 (DQ > CQ)
-  int2 dq[DQ];
-  Cw cq[CQ];
-#pragma unroll
-  for (int i = 0; i < DQ; ++i) dq[i] = load_desc(s0 + i);
-#pragma unroll
-  for (int i = 0; i < CQ; ++i) cq[i] = load_cw(dq[i]);
-  uint64_t dirty[2] = {0, 0};
-  dirty[0] = gather(s0, dq[0], cq[0], a_lds(0), 0);
-  auto advance = [&](int s_new_desc) {                    // queues move up one step; issue the loads that refill them
-#pragma unroll
-    for (int i = 0; i + 1 < DQ; ++i) dq[i] = dq[i + 1];
-#pragma unroll
-    for (int i = 0; i + 1 < CQ; ++i) cq[i] = cq[i + 1];
-    cq[CQ - 1] = load_cw(dq[CQ - 1]);
-    dq[DQ - 1] = load_desc(s_new_desc);
-  };
-  advance(s0 + DQ);
+  int2 d_cur = load_desc(s0), d_nxt = load_desc(s0 + 1);
+  Cw c_cur = load_cw(d_cur);
+  gather(d_cur, c_cur, a_lds(0), rowmap);
+  d_cur = d_nxt;
+  c_cur = load_cw(d_cur);
+  d_nxt = load_desc(s0 + 2);
   __syncthreads();
   int cur = 0;
+  const float4* const wpk4 = reinterpret_cast<const float4*>(wpk);
   for (int s = s0; s < s1; ++s) {
-    // this step's weight slice (arrives behind the gathers of the next step)
-    constexpr bool kPrefetchW = J8 <= 4;                 // a dense 128-wide slice (64 registers) is read in the loop instead
-    const float4* wp = reinterpret_cast<const float4*>(wpk) + ((int64_t)(m_rel[(s - s0) & (kRing - 1)] * 4 + ot) * J8) * 64 + lane;
-    float4 wv[kPrefetchW ? J8 : 1];
-    if (kPrefetchW) {
+    const int n = m_pp[(s + 1 - s0) & (kRing - 1)] - m_pp[(s - s0) & (kRing - 1)];     // pieces of this step (<= 32)
+    const bool mm_on = 16 * ch < n;                        // the second half of the waves only works on crowded steps
+    // this step's weight block in MFMA lane order (arrives behind the gathers of the next step)
+    float4 wv[NOH][NMM];
+    if (mm_on) {
+      const float4* wp = wpk4 + ((int64_t)(m_rel[(s - s0) & (kRing - 1)] * 4 + ot) * (NOH * NMM)) * 64 + lane;
 #pragma unroll
-      for (int jj = 0; jj < J8; ++jj) wv[jj] = wp[jj * 64];
-    }
-    if (s + 1 < s1) {
-      dirty[cur ^ 1] = gather(s + 1, dq[0], cq[0], a_lds(cur ^ 1), dirty[cur ^ 1]);
-      // refills go out AFTER the row gathers: loads return in order, a wait for the rows would wait for these too
-      advance(s + 1 + DQ);
-    }
-    const float* bsrc = a_lds(cur) + (rt * 32 + n_lo) * PITCH + ot * k0_stride + 4 * khalf;
+      for (int oh = 0; oh < NOH; ++oh)
 #pragma unroll
-    for (int jj = 0; jj < J8; ++jj) {
-      const float4 bv = *reinterpret_cast<const float4*>(bsrc + 8 * jj);
-      const float4 wj = kPrefetchW ? wv[kPrefetchW ? jj : 0] : wp[jj * 64];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wj.x, bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wj.y, bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wj.z, bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wj.w, bv.w, acc, 0, 0, 0);
+        for (int mm = 0; mm < NMM; ++mm) wv[oh][mm] = wp[(oh * NMM + mm) * 64];
+    }
+    if (s + 1 < s1) gather(d_cur, c_cur, a_lds(cur ^ 1), rowmap + 32 * (cur ^ 1));
+    d_cur = d_nxt;
+    c_cur = load_cw(d_cur);
+    d_nxt = load_desc(s + 3);
+    if (mm_on) {
+      // D[16 out][16 piece] += W^T[out][k] A^T[k][piece] on v_mfma_f32_16x16x4_f32: lane (j = lane & 15, kq = lane >> 4)
+      // feeds k = k0 + 16 mm + 4 kq + c of piece 16 ch + j (one 16-byte LDS read per mm) and ends with the outputs
+      // 16 oh + 4 kq + c of that piece - added to the piece's node row of the accumulators (distinct rows per step,
+      // the (ot, ch) ranges of the waves are disjoint: no atomics, relations in ascending order)
+      const int j = lane & 15, kq = lane >> 4;
+      const float* bsrc = a_lds(cur) + (16 * ch + j) * PITCH + ot * k0_stride + 4 * kq;
+      f32x4t dacc[NOH];
+#pragma unroll
+      for (int oh = 0; oh < NOH; ++oh) dacc[oh] = f32x4t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mm = 0; mm < NMM; ++mm) {
+        const float4 bv = *reinterpret_cast<const float4*>(bsrc + 16 * mm);
+#pragma unroll
+        for (int oh = 0; oh < NOH; ++oh) {
+          dacc[oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[oh][mm].x, bv.x, dacc[oh], 0, 0, 0);
+          dacc[oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[oh][mm].y, bv.y, dacc[oh], 0, 0, 0);
+          dacc[oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[oh][mm].z, bv.z, dacc[oh], 0, 0, 0);
+          dacc[oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[oh][mm].w, bv.w, dacc[oh], 0, 0, 0);
+        }
+      }
+      if (16 * ch + j < n) {
+        float* dst = acc_lds + rowmap[32 * cur + 16 * ch + j] * OPITCH + OW * ot + 4 * kq;
+#pragma unroll
+        for (int oh = 0; oh < NOH; ++oh) {
+          float4 v = *reinterpret_cast<float4*>(dst + 16 * oh);
+          v.x += dacc[oh][0]; v.y += dacc[oh][1]; v.z += dacc[oh][2]; v.w += dacc[oh][3];
+          *reinterpret_cast<float4*>(dst + 16 * oh) = v;
+        }
+      }
     }
     __syncthreads();
     cur ^= 1;
     if (((s + 1 - s0) & 63) == 0) ring_fill(s + 1 + 128, 64);   // slots of steps every wave has left behind
   }
-  // D[i][j]: j = lane & 31 = node, output OW ot + 8 q + 4 khalf + c in acc[4 q + c] (rows >= OW are padding)
-  const int node = tile * 64 + rt * 32 + n_lo;
-  if (node < n_nodes) {
-    float* dst = y + (int64_t)node * ldy + OW * ot + 4 * khalf;
-#pragma unroll
-    for (int q = 0; q < OW / 8; ++q) {
-      float4 v = *reinterpret_cast<float4*>(dst + 8 * q);
-      v.x += acc[4 * q]; v.y += acc[4 * q + 1]; v.z += acc[4 * q + 2]; v.w += acc[4 * q + 3];
-      *reinterpret_cast<float4*>(dst + 8 * q) = v;
+  // the tile's rows: y += accumulators (a hub's slice rows go to y_ext, added up by the fix-up)
+  for (int i = tid; i < 64 * (DOUT / 4); i += NT) {
+    const int r = i / (DOUT / 4), c4 = i % (DOUT / 4), node = tile * 64 + r;
+    const float4 a = *reinterpret_cast<const float4*>(acc_lds + r * OPITCH + 4 * c4);
+    if (node < n_nodes) {
+      float4* dst = reinterpret_cast<float4*>(y + (int64_t)node * ldy) + c4;
+      *dst = f4_add(*dst, a);
+    } else if (node >= n_pad) {
+      reinterpret_cast<float4*>(y_ext + (int64_t)(node - n_pad) * DOUT)[c4] = a;
     }
-  } else if (node >= n_pad) {                             // a hub's slice: its own row of y_ext, added up by the fix-up
-    float* dst = y_ext + (int64_t)(node - n_pad) * (4 * OW) + OW * ot + 4 * khalf;
-#pragma unroll
-    for (int q = 0; q < OW / 8; ++q)
-      *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
   }
 }
 
@@ -225,23 +225,26 @@ __global__ __launch_bounds__(128) void rgcn_hub_fixup_kernel(const int32_t* __re
   y[(int64_t)hub_node[h] * ldy + f] += acc;
 }
 
-// packed[((r * 4 + t) * (kl / 8) + jj) * 64 + lane][c] = Wdir_r[t k0_stride + 8 jj + 4 (lane >> 5) + c][ow t + (lane & 31)]
-// (0 for lane & 31 >= ow) with Wdir_r the [agg width x out width] block-diagonal matrix of this direction
-// (forward: W_r, trans: W_r^T) and ow = d_out / 4 the outputs of one wave
+// packed[(((r * 4 + t) * (ow / 16) + oh) * (kl / 16) + mm) * 64 + lane][c] =
+//     Wdir_r[t k0_stride + 16 mm + 4 (lane >> 4) + c][ow t + 16 oh + (lane & 15)]
+// with Wdir_r the [agg width x out width] block-diagonal matrix of this direction (forward: W_r, trans: W_r^T) and
+// ow = d_out / 4 the outputs of one wave: the A operand of v_mfma_f32_16x16x4_f32, one 16-byte load per four k steps
 __global__ __launch_bounds__(256) void rgcn_pack_weight_kernel(const float* __restrict__ weight, int32_t n_rel, int32_t n_blocks,
                                                                int32_t ib, int32_t ob, int32_t trans, int32_t ow, int32_t kl,
                                                                int32_t k0_stride, float* __restrict__ packed) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)n_rel * 4 * (kl / 8) * 64 * 4;
+  const int noh = ow / 16, nmm = kl / 16;
+  const int64_t total = (int64_t)n_rel * 4 * noh * nmm * 64 * 4;
   if (e >= total) return;
   const int c = (int)(e & 3), lane = (int)((e >> 2) & 63);
   int64_t rest = e >> 8;
-  const int jj = (int)(rest % (kl / 8)); rest /= (kl / 8);
+  const int mm = (int)(rest % nmm); rest /= nmm;
+  const int oh = (int)(rest % noh); rest /= noh;
   const int t = (int)(rest & 3), r = (int)(rest >> 2);
-  const int k = t * k0_stride + 8 * jj + 4 * (lane >> 5) + c, o = ow * t + (lane & 31);
+  const int k = t * k0_stride + 16 * mm + 4 * (lane >> 4) + c, o = ow * t + 16 * oh + (lane & 15);
   const int kb = trans ? ob : ib, nb = trans ? ib : ob;     // agg features / outputs per block in this direction
   float v = 0.f;
-  if ((lane & 31) < ow && k / kb == o / nb) {
+  if (k / kb == o / nb) {
     const int b = o / nb;
     const float* wb = weight + ((int64_t)r * n_blocks + b) * ib * ob;
     v = trans ? wb[(o % nb) * ob + (k % kb)] : wb[(k % kb) * ob + (o % nb)];
@@ -280,7 +283,7 @@ extern "C" int gd_rgcn_pack_weight_f32(const float* weight, int32_t n_rel, int32
                  tile_geometry(d_in, d_out, n_blocks, din_f / n_blocks, dout_f / n_blocks, trans, &kl, &k0s),
              GD_E_DIM, "gd_rgcn_pack_weight_f32: widths / block structure not supported by the tile kernel (d_in=%d d_out=%d blocks=%d)",
              d_in, d_out, n_blocks);
-  const int64_t total = (int64_t)n_rel * 4 * (kl / 8) * 256;
+  const int64_t total = (int64_t)n_rel * 4 * ((d_out / 4) / 16) * (kl / 16) * 256;
   if (total == 0) return GD_OK;
   hipLaunchKernelGGL(rgcn_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, n_rel,
                      n_blocks, din_f / n_blocks, dout_f / n_blocks, trans, d_out / 4, kl, k0s, packed);
@@ -288,13 +291,13 @@ extern "C" int gd_rgcn_pack_weight_f32(const float* weight, int32_t n_rel, int32
 }
 
 extern "C" int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* tile_step_ptr, const int32_t* step_rel,
-                                     const int32_t* step_piece_ptr, const int64_t* step_mask, const int32_t* piece,
+                                     const int32_t* step_piece_ptr, const int32_t* piece,
                                      const int32_t* col, const float* w, int32_t n_tiles, const float* x, int64_t ldx,
                                      int32_t d_in, const float* packed_w, int32_t n_blocks, int32_t trans, float* y, int64_t ldy,
                                      int32_t d_out, int32_t n_nodes, const int32_t* hub_node, const int32_t* hub_ptr,
                                      int32_t n_hubs, float* y_ext, void* stream) {
   using namespace gd;
-  GD_REQUIRE(tile_step_ptr && step_rel && step_piece_ptr && step_mask && piece && col && w && x && packed_w && y, GD_E_NULL,
+  GD_REQUIRE(tile_step_ptr && step_rel && step_piece_ptr && piece && col && w && x && packed_w && y, GD_E_NULL,
              "gd_rgcn_tile_conv_f32: null pointer");
   const int din_f = trans ? d_out : d_in, dout_f = trans ? d_in : d_out;
   int kl = 0, k0s = 0;
@@ -316,12 +319,12 @@ extern "C" int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* t
   // two A tiles: 67.6 KB at d_in = 128 - above the 64 KB a launch gets without asking
 #define GD_RT_CASE(DIN, OW, KL)                                                                                               \
   do {                                                                                                                        \
-    constexpr int kLds = 2 * 64 * (DIN + 4) * 4 + kRingBytes;                                                                             \
+    constexpr int kLds = (2 * 32 * (DIN + 4) + 64 * (4 * OW + 4)) * 4 + kRing * 8 + 2 * 32 * 4;                                                                             \
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rgcn_tile_kernel<DIN, OW, KL>),        \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds);                      \
     if (attr != hipSuccess) return fail(-(int)attr, "gd_rgcn_tile_conv_f32: %s", hipGetErrorString(attr));                    \
     hipLaunchKernelGGL((rgcn_tile_kernel<DIN, OW, KL>), grid, dim3(512), kLds, s, tile_order, tile_step_ptr, step_rel,  \
-                       step_piece_ptr, reinterpret_cast<const uint64_t*>(step_mask), reinterpret_cast<const int2*>(piece), col, \
+                       step_piece_ptr, reinterpret_cast<const int2*>(piece), col, \
                        w, x, ldx, packed_w, k0s, y, ldy, n_nodes, y_ext, n_real * 64, ((int64_t)(n_nodes - 1) * ldx + d_in) * 4);                                         \
   } while (0)
   const int key = d_in * 1000000 + d_out * 1000 + kl;

@@ -316,7 +316,7 @@ class TypedNodeCSR:
         return cache[key]
 
     @staticmethod
-    def _build_tile_plan(arrays, n, r, cap=16, tile=64, hub_steps=None):
+    def _build_tile_plan(arrays, n, r, cap=16, tile=64, hub_steps=None, max_pieces=32):
         """hub_steps: a node whose runs make more than this many pieces-in-sequence (sum over its relations of
         ceil(|run| / cap)) is spread over V = 2^k <= 64 SLICE rows of extra tiles, piece k of a run to slice k mod V, so
         that a slice walks about hub_steps / 2 steps."""
@@ -331,7 +331,7 @@ class TypedNodeCSR:
         if e == 0:
             return dict(n_tiles=n_real, tile_order=i32(torch.arange(n_real, device=dev)),
                         tile_step_ptr=torch.zeros(n_real + 1, dtype=torch.int32, device=dev), step_rel=z, step_piece_ptr=z,
-                        step_mask=torch.zeros(1, dtype=torch.int64, device=dev), piece=torch.zeros(1, 2, dtype=torch.int32, device=dev),
+                        piece=torch.zeros(1, 2, dtype=torch.int32, device=dev),
                         col=z, w=torch.zeros(1, dtype=torch.float32, device=dev), n_steps=0, n_pieces=0, n_hubs=0,
                         hub_node=z, hub_ptr=z, n_slice_rows=0)
         seg_len = (seg_ptr[1:] - seg_ptr[:-1]).long()
@@ -373,20 +373,25 @@ class TypedNodeCSR:
         piece_key, piece_len = torch.unique_consecutive(pkey[order], return_counts=True)
         piece_e0 = torch.cumsum(piece_len, 0) - piece_len
         piece_row = piece_key % tile
-        step_key, step_np = torch.unique_consecutive(piece_key // tile, return_counts=True)
+        # a step holds at most `max_pieces` pieces (the kernel gives each of its 8 waves 4): the rest of a crowded
+        # (tile, relation, pass) goes to further steps of the same relation
+        base_key, base_np = torch.unique_consecutive(piece_key // tile, return_counts=True)
+        base_first = torch.cumsum(base_np, 0) - base_np
+        base_of_piece = torch.repeat_interleave(torch.arange(base_key.numel(), device=dev), base_np)
+        sub = (torch.arange(piece_key.numel(), device=dev) - base_first[base_of_piece]) // max_pieces
+        n_sub = int(sub.max()) + 1
+        step_key, step_np = torch.unique_consecutive(base_key[base_of_piece] * n_sub + sub, return_counts=True)
+        step_key = step_key // n_sub
         n_steps = int(step_key.numel())
         step_piece_ptr = torch.zeros(n_steps + 1, dtype=torch.int64, device=dev)
         step_piece_ptr[1:] = torch.cumsum(step_np, 0)
-        step_of_piece = torch.repeat_interleave(torch.arange(n_steps, device=dev), step_np)
-        step_mask = torch.zeros(n_steps, dtype=torch.int64, device=dev)
-        step_mask.scatter_add_(0, step_of_piece, torch.ones_like(piece_row) << piece_row)     # distinct rows: no carries
         steps_per_tile = torch.bincount(step_key // (passes * r), minlength=n_tiles)
         tile_step_ptr = torch.zeros(n_tiles + 1, dtype=torch.int64, device=dev)
         tile_step_ptr[1:] = torch.cumsum(steps_per_tile, 0)
         piece = torch.stack([piece_e0, piece_row | (piece_len << 8)], 1)
         return dict(n_tiles=n_tiles, tile_order=i32(torch.argsort(steps_per_tile, descending=True, stable=True)),
                     tile_step_ptr=i32(tile_step_ptr), step_rel=i32((step_key // passes) % r), step_piece_ptr=i32(step_piece_ptr),
-                    step_mask=step_mask.contiguous(), piece=i32(piece), col=col[order].contiguous(), w=w[order].contiguous(),
+                    piece=i32(piece), col=col[order].contiguous(), w=w[order].contiguous(),
                     n_steps=n_steps, n_pieces=int(piece_key.numel()), n_hubs=n_hubs, hub_node=i32(hub_node) if n_hubs else z,
                     hub_ptr=i32(hub_ptr), n_slice_rows=(n_tiles - n_real) * tile, max_steps=int(steps_per_tile.max()))
 

@@ -522,7 +522,7 @@ def rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans):
         if len(_RGCN_PACK_CACHE) >= 16:
             _RGCN_PACK_CACHE.clear()
         wc = weight.detach().contiguous()
-        packed = torch.empty(wc.shape[0] * 4 * (kl // 8) * 256, dtype=torch.float32, device=wc.device)
+        packed = torch.empty(wc.shape[0] * (d_out // 16) * (kl // 16) * 256, dtype=torch.float32, device=wc.device)
         check(_lib.lib().gd_rgcn_pack_weight_f32(ptr(wc), wc.shape[0], n_blocks, d_in, d_out, int(trans), ptr(packed),
                                                  stream_ptr(wc.device)), 'gd_rgcn_pack_weight_f32')
         hit = (packed, weight)
@@ -550,7 +550,7 @@ def rgcn_typed_accumulate(tg, x, weight, n_blocks, trans, y, edge_w=None):
             if y_ext is None:
                 y_ext = bufs[d_out] = torch.zeros(p['n_slice_rows'], d_out, dtype=torch.float32, device=x.device)
         check(_lib.lib().gd_rgcn_tile_conv_f32(ptr(p['tile_order']), ptr(p['tile_step_ptr']), ptr(p['step_rel']),
-                                               ptr(p['step_piece_ptr']), ptr(p['step_mask']), ptr(p['piece']), ptr(p['col']),
+                                               ptr(p['step_piece_ptr']), ptr(p['piece']), ptr(p['col']),
                                                ptr(p['w']), p['n_tiles'], ptr(x), x.stride(0), d_in, ptr(packed), n_blocks,
                                                int(trans), ptr(y), y.stride(0), d_out, tg.n, ptr(p['hub_node']) if p['n_hubs'] else None,
                                                ptr(p['hub_ptr']) if p['n_hubs'] else None, p['n_hubs'], ptr(y_ext),

@@ -202,18 +202,18 @@ int gd_rgcn_conv_f32(const int32_t* node_ptr, const int32_t* seg_ptr, const int3
                      float* y, int64_t ldy, int32_t d_out, int32_t n_nodes, void* stream);
 
 /* The same conv regrouped by (64-node tile, relation) so that a relation weight is fetched once per tile instead
- * of once per (node, relation) run, with the tile's outputs held in MFMA accumulators across all relations
+ * of once per (node, relation) run, with the tile's outputs held in LDS across all relations
  * (csrc/rgcn_tile.hip).  Supported: d_in, d_out in {64, 128}; weight = [R, 4, ib, ob] (the reference's num_blocks = 4,
  * framework/models/rgcn.py:17-22) or dense [R, 1, d_in, d_out]; gd_rgcn_tile_kl() returns the k range per wave (0 =
  * not supported: use gd_rgcn_conv_f32).
  *
- * packed_w: gd_rgcn_pack_weight_f32(weight [R, n_blocks, ib, ob], ...) -> R * 4 * (kl / 8) * 256 floats, the weight of
+ * packed_w: gd_rgcn_pack_weight_f32(weight [R, n_blocks, ib, ob], ...) -> R * (d_out / 16) * (kl / 16) * 256 floats, the weight of
  * this direction in the lane order of the MFMA operand (trans != 0: W_r^T; d_in / d_out are those of the direction).
  *
  * Tile plan of a typed graph (node-major, every (node, relation) run cut into pieces of <= 16 edges; the k-th piece of
  * a run belongs to pass k): steps are the distinct (tile = node / 64, relation, pass) triples in ascending order,
  *     tile_step_ptr[n_tiles + 1]   steps of a tile              step_rel[S]        relation of a step
- *     step_piece_ptr[S + 1]        pieces of a step             step_mask[S]       bit (node % 64) per piece
+ *     step_piece_ptr[S + 1]        pieces of a step (at most 32; a crowded (tile, relation, pass) continues in the next step)
  *     piece[P][2]                  {first edge, (node % 64) | length << 8}, at most one piece per node and step
  *     col[E], w[E]                 source node and weight per edge, in (step, node % 64, source) order
  *     tile_order[n_tiles]          launch order of the tiles (most steps first) or NULL
@@ -227,7 +227,7 @@ int32_t gd_rgcn_tile_kl(int32_t d_in, int32_t d_out, int32_t n_blocks, int32_t t
 int gd_rgcn_pack_weight_f32(const float* weight, int32_t n_rel, int32_t n_blocks, int32_t d_in, int32_t d_out,
                             int32_t trans, float* packed, void* stream);
 int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* tile_step_ptr, const int32_t* step_rel,
-                          const int32_t* step_piece_ptr, const int64_t* step_mask, const int32_t* piece,
+                          const int32_t* step_piece_ptr, const int32_t* piece,
                           const int32_t* col, const float* w, int32_t n_tiles, const float* x, int64_t ldx,
                           int32_t d_in, const float* packed_w, int32_t n_blocks, int32_t trans, float* y, int64_t ldy,
                           int32_t d_out, int32_t n_nodes, const int32_t* hub_node, const int32_t* hub_ptr, int32_t n_hubs,

@@ -536,6 +536,7 @@ def test_rgcn_tile_conv_matches_oracle_and_node_major(n, m, R, din, dout, nb, mo
     tg = TypedNodeCSR(ei.cuda(), et.cuda(), n, R)
     plan = tg.tile_plan(False)
     assert plan['n_pieces'] >= plan['n_steps'] > 0 and int(plan['piece'][:, 1].max()) >> 8 <= 16
+    assert int((plan['step_piece_ptr'][1:] - plan['step_piece_ptr'][:-1]).max()) <= 32
 
     def run():
         xg = x.float().cuda().requires_grad_(True)
