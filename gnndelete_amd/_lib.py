@@ -38,10 +38,10 @@ PROTOTYPES = {
     'gd_gat_balanced_scratch': (_i64, [_i32, _i32]),
     'gd_gat_aggregate_balanced_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p,
                                                      _p, _f32, _i32, _i32, _i32, _p]),
-    'gd_gat_edge_grads_balanced_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p,
+    'gd_gat_edge_grads_balanced_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p,
                                                       _p, _p, _p, _f32, _i32, _i32, _p]),
     'gd_row_dots_f32': (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
-    'gd_gat_transpose_edges_f32': (ctypes.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p]),
+    'gd_gat_transpose_edges_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p, _p]),
     'gd_rank1_add2_f32': (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
     'gd_segment_sum_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p]),
     'gd_rows_gemm_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _i64, _p, _p]),

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void gat_items_bwd_dalpha_kernel(
     const int4* __restrict__ items, int32_t n_items, const int32_t* __restrict__ col,
     const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ rowmax,
     const float* __restrict__ rowsum, const float* __restrict__ h, int64_t ldh, const float* __restrict__ dy,
-    int64_t lddy, float* __restrict__ alpha, float* __restrict__ de, float* __restrict__ t_row,
+    int64_t lddy, float2* __restrict__ ade, float* __restrict__ t_row,
     float* __restrict__ da_dst, float* __restrict__ scratch_t, float slope, int32_t d4, int32_t nnz) {
   constexpr int G = kWave / LPR;
   constexpr int U = 4;                                             // neighbour rows in flight per lane group
@@ -532,8 +532,8 @@ __global__ __launch_bounds__(256) void gat_items_bwd_dalpha_kernel(
     }
     const float e = leaky(as + ad, slope);
     const float al = lane < cnt ? expf(e - rm) / (rs + 1e-16f) : 0.f;
-    if (lane < cnt) alpha[start + lane] = al;
-    // one coalesced store of the item's edge values and the attention-weighted sum, edge per lane
+    // one coalesced 8-byte store of the item's edge values (alpha, score gradient) - interleaved, because the
+    // source-major pass gathers both through the edge permutation: one 64-byte sector per edge instead of two and the attention-weighted sum, edge per lane
     // (LDS operations of one wave complete in order: no barrier needed)
     const float pj = lane < cnt ? pw[lane] : 0.f;
     float tpart = al * pj;
@@ -542,13 +542,13 @@ __global__ __launch_bounds__(256) void gat_items_bwd_dalpha_kernel(
       // the item is the whole row: t_i = sum_j alpha_ij <dy_i, h_j> is complete, so the score gradient
       // de_ij = alpha_ij (<dy_i, h_j> - t_i) leaky'(s_ij) and da_dst_i = sum_j de_ij are finished here
       float v = lane < cnt ? al * (pj - tpart) * (as + ad > 0.f ? 1.0f : slope) : 0.f;
-      if (lane < cnt) de[start + lane] = v;
+      if (lane < cnt) ade[start + lane] = make_float2(al, v);
       v = wave_sum(v);
       if (lane == 0) { t_row[row] = tpart; da_dst[row] = v; }
     } else {
       // a piece of a split row: park <dy_i, h_j> and the partial t; gat_items_bwd_de_kernel finishes the
       // pieces once the row's t is summed
-      if (lane < cnt) de[start + lane] = pj;
+      if (lane < cnt) ade[start + lane] = make_float2(al, pj);
       if (lane == 0) scratch_t[slot] = tpart;
     }
     d0 = d1;
@@ -569,8 +569,8 @@ __global__ __launch_bounds__(256) void scalar_fixup_kernel(const int4* __restric
 // backward pass 2 (edge-parallel inside pieces): de_k = alpha_k (d_alpha_k - t_i) leaky'(s_k); da_dst partials
 __global__ __launch_bounds__(256) void gat_items_bwd_de_kernel(
     const int4* __restrict__ items, int32_t n_items, const int32_t* __restrict__ col,
-    const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ alpha,
-    const float* __restrict__ t_row, float* __restrict__ de, float* __restrict__ scratch_d, float slope, int32_t nnz) {
+    const float* __restrict__ a_src, const float* __restrict__ a_dst, float2* __restrict__ ade,
+    const float* __restrict__ t_row, float* __restrict__ scratch_d, float slope, int32_t nnz) {
   // Only the pieces of split rows are left for this pass (whole rows were finished by
   // gat_items_bwd_dalpha_kernel): a wave looks at kPer consecutive descriptors and skips the whole rows.
   constexpr int kPer = 4;
@@ -588,8 +588,9 @@ __global__ __launch_bounds__(256) void gat_items_bwd_de_kernel(
     if (lane < cnt) {
       const int k = start + lane;
       const float s = a_src[col[k]] + a_dst[row];
-      v = alpha[k] * (de[k] - t_row[row]) * (s > 0.f ? 1.0f : slope);
-      de[k] = v;
+      const float2 ad = ade[k];
+      v = ad.x * (ad.y - t_row[row]) * (s > 0.f ? 1.0f : slope);
+      ade[k] = make_float2(ad.x, v);
     }
     v = wave_sum(v);
     if (lane == 0) scratch_d[slot] = v;
@@ -652,14 +653,13 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const int32_t* __restr
 }
 
 // Edge quantities of the GAT backward moved to the transposed (source-major) edge order in one pass:
-//   alpha_t[k] = alpha[perm[k]]                 (the weights of the transposed SpMM that forms dh)
-//   da_src[j]  = sum_{k in row j} de[perm[k]]   (gradient of the source attention logit)
+//   alpha_t[k] = ade[perm[k]].x                 (the weights of the transposed SpMM that forms dh)
+//   da_src[j]  = sum_{k in row j} ade[perm[k]].y (gradient of the source attention logit)
 // 8 lanes per source row (8 rows per wave; the typical row has ~8 out-edges), rows with more than 256
 // out-edges are redone by the whole wave.  Fixed summation order per row (deterministic).
 __global__ __launch_bounds__(256) void gat_transpose_edge_kernel(const int32_t* __restrict__ rowptr_t,
                                                                  const int32_t* __restrict__ perm,
-                                                                 const float* __restrict__ alpha,
-                                                                 const float* __restrict__ de, int32_t n,
+                                                                 const float2* __restrict__ ade, int32_t n,
                                                                  float* __restrict__ alpha_t,
                                                                  float* __restrict__ da_src) {
   const int lane = threadIdx.x & 63;
@@ -672,9 +672,9 @@ __global__ __launch_bounds__(256) void gat_transpose_edge_kernel(const int32_t* 
   float s = 0.f;
   if (!heavy)
     for (int k = start + li; k < end; k += 8) {
-      const int p = perm[k];
-      alpha_t[k] = alpha[p];
-      s += de[p];
+      const float2 ad = ade[perm[k]];
+      alpha_t[k] = ad.x;
+      s += ad.y;
     }
   s = lanes_sum<8>(s);
   if (r < n && !heavy && li == 0) da_src[r] = s;
@@ -686,9 +686,9 @@ __global__ __launch_bounds__(256) void gat_transpose_edge_kernel(const int32_t* 
     const int s2 = rowptr_t[r2], e2 = rowptr_t[r2 + 1];
     float t = 0.f;
     for (int k = s2 + lane; k < e2; k += kWave) {
-      const int p = perm[k];
-      alpha_t[k] = alpha[p];
-      t += de[p];
+      const float2 ad = ade[perm[k]];
+      alpha_t[k] = ad.x;
+      t += ad.y;
     }
     t = wave_sum(t);
     if (lane == 0) da_src[r2] = t;
@@ -836,15 +836,16 @@ extern "C" int gd_gat_edge_grads_balanced_f32(const int32_t* items, int32_t n_it
                                               int32_t n_split, const int32_t* col, const float* a_src,
                                               const float* a_dst, const float* rowmax, const float* rowsum,
                                               const float* h, int64_t ldh, const float* dy, int64_t lddy,
-                                              float* alpha, float* de, float* da_dst, float* t_row, float* scratch,
+                                              float* ade, float* da_dst, float* t_row, float* scratch,
                                               float slope, int32_t d, int32_t nnz, void* stream) {
   using namespace gd;
-  GD_REQUIRE(items && col && a_src && a_dst && rowmax && rowsum && h && dy && alpha && de && da_dst && t_row, GD_E_NULL,
+  GD_REQUIRE(items && col && a_src && a_dst && rowmax && rowsum && h && dy && ade && da_dst && t_row, GD_E_NULL,
              "gd_gat_edge_grads_balanced_f32: null pointer");
   GD_REQUIRE(n_split == 0 || (split && scratch), GD_E_NULL, "gd_gat_edge_grads_balanced_f32: split rows need scratch");
   GD_REQUIRE(d > 0 && d % 4 == 0 && d <= 1024 && ldh % 4 == 0 && lddy % 4 == 0 && (d & (d - 1)) == 0, GD_E_DIM,
              "gd_gat_edge_grads_balanced_f32: d=%d must be a power of two in [4,1024]", d);
-  GD_REQUIRE(aligned16(h) && aligned16(dy) && aligned16(items), GD_E_ALIGN, "gd_gat_edge_grads_balanced_f32: unaligned");
+  GD_REQUIRE(aligned16(h) && aligned16(dy) && aligned16(items) && (reinterpret_cast<uintptr_t>(ade) & 7u) == 0, GD_E_ALIGN,
+             "gd_gat_edge_grads_balanced_f32: unaligned");
   if (n_items == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
   const int d4 = d / 4;
@@ -853,8 +854,8 @@ extern "C" int gd_gat_edge_grads_balanced_f32(const int32_t* items, int32_t n_it
   const dim3 grid((nblk + 7) / 8 * 8);
   const int4* it = reinterpret_cast<const int4*>(items);
   const int4* sp = reinterpret_cast<const int4*>(split);
-  GD_GAT_ITEMS(gat_items_bwd_dalpha_kernel, it, n_items, col, a_src, a_dst, rowmax, rowsum, h, ldh, dy, lddy, alpha, de,
-               t_row, da_dst, scratch, slope, d4, nnz);
+  GD_GAT_ITEMS(gat_items_bwd_dalpha_kernel, it, n_items, col, a_src, a_dst, rowmax, rowsum, h, ldh, dy, lddy,
+               reinterpret_cast<float2*>(ade), t_row, da_dst, scratch, slope, d4, nnz);
   int rc = launched("gat_items_bwd_dalpha");
   if (rc) return rc;
   if (n_split) {
@@ -864,7 +865,7 @@ extern "C" int gd_gat_edge_grads_balanced_f32(const int32_t* items, int32_t n_it
   if (n_split) {
     // only the pieces of split rows are left (whole rows exit at once)
     hipLaunchKernelGGL(gat_items_bwd_de_kernel, dim3((n_items + 15) / 16), dim3(256), 0, s, it, n_items, col, a_src,
-                       a_dst, alpha, t_row, de, scratch, slope, nnz);
+                       a_dst, reinterpret_cast<float2*>(ade), t_row, scratch, slope, nnz);
     if ((rc = launched("gat_items_bwd_de"))) return rc;
     hipLaunchKernelGGL(scalar_fixup_kernel, dim3((n_split + 255) / 256), dim3(256), 0, s, sp, n_split, scratch, da_dst);
     rc = launched("gat_fixup_dadst");
@@ -918,12 +919,13 @@ extern "C" int gd_rank1_add2_f32(float* y, int64_t ldy, int32_t n, int32_t d, co
   return launched("rank1_add2");
 }
 
-extern "C" int gd_gat_transpose_edges_f32(const int32_t* rowptr_t, const int32_t* perm, const float* alpha,
-                                          const float* de, int32_t n, float* alpha_t, float* da_src, void* stream) {
+extern "C" int gd_gat_transpose_edges_f32(const int32_t* rowptr_t, const int32_t* perm, const float* ade, int32_t n,
+                                          float* alpha_t, float* da_src, void* stream) {
   using namespace gd;
   if (n <= 0) return GD_OK;
-  GD_REQUIRE(rowptr_t && perm && alpha && de && alpha_t && da_src, GD_E_NULL, "gd_gat_transpose_edges_f32: null pointer");
+  GD_REQUIRE(rowptr_t && perm && ade && alpha_t && da_src && (reinterpret_cast<uintptr_t>(ade) & 7u) == 0, GD_E_NULL,
+             "gd_gat_transpose_edges_f32: null or unaligned pointer");
   hipLaunchKernelGGL(gat_transpose_edge_kernel, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, rowptr_t, perm,
-                     alpha, de, n, alpha_t, da_src);
+                     reinterpret_cast<const float2*>(ade), n, alpha_t, da_src);
   return launched("gat_transpose_edges");
 }

@@ -403,9 +403,9 @@ def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope, plan=Non
     n, d = g.n, h.shape[1]
     dev = h.device
     da_dst = torch.empty(n, dtype=torch.float32, device=dev)
-    de = torch.empty(g.nnz, dtype=torch.float32, device=dev)
     if rowsum is None:                     # saved alpha from the row kernel
         alpha = rowmax
+        de = torch.empty(g.nnz, dtype=torch.float32, device=dev)
         dh = torch.empty_like(h)
         da_src = torch.empty(n, dtype=torch.float32, device=dev)
         check(_lib.lib().gd_gat_aggregate_bwd_f32(
@@ -415,19 +415,18 @@ def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope, plan=Non
         return dh, da_src, da_dst
     subset = plan is not None
     plan = plan or g.plan
-    # (edges of rows outside a subset are never computed: keep them finite for the transposition pass)
-    alpha = (torch.zeros if subset else torch.empty)(g.nnz, dtype=torch.float32, device=dev)
-    if subset:
-        de.zero_()
+    # per edge (alpha, score gradient) interleaved; edges of rows outside a subset are never computed: keep them finite
+    # (zero) for the transposition pass
+    ade = (torch.zeros if subset else torch.empty)(g.nnz, 2, dtype=torch.float32, device=dev)
     t_row = torch.empty(n, dtype=torch.float32, device=dev)
     scratch = plan.scratch_flat('gat_bwd', max(4, plan.n_slots), dev)
     check(_lib.lib().gd_gat_edge_grads_balanced_f32(
         ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split, ptr(g.col), ptr(a_src), ptr(a_dst), ptr(rowmax),
-        ptr(rowsum), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(alpha), ptr(de), ptr(da_dst), ptr(t_row),
+        ptr(rowsum), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(ade), ptr(da_dst), ptr(t_row),
         ptr(scratch), float(slope), d, g.nnz, stream_ptr(dev)), 'gd_gat_edge_grads_balanced_f32')
-    alpha_t = torch.empty_like(alpha)
+    alpha_t = torch.empty(g.nnz, dtype=torch.float32, device=dev)
     da_src = torch.empty(n, dtype=torch.float32, device=dev)
-    check(_lib.lib().gd_gat_transpose_edges_f32(ptr(g.rowptr_t), ptr(g.perm_t), ptr(alpha), ptr(de), n, ptr(alpha_t),
+    check(_lib.lib().gd_gat_transpose_edges_f32(ptr(g.rowptr_t), ptr(g.perm_t), ptr(ade), n, ptr(alpha_t),
                                                 ptr(da_src), stream_ptr(dev)), 'gd_gat_transpose_edges_f32')
     dh = _spmm_raw(g.rowptr_t, g.col_t, alpha_t, dy, None, 0.0, n, plan_t or g.plan_t)
     return dh, da_src, da_dst

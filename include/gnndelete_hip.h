@@ -149,10 +149,11 @@ int gd_gat_aggregate_bwd_f32(const int32_t* rowptr, const int32_t* col, const fl
  * per-edge attention it returns the row statistics rowmax[n] / rowsum[n] (alpha_k =
  * exp(e_k - rowmax_i) / (rowsum_i + 1e-16)).  d must be a power of two in [4, 1024];
  * scratch: gd_gat_balanced_scratch(n_slots, d) floats.
- * gd_gat_edge_grads_balanced_f32 is the target-major half of the backward: alpha[nnz] (rebuilt),
- * de[nnz] = d loss / d score, da_dst[n]; t_row[n] and scratch (n_slots floats) are work space.
- * The source-major half (dh = sum alpha dy, da_src = sum de) is gd_spmm_csr_balanced_f32 on the
- * transposed CSR with val = alpha permuted, plus a segment sum of de. */
+ * gd_gat_edge_grads_balanced_f32 is the target-major half of the backward: ade[nnz][2] = per edge
+ * (alpha rebuilt, d loss / d score) interleaved - the source-major half gathers both through the edge
+ * permutation, one sector per edge this way -, da_dst[n]; t_row[n] and scratch (n_slots floats) are work
+ * space.  The source-major half (dh = sum alpha dy, da_src = sum de) is gd_gat_transpose_edges_f32 +
+ * gd_spmm_csr_balanced_f32 on the transposed CSR with val = alpha_t. */
 int64_t gd_gat_balanced_scratch(int32_t n_slots, int32_t d);
 int gd_gat_aggregate_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
                                   int32_t n_slots, const int32_t* col, const float* a_src, const float* a_dst,
@@ -162,7 +163,7 @@ int gd_gat_aggregate_balanced_f32(const int32_t* items, int32_t n_items, const i
 int gd_gat_edge_grads_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
                                    const int32_t* col, const float* a_src, const float* a_dst,
                                    const float* rowmax, const float* rowsum, const float* h, int64_t ldh,
-                                   const float* dy, int64_t lddy, float* alpha, float* de, float* da_dst,
+                                   const float* dy, int64_t lddy, float* ade, float* da_dst,
                                    float* t_row, float* scratch, float slope, int32_t d, int32_t nnz, void* stream);
 
 /* GAT attention logits: a1[i] = <h[i,:], v1>, a2[i] = <h[i,:], v2> in one pass over h
@@ -182,11 +183,11 @@ int gd_rank1_add2_f32(float* y, int64_t ldy, int32_t n, int32_t d, const float* 
                       const float* b, const float* v, void* stream);
 
 /* GAT backward, edge quantities moved to the transposed (source-major) edge order in one pass:
- * alpha_t[k] = alpha[perm[k]] (weights of the transposed SpMM that forms dh) and
- * da_src[j] = sum_{k in source row j} de[perm[k]] (gradient of alpha_src); perm = position of
- * transposed edge k in the forward CSR. */
-int gd_gat_transpose_edges_f32(const int32_t* rowptr_t, const int32_t* perm, const float* alpha, const float* de,
-                               int32_t n, float* alpha_t, float* da_src, void* stream);
+ * alpha_t[k] = ade[perm[k]][0] (weights of the transposed SpMM that forms dh) and
+ * da_src[j] = sum_{k in source row j} ade[perm[k]][1] (gradient of alpha_src); perm = position of
+ * transposed edge k in the forward CSR; ade as written by gd_gat_edge_grads_balanced_f32. */
+int gd_gat_transpose_edges_f32(const int32_t* rowptr_t, const int32_t* perm, const float* ade, int32_t n,
+                               float* alpha_t, float* da_src, void* stream);
 
 /* Fused R-GCN message passing (PyG RGCNConv aggr='mean', framework/models/rgcn.py:16-38) for constant
  * relation weights - no [R, N, d] per-relation aggregate is formed:
