@@ -30,7 +30,8 @@ constexpr int kGemmThreads = 512;   // 8 waves share one LDS weight image; 2 blo
 struct RowDots { const float* u1; const float* u2; float* o1; float* o2; };
 
 // MODE 0: plain, 1: also emit the packed sign pattern of the output, 2: gate the output by such a pattern,
-// 3: plain + the two row dot products of RowDots
+// 3: plain + the two row dot products of RowDots, 4: gated like 2 after a rank-1 correction of the product,
+//    out[r, n] += o1[r] u1[n] + o2[r] u2[n] (RowDots reused: o1 / o2 per-row scalars READ by row id, u1 / u2 per column)
 // SEL: rows may come from a second buffer (in_alt where sel[r] != 0); only instantiated for MODE 0 and 3
 template <int NT, int MODE, bool SEL = false>
 __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
@@ -103,10 +104,12 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // packed ReLU gate of this lane's row (one bit per output feature), in flight during the k loop
     uint32_t gate_w[NT];
-    if (MODE == 2) {
+    float r1a = 0.f, r1b = 0.f;                  // MODE 4: this row's two rank-1 coefficients
+    if (MODE == 2 || MODE == 4) {
       const uint32_t* gsrc = gate_bits + (int64_t)min(s_a, n_sel - 1) * NT;
 #pragma unroll
       for (int t = 0; t < NT; ++t) gate_w[t] = gsrc[t];
+      if (MODE == 4) { r1a = dots.o1[row_cur]; r1b = dots.o2[row_cur]; }
     }
 
     for (int kc = 0; kc < kchunks; ++kc) {
@@ -175,7 +178,13 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
           dot1 = fmaf(v.x, p1.x, dot1); dot1 = fmaf(v.y, p1.y, dot1); dot1 = fmaf(v.z, p1.z, dot1); dot1 = fmaf(v.w, p1.w, dot1);
           dot2 = fmaf(v.x, p2.x, dot2); dot2 = fmaf(v.y, p2.y, dot2); dot2 = fmaf(v.z, p2.z, dot2); dot2 = fmaf(v.w, p2.w, dot2);
         }
-        if (MODE == 2) {   // ReLU backward: pass the gradient where the forward activation input was > 0
+        if (MODE == 4) {
+          const float4 p1 = *reinterpret_cast<const float4*>(dots.u1 + n0 + 4 * khalf);
+          const float4 p2 = *reinterpret_cast<const float4*>(dots.u2 + n0 + 4 * khalf);
+          v.x = fmaf(r1b, p2.x, fmaf(r1a, p1.x, v.x)); v.y = fmaf(r1b, p2.y, fmaf(r1a, p1.y, v.y));
+          v.z = fmaf(r1b, p2.z, fmaf(r1a, p1.z, v.z)); v.w = fmaf(r1b, p2.w, fmaf(r1a, p1.w, v.w));
+        }
+        if (MODE == 2 || MODE == 4) {   // ReLU backward: pass the gradient where the forward activation input was > 0
           const uint32_t m = gate_w[t] >> (8 * q + 4 * khalf);
           v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f;
           v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
@@ -588,7 +597,8 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
                      n_sel, w, d_in, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out, in_alt, sel, dots)
 #define GD_RG_CASE(NT)                                                                                            \
   do {                                                                                                            \
-    if (gate_bits) GD_RG_LAUNCH(NT, 2);                                                                           \
+    if (gate_bits && dots.u1) GD_RG_LAUNCH(NT, 4);                                                                \
+    else if (gate_bits) GD_RG_LAUNCH(NT, 2);                                                                      \
     else if (sign_out) GD_RG_LAUNCH(NT, 1);                                                                       \
     else if (dots.u1 && sel)                                                                                      \
       hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT, 3, true>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in,  \
@@ -662,6 +672,18 @@ extern "C" int gd_rows_gemm_gated_f32(const float* in, int64_t ld_in, const int3
   GD_REQUIRE(gate_bits, GD_E_NULL, "gd_rows_gemm_gated_f32: null gate");
   return rows_gemm_impl(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, nullptr, 0, gate_bits, nullptr, out, ld_out,
                         nullptr, stream);
+}
+
+extern "C" int gd_rows_gemm_gated_rank1_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel,
+                                            const float* w, int32_t d_in, int32_t d_out, int32_t trans_w,
+                                            const uint32_t* gate_bits, const float* row_a, const float* col_p,
+                                            const float* row_b, const float* col_q, float* out, int64_t ld_out,
+                                            void* stream) {
+  GD_REQUIRE(gate_bits && row_a && col_p && row_b && col_q, GD_E_NULL, "gd_rows_gemm_gated_rank1_f32: null pointer");
+  GD_REQUIRE(gd::aligned16(col_p) && gd::aligned16(col_q), GD_E_ALIGN, "gd_rows_gemm_gated_rank1_f32: unaligned column vectors");
+  return rows_gemm_impl(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, nullptr, 0, gate_bits, nullptr, out, ld_out,
+                        nullptr, stream, nullptr, nullptr,
+                        gd::RowDots{col_p, col_q, const_cast<float*>(row_a), const_cast<float*>(row_b)});
 }
 
 extern "C" int64_t gd_rows_gemm_wgrad_workspace(int32_t n_sel, int32_t d_a, int32_t d_b) {

@@ -295,6 +295,11 @@ class NodeembEngine:
                 self._fuse_loss1 = True
         self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat', SAGEConv: 'sage', RGCNConv: 'rgcn'}[type(conv2)]
         self._gat_dots = os.environ.get('GD_NO_GAT_DOTS') != '1'      # attention logits from the GEMM epilogue
+        self._gat_r1 = None                                            # (att_src W2, att_dst W2): constants of the frozen conv2
+        if self._mode == 'gat':
+            w2_ = conv2.lin_src.weight.detach()
+            self._gat_r1 = ((conv2.att_src.detach().reshape(1, -1) @ w2_).reshape(-1).float().contiguous(),
+                            (conv2.att_dst.detach().reshape(1, -1) @ w2_).reshape(-1).float().contiguous())
         if self._mode == 'rgcn':
             from .graph import TypedNodeCSR
             self.typed = TypedNodeCSR(edge_index, edge_type.to(dev), n, conv2.num_relations)
@@ -548,8 +553,15 @@ class NodeembEngine:
                                                    self.dz2, c.negative_slope,
                                                    plan=self._plan2 if self._rows_only else None,
                                                    plan_t=self._plan_t1 if self._rows_only else None)
-            ops.rank1_add2_(dt2, da_s, c.att_src, da_d, c.att_dst)
             w2 = c.lin_src.weight
+            if self._mfma_weight(w2) and os.environ.get('GD_NO_GAT_RANK1_EPILOGUE') != '1':
+                # dh2 = A_alpha^T dy + da_src (x) att_src + da_dst (x) att_dst only feeds the product below: the two
+                # rank-1 terms are added on ITS output side, (a (x) u) W2 = a (x) (u W2), with u W2 constants of the
+                # frozen backbone - the pass over dh2 (gd_rank1_add2_f32) disappears
+                ops.rows_gemm(dt2, self.idx1, w2, trans_w=False, out=self.dh, gate_bits=self.z1_pos,
+                              rank1=(da_s, self._gat_r1[0], da_d, self._gat_r1[1]))
+                return
+            ops.rank1_add2_(dt2, da_s, c.att_src, da_d, c.att_dst)
         # dh[S1] = (dt2[S1] @ W2) * [z1[S1] > 0]   (W2 is [out, in] = [d_in, d_out] of this product; the
         # ReLU backward is applied in the GEMM epilogue so dh can outlive this iteration's z1)
         ops.rows_gemm(dt2, self.idx1, w2, trans_w=False, out=self.dh, gate_bits=self.z1_pos)

@@ -91,10 +91,12 @@ def _const_weight(w, trans_w):
 
 
 def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, save_in=None, gate_bits=None,
-              sign_bits=None, const_w=False):
+              sign_bits=None, const_w=False, rank1=None):
     """out[idx] = act(inp[idx]) @ (w or w^T) - raw call (no autograd).
     sign_bits (int32 [n_sel, ceil(d_out/32)], written): packed [out > 0] of the rows just produced;
     gate_bits (same layout, read): zero the product where the bit is clear (ReLU backward in the epilogue);
+    rank1 = (row_a [N], col_p [d_out], row_b [N], col_q [d_out]), with gate_bits: the product gets
+    row_a[r] col_p + row_b[r] col_q added before the gate (MFMA widths only);
     const_w: the weight is constant across calls (see _const_weight)."""
     inp = _f32_rows(inp)
     if const_w:
@@ -110,6 +112,13 @@ def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, sa
     if gate_bits is not None:
         assert bias is None and not relu_in and save_in is None and sign_bits is None
         assert gate_bits.dtype == torch.int32 and gate_bits.is_contiguous() and gate_bits.numel() >= n_sel * n_words
+        if rank1 is not None:
+            ra, cp, rb, cq = rank1
+            check(_lib.lib().gd_rows_gemm_gated_rank1_f32(ptr(inp), inp.stride(0), ptr(idx), n_sel, ptr(w), d_in, d_out,
+                                                          int(trans_w), ptr(gate_bits), ptr(ra), ptr(cp), ptr(rb), ptr(cq),
+                                                          ptr(out), out.stride(0), stream_ptr(inp.device)),
+                  'gd_rows_gemm_gated_rank1_f32')
+            return out
         check(_lib.lib().gd_rows_gemm_gated_f32(ptr(inp), inp.stride(0), ptr(idx), n_sel, ptr(w), d_in, d_out,
                                                 int(trans_w), ptr(gate_bits), ptr(out), out.stride(0),
                                                 stream_ptr(inp.device)), 'gd_rows_gemm_gated_f32')

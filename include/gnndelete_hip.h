@@ -294,6 +294,17 @@ int gd_rows_gemm_gated_f32(const float* in, int64_t ld_in, const int32_t* idx, i
                            const float* w, int32_t d_in, int32_t d_out, int32_t trans_w,
                            const uint32_t* gate_bits, float* out, int64_t ld_out, void* stream);
 
+/* The same with a rank-2 correction of the product before the gate:
+ *       out[r,n] = gate bit (s,n) ? (in[r,:] @ W)[n] + row_a[r] col_p[n] + row_b[r] col_q[n] : 0
+ * GAT's input gradient dh2 = A_alpha^T dy + da_src (x) att_src + da_dst (x) att_dst (framework/models/gat.py through
+ * PyG's GATConv) feeds this product; with col_p = att_src @ W, col_q = att_dst @ W (constants of a frozen
+ * backbone) the rank-1 terms are added here, on the output side, and the separate pass over dh2 disappears.
+ * MFMA widths only (d_in, d_out multiples of 32, d_out <= 128). */
+int gd_rows_gemm_gated_rank1_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel,
+                                 const float* w, int32_t d_in, int32_t d_out, int32_t trans_w,
+                                 const uint32_t* gate_bits, const float* row_a, const float* col_p,
+                                 const float* row_b, const float* col_q, float* out, int64_t ld_out, void* stream);
+
 /* Weight gradient of the row-subset GEMM:  dW[d_a, d_b] (+)= sum_s a[ia(s),:]^T g[ig(s),:]
  *   ia(s) = a_idx ? a_idx[s] : s, likewise g_idx.  Deterministic split-K: `partials` must hold
  *   gd_rows_gemm_wgrad_workspace(n_sel, d_a, d_b) floats.  accumulate != 0 adds into dW.

@@ -895,3 +895,31 @@ def test_random_walk_kernel_and_device_sampler():
     for k in ('edge_index', 'x', 'edge_flag'):
         assert torch.equal(hb[k], db[k].cpu()), k
     assert make_sampler(data, 10, 1).dev.type == 'cuda'
+
+
+@pytest.mark.parametrize('n,d_in,d_out', [(500, 64, 128), (77, 128, 64), (1000, 32, 32)])
+def test_rows_gemm_gated_rank1_matches_fp64(n, d_in, d_out):
+    """gd_rows_gemm_gated_rank1_f32: out[r] = gate(in[r] @ W + a[r] p + b[r] q) on a row subset - the GAT input gradient's
+    two rank-1 terms moved to the output side of the product that consumes it; rows outside the subset untouched."""
+    from gnndelete_amd import ops
+    g = torch.Generator().manual_seed(n + d_in)
+    x = torch.randn(n, d_in, generator=g)
+    w = torch.randn(d_in, d_out, generator=g) / d_in ** 0.5
+    a, b = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    p, q = torch.randn(d_out, generator=g), torch.randn(d_out, generator=g)
+    idx = torch.randperm(n, generator=g)[:n // 2].sort().values.to(torch.int32)
+    z = torch.randn(idx.numel(), d_out, generator=g)                  # the forward activations whose sign gates the product
+    words = (d_out + 31) // 32
+    bits = torch.zeros(idx.numel(), words, dtype=torch.int64)
+    for c in range(d_out):
+        bits[:, c // 32] |= (z[:, c] > 0).long() << (c % 32)
+    bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32)
+    out = torch.full((n, d_out), -3.0).cuda()
+    ops.rows_gemm(x.cuda(), idx.cuda(), w.cuda(), trans_w=False, out=out, gate_bits=bits.cuda().contiguous(),
+                  rank1=(a.cuda(), p.cuda(), b.cuda(), q.cuda()))
+    rows = idx.long()
+    want = (x.double()[rows] @ w.double() + a.double()[rows, None] * p.double() + b.double()[rows, None] * q.double()) * (z > 0)
+    assert rel_l2(out.cpu()[rows], want) < TOL
+    rest = torch.ones(n, dtype=torch.bool)
+    rest[rows] = False
+    assert bool((out.cpu()[rest] == -3.0).all())
