@@ -265,7 +265,6 @@ def spmm_algorithmic_bytes(n, nnz, d):
 def time_dominant_kernel(eng, reps=20):
     """Average duration of the layer-1 SpMM (d = 128), launched back to back on the current
     stream between two HIP events, with the same operands the step uses."""
-    from gnndelete_amd import _lib
     g = eng.graph
     h = eng.h
     t1 = torch.randn(eng.n, h, device=eng.x.device)

@@ -30,7 +30,6 @@ rows; the halo rows' partials travel back to their owners in the reverse all-to-
 order (deterministic).  The fused single-GPU configuration is required: folded DEC + NI terms, every loss row inside its Del row
 list (always so for the reference's masks), MFMA widths."""
 import torch
-import torch.distributed as dist
 
 from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
