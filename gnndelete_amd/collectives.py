@@ -8,8 +8,14 @@
   all_reduce_sum    one packed fp32 buffer per step: the partial Del-weight gradients
                     (128^2 + 128^2 + 64^2 floats) and the four loss sums.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# GD_FORCE_COLLECTIVES=1: issue the collectives even in a world of one - lets a one-GPU box drive the real RCCL calls
+# (tests/test_dist_cpu.py::test_partitioned_engine_over_rccl_in_a_world_of_one)
+_FORCE = os.environ.get('GD_FORCE_COLLECTIVES') == '1'
 
 
 def row_blocks(n, world):
@@ -31,7 +37,7 @@ def all_gather_rows(full, rank, world, chunk, group=None):
 
 
 def all_reduce_sum(buf, world, group=None):
-    if world > 1:
+    if world > 1 or _FORCE:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
 
 
@@ -82,7 +88,7 @@ def exchange_rows(send_buf, recv_buf, plan, world, group=None):
     RCCL ("nccl") moves device buffers directly and any failure propagates - a silent detour through the host would
     turn a broken transport into a 100x slowdown.  gloo (the CPU-side test backend) has no device all-to-all: there,
     and only there, the buffers are staged through the host."""
-    if world == 1:
+    if world == 1 and not _FORCE:
         return
     send, recv = send_buf[:plan.n_send], recv_buf[:plan.n_recv]
     if dist.get_backend(group) == 'gloo' and send.is_cuda:

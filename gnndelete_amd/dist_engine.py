@@ -33,6 +33,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
+from . import collectives as _collectives
 from .collectives import all_reduce_sum, exchange_rows, exchange_rows_reverse, halo_plan, row_blocks
 from .engine import LOSS_TYPES, _Adam, _LayerTerms, _loss_coefficients, _loss_slots, _rows_inside
 from .graph import SplitPlan, graph_for
@@ -368,7 +369,7 @@ class PartitionedNodeembEngine:
         return [self._seg_a, self._seg_b, self._seg_c, self._seg_d]
 
     def _exchange(self, after_segment):
-        if self.world == 1:
+        if self.world == 1 and not _collectives._FORCE:
             return
         gat = self._mode == 'gat'
         if after_segment == 0 and self.loss_type != 'only1':

@@ -203,7 +203,7 @@ def emulate_partitioned_step(kind, rank, world, data, neg, ni1, ni2, f, h, o):
     assert torch.allclose(g2, want2, rtol=1e-3, atol=1e-7), (kind, float((g2 - want2).abs().max()))
 
 
-def gpu_checks(rank, world):
+def gpu_checks(rank, world, rccl=False):
     from types import SimpleNamespace
     from gnndelete_amd.dist_engine import PartitionedNodeembEngine
     from gnndelete_amd.engine import NodeembEngine
@@ -213,6 +213,11 @@ def gpu_checks(rank, world):
     cases = [(GCNDelete, 'both_layerwise'), (GINDelete, 'both_all'), (GCNDelete, 'only2_all'), (SAGEDelete, 'both_layerwise'),
              (SAGEDelete, 'both_all'), (GCNDelete, 'only1'), (GINDelete, 'only2_layerwise'), (GATDelete, 'both_layerwise'),
              (GATDelete, 'both_all')]
+    group = None
+    if rccl:                  # a world of one over RCCL: the data-path communicator the GPU node uses
+        cases = [(GCNDelete, 'both_layerwise'), (SAGEDelete, 'both_all'), (GATDelete, 'both_layerwise')]
+        group = dist.new_group(backend='nccl', device_id=dev)
+        assert dist.get_backend(group) == 'nccl'
     for cls, lt in cases:
         results = []
         for partitioned in (False, True):
@@ -226,9 +231,9 @@ def gpu_checks(rank, world):
             args = (m, x, e_sdf, z1o, z2o, E[:, data.df_mask.to(dev)], neg.to(dev), ni1, ni2)
             if partitioned:
                 eng = PartitionedNodeembEngine(*args, rank, world, loss_type=lt, alpha=0.5, lr=1e-2,
-                                               use_graph=(lt != 'only1'))
+                                               use_graph=(lt != 'only1'), group=group)
                 rep = eng.halo_report()
-                assert rep['recv_bytes_per_step'] < rep['allgather_bytes_per_step']
+                assert rep['recv_bytes_per_step'] < rep['allgather_bytes_per_step'] or world == 1
             else:
                 eng = NodeembEngine(*args, loss_type=lt, alpha=0.5, lr=1e-2)
             for _ in range(6):
@@ -249,7 +254,11 @@ def main():
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     try:
-        (cpu_checks if mode == 'cpu' else gpu_checks)(rank, world)
+        if mode == 'rccl1':
+            assert world == 1 and os.environ.get('GD_FORCE_COLLECTIVES') == '1'
+            gpu_checks(rank, world, rccl=True)
+        else:
+            (cpu_checks if mode == 'cpu' else gpu_checks)(rank, world)
         dist.barrier()
         if rank == 0:
             print('DIST_OK', flush=True)

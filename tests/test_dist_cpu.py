@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def launch(mode, world, timeout=600):
-    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS='2')
+def launch(mode, world, timeout=600, **extra_env):
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS='2', **extra_env)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
            '--master-addr', '127.0.0.1', '--master-port', str(29500 + world + (7 if mode == 'gpu' else 0)),
            os.path.join(ROOT, 'tests', 'dist_worker.py'), mode]
@@ -32,3 +32,13 @@ def test_partitioned_engine_matches_single_gpu_engine(world):
     --loss_type."""
     out = launch('gpu', world, timeout=900)
     assert out.count('partitioned == single') == 9
+
+
+@pytest.mark.gpu
+def test_partitioned_engine_over_rccl_in_a_world_of_one():
+    """The box has one GPU and RCCL refuses two ranks on one device, so the multi-rank runs above use gloo.  This one
+    drives the REAL data-path calls - all_to_all_single with per-peer split lists and the packed all_reduce on an
+    `nccl` (= RCCL) group, between the hipGraph segments - in a world of one (GD_FORCE_COLLECTIVES=1 keeps the
+    engine from skipping them), and checks the partitioned engine against the single-GPU engine."""
+    out = launch('rccl1', 1, timeout=600, GD_FORCE_COLLECTIVES='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    assert out.count('partitioned == single') == 3
