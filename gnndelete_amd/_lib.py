@@ -26,6 +26,7 @@ PROTOTYPES = {
     'gd_spmm_csr_balanced_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _f32, _p, _p, _i32,
                                                 _i32, _i32, _p, _p]),
     'gd_rgcn_conv_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _i32, _i32, _p, _i64, _i32, _i32, _p]),
+    'gd_rowpair_loss_f32': (ctypes.c_int, [_i32, _p, _i64, _p, _p, _i64, _p, _i32, _i32, _p, _p, _i64, _p]),
     'gd_random_walk': (ctypes.c_int, [_p, _p, _i32, _p, _i32, _i32, ctypes.c_uint64, _p, _p]),
     'gd_rgcn_tile_kl': (ctypes.c_int32, [_i32, _i32, _i32, _i32]),
     'gd_rgcn_pack_weight_f32': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),

@@ -514,3 +514,94 @@ extern "C" int gd_edge_dot_bwd_f32(const float* z, int64_t ld_z, int32_t d, cons
 #undef GD_DOTB_CASE
   return launched("edge_dot_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The non-MSE row losses of the reference's loss zoo (framework/trainer/gnndelete_nodeemb.py:18-28: BoundedKLD*,
+// CosineDistance*), value and gradient with respect to the FIRST argument in one pass over the row pairs:
+//   kind 0 (cosine): val[r] = 1 - <a_r, b_r> / (max(|a_r|, 1e-8) max(|b_r|, 1e-8)),   grad[r,:] = d val[r] / d a_r
+//   kind 1 (KLD):    val[r] = sum_j t_j (log t_j - log_softmax(a_r)_j), t = softmax(b_r),
+//                    grad[r,:] = softmax(a_r) - t      (= d val[r] / d a_r)
+// The reductions over the rows (mean / sum, 1 - exp(-KL)) are scalar work left to the caller.  One wave per row, the
+// row strided over the lanes (d <= 1024), wave-xor reductions; rows of both operands optionally gathered (ia / ib).
+namespace gd {
+
+template <int KIND>
+__global__ __launch_bounds__(256) void rowpair_loss_kernel(const float* __restrict__ a, int64_t ld_a, const int64_t* __restrict__ ia,
+                                                           const float* __restrict__ b, int64_t ld_b, const int64_t* __restrict__ ib,
+                                                           int32_t n_rows, int32_t d, float* __restrict__ val,
+                                                           float* __restrict__ grad, int64_t ld_g) {
+  constexpr int kMax = 16;                                // d <= 1024
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const float* ar = a + (ia ? ia[r] : (int64_t)r) * ld_a;
+  const float* br = b + (ib ? ib[r] : (int64_t)r) * ld_b;
+  float av[kMax], bv[kMax];
+#pragma unroll
+  for (int q = 0; q < kMax; ++q) {
+    const int k = lane + q * kWave;
+    av[q] = k < d ? ar[k] : (KIND == 1 ? -INFINITY : 0.f);
+    bv[q] = k < d ? br[k] : (KIND == 1 ? -INFINITY : 0.f);
+  }
+  float* gr = grad + (int64_t)r * ld_g;
+  if (KIND == 0) {
+    float ab = 0.f, aa = 0.f, bb = 0.f;
+#pragma unroll
+    for (int q = 0; q < kMax; ++q) { ab = fmaf(av[q], bv[q], ab); aa = fmaf(av[q], av[q], aa); bb = fmaf(bv[q], bv[q], bb); }
+    ab = wave_sum(ab); aa = wave_sum(aa); bb = wave_sum(bb);
+    // F.cosine_similarity clamps each norm at eps = 1e-8: cos = <a, b> / (max(|a|, eps) max(|b|, eps))
+    const float na = sqrtf(aa), nb = sqrtf(bb);
+    const bool clamped = na < 1e-8f;
+    const float den = fmaxf(na, 1e-8f) * fmaxf(nb, 1e-8f);
+    const float cs = ab / den;
+    if (lane == 0) val[r] = 1.f - cs;
+    // d/da (ab / (|a| |b|)) = b / den - cos a / aa   (a clamped |a| is a constant: only b / den remains)
+    const float ca = clamped ? 0.f : cs / aa;
+#pragma unroll
+    for (int q = 0; q < kMax; ++q) {
+      const int k = lane + q * kWave;
+      if (k < d) gr[k] = -(bv[q] / den - ca * av[q]);
+    }
+  } else {
+    float ma = -INFINITY, mb = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < kMax; ++q) { ma = fmaxf(ma, av[q]); mb = fmaxf(mb, bv[q]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, off)); mb = fmaxf(mb, __shfl_xor(mb, off)); }
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int q = 0; q < kMax; ++q) { sa += expf(av[q] - ma); sb += expf(bv[q] - mb); }       // exp(-inf) = 0 beyond d
+    sa = wave_sum(sa); sb = wave_sum(sb);
+    const float lsa = ma + logf(sa), lsb = mb + logf(sb);
+    float kl = 0.f;
+#pragma unroll
+    for (int q = 0; q < kMax; ++q) {
+      const int k = lane + q * kWave;
+      if (k < d) {
+        const float lt = bv[q] - lsb, t = expf(lt), la = av[q] - lsa;
+        kl += t > 0.f ? t * (lt - la) : 0.f;                 // (xlogy convention of F.kl_div: 0 where t = 0)
+        gr[k] = expf(la) - t;
+      }
+    }
+    kl = wave_sum(kl);
+    if (lane == 0) val[r] = kl;
+  }
+}
+
+}  // namespace gd
+
+extern "C" int gd_rowpair_loss_f32(int32_t kind, const float* a, int64_t ld_a, const int64_t* ia, const float* b, int64_t ld_b,
+                                   const int64_t* ib, int32_t n_rows, int32_t d, float* val, float* grad, int64_t ld_g,
+                                   void* stream) {
+  using namespace gd;
+  GD_REQUIRE(a && b && val && grad, GD_E_NULL, "gd_rowpair_loss_f32: null pointer");
+  GD_REQUIRE((kind == 0 || kind == 1) && n_rows >= 0 && d > 0 && d <= 1024 && ld_a >= d && ld_b >= d && ld_g >= d, GD_E_DIM,
+             "gd_rowpair_loss_f32: kind must be 0 (cosine) or 1 (KLD), d in [1, 1024] (kind=%d d=%d)", kind, d);
+  if (n_rows == 0) return GD_OK;
+  const dim3 grid((n_rows + 3) / 4), block(256);
+  if (kind == 0)
+    hipLaunchKernelGGL((rowpair_loss_kernel<0>), grid, block, 0, (hipStream_t)stream, a, ld_a, ia, b, ld_b, ib, n_rows, d, val, grad, ld_g);
+  else
+    hipLaunchKernelGGL((rowpair_loss_kernel<1>), grid, block, 0, (hipStream_t)stream, a, ld_a, ia, b, ld_b, ib, n_rows, d, val, grad, ld_g);
+  return launched("rowpair_loss");
+}

@@ -26,20 +26,38 @@ from .base import NodeClassificationTrainer, Trainer, _require_gpu, device
 # ----------------------------------------------------------------------------- loss zoo
 
 
+# The row losses run on the HIP row-pair kernel (value and gradient in one pass, gnndelete_amd.ops.rowpair_loss) where it
+# applies - device tensors, a constant second argument as the trainers pass it - and as the reference's torch expressions
+# otherwise; both forms are checked against the reference's own functions (tests/golden/losses.npz).
+def _kld(logits, truth, per_row_mean):
+    from ... import ops
+    if ops.rowpair_loss_ok(logits, truth):
+        kl = ops.rowpair_loss(logits, truth, 'kld').sum()
+        return 1 - torch.exp(-(kl / logits.shape[0] if per_row_mean else kl))
+    return 1 - torch.exp(-F.kl_div(F.log_softmax(logits, -1), truth.softmax(-1), reduction='batchmean' if per_row_mean else 'sum'))
+
+
+def _cosine(logits, truth):
+    from ... import ops
+    if ops.rowpair_loss_ok(logits, truth):
+        return ops.rowpair_loss(logits, truth, 'cosine')
+    return 1 - F.cosine_similarity(logits, truth)
+
+
 def BoundedKLDMean(logits, truth):
-    return 1 - torch.exp(-F.kl_div(F.log_softmax(logits, -1), truth.softmax(-1), reduction='batchmean'))
+    return _kld(logits, truth, True)
 
 
 def BoundedKLDSum(logits, truth):
-    return 1 - torch.exp(-F.kl_div(F.log_softmax(logits, -1), truth.softmax(-1), reduction='sum'))
+    return _kld(logits, truth, False)
 
 
 def CosineDistanceMean(logits, truth):
-    return (1 - F.cosine_similarity(logits, truth)).mean()
+    return _cosine(logits, truth).mean()
 
 
 def CosineDistanceSum(logits, truth):
-    return (1 - F.cosine_similarity(logits, truth)).sum()
+    return _cosine(logits, truth).sum()
 
 
 def centering(K):

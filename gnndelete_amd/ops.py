@@ -620,6 +620,36 @@ def rgcn_conv_frozen(x, tg, weight, root, bias, n_blocks):
     return _RgcnConvFrozen.apply(x, tg, weight, root, bias, n_blocks)
 
 
+class _RowPairLoss(torch.autograd.Function):
+    """Per-row cosine distance / KL(softmax(b) || softmax(a)) with the gradient w.r.t. a formed in the same pass
+    (gd_rowpair_loss_f32); b is a constant (the reference compares against embeddings computed under no_grad)."""
+
+    @staticmethod
+    def forward(ctx, a, b, kind):
+        a, b = _f32_rows(a), _f32_rows(b.detach())
+        n, d = a.shape
+        val = torch.empty(n, dtype=torch.float32, device=a.device)
+        grad = torch.empty(n, d, dtype=torch.float32, device=a.device)
+        check(_lib.lib().gd_rowpair_loss_f32(kind, ptr(a), a.stride(0), None, ptr(b), b.stride(0), None, n, d, ptr(val), ptr(grad),
+                                             grad.stride(0), stream_ptr(a.device)), 'gd_rowpair_loss_f32')
+        ctx.save_for_backward(grad)
+        return val
+
+    @staticmethod
+    def backward(ctx, dval):
+        (grad,) = ctx.saved_tensors
+        return grad * dval[:, None], None, None
+
+
+def rowpair_loss_ok(a, b):
+    return a.is_cuda and a.dim() == 2 and a.shape == b.shape and 0 < a.shape[1] <= 1024 and not b.requires_grad and a.shape[0] > 0
+
+
+def rowpair_loss(a, b, kind):
+    """kind 'cosine': 1 - cos(a_r, b_r) per row; 'kld': KL(softmax(b_r) || softmax(a_r)) per row.  Differentiable in a."""
+    return _RowPairLoss.apply(a, b, {'cosine': 0, 'kld': 1}[kind])
+
+
 # ------------------------------------------------------------------------------ decoders
 class _EdgeDot(torch.autograd.Function):
     @staticmethod

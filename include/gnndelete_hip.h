@@ -241,6 +241,15 @@ int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* tile_step_pt
 int gd_random_walk(const int32_t* rowptr, const int32_t* col, int32_t n_nodes, const int64_t* start, int32_t n_walks,
                    int32_t walk_length, uint64_t seed, int64_t* out, void* stream);
 
+/* The non-MSE row losses of the reference's loss zoo (framework/trainer/gnndelete_nodeemb.py:18-28), value per row
+ * pair and gradient with respect to a, in one pass; rows of a / b optionally gathered through ia / ib (int64, NULL =
+ * identity):
+ *   kind 0  CosineDistance*:  val[r] = 1 - cos(a_r, b_r)  (each norm clamped at 1e-8 as F.cosine_similarity does)
+ *   kind 1  BoundedKLD*:      val[r] = KL(softmax(b_r) || softmax(a_r)),  grad[r,:] = softmax(a_r) - softmax(b_r)
+ * The caller reduces val over the rows (mean / sum; 1 - exp(-KL / n) for the bounded KLD) and scales grad. */
+int gd_rowpair_loss_f32(int32_t kind, const float* a, int64_t ld_a, const int64_t* ia, const float* b, int64_t ld_b,
+                        const int64_t* ib, int32_t n_rows, int32_t d, float* val, float* grad, int64_t ld_g, void* stream);
+
 /* ---------------------------------------------------------------- Del operator --------- */
 
 /* Row-subset GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):

@@ -923,3 +923,28 @@ def test_rows_gemm_gated_rank1_matches_fp64(n, d_in, d_out):
     rest = torch.ones(n, dtype=torch.bool)
     rest[rows] = False
     assert bool((out.cpu()[rest] == -3.0).all())
+
+
+@pytest.mark.parametrize('n,d', [(300, 64), (77, 128), (1000, 10), (5, 1000), (64, 3)])
+def test_rowpair_loss_kernels_match_torch_forms(n, d):
+    """gd_rowpair_loss_f32: cosine distance and KL(softmax(b) || softmax(a)) per row with the gradient w.r.t. a, against the
+    reference's torch expressions in float64 (framework/trainer/gnndelete_nodeemb.py:18-28), widths on and off the lane
+    grid, a zero row (clamped cosine denominator)."""
+    import torch.nn.functional as F
+    from gnndelete_amd import ops
+    g = torch.Generator().manual_seed(n + d)
+    a, b = torch.randn(n, d, generator=g) * 2, torch.randn(n, d, generator=g) * 2
+    a[0] = 0
+    up = torch.rand(n, generator=g) + 0.5
+    for kind in ('cosine', 'kld'):
+        ad = a.double().requires_grad_(True)
+        if kind == 'cosine':
+            want = 1 - F.cosine_similarity(ad, b.double())
+        else:
+            want = F.kl_div(F.log_softmax(ad, -1), b.double().softmax(-1), reduction='none').sum(-1)
+        want.backward(up.double())
+        ag = a.cuda().requires_grad_(True)
+        got = ops.rowpair_loss(ag, b.cuda(), kind)
+        got.backward(up.cuda())
+        assert rel_l2(got.detach().cpu(), want.detach()) < TOL, kind
+        assert rel_l2(ag.grad.cpu(), ad.grad) < 10 * TOL, kind

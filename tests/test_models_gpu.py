@@ -119,6 +119,39 @@ def test_training_trajectory_matches_reference_loop(gnn, loss_type):
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < TOL
 
 
+@pytest.mark.parametrize('gnn,loss_fct', [('gcn', 'kld_mean'), ('gat', 'cosine_sum'), ('gin', 'cosine_mean'), ('gcn', 'kld_sum')])
+def test_non_mse_losses_train_like_the_oracle(gnn, loss_fct):
+    """--loss_fct kld_* / cosine_* (gnndelete_nodeemb.py:18-28, :196-210): the HIP model with the HIP row-pair loss kernel
+    (gd_rowpair_loss_f32 behind framework.trainer.gnndelete_nodeemb.get_loss_fct) against the oracle model with the
+    reference's torch expressions, five epochs of the both_all update from the same state."""
+    from oracle import gnndelete_ref as R
+    from gnndelete_amd.framework.trainer.gnndelete_nodeemb import get_loss_fct
+    fx = load_golden(f'traj_{gnn}_both_layerwise.npz' if gnn != 'gcn' else 'traj_gcn_both_all.npz')
+    state, data, rest = split_fixture(fx)
+    ni1, ni2 = R.non_df_masks(data['x'].shape[0], data['directed_df_edge_index'], data['sdf_node_1hop_mask'],
+                              data['sdf_node_2hop_mask'])
+    E = data['train_pos_edge_index']
+    results = []
+    for hip in (False, True):
+        make = hip_model if hip else oracle_model
+        m = make(gnn, state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+        m.relational = False
+        to = (lambda v: v.cuda()) if hip else (lambda v: v)
+        x, e_dr, e_sdf = to(data['x']), to(E[:, data['dr_mask']]), to(E[:, data['sdf_mask']])
+        with torch.no_grad():
+            z1o, z2o = m.get_original_embeddings(x, e_dr, return_all_emb=True)
+        targets = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=to(E[:, data['df_mask']]), neg_edge=to(t(rest['neg'])),
+                       ni_mask1=to(ni1), ni_mask2=to(ni2))
+        opt = R.make_optimizer(m, 'both_all', float(rest['lr']))
+        fct = get_loss_fct(loss_fct) if hip else R.LOSSES[loss_fct]
+        logs = [R.nodeemb_epoch(m, lambda: m(x, e_sdf, return_all_emb=True), targets, opt, 'both_all', 0.5, fct) for _ in range(5)]
+        results.append((np.array([l['train_loss'] for l in logs]), m.deletion1.deletion_weight.detach().cpu(),
+                        m.deletion2.deletion_weight.detach().cpu()))
+    (lo, a1, a2), (lh, b1, b2) = results
+    np.testing.assert_allclose(lh, lo, rtol=1e-4, atol=1e-7)
+    assert rel_l2(b1, a1) < TOL and rel_l2(b2, a2) < TOL
+
+
 def test_sage_extension_matches_oracle_forward_and_gradients():
     """GraphSAGE (mean) - named by BASELINE.json config 3, absent from the reference: the HIP model
     against the oracle restatement (itself pinned by a dense KAT only)."""
