@@ -52,6 +52,7 @@ PROTOTYPES = {
                                              _p]),
     'gd_rows_gemm_signs_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _i64, _p, _p, _p]),
     'gd_rows_gemm_gated_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _i64, _p]),
+    'gd_gate_rows_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _i64, _p]),
     'gd_rows_gemm_gated_rank1_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i64, _p]),
     'gd_rows_gemm_wgrad_f32': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p]),
     'gd_rowpair_mse_workspace': (_i64, [_i32]),

@@ -815,3 +815,34 @@ extern "C" int gd_rows_gemm_wgrad_loss_f32(const float* a, int64_t ld_a, const i
   return wgrad_impl(&loss, a, ld_a, a_idx, z, ld_z, z_idx, nullptr, g_add, n_sel, d_a, d_b, dw, accumulate, partials,
                     param ? &adam : nullptr, stream);
 }
+
+// out[idx[s], :] = src[idx[s], :] where bit (s, c) of the packed sign pattern is set, else 0: the ReLU backward on a
+// row subset from the [z > 0] bits gd_rows_gemm_signs_f32 recorded (one launch; the tensor-op form took eight).
+namespace gd {
+__global__ __launch_bounds__(256) void gate_rows_kernel(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ idx,
+                                                        int32_t n_sel, const uint32_t* __restrict__ bits, int32_t d4, int32_t n_words,
+                                                        float* __restrict__ out, int64_t ld_out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)n_sel * d4) return;
+  const int s = (int)(e / d4), c4 = (int)(e % d4);
+  const int64_t row = idx ? idx[s] : s;
+  const uint32_t m = bits[(int64_t)s * n_words + (c4 >> 3)] >> (4 * (c4 & 7));
+  float4 v = reinterpret_cast<const float4*>(src + row * ld_src)[c4];
+  v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+  reinterpret_cast<float4*>(out + row * ld_out)[c4] = v;
+}
+}  // namespace gd
+
+extern "C" int gd_gate_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, int32_t n_sel, const uint32_t* gate_bits,
+                                int32_t d, float* out, int64_t ld_out, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(src && gate_bits && out, GD_E_NULL, "gd_gate_rows_f32: null pointer");
+  GD_REQUIRE(n_sel >= 0 && d > 0 && d % 4 == 0 && ld_src >= d && ld_out >= d && ld_src % 4 == 0 && ld_out % 4 == 0, GD_E_DIM,
+             "gd_gate_rows_f32: d and the row pitches must be multiples of 4 (d=%d)", d);
+  GD_REQUIRE(aligned16(src) && aligned16(out), GD_E_ALIGN, "gd_gate_rows_f32: unaligned pointer");
+  if (n_sel == 0) return GD_OK;
+  const int64_t total = (int64_t)n_sel * (d / 4);
+  hipLaunchKernelGGL(gate_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, idx,
+                     n_sel, gate_bits, d / 4, (d + 31) / 32, out, ld_out);
+  return launched("gate_rows");
+}

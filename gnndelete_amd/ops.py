@@ -138,9 +138,13 @@ def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, sa
 
 def gate_rows(src, idx, sign_bits, out):
     """out[idx[s], :] = src[idx[s], :] where bit c of sign_bits[s] is set, else 0 (ReLU backward from the packed
-    [z > 0] pattern the Del-1 kernel emitted).  Plain tensor ops on static buffers (graph-capturable)."""
+    [z > 0] pattern the Del-1 kernel emitted): gd_gate_rows_f32, one launch on static buffers (graph-capturable)."""
     n_sel, d = int(idx.shape[0]), src.shape[1]
     if n_sel == 0:
+        return out
+    if d % 4 == 0 and src.stride(0) % 4 == 0 and out.stride(0) % 4 == 0 and src.is_cuda:
+        check(_lib.lib().gd_gate_rows_f32(ptr(src), src.stride(0), ptr(idx), n_sel, ptr(sign_bits), d, ptr(out), out.stride(0),
+                                          stream_ptr(src.device)), 'gd_gate_rows_f32')
         return out
     words = (d + 31) // 32
     shifts = torch.arange(32, device=src.device, dtype=torch.int32)

@@ -303,6 +303,12 @@ int gd_rows_gemm_gated_f32(const float* in, int64_t ld_in, const int32_t* idx, i
                            const float* w, int32_t d_in, int32_t d_out, int32_t trans_w,
                            const uint32_t* gate_bits, float* out, int64_t ld_out, void* stream);
 
+/* The ReLU backward alone, on a row subset: out[r,:] = src[r,:] where the gate bit (s, n) is set, else 0, r = idx[s]
+ * (gate_bits as written by gd_rows_gemm_signs_f32 for the same idx list; src may be out).  Used where the gradient that
+ * has to be gated is a sum of several kernels' outputs (R-GCN: root product + typed conv). */
+int gd_gate_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, int32_t n_sel, const uint32_t* gate_bits,
+                     int32_t d, float* out, int64_t ld_out, void* stream);
+
 /* The same with a rank-2 correction of the product before the gate:
  *       out[r,n] = gate bit (s,n) ? (in[r,:] @ W)[n] + row_a[r] col_p[n] + row_b[r] col_q[n] : 0
  * GAT's input gradient dh2 = A_alpha^T dy + da_src (x) att_src + da_dst (x) att_dst (framework/models/gat.py through
