@@ -47,6 +47,17 @@ def main():
         args.checkpoint_dir = os.path.join(base_ckpt, args.dataset, args.gnn, args.unlearning_model, variant, tail)
     else:
         args.checkpoint_dir = os.path.join(base_ckpt, args.dataset, args.gnn, args.unlearning_model, tail)
+    # Launched under torch.distributed (python -m torch.distributed.run --nproc-per-node N delete_gnn.py ... --minibatch): the
+    # mini-batch loops are batch-data-parallel - every rank draws its own GraphSAINT batches, the Del gradients are averaged
+    # before each optimizer step (framework/trainer/sampler.py: sync_gradients); rank 0 owns the checkpoint directory
+    world, rank = int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('RANK', 0))
+    if world > 1:
+        import torch.distributed as dist
+        if torch.cuda.is_available() and torch.cuda.device_count() > 1:
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
+        dist.init_process_group(os.environ.get('GNNDELETE_DIST_BACKEND', 'nccl'))
+        if rank:
+            args.checkpoint_dir = os.path.join(args.checkpoint_dir, f'rank{rank}')
     os.makedirs(args.checkpoint_dir, exist_ok=True)
 
     data = Data.load(os.path.join(args.data_dir, args.dataset, f'd_{args.random_seed}.pt'))

@@ -160,10 +160,12 @@ class KGGNNDeleteNodeembTrainer(KGTrainer):
                 r1, r2, l1, l2 = _four_terms(loss_fct, z1, z2, z1_ori, z2_ori, dec_index, neg_index, m1, m2)
                 loss1 = alpha * r1 + (1 - alpha) * l1
                 loss1.backward(retain_graph=True)
+                _sampler.sync_gradients(optimizer[0])
                 optimizer[0].step()
                 optimizer[0].zero_grad()
                 loss2 = alpha * r2 + (1 - alpha) * l2
                 loss2.backward(retain_graph=True)
+                _sampler.sync_gradients(optimizer[1])
                 optimizer[1].step()
                 optimizer[1].zero_grad()
                 last = (loss1 + loss2, r1 + r2, l1 + l2)

@@ -112,12 +112,46 @@ class FixedNodeSets(RandomWalkSubgraphSampler):
         return iter(self._sets)
 
 
+def data_parallel_world():
+    """(rank, world) of the batch-data-parallel mini-batch mode (SURVEY 8e option 1): the mini-batch loops are
+    data-parallel whenever the process runs under torch.distributed with more than one rank - every rank draws its OWN
+    GraphSAINT batches and the Del-weight gradients are averaged over the ranks before each optimizer step."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def sync_gradients(optimizer):
+    """all-reduce (mean) of the gradients this optimizer is about to apply - one call per optimizer step, in step order
+    (both_layerwise: W_D1's gradient, then W_D2's: two small all-reduces of 64 KiB and 16 KiB at H = 128, O = 64).
+    RCCL on the GPU node (backend "nccl"), gloo in the tests; a no-op outside torch.distributed."""
+    rank, world = data_parallel_world()
+    if world == 1:
+        return
+    import torch.distributed as dist
+    grads = [p.grad for g in optimizer.param_groups for p in g['params'] if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    flat /= world
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
 def make_sampler(data, batch_size, num_steps, walk_length=2):
     """Sampler factory of the mini-batch loops (a seam for tests: monkeypatch to inject FixedNodeSets).  The loops keep
     their Data on the host as upstream does; the sampler gets a device copy and cuts its batches there."""
     if torch.cuda.is_available() and data.edge_index.device.type == 'cpu':
         data = data.clone().to(device)
-    return RandomWalkSubgraphSampler(data, batch_size=batch_size, walk_length=walk_length, num_steps=num_steps)
+    rank, world = data_parallel_world()
+    gen = None
+    if world > 1:                                   # every rank its own stream of roots and walks
+        gen = torch.Generator(device=data.edge_index.device).manual_seed(int(torch.initial_seed()) % (2 ** 31) * 64 + rank + 1)
+    return RandomWalkSubgraphSampler(data, batch_size=batch_size, walk_length=walk_length, num_steps=num_steps, generator=gen)
 
 
 def train_minibatch(trainer, model, data, optimizer, args):
@@ -150,10 +184,12 @@ def train_minibatch(trainer, model, data, optimizer, args):
                                          batch.sdf_node_1hop_mask_non_df_mask, batch.sdf_node_2hop_mask_non_df_mask)
             loss1 = trainer.args.alpha * r1 + (1 - trainer.args.alpha) * l1
             loss1.backward(retain_graph=True)
+            sync_gradients(optimizer[0])
             optimizer[0].step()
             optimizer[0].zero_grad()
             loss2 = trainer.args.alpha * r2 + (1 - trainer.args.alpha) * l2
             loss2.backward(retain_graph=True)
+            sync_gradients(optimizer[1])
             optimizer[1].step()
             optimizer[1].zero_grad()
             step_log = {'Epoch': epoch, 'train_loss': (loss1 + loss2).item(), 'train_loss_l': (l1 + l2).item(),

@@ -151,6 +151,40 @@ def test_minibatch_trainer_runs(tmp_path, monkeypatch):
     assert 0.0 <= log['dt_auc'] <= 1.0
 
 
+def test_minibatch_trainer_is_data_parallel_under_torch_distributed(tmp_path):
+    """SURVEY 8e, option 1: `torch.distributed.run --nproc-per-node 2 delete_gnn.py ... --minibatch` - every rank draws
+    its own GraphSAINT batches on the device, the Del-weight gradients are all-reduced (mean) before each optimizer step
+    (gloo here: both ranks share the box's one GPU; RCCL on the node).  The ranks must end with IDENTICAL Del weights
+    (same initial state, same averaged gradients) that differ from a single-process run (other batches)."""
+    import subprocess
+    import sys
+    cwd = str(tmp_path)
+    env = dict(os.environ, GNNDELETE_FORCE_EPOCHS='2', GNNDELETE_FORCE_VALID_FREQ='2', GNNDELETE_FORCE_NUM_STEPS='3',
+               GNNDELETE_DIST_BACKEND='gloo', PYTHONPATH=ROOT)
+    data_dir = os.path.join(cwd, 'data', 'ogbl-synth')
+    os.makedirs(data_dir)
+    from gnndelete_amd.framework.synth import make_linkpred_dataset
+    data, df = make_linkpred_dataset(None, seed=42, shape=(800, 32, 4000, 'dense'))
+    data.save(os.path.join(data_dir, 'd_42.pt'))
+    torch.save(df, os.path.join(data_dir, 'df_42.pt'))
+    common = ['--dataset', 'ogbl-synth', '--gnn', 'gcn', '--random_seed', '42', '--batch_size', '200']
+    delete = common + ['--unlearning_model', 'gnndelete_nodeemb', '--df', 'in', '--df_size', '5', '--minibatch']
+    subprocess.run([sys.executable, os.path.join(ROOT, 'train_gnn.py')] + common, cwd=cwd, env=env, check=True, capture_output=True)
+    out = os.path.join(cwd, 'checkpoint', 'ogbl-synth', 'gcn', 'gnndelete_nodeemb', 'mse_mean-both_layerwise-0.5-non_connected',
+                       'in-5.0-42')
+    subprocess.run([sys.executable, os.path.join(ROOT, 'delete_gnn.py')] + delete, cwd=cwd, env=env, check=True, capture_output=True)
+    single = torch.load(os.path.join(out, 'model_final.pt'))['model_state']
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29561', os.path.join(ROOT, 'delete_gnn.py')] + delete, cwd=cwd, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    w0 = torch.load(os.path.join(out, 'model_final.pt'))['model_state']
+    w1 = torch.load(os.path.join(out, 'rank1', 'model_final.pt'))['model_state']
+    for k in ('deletion1.deletion_weight', 'deletion2.deletion_weight'):
+        assert torch.equal(w0[k], w1[k]), k
+        assert not torch.equal(w0[k], single[k]) and bool(torch.isfinite(w0[k]).all()), k
+
+
 @pytest.mark.parametrize('gnn', ['gcn', 'gat'])
 def test_edgeprob_trainer_reproduces_reference_trajectory(tmp_path, monkeypatch, gnn):
     """GNNDeleteTrainer.train_fullbatch on the HIP path (fused pair kernel, csrc/pairs.hip) against the
