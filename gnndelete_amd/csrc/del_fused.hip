@@ -8,9 +8,10 @@
 // row the kernel reads p and tbar and writes dz (for the weight gradient) and dp (for conv2's backward) -
 // 4 row-streams instead of the 10 of the separate Del / loss / Del-backward kernels.
 //
-// Same mapping as rows_gemm.hip (transposed product, weight image in LDS, sample rows straight from global
-// memory); the image rows are padded by one float (pitch D + 1) so that reads along either axis are
-// conflict-free AND every LDS address is one per-lane base plus a compile-time offset.  The second product needs no layout change: after the first one a lane
+// Same mapping as rows_gemm.hip (transposed product, weight images in LDS, sample rows straight from global
+// memory); W_D is held twice, once per product, each in the order its MFMA operands are consumed, so that one
+// vector read (8 / 16 bytes) feeds NT / 4 consecutive MFMAs (one 4-byte read per MFMA before);
+// every LDS address is one per-lane base plus a compile-time offset.  The second product needs no layout change: after the first one a lane
 // holds, for its own sample j, the features i = 32t + (r&3) + 8(r>>2) + 4kh in acc[t][r]; using exactly that
 // feature as MFMA k slot (r, kh) of the second product - both operands agree on the permutation - the
 // accumulator registers ARE its "B" operand, and its "A" operand W_D[c][i] comes out of the same LDS image
@@ -36,19 +37,26 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
                                                               float* __restrict__ dz, int64_t ld_dz,
                                                               float* __restrict__ dp, int64_t ld_dp) {
   constexpr int D = 32 * NT;
-  constexpr int P = D + 1;                                       // image pitch
-  extern __shared__ __attribute__((aligned(16))) float wl[];     // wl[k * P + n] = W_D[k][n]
+  constexpr int PB = D + 4;                                      // pitch of the row-major image (16-byte rows, conflict-free b128)
+  // two images of W_D, one per product, so that the NT (4) operands of consecutive MFMAs are ONE vector read:
+  //   fw[(k * 32 + n % 32) * NT + n / 32] = W_D[k][n]   forward:  the NT output tiles of one k step
+  //   bw[k * PB + n]                      = W_D[k][n]   backward: four consecutive k slots of one output tile
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  float* const fw = wl;
+  float* const bw = wl + D * D;
   __shared__ float lred[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo = lane & 31, kh = lane >> 5;
   for (int e = tid; e < D * D; e += 256) {
     const int k = e / D, n = e % D;
-    wl[k * P + n] = w[e];
+    const float v = w[e];
+    fw[(k * 32 + (n & 31)) * NT + (n >> 5)] = v;
+    bw[k * PB + n] = v;
   }
   __syncthreads();
 
-  const float* w_fwd = wl + kh * (D / 2) * P + lo;               // per-lane bases of the two read patterns
-  const float* w_bwd = wl + lo * P + 4 * kh;
+  const float* w_fwd = fw + (kh * (D / 2) * 32 + lo) * NT;        // per-lane bases of the two read patterns
+  const float* w_bwd = bw + lo * PB + 4 * kh;
   float ls0 = 0.f, ls1 = 0.f;
   const int n_tiles = (n_sel + 31) >> 5;
   // Operands of one tile: sample row index, loss slot, this lane's half of the p row, its target runs.
@@ -107,9 +115,12 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
       const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float* wk = w_fwd + (4 * c4 + e) * P;              // W_D[kh*D/2 + 4c4 + e][lo + 32t]
+        const float* wk = w_fwd + (4 * c4 + e) * 32 * NT;        // W_D[kh*D/2 + 4c4 + e][lo + 32t], t = 0 .. NT-1 adjacent
+        float wv[NT];
+        if (NT == 2) { const float2 f = *reinterpret_cast<const float2*>(wk); wv[0] = f.x; wv[NT - 1] = f.y; }
+        else wv[0] = wk[0];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[32 * t], av[e], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t], av[e], acc[t], 0, 0, 0);
       }
     }
     // ---- loss gradient in place: acc[t][r] (feature 32t + (r&3) + 8(r>>2) + 4kh of sample lo) -> dz
@@ -152,12 +163,15 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int i0 = 32 * t + (kk & 3) + 8 * (kk >> 2);                        // + 4 kh folded into w_bwd
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int c = 0; c < NT; ++c)                                              // W_D[32c + lo][i0 + 4kh]
-          dacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w_bwd[32 * c * P + i0], acc[t][kk], dacc[c], 0, 0, 0);
-      }
+        for (int c = 0; c < NT; ++c) {                                            // W_D[32c + lo][32t + 8m + 4kh + j], j = 0..3
+          const float4 f = *reinterpret_cast<const float4*>(w_bwd + 32 * c * PB + 32 * t + 8 * m);
+          dacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.x, acc[t][4 * m + 0], dacc[c], 0, 0, 0);
+          dacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.y, acc[t][4 * m + 1], dacc[c], 0, 0, 0);
+          dacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.z, acc[t][4 * m + 2], dacc[c], 0, 0, 0);
+          dacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w, acc[t][4 * m + 3], dacc[c], 0, 0, 0);
+        }
     if (live) {
       float* orow = dp + (int64_t)row * ld_dp + 4 * kh;
 #pragma unroll
@@ -205,7 +219,7 @@ extern "C" int gd_del_loss_bwd_f32(const float* p, int64_t ld_p, const int32_t* 
   hipStream_t s = (hipStream_t)stream;
   const DelLoss loss{loss_slot, tm, coef, cnt_signed, loss_partials};
   const dim3 grid(del_fused_grid(n_sel));
-  const size_t lds = (size_t)d * (d + 1) * sizeof(float);
+  const size_t lds = ((size_t)d * d + (size_t)d * (d + 4)) * sizeof(float);     // the two weight images
   switch (d / 32) {
     case 1: hipLaunchKernelGGL((del_loss_bwd_kernel<1>), grid, dim3(256), lds, s, p, ld_p, idx, n_sel, w, loss, dz, ld_dz, dp, ld_dp); break;
     default: hipLaunchKernelGGL((del_loss_bwd_kernel<2>), grid, dim3(256), lds, s, p, ld_p, idx, n_sel, w, loss, dz, ld_dz, dp, ld_dp); break;
