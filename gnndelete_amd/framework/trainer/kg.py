@@ -134,6 +134,8 @@ class KGGNNDeleteNodeembTrainer(KGTrainer):
         S_Df-minus-Df node masks as Del masks, DEC on the forward-direction Df triples vs
         per-relation head-shuffled negatives, NI on the masked nodes, layer-wise update."""
         _require_gpu()
+        if getattr(args, 'fullgraph', False):
+            return self.train_fullgraph(model, data, optimizer, args)
         loss_fct = get_loss_fct(self.args.loss_fct)
         model = model.to(device)
         data = data.to('cpu')
@@ -182,5 +184,53 @@ class KGGNNDeleteNodeembTrainer(KGTrainer):
                     print(f'Save best checkpoint at epoch {epoch:04d}. Valid loss = {valid_loss:.4f}')
                     torch.save({'model_state': model.state_dict()}, os.path.join(args.checkpoint_dir, 'model_best.pt'))
                 data = data.to('cpu')
+        torch.save({'model_state': {k: v.to('cpu') for k, v in model.state_dict().items()}},
+                   os.path.join(args.checkpoint_dir, 'model_final.pt'))
+
+    def train_fullgraph(self, model, data, optimizer, args):
+        """--fullgraph: the same objective as the batch loop above, on the WHOLE graph with the fused R-GCN step
+        (gnndelete_amd.engine.NodeembEngine, mode rgcn: typed tile conv, Del, folded losses, Del-weight gradients and
+        Adam in one hipGraph per epoch) - message passing on the Dr triples with the S_Df-minus-Df node masks as Del
+        masks, DEC on the forward-direction Df triples against head-shuffled negatives drawn ONCE (upstream redraws
+        them per batch), NI on the masked nodes.  Upstream has no full-graph KG loop: ogbl-biokg does not fit its GPUs."""
+        from ...engine import NodeembEngine
+        from .gnndelete_nodeemb import _adam_hyper, _export_adam_state
+        if self.args.loss_fct not in ('mse_mean', 'mse_sum'):
+            raise NotImplementedError('--fullgraph needs --loss_fct mse_mean | mse_sum (the fused step folds the MSE terms)')
+        model = model.to(device)
+        data = data.to(device)
+        _non_df_masks(data)
+        ei = data.edge_index[:, data.dr_mask].contiguous()
+        et = data.edge_type[data.dr_mask].contiguous()
+        m1, m2 = data.sdf_node_1hop_mask_non_df_mask, data.sdf_node_2hop_mask_non_df_mask
+        with torch.no_grad():
+            z1_ori, z2_ori = model.get_original_embeddings(data.x, ei, et, return_all_emb=True)
+        pos, pos_type = data.edge_index[:, data.df_mask], data.edge_type[data.df_mask]
+        forward = pos_type < self.args.num_edge_type
+        dec = pos[:, forward].contiguous()
+        neg = negative_sampling_kg(edge_index=dec, edge_type=pos_type[forward])
+        lr, betas, eps = _adam_hyper(optimizer)
+        engine = NodeembEngine(model, data.x, ei, z1_ori, z2_ori, dec, neg, m1, m2, loss_type=self.args.loss_type,
+                               alpha=self.args.alpha, lr=lr, reduction='mean' if self.args.loss_fct == 'mse_mean' else 'sum',
+                               mask_1hop=m1, mask_2hop=m2, history=max(16, args.epochs), edge_type=et)
+        engine.adam1.betas = engine.adam2.betas = betas
+        engine.adam1.eps = engine.adam2.eps = eps
+        best_metric = 0
+        for epoch in range(args.epochs):
+            model.train()
+            engine.step()
+            if (epoch + 1) % self.args.valid_freq == 0:
+                last = engine.loss_history()[-1]
+                valid_loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, _, valid_log = self.eval(model, data, 'val')
+                valid_log['epoch'] = epoch
+                self._record({'epoch': epoch, 'train_loss': float(last[0]), 'loss_r': float(last[1]), 'loss_l': float(last[2])},
+                             valid_log)
+                if dt_auc + df_auc > best_metric:
+                    best_metric = dt_auc + df_auc
+                    print(f'Save best checkpoint at epoch {epoch:04d}. Valid loss = {valid_loss:.4f}')
+                    torch.save({'model_state': model.state_dict()}, os.path.join(args.checkpoint_dir, 'model_best.pt'))
+                data = data.to(device)
+        _export_adam_state(engine, model, optimizer)
+        self.trainer_log['loss_history'] = engine.loss_history().tolist()
         torch.save({'model_state': {k: v.to('cpu') for k, v in model.state_dict().items()}},
                    os.path.join(args.checkpoint_dir, 'model_final.pt'))

@@ -65,6 +65,7 @@ FLAGS = [
 
 EXTRA_FLAGS = [
     ('minibatch', None, False, 'train ogbl-* graphs on GraphSAINT mini-batches as upstream does (default: full graph)'),
+    ('fullgraph', None, False, 'knowledge-graph unlearning (R-GCN): one fused full-graph step per epoch instead of the GraphSAINT batches upstream trains on'),
     ('no_fused_step', None, False, 'use the autograd path even where the fused hipGraph step applies'),
     ('no_layer1_cache', None, False, 'recompute the frozen layer-1 output every epoch as upstream does (identical results)'),
     ('all_rows', None, False, 'run every row of the graph through the unlearning step as upstream does, not only the rows the request can influence (identical results)'),

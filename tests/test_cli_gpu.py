@@ -98,6 +98,30 @@ def test_cli_pipeline_knowledge_graph(tmp_path, monkeypatch, gnn):
     assert 'node_emb.weight' in state and 'W' in state and state['conv1.weight'].shape[0] == 8
 
 
+def test_cli_knowledge_graph_fullgraph_fused_step(tmp_path, monkeypatch):
+    """delete_gnn.py --gnn rgcn --fullgraph: the fused R-GCN engine behind the KG trainer (one hipGraph per epoch on the
+    whole Dr graph) - runs end to end, lowers its loss and writes the reference's checkpoint layout (the engine itself is
+    checked against the oracle in tests/test_engine_gpu.py::test_rgcn_engine_matches_oracle_training)."""
+    cwd = str(tmp_path)
+    monkeypatch.setenv('GNNDELETE_FORCE_EPOCHS', '6')
+    monkeypatch.setenv('GNNDELETE_FORCE_VALID_FREQ', '3')
+    run([os.path.join(ROOT, 'prepare_dataset.py'), '--dataset', 'synth-kg-tiny', '--seeds', '42'], cwd)
+    common = ['--dataset', 'synth-kg-tiny', '--gnn', 'rgcn', '--random_seed', '42', '--in_dim', '32', '--hidden_dim', '32',
+              '--out_dim', '16']
+    run([os.path.join(ROOT, 'train_gnn.py')] + common, cwd)
+    run([os.path.join(ROOT, 'delete_gnn.py')] + common + ['--unlearning_model', 'gnndelete', '--df', 'in', '--df_size', '5',
+                                                          '--fullgraph'], cwd)
+    out = os.path.join(cwd, 'checkpoint', 'synth-kg-tiny', 'rgcn', 'gnndelete', 'mse_mean-both_layerwise-0.5-non_connected',
+                       'in-5.0-42')
+    with open(os.path.join(out, 'trainer_log.json')) as f:
+        log = json.load(f)
+    hist = np.array(log['loss_history'])
+    assert hist.shape[0] == 6 and np.isfinite(hist).all() and hist[-1, 0] < hist[0, 0]
+    assert 0.0 <= log['dt_auc'] <= 1.0 and 0.0 <= log['df_auc'] <= 1.0
+    state = torch.load(os.path.join(out, 'model_final.pt'))['model_state']
+    assert 'deletion1.deletion_weight' in state and 'node_emb.weight' in state
+
+
 @pytest.mark.parametrize('gnn', ['gat', 'gcn'])
 def test_cli_node_deletion(tmp_path, monkeypatch, gnn):
     """delete_node.py: node unlearning with accuracy / F1 evaluation (out_dim = #classes = 4, so
