@@ -591,7 +591,9 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
   if (mfma_ok) {
     const int n_tiles = (n_sel + 31) / 32;
     int grid = (n_tiles + 7) / 8;
-    if (grid > 512) grid = 512;
+    // persistent blocks, 2 per CU by default (GD_ROWS_GEMM_GRID: A-B knob, read once)
+    static const int grid_cap = [] { const char* e = getenv("GD_ROWS_GEMM_GRID"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    if (grid > grid_cap) grid = grid_cap;
 #define GD_RG_LAUNCH(NT, MODE)                                                                                    \
   hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT, MODE>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in, idx,   \
                      n_sel, w, d_in, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out, in_alt, sel, dots)
