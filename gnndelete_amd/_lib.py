@@ -14,6 +14,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'gnndelete_hip.h')
 _i32, _i64, _f32, _f64, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
 # name -> (restype, argtypes); must list every symbol the header declares
+ABI_VERSION = 2          # GD_ABI_VERSION of include/gnndelete_hip.h this binding was written against
+
 PROTOTYPES = {
     'gd_abi_version': (ctypes.c_int, []),
     'gd_last_error_string': (ctypes.c_char_p, []),
@@ -108,8 +110,8 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.gd_abi_version() != 1:
-            raise GnnDeleteHipError('libgnndelete_hip.so ABI version mismatch')
+        if handle.gd_abi_version() != ABI_VERSION:
+            raise GnnDeleteHipError(f'libgnndelete_hip.so ABI version {handle.gd_abi_version()}, this package binds version {ABI_VERSION}: rebuild (make -C gnndelete_amd/csrc)')
         _lib = handle
     return _lib
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 1
+#define GD_ABI_VERSION 2   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...) */
 
 enum {
   GD_OK = 0,
