@@ -65,7 +65,7 @@ PROTOTYPES = {
     'gd_gemm_f32_workspace': (_i64, [_i32, _i32, _i32]),
     'gd_gemm_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _i32, _p, _p, _i64, _p, _p]),
     'gd_edge_dot_f32': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p]),
-    'gd_edge_dot_bwd_f32': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p]),
+    'gd_edge_dot_bwd_f32': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _p, _p, _i64, _p, _i64, _p]),
     'gd_rows_gemm_wgrad_adam_f32': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _p, _p, _i32, _i32, _i32, _p, _i32, _p,
                                                    _p, _p, _p, _p, _f64, _f64, _f64, _f64, _p]),
     'gd_rows_gemm_wgrad_blocks': (_i32, [_i32]),

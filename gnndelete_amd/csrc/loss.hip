@@ -190,54 +190,66 @@ __global__ __launch_bounds__(256) void edge_dot_kernel(const float* __restrict__
   if (li == 0 && m < n_edges) out[m] = p;
 }
 
-// Decoder backward (input gradient): dz[v,:] = sum over the decoded edges m incident to v of
-//     dout[m] * z[other endpoint of m,:]  (* rel[etype[m],:] for DistMult)
-// over a node-major incidence list (inc_ptr[n+1], inc[k] = 2 m + side; side 0: v = e0[m], the other endpoint is
-// e1[m]).  One lane group per node, its incidences summed in list order: no atomics, the same bits every run
+// Decoder backward (input gradient): dz[v,:] = sum over the decoded edges incident to v of
+//     w[k] * z[other[k],:]  (* rel[et[k],:] for DistMult)
+// over a node-major incidence list inc_ptr[n+1] whose entries carry the OTHER endpoint, the upstream gradient of
+// the edge and (DistMult) its relation - so an incidence costs one dependent gather, the z row.  One lane group per
+// node, four incidences in flight, added in list order; a node with more than kHeavy incidences (a hub of a heavy-tailed
+// graph: 2,000 positive edges at collab size, which alone took 1 ms in list order) is redone by the whole wave, its lane
+// groups taking every G-th incidence and adding up in a fixed shuffle pattern.  No atomics, the same bits every run
 // (autograd's two index_add_ calls add with atomics in arrival order).  Nodes without decoded edges get zeros.
 template <int LPR, bool DISTMULT>
 __global__ __launch_bounds__(256) void edge_dot_bwd_kernel(const float* __restrict__ z, int64_t ld_z, int32_t d4,
-                                                           const int64_t* __restrict__ e0, const int64_t* __restrict__ e1,
+                                                           const int32_t* __restrict__ other, const float* __restrict__ wv,
                                                            const float* __restrict__ rel, int64_t ld_rel,
-                                                           const int64_t* __restrict__ etype,
-                                                           const float* __restrict__ dout,
-                                                           const int64_t* __restrict__ inc_ptr,
-                                                           const int64_t* __restrict__ inc, int64_t n_nodes,
+                                                           const int32_t* __restrict__ et,
+                                                           const int64_t* __restrict__ inc_ptr, int64_t n_nodes,
                                                            float* __restrict__ dz, int64_t ld_dz) {
   constexpr int G = kWave / LPR;
+  constexpr int kHeavy = 64;
   const int lane = threadIdx.x & 63;
   const int g = lane / LPR, li = lane % LPR;
-  const int64_t v = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G + g;
-  if (v >= n_nodes) return;
-  const int64_t k0 = inc_ptr[v], k1 = inc_ptr[v + 1];
-  for (int vec = li; vec < d4; vec += LPR) {
+  const int64_t base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * G;
+  const int64_t v = base + g;
+  int64_t k0 = 0, k1 = 0;
+  if (v < n_nodes) { k0 = inc_ptr[v]; k1 = inc_ptr[v + 1]; }
+  // sum of the incidences first, first + step, ... < last of one node, this lane's float4 `vec`
+  auto walk = [&](int64_t first, int64_t last, int step, int vec) -> float4 {
+    auto term = [&](int64_t k) -> float4 {
+      float4 a = reinterpret_cast<const float4*>(z + (int64_t)other[k] * ld_z)[vec];
+      if (DISTMULT) {
+        const float4 r = reinterpret_cast<const float4*>(rel + (int64_t)et[k] * ld_rel)[vec];
+        a.x *= r.x; a.y *= r.y; a.z *= r.z; a.w *= r.w;
+      }
+      return a;
+    };
     float4 acc = f4_zero();
-    int64_t k = k0;
-    for (; k + 2 <= k1; k += 2) {                    // two incidences in flight, added in list order
-      const int64_t c0 = inc[k], c1 = inc[k + 1];
-      const int64_t m0 = c0 >> 1, m1 = c1 >> 1;
-      const int64_t o0 = (c0 & 1) ? e0[m0] : e1[m0], o1 = (c1 & 1) ? e0[m1] : e1[m1];
-      float4 a0 = reinterpret_cast<const float4*>(z + o0 * ld_z)[vec], a1 = reinterpret_cast<const float4*>(z + o1 * ld_z)[vec];
-      const float w0 = dout[m0], w1 = dout[m1];
-      if (DISTMULT) {
-        const float4 r0 = reinterpret_cast<const float4*>(rel + etype[m0] * ld_rel)[vec];
-        const float4 r1 = reinterpret_cast<const float4*>(rel + etype[m1] * ld_rel)[vec];
-        a0.x *= r0.x; a0.y *= r0.y; a0.z *= r0.z; a0.w *= r0.w;
-        a1.x *= r1.x; a1.y *= r1.y; a1.z *= r1.z; a1.w *= r1.w;
-      }
-      acc = f4_fma(w0, a0, acc);
-      acc = f4_fma(w1, a1, acc);
+    int64_t k = first;
+    for (; k + 3 * step < last; k += 4 * step) {
+      const float4 a0 = term(k), a1 = term(k + step), a2 = term(k + 2 * step), a3 = term(k + 3 * step);
+      acc = f4_fma(wv[k], a0, acc);
+      acc = f4_fma(wv[k + step], a1, acc);
+      acc = f4_fma(wv[k + 2 * step], a2, acc);
+      acc = f4_fma(wv[k + 3 * step], a3, acc);
     }
-    if (k < k1) {
-      const int64_t c0 = inc[k], m0 = c0 >> 1, o0 = (c0 & 1) ? e0[m0] : e1[m0];
-      float4 a0 = reinterpret_cast<const float4*>(z + o0 * ld_z)[vec];
-      if (DISTMULT) {
-        const float4 r0 = reinterpret_cast<const float4*>(rel + etype[m0] * ld_rel)[vec];
-        a0.x *= r0.x; a0.y *= r0.y; a0.z *= r0.z; a0.w *= r0.w;
-      }
-      acc = f4_fma(dout[m0], a0, acc);
+    for (; k < last; k += step) acc = f4_fma(wv[k], term(k), acc);
+    return acc;
+  };
+  const bool heavy = G > 1 && k1 - k0 > kHeavy;
+  if (v < n_nodes && !heavy)
+    for (int vec = li; vec < d4; vec += LPR) reinterpret_cast<float4*>(dz + v * ld_dz)[vec] = walk(k0, k1, 1, vec);
+  unsigned long long todo = __ballot(heavy && li == 0);
+  while (todo) {                                           // wave-uniform: every lane group helps with each hub of the wave
+    const int g2 = (__ffsll((long long)todo) - 1) / LPR;
+    todo &= todo - 1;
+    const int64_t v2 = base + g2;
+    const int64_t h0 = inc_ptr[v2], h1 = inc_ptr[v2 + 1];
+    for (int vec = li; vec < d4; vec += LPR) {
+      float4 acc = walk(h0 + g, h1, G, vec);
+#pragma unroll
+      for (int off = LPR; off < kWave; off <<= 1) acc = f4_add(acc, f4_shfl_xor(acc, off));
+      if (g == 0) reinterpret_cast<float4*>(dz + v2 * ld_dz)[vec] = acc;
     }
-    reinterpret_cast<float4*>(dz + v * ld_dz)[vec] = acc;
   }
 }
 
@@ -480,18 +492,15 @@ extern "C" int gd_adam_f32(float* param, const float* grad, float* exp_avg, floa
   return launched("adam_bump");
 }
 
-extern "C" int gd_edge_dot_bwd_f32(const float* z, int64_t ld_z, int32_t d, const int64_t* e0, const int64_t* e1,
-                                   const float* rel, int64_t ld_rel, const int64_t* etype, const float* dout,
-                                   const int64_t* inc_ptr, const int64_t* inc, int64_t n_nodes, float* dz, int64_t ld_dz,
-                                   void* stream) {
+extern "C" int gd_edge_dot_bwd_f32(const float* z, int64_t ld_z, int32_t d, const int32_t* other, const float* w,
+                                   const float* rel, int64_t ld_rel, const int32_t* etype, const int64_t* inc_ptr,
+                                   int64_t n_nodes, float* dz, int64_t ld_dz, void* stream) {
   using namespace gd;
-  if (n_nodes == 0) return GD_OK;
-  GD_REQUIRE(z && e0 && e1 && dout && inc_ptr && inc && dz, GD_E_NULL, "gd_edge_dot_bwd_f32: null pointer");
-  GD_REQUIRE((rel == nullptr) == (etype == nullptr), GD_E_NULL, "gd_edge_dot_bwd_f32: rel and etype go together");
-  GD_REQUIRE(d > 0 && d % 4 == 0 && d <= 1024 && ld_z >= d && ld_dz >= d && ld_z % 4 == 0 && ld_dz % 4 == 0 &&
-                 (!rel || ld_rel % 4 == 0), GD_E_DIM, "gd_edge_dot_bwd_f32: d=%d must be a multiple of 4 with 16-byte rows", d);
-  GD_REQUIRE(aligned16(z) && aligned16(dz) && (!rel || aligned16(rel)) && z != dz, GD_E_ALIGN,
-             "gd_edge_dot_bwd_f32: unaligned or aliasing pointer");
+  GD_REQUIRE(z && inc_ptr && dz && (!rel || etype), GD_E_NULL, "gd_edge_dot_bwd_f32: null pointer");
+  GD_REQUIRE(d > 0 && d % 4 == 0 && d <= 1024 && ld_z % 4 == 0 && ld_dz % 4 == 0 && ld_z >= d && ld_dz >= d && (!rel || ld_rel % 4 == 0),
+             GD_E_DIM, "gd_edge_dot_bwd_f32: d=%d must be a multiple of 4 (<= 1024) with 16-byte row strides", d);
+  GD_REQUIRE(aligned16(z) && aligned16(dz) && (!rel || aligned16(rel)) && z != dz, GD_E_ALIGN, "gd_edge_dot_bwd_f32: unaligned or aliasing pointer");
+  if (n_nodes <= 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
   const int d4 = d / 4;
   const int lpr = lanes_per_row(d4);
@@ -499,8 +508,8 @@ extern "C" int gd_edge_dot_bwd_f32(const float* z, int64_t ld_z, int32_t d, cons
   const dim3 grid((unsigned)((n_nodes + per_block - 1) / per_block));
 #define GD_DOTB_CASE(LPR)                                                                                              \
   do {                                                                                                                 \
-    if (rel) hipLaunchKernelGGL((edge_dot_bwd_kernel<LPR, true>), grid, dim3(256), 0, s, z, ld_z, d4, e0, e1, rel, ld_rel, etype, dout, inc_ptr, inc, n_nodes, dz, ld_dz); \
-    else hipLaunchKernelGGL((edge_dot_bwd_kernel<LPR, false>), grid, dim3(256), 0, s, z, ld_z, d4, e0, e1, rel, ld_rel, etype, dout, inc_ptr, inc, n_nodes, dz, ld_dz);    \
+    if (rel) hipLaunchKernelGGL((edge_dot_bwd_kernel<LPR, true>), grid, dim3(256), 0, s, z, ld_z, d4, other, w, rel, ld_rel, etype, inc_ptr, n_nodes, dz, ld_dz); \
+    else hipLaunchKernelGGL((edge_dot_bwd_kernel<LPR, false>), grid, dim3(256), 0, s, z, ld_z, d4, other, w, rel, ld_rel, etype, inc_ptr, n_nodes, dz, ld_dz);    \
   } while (0)
   switch (lpr) {
     case 1: GD_DOTB_CASE(1); break;

@@ -677,17 +677,19 @@ class _EdgeDot(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             n, d = z.shape
             if d % 4 == 0 and z.stride(0) % 4 == 0 and (rel is None or rel.stride(0) % 4 == 0):
-                # node-major incidence list of the decoded edges (one stable sort), then one deterministic kernel
+                # node-major incidence list of the decoded edges (one stable sort) carrying, per incidence, the other
+                # endpoint, the edge's upstream gradient and its relation; then one deterministic kernel
                 m = e0.shape[0]
                 ends = torch.cat([e0, e1])
-                order = torch.argsort(ends, stable=True)
-                inc = (order % m) * 2 + (order >= m).long()
-                inc_ptr = torch.zeros(n + 1, dtype=torch.long, device=z.device)
-                inc_ptr[1:] = torch.cumsum(torch.bincount(ends, minlength=n), 0)
+                ends_sorted, order = torch.sort(ends, stable=True)
+                edge = order % m
+                other = torch.where(order >= m, e0[edge], e1[edge]).to(torch.int32)
+                inc_ptr = torch.searchsorted(ends_sorted, torch.arange(n + 1, device=z.device))     # (a histogram of 8 M keys costs 0.4 ms)
                 dz = torch.empty(n, d, dtype=torch.float32, device=z.device)
-                check(_lib.lib().gd_edge_dot_bwd_f32(ptr(z), z.stride(0), d, ptr(e0), ptr(e1), ptr(rel),
-                                                     rel.stride(0) if rel is not None else 0, ptr(etype), ptr(dout),
-                                                     ptr(inc_ptr), ptr(inc), n, ptr(dz), dz.stride(0), stream_ptr(z.device)),
+                et_inc = etype[edge].to(torch.int32) if rel is not None else None
+                check(_lib.lib().gd_edge_dot_bwd_f32(ptr(z), z.stride(0), d, ptr(other), ptr(dout[edge]), ptr(rel),
+                                                     rel.stride(0) if rel is not None else 0, ptr(et_inc),
+                                                     ptr(inc_ptr), n, ptr(dz), dz.stride(0), stream_ptr(z.device)),
                       'gd_edge_dot_bwd_f32')
             else:
                 a, b = z[e0], z[e1]

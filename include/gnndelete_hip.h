@@ -434,14 +434,14 @@ int gd_edge_dot_f32(const float* z, int64_t ld_z, int32_t d, const int64_t* e0, 
                     int64_t n_edges, float* out, void* stream);
 
 /* Input gradient of the decoders (autograd of gcn.py:26-36 / rgcn.py:40-47: two scatter-adds with atomics):
- *     dz[v,:] = sum_{m incident to v} dout[m] * z[other endpoint of m,:]  (* rel[etype[m],:] for DistMult)
- * over a node-major incidence list inc_ptr[n_nodes+1], inc[k] = 2 m + side (side 0: v = e0[m]); every row of dz is
- * written (zeros where nothing is incident), incidences are added in list order: deterministic, no atomics.
- * d % 4 == 0, 16-byte aligned rows; dz must not alias z. */
-int gd_edge_dot_bwd_f32(const float* z, int64_t ld_z, int32_t d, const int64_t* e0, const int64_t* e1,
-                        const float* rel, int64_t ld_rel, const int64_t* etype, const float* dout,
-                        const int64_t* inc_ptr, const int64_t* inc, int64_t n_nodes, float* dz, int64_t ld_dz,
-                        void* stream);
+ *     dz[v,:] = sum_{k in [inc_ptr[v], inc_ptr[v+1])} w[k] * z[other[k],:]  (* rel[etype[k],:] for DistMult)
+ * over a node-major incidence list of the decoded edges: for every edge m = (a, b) with upstream gradient dout[m] the
+ * list of a holds (other = b, w = dout[m], etype = type of m) and the list of b holds (other = a, ...).  Every row of
+ * dz is written (zeros where nothing is incident); incidences are added in list order, hubs (> 64 incidences) by the
+ * whole wave in a fixed pattern: deterministic, no atomics.  d % 4 == 0, 16-byte aligned rows; dz must not alias z. */
+int gd_edge_dot_bwd_f32(const float* z, int64_t ld_z, int32_t d, const int32_t* other, const float* w,
+                        const float* rel, int64_t ld_rel, const int32_t* etype, const int64_t* inc_ptr,
+                        int64_t n_nodes, float* dz, int64_t ld_dz, void* stream);
 
 /* Edge-probability Neighborhood-Influence term of GNNDeleteTrainer
  * (framework/trainer/gnndelete.py:174-193 pair mask, :239-241 loss) over the n_s x n_s block of

@@ -750,8 +750,8 @@ def test_gat_hub_row_with_more_pieces_than_feature_lanes(d, hub_degree):
 def test_edge_dot_backward_kernel_is_exact_and_reproducible(d):
     """Decoder input gradients (dot product and DistMult) from gd_edge_dot_bwd_f32 - one deterministic pass over a
     node-major incidence list instead of autograd's two atomic scatter-adds - against fp64 autograd, with random
-    upstream gradients, repeated edges, self pairs and isolated nodes; two runs give the same bits.  d = 10 takes the
-    scatter fallback (rows not 16-byte aligned)."""
+    upstream gradients, repeated edges, self pairs, a hub node (the cooperative path) and isolated nodes; two runs give
+    the same bits.  d = 10 takes the scatter fallback (rows not 16-byte aligned)."""
     from gnndelete_amd import ops
     g = torch.Generator().manual_seed(d + 1)
     n, m, r = 90, 700, 5
@@ -759,6 +759,7 @@ def test_edge_dot_backward_kernel_is_exact_and_reproducible(d):
     e = torch.randint(0, n - 7, (2, m), generator=g)              # the last 7 nodes stay isolated
     e[:, :20] = e[:, 20:40]                                        # repeated edges
     e[1, 40:50] = e[0, 40:50]                                      # self pairs
+    e[0, 100:420] = 3                                              # a hub: 320+ incidences, summed by the whole wave
     rel = torch.randn(r, d, generator=g)
     et = torch.randint(0, r, (m,), generator=g)
     up = torch.randn(m, generator=g)
