@@ -28,9 +28,10 @@
 // of extra tiles (piece k of a run -> slice k mod V); a slice row is an ordinary row to this kernel except that its
 // outputs go to y_ext, and rgcn_hub_fixup_kernel adds a hub's slices to its row of y in slice order (deterministic).
 //
-// The A tile is double buffered: while the MFMAs of step s read one buffer the same waves gather step s + 1 into the
-// other - one barrier per step; step scalars sit in an LDS ring, piece descriptors and edge (col, w) pairs are fetched
-// into registers a step ahead of their use.
+// One A tile per block, two barriers per step (products of step s | gather of step s + 1): at 53 KB of LDS three blocks
+// share a CU, and the third block hides more of the gathers' latency than a second A buffer did inside a block
+// (measured: 1.25 -> 1.21 ms per launch).  Step scalars sit in an LDS ring, piece descriptors and edge (col, w) pairs
+// are fetched into registers a step ahead of their use.
 #include "common.h"
 
 namespace gd {
@@ -41,7 +42,7 @@ using f32x4t = __attribute__((ext_vector_type(4))) float;
 constexpr int kRing = 256;                              // steps in the LDS ring (power of two)
 
 template <int DIN, int OW, int KL>
-__global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
+__global__ __launch_bounds__(512, 6) void rgcn_tile_kernel(
     const int32_t* __restrict__ tile_order, const int32_t* __restrict__ tile_step_ptr, const int32_t* __restrict__ step_rel,
     const int32_t* __restrict__ step_piece_ptr, const int2* __restrict__ piece,
     const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ x, int64_t ldx,
@@ -52,11 +53,13 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
   constexpr int DOUT = 4 * OW, OPITCH = DOUT + 4, NOH = OW / 16, NMM = KL / 16;
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   // LDS: two compact A tiles (32 pieces x PITCH), the tile's accumulators (64 nodes x OPITCH), the step ring, row maps
-  auto a_lds = [&](int b) -> float* { return lds_raw + b * (32 * PITCH); };
-  float* const acc_lds = lds_raw + 2 * 32 * PITCH;
+  // ONE compact A tile: with 53 KB per block three blocks share a CU (24 waves) - the kernel waits on memory more than on
+  // anything else, and the second buffer bought less overlap inside a block than a third block buys across blocks
+  float* const a_tile = lds_raw;
+  float* const acc_lds = lds_raw + 32 * PITCH;
   int32_t* const m_rel = reinterpret_cast<int32_t*>(acc_lds + 64 * OPITCH);
   int32_t* const m_pp = m_rel + kRing;
-  int32_t* const rowmap = m_pp + kRing;                     // [2][32]: node row of the piece in compact row q
+  int32_t* const rowmap = m_pp + kRing;                     // [32]: node row of the piece in compact row q
   const int tile = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
   const int s0 = tile_step_ptr[tile], s1 = tile_step_ptr[tile + 1];
   if (s0 == s1) return;
@@ -143,12 +146,11 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
 
   int2 d_cur = load_desc(s0), d_nxt = load_desc(s0 + 1);
   Cw c_cur = load_cw(d_cur);
-  gather(d_cur, c_cur, a_lds(0), rowmap);
+  gather(d_cur, c_cur, a_tile, rowmap);
   d_cur = d_nxt;
   c_cur = load_cw(d_cur);
   d_nxt = load_desc(s0 + 2);
   __syncthreads();
-  int cur = 0;
   const float4* const wpk4 = reinterpret_cast<const float4*>(wpk);
   for (int s = s0; s < s1; ++s) {
     const int n = m_pp[(s + 1 - s0) & (kRing - 1)] - m_pp[(s - s0) & (kRing - 1)];     // pieces of this step (<= 32)
@@ -162,17 +164,13 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
 #pragma unroll
         for (int mm = 0; mm < NMM; ++mm) wv[oh][mm] = wp[(oh * NMM + mm) * 64];
     }
-    if (s + 1 < s1) gather(d_cur, c_cur, a_lds(cur ^ 1), rowmap + 32 * (cur ^ 1));
-    d_cur = d_nxt;
-    c_cur = load_cw(d_cur);
-    d_nxt = load_desc(s + 3);
     if (mm_on) {
       // D[16 out][16 piece] += W^T[out][k] A^T[k][piece] on v_mfma_f32_16x16x4_f32: lane (j = lane & 15, kq = lane >> 4)
       // feeds k = k0 + 16 mm + 4 kq + c of piece 16 ch + j (one 16-byte LDS read per mm) and ends with the outputs
       // 16 oh + 4 kq + c of that piece - added to the piece's node row of the accumulators (distinct rows per step,
       // the (ot, ch) ranges of the waves are disjoint: no atomics, relations in ascending order)
       const int j = lane & 15, kq = lane >> 4;
-      const float* bsrc = a_lds(cur) + (16 * ch + j) * PITCH + ot * k0_stride + 4 * kq;
+      const float* bsrc = a_tile + (16 * ch + j) * PITCH + ot * k0_stride + 4 * kq;
       f32x4t dacc[NOH];
 #pragma unroll
       for (int oh = 0; oh < NOH; ++oh) dacc[oh] = f32x4t{0.f, 0.f, 0.f, 0.f};
@@ -188,7 +186,7 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
         }
       }
       if (16 * ch + j < n) {
-        float* dst = acc_lds + rowmap[32 * cur + 16 * ch + j] * OPITCH + OW * ot + 4 * kq;
+        float* dst = acc_lds + rowmap[16 * ch + j] * OPITCH + OW * ot + 4 * kq;
 #pragma unroll
         for (int oh = 0; oh < NOH; ++oh) {
           float4 v = *reinterpret_cast<float4*>(dst + 16 * oh);
@@ -197,8 +195,12 @@ __global__ __launch_bounds__(512, 4) void rgcn_tile_kernel(
         }
       }
     }
-    __syncthreads();
-    cur ^= 1;
+    __syncthreads();                                       // every wave is done with the A tile and the row map
+    if (s + 1 < s1) gather(d_cur, c_cur, a_tile, rowmap);
+    d_cur = d_nxt;
+    c_cur = load_cw(d_cur);
+    d_nxt = load_desc(s + 3);
+    __syncthreads();                                       // the next step's tile is complete
     if (((s + 1 - s0) & 63) == 0) ring_fill(s + 1 + 128, 64);   // slots of steps every wave has left behind
   }
   // the tile's rows: y += accumulators (a hub's slice rows go to y_ext, added up by the fix-up)
@@ -319,7 +321,7 @@ extern "C" int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* t
   // two A tiles: 67.6 KB at d_in = 128 - above the 64 KB a launch gets without asking
 #define GD_RT_CASE(DIN, OW, KL)                                                                                               \
   do {                                                                                                                        \
-    constexpr int kLds = (2 * 32 * (DIN + 4) + 64 * (4 * OW + 4)) * 4 + kRing * 8 + 2 * 32 * 4;                                                                             \
+    constexpr int kLds = (32 * (DIN + 4) + 64 * (4 * OW + 4)) * 4 + kRing * 8 + 32 * 4;                                                                             \
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rgcn_tile_kernel<DIN, OW, KL>),        \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds);                      \
     if (attr != hipSuccess) return fail(-(int)attr, "gd_rgcn_tile_conv_f32: %s", hipGetErrorString(attr));                    \
