@@ -641,6 +641,26 @@ def main():
                 torch.cuda.synchronize()
                 out['extras'][key] = args.steps / (time.perf_counter() - t1)
             out['extras']['affected_rows'] = {'S2': int(data.sdf_node_2hop_mask.sum()), 'of': data.num_nodes}
+            # informational only: the same full step with the 128-wide row GEMMs' fp32 products formed from bf16 partial
+            # products (gd_set_matrix_split(6), opt-in) - `value` above uses the fp32 instruction
+            from gnndelete_amd import ops as _ops
+            if _ops.matrix_split() == 0:
+                _ops.set_matrix_split(6)
+                try:
+                    model.load_state_dict(state)
+                    seng = NodeembEngine(*eng_args, loss_type=args.loss_type, alpha=0.5, lr=1e-3)
+                    if args.unroll > 1:
+                        seng.prepare_unrolled(args.unroll)
+                    for _ in range(args.warmup):
+                        seng.step()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    seng.run(args.steps, unroll=args.unroll)
+                    torch.cuda.synchronize()
+                    out['extras']['iters_per_s_bf16x6_split_products'] = args.steps / (time.perf_counter() - t1)
+                    out['extras']['roofline_del_gemm_bf16x6_split'] = time_del_gemm(seng)
+                finally:
+                    _ops.set_matrix_split(0)
         if rep_rate is not None:
             out.setdefault('extras', {})['iters_per_s_independent_replicas'] = rep_rate
         if world == 1 and hasattr(eng, 'idx1'):

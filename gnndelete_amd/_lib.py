@@ -14,11 +14,13 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'gnndelete_hip.h')
 _i32, _i64, _f32, _f64, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
 # name -> (restype, argtypes); must list every symbol the header declares
-ABI_VERSION = 2          # GD_ABI_VERSION of include/gnndelete_hip.h this binding was written against
+ABI_VERSION = 3          # GD_ABI_VERSION of include/gnndelete_hip.h this binding was written against
 
 PROTOTYPES = {
     'gd_abi_version': (ctypes.c_int, []),
     'gd_last_error_string': (ctypes.c_char_p, []),
+    'gd_matrix_split': (ctypes.c_int, []),
+    'gd_set_matrix_split': (ctypes.c_int, [ctypes.c_int]),
     'gd_csr_from_coo_workspace': (_i64, [_i32, _i64]),
     'gd_csr_from_coo': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i64, _p]),
     'gd_agg_gemm_f32': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p, _i64, _i32,

@@ -12,6 +12,7 @@ namespace gd {
 constexpr int kWave = 64;  // CDNA wavefront width (hard-coded on purpose: gfx950 only)
 
 char* error_buffer();  // thread-local, defined in api.cpp
+int matrix_split();    // 0 / 6 / 9, see gd_set_matrix_split (api.cpp)
 
 inline int fail(int code, const char* fmt, ...) {
   va_list ap;

@@ -21,6 +21,40 @@
 namespace gd {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x4v = __attribute__((ext_vector_type(4))) uint32_t;
+
+// Split arithmetic (NP = 6 / 9 below): an fp32 value is the exact sum of three successive round-to-nearest bf16 pieces
+// (3 x 8 significant bits + signs), x = x1 + x2 + x3, so the fp32 product s w is the sum of nine partial products
+// s_i w_j, each EXACT in fp32 (8 x 8 bits), formed on v_mfma_f32_32x32x16_bf16 and accumulated in fp32 like the products
+// of the fp32 instruction.  NP = 9 takes all nine; NP = 6 leaves out s2 w3, s3 w2, s3 w3 (each <= 2^-26 |s w|, a quarter
+// of an fp32 rounding).  Measured against an fp64 product on the Del operator's shape (tools/experiments/split_lab.hip):
+// rel-L2 1.6e-7 for both, 2.0e-7 for v_mfma_f32_32x32x2_f32 - and 44 us instead of 70 us, because the fp32 instruction
+// is what keeps this kernel at the chip's power limit.
+__device__ inline void split8(const float4 a, const float4 b, bf16x8 (&s)[3]) {
+  const f32x2 v[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
+  u32x4v p[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x2 r = v[i];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));     // v_cvt_pk_bf16_f32 (RNE)
+      p[q][i] = w;
+      if (q < 2) {
+        f32x2 h;
+        h[0] = __builtin_bit_cast(float, w << 16);
+        h[1] = __builtin_bit_cast(float, w & 0xffff0000u);
+        r = r - h;                                           // exact
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) s[q] = __builtin_bit_cast(bf16x8, p[q]);
+}
+
 constexpr int kWgradMaxRows = 1024;   // rows of the reduction dimension one wgrad block owns
 
 constexpr int kGemmThreads = 512;   // 8 waves share one LDS weight image; 2 blocks per CU
@@ -33,8 +67,10 @@ struct RowDots { const float* u1; const float* u2; float* o1; float* o2; };
 // 3: plain + the two row dot products of RowDots, 4: gated like 2 after a rank-1 correction of the product,
 //    out[r, n] += o1[r] u1[n] + o2[r] u2[n] (RowDots reused: o1 / o2 per-row scalars READ by row id, u1 / u2 per column)
 // SEL: rows may come from a second buffer (in_alt where sel[r] != 0); only instantiated for MODE 0 and 3
-template <int NT, int MODE, bool SEL = false>
-__global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
+// NP: 0 = products on v_mfma_f32_32x32x2_f32; 6 / 9 = split arithmetic on the bf16 matrix instruction (above)
+// KC (split form only): d_in / 32, a compile-time constant there - the wave keeps whole half rows in registers
+template <int NT, int MODE, bool SEL = false, int NP = 0, int KC = 0>
+__global__ __launch_bounds__(kGemmThreads, NP ? 2 : 4) void rows_gemm_mfma_kernel(
     const float* in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel,
     const float* __restrict__ w, int32_t d_in, int32_t trans_w, const float* __restrict__ bias, int32_t relu_in,
     float* out, int64_t ld_out, float* __restrict__ save_in, const uint32_t* __restrict__ gate_bits,
@@ -53,7 +89,25 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
   // (trans_w = 0) the loads are coalesced as well; with [n][k] weights they are strided (slow fill: callers with
   // constant weights hand over a pre-transposed copy, see engine.py).
   constexpr int NTP = NT == 3 ? 4 : NT;
-  for (int e = tid; e < d_in * 32; e += kGemmThreads) {
+  // split form: three bf16 images [piece][k chunk kc][8-k group m][output tile t][khalf][feature r] of 16-byte operands
+  // (k = 32 kc + 16 khalf + 8 m + c: the k slots lane (r, khalf) of the sample operand holds); one (8-k group, feature)
+  // item per thread and step - 8 loads in flight, three 16-byte LDS stores
+  bf16x8* const wimg = reinterpret_cast<bf16x8*>(wl);
+  const int pstride = (d_in >> 3) * d_out;                   // operands per piece image
+  if (NP) {
+    for (int e = tid; e < pstride; e += kGemmThreads) {
+      const int kg = e / d_out, n = e - kg * d_out;
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = trans_w ? w[(int64_t)n * d_in + 8 * kg + c] : w[(int64_t)(8 * kg + c) * d_out + n];
+      bf16x8 pc[3];
+      split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), pc);
+      const int off = ((((kg >> 2) * 2 + (kg & 1)) * NT + (n >> 5)) * 2 + ((kg >> 1) & 1)) * 32 + (n & 31);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) wimg[q * pstride + off] = pc[q];
+    }
+  }
+  for (int e = tid; !NP && e < d_in * 32; e += kGemmThreads) {
     const int k = e >> 5, r = e & 31;
     float v[NTP];
 #pragma unroll
@@ -80,6 +134,142 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
   };
   // row r is read from in_alt instead of in where sel[r] != 0 (a matrix whose rows live in two buffers)
   auto base_of = [&](int32_t r) -> const float* { return (SEL && sel[r]) ? in_alt : in; };
+  // ---- epilogue: D[i][j], j = lane&31 = sample, i = (r&3) + 8*(r>>2) + 4*(lane>>5) = feature
+  auto epilogue = [&](f32x16 (&acc)[NT], int32_t row_cur, int s_a, bool live, const uint32_t (&gate_w)[NT], float r1a, float r1b) {
+      // (feature 32t + 8q + 4 khalf + c sits in acc[t][4q + c]; bit b of word t of a row's packed
+      //  sign / gate mask is feature 32t + b, so this lane owns bits 8q + 4 khalf + c of each word)
+      float* dst = out + (int64_t)row_cur * ld_out + 4 * khalf;
+      constexpr bool want_dots = MODE == 3;
+      // (the u vectors are the same for every tile: without the clobber LICM keeps all of them in registers)
+      if (want_dots) asm volatile("" ::: "memory");
+      float dot1 = 0.f, dot2 = 0.f;
+  #pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        uint32_t pos = 0;
+  #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 v = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+          const int n0 = 32 * t + 8 * q;
+          if (bias) v = f4_add(v, *reinterpret_cast<const float4*>(bias + n0 + 4 * khalf));
+          if (want_dots) {
+            asm volatile("" ::: "memory");      // one pair of u loads in flight, not all 8 NT of them
+            const float4 p1 = *reinterpret_cast<const float4*>(dots.u1 + n0 + 4 * khalf);
+            const float4 p2 = *reinterpret_cast<const float4*>(dots.u2 + n0 + 4 * khalf);
+            dot1 = fmaf(v.x, p1.x, dot1); dot1 = fmaf(v.y, p1.y, dot1); dot1 = fmaf(v.z, p1.z, dot1); dot1 = fmaf(v.w, p1.w, dot1);
+            dot2 = fmaf(v.x, p2.x, dot2); dot2 = fmaf(v.y, p2.y, dot2); dot2 = fmaf(v.z, p2.z, dot2); dot2 = fmaf(v.w, p2.w, dot2);
+          }
+          if (MODE == 4) {
+            const float4 p1 = *reinterpret_cast<const float4*>(dots.u1 + n0 + 4 * khalf);
+            const float4 p2 = *reinterpret_cast<const float4*>(dots.u2 + n0 + 4 * khalf);
+            v.x = fmaf(r1b, p2.x, fmaf(r1a, p1.x, v.x)); v.y = fmaf(r1b, p2.y, fmaf(r1a, p1.y, v.y));
+            v.z = fmaf(r1b, p2.z, fmaf(r1a, p1.z, v.z)); v.w = fmaf(r1b, p2.w, fmaf(r1a, p1.w, v.w));
+          }
+          if (MODE == 2 || MODE == 4) {   // ReLU backward: pass the gradient where the forward activation input was > 0
+            const uint32_t m = gate_w[t] >> (8 * q + 4 * khalf);
+            v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f;
+            v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+          }
+          if (MODE == 1)
+            pos |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
+                   << (8 * q + 4 * khalf);
+          if (live) *reinterpret_cast<float4*>(dst + n0) = v;
+        }
+        if (MODE == 1) {     // the two half-row lanes merge their bits (all lanes shuffle)
+          pos |= (uint32_t)__shfl_xor((int)pos, 32);
+          if (live && khalf == 0) sign_out[(int64_t)s_a * NT + t] = pos;
+        }
+      }
+      if (want_dots) {       // the two half-row lanes of a sample add their halves (all lanes shuffle)
+        dot1 += __shfl_xor(dot1, 32);
+        dot2 += __shfl_xor(dot2, 32);
+        if (live && khalf == 0) { dots.o1[row_cur] = dot1; dots.o2[row_cur] = dot2; }
+      }
+  };
+
+  if constexpr (NP != 0) {
+    // ---- split form: whole half rows in registers (4 KC float4 per lane), the NEXT tile's in flight while this one feeds
+    // the matrix cores - a 32-wide k chunk lasts < 1 us here, chunk-wise prefetch no longer covers the HBM latency
+    int tile = blockIdx.x * kWaves + wave;
+    if (tile >= n_tiles) return;
+    auto fetch = [&](int t_, float4 (&a)[4 * KC], int32_t& row) {
+      row = row_of(min(t_, n_tiles - 1));
+      const float4* s0 = reinterpret_cast<const float4*>(base_of(row) + (int64_t)row * ld_in) + khalf * 4;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[kc * 4 + i] = s0[kc * 8 + i];
+    };
+    auto work = [&](int t_, float4 (&a)[4 * KC], int32_t row) {
+      const int s_a = t_ * 32 + r_lo;
+      const bool live = s_a < n_sel;
+      uint32_t gate_w[NT];
+      float r1a = 0.f, r1b = 0.f;
+      if (MODE == 2 || MODE == 4) {
+        const uint32_t* gsrc = gate_bits + (int64_t)min(s_a, n_sel - 1) * NT;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gate_w[t] = gsrc[t];
+        if (MODE == 4) { r1a = dots.o1[row]; r1b = dots.o2[row]; }
+      }
+      if (save_in && live) {
+        float4* sav = reinterpret_cast<float4*>(save_in + (int64_t)s_a * d_in) + khalf * 4;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sav[kc * 8 + i] = a[kc * 4 + i];
+      }
+      f32x16 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          float4 lo = a[kc * 4 + 2 * m], hi = a[kc * 4 + 2 * m + 1];
+          if (relu_in) {
+            lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); lo.z = fmaxf(lo.z, 0.f); lo.w = fmaxf(lo.w, 0.f);
+            hi.x = fmaxf(hi.x, 0.f); hi.y = fmaxf(hi.y, 0.f); hi.z = fmaxf(hi.z, 0.f); hi.w = fmaxf(hi.w, 0.f);
+          }
+          bf16x8 sp[3];
+          split8(lo, hi, sp);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const bf16x8* wk = wimg + (((kc * 2 + m) * NT + t) * 2 + khalf) * 32 + r_lo;
+            const bf16x8 w1 = wk[0], w2 = wk[pstride], w3 = wk[2 * pstride];
+            // transposed product (weight = "A" operand: D rows = output features; sample = "B" operand: D cols =
+            // samples, as in the fp32 form below); small terms first
+            if (NP == 9) {
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, sp[2], acc[t], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, sp[1], acc[t], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, sp[2], acc[t], 0, 0, 0);
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, sp[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, sp[1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, sp[2], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, sp[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, sp[1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, sp[0], acc[t], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);                 // keep the LDS reads of later k groups where they are
+        }
+      }
+      epilogue(acc, row, s_a, live, gate_w, r1a, r1b);
+    };
+    constexpr int KCR = KC ? KC : 1;
+    float4 ra[4 * KCR], rb[4 * KCR];
+    int32_t rowa, rowb;
+    fetch(tile, ra, rowa);
+    for (; tile < n_tiles; tile += 2 * stride) {
+      fetch(tile + stride, rb, rowb);
+      work(tile, ra, rowa);
+      if (tile + stride >= n_tiles) break;
+      fetch(tile + 2 * stride, ra, rowa);
+      work(tile + stride, rb, rowb);
+    }
+    return;
+  }
+
   int tile = blockIdx.x * kWaves + wave;
   if (tile >= n_tiles) return;
   int32_t row_cur = row_of(tile);
@@ -155,55 +345,7 @@ __global__ __launch_bounds__(kGemmThreads, 4) void rows_gemm_mfma_kernel(
       }
     }
 
-    // ---- epilogue: D[i][j], j = lane&31 = sample, i = (r&3) + 8*(r>>2) + 4*(lane>>5) = feature
-    // (feature 32t + 8q + 4 khalf + c sits in acc[t][4q + c]; bit b of word t of a row's packed
-    //  sign / gate mask is feature 32t + b, so this lane owns bits 8q + 4 khalf + c of each word)
-    float* dst = out + (int64_t)row_cur * ld_out + 4 * khalf;
-    constexpr bool want_dots = MODE == 3;
-    // (the u vectors are the same for every tile: without the clobber LICM keeps all of them in registers)
-    if (want_dots) asm volatile("" ::: "memory");
-    float dot1 = 0.f, dot2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      uint32_t pos = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 v = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
-        const int n0 = 32 * t + 8 * q;
-        if (bias) v = f4_add(v, *reinterpret_cast<const float4*>(bias + n0 + 4 * khalf));
-        if (want_dots) {
-          asm volatile("" ::: "memory");      // one pair of u loads in flight, not all 8 NT of them
-          const float4 p1 = *reinterpret_cast<const float4*>(dots.u1 + n0 + 4 * khalf);
-          const float4 p2 = *reinterpret_cast<const float4*>(dots.u2 + n0 + 4 * khalf);
-          dot1 = fmaf(v.x, p1.x, dot1); dot1 = fmaf(v.y, p1.y, dot1); dot1 = fmaf(v.z, p1.z, dot1); dot1 = fmaf(v.w, p1.w, dot1);
-          dot2 = fmaf(v.x, p2.x, dot2); dot2 = fmaf(v.y, p2.y, dot2); dot2 = fmaf(v.z, p2.z, dot2); dot2 = fmaf(v.w, p2.w, dot2);
-        }
-        if (MODE == 4) {
-          const float4 p1 = *reinterpret_cast<const float4*>(dots.u1 + n0 + 4 * khalf);
-          const float4 p2 = *reinterpret_cast<const float4*>(dots.u2 + n0 + 4 * khalf);
-          v.x = fmaf(r1b, p2.x, fmaf(r1a, p1.x, v.x)); v.y = fmaf(r1b, p2.y, fmaf(r1a, p1.y, v.y));
-          v.z = fmaf(r1b, p2.z, fmaf(r1a, p1.z, v.z)); v.w = fmaf(r1b, p2.w, fmaf(r1a, p1.w, v.w));
-        }
-        if (MODE == 2 || MODE == 4) {   // ReLU backward: pass the gradient where the forward activation input was > 0
-          const uint32_t m = gate_w[t] >> (8 * q + 4 * khalf);
-          v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f;
-          v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
-        }
-        if (MODE == 1)
-          pos |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
-                 << (8 * q + 4 * khalf);
-        if (live) *reinterpret_cast<float4*>(dst + n0) = v;
-      }
-      if (MODE == 1) {     // the two half-row lanes merge their bits (all lanes shuffle)
-        pos |= (uint32_t)__shfl_xor((int)pos, 32);
-        if (live && khalf == 0) sign_out[(int64_t)s_a * NT + t] = pos;
-      }
-    }
-    if (want_dots) {       // the two half-row lanes of a sample add their halves (all lanes shuffle)
-      dot1 += __shfl_xor(dot1, 32);
-      dot2 += __shfl_xor(dot2, 32);
-      if (live && khalf == 0) { dots.o1[row_cur] = dot1; dots.o2[row_cur] = dot2; }
-    }
+    epilogue(acc, row_cur, s_a, live, gate_w, r1a, r1b);
     row_cur = row_nxt;
     // row index of the tile after next: its first loads are only issued at the end of the next tile
     row_nxt = row_of(min(tile + 2 * stride, n_tiles - 1));
@@ -584,7 +726,8 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
   GD_REQUIRE(!(gate_bits && sign_out), GD_E_DIM, "gd_rows_gemm_f32: gate and sign output are exclusive");
   if (n_sel == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = (size_t)d_in * 32 * (d_out / 32 == 3 ? 4 : d_out / 32) * sizeof(float);   // NT = 3 is padded to 4
+  size_t lds = (size_t)d_in * 32 * (d_out / 32 == 3 ? 4 : d_out / 32) * sizeof(float);   // NT = 3 is padded to 4
+  const int np = matrix_split();
   const bool mfma_ok = (d_out % 32 == 0) && d_out <= 128 && (d_in % 32 == 0) && lds <= 64 * 1024 && aligned16(in) &&
                        (ld_in % 4 == 0) && (!save_in || aligned16(save_in)) && aligned16(out) && (ld_out % 4 == 0) &&
                        (!bias || aligned16(bias));
@@ -594,24 +737,38 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
     // persistent blocks, 2 per CU by default (GD_ROWS_GEMM_GRID: A-B knob, read once)
     static const int grid_cap = [] { const char* e = getenv("GD_ROWS_GEMM_GRID"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
     if (grid > grid_cap) grid = grid_cap;
-#define GD_RG_LAUNCH(NT, MODE)                                                                                    \
-  hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT, MODE>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in, idx,   \
-                     n_sel, w, d_in, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out, in_alt, sel, dots)
+    // split arithmetic where its register-resident rows are instantiated (d_in = 64 / 128); other widths keep the fp32 instruction
+    // (and only for 96 / 128 outputs: narrower products are bound by their row traffic under either instruction)
+    const int kc_split = (np && (d_in == 64 || d_in == 128) && d_out >= 96) ? d_in / 32 : 0;
+    if (kc_split) {
+      lds = (size_t)3 * d_in * d_out * 2;                    // three bf16 images, no padding of NT = 3
+      if (grid > grid_cap / 2 && lds > 80 * 1024) grid = grid_cap / 2;      // one block per CU fits
+    }
+#define GD_RG_KERNEL(NT, MODE, SELV, NPV, KCV)                                                                    \
+  do {                                                                                                            \
+    auto kern = rows_gemm_mfma_kernel<NT, MODE, SELV, NPV, KCV>;                                                  \
+    if (NPV && lds > 64 * 1024) {                                                                                 \
+      static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      GD_REQUIRE(once == hipSuccess, -(int)once, "gd_rows_gemm_f32: cannot raise the LDS limit");                \
+    }                                                                                                             \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in, idx, n_sel, w, d_in, trans_w,     \
+                       bias, relu_in, out, ld_out, save_in, gate_bits, sign_out, in_alt, sel, dots);              \
+  } while (0)
+#define GD_RG_LAUNCH(NT, MODE, SELV)                                                                              \
+  do {                                                                                                            \
+    if (kc_split == 4) GD_RG_KERNEL(NT, MODE, SELV, 6, 4);                                                        \
+    else if (kc_split == 2) GD_RG_KERNEL(NT, MODE, SELV, 6, 2);                                                   \
+    else GD_RG_KERNEL(NT, MODE, SELV, 0, 0);                                                                      \
+  } while (0)
 #define GD_RG_CASE(NT)                                                                                            \
   do {                                                                                                            \
-    if (gate_bits && dots.u1) GD_RG_LAUNCH(NT, 4);                                                                \
-    else if (gate_bits) GD_RG_LAUNCH(NT, 2);                                                                      \
-    else if (sign_out) GD_RG_LAUNCH(NT, 1);                                                                       \
-    else if (dots.u1 && sel)                                                                                      \
-      hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT, 3, true>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in,  \
-                         idx, n_sel, w, d_in, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out,  \
-                         in_alt, sel, dots);                                                                      \
-    else if (dots.u1) GD_RG_LAUNCH(NT, 3);                                                                        \
-    else if (sel)                                                                                                 \
-      hipLaunchKernelGGL((rows_gemm_mfma_kernel<NT, 0, true>), dim3(grid), dim3(kGemmThreads), lds, s, in, ld_in,  \
-                         idx, n_sel, w, d_in, trans_w, bias, relu_in, out, ld_out, save_in, gate_bits, sign_out,  \
-                         in_alt, sel, dots);                                                                      \
-    else GD_RG_LAUNCH(NT, 0);                                                                                     \
+    if (gate_bits && dots.u1) GD_RG_LAUNCH(NT, 4, false);                                                         \
+    else if (gate_bits) GD_RG_LAUNCH(NT, 2, false);                                                               \
+    else if (sign_out) GD_RG_LAUNCH(NT, 1, false);                                                                \
+    else if (dots.u1 && sel) GD_RG_LAUNCH(NT, 3, true);                                                           \
+    else if (dots.u1) GD_RG_LAUNCH(NT, 3, false);                                                                 \
+    else if (sel) GD_RG_LAUNCH(NT, 0, true);                                                                      \
+    else GD_RG_LAUNCH(NT, 0, false);                                                                              \
   } while (0)
     switch (d_out / 32) {
       case 1: GD_RG_CASE(1); break;
@@ -619,6 +776,7 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
       case 3: GD_RG_CASE(3); break;
       default: GD_RG_CASE(4); break;
     }
+#undef GD_RG_KERNEL
 #undef GD_RG_LAUNCH
 #undef GD_RG_CASE
     return launched("rows_gemm_mfma");

@@ -10,6 +10,16 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 
 
+def matrix_split():
+    """How the row GEMMs form their fp32 products: 0 = fp32 matrix instruction, 6 / 9 = split arithmetic on the bf16
+    matrix instruction (include/gnndelete_hip.h: gd_set_matrix_split)."""
+    return _lib.lib().gd_matrix_split()
+
+
+def set_matrix_split(n_products):
+    _lib.check(_lib.lib().gd_set_matrix_split(int(n_products)), 'gd_set_matrix_split')
+
+
 def _f32_rows(t):
     """fp32, unit column stride, 16-byte aligned rows (what the kernels require)."""
     if t.device.type != 'cuda':

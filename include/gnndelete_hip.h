@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 2   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...) */
+#define GD_ABI_VERSION 3   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split */
 
 enum {
   GD_OK = 0,
@@ -41,6 +41,18 @@ enum {
 
 int gd_abi_version(void);
 const char* gd_last_error_string(void);
+
+/* How the dense fp32 products of the row GEMMs are formed (process-wide switch; initial value from the environment
+ * variable GD_MATRIX_SPLIT, else GD_MATRIX_SPLIT_DEFAULT):
+ *   0  v_mfma_f32_32x32x2_f32 (the fp32 matrix instruction);
+ *   6  (opt-in) every fp32 operand is the exact sum of three bf16 pieces; the product is formed from the six largest of
+ *      the nine partial products on v_mfma_f32_32x32x16_bf16, each exact in fp32, accumulated in fp32 (the three left out
+ *      are <= 2^-26 of the product): same fp32 inputs and outputs, error against an fp64 product not larger than the fp32
+ *      instruction's (rows_gemm.hip; tests/test_kernels_gpu.py).  Used where d_in is 64 / 128 and d_out 96 / 128.
+ * Replaces nothing upstream (torch.mm on fp32 tensors, framework/models/deletion.py:27). */
+#define GD_MATRIX_SPLIT_DEFAULT 0
+int gd_matrix_split(void);
+int gd_set_matrix_split(int n_products);
 
 /* ---------------------------------------------------------------- message passing ----- */
 

@@ -45,12 +45,22 @@ def test_engine_reproduces_reference_trajectory(gnn, loss_type, use_graph):
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < 1e-4
 
 
+@pytest.fixture(params=[0, 6], ids=['f32-instruction', 'bf16x6-split'])
+def matrix_split(request):
+    from gnndelete_amd import ops
+    before = ops.matrix_split()
+    ops.set_matrix_split(request.param)
+    yield request.param
+    ops.set_matrix_split(before)
+
+
 @pytest.mark.parametrize('use_graph', [False, True])
 @pytest.mark.parametrize('gnn,loss_type', [('gcn', 'both_all'), ('gat', 'both_layerwise')])
-def test_engine_reproduces_wide_reference_trajectory(gnn, loss_type, use_graph):
+def test_engine_reproduces_wide_reference_trajectory(gnn, loss_type, use_graph, matrix_split):
     """The reference's real loop at widths 32 -> 128 -> 64: these fixtures drive the MFMA row kernels, the loss
     folded into the W_D1 weight-gradient fetch and the fused Del-2 / loss / input-gradient kernel (asserted), not the
-    generic-width fallbacks the 10 -> 32 -> 16 fixtures take."""
+    generic-width fallbacks the 10 -> 32 -> 16 fixtures take.  Also with the Del-1 products formed from bf16 partial
+    products (gd_set_matrix_split(6)): same trajectory, same tolerances."""
     eng, m, rest = make_engine(gnn, loss_type, use_graph, load_golden(f'traj_wide_{gnn}_{loss_type}.npz'))
     assert eng._fuse_loss1 and eng._fuse_l2 and eng._split1 and eng._split2
     for _ in range(int(rest['epochs'])):

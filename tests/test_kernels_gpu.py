@@ -80,10 +80,45 @@ def test_gcn_norm_matches_oracle():
     assert rel_l2(got_t, dense) < 1e-6
 
 
+@pytest.fixture(params=[0, 6], ids=['f32-instruction', 'bf16x6-split'])
+def matrix_split(request):
+    """Both ways the row GEMMs form their fp32 products (gd_set_matrix_split): same tests, same tolerances."""
+    from gnndelete_amd import ops
+    before = ops.matrix_split()
+    ops.set_matrix_split(request.param)
+    yield request.param
+    ops.set_matrix_split(before)
+
+
+def test_split_products_are_as_accurate_as_the_fp32_instruction():
+    """gd_set_matrix_split(6) on the Del operator's shape, inputs spread over six orders of magnitude: the error against
+    an fp64 product is not larger than the fp32 matrix instruction's, and the two fp32 results agree to a few ulps of
+    the row scale."""
+    from gnndelete_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(4096, 128, generator=g) * torch.exp(3.0 * torch.randn(4096, 128, generator=g))).cuda()
+    w = (torch.randn(128, 128, generator=g) * 0.1 * torch.exp(2.0 * torch.randn(128, 128, generator=g))).cuda()
+    want = x.double() @ w.double()
+    before = ops.matrix_split()
+    try:
+        got = {}
+        for mode in (0, 6):
+            ops.set_matrix_split(mode)
+            assert ops.matrix_split() == mode
+            got[mode] = ops.rows_gemm(x, None, w)
+    finally:
+        ops.set_matrix_split(before)
+    err = {m: float(((got[m].double() - want).norm() / want.norm())) for m in got}
+    assert err[6] <= 1.2 * err[0] + 1e-9 and err[0] < 5e-7, err
+    assert float((got[6] - got[0]).abs().max() / want.abs().max()) < 2e-6
+    with pytest.raises(Exception):
+        ops.set_matrix_split(3)
+
+
 @pytest.mark.parametrize('n,d_in,d_out,frac', [(200, 128, 128, 0.4), (200, 64, 64, 0.5), (77, 128, 64, 1.0),
                                                (50, 32, 32, 0.3), (40, 12, 12, 0.5), (64, 128, 4, 0.5),
                                                (90, 64, 96, 0.7), (33, 128, 128, 0.0), (5000, 128, 128, 0.9)])
-def test_rows_gemm_forward_transpose_and_inplace(n, d_in, d_out, frac):
+def test_rows_gemm_forward_transpose_and_inplace(n, d_in, d_out, frac, matrix_split):
     from gnndelete_amd import ops
     g = torch.Generator().manual_seed(n + d_in)
     x = torch.randn(n, d_in, generator=g)
@@ -687,7 +722,7 @@ def test_agg_gemm_matches_dense_closed_form(n, m, d_in, d_out, hub):
 
 @pytest.mark.parametrize('n,d_in,d_out,select', [(500, 128, 64, False), (500, 128, 64, True), (77, 64, 32, True),
                                                  (300, 128, 128, False), (1, 32, 64, False)])
-def test_rows_gemm_dots_matches_fp64(n, d_in, d_out, select):
+def test_rows_gemm_dots_matches_fp64(n, d_in, d_out, select, matrix_split):
     """gd_rows_gemm_dots_f32: h = act(x or x_alt) W^T and the two row dots <h, u1>, <h, u2> from its epilogue
     (GATConv lin_src + attention logits, framework/models/gat.py:11-12)."""
     from gnndelete_amd import ops
@@ -899,7 +934,7 @@ def test_random_walk_kernel_and_device_sampler():
 
 
 @pytest.mark.parametrize('n,d_in,d_out', [(500, 64, 128), (77, 128, 64), (1000, 32, 32)])
-def test_rows_gemm_gated_rank1_matches_fp64(n, d_in, d_out):
+def test_rows_gemm_gated_rank1_matches_fp64(n, d_in, d_out, matrix_split):
     """gd_rows_gemm_gated_rank1_f32: out[r] = gate(in[r] @ W + a[r] p + b[r] q) on a row subset - the GAT input gradient's
     two rank-1 terms moved to the output side of the product that consumes it; rows outside the subset untouched."""
     from gnndelete_amd import ops
