@@ -151,6 +151,188 @@ __global__ __launch_bounds__(kKtThreads) void gemm_ktile_mfma_kernel(
   }
 }
 
+// The same product with split arithmetic (gd_set_matrix_split(6), rows_gemm.hip: every fp32 product from six exact bf16
+// partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulation).  A 32-wide k chunk then lasts 0.7 us on the matrix
+// cores instead of 2 us, too short to hide a memory round trip behind, so the pipeline is deeper: the unit of the stream-K
+// partition is a MACRO chunk of 4 chunks (128 k) whose operand rows a lane keeps in registers (16 float4), the next
+// unit's in flight in a second set; the weight streams through a ring of three 24 KB chunk images (three bf16 pieces in
+// the instruction's operand order), cut from registers that were loaded one chunk earlier - one barrier per chunk.
+using bf16x8k = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2k = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2k = __attribute__((ext_vector_type(2))) float;
+using u32x4k = __attribute__((ext_vector_type(4))) uint32_t;
+
+__device__ inline void split8k(const float (&v)[8], bf16x8k (&s)[3]) {
+  u32x4k p[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x2k r = {v[2 * i], v[2 * i + 1]};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2k));
+      p[q][i] = w;
+      if (q < 2) {
+        f32x2k h;
+        h[0] = __builtin_bit_cast(float, w << 16);
+        h[1] = __builtin_bit_cast(float, w & 0xffff0000u);
+        r = r - h;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) s[q] = __builtin_bit_cast(bf16x8k, p[q]);
+}
+
+template <int NT>
+__global__ __launch_bounds__(kKtThreads, 2) void gemm_ktile_split_kernel(
+    const float* __restrict__ in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_rows,
+    const float* __restrict__ w, int32_t n_chunks, int32_t n_mac, int32_t per, int32_t n_units, const float* __restrict__ bias,
+    float* __restrict__ out, int64_t ld_out, float* __restrict__ pieces, int32_t s_max) {
+  constexpr int N = 32 * NT;
+  constexpr int kOps = 2 * NT * 2 * 32;                  // 16-byte operands of one piece of one chunk: [m][t][khalf][r]
+  extern __shared__ __attribute__((aligned(16))) unsigned char kt_lds[];
+  bf16x8k* const wimg = reinterpret_cast<bf16x8k*>(kt_lds);     // [ring slot 3][piece 3][kOps]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r_lo = lane & 31, khalf = lane >> 5;
+  const int u0 = blockIdx.x * per, u1 = min(n_units, u0 + per);
+  if (u0 >= u1) return;
+  const int n_tiles = (n_rows + 31) >> 5;
+
+  // ---- weight stream: position = (unit, chunk j of its macro chunk).  Every load below is UNCONDITIONAL (clamped
+  // addresses): a load under a branch makes the number of loads in flight path-dependent, and the compiler then waits
+  // for ALL of them (s_waitcnt vmcnt(0)) in front of every chunk - the operand prefetch and the weight chunk requested
+  // a moment ago included (measured: 1.8 us of stall per 0.7 us chunk)
+  int wu = u0, wj = 0;                                   // position of the next chunk to LOAD
+  bool w_pending = false;                                // wreg holds a chunk that is not in LDS yet
+  float wreg[8];
+  const bool w_thread = tid < 4 * N;
+  const int w_kg = min(tid / N, 3), w_n = tid % N;       // this thread's (8-k group, feature) item of every chunk
+  auto load_w = [&]() {                                  // wreg <- the chunk at (wu, wj); advance
+    const bool valid = wu < u1;
+    const int uu = valid ? wu : u1 - 1, jj = valid ? wj : 3;
+    const int cg = (uu % n_mac) * 4 + jj;
+    const float* wp = w + (int64_t)(cg * 32 + 8 * w_kg) * N + w_n;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) wreg[c] = wp[c * N];
+    w_pending = valid;
+    if (valid && ++wj == 4) { wj = 0; ++wu; }
+  };
+  auto stash_w = [&](int slot) {
+    if (w_pending && w_thread) {
+      bf16x8k pc[3];
+      split8k(wreg, pc);
+      const int off = (((w_kg & 1) * NT + (w_n >> 5)) * 2 + ((w_kg >> 1) & 1)) * 32 + (w_n & 31);
+#pragma unroll
+      for (int qq = 0; qq < 3; ++qq) wimg[(slot * 3 + qq) * kOps + off] = pc[qq];
+    }
+  };
+
+  // ---- operand rows: the unit's 4 x 64 bytes of this lane's row (its khalf of every chunk)
+  auto fetch = [&](int u_, float4 (&a)[16]) {
+    const int u = min(u_, u1 - 1);
+    const int g = u / n_mac, cm = u - g * n_mac;
+    const int s_a = min((g * 8 + wave) * 32 + r_lo, n_rows - 1);
+    const int64_t row = idx ? idx[s_a] : s_a;
+    const float4* src = reinterpret_cast<const float4*>(in + row * ld_in) + khalf * 4 + (cm * 4) * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[j * 4 + i] = src[j * 8 + i];
+  };
+
+  f32x16k acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  int q = 0;                                             // chunks done by this block: chunk q sits in ring slot q % 3
+  auto work = [&](int u, float4 (&a)[16]) {
+    const int g = u / n_mac, cm = u - g * n_mac;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      {
+        const bf16x8k* wk = wimg + (q % 3) * 3 * kOps + khalf * 32 + r_lo;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const float4 lo = a[j * 4 + 2 * m], hi = a[j * 4 + 2 * m + 1];
+          const float v8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          bf16x8k sp[3];
+          split8k(v8, sp);
+          // two output tiles at a time: consecutive matrix instructions accumulate into DIFFERENT registers, so the
+          // wave issues them back to back instead of waiting out each one's latency on a six-deep dependent chain
+#pragma unroll
+          for (int t0 = 0; t0 < NT; t0 += 2) {
+            constexpr int kPairs[6][2] = {{2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};    // (weight piece, sample piece), small terms first
+            bf16x8k wq[2][3];
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+              if (t0 + d < NT) {
+                const bf16x8k* wo = wk + (m * NT + t0 + d) * 64;
+                wq[d][0] = wo[0]; wq[d][1] = wo[kOps]; wq[d][2] = wo[2 * kOps];
+              }
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+              for (int d = 0; d < 2; ++d)
+                if (t0 + d < NT)
+                  acc[t0 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[d][kPairs[pr][0]], sp[kPairs[pr][1]], acc[t0 + d], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        stash_w((q + 2) % 3);                            // chunk q + 2 (loaded one chunk ago) -> the slot chunk q - 1 left
+        load_w();                                        // chunk q + 3 -> registers
+        __syncthreads();
+        ++q;
+      }
+    }
+    if (cm + 1 == n_mac || u + 1 == u1) {
+      // D[i][j]: j = lane & 31 = sample, feature 32 t + 8 q + 4 khalf + c in acc[t][4 q + c] (as rows_gemm.hip)
+      if (pieces) {                                      // piece number = blocks since the one holding the group's first unit
+        const int piece = blockIdx.x - (g * n_mac) / per;
+        float4* dst = reinterpret_cast<float4*>(pieces + ((int64_t)g * s_max + piece) * (256 * N)) + wave * (NT * 4 * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq)
+            dst[(t * 4 + qq) * 64] = make_float4(acc[t][4 * qq], acc[t][4 * qq + 1], acc[t][4 * qq + 2], acc[t][4 * qq + 3]);
+      } else {
+        const int tile = g * 8 + wave, s_a = tile * 32 + r_lo;
+        if (tile < n_tiles && s_a < n_rows) {
+          const int64_t orow = idx ? idx[s_a] : s_a;
+          float* dst = out + orow * ld_out + 4 * khalf;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+              float4 v = make_float4(acc[t][4 * qq], acc[t][4 * qq + 1], acc[t][4 * qq + 2], acc[t][4 * qq + 3]);
+              if (bias) v = f4_add(v, *reinterpret_cast<const float4*>(bias + 32 * t + 8 * qq + 4 * khalf));
+              *reinterpret_cast<float4*>(dst + 32 * t + 8 * qq) = v;
+            }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    }
+  };
+
+  float4 ra[16], rb[16];
+  fetch(u0, ra);
+  load_w(); stash_w(0);
+  load_w(); stash_w(1);
+  load_w();
+  __syncthreads();
+  for (int u = u0; u < u1; u += 2) {
+    fetch(u + 1, rb);
+    work(u, ra);
+    if (u + 1 >= u1) break;
+    fetch(u + 2, ra);
+    work(u + 1, rb);
+  }
+}
+
 // out[row, :] = bias + the pieces of the row's group in k order.  One thread per float4 of the piece layout
 // (coalesced reads of every piece; the 16-byte results go to their rows).
 __global__ __launch_bounds__(256) void gemm_ktile_reduce_kernel(const float* __restrict__ pieces, int32_t s_max, int32_t n_chunks,
@@ -203,12 +385,33 @@ static KtileGeometry ktile_geometry(int32_t n_rows, int32_t k) {
   return q;
 }
 
+// split form: units are macro chunks (128 k), one block per CU (72 KB of LDS, 200+ registers)
+static KtileGeometry ktile_geometry_split(int32_t n_rows, int32_t k) {
+  KtileGeometry q;
+  q.groups = (n_rows + 255) / 256;
+  q.chunks = k / 128;                                    // macro chunks (k % 128 == 0)
+  const int64_t units = (int64_t)q.groups * q.chunks;
+  int per = (int)((units + 255) / 256);
+  if (per < 1) per = 1;
+  if (per >= q.chunks) {
+    per = (per + q.chunks - 1) / q.chunks * q.chunks;
+    q.s_max = 0;
+  } else {
+    q.s_max = (q.chunks + per - 2) / per + 1;
+  }
+  q.per = per;
+  q.blocks = (int)((units + per - 1) / per);
+  return q;
+}
+
 }  // namespace gd
 
 extern "C" int64_t gd_gemm_f32_workspace(int32_t n_rows, int32_t k, int32_t n) {
   if (n_rows <= 0 || k <= 0 || k % 32) return 0;
+  // (the larger of the two forms: the arithmetic switch may change between this call and the product)
   const gd::KtileGeometry q = gd::ktile_geometry(n_rows, k);
-  return (int64_t)q.groups * q.s_max * 256 * n;
+  const int s_split = k % 128 == 0 ? gd::ktile_geometry_split(n_rows, k).s_max : 0;
+  return (int64_t)q.groups * (q.s_max > s_split ? q.s_max : s_split) * 256 * n;
 }
 
 extern "C" int gd_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_rows, const float* w, int32_t k,
@@ -222,10 +425,35 @@ extern "C" int gd_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, i
              "gd_gemm_f32: unaligned or aliasing pointer");
   if (n_rows == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
-  const KtileGeometry q = ktile_geometry(n_rows, k);
+  const bool split = matrix_split() == 6 && k % 128 == 0;     // (other widths: the fp32 instruction; ops.gemm_wide pads)
+  const KtileGeometry q = split ? ktile_geometry_split(n_rows, k) : ktile_geometry(n_rows, k);
   GD_REQUIRE(q.s_max == 0 || (workspace && aligned16(workspace)), GD_E_NULL, "gd_gemm_f32: workspace of gd_gemm_f32_workspace() floats");
   const dim3 grid(q.blocks), block(kKtThreads);
   float* pieces = q.s_max ? workspace : nullptr;
+  if (split) {
+    const size_t lds = (size_t)3 * 3 * (2 * (n / 32) * 2 * 32) * 16;
+#define GD_KS_CASE(NT)                                                                                                        \
+  do {                                                                                                                        \
+    auto kern = gemm_ktile_split_kernel<NT>;                                                                                  \
+    static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+    GD_REQUIRE(once == hipSuccess, -(int)once, "gd_gemm_f32: cannot raise the LDS limit");                                    \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, in, ld_in, idx, n_rows, w, k / 32, q.chunks, q.per, q.groups * q.chunks,     \
+                       bias, out, ld_out, pieces, q.s_max);                                                                   \
+  } while (0)
+    switch (n / 32) {
+      case 1: GD_KS_CASE(1); break;
+      case 2: GD_KS_CASE(2); break;
+      case 3: GD_KS_CASE(3); break;
+      default: GD_KS_CASE(4); break;
+    }
+#undef GD_KS_CASE
+    int rc = launched("gemm_ktile_split");
+    if (rc || !q.s_max) return rc;
+    const int64_t total = (int64_t)q.groups * 8 * (n / 32) * 4 * 64;
+    hipLaunchKernelGGL(gemm_ktile_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, workspace, q.s_max, q.chunks,
+                       q.per, n / 32, idx, n_rows, bias, out, ld_out);
+    return launched("gemm_ktile_reduce");
+  }
 #define GD_KT_CASE(NT) \
   hipLaunchKernelGGL((gemm_ktile_mfma_kernel<NT>), grid, block, 0, s, in, ld_in, idx, n_rows, w, q.chunks, q.per, q.groups * q.chunks, \
                      bias, out, ld_out, pieces, q.s_max)

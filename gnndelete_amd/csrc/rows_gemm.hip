@@ -233,23 +233,26 @@ __global__ __launch_bounds__(kGemmThreads, NP ? 2 : 4) void rows_gemm_mfma_kerne
           }
           bf16x8 sp[3];
           split8(lo, hi, sp);
+          // transposed product (weight = "A" operand: D rows = output features; sample = "B" operand: D cols = samples,
+          // as in the fp32 form below), small terms first.  Two output tiles at a time: consecutive matrix instructions
+          // accumulate into different registers, so the wave issues them back to back instead of waiting out each
+          // one's latency on a six-deep dependent chain
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const bf16x8* wk = wimg + (((kc * 2 + m) * NT + t) * 2 + khalf) * 32 + r_lo;
-            const bf16x8 w1 = wk[0], w2 = wk[pstride], w3 = wk[2 * pstride];
-            // transposed product (weight = "A" operand: D rows = output features; sample = "B" operand: D cols =
-            // samples, as in the fp32 form below); small terms first
-            if (NP == 9) {
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, sp[2], acc[t], 0, 0, 0);
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, sp[1], acc[t], 0, 0, 0);
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, sp[2], acc[t], 0, 0, 0);
-            }
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, sp[0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, sp[1], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, sp[2], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, sp[0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, sp[1], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, sp[0], acc[t], 0, 0, 0);
+          for (int t0 = 0; t0 < NT; t0 += 2) {
+            constexpr int kPairs[9][2] = {{2, 2}, {2, 1}, {1, 2}, {2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};   // (weight piece, sample piece)
+            bf16x8 wq[2][3];
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+              if (t0 + d < NT) {
+                const bf16x8* wk = wimg + (((kc * 2 + m) * NT + t0 + d) * 2 + khalf) * 32 + r_lo;
+                wq[d][0] = wk[0]; wq[d][1] = wk[pstride]; wq[d][2] = wk[2 * pstride];
+              }
+#pragma unroll
+            for (int pr = (NP == 9 ? 0 : 3); pr < 9; ++pr)
+#pragma unroll
+              for (int d = 0; d < 2; ++d)
+                if (t0 + d < NT)
+                  acc[t0 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[d][kPairs[pr][0]], sp[kPairs[pr][1]], acc[t0 + d], 0, 0, 0);
           }
           __builtin_amdgcn_sched_barrier(0);                 // keep the LDS reads of later k groups where they are
         }

@@ -234,9 +234,9 @@ def _cached(tag, t, build):
     return hit[0]
 
 
-def _pad_cols32(t):
+def _pad_cols32(t, mult=32):
     k = t.shape[1]
-    kp = (k + 31) // 32 * 32
+    kp = (k + mult - 1) // mult * mult
     if kp == k and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and t.stride(1) == 1:
         return t
     out = torch.zeros(t.shape[0], kp, dtype=torch.float32, device=t.device)
@@ -250,11 +250,13 @@ def mfma_out_width(n):
 
 def gemm_wide(x, w_kn, bias=None, idx=None, out=None, const_x=False):
     """out[rows] = x[rows] @ w_kn (+ bias) with a reduction dimension of any width (gd_gemm_f32): x [M, K], w_kn [K, N]
-    (the transpose of a torch Linear weight), N in {32, 64, 96, 128}.  K is zero-padded to a multiple of 32 (x: a
+    (the transpose of a torch Linear weight), N in {32, 64, 96, 128}.  K is zero-padded to a multiple of 32 (128 with split
+    arithmetic on; x: a
     padded copy, cached when const_x says the matrix does not change between calls - the node features)."""
     assert mfma_out_width(w_kn.shape[1]) and w_kn.shape[0] == x.shape[1]
     x = _f32_rows(x)
-    xp = _cached('padx', x, _pad_cols32) if const_x else _pad_cols32(x)
+    mult = 128 if matrix_split() == 6 else 32            # the split form walks K in macro chunks of 128
+    xp = _cached(f'padx{mult}', x, lambda t: _pad_cols32(t, mult)) if const_x else _pad_cols32(x, mult)
     k = xp.shape[1]
     if w_kn.shape[0] != k or not w_kn.is_contiguous():
         wp = torch.zeros(k, w_kn.shape[1], dtype=torch.float32, device=x.device)

@@ -833,7 +833,7 @@ def test_loss_zoo_on_the_device_matches_reference_golden(name):
 
 @pytest.mark.parametrize('m,k,n', [(300, 1639, 128), (1000, 96, 64), (77, 8710, 128), (2500, 333, 96), (64, 32, 32),
                                    (5000, 1664, 64), (3000, 1433, 128), (17716, 1639, 128), (20000, 224, 64)])
-def test_gemm_wide_matches_fp64(m, k, n):
+def test_gemm_wide_matches_fp64(m, k, n, matrix_split):
     """gd_gemm_f32 (K-tiled MFMA GEMM, W streamed through LDS in 32-row chunks, equal unit ranges per block whose
     pieces are added in k order): any reduction width (zero-padded to 32), every supported output width, with bias, on
     all rows and on a gathered row subset; ranges inside one row group, across groups, and whole groups per block."""

@@ -33,5 +33,11 @@ for name, m, k, n in [('synth-dblp', 17716, 1639, 128), ('synth-cora', 19793, 87
         t_blas = timeit(lambda: torch.mm(x, w, out=out))
         t_lin = timeit(lambda: torch.nn.functional.linear(x, wt))
         t_gd = timeit(lambda: ops.gemm_wide(x, w, out=out, const_x=True))
+        ops.set_matrix_split(6)                         # opt-in: fp32 products from six exact bf16 partial products
+        ys = ops.gemm_wide(x, w, out=torch.empty_like(out), const_x=True)
+        err_s = ((ys.double() - ref).norm() / ref.norm()).item()
+        t_sp = timeit(lambda: ops.gemm_wide(x, w, out=out, const_x=True))
+        ops.set_matrix_split(0)
+        print(f'{name:16s}   split arithmetic: gd_gemm_f32 {t_sp*1e6:7.1f} us {flop/t_sp/1e12:5.1f} TF fp32-equivalent | rel err {err_s:.1e}', flush=True)
         print(f'{name:16s} M={m} K={k} N={n}: torch.mm {t_blas*1e6:7.1f} us {flop/t_blas/1e12:5.1f} TF | F.linear {t_lin*1e6:7.1f} us '
               f'{flop/t_lin/1e12:5.1f} TF | gd_gemm_f32 {t_gd*1e6:7.1f} us {flop/t_gd/1e12:5.1f} TF | rel err gd {err:.1e} blas {err_b:.1e}', flush=True)
