@@ -155,8 +155,9 @@ __global__ __launch_bounds__(kKtThreads) void gemm_ktile_mfma_kernel(
 // partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulation).  A 32-wide k chunk then lasts 0.7 us on the matrix
 // cores instead of 2 us, too short to hide a memory round trip behind, so the pipeline is deeper: the unit of the stream-K
 // partition is a MACRO chunk of 4 chunks (128 k) whose operand rows a lane keeps in registers (16 float4), the next
-// unit's in flight in a second set; the weight streams through a ring of three 24 KB chunk images (three bf16 pieces in
-// the instruction's operand order), cut from registers that were loaded one chunk earlier - one barrier per chunk.
+// unit's in flight in a second set; the weight streams through two 48 KB slots of two chunk images each (three bf16
+// pieces in the instruction's operand order), cut from registers that were loaded one chunk pair earlier - one barrier
+// per 64 k.
 using bf16x8k = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2k = __attribute__((ext_vector_type(2))) __bf16;
 using f32x2k = __attribute__((ext_vector_type(2))) float;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(kKtThreads, 2) void gemm_ktile_split_kernel(
   constexpr int N = 32 * NT;
   constexpr int kOps = 2 * NT * 2 * 32;                  // 16-byte operands of one piece of one chunk: [m][t][khalf][r]
   extern __shared__ __attribute__((aligned(16))) unsigned char kt_lds[];
-  bf16x8k* const wimg = reinterpret_cast<bf16x8k*>(kt_lds);     // [ring slot 3][piece 3][kOps]
+  bf16x8k* const wimg = reinterpret_cast<bf16x8k*>(kt_lds);     // [slot 2][chunk of the pair 2][piece 3][kOps]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r_lo = lane & 31, khalf = lane >> 5;
   const int u0 = blockIdx.x * per, u1 = min(n_units, u0 + per);
@@ -202,28 +203,33 @@ __global__ __launch_bounds__(kKtThreads, 2) void gemm_ktile_split_kernel(
   // addresses): a load under a branch makes the number of loads in flight path-dependent, and the compiler then waits
   // for ALL of them (s_waitcnt vmcnt(0)) in front of every chunk - the operand prefetch and the weight chunk requested
   // a moment ago included (measured: 1.8 us of stall per 0.7 us chunk)
-  int wu = u0, wj = 0;                                   // position of the next chunk to LOAD
-  bool w_pending = false;                                // wreg holds a chunk that is not in LDS yet
-  float wreg[8];
+  int wu = u0, wj = 0;                                   // position of the next chunk PAIR to load (wj = 0 or 2)
+  bool w_pending = false;                                // wreg holds a pair that is not in LDS yet
+  float wreg[2][8];
   const bool w_thread = tid < 4 * N;
   const int w_kg = min(tid / N, 3), w_n = tid % N;       // this thread's (8-k group, feature) item of every chunk
-  auto load_w = [&]() {                                  // wreg <- the chunk at (wu, wj); advance
+  auto load_w = [&]() {                                  // wreg <- the two chunks at (wu, wj), (wu, wj + 1); advance
     const bool valid = wu < u1;
-    const int uu = valid ? wu : u1 - 1, jj = valid ? wj : 3;
+    const int uu = valid ? wu : u1 - 1, jj = valid ? wj : 2;
     const int cg = (uu % n_mac) * 4 + jj;
     const float* wp = w + (int64_t)(cg * 32 + 8 * w_kg) * N + w_n;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) wreg[c] = wp[c * N];
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) wreg[h][c] = wp[(h * 32 + c) * N];
     w_pending = valid;
-    if (valid && ++wj == 4) { wj = 0; ++wu; }
+    if (valid) { wj += 2; if (wj == 4) { wj = 0; ++wu; } }
   };
   auto stash_w = [&](int slot) {
     if (w_pending && w_thread) {
-      bf16x8k pc[3];
-      split8k(wreg, pc);
       const int off = (((w_kg & 1) * NT + (w_n >> 5)) * 2 + ((w_kg >> 1) & 1)) * 32 + (w_n & 31);
 #pragma unroll
-      for (int qq = 0; qq < 3; ++qq) wimg[(slot * 3 + qq) * kOps + off] = pc[qq];
+      for (int h = 0; h < 2; ++h) {
+        bf16x8k pc[3];
+        split8k(wreg[h], pc);
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) wimg[((slot * 2 + h) * 3 + qq) * kOps + off] = pc[qq];
+      }
     }
   };
 
@@ -246,16 +252,18 @@ __global__ __launch_bounds__(kKtThreads, 2) void gemm_ktile_split_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  int q = 0;                                             // chunks done by this block: chunk q sits in ring slot q % 3
+  int q = 0;                                             // chunks done by this block: chunk q is chunk q & 1 of slot (q >> 1) & 1
   auto work = [&](int u, float4 (&a)[16]) {
     const int g = u / n_mac, cm = u - g * n_mac;
-#pragma unroll
+    // ONE copy of the chunk body (the lane's rows rotate through a[0..3] by register moves): unrolled four times and
+    // duplicated for the two register sets it was 35 KB of code, more than the instruction cache feeds 16 waves from
+#pragma unroll 1
     for (int j = 0; j < 4; ++j) {
       {
-        const bf16x8k* wk = wimg + (q % 3) * 3 * kOps + khalf * 32 + r_lo;
+        const bf16x8k* wk = wimg + (((q >> 1) & 1) * 2 + (j & 1)) * 3 * kOps + khalf * 32 + r_lo;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const float4 lo = a[j * 4 + 2 * m], hi = a[j * 4 + 2 * m + 1];
+          const float4 lo = a[2 * m], hi = a[2 * m + 1];
           const float v8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
           bf16x8k sp[3];
           split8k(v8, sp);
@@ -280,10 +288,14 @@ __global__ __launch_bounds__(kKtThreads, 2) void gemm_ktile_split_kernel(
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        stash_w((q + 2) % 3);                            // chunk q + 2 (loaded one chunk ago) -> the slot chunk q - 1 left
-        load_w();                                        // chunk q + 3 -> registers
-        __syncthreads();
+        if (j & 1) {                                     // one barrier per PAIR of chunks (64 k): the waves of a block leave
+          stash_w(((q >> 1) + 1) & 1);                   // it in step, so whatever is not matrix work between two barriers
+          load_w();                                      // idles the matrix cores of the whole CU - half as often this way
+          __syncthreads();
+        }
         ++q;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) a[i] = a[i + 4];
       }
     }
     if (cm + 1 == n_mac || u + 1 == u1) {
@@ -321,15 +333,14 @@ __global__ __launch_bounds__(kKtThreads, 2) void gemm_ktile_split_kernel(
   float4 ra[16], rb[16];
   fetch(u0, ra);
   load_w(); stash_w(0);
-  load_w(); stash_w(1);
   load_w();
   __syncthreads();
-  for (int u = u0; u < u1; u += 2) {
+#pragma unroll 1
+  for (int u = u0; u < u1; ++u) {
     fetch(u + 1, rb);
     work(u, ra);
-    if (u + 1 >= u1) break;
-    fetch(u + 2, ra);
-    work(u + 1, rb);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ra[i] = rb[i];
   }
 }
 
@@ -431,11 +442,11 @@ extern "C" int gd_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, i
   const dim3 grid(q.blocks), block(kKtThreads);
   float* pieces = q.s_max ? workspace : nullptr;
   if (split) {
-    const size_t lds = (size_t)3 * 3 * (2 * (n / 32) * 2 * 32) * 16;
+    const size_t lds = (size_t)2 * 2 * 3 * (2 * (n / 32) * 2 * 32) * 16;        // two slots of two chunks of three pieces
 #define GD_KS_CASE(NT)                                                                                                        \
   do {                                                                                                                        \
     auto kern = gemm_ktile_split_kernel<NT>;                                                                                  \
-    static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+    static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
     GD_REQUIRE(once == hipSuccess, -(int)once, "gd_gemm_f32: cannot raise the LDS limit");                                    \
     hipLaunchKernelGGL(kern, grid, block, lds, s, in, ld_in, idx, n_rows, w, k / 32, q.chunks, q.per, q.groups * q.chunks,     \
                        bias, out, ld_out, pieces, q.s_max);                                                                   \
