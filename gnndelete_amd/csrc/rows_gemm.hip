@@ -68,9 +68,10 @@ struct RowDots { const float* u1; const float* u2; float* o1; float* o2; };
 //    out[r, n] += o1[r] u1[n] + o2[r] u2[n] (RowDots reused: o1 / o2 per-row scalars READ by row id, u1 / u2 per column)
 // SEL: rows may come from a second buffer (in_alt where sel[r] != 0); only instantiated for MODE 0 and 3
 // NP: 0 = products on v_mfma_f32_32x32x2_f32; 6 / 9 = split arithmetic on the bf16 matrix instruction (above)
-// KC (split form only): d_in / 32, a compile-time constant there - the wave keeps whole half rows in registers
+// KC (split form only): d_in / 32 as a compile-time constant - the wave keeps whole half rows in registers (wide outputs);
+// KC = 0 with NP != 0: split products inside the chunk-wise loop of the fp32 form (narrow outputs: 4 waves per SIMD)
 template <int NT, int MODE, bool SEL = false, int NP = 0, int KC = 0>
-__global__ __launch_bounds__(kGemmThreads, NP ? 2 : 4) void rows_gemm_mfma_kernel(
+__global__ __launch_bounds__(kGemmThreads, (NP && KC) ? 2 : 4) void rows_gemm_mfma_kernel(
     const float* in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel,
     const float* __restrict__ w, int32_t d_in, int32_t trans_w, const float* __restrict__ bias, int32_t relu_in,
     float* out, int64_t ld_out, float* __restrict__ save_in, const uint32_t* __restrict__ gate_bits,
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kGemmThreads, NP ? 2 : 4) void rows_gemm_mfma_kerne
       }
   };
 
-  if constexpr (NP != 0) {
+  if constexpr (NP != 0 && KC != 0) {
     // ---- split form: whole half rows in registers (4 KC float4 per lane), the NEXT tile's in flight while this one feeds
     // the matrix cores - a 32-wide k chunk lasts < 1 us here, chunk-wise prefetch no longer covers the HBM latency
     int tile = blockIdx.x * kWaves + wave;
@@ -316,8 +317,32 @@ __global__ __launch_bounds__(kGemmThreads, NP ? 2 : 4) void rows_gemm_mfma_kerne
 #pragma unroll
         for (int i = 0; i < 4; ++i) sav[kc * 8 + i] = a4[i];
       }
+      if (NP) {                                             // split products, chunk by chunk (KC == 0)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i)
+          if (relu_in) {
+            a4[i].x = fmaxf(a4[i].x, 0.f); a4[i].y = fmaxf(a4[i].y, 0.f);
+            a4[i].z = fmaxf(a4[i].z, 0.f); a4[i].w = fmaxf(a4[i].w, 0.f);
+          }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          bf16x8 sp[3];
+          split8(a4[2 * m], a4[2 * m + 1], sp);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const bf16x8* wk = wimg + (((kc * 2 + m) * NT + t) * 2 + khalf) * 32 + r_lo;
+            const bf16x8 w1 = wk[0], w2 = wk[pstride], w3 = wk[2 * pstride];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, sp[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, sp[1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, sp[2], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, sp[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, sp[1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, sp[0], acc[t], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; !NP && i < 4; ++i) {
         if (relu_in) {
           a4[i].x = fmaxf(a4[i].x, 0.f); a4[i].y = fmaxf(a4[i].y, 0.f);
           a4[i].z = fmaxf(a4[i].z, 0.f); a4[i].w = fmaxf(a4[i].w, 0.f);
@@ -741,9 +766,10 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
     static const int grid_cap = [] { const char* e = getenv("GD_ROWS_GEMM_GRID"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
     if (grid > grid_cap) grid = grid_cap;
     // split arithmetic where its register-resident rows are instantiated (d_in = 64 / 128); other widths keep the fp32 instruction
-    // (and only for 96 / 128 outputs: narrower products are bound by their row traffic under either instruction)
+    // (96 / 128 outputs with whole rows in registers; the 128 -> 64 product chunk-wise, which keeps 4 waves per SIMD)
     const int kc_split = (np && (d_in == 64 || d_in == 128) && d_out >= 96) ? d_in / 32 : 0;
-    if (kc_split) {
+    const bool narrow_split = np && !kc_split && d_out == 64 && d_in == 128;      // the 128 -> 64 product of the step
+    if (kc_split || narrow_split) {
       lds = (size_t)3 * d_in * d_out * 2;                    // three bf16 images, no padding of NT = 3
       if (grid > grid_cap / 2 && lds > 80 * 1024) grid = grid_cap / 2;      // one block per CU fits
     }
@@ -761,6 +787,7 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
   do {                                                                                                            \
     if (kc_split == 4) GD_RG_KERNEL(NT, MODE, SELV, 6, 4);                                                        \
     else if (kc_split == 2) GD_RG_KERNEL(NT, MODE, SELV, 6, 2);                                                   \
+    else if (narrow_split && NT == 2) GD_RG_KERNEL(2, MODE, SELV, 6, 0);                                          \
     else GD_RG_KERNEL(NT, MODE, SELV, 0, 0);                                                                      \
   } while (0)
 #define GD_RG_CASE(NT)                                                                                            \
