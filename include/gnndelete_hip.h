@@ -48,7 +48,7 @@ const char* gd_last_error_string(void);
  *   6  (opt-in) every fp32 operand is the exact sum of three bf16 pieces; the product is formed from the six largest of
  *      the nine partial products on v_mfma_f32_32x32x16_bf16, each exact in fp32, accumulated in fp32 (the three left out
  *      are <= 2^-26 of the product): same fp32 inputs and outputs, error against an fp64 product not larger than the fp32
- *      instruction's (rows_gemm.hip; tests/test_kernels_gpu.py).  Used where d_in is 64 / 128 and d_out 96 / 128.
+ *      instruction's (rows_gemm.hip; tests/test_kernels_gpu.py).  Used where d_in is 64 / 128 and d_out 96 / 128, and for 128 -> 64.
  * Operands are expected finite and below 2^127 (an infinity, or a value that rounds to one in bf16, turns into NaN where
  * the fp32 instruction would propagate the infinity).  The switch is read at launch time: a hipGraph keeps the kernels it was captured with.  gd_gemm_f32 follows it when k is
  * a multiple of 128.  Replaces nothing upstream (torch.mm on fp32 tensors, framework/models/deletion.py:27). */
