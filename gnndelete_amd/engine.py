@@ -390,7 +390,7 @@ class NodeembEngine:
             return ops.rows_gemm(x, None, weight, trans_w=True, const_w=True, relu_in=relu_in)
         if ops.mfma_out_width(out_f):
             xin = torch.relu(x) if relu_in else x
-            return ops.gemm_wide(xin, ops._const_weight(weight, True)[0], const_x=not relu_in)
+            return ops.gemm_wide(xin, ops._const_weight(weight, True)[0], const_x=not relu_in, const_w=True)
         return torch.nn.functional.linear(torch.relu(x) if relu_in else x, weight)
 
     def _linear_relu_z1(self, weight):

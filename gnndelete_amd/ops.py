@@ -248,20 +248,24 @@ def mfma_out_width(n):
     return n % 32 == 0 and 32 <= n <= 128
 
 
-def gemm_wide(x, w_kn, bias=None, idx=None, out=None, const_x=False):
+def gemm_wide(x, w_kn, bias=None, idx=None, out=None, const_x=False, const_w=False):
     """out[rows] = x[rows] @ w_kn (+ bias) with a reduction dimension of any width (gd_gemm_f32): x [M, K], w_kn [K, N]
     (the transpose of a torch Linear weight), N in {32, 64, 96, 128}.  K is zero-padded to a multiple of 32 (128 with split
     arithmetic on; x: a
-    padded copy, cached when const_x says the matrix does not change between calls - the node features)."""
+    padded copy, cached when const_x says the matrix does not change between calls - the node features; const_w likewise
+    for the zero-padded weight)."""
     assert mfma_out_width(w_kn.shape[1]) and w_kn.shape[0] == x.shape[1]
     x = _f32_rows(x)
     mult = 128 if matrix_split() == 6 else 32            # the split form walks K in macro chunks of 128
     xp = _cached(f'padx{mult}', x, lambda t: _pad_cols32(t, mult)) if const_x else _pad_cols32(x, mult)
     k = xp.shape[1]
     if w_kn.shape[0] != k or not w_kn.is_contiguous():
-        wp = torch.zeros(k, w_kn.shape[1], dtype=torch.float32, device=x.device)
-        wp[:w_kn.shape[0]] = w_kn
-        w_kn = wp
+        def pad_rows(t):
+            wp = torch.zeros(k, t.shape[1], dtype=torch.float32, device=x.device)
+            wp[:t.shape[0]] = t
+            return wp
+        # (a frozen weight is padded once, not with a fill + copy in front of every product)
+        w_kn = _cached(f'padw{k}', w_kn, pad_rows) if const_w else pad_rows(w_kn)
     n = w_kn.shape[1]
     n_rows = x.shape[0] if idx is None else int(idx.shape[0])
     if out is None:
