@@ -177,7 +177,8 @@ def kg_main(args, device):
            'config': {'workload': f'{args.workload} R-GCN 2-layer ({data.kg_num_edge_type} relation types, block-diagonal weights), '
                                   f'{args.df_size}% {args.df.upper()} triple deletion, full-graph fused Del step ({args.loss_type}, mse_mean)',
                       'num_nodes': data.num_nodes, 'typed_edges_dr': int(data.dr_mask.sum()), 'df_triples': int(data.directed_df_edge_index.shape[1]),
-                      'S1': int(ni1.sum()), 'S2': int(ni2.sum()), 'hip_graph': not args.no_graph, 'parallelism': 'single'},
+                      'S1': int(ni1.sum()), 'S2': int(ni2.sum()), 'hip_graph': not args.no_graph,
+                      'matrix_products': matrix_products_label(), 'parallelism': 'single'},
            'roofline': time_typed_conv(eng), 'final_loss': float(eng.loss_history()[-1, 0])}
     if not args.no_cpu_baseline:
         iters = max(1, min(args.cpu_baseline_iters, 2))
@@ -255,6 +256,13 @@ def replicas_rate(args, model, state, device, world, barrier):
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return world * args.steps / float(t)
+
+
+def matrix_products_label():
+    """Which arithmetic `value` was measured with (gd_set_matrix_split / GD_MATRIX_SPLIT)."""
+    from gnndelete_amd import ops
+    return ('fp32 matrix instruction (v_mfma_f32_32x32x2_f32)' if ops.matrix_split() == 0 else
+            'fp32 products from six exact bf16 partial products (v_mfma_f32_32x32x16_bf16), fp32 accumulation - GD_MATRIX_SPLIT=6')
 
 
 def spmm_algorithmic_bytes(n, nnz, d):
@@ -596,6 +604,7 @@ def main():
                                    f'(BCE link prediction, final loss {pretrain_loss:.4f})' if pretrain_loss is not None
                                    else 'random init',
                        'hip_graph': not args.no_graph, 'iterations_per_graph_launch': 1 if args.no_graph else args.unroll,
+                       'matrix_products': matrix_products_label(),
                        'parallelism': 'single' if world == 1 else (f'row-partition x{world} (RCCL halo all-to-all + all-reduce)'
                                                                   if partitioned else f'replicas x{world}')},
             'roofline': {'kernel': 'spmm_persist_kernel<32,1,4,true,true> (layer-1 CSR SpMM, d=128)', 'bound': 'hbm',
