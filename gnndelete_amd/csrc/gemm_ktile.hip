@@ -184,7 +184,9 @@ __device__ inline void split8k(const float (&v)[8], bf16x8k (&s)[3]) {
   for (int q = 0; q < 3; ++q) s[q] = __builtin_bit_cast(bf16x8k, p[q]);
 }
 
-template <int NT>
+// IDX: rows through an index list (compile-time: a load under a run-time branch makes the count of loads in flight
+// path-dependent, and every later wait becomes s_waitcnt vmcnt(0) - which drains the operand prefetch)
+template <int NT, bool IDX>
 __global__ __launch_bounds__(kKtThreads, 2) void gemm_ktile_split_kernel(
     const float* __restrict__ in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_rows,
     const float* __restrict__ w, int32_t n_chunks, int32_t n_mac, int32_t per, int32_t n_units, const float* __restrict__ bias,
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(kKtThreads, 2) void gemm_ktile_split_kernel(
     const int u = min(u_, u1 - 1);
     const int g = u / n_mac, cm = u - g * n_mac;
     const int s_a = min((g * 8 + wave) * 32 + r_lo, n_rows - 1);
-    const int64_t row = idx ? idx[s_a] : s_a;
+    const int64_t row = IDX ? idx[s_a] : s_a;
     const float4* src = reinterpret_cast<const float4*>(in + row * ld_in) + khalf * 4 + (cm * 4) * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -255,15 +257,13 @@ __global__ __launch_bounds__(kKtThreads, 2) void gemm_ktile_split_kernel(
   int q = 0;                                             // chunks done by this block: chunk q is chunk q & 1 of slot (q >> 1) & 1
   auto work = [&](int u, float4 (&a)[16]) {
     const int g = u / n_mac, cm = u - g * n_mac;
-    // ONE copy of the chunk body (the lane's rows rotate through a[0..3] by register moves): unrolled four times and
-    // duplicated for the two register sets it was 35 KB of code, more than the instruction cache feeds 16 waves from
-#pragma unroll 1
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
       {
         const bf16x8k* wk = wimg + (((q >> 1) & 1) * 2 + (j & 1)) * 3 * kOps + khalf * 32 + r_lo;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const float4 lo = a[2 * m], hi = a[2 * m + 1];
+          const float4 lo = a[j * 4 + 2 * m], hi = a[j * 4 + 2 * m + 1];
           const float v8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
           bf16x8k sp[3];
           split8k(v8, sp);
@@ -294,8 +294,6 @@ __global__ __launch_bounds__(kKtThreads, 2) void gemm_ktile_split_kernel(
           __syncthreads();
         }
         ++q;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) a[i] = a[i + 4];
       }
     }
     if (cm + 1 == n_mac || u + 1 == u1) {
@@ -311,7 +309,7 @@ __global__ __launch_bounds__(kKtThreads, 2) void gemm_ktile_split_kernel(
       } else {
         const int tile = g * 8 + wave, s_a = tile * 32 + r_lo;
         if (tile < n_tiles && s_a < n_rows) {
-          const int64_t orow = idx ? idx[s_a] : s_a;
+          const int64_t orow = IDX ? idx[s_a] : s_a;
           float* dst = out + orow * ld_out + 4 * khalf;
 #pragma unroll
           for (int t = 0; t < NT; ++t)
@@ -335,12 +333,12 @@ __global__ __launch_bounds__(kKtThreads, 2) void gemm_ktile_split_kernel(
   load_w(); stash_w(0);
   load_w();
   __syncthreads();
-#pragma unroll 1
-  for (int u = u0; u < u1; ++u) {
+  for (int u = u0; u < u1; u += 2) {
     fetch(u + 1, rb);
     work(u, ra);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ra[i] = rb[i];
+    if (u + 1 >= u1) break;
+    fetch(u + 2, ra);
+    work(u + 1, rb);
   }
 }
 
@@ -445,8 +443,8 @@ extern "C" int gd_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, i
     const size_t lds = (size_t)2 * 2 * 3 * (2 * (n / 32) * 2 * 32) * 16;        // two slots of two chunks of three pieces
 #define GD_KS_CASE(NT)                                                                                                        \
   do {                                                                                                                        \
-    auto kern = gemm_ktile_split_kernel<NT>;                                                                                  \
-    static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
+    auto kern = idx ? gemm_ktile_split_kernel<NT, true> : gemm_ktile_split_kernel<NT, false>;                                 \
+    const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
     GD_REQUIRE(once == hipSuccess, -(int)once, "gd_gemm_f32: cannot raise the LDS limit");                                    \
     hipLaunchKernelGGL(kern, grid, block, lds, s, in, ld_in, idx, n_rows, w, k / 32, q.chunks, q.per, q.groups * q.chunks,     \
                        bias, out, ld_out, pieces, q.s_max);                                                                   \
