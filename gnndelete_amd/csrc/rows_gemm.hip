@@ -31,8 +31,8 @@ using u32x4v = __attribute__((ext_vector_type(4))) uint32_t;
 // s_i w_j, each EXACT in fp32 (8 x 8 bits), formed on v_mfma_f32_32x32x16_bf16 and accumulated in fp32 like the products
 // of the fp32 instruction.  NP = 9 takes all nine; NP = 6 leaves out s2 w3, s3 w2, s3 w3 (each <= 2^-26 |s w|, a quarter
 // of an fp32 rounding).  Measured against an fp64 product on the Del operator's shape (tools/experiments/split_lab.hip):
-// rel-L2 1.6e-7 for both, 2.0e-7 for v_mfma_f32_32x32x2_f32 - and 44 us instead of 70 us, because the fp32 instruction
-// is what keeps this kernel at the chip's power limit.
+// rel-L2 1.6e-7 for both, 2.0e-7 for v_mfma_f32_32x32x2_f32 - and 44 us instead of 70 us: 2.7 x fewer matrix-pipe cycles
+// (DESIGN section 4).
 __device__ inline void split8(const float4 a, const float4 b, bf16x8 (&s)[3]) {
   const f32x2 v[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
   u32x4v p[3];

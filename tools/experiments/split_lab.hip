@@ -149,8 +149,10 @@ __global__ __launch_bounds__(kThreads, 2) void split_gemm_kernel(const float* __
 }
 
 // the production form: fp32 matrix instruction, tile-interleaved fp32 weight image
+__device__ unsigned long long g_clk[4];
 __global__ __launch_bounds__(kThreads, 4) void f32_gemm_kernel(const float* __restrict__ in, int n_rows, const float* __restrict__ w,
                                                               float* __restrict__ out) {
+  const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float* const wl = reinterpret_cast<float*>(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(kThreads, 4) void f32_gemm_kernel(const float* __re
     row_cur = row_nxt;
     row_nxt = row_of(min(tile + 2 * stride, n_tiles - 1));
   }
+  if (blockIdx.x == 7 && threadIdx.x == 0) { g_clk[0] = __builtin_readcyclecounter() - c0; g_clk[1] = wall_clock64() - w0; }
 }
 
 static float frand(uint64_t& s) {                           // roughly normal, a few orders of magnitude of spread
@@ -276,5 +279,9 @@ int main(int argc, char** argv) {
     run("bf16 split x6", [&] { hipLaunchKernelGGL(split_gemm_kernel<6>, dim3(grid), dim3(kThreads), 98304, 0, x, n, w, o); });
     run("bf16 split x3", [&] { hipLaunchKernelGGL(split_gemm_kernel<3>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
   }
+  unsigned long long clk[4];
+  CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk)));
+  printf("fp32 kernel, block 7 wave 0: %llu shader cycles in %llu ticks of the 100 MHz wall clock -> %.0f MHz shader clock under this kernel\n", clk[0], clk[1],
+         100.0 * (double)clk[0] / (double)clk[1]);
   return 0;
 }
