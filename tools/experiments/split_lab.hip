@@ -216,6 +216,76 @@ __global__ __launch_bounds__(kThreads, 4) void f32_gemm_kernel(const float* __re
 }
 
 // the production form: fp32 matrix instruction, tile-interleaved fp32 weight image
+// STAG: the waves that share a SIMD start STAG x 127 x 64 cycles apart, so that their tile epilogues (16 row stores each) stop coinciding
+template <int STAG>
+__global__ __launch_bounds__(kThreads, 4) void f32_stag_kernel_(const float* __restrict__ in, int n_rows, const float* __restrict__ w,
+                                                              float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float* const wl = reinterpret_cast<float*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r_lo = lane & 31, khalf = lane >> 5;
+  for (int e = tid; e < 128 * 32; e += kThreads) {
+    const int k = e >> 5, r = e & 31;
+    *reinterpret_cast<float4*>(wl + e * 4) = make_float4(w[k * 128 + r], w[k * 128 + 32 + r], w[k * 128 + 64 + r], w[k * 128 + 96 + r]);
+  }
+  __syncthreads();
+  {
+    const int phase = (wave >> 2) + 2 * ((blockIdx.x >> 8) & 1);
+    for (int i = 0; i < phase * STAG; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  const int n_tiles = (n_rows + 31) >> 5, stride = gridDim.x * kWaves;
+  int tile = blockIdx.x * kWaves + wave;
+  if (tile >= n_tiles) return;
+  auto row_of = [&](int t) { return min(t * 32 + r_lo, n_rows - 1); };
+  int row_cur = row_of(tile), row_nxt = row_of(min(tile + stride, n_tiles - 1));
+  float4 a_next[4];
+  {
+    const float4* s0 = reinterpret_cast<const float4*>(in + (int64_t)row_cur * 128) + khalf * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_next[i] = s0[i];
+  }
+  for (; tile < n_tiles; tile += stride) {
+    const bool live = tile * 32 + r_lo < n_rows;
+    const float4* src = reinterpret_cast<const float4*>(in + (int64_t)row_cur * 128) + khalf * 4;
+    const float4* src_n = reinterpret_cast<const float4*>(in + (int64_t)row_nxt * 128) + khalf * 4;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll 1
+    for (int kc = 0; kc < 4; ++kc) {
+      float4 a4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a4[i] = a_next[i];
+      const float4* nsrc = kc + 1 < 4 ? src + (kc + 1) * 8 : src_n;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_next[i] = nsrc[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float av[4] = {a4[i].x, a4[i].y, a4[i].z, a4[i].w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float4 f = *reinterpret_cast<const float4*>(wl + ((kc * 32 + khalf * 16 + i * 4 + s) * 32 + r_lo) * 4);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.x, av[s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.y, av[s], acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.z, av[s], acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w, av[s], acc[3], 0, 0, 0);
+        }
+      }
+    }
+    float* dst = out + (int64_t)row_cur * 128 + 4 * khalf;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (live) *reinterpret_cast<float4*>(dst + 32 * t + 8 * q) = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+    row_cur = row_nxt;
+    row_nxt = row_of(min(tile + 2 * stride, n_tiles - 1));
+  }
+}
+
+// the production form: fp32 matrix instruction, tile-interleaved fp32 weight image
 __global__ __launch_bounds__(kThreads, 4) void f32_pf_kernel(const float* __restrict__ in, int n_rows, const float* __restrict__ w,
                                                               float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -417,6 +487,10 @@ int main(int argc, char** argv) {
   run("fp32, knock-out: matrix instructions only", [&] { hipLaunchKernelGGL(f32_ko_kernel<7>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
   CK(hipFuncSetAttribute((const void*)f32_pf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   run("fp32, LDS operands one k step ahead", [&] { hipLaunchKernelGGL(f32_pf_kernel, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
+  CK(hipFuncSetAttribute((const void*)f32_stag_kernel_<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  CK(hipFuncSetAttribute((const void*)f32_stag_kernel_<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  run("fp32, waves of a SIMD staggered by 8 k cycles", [&] { hipLaunchKernelGGL(f32_stag_kernel_<1>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
+  run("fp32, waves of a SIMD staggered by 16 k cycles", [&] { hipLaunchKernelGGL(f32_stag_kernel_<2>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
   for (int round = 0; round < 2; ++round) {
     run("fp32 mfma 32x32x2 (production form)", [&] { hipLaunchKernelGGL(f32_gemm_kernel, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
     run("bf16 split x9", [&] { hipLaunchKernelGGL(split_gemm_kernel<9>, dim3(grid), dim3(kThreads), 98304, 0, x, n, w, o); });
