@@ -224,13 +224,25 @@ __global__ __launch_bounds__(kThreads, 4) void f32_stag_kernel_(const float* __r
   float* const wl = reinterpret_cast<float*>(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r_lo = lane & 31, khalf = lane >> 5;
+  if (STAG == 3) {
+    // fast fill: 8 coalesced 16-byte loads per thread, all in flight at once, scattered into the interleaved image
+    float4 v[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) v[it] = reinterpret_cast<const float4*>(w)[tid + it * kThreads];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int e4 = tid + it * kThreads, k = e4 >> 5, n0 = (e4 & 31) * 4, t = n0 >> 5, r = n0 & 31;
+      float* dst = wl + (k * 32 + r) * 4 + t;
+      dst[0] = v[it].x; dst[4] = v[it].y; dst[8] = v[it].z; dst[12] = v[it].w;
+    }
+  } else
   for (int e = tid; e < 128 * 32; e += kThreads) {
     const int k = e >> 5, r = e & 31;
     *reinterpret_cast<float4*>(wl + e * 4) = make_float4(w[k * 128 + r], w[k * 128 + 32 + r], w[k * 128 + 64 + r], w[k * 128 + 96 + r]);
   }
   __syncthreads();
   {
-    const int phase = (wave >> 2) + 2 * ((blockIdx.x >> 8) & 1);
+    const int phase = STAG == 3 ? 0 : (wave >> 2) + 2 * ((blockIdx.x >> 8) & 1);
     for (int i = 0; i < phase * STAG; ++i) __builtin_amdgcn_s_sleep(127);
   }
   const int n_tiles = (n_rows + 31) >> 5, stride = gridDim.x * kWaves;
@@ -490,6 +502,8 @@ int main(int argc, char** argv) {
   CK(hipFuncSetAttribute((const void*)f32_stag_kernel_<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   CK(hipFuncSetAttribute((const void*)f32_stag_kernel_<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   run("fp32, waves of a SIMD staggered by 8 k cycles", [&] { hipLaunchKernelGGL(f32_stag_kernel_<1>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
+  CK(hipFuncSetAttribute((const void*)f32_stag_kernel_<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  run("fp32, weight image filled by 8 vector loads in flight", [&] { hipLaunchKernelGGL(f32_stag_kernel_<3>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
   run("fp32, waves of a SIMD staggered by 16 k cycles", [&] { hipLaunchKernelGGL(f32_stag_kernel_<2>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
   for (int round = 0; round < 2; ++round) {
     run("fp32 mfma 32x32x2 (production form)", [&] { hipLaunchKernelGGL(f32_gemm_kernel, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
