@@ -11,8 +11,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+__device__ unsigned long long g_clk[2];
 template <bool BF16>
 __global__ __launch_bounds__(256) void mfma_loop(float* sink, int iters, uint32_t seed) {
+  const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
   f32x16 acc[4];
   for (int t = 0; t < 4; ++t)
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
@@ -43,6 +45,7 @@ __global__ __launch_bounds__(256) void mfma_loop(float* sink, int iters, uint32_
   for (int t = 0; t < 4; ++t)
     for (int r = 0; r < 16; ++r) s += acc[t][r];
   sink[blockIdx.x * 256 + threadIdx.x] = s;
+  if (blockIdx.x == 3 && threadIdx.x == 0) { g_clk[0] = __builtin_readcyclecounter() - c0; g_clk[1] = wall_clock64() - w0; }
 }
 
 int main() {
@@ -68,8 +71,10 @@ int main() {
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double flop = 3.0 * grid * 4.0 * iters * 4.0 * (bf ? 32768.0 : 4096.0);
-        printf("%-5s %-9s operands, %d wave(s) per SIMD: %8.1f TFLOP/s  (%.0f ms of continuous matrix work)\n", bf ? "bf16" : "fp32",
-               random ? "random" : "constant", wps, flop / (ms * 1e-3) / 1e12, ms);
+        unsigned long long clk[2];
+        CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk)));
+        printf("%-5s %-9s operands, %d wave(s) per SIMD: %8.1f TFLOP/s  (%.0f ms of continuous matrix work, shader clock %.0f MHz)\n", bf ? "bf16" : "fp32",
+               random ? "random" : "constant", wps, flop / (ms * 1e-3) / 1e12, ms, 100.0 * (double)clk[0] / (double)clk[1]);
       }
   return 0;
 }

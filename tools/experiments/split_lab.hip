@@ -150,6 +150,9 @@ __global__ __launch_bounds__(kThreads, 2) void split_gemm_kernel(const float* __
 
 // the production form: fp32 matrix instruction, tile-interleaved fp32 weight image
 __device__ unsigned long long g_clk[4];
+__device__ unsigned long long g_ph[16];
+__device__ unsigned long long g_wave[4 * 8192];      // per wave: hw id | xcc id << 32, block * 8 + wave, wall-clock start, end
+__device__ unsigned long long g_span[2 * 1024];     // wall-clock start / end of wave 0 of every block       // phase stamps of block 7 wave 0: start, after fill, then (k loop end, stores issued) per tile
 __global__ __launch_bounds__(kThreads, 4) void f32_gemm_kernel(const float* __restrict__ in, int n_rows, const float* __restrict__ w,
                                                               float* __restrict__ out) {
   const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
@@ -162,6 +165,9 @@ __global__ __launch_bounds__(kThreads, 4) void f32_gemm_kernel(const float* __re
     *reinterpret_cast<float4*>(wl + e * 4) = make_float4(w[k * 128 + r], w[k * 128 + 32 + r], w[k * 128 + 64 + r], w[k * 128 + 96 + r]);
   }
   __syncthreads();
+  const bool probe = blockIdx.x == 7 && threadIdx.x == 0;
+  int ph = 0;
+  if (probe) { g_ph[ph++] = c0; g_ph[ph++] = __builtin_readcyclecounter(); }
   const int n_tiles = (n_rows + 31) >> 5, stride = gridDim.x * kWaves;
   int tile = blockIdx.x * kWaves + wave;
   if (tile >= n_tiles) return;
@@ -203,16 +209,109 @@ __global__ __launch_bounds__(kThreads, 4) void f32_gemm_kernel(const float* __re
         }
       }
     }
+    if (probe && ph < 14) g_ph[ph++] = __builtin_readcyclecounter();
     float* dst = out + (int64_t)row_cur * 128 + 4 * khalf;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (live) *reinterpret_cast<float4*>(dst + 32 * t + 8 * q) = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+    if (probe && ph < 14) g_ph[ph++] = __builtin_readcyclecounter();
     row_cur = row_nxt;
     row_nxt = row_of(min(tile + 2 * stride, n_tiles - 1));
   }
+  if (probe) g_ph[15] = ph;
+  if (lane == 0 && blockIdx.x * 8 + wave < 8192) {
+    unsigned int hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* rec = g_wave + 4 * (blockIdx.x * 8 + wave);
+    rec[0] = hw | ((unsigned long long)(xcc & 15) << 32);
+    rec[1] = blockIdx.x * 8 + wave;
+    rec[2] = w0;
+    rec[3] = wall_clock64();
+  }
+  if (threadIdx.x == 0 && blockIdx.x < 1024) { g_span[2 * blockIdx.x] = w0; g_span[2 * blockIdx.x + 1] = wall_clock64(); }
   if (blockIdx.x == 7 && threadIdx.x == 0) { g_clk[0] = __builtin_readcyclecounter() - c0; g_clk[1] = wall_clock64() - w0; }
+}
+
+// the production form: fp32 matrix instruction, tile-interleaved fp32 weight image
+// one block of 16 waves per CU sharing ONE weight image, the block's tiles handed out through an LDS counter: a wave that
+// the (oldest-first) arbitration of the matrix pipe lets run ahead simply takes more tiles
+__global__ __launch_bounds__(1024, 4) void f32_queue_kernel(const float* __restrict__ in, int n_rows, const float* __restrict__ w,
+                                                              float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float* const wl = reinterpret_cast<float*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r_lo = lane & 31, khalf = lane >> 5;
+  for (int e = tid; e < 128 * 32; e += 1024) {
+    const int k = e >> 5, r = e & 31;
+    *reinterpret_cast<float4*>(wl + e * 4) = make_float4(w[k * 128 + r], w[k * 128 + 32 + r], w[k * 128 + 64 + r], w[k * 128 + 96 + r]);
+  }
+  __syncthreads();
+  __shared__ int q_next;
+  const int n_tiles = (n_rows + 31) >> 5;
+  const int per_block = (n_tiles + gridDim.x - 1) / gridDim.x, t_lo = blockIdx.x * per_block, t_hi = min(n_tiles, t_lo + per_block);
+  if (tid == 0) q_next = 0;
+  __syncthreads();
+  auto grab = [&]() -> int {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(&q_next, 1);
+    t = __builtin_amdgcn_readfirstlane(t) + t_lo;
+    return t < t_hi ? t : n_tiles;
+  };
+  int tile = grab();
+  if (tile >= n_tiles) return;
+  int tile_nxt = grab();
+  auto row_of = [&](int t) { return min(t * 32 + r_lo, n_rows - 1); };
+  int row_cur = row_of(tile), row_nxt = row_of(min(tile_nxt, n_tiles - 1));
+  float4 a_next[4];
+  {
+    const float4* s0 = reinterpret_cast<const float4*>(in + (int64_t)row_cur * 128) + khalf * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_next[i] = s0[i];
+  }
+  for (; tile < n_tiles;) {
+    const bool live = tile * 32 + r_lo < n_rows;
+    const float4* src = reinterpret_cast<const float4*>(in + (int64_t)row_cur * 128) + khalf * 4;
+    const float4* src_n = reinterpret_cast<const float4*>(in + (int64_t)row_nxt * 128) + khalf * 4;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll 1
+    for (int kc = 0; kc < 4; ++kc) {
+      float4 a4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a4[i] = a_next[i];
+      const float4* nsrc = kc + 1 < 4 ? src + (kc + 1) * 8 : src_n;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_next[i] = nsrc[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float av[4] = {a4[i].x, a4[i].y, a4[i].z, a4[i].w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float4 f = *reinterpret_cast<const float4*>(wl + ((kc * 32 + khalf * 16 + i * 4 + s) * 32 + r_lo) * 4);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.x, av[s], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.y, av[s], acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.z, av[s], acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w, av[s], acc[3], 0, 0, 0);
+        }
+      }
+    }
+    float* dst = out + (int64_t)row_cur * 128 + 4 * khalf;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (live) *reinterpret_cast<float4*>(dst + 32 * t + 8 * q) = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+    tile = tile_nxt;
+    tile_nxt = tile < n_tiles ? grab() : n_tiles;
+    row_cur = row_nxt;
+    row_nxt = row_of(min(tile_nxt, n_tiles - 1));
+  }
 }
 
 // the production form: fp32 matrix instruction, tile-interleaved fp32 weight image
@@ -419,6 +518,14 @@ __global__ __launch_bounds__(kThreads, 4) void f32_ko_kernel(const float* __rest
       }
     }
     float* dst = out + (int64_t)row_cur * 128 + 4 * khalf;
+    if (KO & 4) {                                           // ONE store per tile instead of 16 (everything folded into it)
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sum.x += acc[t][4 * q]; sum.y += acc[t][4 * q + 1]; sum.z += acc[t][4 * q + 2]; sum.w += acc[t][4 * q + 3]; }
+      if (live) *reinterpret_cast<float4*>(dst) = sum;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -495,8 +602,8 @@ int main(int argc, char** argv) {
   run("fp32, knock-out: operand rows in registers", [&] { hipLaunchKernelGGL(f32_ko_kernel<1>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
   run("fp32, knock-out: no LDS weight reads", [&] { hipLaunchKernelGGL(f32_ko_kernel<2>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
   run("fp32, knock-out: neither", [&] { hipLaunchKernelGGL(f32_ko_kernel<3>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
-  run("fp32, knock-out: no stores", [&] { hipLaunchKernelGGL(f32_ko_kernel<4>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
-  run("fp32, knock-out: matrix instructions only", [&] { hipLaunchKernelGGL(f32_ko_kernel<7>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
+  run("fp32, knock-out: one store per tile instead of 16", [&] { hipLaunchKernelGGL(f32_ko_kernel<4>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
+  run("fp32, knock-out: no loads, no LDS reads, one store per tile", [&] { hipLaunchKernelGGL(f32_ko_kernel<7>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
   CK(hipFuncSetAttribute((const void*)f32_pf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   run("fp32, LDS operands one k step ahead", [&] { hipLaunchKernelGGL(f32_pf_kernel, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
   CK(hipFuncSetAttribute((const void*)f32_stag_kernel_<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -505,6 +612,8 @@ int main(int argc, char** argv) {
   CK(hipFuncSetAttribute((const void*)f32_stag_kernel_<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   run("fp32, weight image filled by 8 vector loads in flight", [&] { hipLaunchKernelGGL(f32_stag_kernel_<3>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
   run("fp32, waves of a SIMD staggered by 16 k cycles", [&] { hipLaunchKernelGGL(f32_stag_kernel_<2>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
+  CK(hipFuncSetAttribute((const void*)f32_queue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  run("fp32, 16 waves per CU sharing an LDS tile queue", [&] { hipLaunchKernelGGL(f32_queue_kernel, dim3(grid), dim3(1024), 65536, 0, x, n, w, o); });
   for (int round = 0; round < 2; ++round) {
     run("fp32 mfma 32x32x2 (production form)", [&] { hipLaunchKernelGGL(f32_gemm_kernel, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
     run("bf16 split x9", [&] { hipLaunchKernelGGL(split_gemm_kernel<9>, dim3(grid), dim3(kThreads), 98304, 0, x, n, w, o); });
@@ -513,6 +622,49 @@ int main(int argc, char** argv) {
   }
   unsigned long long clk[4];
   CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk)));
+  unsigned long long ph[16];
+  CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_ph), sizeof(ph)));
+  printf("phases of block 7 wave 0 (shader cycles): fill %llu", ph[1] - ph[0]);
+  for (int i = 2; i + 1 < (int)ph[15]; i += 2) printf(" | tile k-loop %llu epilogue %llu", ph[i] - ph[i - 1], ph[i + 1] - ph[i]);
+  printf("\n");
+  {
+    static unsigned long long span[2048];
+    CK(hipMemcpyFromSymbol(span, HIP_SYMBOL(g_span), sizeof(span)));
+    unsigned long long s_min = ~0ull, s_max = 0, e_min = ~0ull, e_max = 0;
+    const int nb = 2 * grid;
+    for (int i = 0; i < nb && i < 1024; ++i) {
+      if (span[2 * i] < s_min) s_min = span[2 * i];
+      if (span[2 * i] > s_max) s_max = span[2 * i];
+      if (span[2 * i + 1] < e_min) e_min = span[2 * i + 1];
+      if (span[2 * i + 1] > e_max) e_max = span[2 * i + 1];
+    }
+    printf("last fp32 launch, wave 0 of %d blocks (us, from the first start): last start %.1f, first end %.1f, last end %.1f\n", nb,
+           (s_max - s_min) * 0.01, (e_min - s_min) * 0.01, (e_max - s_min) * 0.01);
+    printf("  mean / min / max end per XCD (block index mod 8):");
+    for (int x = 0; x < 8; ++x) {
+      double sum = 0, mn = 1e30, mx = 0;
+      int cnt = 0;
+      for (int i = x; i < nb && i < 1024; i += 8) { const double e = (span[2 * i + 1] - s_min) * 0.01; sum += e; mn = e < mn ? e : mn; mx = e > mx ? e : mx; ++cnt; }
+      printf("  [%d] %.0f / %.0f / %.0f", x, sum / cnt, mn, mx);
+    }
+    {
+      static unsigned long long wv[4 * 8192];
+      CK(hipMemcpyFromSymbol(wv, HIP_SYMBOL(g_wave), sizeof(wv)));
+      const int nw = nb * 8 < 8192 ? nb * 8 : 8192;
+      // waves that shared SIMD (xcc 0, se 0, sh 0, cu of block 0, simd of block 0 wave 0) and two more SIMDs
+      for (int pick = 0; pick < 3; ++pick) {
+        const unsigned long long key = wv[4 * (pick * 8 * 37)] & 0xf0000fff0ull;      // xcc | se sh cu | simd
+        printf("\n  SIMD of wave %d (xcc %llu, hw id bits %03llx): [block.wave start-end us]", pick * 8 * 37, wv[4 * (pick * 8 * 37)] >> 32,
+               (wv[4 * (pick * 8 * 37)] >> 4) & 0xfff);
+        for (int i = 0; i < nw; ++i)
+          if ((wv[4 * i] & 0xf0000fff0ull) == key)
+            printf("  %llu.%llu %.0f-%.0f", wv[4 * i + 1] / 8, wv[4 * i + 1] % 8, (wv[4 * i + 2] - s_min) * 0.01, (wv[4 * i + 3] - s_min) * 0.01);
+      }
+    }
+    printf("\n  ends of blocks 0..31:");
+    for (int i = 0; i < 32; ++i) printf(" %.0f", (span[2 * i + 1] - s_min) * 0.01);
+    printf("\n");
+  }
   printf("fp32 kernel, block 7 wave 0: %llu shader cycles in %llu ticks of the 100 MHz wall clock -> %.0f MHz shader clock under this kernel\n", clk[0], clk[1],
          100.0 * (double)clk[0] / (double)clk[1]);
   return 0;
