@@ -236,6 +236,77 @@ __global__ __launch_bounds__(kThreads, 4) void f32_gemm_kernel(const float* __re
 }
 
 // the production form: fp32 matrix instruction, tile-interleaved fp32 weight image
+// NON-transposed product (sample rows = D rows): a lane ends with ONE feature of 16 samples, and every store instruction
+// writes 128 contiguous bytes of two rows (dword per lane) instead of 32-byte pieces of 32 rows
+__global__ __launch_bounds__(kThreads, 4) void f32_rowmajor_kernel(const float* __restrict__ in, int n_rows, const float* __restrict__ w,
+                                                              float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float* const wl = reinterpret_cast<float*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r_lo = lane & 31, khalf = lane >> 5;
+  for (int e = tid; e < 128 * 32; e += kThreads) {
+    const int k = e >> 5, r = e & 31;
+    *reinterpret_cast<float4*>(wl + e * 4) = make_float4(w[k * 128 + r], w[k * 128 + 32 + r], w[k * 128 + 64 + r], w[k * 128 + 96 + r]);
+  }
+  __syncthreads();
+  const int n_tiles = (n_rows + 31) >> 5, stride = gridDim.x * kWaves;
+  int tile = blockIdx.x * kWaves + wave;
+  if (tile >= n_tiles) return;
+  auto row_of = [&](int t) { return min(t * 32 + r_lo, n_rows - 1); };
+  int row_cur = row_of(tile), row_nxt = row_of(min(tile + stride, n_tiles - 1));
+  float4 a_next[4];
+  {
+    const float4* s0 = reinterpret_cast<const float4*>(in + (int64_t)row_cur * 128) + khalf * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_next[i] = s0[i];
+  }
+  for (; tile < n_tiles; tile += stride) {
+    const bool live = tile * 32 + r_lo < n_rows;
+    const float4* src = reinterpret_cast<const float4*>(in + (int64_t)row_cur * 128) + khalf * 4;
+    const float4* src_n = reinterpret_cast<const float4*>(in + (int64_t)row_nxt * 128) + khalf * 4;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll 1
+    for (int kc = 0; kc < 4; ++kc) {
+      float4 a4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a4[i] = a_next[i];
+      const float4* nsrc = kc + 1 < 4 ? src + (kc + 1) * 8 : src_n;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_next[i] = nsrc[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float av[4] = {a4[i].x, a4[i].y, a4[i].z, a4[i].w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float4 f = *reinterpret_cast<const float4*>(wl + ((kc * 32 + khalf * 16 + i * 4 + s) * 32 + r_lo) * 4);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], f.x, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], f.y, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], f.z, acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], f.w, acc[3], 0, 0, 0);
+        }
+      }
+    }
+    // D[i][j]: i = sample (r & 3) + 8 (r >> 2) + 4 khalf, j = lane & 31 = feature within tile t
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      const int rowi = __shfl(row_cur, i);
+      if (tile * 32 + i < n_rows) {
+        float* dst = out + (int64_t)rowi * 128 + r_lo;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dst[32 * t] = acc[t][r];
+      }
+    }
+    row_cur = row_nxt;
+    row_nxt = row_of(min(tile + 2 * stride, n_tiles - 1));
+  }
+}
+
+// the production form: fp32 matrix instruction, tile-interleaved fp32 weight image
 // one block of 16 waves per CU sharing ONE weight image, the block's tiles handed out through an LDS counter: a wave that
 // the (oldest-first) arbitration of the matrix pipe lets run ahead simply takes more tiles
 __global__ __launch_bounds__(1024, 4) void f32_queue_kernel(const float* __restrict__ in, int n_rows, const float* __restrict__ w,
@@ -614,6 +685,8 @@ int main(int argc, char** argv) {
   run("fp32, waves of a SIMD staggered by 16 k cycles", [&] { hipLaunchKernelGGL(f32_stag_kernel_<2>, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
   CK(hipFuncSetAttribute((const void*)f32_queue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
   run("fp32, 16 waves per CU sharing an LDS tile queue", [&] { hipLaunchKernelGGL(f32_queue_kernel, dim3(grid), dim3(1024), 65536, 0, x, n, w, o); });
+  CK(hipFuncSetAttribute((const void*)f32_rowmajor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  run("fp32, non-transposed product: 128-byte row segments per store", [&] { hipLaunchKernelGGL(f32_rowmajor_kernel, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
   for (int round = 0; round < 2; ++round) {
     run("fp32 mfma 32x32x2 (production form)", [&] { hipLaunchKernelGGL(f32_gemm_kernel, dim3(2 * grid), dim3(kThreads), 65536, 0, x, n, w, o); });
     run("bf16 split x9", [&] { hipLaunchKernelGGL(split_gemm_kernel<9>, dim3(grid), dim3(kThreads), 98304, 0, x, n, w, o); });
