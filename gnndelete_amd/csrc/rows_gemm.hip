@@ -888,16 +888,18 @@ struct AdamArgs { float* param; float* m; float* v; const int32_t* iter; double 
 
 static int wgrad_impl(const gd::WgradLoss* loss, const float* a, int64_t ld_a, const int32_t* a_idx, const float* g,
                       int64_t ld_g, const int32_t* g_idx, const float* relu_mask, const float* g_add, int32_t n_sel, int32_t d_a, int32_t d_b, float* dw,
-                      int32_t accumulate, float* partials, const gd::AdamArgs* adam, void* stream) {
+                      int32_t accumulate, float* partials, const gd::AdamArgs* adam, void* stream, bool reduce_only = false) {
   using namespace gd;
-  GD_REQUIRE(dw && partials, GD_E_NULL, "gd_rows_gemm_wgrad_f32: null output");
-  GD_REQUIRE(n_sel == 0 || (a && g), GD_E_NULL, "gd_rows_gemm_wgrad_f32: null input");
+  GD_REQUIRE(partials, GD_E_NULL, "gd_rows_gemm_wgrad_f32: null partials");
+  GD_REQUIRE(dw || !adam, GD_E_NULL, "gd_rows_gemm_wgrad_f32: an optimizer step needs dw");
+  GD_REQUIRE(n_sel == 0 || reduce_only || (a && g), GD_E_NULL, "gd_rows_gemm_wgrad_f32: null input");
   GD_REQUIRE(n_sel >= 0 && d_a > 0 && d_b > 0 && ld_a >= d_a && ld_g >= d_b, GD_E_DIM,
              "gd_rows_gemm_wgrad_f32: bad dims");
   hipStream_t s = (hipStream_t)stream;
   const int n_elem = d_a * d_b;
   int nb = 0, rpb = 8;
-  if (n_sel > 0) {
+  if (n_sel > 0 && reduce_only) wgrad_geometry(n_sel, &nb, &rpb);
+  if (n_sel > 0 && !reduce_only) {
     wgrad_geometry(n_sel, &nb, &rpb);
     const int ta = d_a / 32, tb = d_b / 32;
     const bool mfma_ok = (d_a % 32 == 0) && (d_b % 32 == 0) && ta <= 4 && tb <= 4 && ta != 3 && tb != 3 &&
@@ -944,6 +946,7 @@ static int wgrad_impl(const gd::WgradLoss* loss, const float* a, int64_t ld_a, c
     int rc = launched("rows_wgrad");
     if (rc) return rc;
   }
+  if (!dw) return GD_OK;       // partial products only: the caller reduces them (gd_rows_gemm_wgrad_reduce_f32)
   const bool vec = n_elem % 4 == 0 && aligned16(dw) && aligned16(partials);
   if (adam && vec) {
     hipLaunchKernelGGL(wgrad_reduce_adam_kernel, dim3((n_elem / 4 + 15) / 16), dim3(256), 0, s, partials, nb, n_elem,
@@ -981,6 +984,19 @@ extern "C" int gd_rows_gemm_wgrad_adam_f32(const float* a, int64_t ld_a, const i
   const gd::AdamArgs adam{param, exp_avg, exp_avg_sq, iter, lr, beta1, beta2, eps};
   return wgrad_impl(nullptr, a, ld_a, a_idx, g, ld_g, g_idx, relu_mask, g_add, n_sel, d_a, d_b, dw, accumulate,
                     partials, &adam, stream);
+}
+
+extern "C" int gd_rows_gemm_wgrad_reduce_f32(const float* partials, int32_t n_sel, int32_t d_a, int32_t d_b, float* dw,
+                                             int32_t accumulate, float* param, float* exp_avg, float* exp_avg_sq,
+                                             const int32_t* iter, double lr, double beta1, double beta2, double eps,
+                                             void* stream) {
+  GD_REQUIRE(partials && dw, GD_E_NULL, "gd_rows_gemm_wgrad_reduce_f32: null pointer");
+  GD_REQUIRE(!param || (exp_avg && exp_avg_sq && iter), GD_E_NULL, "gd_rows_gemm_wgrad_reduce_f32: null optimizer state");
+  GD_REQUIRE(n_sel >= 0 && d_a > 0 && d_b > 0, GD_E_DIM, "gd_rows_gemm_wgrad_reduce_f32: bad dims");
+  const gd::AdamArgs adam{param, exp_avg, exp_avg_sq, iter, lr, beta1, beta2, eps};
+  // n_sel = 0 rows: no partials exist, dW (+)= 0 (wgrad_impl with nothing to launch but the reduction)
+  return wgrad_impl(nullptr, nullptr, d_a, nullptr, nullptr, d_b, nullptr, nullptr, nullptr, n_sel, d_a, d_b, dw, accumulate,
+                    const_cast<float*>(partials), param ? &adam : nullptr, stream, true);
 }
 
 extern "C" int32_t gd_rows_gemm_wgrad_blocks(int32_t n_sel) {

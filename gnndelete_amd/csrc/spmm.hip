@@ -119,7 +119,7 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
                                                   const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
                                                   int64_t ldy, const float* __restrict__ bias, float self_coef,
                                                   const float* __restrict__ xs, float* __restrict__ scratch, int32_t d4,
-                                                  int32_t nnz) {
+                                                  int32_t nnz, const int4* __restrict__ hubs, int32_t n_hubs) {
   constexpr int G = kWave / LPR;
   constexpr int kXcd = 8;
   const int lane = threadIdx.x & 63;
@@ -130,8 +130,6 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
   const int per = (n_items + kXcd - 1) / kXcd;
   const int i0 = xcd_bounds ? xcd_bounds[xcd] : xcd * per;
   const int i1 = xcd_bounds ? xcd_bounds[xcd + 1] : min(n_items, i0 + per);
-  int i = i0 + wx;
-  if (i >= i1) return;
 
   // per-lane constants: byte offset of this lane's vectors inside a row, its slice of the bias
   uint32_t lo[VPL];
@@ -140,6 +138,84 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
   const char* bb = reinterpret_cast<const char*>(bias);
   const uint32_t pitch_b = (uint32_t)ldx * 4u;
   const char* xb = reinterpret_cast<const char*>(x);
+
+  // ---- hub rows (more than 64 in-edges), one-pass form: hubs[h] = {row, start, end, -}.  The block's four waves take
+  // the row's 64-edge pieces round robin (each wave keeps ONE accumulator over its pieces), the four partial rows meet
+  // in LDS and wave 0 adds them in wave order (+ self term, + bias) and writes the row: no scratch rows, no fix-up
+  // launch, no atomics - the summation order is fixed by (row, piece, lane group), bit-reproducible.  XCD k's blocks
+  // take the hubs [xcd_bounds[9 + k], xcd_bounds[10 + k]) - the hub rows of the row range whose whole rows it sweeps.
+  if (n_hubs > 0) {
+    __shared__ float4 hub_red[4][LPR * VPL];
+    const int wave = threadIdx.x >> 6;
+    const int nbx = gridDim.x / kXcd, bx = blockIdx.x / kXcd;
+    const int hper = (n_hubs + kXcd - 1) / kXcd;
+    const int h0 = xcd_bounds ? xcd_bounds[9 + xcd] : min(n_hubs, xcd * hper);
+    const int h1 = xcd_bounds ? xcd_bounds[10 + xcd] : min(n_hubs, h0 + hper);
+    for (int h = h0 + bx; h < h1; h += nbx) {
+      int4 hv = make_int4(0, 0, 0, 0);
+      if (lane == 0) hv = hubs[h];
+      const int row = __builtin_amdgcn_readfirstlane(hv.x), start = __builtin_amdgcn_readfirstlane(hv.y),
+                end = __builtin_amdgcn_readfirstlane(hv.z);
+      float4 acc[VPL];
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
+      for (int base = start + wave * kWave; base < end; base += 4 * kWave) {
+        const int cnt = min(kWave, end - base);
+        const int kk = min(base + lane, nnz - 1);
+        const int c_cur = col[kk];
+        const float w_cur = lane < cnt ? (val ? val[kk] : 1.0f) : 0.f;
+        const int trips = (cnt + G - 1) / G;
+        const int last4 = 4 * cnt - 4, end4 = 4 * cnt;
+        for (int t0 = 0; t0 < trips; t0 += U) {
+          float4 xv[U][VPL];
+          float wj[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {       // trips past the end re-read the last neighbour with weight 0 (lane `cnt`)
+            const int j4 = 4 * ((t0 + u) * G) + 4 * g;
+            const int cs = __builtin_amdgcn_ds_bpermute(min(j4, last4), c_cur);
+            wj[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(min(j4, end4), __float_as_int(w_cur)));
+            if (ADDR32) {
+              const uint32_t ro = __umul24((uint32_t)cs, pitch_b);
+#pragma unroll
+              for (int v = 0; v < VPL; ++v) xv[u][v] = *reinterpret_cast<const float4*>(xb + (ro + lo[v]));
+            } else {
+              const char* xr = reinterpret_cast<const char*>(x + (int64_t)cs * ldx);
+#pragma unroll
+              for (int v = 0; v < VPL; ++v) xv[u][v] = *reinterpret_cast<const float4*>(xr + lo[v]);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) acc[v] = f4_group_sum<LPR>(acc[v]);
+      if (g == 0) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) hub_red[wave][li + v * LPR] = acc[v];
+      }
+      __syncthreads();
+      if (wave == 0 && g == 0) {
+        char* ob = reinterpret_cast<char*>(y + (int64_t)row * ldy);
+        const char* sb = reinterpret_cast<const char*>(xs + (int64_t)row * ldx);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          if (!EXACT && li + v * LPR >= d4) continue;
+          const int e = li + v * LPR;
+          float4 o = f4_add(f4_add(f4_add(hub_red[0][e], hub_red[1][e]), hub_red[2][e]), hub_red[3][e]);
+          if (self_coef != 0.0f) o = f4_fma(self_coef, *reinterpret_cast<const float4*>(sb + lo[v]), o);
+          if (bias) o = f4_add(o, *reinterpret_cast<const float4*>(bb + lo[v]));
+          *reinterpret_cast<float4*>(ob + lo[v]) = o;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  int i = i0 + wx;
+  if (i >= i1) return;
 
   // Descriptors are wave-uniform: ONE lane fetches them (a 64-lane load of one address would still occupy the
   // texture addresser like a full gather) and they are kept in SGPRs, so the trip structure and the
@@ -266,9 +342,10 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
                                                            float* __restrict__ y, int64_t ldy,
                                                            const float* __restrict__ bias, float self_coef,
                                                            const float* __restrict__ xs,
-                                                           float* __restrict__ scratch, int32_t d4, int32_t nnz) {
+                                                           float* __restrict__ scratch, int32_t d4, int32_t nnz,
+                                                           const int4* __restrict__ hubs, int32_t n_hubs) {
   spmm_persist_body<LPR, VPL, U, EXACT, ADDR32>(items, n_items, xcd_bounds, col, val, x, ldx, y, ldy, bias, self_coef, xs,
-                                                scratch, d4, nnz);
+                                                scratch, d4, nnz, hubs, n_hubs);
 }
 
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int4* __restrict__ split, int32_t n_split,
@@ -407,28 +484,17 @@ extern "C" int gd_rgcn_mean_f32(const int32_t* rowptr, const int32_t* col, const
                                (hipStream_t)stream);
 }
 
-extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
-                                        const int32_t* col, const float* val, const float* x, int64_t ldx, float* y,
-                                        int64_t ldy, const float* bias, float self_coef, const float* x_self,
-                                        float* scratch, int32_t d, int32_t nnz, int32_t x_rows,
-                                        const int32_t* xcd_bounds, void* stream) {
-  using namespace gd;
-  GD_REQUIRE(items && col && x && y, GD_E_NULL, "gd_spmm_csr_balanced_f32: null pointer");
-  GD_REQUIRE(n_split == 0 || (split && scratch), GD_E_NULL, "gd_spmm_csr_balanced_f32: split rows need scratch");
-  GD_REQUIRE(n_items >= 0 && n_split >= 0 && d > 0 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldy % 4 == 0, GD_E_DIM,
-             "gd_spmm_csr_balanced_f32: d=%d must be a multiple of 4 (<=1024) with 16-byte row strides", d);
-  GD_REQUIRE(aligned16(x) && aligned16(y) && aligned16(items) && (!bias || aligned16(bias)) &&
-                 (!scratch || aligned16(scratch)) && (!split || aligned16(split)), GD_E_ALIGN,
-             "gd_spmm_csr_balanced_f32: unaligned pointer");
-  GD_REQUIRE(x != y, GD_E_DIM, "gd_spmm_csr_balanced_f32: x and y must not alias");
-  if (n_items == 0) return GD_OK;
-  hipStream_t s = (hipStream_t)stream;
+namespace gd {
+// shared launch of the persistent kernel: legacy form (pieces -> scratch, fix-up by the caller) when hubs == nullptr
+static int launch_persist(const int32_t* items, int32_t n_items, const int32_t* hubs, int32_t n_hubs, const int32_t* col,
+                          const float* val, const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias,
+                          float self_coef, const float* xs, float* scratch, int32_t d, int32_t nnz, int32_t x_rows,
+                          const int32_t* xcd_bounds, hipStream_t s) {
   const int d4 = d / 4;
-  const float* xs = x_self ? x_self : x;            // rows of the self / residual term (same pitch as x)
-  GD_REQUIRE(aligned16(xs) && xs != y, GD_E_ALIGN, "gd_spmm_csr_balanced_f32: bad x_self");
   // grid: a few visits per wave (4 x the resident set of 256 CUs x 8 blocks measured best), a
   // multiple of the 8 XCDs
   int nblk = (n_items + 3) / 4;
+  if (nblk < n_hubs) nblk = n_hubs;
   static const int cap = [] {                                       // tuning knob (blocks), read once per process
     const char* e = getenv("GD_SPMM_GRID_CAP");
     const int v = e ? atoi(e) : 0;
@@ -438,13 +504,14 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   nblk = (nblk + 7) / 8 * 8;
   const dim3 grid(nblk), block(256);
   const int4* it = reinterpret_cast<const int4*>(items);
+  const int4* hb = reinterpret_cast<const int4*>(hubs);
   // 24-bit fast addressing needs: row ids < 2^24, row pitches in bytes < 2^24, x and y smaller than 4 GiB
   const bool addr32 = x_rows > 0 && x_rows <= (1 << 24) && ldx * 4 < (1 << 24) && ldy * 4 < (1 << 24) &&
                       (int64_t)x_rows * ldx * 4 < (1ll << 32) && (int64_t)x_rows * ldy * 4 < (1ll << 32);
 #define GD_ITEMS_LAUNCH(LPR, VPL, EXACT, A32)                                                                        \
   hipLaunchKernelGGL((spmm_persist_kernel<LPR, VPL, ((64 / (64 / LPR)) >= 4 ? 4 : (64 / (64 / LPR))), EXACT, A32>), \
                      grid, block, 0, s, it, n_items, xcd_bounds, col, val, x, ldx, y, ldy, bias, self_coef, xs, scratch, \
-                     d4, nnz)
+                     d4, nnz, hb, n_hubs)
 #define GD_ITEMS_CASE(LPR, VPL)                                                                                    \
   do {                                                                                                             \
     if (d4 == LPR * VPL) {                                                                                         \
@@ -466,9 +533,51 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   else GD_ITEMS_CASE(64, 4);
 #undef GD_ITEMS_CASE
 #undef GD_ITEMS_LAUNCH
-  int rc = launched("spmm_persist");
+  return launched("spmm_persist");
+}
+}  // namespace gd
+
+extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
+                                        const int32_t* col, const float* val, const float* x, int64_t ldx, float* y,
+                                        int64_t ldy, const float* bias, float self_coef, const float* x_self,
+                                        float* scratch, int32_t d, int32_t nnz, int32_t x_rows,
+                                        const int32_t* xcd_bounds, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(items && col && x && y, GD_E_NULL, "gd_spmm_csr_balanced_f32: null pointer");
+  GD_REQUIRE(n_split == 0 || (split && scratch), GD_E_NULL, "gd_spmm_csr_balanced_f32: split rows need scratch");
+  GD_REQUIRE(n_items >= 0 && n_split >= 0 && d > 0 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldy % 4 == 0, GD_E_DIM,
+             "gd_spmm_csr_balanced_f32: d=%d must be a multiple of 4 (<=1024) with 16-byte row strides", d);
+  GD_REQUIRE(aligned16(x) && aligned16(y) && aligned16(items) && (!bias || aligned16(bias)) &&
+                 (!scratch || aligned16(scratch)) && (!split || aligned16(split)), GD_E_ALIGN,
+             "gd_spmm_csr_balanced_f32: unaligned pointer");
+  GD_REQUIRE(x != y, GD_E_DIM, "gd_spmm_csr_balanced_f32: x and y must not alias");
+  if (n_items == 0) return GD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int d4 = d / 4;
+  const float* xs = x_self ? x_self : x;            // rows of the self / residual term (same pitch as x)
+  GD_REQUIRE(aligned16(xs) && xs != y, GD_E_ALIGN, "gd_spmm_csr_balanced_f32: bad x_self");
+  int rc = launch_persist(items, n_items, nullptr, 0, col, val, x, ldx, y, ldy, bias, self_coef, xs, scratch, d, nnz, x_rows,
+                          xcd_bounds, s);
   if (rc || n_split == 0) return rc;
-  hipLaunchKernelGGL(spmm_fixup_kernel, dim3((n_split + 3) / 4), block, 0, s, reinterpret_cast<const int4*>(split),
+  hipLaunchKernelGGL(spmm_fixup_kernel, dim3((n_split + 3) / 4), dim3(256), 0, s, reinterpret_cast<const int4*>(split),
                      n_split, scratch, xs, ldx, y, ldy, bias, self_coef, d4);
   return launched("spmm_fixup");
+}
+
+extern "C" int gd_spmm_csr_onepass_f32(const int32_t* items, int32_t n_items, const int32_t* hubs, int32_t n_hubs,
+                                       const int32_t* col, const float* val, const float* x, int64_t ldx, float* y,
+                                       int64_t ldy, const float* bias, float self_coef, const float* x_self, int32_t d,
+                                       int32_t nnz, int32_t x_rows, const int32_t* xcd_bounds, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(col && x && y && (items || n_items == 0) && (hubs || n_hubs == 0), GD_E_NULL, "gd_spmm_csr_onepass_f32: null pointer");
+  GD_REQUIRE(n_items >= 0 && n_hubs >= 0 && d > 0 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldy % 4 == 0, GD_E_DIM,
+             "gd_spmm_csr_onepass_f32: d=%d must be a multiple of 4 (<=1024) with 16-byte row strides", d);
+  GD_REQUIRE(aligned16(x) && aligned16(y) && aligned16(items) && aligned16(hubs) && (!bias || aligned16(bias)), GD_E_ALIGN,
+             "gd_spmm_csr_onepass_f32: unaligned pointer");
+  GD_REQUIRE(x != y, GD_E_DIM, "gd_spmm_csr_onepass_f32: x and y must not alias");
+  if (n_items == 0 && n_hubs == 0) return GD_OK;
+  const float* xs = x_self ? x_self : x;
+  GD_REQUIRE(aligned16(xs) && xs != y, GD_E_ALIGN, "gd_spmm_csr_onepass_f32: bad x_self");
+  return launch_persist(items, n_items, hubs, n_hubs, col, val, x, ldx, y, ldy, bias, self_coef, xs, nullptr, d, nnz, x_rows,
+                        xcd_bounds, (hipStream_t)stream);
 }

@@ -277,6 +277,12 @@ class NodeembEngine:
         self.steps_done = 0
         self._graph = None
         self._use_graph = use_graph
+        # The split-K reductions (+ Adam) and the loss finalize are launch-sized and nothing later in the iteration reads
+        # what they write (the Del weights are next read by the NEXT iteration's Del operators): they run on a side
+        # stream, forked behind the kernel that feeds them and joined at the end of the iteration - inside a hipGraph
+        # that is a branch next to the main chain instead of three 5-10 us links (+ their launch gaps) in it.
+        self._overlap = os.environ.get('GD_NO_SIDE_STREAM') != '1'
+        self._side = torch.cuda.Stream(device=dev) if self._overlap else None
         # layer-1 loss folded into the W_D1 weight-gradient fetch (see _wgrad1): needs the folded loss form on
         # both layers, MFMA-able widths, a loss type whose layer-1 gradient feeds W_D1, every loss row inside S1
         self._fuse_loss1 = False
@@ -577,6 +583,14 @@ class NodeembEngine:
         """out (+)= a^T (g + g_add) over the selected rows; with `adam` the optimizer update of that Del
         weight is applied inside the split-K reduction (one launch less)."""
         d_a, d_b = a_compact.shape[1], g.shape[1]
+        if adam is not None and self._overlap:
+            adam.applied += 1
+            check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(a_compact), a_compact.stride(0), ptr(a_idx), ptr(g), g.stride(0),
+                                                    ptr(g_idx), None, ptr(g_add), n_sel, d_a, d_b, None,
+                                                    int(accumulate), ptr(ws), stream_ptr(g.device)),
+                  'gd_rows_gemm_wgrad_f32')
+            self._reduce_on_side(ws, n_sel, d_a, d_b, out, accumulate, adam)
+            return
         if adam is not None:
             adam.applied += 1
             check(_lib.lib().gd_rows_gemm_wgrad_adam_f32(
@@ -590,6 +604,18 @@ class NodeembEngine:
                                                 int(accumulate), ptr(ws), stream_ptr(g.device)),
               'gd_rows_gemm_wgrad_f32')
 
+    def _fork(self):
+        """Context: launches inside go to the side stream, ordered after everything enqueued on the current one."""
+        self._side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self._side)
+
+    def _reduce_on_side(self, ws, n_sel, d_a, d_b, out, accumulate, adam):
+        with self._fork():
+            check(_lib.lib().gd_rows_gemm_wgrad_reduce_f32(
+                ptr(ws), n_sel, d_a, d_b, ptr(out), int(accumulate), ptr(adam.param), ptr(adam.m), ptr(adam.v),
+                ptr(adam.iter_ctr), adam.lr, adam.betas[0], adam.betas[1], adam.eps, stream_ptr(out.device)),
+                'gd_rows_gemm_wgrad_reduce_f32')
+
     # ------------------------------------------------------------------ one iteration
     def _wgrad1(self, accumulate, g_add):
         """g1 (+)= xs1^T (dz1 + g_add) followed by Adam on W_D1.  With the fused form dz1 = coef (z1 - tbar)
@@ -602,12 +628,16 @@ class NodeembEngine:
             return
         a = self.adam1
         a.applied += 1
+        ov = self._overlap
         check(_lib.lib().gd_rows_gemm_wgrad_loss_f32(
             ptr(a1), a1.stride(0), ptr(a1_idx), ptr(self.z1), self.z1.stride(0), ptr(self.idx1),
             ptr(self._slot1), ptr(self.t1.tm), ptr(self.t1.coef), ptr(self._cnt_signed1), ptr(g_add), self.s1, self.h,
-            self.h, ptr(self.g1), int(accumulate), ptr(self.ws1), ptr(self._lp1), ptr(a.param), ptr(a.m), ptr(a.v),
+            self.h, None if ov else ptr(self.g1), int(accumulate), ptr(self.ws1), ptr(self._lp1),
+            None if ov else ptr(a.param), ptr(a.m), ptr(a.v),
             ptr(a.iter_ctr), a.lr, a.betas[0], a.betas[1], a.eps, stream_ptr(self.x.device)),
             'gd_rows_gemm_wgrad_loss_f32')
+        if ov:
+            self._reduce_on_side(self.ws1, self.s1, self.h, self.h, self.g1, accumulate, a)
 
     def _iteration(self):
         """One training iteration, a single dependent chain of launches (every kernel here fills the chip on
@@ -674,11 +704,19 @@ class NodeembEngine:
             # ---- loss sums -> history ring, advance the iteration counter (Adam's step number)
             p1, n1 = (self._lp1, self._lp1_blocks) if self._fuse_loss1 else (self.t1.partials, self.t1.n_partial_blocks())
             p2, n2 = (self._lp2, self._lp2_blocks) if self._fuse_l2 else (self.t2.partials, self.t2.n_partial_blocks())
-            check(_lib.lib().gd_loss_finalize_f32(
-                ptr(p1) if fused_fin else None, n1 if fused_fin else 0,
-                ptr(p2) if fused_fin else None, n2 if fused_fin else 0,
-                None if fused_fin else ptr(self.sums), ptr(self.hist), self.hist.shape[0], ptr(self.hist_pos),
-                ptr(self.iter_ctr), stream_ptr(self.x.device)), 'gd_loss_finalize_f32')
+
+            def finalize():
+                check(_lib.lib().gd_loss_finalize_f32(
+                    ptr(p1) if fused_fin else None, n1 if fused_fin else 0,
+                    ptr(p2) if fused_fin else None, n2 if fused_fin else 0,
+                    None if fused_fin else ptr(self.sums), ptr(self.hist), self.hist.shape[0], ptr(self.hist_pos),
+                    ptr(self.iter_ctr), stream_ptr(self.x.device)), 'gd_loss_finalize_f32')
+            if self._overlap:
+                with self._fork():
+                    finalize()
+                torch.cuda.current_stream().wait_stream(self._side)       # join: the iteration ends when both branches have
+            else:
+                finalize()
 
     def _layer2_backward(self, to_w1=True, g2_accumulate=False):
         """g2 (+)= dW_D2; with to_w1 also dh[S1] = d loss2 / d z1[S1] (ReLU-gated)."""

@@ -56,8 +56,20 @@ class SplitPlan:
         self._scratch = {}
         self._edges_per_item = (end - start)
         self._bounds = {}
+        # one-launch form (gd_spmm_csr_onepass_f32): the rows of at most `chunk` in-edges as wave items, the heavier
+        # (hub) rows as block items {row, start, end, 0} - no scratch rows, no fix-up launch
+        whole = pieces <= 1
+        w_ids = whole.nonzero().flatten()
+        self.items_whole = torch.stack([ids[w_ids], r_start[w_ids], r_end[w_ids], torch.full_like(w_ids, -1)],
+                                       1).to(torch.int32).contiguous()
+        self.n_whole = int(w_ids.numel())
+        self.hubs = torch.stack([ids[srows], r_start[srows], r_end[srows], torch.zeros_like(srows)],
+                                1).to(torch.int32).contiguous()
+        self._row_deg, self._row_pieces, self._whole_pos, self._hub_pos = deg, pieces, w_ids, srows
+        self._bounds1 = {}
         for d in (64, 128):          # the path's widths, ahead of any hipGraph capture (the tables are built lazily)
             self.xcd_bounds(d)
+            self.xcd_bounds_onepass(d)
 
     def xcd_bounds(self, d):
         """Item range of each of the 8 XCDs for a width-d SpMM (int32 [9] on the device, None for small plans),
@@ -76,6 +88,26 @@ class SplitPlan:
             cuts = torch.searchsorted(cost, cost[-1] * torch.arange(1, 8, device=dev, dtype=torch.float64) / 8)
             b = torch.cat([cuts.new_zeros(1), cuts, cuts.new_full((1,), self.n_items)]).to(torch.int32).contiguous()
             self._bounds[a] = b
+        return b
+
+    def xcd_bounds_onepass(self, d):
+        """int32 [18] for gd_spmm_csr_onepass_f32 (None for small plans): the plan's rows are cut into eight contiguous
+        ranges of equal cost (in-edges + the per-visit overhead of xcd_bounds, once per 64-edge piece); [0..8] = the range
+        limits as indices into items_whole, [9..17] as indices into hubs - an XCD sums the hub rows of the same row range
+        whose light rows it sweeps."""
+        if self.n_items < 8 * 1024:
+            return None
+        a = int(min(48, max(8, 1536 // max(int(d), 1))))
+        b = self._bounds1.get(a)
+        if b is None:
+            cost = torch.cumsum((self._row_deg + a * self._row_pieces).double(), 0)
+            dev = cost.device
+            cuts = torch.searchsorted(cost, cost[-1] * torch.arange(1, 8, device=dev, dtype=torch.float64) / 8)   # row positions
+            wb = torch.searchsorted(self._whole_pos, cuts)
+            hb = torch.searchsorted(self._hub_pos, cuts)
+            b = torch.cat([wb.new_zeros(1), wb, wb.new_full((1,), self.n_whole),
+                           hb.new_zeros(1), hb, hb.new_full((1,), self.n_split)]).to(torch.int32).contiguous()
+            self._bounds1[a] = b
         return b
 
     def scratch_flat(self, tag, n_floats, device):

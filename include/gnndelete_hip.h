@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 3   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split */
+#define GD_ABI_VERSION 4   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
+                              4: gd_spmm_csr_onepass_f32, gd_rows_gemm_wgrad_reduce_f32 (dw = NULL in the wgrad entries) */
 
 enum {
   GD_OK = 0,
@@ -129,6 +130,21 @@ int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_
                              float* y, int64_t ldy, const float* bias, float self_coef,
                              const float* x_self, float* scratch, int32_t d, int32_t nnz, int32_t x_rows,
                              const int32_t* xcd_bounds, void* stream);
+
+/* One-launch form of gd_spmm_csr_balanced_f32 (same arithmetic, same call sites): no scratch rows, no fix-up kernel.
+ *   items [n_items, 4] = {row, start, end, -1}: the rows of at most 64 in-edges, one wave each (ascending rows);
+ *   hubs  [n_hubs, 4]  = {row, start, end, 0}: the rows above 64 in-edges.  A hub row is summed by ONE block: its four
+ *   waves take the row's 64-edge pieces round robin (one accumulator per wave), the four partial rows are added in
+ *   LDS in wave order and written once - deterministic, no atomics.  The hub rows run first, then the block's waves
+ *   sweep the items as in the balanced form.
+ *   xcd_bounds (optional, 18 ints): [0..8] ascending item indices, [9..17] ascending hub indices - XCD k sweeps the items
+ *   [b[k], b[k+1]) and the hubs [b[9+k], b[10+k]); NULL = equal eighths of both lists.  A placement hint only.
+ * The sum of a hub row is associated differently from the balanced form's (piece partials in slot order), so the two
+ * entries agree to fp32 rounding, not bit for bit; each is bit-reproducible run to run. */
+int gd_spmm_csr_onepass_f32(const int32_t* items, int32_t n_items, const int32_t* hubs, int32_t n_hubs,
+                            const int32_t* col, const float* val, const float* x, int64_t ldx,
+                            float* y, int64_t ldy, const float* bias, float self_coef, const float* x_self,
+                            int32_t d, int32_t nnz, int32_t x_rows, const int32_t* xcd_bounds, void* stream);
 
 /* Per-relation mean aggregation of R-GCN ("typed SpMM") over a relation-major CSR:
  *   rowptr[(r*n_rows + i) .. +1] delimit the in-edges of type r into node i;
@@ -342,6 +358,9 @@ int gd_rows_gemm_gated_rank1_f32(const float* in, int64_t ld_in, const int32_t* 
  *   g_add (optional, same indexing and ld as g): a second upstream gradient added row by row
  *   after the mask, dW = a^T (mask(g) + g_add) - one pass over `a` for a weight that receives
  *   gradient from two losses (both_all / both_layerwise, gnndelete_nodeemb.py:215-262).
+ *   dw = NULL (this entry and gd_rows_gemm_wgrad_loss_f32 with param = NULL): only the per-block partial products are
+ *   written; gd_rows_gemm_wgrad_reduce_f32 adds them up later - on another stream if the caller orders it after this
+ *   one - so that the launch-sized reduction leaves the step's critical path.
  * Replaces autograd's matmul backward for deletion_weight. */
 int64_t gd_rows_gemm_wgrad_workspace(int32_t n_sel, int32_t d_a, int32_t d_b);
 int gd_rows_gemm_wgrad_f32(const float* a, int64_t ld_a, const int32_t* a_idx,
@@ -358,6 +377,13 @@ int gd_rows_gemm_wgrad_adam_f32(const float* a, int64_t ld_a, const int32_t* a_i
                                 int32_t d_b, float* dw, int32_t accumulate, float* partials,
                                 float* param, float* exp_avg, float* exp_avg_sq, const int32_t* iter,
                                 double lr, double beta1, double beta2, double eps, void* stream);
+
+/* The second half of the weight gradient on its own: dW (+)= sum of the gd_rows_gemm_wgrad_blocks(n_sel) partial
+ * products a wgrad entry left in `partials` (called with dw = NULL, same n_sel / d_a / d_b), added in block order
+ * (deterministic); param != NULL applies torch.optim.Adam with the reduced gradient in the same launch (t = *iter + 1). */
+int gd_rows_gemm_wgrad_reduce_f32(const float* partials, int32_t n_sel, int32_t d_a, int32_t d_b, float* dw,
+                                  int32_t accumulate, float* param, float* exp_avg, float* exp_avg_sq,
+                                  const int32_t* iter, double lr, double beta1, double beta2, double eps, void* stream);
 
 /* Weight gradient whose upstream gradient is FORMED while it is fetched, from the folded DEC + NI
  * row-target terms of that layer (see gd_rowtarget_mse_f32): for selected row s with loss slot

@@ -440,6 +440,53 @@ def test_balanced_spmm_splits_hub_rows_and_matches_plain_kernel(d):
     assert rel_l2(yt.cpu(), want_t) < TOL
 
 
+@pytest.mark.parametrize('d,self_coef', [(128, 0.0), (64, 1.0), (32, 0.5), (8, 0.0), (260, 0.0)])
+def test_onepass_spmm_sums_hub_rows_inside_the_launch(d, self_coef, monkeypatch):
+    """gd_spmm_csr_onepass_f32: hub rows (65 ... 5,000 in-edges) summed by whole blocks in the same launch that sweeps
+    the light rows, with XCD range tables (>= 8 k items), on the full plan and on a row-subset plan; against the fp64
+    dense product and against the two-launch form (pieces + fix-up), which associates a hub row's sum differently."""
+    from gnndelete_amd import ops
+    from gnndelete_amd.graph import SplitPlan, build_csr
+    n = 12000
+    g = torch.Generator().manual_seed(d)
+    hubs = [(0, 5000), (7, 65), (11, 128), (12, 129), (4000, 257), (11999, 1000), (6000, 64)]
+    star = [torch.stack([torch.randint(0, n, (k,), generator=g), torch.full((k,), h)]) for h, k in hubs]
+    ei = torch.cat([random_graph(n, 40000, seed=d)] + star, 1)
+    x = torch.randn(n, d, generator=g)
+    b = torch.randn(d, generator=g)
+    gr = build_csr(ei.cuda(), n, 'sum')
+    assert gr.plan.n_split >= 6 and gr.plan.xcd_bounds_onepass(d) is not None and gr.plan.n_whole + gr.plan.n_split == n
+    a = dense_adj(ei, n)
+    want = a @ x.double() + self_coef * x.double() + b.double()
+    xc, bc = x.cuda(), b.cuda()
+    y = ops._spmm_raw(gr.rowptr, gr.col, None, xc, bc, self_coef, n, gr.plan)
+    assert rel_l2(y.cpu(), want) < TOL
+    assert torch.equal(y, ops._spmm_raw(gr.rowptr, gr.col, None, xc, bc, self_coef, n, gr.plan))     # bit-reproducible
+    monkeypatch.setenv('GD_SPMM_TWO_LAUNCH', '1')
+    y2 = ops._spmm_raw(gr.rowptr, gr.col, None, xc, bc, self_coef, n, gr.plan)
+    monkeypatch.delenv('GD_SPMM_TWO_LAUNCH')
+    assert rel_l2(y.cpu(), y2.cpu()) < 1e-6
+    light = (gr.rowptr[1:] - gr.rowptr[:-1]) <= 64
+    assert int((~light).sum()) == gr.plan.n_split
+    assert torch.equal(y[light], y2[light])                         # rows of <= 64 in-edges: the same sum, bit for bit
+    # a row subset (the rows a request can influence): only those rows are written
+    rows = torch.cat([torch.tensor([0, 7, 12, 11999]), torch.randperm(n, generator=g)[:9000]]).unique().cuda()
+    plan = SplitPlan(gr.rowptr, rows=rows)
+    out = torch.full((n, d), 7.0, device='cuda')
+    ops._spmm_raw(gr.rowptr, gr.col, None, xc, bc, self_coef, n, plan, out=out)
+    assert torch.equal(out[rows], y[rows])
+    rest = torch.ones(n, dtype=torch.bool, device='cuda')
+    rest[rows] = False
+    assert bool((out[rest] == 7.0).all())
+    # transposed graph with values
+    val_t = torch.rand(gr.col_t.shape[0], generator=g).cuda()
+    yt = ops._spmm_raw(gr.rowptr_t, gr.col_t, val_t, xc, None, 0.0, n, gr.plan_t)
+    at = torch.zeros(n, n, dtype=torch.float64)
+    rt = torch.repeat_interleave(torch.arange(n), (gr.rowptr_t[1:] - gr.rowptr_t[:-1]).long().cpu())
+    at.index_put_((rt, gr.col_t.long().cpu()), val_t.double().cpu(), accumulate=True)
+    assert rel_l2(yt.cpu(), at @ x.double()) < TOL
+
+
 @pytest.mark.parametrize('d', [128, 64, 16, 260])
 def test_rowtarget_mse_matches_direct_formula(d):
     from gnndelete_amd import _lib
