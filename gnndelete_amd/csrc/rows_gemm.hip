@@ -70,15 +70,22 @@ struct RowDots { const float* u1; const float* u2; float* o1; float* o2; };
 // NP: 0 = products on v_mfma_f32_32x32x2_f32; 6 / 9 = split arithmetic on the bf16 matrix instruction (above)
 // KC (split form only): d_in / 32 as a compile-time constant - the wave keeps whole half rows in registers (wide outputs);
 // KC = 0 with NP != 0: split products inside the chunk-wise loop of the fp32 form (narrow outputs: 4 waves per SIMD)
-template <int NT, int MODE, bool SEL = false, int NP = 0, int KC = 0>
-__global__ __launch_bounds__(kGemmThreads, (NP && KC) ? 2 : 4) void rows_gemm_mfma_kernel(
+// QUEUE (fp32 form only): ONE block of 16 waves per CU shares the weight image and hands the tiles of the block's
+// contiguous tile range out through an LDS counter.  The matrix pipe of a SIMD serves its resident waves oldest
+// first (per-wave time stamps: four waves with identical static work finish at 109 / 136 / 156 / 166 us), so with a
+// static tile-to-wave map the kernel lasts as long as its slowest wave; with the counter the waves that run ahead take
+// more tiles and all end together (split_lab: 60.0 vs 61.8 us at the Del-1 size, 77.8 vs 80.4 us at N rows).
+template <int NT, int MODE, bool SEL = false, int NP = 0, int KC = 0, bool QUEUE = false>
+__global__ __launch_bounds__(QUEUE ? 1024 : kGemmThreads, (NP && KC) ? 2 : 4) void rows_gemm_mfma_kernel(
     const float* in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel,
     const float* __restrict__ w, int32_t d_in, int32_t trans_w, const float* __restrict__ bias, int32_t relu_in,
     float* out, int64_t ld_out, float* __restrict__ save_in, const uint32_t* __restrict__ gate_bits,
     uint32_t* __restrict__ sign_out, const float* in_alt, const uint8_t* __restrict__ sel, RowDots dots) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   constexpr int d_out = 32 * NT;
+  constexpr int kGemmThreads = QUEUE ? 1024 : gd::kGemmThreads;       // (shadows the namespace constant in here)
   constexpr int kWaves = kGemmThreads / 64;
+  static_assert(!QUEUE || (NP == 0 && KC == 0), "the tile queue is built for the fp32 form");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -274,17 +281,33 @@ __global__ __launch_bounds__(kGemmThreads, (NP && KC) ? 2 : 4) void rows_gemm_mf
     return;
   }
 
-  int tile = blockIdx.x * kWaves + wave;
+  // tile hand-out: static (tile = block * waves + wave, + stride) or, with QUEUE, tickets from the block's LDS counter
+  // over its contiguous range [t_lo, t_hi) - a ticket past the range ends the wave (n_tiles = "none")
+  __shared__ int q_next;
+  const int per_block = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_lo = blockIdx.x * per_block, t_hi = min(n_tiles, t_lo + per_block);
+  if (QUEUE) {
+    if (tid == 0) q_next = 0;
+    __syncthreads();
+  }
+  auto grab = [&]() -> int {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(&q_next, 1);
+    t = __builtin_amdgcn_readfirstlane(t) + t_lo;
+    return t < t_hi ? t : n_tiles;
+  };
+  int tile = QUEUE ? grab() : blockIdx.x * kWaves + wave;
   if (tile >= n_tiles) return;
+  int tile_nxt = QUEUE ? grab() : tile + stride;
   int32_t row_cur = row_of(tile);
-  int32_t row_nxt = row_of(min(tile + stride, n_tiles - 1));
+  int32_t row_nxt = row_of(min(tile_nxt, n_tiles - 1));
   float4 a_next[4];
   {
     const float4* src0 = reinterpret_cast<const float4*>(base_of(row_cur) + (int64_t)row_cur * ld_in) + khalf * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) a_next[i] = src0[i];
   }
-  for (; tile < n_tiles; tile += stride) {
+  for (; tile < n_tiles;) {
     const int s_a = tile * 32 + r_lo;
     const bool live = s_a < n_sel;
     const float4* src = reinterpret_cast<const float4*>(base_of(row_cur) + (int64_t)row_cur * ld_in) + khalf * 4;
@@ -375,8 +398,10 @@ __global__ __launch_bounds__(kGemmThreads, (NP && KC) ? 2 : 4) void rows_gemm_mf
 
     epilogue(acc, row_cur, s_a, live, gate_w, r1a, r1b);
     row_cur = row_nxt;
+    tile = tile_nxt;
+    tile_nxt = QUEUE ? (tile < n_tiles ? grab() : n_tiles) : tile + stride;
     // row index of the tile after next: its first loads are only issued at the end of the next tile
-    row_nxt = row_of(min(tile + 2 * stride, n_tiles - 1));
+    row_nxt = row_of(min(tile_nxt, n_tiles - 1));
   }
 }
 
@@ -773,8 +798,18 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
       lds = (size_t)3 * d_in * d_out * 2;                    // three bf16 images, no padding of NT = 3
       if (grid > grid_cap / 2 && lds > 80 * 1024) grid = grid_cap / 2;      // one block per CU fits
     }
+    // tile queue (one 16-wave block per CU) where a block gets enough tiles to hand out: the step's N- and S-row products
+    static const bool queue_on = [] { const char* e = getenv("GD_ROWS_GEMM_QUEUE"); return !(e && atoi(e) == 0); }();
+    const bool use_queue = queue_on && !kc_split && !narrow_split && n_tiles >= 16 * 256;
+    if (use_queue && grid > 256) grid = 256;
 #define GD_RG_KERNEL(NT, MODE, SELV, NPV, KCV)                                                                    \
   do {                                                                                                            \
+    if (use_queue && !NPV) {                                                                                      \
+      auto kq = rows_gemm_mfma_kernel<NT, MODE, SELV, 0, 0, true>;                                                \
+      hipLaunchKernelGGL(kq, dim3(grid), dim3(1024), lds, s, in, ld_in, idx, n_sel, w, d_in, trans_w,             \
+                         bias, relu_in, out, ld_out, save_in, gate_bits, sign_out, in_alt, sel, dots);            \
+      break;                                                                                                      \
+    }                                                                                                             \
     auto kern = rows_gemm_mfma_kernel<NT, MODE, SELV, NPV, KCV>;                                                  \
     if (NPV && lds > 64 * 1024) {                                                                                 \
       static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \

@@ -119,7 +119,7 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
                                                   const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
                                                   int64_t ldy, const float* __restrict__ bias, float self_coef,
                                                   const float* __restrict__ xs, float* __restrict__ scratch, int32_t d4,
-                                                  int32_t nnz, const int4* __restrict__ hubs, int32_t n_hubs) {
+                                                  int32_t nnz) {
   constexpr int G = kWave / LPR;
   constexpr int kXcd = 8;
   const int lane = threadIdx.x & 63;
@@ -138,81 +138,6 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
   const char* bb = reinterpret_cast<const char*>(bias);
   const uint32_t pitch_b = (uint32_t)ldx * 4u;
   const char* xb = reinterpret_cast<const char*>(x);
-
-  // ---- hub rows (more than 64 in-edges), one-pass form: hubs[h] = {row, start, end, -}.  The block's four waves take
-  // the row's 64-edge pieces round robin (each wave keeps ONE accumulator over its pieces), the four partial rows meet
-  // in LDS and wave 0 adds them in wave order (+ self term, + bias) and writes the row: no scratch rows, no fix-up
-  // launch, no atomics - the summation order is fixed by (row, piece, lane group), bit-reproducible.  XCD k's blocks
-  // take the hubs [xcd_bounds[9 + k], xcd_bounds[10 + k]) - the hub rows of the row range whose whole rows it sweeps.
-  if (n_hubs > 0) {
-    __shared__ float4 hub_red[4][LPR * VPL];
-    const int wave = threadIdx.x >> 6;
-    const int nbx = gridDim.x / kXcd, bx = blockIdx.x / kXcd;
-    const int hper = (n_hubs + kXcd - 1) / kXcd;
-    const int h0 = xcd_bounds ? xcd_bounds[9 + xcd] : min(n_hubs, xcd * hper);
-    const int h1 = xcd_bounds ? xcd_bounds[10 + xcd] : min(n_hubs, h0 + hper);
-    for (int h = h0 + bx; h < h1; h += nbx) {
-      int4 hv = make_int4(0, 0, 0, 0);
-      if (lane == 0) hv = hubs[h];
-      const int row = __builtin_amdgcn_readfirstlane(hv.x), start = __builtin_amdgcn_readfirstlane(hv.y),
-                end = __builtin_amdgcn_readfirstlane(hv.z);
-      float4 acc[VPL];
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
-      for (int base = start + wave * kWave; base < end; base += 4 * kWave) {
-        const int cnt = min(kWave, end - base);
-        const int kk = min(base + lane, nnz - 1);
-        const int c_cur = col[kk];
-        const float w_cur = lane < cnt ? (val ? val[kk] : 1.0f) : 0.f;
-        const int trips = (cnt + G - 1) / G;
-        const int last4 = 4 * cnt - 4, end4 = 4 * cnt;
-        for (int t0 = 0; t0 < trips; t0 += U) {
-          float4 xv[U][VPL];
-          float wj[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {       // trips past the end re-read the last neighbour with weight 0 (lane `cnt`)
-            const int j4 = 4 * ((t0 + u) * G) + 4 * g;
-            const int cs = __builtin_amdgcn_ds_bpermute(min(j4, last4), c_cur);
-            wj[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(min(j4, end4), __float_as_int(w_cur)));
-            if (ADDR32) {
-              const uint32_t ro = __umul24((uint32_t)cs, pitch_b);
-#pragma unroll
-              for (int v = 0; v < VPL; ++v) xv[u][v] = *reinterpret_cast<const float4*>(xb + (ro + lo[v]));
-            } else {
-              const char* xr = reinterpret_cast<const char*>(x + (int64_t)cs * ldx);
-#pragma unroll
-              for (int v = 0; v < VPL; ++v) xv[u][v] = *reinterpret_cast<const float4*>(xr + lo[v]);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
-        }
-      }
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) acc[v] = f4_group_sum<LPR>(acc[v]);
-      if (g == 0) {
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) hub_red[wave][li + v * LPR] = acc[v];
-      }
-      __syncthreads();
-      if (wave == 0 && g == 0) {
-        char* ob = reinterpret_cast<char*>(y + (int64_t)row * ldy);
-        const char* sb = reinterpret_cast<const char*>(xs + (int64_t)row * ldx);
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          if (!EXACT && li + v * LPR >= d4) continue;
-          const int e = li + v * LPR;
-          float4 o = f4_add(f4_add(f4_add(hub_red[0][e], hub_red[1][e]), hub_red[2][e]), hub_red[3][e]);
-          if (self_coef != 0.0f) o = f4_fma(self_coef, *reinterpret_cast<const float4*>(sb + lo[v]), o);
-          if (bias) o = f4_add(o, *reinterpret_cast<const float4*>(bb + lo[v]));
-          *reinterpret_cast<float4*>(ob + lo[v]) = o;
-        }
-      }
-      __syncthreads();
-    }
-  }
 
   int i = i0 + wx;
   if (i >= i1) return;
@@ -238,18 +163,26 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
   int kk = min(d0.start + lane, nnz - 1);
   int c = col[kk];
   float w = val ? val[kk] : 1.0f;
+  // One-launch form (gd_spmm_csr_onepass_f32): slot == -2 marks a GROUP member - the four waves of a block visit four
+  // consecutive, 4-aligned items at the same time, and a hub row (more than 64 in-edges) is laid out as such a
+  // quadruple, member w = wave w's own contiguous share [start, end) of the row's edges (walked 64 at a time: the
+  // first chunk rides the sweep's prefetch pipeline like any item, further chunks - rows above 256 in-edges - are
+  // fetched in place).  The four partial rows meet in LDS and wave 0 adds them in wave order (+ self term + bias) and
+  // writes the row: no scratch rows, no fix-up launch, no atomics, a fixed summation order.  row < 0 = padding.
+  __shared__ float4 grp_red[4][LPR * VPL];
   for (; i < i1; i += stride) {
-    const int row = d0.row, slot = d0.slot, cnt = d0.end - d0.start;
-    const int c_cur = c;
-    const float w_cur = lane < cnt ? w : 0.f;
+    const int row = d0.row, slot = d0.slot;
+    int base = d0.start;
+    int c_cur = c;
+    float w_raw = w;
     // prefetch (clamped, branch-free): descriptor of the visit after next, indices of the next visit
     if (lane == 0) dv = items[min(i + 2 * stride, i1 - 1)];
     kk = min(d1.start + lane, nnz - 1);
     c = col[kk];
     w = val ? val[kk] : 1.0f;
-    const bool whole = slot < 0, self = whole && self_coef != 0.0f;
+    const bool whole = slot == -1 && row >= 0, self = whole && self_coef != 0.0f;
     // the accumulators of lane group 0 start from the bias (requested with the gathers: no round trip of its
-    // own, no registers held across rows); the pieces of a split row get theirs in the fix-up
+    // own, no registers held across rows); the pieces of a split row get theirs in the fix-up / group sum
     float4 acc[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
@@ -266,6 +199,9 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
 #pragma unroll
       for (int v = 0; v < VPL; ++v) acc[v] = *reinterpret_cast<const float4*>(sb0 + lo[v]);
     }
+    for (;;) {       // 64-edge chunks of the item: one, except for the members of a hub row above 256 in-edges
+    const int cnt = min(kWave, d0.end - base);
+    const float w_cur = lane < cnt ? w_raw : 0.f;
     const int trips = (cnt + G - 1) / G;
     // Slot j of the item (j = trip * G + g) is fetched from lane j of (c_cur, w_cur) through the LDS
     // crossbar (byte-addressed ds_bpermute, everything kept pre-multiplied by 4).  A wave64 x 16-byte load
@@ -314,9 +250,36 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
           }
       }
     }
+    base += kWave;
+    if (base >= d0.end) break;
+    const int k2 = min(base + lane, nnz - 1);
+    c_cur = col[k2];
+    w_raw = val ? val[k2] : 1.0f;
+    }
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_group_sum<LPR>(acc[v]);
-    if (g == 0) {
+    if (slot == -2) {          // group member (block-uniform: the planner aligns the quadruples and the XCD ranges to 4)
+      const int wave = threadIdx.x >> 6;
+      if (g == 0) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) grp_red[wave][li + v * LPR] = acc[v];
+      }
+      __syncthreads();
+      if (wave == 0 && g == 0) {
+        char* ob = reinterpret_cast<char*>(y + (int64_t)row * ldy);
+        const char* sb = reinterpret_cast<const char*>(xs + (int64_t)row * ldx);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          if (!EXACT && li + v * LPR >= d4) continue;
+          const int e = li + v * LPR;
+          float4 o = f4_add(f4_add(f4_add(grp_red[0][e], grp_red[1][e]), grp_red[2][e]), grp_red[3][e]);
+          if (self_coef != 0.0f) o = f4_fma(self_coef, *reinterpret_cast<const float4*>(sb + lo[v]), o);
+          if (bias) o = f4_add(o, *reinterpret_cast<const float4*>(bb + lo[v]));
+          *reinterpret_cast<float4*>(ob + lo[v]) = o;
+        }
+      }
+      __syncthreads();
+    } else if (g == 0 && row >= 0) {
       char* ob = whole ? reinterpret_cast<char*>(y + (int64_t)row * ldy)
                        : reinterpret_cast<char*>(scratch + (int64_t)slot * d4 * 4);
       const char* sb = reinterpret_cast<const char*>(xs + (int64_t)row * ldx);
@@ -342,10 +305,9 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
                                                            float* __restrict__ y, int64_t ldy,
                                                            const float* __restrict__ bias, float self_coef,
                                                            const float* __restrict__ xs,
-                                                           float* __restrict__ scratch, int32_t d4, int32_t nnz,
-                                                           const int4* __restrict__ hubs, int32_t n_hubs) {
+                                                           float* __restrict__ scratch, int32_t d4, int32_t nnz) {
   spmm_persist_body<LPR, VPL, U, EXACT, ADDR32>(items, n_items, xcd_bounds, col, val, x, ldx, y, ldy, bias, self_coef, xs,
-                                                scratch, d4, nnz, hubs, n_hubs);
+                                                scratch, d4, nnz);
 }
 
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int4* __restrict__ split, int32_t n_split,
@@ -486,7 +448,7 @@ extern "C" int gd_rgcn_mean_f32(const int32_t* rowptr, const int32_t* col, const
 
 namespace gd {
 // shared launch of the persistent kernel: legacy form (pieces -> scratch, fix-up by the caller) when hubs == nullptr
-static int launch_persist(const int32_t* items, int32_t n_items, const int32_t* hubs, int32_t n_hubs, const int32_t* col,
+static int launch_persist(const int32_t* items, int32_t n_items, const int32_t* col,
                           const float* val, const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias,
                           float self_coef, const float* xs, float* scratch, int32_t d, int32_t nnz, int32_t x_rows,
                           const int32_t* xcd_bounds, hipStream_t s) {
@@ -494,7 +456,6 @@ static int launch_persist(const int32_t* items, int32_t n_items, const int32_t* 
   // grid: a few visits per wave (4 x the resident set of 256 CUs x 8 blocks measured best), a
   // multiple of the 8 XCDs
   int nblk = (n_items + 3) / 4;
-  if (nblk < n_hubs) nblk = n_hubs;
   static const int cap = [] {                                       // tuning knob (blocks), read once per process
     const char* e = getenv("GD_SPMM_GRID_CAP");
     const int v = e ? atoi(e) : 0;
@@ -504,14 +465,13 @@ static int launch_persist(const int32_t* items, int32_t n_items, const int32_t* 
   nblk = (nblk + 7) / 8 * 8;
   const dim3 grid(nblk), block(256);
   const int4* it = reinterpret_cast<const int4*>(items);
-  const int4* hb = reinterpret_cast<const int4*>(hubs);
   // 24-bit fast addressing needs: row ids < 2^24, row pitches in bytes < 2^24, x and y smaller than 4 GiB
   const bool addr32 = x_rows > 0 && x_rows <= (1 << 24) && ldx * 4 < (1 << 24) && ldy * 4 < (1 << 24) &&
                       (int64_t)x_rows * ldx * 4 < (1ll << 32) && (int64_t)x_rows * ldy * 4 < (1ll << 32);
 #define GD_ITEMS_LAUNCH(LPR, VPL, EXACT, A32)                                                                        \
   hipLaunchKernelGGL((spmm_persist_kernel<LPR, VPL, ((64 / (64 / LPR)) >= 4 ? 4 : (64 / (64 / LPR))), EXACT, A32>), \
                      grid, block, 0, s, it, n_items, xcd_bounds, col, val, x, ldx, y, ldy, bias, self_coef, xs, scratch, \
-                     d4, nnz, hb, n_hubs)
+                     d4, nnz)
 #define GD_ITEMS_CASE(LPR, VPL)                                                                                    \
   do {                                                                                                             \
     if (d4 == LPR * VPL) {                                                                                         \
@@ -556,7 +516,7 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   const int d4 = d / 4;
   const float* xs = x_self ? x_self : x;            // rows of the self / residual term (same pitch as x)
   GD_REQUIRE(aligned16(xs) && xs != y, GD_E_ALIGN, "gd_spmm_csr_balanced_f32: bad x_self");
-  int rc = launch_persist(items, n_items, nullptr, 0, col, val, x, ldx, y, ldy, bias, self_coef, xs, scratch, d, nnz, x_rows,
+  int rc = launch_persist(items, n_items, col, val, x, ldx, y, ldy, bias, self_coef, xs, scratch, d, nnz, x_rows,
                           xcd_bounds, s);
   if (rc || n_split == 0) return rc;
   hipLaunchKernelGGL(spmm_fixup_kernel, dim3((n_split + 3) / 4), dim3(256), 0, s, reinterpret_cast<const int4*>(split),
@@ -564,20 +524,20 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   return launched("spmm_fixup");
 }
 
-extern "C" int gd_spmm_csr_onepass_f32(const int32_t* items, int32_t n_items, const int32_t* hubs, int32_t n_hubs,
-                                       const int32_t* col, const float* val, const float* x, int64_t ldx, float* y,
-                                       int64_t ldy, const float* bias, float self_coef, const float* x_self, int32_t d,
-                                       int32_t nnz, int32_t x_rows, const int32_t* xcd_bounds, void* stream) {
+extern "C" int gd_spmm_csr_onepass_f32(const int32_t* items, int32_t n_items, const int32_t* col, const float* val,
+                                       const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias,
+                                       float self_coef, const float* x_self, int32_t d, int32_t nnz, int32_t x_rows,
+                                       const int32_t* xcd_bounds, void* stream) {
   using namespace gd;
-  GD_REQUIRE(col && x && y && (items || n_items == 0) && (hubs || n_hubs == 0), GD_E_NULL, "gd_spmm_csr_onepass_f32: null pointer");
-  GD_REQUIRE(n_items >= 0 && n_hubs >= 0 && d > 0 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldy % 4 == 0, GD_E_DIM,
-             "gd_spmm_csr_onepass_f32: d=%d must be a multiple of 4 (<=1024) with 16-byte row strides", d);
-  GD_REQUIRE(aligned16(x) && aligned16(y) && aligned16(items) && aligned16(hubs) && (!bias || aligned16(bias)), GD_E_ALIGN,
+  GD_REQUIRE(col && x && y && xcd_bounds && (items || n_items == 0), GD_E_NULL, "gd_spmm_csr_onepass_f32: null pointer");
+  GD_REQUIRE(n_items >= 0 && n_items % 4 == 0 && d > 0 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldy % 4 == 0, GD_E_DIM,
+             "gd_spmm_csr_onepass_f32: d=%d must be a multiple of 4 (<=1024) with 16-byte row strides, n_items a multiple of 4", d);
+  GD_REQUIRE(aligned16(x) && aligned16(y) && aligned16(items) && (!bias || aligned16(bias)), GD_E_ALIGN,
              "gd_spmm_csr_onepass_f32: unaligned pointer");
   GD_REQUIRE(x != y, GD_E_DIM, "gd_spmm_csr_onepass_f32: x and y must not alias");
-  if (n_items == 0 && n_hubs == 0) return GD_OK;
+  if (n_items == 0) return GD_OK;
   const float* xs = x_self ? x_self : x;
   GD_REQUIRE(aligned16(xs) && xs != y, GD_E_ALIGN, "gd_spmm_csr_onepass_f32: bad x_self");
-  return launch_persist(items, n_items, hubs, n_hubs, col, val, x, ldx, y, ldy, bias, self_coef, xs, nullptr, d, nnz, x_rows,
+  return launch_persist(items, n_items, col, val, x, ldx, y, ldy, bias, self_coef, xs, nullptr, d, nnz, x_rows,
                         xcd_bounds, (hipStream_t)stream);
 }

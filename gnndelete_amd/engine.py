@@ -277,11 +277,12 @@ class NodeembEngine:
         self.steps_done = 0
         self._graph = None
         self._use_graph = use_graph
-        # The split-K reductions (+ Adam) and the loss finalize are launch-sized and nothing later in the iteration reads
-        # what they write (the Del weights are next read by the NEXT iteration's Del operators): they run on a side
-        # stream, forked behind the kernel that feeds them and joined at the end of the iteration - inside a hipGraph
-        # that is a branch next to the main chain instead of three 5-10 us links (+ their launch gaps) in it.
-        self._overlap = os.environ.get('GD_NO_SIDE_STREAM') != '1'
+        # OPT-IN (GD_SIDE_STREAM=1), measured and NOT kept as the default: the split-K reductions (+ Adam) and the loss
+        # finalize are launch-sized and nothing later in the iteration reads what they write, so they can run on a side
+        # stream, forked behind the kernel that feeds them and joined at the end of the iteration.  On this part the
+        # cross-queue dependencies of the replayed hipGraph cost more than the three links they remove from the chain:
+        # 683 -> 715 us per step (profiles/r03_ab.txt).
+        self._overlap = os.environ.get('GD_SIDE_STREAM') == '1'
         self._side = torch.cuda.Stream(device=dev) if self._overlap else None
         # layer-1 loss folded into the W_D1 weight-gradient fetch (see _wgrad1): needs the folded loss form on
         # both layers, MFMA-able widths, a loss type whose layer-1 gradient feeds W_D1, every loss row inside S1
@@ -674,10 +675,7 @@ class NodeembEngine:
             # ---- forward layer 2 + its loss
             self._conv2_forward()
             if self._fuse_l2:
-                check(_lib.lib().gd_del_loss_bwd_f32(
-                    ptr(self.p2), self.p2.stride(0), ptr(self.idx2), self.s2, ptr(self.wd2), self.o, ptr(self._slot2),
-                    ptr(self.t2.tm), ptr(self.t2.coef), ptr(self._cnt_signed2), ptr(self.dz2c), self.dz2c.stride(0),
-                    ptr(self.dz2), self.dz2.stride(0), ptr(self._lp2), stream_ptr(self.x.device)), 'gd_del_loss_bwd_f32')
+                self._del2_fused()
             else:
                 ops.rows_gemm(self.p2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
                 self.t2.launch(self.z2, self.dz2, s2)
@@ -717,6 +715,13 @@ class NodeembEngine:
                 torch.cuda.current_stream().wait_stream(self._side)       # join: the iteration ends when both branches have
             else:
                 finalize()
+
+    def _del2_fused(self):
+        """Del-2 forward + folded layer-2 loss + Del-2 input gradient in one kernel (csrc/del_fused.hip)."""
+        check(_lib.lib().gd_del_loss_bwd_f32(
+            ptr(self.p2), self.p2.stride(0), ptr(self.idx2), self.s2, ptr(self.wd2), self.o, ptr(self._slot2),
+            ptr(self.t2.tm), ptr(self.t2.coef), ptr(self._cnt_signed2), ptr(self.dz2c), self.dz2c.stride(0),
+            ptr(self.dz2), self.dz2.stride(0), ptr(self._lp2), stream_ptr(self.x.device)), 'gd_del_loss_bwd_f32')
 
     def _layer2_backward(self, to_w1=True, g2_accumulate=False):
         """g2 (+)= dW_D2; with to_w1 also dh[S1] = d loss2 / d z1[S1] (ReLU-gated)."""
@@ -777,6 +782,10 @@ class NodeembEngine:
             with torch.cuda.graph(graph):
                 for _ in range(unroll):
                     self._iteration()
+            # the first launch of a graph exec uploads it to the device (tens of us): do it now, on state that is
+            # restored right after - a short run (the driver times 20 steps = 5 launches) should not pay it
+            graph.replay()
+            torch.cuda.synchronize()
             for t, sv in zip(self._mutable_state(), saved):
                 t.copy_(sv)
             self._graph_k = (unroll, graph)
@@ -795,8 +804,10 @@ class NodeembEngine:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self._iteration()
+        graph.replay()                             # first launch = upload of the exec; on scratch state
+        torch.cuda.synchronize()
         for t, s in zip(self._mutable_state(), saved):
-            t.copy_(s)                             # capture does not execute; undo the warm-up
+            t.copy_(s)                             # undo the warm-up iterations
         self._graph = graph
 
     def loss_history(self):

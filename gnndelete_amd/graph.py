@@ -56,20 +56,13 @@ class SplitPlan:
         self._scratch = {}
         self._edges_per_item = (end - start)
         self._bounds = {}
-        # one-launch form (gd_spmm_csr_onepass_f32): the rows of at most `chunk` in-edges as wave items, the heavier
-        # (hub) rows as block items {row, start, end, 0} - no scratch rows, no fix-up launch
-        whole = pieces <= 1
-        w_ids = whole.nonzero().flatten()
-        self.items_whole = torch.stack([ids[w_ids], r_start[w_ids], r_end[w_ids], torch.full_like(w_ids, -1)],
-                                       1).to(torch.int32).contiguous()
-        self.n_whole = int(w_ids.numel())
-        self.hubs = torch.stack([ids[srows], r_start[srows], r_end[srows], torch.zeros_like(srows)],
-                                1).to(torch.int32).contiguous()
-        self._row_deg, self._row_pieces, self._whole_pos, self._hub_pos = deg, pieces, w_ids, srows
-        self._bounds1 = {}
+        # one-launch form (gd_spmm_csr_onepass_f32), laid out per width on demand (onepass)
+        self._row_ids, self._row_start, self._row_end = ids, r_start, r_end
+        self._row_deg, self._row_pieces = deg, pieces
+        self._onepass = {}
         for d in (64, 128):          # the path's widths, ahead of any hipGraph capture (the tables are built lazily)
             self.xcd_bounds(d)
-            self.xcd_bounds_onepass(d)
+            self.onepass(d)
 
     def xcd_bounds(self, d):
         """Item range of each of the 8 XCDs for a width-d SpMM (int32 [9] on the device, None for small plans),
@@ -90,25 +83,58 @@ class SplitPlan:
             self._bounds[a] = b
         return b
 
-    def xcd_bounds_onepass(self, d):
-        """int32 [18] for gd_spmm_csr_onepass_f32 (None for small plans): the plan's rows are cut into eight contiguous
-        ranges of equal cost (in-edges + the per-visit overhead of xcd_bounds, once per 64-edge piece); [0..8] = the range
-        limits as indices into items_whole, [9..17] as indices into hubs - an XCD sums the hub rows of the same row range
-        whose light rows it sweeps."""
-        if self.n_items < 8 * 1024:
-            return None
+    def onepass(self, d):
+        """(items int32 [n, 4], n, bounds int32 [9]) for gd_spmm_csr_onepass_f32 at width d.  The plan's rows are cut into
+        eight contiguous ranges of equal cost (in-edges + the per-visit overhead of xcd_bounds, once per 64-edge piece),
+        one per XCD.  Inside a range: first its hub rows (more than `chunk` in-edges), heaviest first, each as a GROUP of
+        four member items (the w-th contiguous share of the row's edges, a multiple of `chunk`) that the four waves of a
+        block sum together; then its light rows in row order, one item each; then padding to a multiple of 4 - so every
+        group sits at a 4-aligned position and every range limit is a multiple of 4."""
         a = int(min(48, max(8, 1536 // max(int(d), 1))))
-        b = self._bounds1.get(a)
-        if b is None:
-            cost = torch.cumsum((self._row_deg + a * self._row_pieces).double(), 0)
-            dev = cost.device
-            cuts = torch.searchsorted(cost, cost[-1] * torch.arange(1, 8, device=dev, dtype=torch.float64) / 8)   # row positions
-            wb = torch.searchsorted(self._whole_pos, cuts)
-            hb = torch.searchsorted(self._hub_pos, cuts)
-            b = torch.cat([wb.new_zeros(1), wb, wb.new_full((1,), self.n_whole),
-                           hb.new_zeros(1), hb, hb.new_full((1,), self.n_split)]).to(torch.int32).contiguous()
-            self._bounds1[a] = b
-        return b
+        hit = self._onepass.get(a)
+        if hit is not None:
+            return hit
+        ids, r_start, r_end, deg, pieces = self._row_ids, self._row_start, self._row_end, self._row_deg, self._row_pieces
+        dev = ids.device
+        n = int(ids.numel())
+        chunk = CHUNK
+        if n == 0:
+            hit = (torch.zeros(0, 4, dtype=torch.int32, device=dev), 0, torch.zeros(9, dtype=torch.int32, device=dev))
+            self._onepass[a] = hit
+            return hit
+        cost = torch.cumsum((deg + a * pieces).double(), 0)
+        cuts = torch.searchsorted(cost, cost[-1] * torch.arange(1, 8, device=dev, dtype=torch.float64) / 8)
+        lim = [0] + [int(c) for c in cuts.tolist()] + [n]
+        for k in range(1, 9):
+            lim[k] = max(lim[k], lim[k - 1])
+        parts, bounds, total = [], [0], 0
+        q4 = torch.arange(4, device=dev)
+        for k in range(8):
+            lo, hi = lim[k], lim[k + 1]
+            sel = torch.arange(lo, hi, device=dev)
+            hub = sel[pieces[lo:hi] > 1]
+            if hub.numel():
+                hub = hub[torch.argsort(deg[hub], descending=True, stable=True)]
+                share = chunk * ((pieces[hub] + 3) // 4)                           # edges per member, a multiple of chunk
+                ms = r_start[hub][:, None] + share[:, None] * q4[None, :]
+                me = torch.minimum(ms + share[:, None], r_end[hub][:, None])
+                ms = torch.minimum(ms, me)
+                grp = torch.stack([ids[hub][:, None].expand(-1, 4), ms, me, torch.full_like(ms, -2)], 2).reshape(-1, 4)
+                parts.append(grp)
+                total += int(grp.shape[0])
+            light = sel[pieces[lo:hi] <= 1]
+            if light.numel():
+                parts.append(torch.stack([ids[light], r_start[light], r_end[light], torch.full_like(light, -1)], 1))
+                total += int(light.numel())
+            pad = (-total) % 4
+            if pad:
+                parts.append(torch.tensor([[-1, 0, 0, -1]], device=dev).expand(pad, 4))
+                total += pad
+            bounds.append(total)
+        items = torch.cat(parts, 0).to(torch.int32).contiguous() if parts else torch.zeros(0, 4, dtype=torch.int32, device=dev)
+        hit = (items, total, torch.tensor(bounds, dtype=torch.int32, device=dev))
+        self._onepass[a] = hit
+        return hit
 
     def scratch_flat(self, tag, n_floats, device):
         """Named flat work buffers (e.g. the GAT kernels' merge scratch), kept per plan."""

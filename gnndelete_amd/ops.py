@@ -40,12 +40,11 @@ def _spmm_raw(rowptr, col, val, x, bias, self_coef, n_rows, plan=None, out=None,
     y = out if out is not None else torch.empty(n_rows, d, dtype=torch.float32, device=x.device)
     if (plan is not None and d % 4 == 0 and d <= 1024 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
             and os.environ.get('GD_SPMM_TWO_LAUNCH') != '1'):
-        # hub rows summed by whole blocks inside the same launch (no scratch rows, no fix-up kernel)
-        check(_lib.lib().gd_spmm_csr_onepass_f32(ptr(plan.items_whole), plan.n_whole, ptr(plan.hubs), plan.n_split,
-                                                 ptr(col), ptr(val), ptr(x), x.stride(0), ptr(y), y.stride(0),
-                                                 ptr(bias), float(self_coef), ptr(x_self), d, int(col.shape[0]),
-                                                 max(int(x.shape[0]), int(y.shape[0])), ptr(plan.xcd_bounds_onepass(d)),
-                                                 stream_ptr(x.device)),
+        # hub rows summed by the four waves of a block inside the same launch (no scratch rows, no fix-up kernel)
+        items, n_items, bounds = plan.onepass(d)
+        check(_lib.lib().gd_spmm_csr_onepass_f32(ptr(items), n_items, ptr(col), ptr(val), ptr(x), x.stride(0), ptr(y),
+                                                 y.stride(0), ptr(bias), float(self_coef), ptr(x_self), d, int(col.shape[0]),
+                                                 max(int(x.shape[0]), int(y.shape[0])), ptr(bounds), stream_ptr(x.device)),
               'gd_spmm_csr_onepass_f32')
         return y
     if plan is not None and d % 4 == 0 and d <= 1024 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:

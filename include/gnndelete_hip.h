@@ -132,19 +132,22 @@ int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_
                              const int32_t* xcd_bounds, void* stream);
 
 /* One-launch form of gd_spmm_csr_balanced_f32 (same arithmetic, same call sites): no scratch rows, no fix-up kernel.
- *   items [n_items, 4] = {row, start, end, -1}: the rows of at most 64 in-edges, one wave each (ascending rows);
- *   hubs  [n_hubs, 4]  = {row, start, end, 0}: the rows above 64 in-edges.  A hub row is summed by ONE block: its four
- *   waves take the row's 64-edge pieces round robin (one accumulator per wave), the four partial rows are added in
- *   LDS in wave order and written once - deterministic, no atomics.  The hub rows run first, then the block's waves
- *   sweep the items as in the balanced form.
- *   xcd_bounds (optional, 18 ints): [0..8] ascending item indices, [9..17] ascending hub indices - XCD k sweeps the items
- *   [b[k], b[k+1]) and the hubs [b[9+k], b[10+k]); NULL = equal eighths of both lists.  A placement hint only.
+ *   items [n_items, 4], n_items a multiple of 4, in three flavours:
+ *     {row, start, end, -1}  a row of at most 64 in-edges (one wave);
+ *     {row, start, end, -2}  a GROUP member: a row above 64 in-edges is laid out as four consecutive items at a
+ *                            4-aligned position, member w = the w-th contiguous share [start, end) of the row's
+ *                            in-edges (shares are multiples of 64 edges, trailing shares may be empty); the block's
+ *                            four waves take one member each, the four partial rows are added in LDS in member order and
+ *                            written once - deterministic, no atomics;
+ *     {-1, 0, 0, -1}         padding.
+ *   xcd_bounds (required, 9 ascending item indices, all multiples of 4, [0] = 0, [8] = n_items): the item range each of
+ *   the 8 XCDs sweeps.  Groups may sit anywhere in a range (the planner puts a range's hub rows first, heaviest first).
  * The sum of a hub row is associated differently from the balanced form's (piece partials in slot order), so the two
  * entries agree to fp32 rounding, not bit for bit; each is bit-reproducible run to run. */
-int gd_spmm_csr_onepass_f32(const int32_t* items, int32_t n_items, const int32_t* hubs, int32_t n_hubs,
-                            const int32_t* col, const float* val, const float* x, int64_t ldx,
-                            float* y, int64_t ldy, const float* bias, float self_coef, const float* x_self,
-                            int32_t d, int32_t nnz, int32_t x_rows, const int32_t* xcd_bounds, void* stream);
+int gd_spmm_csr_onepass_f32(const int32_t* items, int32_t n_items, const int32_t* col, const float* val,
+                            const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias, float self_coef,
+                            const float* x_self, int32_t d, int32_t nnz, int32_t x_rows, const int32_t* xcd_bounds,
+                            void* stream);
 
 /* Per-relation mean aggregation of R-GCN ("typed SpMM") over a relation-major CSR:
  *   rowptr[(r*n_rows + i) .. +1] delimit the in-edges of type r into node i;

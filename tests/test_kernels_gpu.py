@@ -455,7 +455,8 @@ def test_onepass_spmm_sums_hub_rows_inside_the_launch(d, self_coef, monkeypatch)
     x = torch.randn(n, d, generator=g)
     b = torch.randn(d, generator=g)
     gr = build_csr(ei.cuda(), n, 'sum')
-    assert gr.plan.n_split >= 6 and gr.plan.xcd_bounds_onepass(d) is not None and gr.plan.n_whole + gr.plan.n_split == n
+    items, n_items, bounds = gr.plan.onepass(d)
+    assert gr.plan.n_split >= 6 and n_items % 4 == 0 and bool((bounds % 4 == 0).all()) and int((items[:, 3] == -2).sum()) == 4 * gr.plan.n_split
     a = dense_adj(ei, n)
     want = a @ x.double() + self_coef * x.double() + b.double()
     xc, bc = x.cuda(), b.cuda()

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void stamped_kernel(const int4* items, int32_t
                                                       int32_t nnz, uint64_t* stamps) {
   const uint64_t t0 = wall_clock64();
   gd::spmm_persist_body<LPR, 1, U, true, true>(items, n_items, xcd_bounds, col, val, x, ldx, y, ldy, bias, 0.f, x, scratch, d4,
-                                               nnz, nullptr, 0);
+                                               nnz);
   __syncthreads();
   if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t0; stamps[2 * blockIdx.x + 1] = wall_clock64(); }
 }
