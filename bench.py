@@ -109,7 +109,17 @@ def build_kg_request(args):
     return data, model, neg, ni1, ni2
 
 
-def make_kg_engine(args, data, model, neg, ni1, ni2, device):
+def gather_halo_bytes(eng, world, ctl):
+    """[recv, send] bytes per step of every rank of a partitioned engine (all ranks call this; control group)."""
+    import torch.distributed as dist
+    rep = eng.halo_report()
+    mine = torch.tensor([rep['recv_bytes_per_step'], rep['send_bytes_per_step']], dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=ctl)
+    return [[int(v) for v in t.tolist()] for t in every]
+
+
+def make_kg_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1, group=None, partition=False):
     from gnndelete_amd.engine import NodeembEngine
     model = model.to(device)
     ei = data.edge_index[:, data.dr_mask].to(device).contiguous()
@@ -117,8 +127,13 @@ def make_kg_engine(args, data, model, neg, ni1, ni2, device):
     x = data.x.to(device)
     with torch.no_grad():
         z1o, z2o = model.get_original_embeddings(x, ei, et, return_all_emb=True)
-    return NodeembEngine(model, x, ei, z1o, z2o, data.kg_dec_edge.to(device), neg.to(device), ni1, ni2,
-                         loss_type=args.loss_type, alpha=0.5, lr=1e-3, use_graph=not args.no_graph, edge_type=et)
+    common = (model, x, ei, z1o, z2o, data.kg_dec_edge.to(device), neg.to(device), ni1, ni2)
+    if partition and world > 1:
+        # ONE request, target rows partitioned over the ranks with typed halos (dist_engine, mode 'rgcn')
+        from gnndelete_amd.dist_engine import PartitionedNodeembEngine
+        return PartitionedNodeembEngine(*common, rank, world, loss_type=args.loss_type, alpha=0.5, lr=1e-3,
+                                        use_graph=not args.no_graph, group=group, edge_type=et)
+    return NodeembEngine(*common, loss_type=args.loss_type, alpha=0.5, lr=1e-3, use_graph=not args.no_graph, edge_type=et)
 
 
 def time_typed_conv(eng):
@@ -176,23 +191,62 @@ def kg_cpu_baseline(args, data, state, neg, ni1, ni2, iters):
             'sample': f'{iters} full-graph R-GCN iterations of the same request, median ({med:.1f} s; torch CPU, {threads} host threads)'}, m
 
 
-def kg_main(args, device):
-    """One GPU, BASELINE config 4 (`--workload synth-biokg --gnn rgcn`): ONE JSON line with the same contract."""
+def kg_main(args, device, rank=0, world=1, group=None, barrier=lambda: None, ctl=None):
+    """BASELINE config 4 (`--workload synth-biokg --gnn rgcn`): ONE JSON line with the same contract.  N > 1: the request's
+    target rows are partitioned over the ranks (typed halo all-to-all + packed all-reduce per step, strong scaling) or, with
+    --parallel replicas, every rank serves its own copy of the request."""
     data, model, neg, ni1, ni2 = build_kg_request(args)
     state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    eng = make_kg_engine(args, data, model, neg, ni1, ni2, device)
-    if args.unroll > 1 and not args.no_graph:
+    partitioned = world > 1 and args.parallel == 'partition'
+    eng = make_kg_engine(args, data, model, neg, ni1, ni2, device, rank, world, group, partition=partitioned)
+    run = getattr(eng, 'run', None)
+    if run is not None and args.unroll > 1 and not args.no_graph:
         eng.prepare_unrolled(args.unroll)
     for _ in range(args.warmup):
         eng.step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.run(args.steps, unroll=args.unroll)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+
+    def timed_region():
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if run is not None:
+            run(args.steps, unroll=args.unroll)
+        else:
+            for _ in range(args.steps):
+                eng.step()
+        torch.cuda.synchronize()
+        barrier()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tmax = torch.tensor([dt_], dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=ctl)
+            dt_ = float(tmax)
+        return dt_
+    n_regions = args.repeats if args.repeats > 0 else (5 if args.steps < 100 else 1)
+    region_s = [timed_region() for _ in range(n_regions)]
+    dt = sorted(region_s)[len(region_s) // 2]
+    units = args.steps if (partitioned or world == 1) else world * args.steps
+    per_rank = gather_halo_bytes(eng, world, ctl) if partitioned else None
+    if rank != 0:
+        return
+    if world > 1:
+        out = {'metric': 'Del-op train iters/sec', 'value': units / dt, 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+               'scaling': 'strong' if partitioned else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': f'{args.workload} R-GCN 2-layer, {args.df_size}% {args.df.upper()} triple deletion, full-graph fused Del step',
+                          'num_nodes': data.num_nodes, 'hip_graph': not args.no_graph,
+                          'parallelism': f'row-partition x{world} (typed halo all-to-all + all-reduce)' if partitioned else f'replicas x{world}',
+                          'ranks_seen': world, 'halo': eng.halo_report() if partitioned else None,
+                          'halo_recv_send_bytes_per_rank': per_rank},
+               'timing': {'regions': n_regions, 'ms_per_step_each_region': [1e3 * t / args.steps for t in region_s]},
+               'final_loss': float(eng.loss_history()[-1, 0])}
+        print(json.dumps(out))
+        return
     out = {'metric': 'Del-op train iters/sec', 'value': args.steps / dt, 'unit': 'iters/s', 'n_gpus': 1, 'steps': args.steps,
            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'timing': {'regions': n_regions, 'ms_per_step_each_region': [1e3 * t / args.steps for t in region_s]},
            'config': {'workload': f'{args.workload} R-GCN 2-layer ({data.kg_num_edge_type} relation types, block-diagonal weights), '
                                   f'{args.df_size}% {args.df.upper()} triple deletion, full-graph fused Del step ({args.loss_type}, mse_mean)',
                       'num_nodes': data.num_nodes, 'typed_edges_dr': int(data.dr_mask.sum()), 'df_triples': int(data.directed_df_edge_index.shape[1]),
@@ -653,8 +707,12 @@ def main():
             dist.barrier(group=ctl)
 
     if args.gnn == 'rgcn':
-        assert world == 1, 'the KG line is a one-GPU line'
-        return kg_main(args, device)
+        if args.probe_partition:
+            args.workload, args.steps, args.warmup, args.repeats = 'synth-kg-small', 3, 1, 1
+        kg_main(args, device, rank, world, group, barrier, ctl)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     data, model, neg, ni1, ni2 = build_request(args, device)
     pretrain_loss = None
     if args.pretrain_epochs > 0 and not args.probe_partition:
@@ -719,6 +777,7 @@ def main():
 
     partitioned = mode == 'partition'
     units = args.steps if partitioned else world * args.steps      # iterations of whole requests
+    per_rank_halo = gather_halo_bytes(eng, world, ctl) if (partitioned and world > 1) else None
     rep_rate = replicas_rate(args, model, state, device, world, barrier) if (partitioned and world > 1) else None
     if rank == 0:
         kdur, kbytes = time_dominant_kernel(eng)
@@ -763,8 +822,14 @@ def main():
         }
         if note:
             out['config']['partition_fallback'] = note
+        out['config']['ranks_seen'] = world          # WORLD_SIZE of the torch.distributed job this line was measured in
         if partitioned:
-            out['config']['halo'] = eng.halo_report()
+            # rank 0's own figures + every rank's bytes (gathered over the control group): xGMI is point-to-point, the
+            # heaviest rank / pair bounds an exchange
+            rep = eng.halo_report()
+            out['config']['halo'] = rep
+            out['config']['halo_recv_send_bytes_per_rank'] = per_rank_halo
+            out['config']['collective_backend'] = backend
         if world == 1 and not args.no_cached_rate:
             # informational only (never `value`): the same step with the loop-invariant frozen layer-1
             # output computed once, which is how the trainer runs by default

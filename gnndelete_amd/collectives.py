@@ -18,6 +18,55 @@ import torch.distributed as dist
 _FORCE = os.environ.get('GD_FORCE_COLLECTIVES') == '1'
 
 
+class DirectComm:
+    """An RCCL communicator owned by the HIP library itself (include/gnndelete_hip.h: gd_comm_init, gd_allreduce_f32,
+    gd_exchange_rows_f32) instead of torch.distributed's process group: the 128-byte unique id is made on rank 0 and
+    broadcast over an existing (host-side, e.g. gloo) group, after which the data path never goes through torch's
+    collectives.  Pass it as `group` to all_reduce_sum / exchange_rows / PartitionedNodeembEngine.  The calls only enqueue
+    work on the current HIP stream (no host synchronisation)."""
+
+    def __init__(self, rank, world, device, bootstrap_group=None):
+        import ctypes
+        from . import _lib
+        self.rank, self.world, self.device = rank, world, torch.device(device)
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            _lib.check(_lib.lib().gd_comm_unique_id(uid.data_ptr()), 'gd_comm_unique_id')
+        if world > 1:
+            dist.broadcast(uid, 0, group=bootstrap_group)
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().gd_comm_init(uid.data_ptr(), world, rank, ctypes.byref(comm)), 'gd_comm_init')
+        self._comm = comm
+        self._counts = {}
+
+    def all_reduce(self, buf):
+        from . import _lib
+        assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
+        _lib.check(_lib.lib().gd_allreduce_f32(buf.data_ptr(), buf.numel(), self._comm, _lib.stream_ptr(buf.device)),
+                   'gd_allreduce_f32')
+
+    def exchange(self, send, recv, in_splits, out_splits):
+        """rows of `send` grouped by destination (in_splits[p] rows to peer p) -> rows of `recv` grouped by source."""
+        from . import _lib
+        key = (tuple(in_splits), tuple(out_splits))
+        host = self._counts.get(key)
+        if host is None:
+            host = self._counts[key] = (torch.tensor(in_splits, dtype=torch.int64), torch.tensor(out_splits, dtype=torch.int64))
+        assert send.is_contiguous() and recv.is_contiguous() and send.shape[1:] == recv.shape[1:]
+        row = int(send[0].numel()) if send.shape[0] else (int(recv[0].numel()) if recv.shape[0] else 1)
+        _lib.check(_lib.lib().gd_exchange_rows_f32(send.data_ptr() if send.numel() else None, host[0].data_ptr(),
+                                                   recv.data_ptr() if recv.numel() else None, host[1].data_ptr(), row,
+                                                   self.world, self._comm, _lib.stream_ptr(self.device)),
+                   'gd_exchange_rows_f32')
+
+    def close(self):
+        from . import _lib
+        if self._comm is not None:
+            _lib.lib().gd_comm_destroy(self._comm)
+            self._comm = None
+
+
 def row_blocks(n, world):
     """Equal row blocks: (chunk, n_pad); rank r owns rows [r*chunk, min(n, (r+1)*chunk))."""
     chunk = (n + world - 1) // world
@@ -38,7 +87,10 @@ def all_gather_rows(full, rank, world, chunk, group=None):
 
 def all_reduce_sum(buf, world, group=None):
     if world > 1 or _FORCE:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        if isinstance(group, DirectComm):
+            group.all_reduce(buf)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
 
 
 class HaloPlan:
@@ -91,6 +143,9 @@ def exchange_rows(send_buf, recv_buf, plan, world, group=None):
     if world == 1 and not _FORCE:
         return
     send, recv = send_buf[:plan.n_send], recv_buf[:plan.n_recv]
+    if isinstance(group, DirectComm):
+        group.exchange(send, recv, plan.in_splits, plan.out_splits)
+        return
     if dist.get_backend(group) == 'gloo' and send.is_cuda:
         host = torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_to_all_single(host, send.cpu(), plan.out_splits, plan.in_splits, group=group)

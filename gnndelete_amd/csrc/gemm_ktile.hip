@@ -444,7 +444,14 @@ extern "C" int gd_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, i
 #define GD_KS_CASE(NT)                                                                                                        \
   do {                                                                                                                        \
     auto kern = idx ? gemm_ktile_split_kernel<NT, true> : gemm_ktile_split_kernel<NT, false>;                                 \
-    const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
+    /* the LDS limit of both instantiations is raised once per process, not on every launch */                               \
+    static const hipError_t once = [] {                                                                                       \
+      const hipError_t a = hipFuncSetAttribute((const void*)gemm_ktile_split_kernel<NT, true>,                                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);                       \
+      const hipError_t b = hipFuncSetAttribute((const void*)gemm_ktile_split_kernel<NT, false>,                               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);                       \
+      return a != hipSuccess ? a : b;                                                                                         \
+    }();                                                                                                                      \
     GD_REQUIRE(once == hipSuccess, -(int)once, "gd_gemm_f32: cannot raise the LDS limit");                                    \
     hipLaunchKernelGGL(kern, grid, block, lds, s, in, ld_in, idx, n_rows, w, k / 32, q.chunks, q.per, q.groups * q.chunks,     \
                        bias, out, ld_out, pieces, q.s_max);                                                                   \

@@ -23,6 +23,12 @@ segments by the three collectives; the halo pack / unpack copies are part of the
   D  the --loss_type gradient bookkeeping (SURVEY F6) + Adam on both Del weights, identically on every rank;
      loss history, iteration counter.
 
+Overlap (GCN / GIN / GraphSAGE): the exchanges run on a communication stream while the compute stream does the work that
+does not need the halo - A2 = the partial dW_D1 (layer-wise types) and the layer-2 aggregation of the INTERIOR rows (own
+rows all of whose in-neighbours are own), B2 = the partial dW_D2 and the transposed aggregation of the interior S1 rows;
+the BOUNDARY rows follow once the halo has arrived.  (No multi-GPU node was available to this build: the overlap is
+correct by construction and covered by the gloo tests; its benefit is unmeasured.)
+
 GCN, GIN, GraphSAGE and GAT backbones.  GAT keeps every softmax on the rank that owns the target row; its backward
 needs no second forward-direction exchange: a rank computes the attention gradients of its OWN target rows (it
 holds their halo h rows since the forward exchange), which yields partial message gradients for own AND halo source
@@ -37,17 +43,23 @@ from . import collectives as _collectives
 from .collectives import all_reduce_sum, exchange_rows, exchange_rows_reverse, halo_plan, row_blocks
 from .engine import LOSS_TYPES, _Adam, _LayerTerms, _loss_coefficients, _loss_slots, _rows_inside
 from .graph import SplitPlan, graph_for
-from .nn import GATConv, GCNConv, GINConv, SAGEConv
+from .nn import GATConv, GCNConv, GINConv, RGCNConv, SAGEConv
 
 
 class PartitionedNodeembEngine:
     def __init__(self, model, x, edge_index, z1_ori, z2_ori, pos_edge, neg_edge, ni_mask1, ni_mask2, rank, world,
                  loss_type='both_layerwise', alpha=0.5, lr=1e-3, reduction='mean', use_graph=True, history=4096,
-                 reorder=True, group=None):
+                 reorder=True, group=None, edge_type=None):
+        """edge_type (R-GCN, BASELINE config 4): relation type per column of edge_index; x is then the entity id vector
+        (the frozen embedding table is replicated and looked up once)."""
         assert loss_type in LOSS_TYPES, loss_type
         conv1, conv2 = model.conv1, model.conv2
-        if not isinstance(conv2, (GCNConv, GINConv, SAGEConv, GATConv)):
-            raise NotImplementedError('PartitionedNodeembEngine supports GCN, GIN, GraphSAGE and GAT backbones')
+        if not isinstance(conv2, (GCNConv, GINConv, SAGEConv, GATConv, RGCNConv)):
+            raise NotImplementedError('PartitionedNodeembEngine supports GCN, GIN, GraphSAGE, GAT and R-GCN backbones')
+        if isinstance(conv2, RGCNConv):
+            assert edge_type is not None, 'R-GCN needs edge_type'
+            reorder = False
+            x = model.node_emb.weight.detach()[x.to(model.node_emb.weight.device)]
         dev = x.device
         if dev.type != 'cuda':
             raise _lib.GnnDeleteHipError('PartitionedNodeembEngine needs CUDA(HIP) tensors (no CPU fallback)')
@@ -73,7 +85,7 @@ class PartitionedNodeembEngine:
         self.hi = hi = min(n, lo + self.chunk)
         self.wd1, self.wd2 = model.deletion1.deletion_weight, model.deletion2.deletion_weight
         self.h, self.o = self.wd1.shape[0], self.wd2.shape[0]
-        self._mode = {GCNConv: 'gcn', GINConv: 'gin', SAGEConv: 'sage', GATConv: 'gat'}[type(conv2)]
+        self._mode = {GCNConv: 'gcn', GINConv: 'gin', SAGEConv: 'sage', GATConv: 'gat', RGCNConv: 'rgcn'}[type(conv2)]
         if self.h not in (32, 64, 128) or self.o not in (32, 64) or x.shape[1] % 32 or x.shape[1] * self.h * 4 > 65536:
             raise NotImplementedError('partitioned step: widths must suit the fused kernels (in % 32 == 0, hidden in '
                                       '{32, 64, 128}, out in {32, 64})')
@@ -116,10 +128,40 @@ class PartitionedNodeembEngine:
         self._coef1 = self.t1.coef if self.t1.n_rows else torch.zeros(1, **f32)
         self._coef2 = self.t2.coef if self.t2.n_rows else torch.zeros(1, **f32)
 
-        gmode = {'gcn': 'gcn', 'gin': 'sum', 'sage': 'mean', 'gat': 'gat'}[self._mode]
+        gmode = {'gcn': 'gcn', 'gin': 'sum', 'sage': 'mean', 'gat': 'gat', 'rgcn': 'sum'}[self._mode]
+        # (R-GCN: the untyped union graph is only the STRUCTURE the halo lists are derived from)
         self.graph = g = graph_for(edge_index, n, gmode)
+        if self._mode == 'rgcn':
+            from .graph import TypedNodeCSR
+            # typed graph of this rank: in-edges of the own target rows (forward), out-edges of the own source rows with
+            # the global mean weights (input gradient); tile plans and packed weights made outside any capture
+            self.typed = TypedNodeCSR(edge_index, edge_type.to(dev), n, conv2.num_relations, row_range=(lo, hi))
+            for c_, din, dout, tr in ((conv1, x.shape[1], self.h, 0), (conv2, self.h, self.o, 0), (conv2, self.o, self.h, 1)):
+                if int(_lib.lib().gd_rgcn_tile_kl(din, dout, c_.num_blocks or 1, tr)) > 0:
+                    self.typed.tile_plan(bool(tr))
+                    ops.rgcn_packed_weight(c_.weight.detach(), c_.num_blocks or 1, din, dout, tr)
         self.plan = SplitPlan(g.rowptr, row_range=(lo, hi))                    # forward aggregations: own rows
         self.plan_t = SplitPlan(g.rowptr_t, rows=self.idx1) if self.s1 else None   # transposed: own S1 rows only
+
+        def split_rows(rowptr, col, rows):
+            """rows (int32 ids) -> (interior, boundary): interior = every gathered row is owned by this rank."""
+            deg = (rowptr[1:] - rowptr[:-1]).long()
+            tgt = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+            c = col.long()
+            remote = torch.zeros(n, dtype=torch.bool, device=dev)
+            remote[tgt[(c < lo) | (c >= hi)]] = True
+            r = rows.long()
+            return rows[~remote[r]].contiguous(), rows[remote[r]].contiguous()
+        self._overlap = self._mode not in ('gat', 'rgcn')
+        if self._overlap:
+            i_f, b_f = split_rows(g.rowptr, g.col, self.own)
+            self.plan_int, self.plan_bnd = SplitPlan(g.rowptr, rows=i_f), SplitPlan(g.rowptr, rows=b_f)
+            self.n_interior = int(i_f.numel())
+            if self.s1:
+                i_t, b_t = split_rows(g.rowptr_t, g.col_t, self.idx1)
+                self.plan_t_int, self.plan_t_bnd = SplitPlan(g.rowptr_t, rows=i_t), SplitPlan(g.rowptr_t, rows=b_t)
+                self.n_interior_t = int(i_t.numel())
+        self._comm_stream = torch.cuda.Stream(device=dev)
         # ---- halo lists (device-side, one host transfer of the [world, world] count matrix each)
         own_mask = torch.zeros(n, dtype=torch.bool, device=dev)
         own_mask[lo:hi] = True
@@ -134,12 +176,16 @@ class PartitionedNodeembEngine:
             self.rsend = torch.zeros(max(1, self.halo_f.n_recv), self.o, **f32)
             self.rrecv = torch.zeros(max(1, self.halo_f.n_send), self.o, **f32)
             self.halo_b = self.halo_f                       # (report only: the reverse exchange moves the same rows)
-        self.send_f = torch.zeros(max(1, self.halo_f.n_send), self.o, **f32)
-        self.recv_f = torch.zeros(max(1, self.halo_f.n_recv), self.o, **f32)
+        self.wf = self.h if self._mode == 'rgcn' else self.o        # R-GCN aggregates BEFORE its transform: h-wide halo rows
+        self.send_f = torch.zeros(max(1, self.halo_f.n_send), self.wf, **f32)
+        self.recv_f = torch.zeros(max(1, self.halo_f.n_recv), self.wf, **f32)
         self.send_b = torch.zeros(max(1, self.halo_b.n_send), self.o, **f32)
         self.recv_b = torch.zeros(max(1, self.halo_b.n_recv), self.o, **f32)
 
         w_o = 2 * self.o if self._mode == 'sage' else self.o
+        if self._mode == 'rgcn':
+            self.hbuf = torch.zeros(n, self.h, **f32)               # relu(z1 | pre1): own rows + received halo rows
+            self.dxbuf = torch.zeros(n, self.h, **f32)              # conv2's input gradient on the own rows
         self.t1buf = torch.zeros(n, self.h, **f32)                  # x W1^T on the rows need1 (others never read)
         self.t1rbuf = torch.zeros(n, self.h, **f32) if self._mode == 'sage' else None
         self.aggbuf = torch.zeros(n, x.shape[1], **f32) if self._gin_agg_first else None
@@ -178,16 +224,17 @@ class PartitionedNodeembEngine:
         self.steps_done = 0
         self._use_graph = use_graph
         self._graphs = None
+        self._const_refs = {}
         self.uses_l1 = loss_type in ('both_all', 'both_layerwise', 'only1')
         self.needs_l2_to_w1 = loss_type in ('both_all', 'both_layerwise', 'only2_all')
 
     # ------------------------------------------------------------------ pieces
-    def _spmm(self, transposed, val, x, y, bias, self_coef, x_self=None):
+    def _spmm(self, transposed, val, x, y, bias, self_coef, x_self=None, plan=None):
         g = self.graph
         if transposed:
-            ops._spmm_raw(g.rowptr_t, g.col_t, val, x, bias, self_coef, self.n, self.plan_t, out=y, x_self=x_self)
+            ops._spmm_raw(g.rowptr_t, g.col_t, val, x, bias, self_coef, self.n, plan or self.plan_t, out=y, x_self=x_self)
         else:
-            ops._spmm_raw(g.rowptr, g.col, val, x, bias, self_coef, self.n, self.plan, out=y, x_self=x_self)
+            ops._spmm_raw(g.rowptr, g.col, val, x, bias, self_coef, self.n, plan or self.plan, out=y, x_self=x_self)
 
     def _wgrad1_partial(self, with_loss, g_add):
         """p_g1 = pre1[S1]^T (layer-1 loss gradient and / or g_add) over the OWN S1 rows; the layer-1 loss sums
@@ -213,6 +260,62 @@ class PartitionedNodeembEngine:
         fetch is still the cheapest place to form them, its product is discarded."""
         self._wgrad1_partial(True, None)
         self.p_g1.zero_()
+
+    # ------------------------------------------------------------------ R-GCN segments (own target rows, typed halo)
+    def _rgcn_conv_own(self, conv, inp, out, trans, rows):
+        """out[rows] = inp[rows] @ root (+ bias) + the typed conv of this rank's restricted graph (forward: in-edges of
+        the own rows; trans: the transposed graph of the own source rows with W_r^T)."""
+        nb = conv.num_blocks or 1
+        ops.rows_gemm(inp, rows, conv.root.detach(), trans_w=bool(trans), bias=None if trans else conv.bias.detach(), out=out)
+        ops.rgcn_typed_accumulate(self.typed, inp, conv.weight.detach(), nb, int(trans), out)
+
+    def _seg_a_rgcn(self):
+        c1 = self.model.conv1
+        self._rgcn_conv_own(c1, self.x, self.pre1, 0, self.own)          # x is replicated: layer 1 needs no halo
+        if self.s1:
+            ops.rows_gemm(self.pre1, self.idx1, self.wd1, out=self.z1, sign_bits=self.z1_pos)
+        if self.loss_type != 'only1':
+            lo, hi = self.lo, self.hi
+            torch.where(self._sel1[lo:hi].bool()[:, None], self.z1[lo:hi], self.pre1[lo:hi], out=self.hbuf[lo:hi])
+            self.hbuf[lo:hi].clamp_(min=0)
+            if self.halo_f.n_send:
+                torch.index_select(self.hbuf, 0, self.halo_f.send_rows, out=self.send_f)
+
+    def _seg_b_rgcn(self):
+        lt = self.loss_type
+        if lt == 'only1':
+            self._lp2.zero_()
+            self.p_g2.zero_()
+            return
+        if self.halo_f.n_recv:
+            self.hbuf.index_copy_(0, self.halo_f.recv_rows, self.recv_f)
+        self._rgcn_conv_own(self.model.conv2, self.hbuf, self.p2, 0, self.own)
+        if self.s2:
+            check(_lib.lib().gd_del_loss_bwd_f32(
+                ptr(self.p2), self.p2.stride(0), ptr(self.idx2), self.s2, ptr(self.wd2), self.o, ptr(self._slot2),
+                ptr(self._tm2), ptr(self._coef2), ptr(self._cnt_signed2), ptr(self.dz2c), self.dz2c.stride(0),
+                ptr(self.dz2), self.dz2.stride(0), ptr(self._lp2), stream_ptr(self.x.device)), 'gd_del_loss_bwd_f32')
+        else:
+            self._lp2.zero_()
+        if self.needs_l2_to_w1 and self.halo_b.n_send:
+            torch.index_select(self.dz2, 0, self.halo_b.send_rows, out=self.send_b)
+
+    def _seg_c_rgcn(self):
+        lt = self.loss_type
+        if self.needs_l2_to_w1:
+            if self.halo_b.n_recv:
+                self.dz2.index_copy_(0, self.halo_b.recv_rows, self.recv_b)
+            if self.s1:
+                self._rgcn_conv_own(self.model.conv2, self.dz2, self.dxbuf, 1, self.own)
+                ops.gate_rows(self.dxbuf, self.idx1, self.z1_pos, self.dh)       # ReLU backward from the packed sign bits
+            if lt == 'both_all':
+                self._wgrad1_partial(True, self.dh)
+            elif lt == 'only2_all':
+                lp1 = self._lp1.clone()
+                self._wgrad1_partial(False, self.dh) if self.s1 else self.p_g1.zero_()
+                self._lp1.copy_(lp1)
+        self.p_sums[0:2] = self._lp1.view(-1, 2)[:max(self._lp1_blocks, 1)].sum(0)
+        self.p_sums[2:4] = self._lp2.view(-1, 2)[:max(self._lp2_blocks, 1)].sum(0)
 
     # ------------------------------------------------------------------ the four segments
     def _seg_a(self):
@@ -242,17 +345,62 @@ class PartitionedNodeembEngine:
             w2 = self._w2cat
         if self.s1:
             ops.rows_gemm(self.pre1, self.idx1, self.wd1, out=self.z1, sign_bits=self.z1_pos)
+        if not self._overlap:
+            self._layer1_partials()
+        if lt != 'only1':
+            ops.rows_gemm_select(self.pre1, self.z1, self._sel1, w2, trans_w=True, const_w=True, relu_in=True,
+                                 out=self.t2buf, idx=self.own)
+            if self.halo_f.n_send:
+                torch.index_select(self.t2buf[:, :self.o], 0, self.halo_f.send_rows, out=self.send_f)
+
+    def _layer1_partials(self):
+        """Partial dW_D1 / layer-1 loss sums of the layer-wise loss types (they only need Del-1's output)."""
+        lt = self.loss_type
         if lt == 'both_layerwise':
             self._wgrad1_partial(True, self.dh)          # dh = the PREVIOUS iteration's layer-2 gradient (SURVEY F6)
         elif lt == 'only1':
             self._wgrad1_partial(True, None)
         elif lt in ('only2_layerwise', 'only2_all'):
             self._layer1_loss_only()
-        if lt != 'only1':
-            ops.rows_gemm_select(self.pre1, self.z1, self._sel1, w2, trans_w=True, const_w=True, relu_in=True,
-                                 out=self.t2buf, idx=self.own)
-            if self.halo_f.n_send:
-                torch.index_select(self.t2buf[:, :self.o], 0, self.halo_f.send_rows, out=self.send_f)
+
+    def _agg2(self, plan):
+        """Layer-2 aggregation of the rows of `plan` (own rows, or their interior / boundary part)."""
+        c2, g = self.model.conv2, self.graph
+        if self._mode == 'gcn':
+            self._spmm(False, g.val, self.t2buf, self.p2, c2.bias, 0.0, plan=plan)
+        elif self._mode == 'gin':
+            self._spmm(False, None, self.t2buf, self.p2, c2.nn.bias, 1.0 + c2.eps, plan=plan)
+        else:
+            self._spmm(False, g.val, self.t2buf[:, :self.o], self.p2, c2.lin_l.bias, 1.0, x_self=self.t2buf[:, self.o:], plan=plan)
+
+    def _agg2_t(self, plan):
+        """Transposed layer-2 aggregation (conv2's input gradient before the Linear) of the S1 rows of `plan`."""
+        c2, g = self.model.conv2, self.graph
+        if self._mode == 'sage':
+            self._spmm(True, g.val_t, self.dz2, self.dcat[:, :self.o], None, 0.0, plan=plan)
+        elif self._mode == 'gcn':
+            self._spmm(True, g.val_t, self.dz2, self.dt2, None, 0.0, plan=plan)
+        else:
+            self._spmm(True, None, self.dz2, self.dt2, None, 1.0 + c2.eps, plan=plan)
+
+    def _wgrad2_partial(self):
+        if self.s2:
+            check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(self.p2), self.p2.stride(0), ptr(self.idx2), ptr(self.dz2c),
+                                                    self.dz2c.stride(0), None, None, None, self.s2, self.o, self.o,
+                                                    ptr(self.p_g2), 0, ptr(self.ws2), stream_ptr(self.x.device)),
+                  'gd_rows_gemm_wgrad_f32')
+        else:
+            self.p_g2.zero_()
+
+    def _wgrad2_partial_if_used(self):
+        if self.loss_type != 'only1':
+            self._wgrad2_partial()
+
+    def _seg_a2(self):
+        """While exchange #1 is in flight: the layer-1 partials and the layer-2 aggregation of the interior rows."""
+        self._layer1_partials()
+        if self.loss_type != 'only1':
+            self._agg2(self.plan_int)
 
     def _seg_b(self):
         c2 = self.model.conv2
@@ -263,31 +411,32 @@ class PartitionedNodeembEngine:
             return
         if self.halo_f.n_recv:
             self.t2buf[:, :self.o].index_copy_(0, self.halo_f.recv_rows, self.recv_f)
-        if self._mode == 'gcn':
-            self._spmm(False, g.val, self.t2buf, self.p2, c2.bias, 0.0)
-        elif self._mode == 'gin':
-            self._spmm(False, None, self.t2buf, self.p2, c2.nn.bias, 1.0 + c2.eps)
-        elif self._mode == 'gat':
+        if self._mode == 'gat':
             a_s, a_d = ops.row_dots(self.t2buf, c2.att_src, c2.att_dst)          # own + halo rows hold h2
             _, rowmax, rowsum = ops.gat_forward_raw(g, self.t2buf, a_s, a_d, c2.bias, c2.negative_slope, out=self.p2,
                                                     plan=self.plan)
             self._gat2 = (a_s, a_d, rowmax, rowsum)
         else:
-            self._spmm(False, g.val, self.t2buf[:, :self.o], self.p2, c2.lin_l.bias, 1.0, x_self=self.t2buf[:, self.o:])
+            self._agg2(self.plan_bnd if self._overlap else self.plan)
         if self.s2:
             check(_lib.lib().gd_del_loss_bwd_f32(
                 ptr(self.p2), self.p2.stride(0), ptr(self.idx2), self.s2, ptr(self.wd2), self.o, ptr(self._slot2),
                 ptr(self._tm2), ptr(self._coef2), ptr(self._cnt_signed2), ptr(self.dz2c), self.dz2c.stride(0),
                 ptr(self.dz2), self.dz2.stride(0), ptr(self._lp2), stream_ptr(self.x.device)), 'gd_del_loss_bwd_f32')
-            check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(self.p2), self.p2.stride(0), ptr(self.idx2), ptr(self.dz2c),
-                                                    self.dz2c.stride(0), None, None, None, self.s2, self.o, self.o,
-                                                    ptr(self.p_g2), 0, ptr(self.ws2), stream_ptr(self.x.device)),
-                  'gd_rows_gemm_wgrad_f32')
         else:
             self._lp2.zero_()
-            self.p_g2.zero_()
+        if not self._overlap:
+            self._wgrad2_partial()
         if self.needs_l2_to_w1 and self._mode != 'gat' and self.halo_b.n_send:
             torch.index_select(self.dz2, 0, self.halo_b.send_rows, out=self.send_b)
+
+    def _seg_b2(self):
+        """While exchange #2 is in flight: the partial dW_D2 and the transposed aggregation of the interior S1 rows."""
+        if self.loss_type == 'only1':
+            return
+        self._wgrad2_partial()
+        if self.needs_l2_to_w1 and self.s1:
+            self._agg2_t(self.plan_t_int)
 
     def _seg_c_gat_edges(self):
         """GAT only: attention gradients of the OWN target rows -> partial message gradients dt2 for own and halo
@@ -327,14 +476,12 @@ class PartitionedNodeembEngine:
             if self.halo_b.n_recv:
                 self.dz2.index_copy_(0, self.halo_b.recv_rows, self.recv_b)
             if self.s1:
+                self._agg2_t(self.plan_t_bnd if self._overlap else self.plan_t)
                 if self._mode == 'sage':
-                    self._spmm(True, g.val_t, self.dz2, self.dcat[:, :self.o], None, 0.0)
                     dt2, w2 = self.dcat, self._w2cat
                 elif self._mode == 'gcn':
-                    self._spmm(True, g.val_t, self.dz2, self.dt2, None, 0.0)
                     dt2, w2 = self.dt2, c2.lin.weight
                 else:
-                    self._spmm(True, None, self.dz2, self.dt2, None, 1.0 + c2.eps)
                     dt2, w2 = self.dt2, c2.nn.weight
                 ops.rows_gemm(dt2, self.idx1, w2, trans_w=False, out=self.dh, gate_bits=self.z1_pos)
             if lt == 'both_all':
@@ -363,23 +510,37 @@ class PartitionedNodeembEngine:
                                               ptr(self.hist_pos), ptr(self.iter_ctr), stream_ptr(self.x.device)),
               'gd_loss_finalize_f32')
 
-    def _segments(self):
+    def _program(self):
+        """The step as a list of compute segments (callables, one hipGraph each) and communication ops ('x', what, mode):
+        mode 'async' starts the exchange on the communication stream and lets the compute stream go on; 'wait' makes the
+        compute stream wait for it; 'sync' = both at once."""
         if self._mode == 'gat':
-            return [self._seg_a, self._seg_b, self._seg_c_gat_edges, self._seg_c, self._seg_d]
-        return [self._seg_a, self._seg_b, self._seg_c, self._seg_d]
+            return [self._seg_a, ('x', 'halo_f', 'sync'), self._seg_b, self._seg_c_gat_edges, ('x', 'halo_r', 'sync'),
+                    self._seg_c, ('x', 'reduce', 'sync'), self._seg_d]
+        if self._mode == 'rgcn':          # the partial weight gradients run under the exchanges
+            return [self._seg_a_rgcn, ('x', 'halo_f', 'async'), self._layer1_partials, ('x', None, 'wait'), self._seg_b_rgcn,
+                    ('x', 'halo_b', 'async'), self._wgrad2_partial_if_used, ('x', None, 'wait'), self._seg_c_rgcn,
+                    ('x', 'reduce', 'sync'), self._seg_d]
+        return [self._seg_a, ('x', 'halo_f', 'async'), self._seg_a2, ('x', None, 'wait'), self._seg_b,
+                ('x', 'halo_b', 'async'), self._seg_b2, ('x', None, 'wait'), self._seg_c, ('x', 'reduce', 'sync'), self._seg_d]
 
-    def _exchange(self, after_segment):
+    def _comm(self, what, mode):
         if self.world == 1 and not _collectives._FORCE:
             return
-        gat = self._mode == 'gat'
-        if after_segment == 0 and self.loss_type != 'only1':
-            exchange_rows(self.send_f, self.recv_f, self.halo_f, self.world, self.group)
-        elif after_segment == 1 and self.needs_l2_to_w1 and not gat:
-            exchange_rows(self.send_b, self.recv_b, self.halo_b, self.world, self.group)
-        elif after_segment == 2 and gat and self.needs_l2_to_w1:
-            exchange_rows_reverse(self.rsend, self.rrecv, self.halo_f, self.world, self.group)
-        elif after_segment == (3 if gat else 2):
-            all_reduce_sum(self.pack, self.world, self.group)
+        cur = torch.cuda.current_stream()
+        if what is not None:
+            self._comm_stream.wait_stream(cur)                     # the packed rows are complete
+            with torch.cuda.stream(self._comm_stream):
+                if what == 'halo_f' and self.loss_type != 'only1':
+                    exchange_rows(self.send_f, self.recv_f, self.halo_f, self.world, self.group)
+                elif what == 'halo_b' and self.needs_l2_to_w1:
+                    exchange_rows(self.send_b, self.recv_b, self.halo_b, self.world, self.group)
+                elif what == 'halo_r' and self.needs_l2_to_w1:
+                    exchange_rows_reverse(self.rsend, self.rrecv, self.halo_f, self.world, self.group)
+                elif what == 'reduce':
+                    all_reduce_sum(self.pack, self.world, self.group)
+        if mode in ('wait', 'sync'):
+            cur.wait_stream(self._comm_stream)
 
     # ------------------------------------------------------------------ public
     def _mutable_state(self):
@@ -387,28 +548,37 @@ class PartitionedNodeembEngine:
                 self.iter_ctr, self.hist, self.hist_pos, self.dh]
 
     def _run_eager(self):
-        with torch.no_grad():
-            for i, seg in enumerate(self._segments()):
-                seg()
-                self._exchange(i)
+        with torch.no_grad(), ops.keep_constants(self._const_refs):
+            for op in self._program():
+                if isinstance(op, tuple):
+                    self._comm(op[1], op[2])
+                else:
+                    op()
 
     def _capture(self):
         saved = [t.clone() for t in self._mutable_state()]
         applied = (self.adam1.applied, self.adam2.applied)
         self._run_eager()                                  # warm-up incl. the collectives (all ranks)
         torch.cuda.synchronize()
-        graphs = []
-        with torch.no_grad():
-            for seg in self._segments():
+        prog = []
+        # ONE memory pool for all segments: tensors a segment allocates while it is captured (GAT's row statistics and
+        # logits, the per-edge gradient buffer) are read by LATER segments' graphs - with a pool per graph they would
+        # only stay valid through the Python references
+        pool = torch.cuda.graph_pool_handle()
+        with torch.no_grad(), ops.keep_constants(self._const_refs):
+            for op in self._program():
+                if isinstance(op, tuple):
+                    prog.append(op)
+                    continue
                 g = torch.cuda.CUDAGraph()
                 # thread_local: the RCCL watchdog thread must not invalidate the capture
-                with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                    seg()
-                graphs.append(g)
+                with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
+                    op()
+                prog.append(g)
         for t, s in zip(self._mutable_state(), saved):
             t.copy_(s)
         self.adam1.applied, self.adam2.applied = applied
-        self._graphs = graphs
+        self._graphs = prog
 
     def step(self):
         if not self._use_graph:
@@ -416,18 +586,28 @@ class PartitionedNodeembEngine:
         else:
             if self._graphs is None:
                 self._capture()
-            for i, g in enumerate(self._graphs):
-                g.replay()
-                self._exchange(i)
+            for op in self._graphs:
+                if isinstance(op, tuple):
+                    self._comm(op[1], op[2])
+                else:
+                    op.replay()
         self.steps_done += 1
 
     def halo_report(self):
         """Bytes this rank receives per step in the two row exchanges, and what the dense all-gather would move."""
         row = 4 * self.o
-        return {'recv_rows_forward': self.halo_f.n_recv, 'recv_rows_backward': self.halo_b.n_recv,
-                'recv_bytes_per_step': row * (self.halo_f.n_recv + self.halo_b.n_recv),
-                'allgather_bytes_per_step': 2 * row * (self.n - (self.hi - self.lo)),
-                'layer1_rows_recomputed': int(self.need1.numel()) - (self.hi - self.lo)}
+        rowf = 4 * getattr(self, 'wf', self.o)
+        rep = {'rank': self.rank, 'world': self.world, 'own_rows': self.hi - self.lo,
+               'recv_rows_forward': self.halo_f.n_recv, 'recv_rows_backward': self.halo_b.n_recv,
+               'recv_bytes_per_step': rowf * self.halo_f.n_recv + row * self.halo_b.n_recv,
+               'send_bytes_per_step': rowf * self.halo_f.n_send + row * self.halo_b.n_send,
+               'allgather_bytes_per_step': (rowf + row) * (self.n - (self.hi - self.lo)),
+               'layer1_rows_recomputed': int(self.need1.numel()) - (self.hi - self.lo)}
+        if self._overlap:
+            rep['interior_rows_forward'] = self.n_interior
+            rep['interior_rows_backward'] = getattr(self, 'n_interior_t', 0)
+            rep['overlap'] = 'exchange on a communication stream under the partial weight gradients + interior-row aggregation'
+        return rep
 
     def loss_history(self):
         k = min(self.steps_done, self.hist.shape[0])

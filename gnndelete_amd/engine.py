@@ -277,6 +277,7 @@ class NodeembEngine:
         self.steps_done = 0
         self._graph = None
         self._use_graph = use_graph
+        self._const_refs = {}
         # OPT-IN (GD_SIDE_STREAM=1), measured and NOT kept as the default: the split-K reductions (+ Adam) and the loss
         # finalize are launch-sized and nothing later in the iteration reads what they write, so they can run on a side
         # stream, forked behind the kernel that feeds them and joined at the end of the iteration.  On this part the
@@ -653,7 +654,9 @@ class NodeembEngine:
                           left in .grad by the PREVIOUS one (zero_grad only after loss-1's step,
                           :232-262), i.e. dh is consumed one iteration late (zeros at iteration 0)."""
         lt = self.loss_type
-        with torch.no_grad():
+        # cached constant operands (transposed / padded / packed copies of frozen tensors) used in here are pinned by
+        # this engine: a captured graph replays from their addresses (ops.keep_constants)
+        with torch.no_grad(), ops.keep_constants(self._const_refs):
             # ---- forward, layer 1
             if self.cache_layer1:
                 ops.rows_gemm(self.p1, self.idx1, self.wd1, out=self.z1, sign_bits=self.z1_pos)   # other rows stay = p1

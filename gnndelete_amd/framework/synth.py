@@ -113,6 +113,7 @@ def make_linkpred_dataset(name='synth-collab', seed=42, val_ratio=0.05, test_rat
 # name -> (num_nodes, num_relations, unique triples)
 KG_SHAPES = {
     'synth-kg-tiny': (500, 4, 3000),
+    'synth-kg-small': (4000, 25, 60000),          # > 20 relation types: block-diagonal relation weights like ogbl-biokg
     'synth-wn18': (40943, 18, 151442),
     'synth-biokg': (93773, 51, 4762678),
 }

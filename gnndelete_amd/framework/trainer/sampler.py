@@ -130,16 +130,23 @@ def sync_gradients(optimizer):
     if world == 1:
         return
     import torch.distributed as dist
-    grads = [p.grad for g in optimizer.param_groups for p in g['params'] if p.grad is not None]
-    if not grads:
+    # Fixed layout over EVERY parameter of the optimizer (zeros where this rank's batch gave a parameter no gradient):
+    # each rank draws different batches, and a collective whose size - or whose existence - depended on which
+    # parameters happened to receive a gradient would hang or silently misalign the averages.
+    params = [p for g in optimizer.param_groups for p in g['params']]
+    if not params:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat)
     flat /= world
     off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
-        off += g.numel()
+    for p in params:
+        g = flat[off:off + p.numel()].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += p.numel()
 
 
 def make_sampler(data, batch_size, num_steps, walk_length=2):

@@ -88,7 +88,44 @@ def spmm(x, graph, bias=None, self_coef=0.0):
     return _SpMM.apply(x, bias, graph, self_coef)
 
 
-# ------------------------------------------------------------------------------ Del operator
+# ------------------------------------------------------------------------------ constant-operand caches
+# Derived copies of operands a caller declares constant (transposed frozen weights, zero-padded node features).  The
+# caches evict ONE least-recently-used entry at a time, and every tensor they hand out is also reported to the active
+# `keep_constants` stores: an engine whose hipGraph has the address of such a copy baked in holds its own reference, so
+# an eviction (or a clear) can never free memory a captured graph still replays from.
+_SINKS = []
+
+
+class keep_constants:
+    """with keep_constants(store): every cached constant operand handed out inside is added to `store` (a dict)."""
+
+    def __init__(self, store):
+        self.store = store
+
+    def __enter__(self):
+        _SINKS.append(self.store)
+        return self.store
+
+    def __exit__(self, *exc):
+        _SINKS.pop()
+
+
+def _note_constant(t):
+    for store in _SINKS:
+        store[id(t)] = t
+    return t
+
+
+def _lru_get(cache, key, capacity, build):
+    hit = cache.pop(key, None)
+    if hit is None:
+        while len(cache) >= capacity:
+            cache.pop(next(iter(cache)))            # oldest entry only
+        hit = build()
+    cache[key] = hit                                # (re-)insert as most recently used
+    return hit
+
+
 _WT_CACHE = {}
 
 
@@ -100,13 +137,8 @@ def _const_weight(w, trans_w):
     if not trans_w:
         return w, trans_w
     key = (w.data_ptr(), tuple(w.shape), w._version)
-    hit = _WT_CACHE.get(key)
-    if hit is None:
-        if len(_WT_CACHE) >= 64:
-            _WT_CACHE.clear()
-        hit = (w.detach().t().contiguous(), w)
-        _WT_CACHE[key] = hit
-    return hit[0], False
+    hit = _lru_get(_WT_CACHE, key, 64, lambda: (w.detach().t().contiguous(), w))
+    return _note_constant(hit[0]), False
 
 
 def rows_gemm(inp, idx, w, trans_w=False, bias=None, relu_in=False, out=None, save_in=None, gate_bits=None,
@@ -226,21 +258,19 @@ def rows_gemm_dots(inp, w, u1, u2, inp_alt=None, sel=None, relu_in=False, out=No
     return out, a1, a2
 
 
-_PAD_CACHE = {}
+_PAD_CACHE = {}          # copies derived from the node features (large: a handful of entries)
+_WPAD_CACHE = {}         # copies derived from weights (small, many)
 
 
 def _cached(tag, t, build):
     """build(t) cached per tensor content identity (storage address, shape, strides, torch's version counter); the
     entry keeps `t` alive so the address cannot be recycled.  For operands that stay constant across calls (the
-    node features, frozen weights): padded / transposed copies are made once."""
+    node features, frozen weights): padded / transposed copies are made once.  Feature-derived and weight-derived
+    copies live in separate LRU caches, so a stream of weight entries cannot push out a 100 MB padded feature matrix."""
     key = (tag, t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version)
-    hit = _PAD_CACHE.get(key)
-    if hit is None:
-        if len(_PAD_CACHE) >= 8:
-            _PAD_CACHE.clear()
-        hit = (build(t), t)
-        _PAD_CACHE[key] = hit
-    return hit[0]
+    cache, cap = (_WPAD_CACHE, 64) if tag.startswith(('padw', 'wT')) else (_PAD_CACHE, 8)
+    hit = _lru_get(cache, key, cap, lambda: (build(t), t))
+    return _note_constant(hit[0])
 
 
 def _pad_cols32(t, mult=32):
@@ -309,7 +339,10 @@ class _Dense(torch.autograd.Function):
         if _small_weight(in_f, out_f) and x.stride(0) % 4 == 0:
             return rows_gemm(x, None, w, trans_w=True, bias=b)
         if mfma_out_width(out_f):
-            return gemm_wide(x, _cached('wT', w, lambda t: t.t().contiguous()), b, const_x=const_x)
+            # a trainable weight changes every optimizer step: caching its transpose would miss every time and only
+            # churn the cache - transpose on the fly; a frozen weight's transpose is made once
+            wt = w.t().contiguous() if weight.requires_grad else _cached('wT', w, lambda t: t.t().contiguous())
+            return gemm_wide(x, wt, b, const_x=const_x)
         if in_f <= 1024:
             return rows_gemm(x, None, w, trans_w=True, bias=b)            # any widths: the one-wave-per-row kernel
         return torch.nn.functional.linear(x, w, b)
@@ -554,17 +587,13 @@ def rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans):
     kl = int(_lib.lib().gd_rgcn_tile_kl(d_in, d_out, n_blocks, int(trans)))
     assert kl > 0
     key = (weight.data_ptr(), tuple(weight.shape), weight._version, int(trans))
-    hit = _RGCN_PACK_CACHE.get(key)
-    if hit is None:
-        if len(_RGCN_PACK_CACHE) >= 16:
-            _RGCN_PACK_CACHE.clear()
+    def build():
         wc = weight.detach().contiguous()
         packed = torch.empty(wc.shape[0] * (d_out // 16) * (kl // 16) * 256, dtype=torch.float32, device=wc.device)
         check(_lib.lib().gd_rgcn_pack_weight_f32(ptr(wc), wc.shape[0], n_blocks, d_in, d_out, int(trans), ptr(packed),
                                                  stream_ptr(wc.device)), 'gd_rgcn_pack_weight_f32')
-        hit = (packed, weight)
-        _RGCN_PACK_CACHE[key] = hit
-    return hit[0]
+        return (packed, weight)
+    return _note_constant(_lru_get(_RGCN_PACK_CACHE, key, 16, build)[0])
 
 
 def rgcn_typed_accumulate(tg, x, weight, n_blocks, trans, y, edge_w=None):

@@ -18,7 +18,10 @@
  *       rowptr[n_rows+1], col[nnz] = source node of each in-edge, val[nnz] = edge weight;
  *   - return value: 0 = ok, >0 = argument error (GD_E_*), <0 = -(hipError_t).
  *     Nothing throws; gd_last_error_string() describes the last failure of the calling thread.
- *   - no global mutable state besides that thread-local error string: re-entrant per stream.
+ *   - re-entrant per stream.  Process-wide state is limited to: the thread-local error string; the opt-in
+ *     gd_set_matrix_split() switch (initialised from the environment, read at launch time; leave it alone and every
+ *     call is a pure function of its arguments); tuning knobs read ONCE from the environment at first use
+ *     (GD_SPMM_GRID_CAP, GD_ROWS_GEMM_GRID, GD_ROWS_GEMM_QUEUE); the lazily resolved RCCL entry points.
  */
 #ifndef GNNDELETE_HIP_H
 #define GNNDELETE_HIP_H
@@ -30,7 +33,8 @@ extern "C" {
 #endif
 
 #define GD_ABI_VERSION 4   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
-                              4: gd_spmm_csr_onepass_f32, gd_rows_gemm_wgrad_reduce_f32 (dw = NULL in the wgrad entries) */
+                              4: gd_spmm_csr_onepass_f32, gd_rows_gemm_wgrad_reduce_f32 (dw = NULL in the wgrad entries),
+                                 gd_comm_* / gd_allreduce_f32 / gd_exchange_rows_f32 */
 
 enum {
   GD_OK = 0,
@@ -510,6 +514,30 @@ int gd_adam_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_
 /* gd_adam_f32 with the step number read from a shared iteration counter (t = *iter + 1). */
 int gd_adam_at_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int32_t* iter,
                    int64_t n, double lr, double beta1, double beta2, double eps, void* stream);
+
+/* ---------------------------------------------------------------- collectives (RCCL) ---- */
+
+/* The two exchanges of the row-partitioned multi-GPU step (the reference has no distributed code at all: SURVEY
+ * section 5; north_star adds "RCCL all-reduce of partial aggregates and Del-operator gradients over xGMI").  One process
+ * per GPU; a communicator is an RCCL ncclComm_t behind a void*.  RCCL is looked up at first use (dlsym among the loaded
+ * libraries - a PyTorch-ROCm process carries its own librccl - then librccl.so by name): without it these entries return
+ * GD_E_NULL and everything else in the library works.  Failures of RCCL itself come back as -(1000 + ncclResult_t).
+ *   gd_comm_unique_id   rank 0 fills 128 bytes (ncclUniqueId, HOST memory) and ships them to every rank out of band
+ *   gd_comm_init        collective over the n_ranks processes: *comm <- the communicator of `rank` on the CURRENT device
+ *   gd_comm_destroy     NULL is accepted
+ *   gd_allreduce_f32    buf[0..n) <- sum over ranks, in place, enqueued on `stream`: the packed [dW_D1 | dW_D2 | loss sums]
+ *                       buffer of a step (80 KiB, latency-bound) - replaces nothing upstream
+ *   gd_exchange_rows_f32  sparse all-to-all of feature rows: send_rows[p] / recv_rows[p] (HOST arrays of n_ranks int64 row
+ *                       counts) rows of row_elems floats go to / come from peer p, packed back to back in peer order in
+ *                       `send` / `recv` (device); one grouped ncclSend / ncclRecv per non-empty pair on `stream` - xGMI is
+ *                       point-to-point, so every pair moves over its own link concurrently.  The halo rows of a layer's
+ *                       aggregation (forward) and of its transpose (backward). */
+int gd_comm_unique_id(void* id128);
+int gd_comm_init(const void* id128, int32_t n_ranks, int32_t rank, void** comm);
+int gd_comm_destroy(void* comm);
+int gd_allreduce_f32(float* buf, int64_t n, void* comm, void* stream);
+int gd_exchange_rows_f32(const float* send, const int64_t* send_rows, float* recv, const int64_t* recv_rows,
+                         int32_t row_elems, int32_t n_ranks, void* comm, void* stream);
 
 #ifdef __cplusplus
 }

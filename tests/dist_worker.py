@@ -203,7 +203,7 @@ def emulate_partitioned_step(kind, rank, world, data, neg, ni1, ni2, f, h, o):
     assert torch.allclose(g2, want2, rtol=1e-3, atol=1e-7), (kind, float((g2 - want2).abs().max()))
 
 
-def gpu_checks(rank, world, rccl=False):
+def gpu_checks(rank, world, rccl=False, direct=False):
     from types import SimpleNamespace
     from gnndelete_amd.dist_engine import PartitionedNodeembEngine
     from gnndelete_amd.engine import NodeembEngine
@@ -216,8 +216,20 @@ def gpu_checks(rank, world, rccl=False):
     group = None
     if rccl:                  # a world of one over RCCL: the data-path communicator the GPU node uses
         cases = [(GCNDelete, 'both_layerwise'), (SAGEDelete, 'both_all'), (GATDelete, 'both_layerwise')]
-        group = dist.new_group(backend='nccl', device_id=dev)
-        assert dist.get_backend(group) == 'nccl'
+        if direct:
+            from gnndelete_amd.collectives import DirectComm, HaloPlan, all_reduce_sum, exchange_rows
+            group = DirectComm(rank, world, dev)
+            buf = torch.arange(20480 + 4, dtype=torch.float32, device=dev)
+            all_reduce_sum(buf, world, group)
+            send = torch.randn(37, 64, device=dev)
+            recv = torch.zeros(40, 64, device=dev)
+            exchange_rows(send, recv, HaloPlan(None, [37], None, [37], [[37]]), world, group)
+            torch.cuda.synchronize()
+            assert torch.equal(buf.cpu(), torch.arange(20480 + 4, dtype=torch.float32)) and torch.equal(recv[:37], send)
+            print('direct collectives ok', flush=True)
+        else:
+            group = dist.new_group(backend='nccl', device_id=dev)
+            assert dist.get_backend(group) == 'nccl'
     for cls, lt in cases:
         results = []
         for partitioned in (False, True):
@@ -249,14 +261,43 @@ def gpu_checks(rank, world, rccl=False):
             print(f'{cls.__name__} {lt}: partitioned == single (rel err {err:.2e})', flush=True)
 
 
+def rgcn_checks(rank, world):
+    """R-GCN (block-diagonal relation weights, 50 relation types): the row-partitioned engine with typed halos against the
+    single-GPU fused engine on the same knowledge-graph request."""
+    from types import SimpleNamespace
+    import bench
+    from gnndelete_amd.dist_engine import PartitionedNodeembEngine
+    dev = torch.device('cuda', 0)
+    for lt in ('both_layerwise', 'both_all', 'only2_all'):
+        results = []
+        for partitioned in (False, True):
+            args = SimpleNamespace(gnn='rgcn', workload='synth-kg-small', seed=42, df='in', df_size=2.5, loss_type=lt, no_graph=False)
+            data, model, neg, ni1, ni2 = bench.build_kg_request(args)
+            eng = bench.make_kg_engine(args, data, model, neg, ni1, ni2, dev, rank, world, None, partition=partitioned)
+            assert isinstance(eng, PartitionedNodeembEngine) == partitioned
+            for _ in range(4):
+                eng.step()
+            torch.cuda.synchronize()
+            results.append((model.deletion1.deletion_weight.detach().cpu(), model.deletion2.deletion_weight.detach().cpu(),
+                            eng.loss_history()))
+        (a1, a2, ah), (b1, b2, bh) = results
+        err = max(float((a1 - b1).norm() / a1.norm()), float((a2 - b2).norm() / a2.norm()))
+        assert err < 1e-4, (lt, err)
+        assert torch.allclose(ah, bh, rtol=1e-4, equal_nan=True), (lt, ah, bh)
+        if rank == 0:
+            print(f'RGCNDelete {lt}: partitioned == single (rel err {err:.2e})', flush=True)
+
+
 def main():
     mode = sys.argv[1]
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     try:
-        if mode == 'rccl1':
+        if mode in ('rccl1', 'direct1'):
             assert world == 1 and os.environ.get('GD_FORCE_COLLECTIVES') == '1'
-            gpu_checks(rank, world, rccl=True)
+            gpu_checks(rank, world, rccl=True, direct=mode == 'direct1')
+        elif mode == 'rgcn':
+            rgcn_checks(rank, world)
         else:
             (cpu_checks if mode == 'cpu' else gpu_checks)(rank, world)
         dist.barrier()

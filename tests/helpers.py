@@ -81,3 +81,12 @@ def hip_model(gnn, state, mask1=None, mask2=None, num_nodes=None, num_edge_type=
     res = m.load_state_dict(state, strict=False)
     assert not res.unexpected_keys and not [k for k in res.missing_keys if 'lin_dst' not in k], res
     return m.to(device)
+
+
+def free_port():
+    """A TCP port that is free right now (bind to port 0): torch.distributed.run rendezvous of the multi-process tests -
+    a hard-coded port collides with a concurrent run or with a socket still in TIME_WAIT."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]

@@ -9,6 +9,8 @@ import sys
 
 import pytest
 
+from helpers import free_port
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ['--workload', 'synth-small', '--steps', '8', '--warmup', '2', '--pretrain_epochs', '3', '--no_cpu_baseline',
@@ -36,13 +38,29 @@ def test_bench_single_gpu_line():
 def test_bench_two_ranks_run_the_partitioned_step(probe):
     env = dict(os.environ, GD_BENCH_BACKEND='gloo', GD_BENCH_FORCE_PROBE=probe, HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(29611 + int(probe)), os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + SMALL
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + SMALL
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     d = _json_line(r.stdout)
     assert d['n_gpus'] == 2 and d['scaling'] == 'strong', d
     assert 'partition_fallback' not in d['config'], d['config']
     assert 'row-partition' in d['config']['parallelism']
-    assert d['config']['halo']['recv_bytes_per_step'] > 0
+    assert d['config']['halo']['recv_bytes_per_step'] > 0 and d['config']['ranks_seen'] == 2
+    assert len(d['config']['halo_recv_send_bytes_per_rank']) == 2 and 'interior_rows_forward' in d['config']['halo']
     assert d['extras']['iters_per_s_independent_replicas'] > 0
     assert d['value'] > 0 and abs(d['value'] - d['steps'] / (d['ms_per_step'] * d['steps'] / 1e3)) < 1e-6 * d['value']
+
+
+def test_bench_two_ranks_partition_the_rgcn_request():
+    """BASELINE config 4 over two ranks (gloo on the one-GPU box): the R-GCN request's target rows partitioned with typed
+    halos - `bench.py --gnn rgcn --gpus 2` as the driver launches it."""
+    env = dict(os.environ, GD_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--gnn', 'rgcn', '--workload',
+           'synth-kg-small', '--df_size', '2.5', '--steps', '6', '--warmup', '2', '--no_cpu_baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['config']['ranks_seen'] == 2, d
+    assert 'row-partition' in d['config']['parallelism'] and d['config']['halo']['recv_bytes_per_step'] > 0
+    assert len(d['config']['halo_recv_send_bytes_per_rank']) == 2 and d['value'] > 0

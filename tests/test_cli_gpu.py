@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import hip_model, load_golden, rel_l2, split_fixture, t
+from helpers import hip_model, load_golden, rel_l2, split_fixture, t, free_port
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -199,7 +199,7 @@ def test_minibatch_trainer_is_data_parallel_under_torch_distributed(tmp_path):
     subprocess.run([sys.executable, os.path.join(ROOT, 'delete_gnn.py')] + delete, cwd=cwd, env=env, check=True, capture_output=True)
     single = torch.load(os.path.join(out, 'model_final.pt'))['model_state']
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-                        '--master-port', '29561', os.path.join(ROOT, 'delete_gnn.py')] + delete, cwd=cwd, env=env, capture_output=True,
+                        '--master-port', str(free_port()), os.path.join(ROOT, 'delete_gnn.py')] + delete, cwd=cwd, env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     w0 = torch.load(os.path.join(out, 'model_final.pt'))['model_state']

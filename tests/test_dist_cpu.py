@@ -6,22 +6,26 @@ import sys
 
 import pytest
 
+from helpers import free_port
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def launch(mode, world, timeout=600, **extra_env):
-    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS='2', **extra_env)
+    env = {**os.environ, 'PYTHONPATH': ROOT, 'OMP_NUM_THREADS': '2', **extra_env}
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
-           '--master-addr', '127.0.0.1', '--master-port', str(29500 + world + (7 if mode == 'gpu' else 0)),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
            os.path.join(ROOT, 'tests', 'dist_worker.py'), mode]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0 and 'DIST_OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     return r.stdout
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 def test_partitioned_step_algebra_and_collectives_over_gloo(world):
-    launch('cpu', world)
+    """world 8 = the node the scaling curve is asked for: planner tiling, halo lists and the segment algebra with eight
+    row blocks (one thread per rank: the container has eight cores)."""
+    launch('cpu', world, OMP_NUM_THREADS='1' if world > 4 else '2')
 
 
 @pytest.mark.gpu
@@ -41,4 +45,22 @@ def test_partitioned_engine_over_rccl_in_a_world_of_one():
     `nccl` (= RCCL) group, between the hipGraph segments - in a world of one (GD_FORCE_COLLECTIVES=1 keeps the
     engine from skipping them), and checks the partitioned engine against the single-GPU engine."""
     out = launch('rccl1', 1, timeout=600, GD_FORCE_COLLECTIVES='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    assert out.count('partitioned == single') == 3
+
+
+@pytest.mark.gpu
+def test_partitioned_engine_over_the_library_owned_rccl_communicator():
+    """The same in a world of one over gd_comm_init / gd_allreduce_f32 / gd_exchange_rows_f32 (collectives.DirectComm): the
+    C-ABI collectives of include/gnndelete_hip.h driven by the engine between its hipGraph segments, plus the raw calls
+    (an all-reduce over one rank is the identity, a one-peer exchange a copy)."""
+    out = launch('direct1', 1, timeout=600, GD_FORCE_COLLECTIVES='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    assert out.count('partitioned == single') == 3 and 'direct collectives ok' in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world', [2, 3])
+def test_partitioned_rgcn_engine_matches_single_gpu_engine(world):
+    """BASELINE config 4's model over 2 / 3 ranks sharing cuda:0 (gloo): target rows partitioned, typed graph restricted
+    to the own rows, h-wide halo rows forward and o-wide backward, against the single-GPU fused R-GCN step."""
+    out = launch('rgcn', world, timeout=900)
     assert out.count('partitioned == single') == 3
