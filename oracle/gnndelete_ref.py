@@ -21,6 +21,7 @@ What each piece follows (paths relative to /root/reference):
   kg_nodeemb_minibatch     framework/trainer/gnndelete_nodeemb.py:734-800
   eval_kg                  framework/trainer/base.py:495-567
   retrain_fullbatch        framework/trainer/retrain.py:57-131
+  kg_retrain_minibatch     framework/trainer/retrain.py:235-339 (GraphSAINT batches injected)
   verification_error       framework/evaluation.py:63-81
   split_edges              prepare_dataset.py:31-136 (+ IN / OUT masks :205-214)
   original_minibatch       framework/trainer/base.py:144-227 (GraphSAINT batches injected)
@@ -535,6 +536,34 @@ def kg_original_minibatch(model, data, node_sets, num_edge_type, epochs, lr):
             label = torch.cat([torch.ones(dec.shape[1]), torch.zeros(neg.shape[1])])
             loss = F.binary_cross_entropy_with_logits(logits, label)
             loss.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+    return losses
+
+
+def kg_retrain_minibatch(model, data, node_sets, num_edge_type, epochs, lr):
+    """KGRetrainTrainer.train (framework/trainer/retrain.py:235-339) without validation: per GraphSAINT batch, message
+    passing and positives on the batch's Dr edges ONLY (the deleted triples never enter), DistMult scores of the
+    forward-direction types against per-relation head-shuffled negatives (global torch RNG), BCE-with-logits, gradient
+    norm clipped to 1 (:285), Adam on every parameter.  -> per-step train_loss."""
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    losses = []
+    for _ in range(epochs):
+        model.train()
+        for nodes in node_sets:
+            b = pyg.saint_subgraph(dict(data), nodes)
+            keep = b['dr_mask']
+            ei, et = b['edge_index'][:, keep], b['edge_type'][keep]
+            z = model(b['x'], ei, et)
+            fw = et < num_edge_type
+            dec, dec_t = ei[:, fw], et[fw]
+            neg = negative_sampling_kg(dec, dec_t)
+            logits = torch.cat([model.decode(z, dec, dec_t), model.decode(z, neg, dec_t)], -1)
+            label = torch.cat([torch.ones(dec.shape[1]), torch.zeros(neg.shape[1])])
+            loss = F.binary_cross_entropy_with_logits(logits, label)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1)
             opt.step()
             opt.zero_grad()
             losses.append(float(loss))

@@ -805,6 +805,45 @@ def golden_retrain(A):
     np.savez_compressed(os.path.join(HERE, 'retrain_gcn.npz'), **out)
 
 
+def golden_retrain_kg(A):
+    """KGRetrainTrainer.train (framework/trainer/retrain.py:235-339) on the reference's own RGCN at 21 relation types
+    (block-diagonal branch), injected GraphSAINT batches: message passing and positives on the batch's Dr edges only,
+    forward-direction types decoded against head-shuffled negatives (global torch RNG, recorded seed), gradient norm
+    clipped to 1, KGTrainer.eval for model selection."""
+    RT = importlib.import_module('framework.trainer.retrain')
+    RGCN = importlib.import_module('framework.models.rgcn').RGCN
+    R_, n = 21, 150
+    d = kg_request(n, 900, R_, seed=75, df_count=60)
+    args = make_args(A, ['--gnn', 'rgcn', '--unlearning_model', 'retrain', '--dataset', 'WordNet18', '--in_dim', '32',
+                         '--hidden_dim', '32', '--out_dim', '16', '--checkpoint_dir', tempfile.mkdtemp()])
+    args.epochs, args.valid_freq, args.num_steps, args.lr, args.num_edge_type = 2, 2, 3, 0.01, R_
+    torch.manual_seed(24)
+    model = RGCN(args, n, R_)
+    init = state_np(model)
+    model.to = lambda *a, **k: model
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    STATE['batches'] = _node_sets(n, 3, 110, seed=8)
+    STATE['wandb'] = []
+    torch.manual_seed(87)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')                  # (upstream ends with np.mean of an empty list)
+        RT.KGRetrainTrainer(args).train(model, d, opt, args)
+    steps = [w for w in STATE['wandb'] if 'step' in w]
+    vals = [w for w in STATE['wandb'] if 'val_loss' in w]
+    out = dict(init)
+    d2 = Bag({k: v for k, v in d.items()})
+    out.update(data_np(d2, torch.zeros(2, 0, dtype=torch.long)))
+    out.update({f'final::{k}': np_(v) for k, v in model.state_dict().items()})
+    for i, b in enumerate(STATE['batches']):
+        out[f'batch::{i}'] = np_(b)
+    out.update(n_batches=np.int64(3), num_edge_type=np.int64(R_), train_loss=np.array([s_['train_loss'] for s_ in steps]),
+               val_loss=np.array([v['val_loss'] for v in vals]), val_dt_auc=np.array([v['val_dt_auc'] for v in vals]),
+               val_dt_aup=np.array([v['val_dt_aup'] for v in vals]), val_df_auc=np.array([v['val_df_auc'] for v in vals]),
+               lr=np.float64(args.lr), epochs=np.int64(2), seed=np.int64(87))
+    np.savez_compressed(os.path.join(HERE, 'retrain_kg_rgcn.npz'), **out)
+
+
 def golden_split():
     """train_test_split_edges_no_neg_adj_mask (prepare_dataset.py:31-136) and the IN / OUT candidate masks
     (:205-214) run from the reference's own module: plain, with the two-hop-degree ordering the ogbl-* datasets
@@ -1237,6 +1276,10 @@ def main():
     if sys.argv[1:] == ['wide']:
         golden_wide_trajectories(D, T, A)
         return
+    if sys.argv[1:] == ['retrain_kg']:          # round 3
+        golden_retrain_kg(A)
+        write_manifest(None)
+        return
     if sys.argv[1:] == ['process_kg']:
         golden_process_kg()
         write_manifest(None)
@@ -1256,6 +1299,7 @@ def main():
     golden_minibatch(D, T, A)
     golden_kg(D, T, A, B)
     golden_retrain(A)
+    golden_retrain_kg(A)
     golden_split()
     golden_wide_trajectories(D, T, A)
     golden_original_minibatch(B, A)

@@ -521,3 +521,37 @@ def test_original_minibatch_trainers_reproduce_reference(tmp_path, monkeypatch):
         assert rel_l2(v.cpu(), final[k]) < 2e-4, k
     vals = [r for r in tr.trainer_log['log'] if 'val_dt_aup' in r]
     assert abs(vals[-1]['val_dt_aup'] - float(rest['val_dt_aup'][-1])) < 2e-3
+
+
+def test_kg_retrain_trainer_reproduces_reference(tmp_path, monkeypatch):
+    """KGRetrainTrainer.train (framework/trainer/retrain.py:235-339) on the HIP convs, on the batches / negatives stream the
+    reference's loop consumed (retrain_kg_rgcn.npz, recorded from the reference's own KGRetrainTrainer + RGCN at 21
+    relation types): per-step losses, final weights (gradient-norm clipping included), validation figures."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework import get_model
+    from gnndelete_amd.framework.data import Data
+    from gnndelete_amd.framework.trainer import retrain as TR
+    from gnndelete_amd.framework.trainer import sampler as S
+    fx = load_golden('retrain_kg_rgcn.npz')
+    state, data, rest = split_fixture(fx)
+    R_ = int(rest['num_edge_type'])
+    sets = _lists(fx, 'batch', 'n_batches')
+    monkeypatch.setattr(S, 'make_sampler', lambda d, batch_size, num_steps, walk_length=2: S.FixedNodeSets(d, sets))
+    epochs = int(rest['epochs'])
+    args = SimpleNamespace(unlearning_model='retrain', gnn='rgcn', dataset='WordNet18', checkpoint_dir=str(tmp_path),
+                           in_dim=state['node_emb.weight'].shape[1], hidden_dim=state['conv1.root'].shape[1],
+                           out_dim=state['conv2.root'].shape[1], eval_on_cpu=False, epochs=epochs, valid_freq=epochs,
+                           lr=float(rest['lr']), num_steps=len(sets), num_edge_type=R_)
+    m = get_model(args, num_nodes=data['num_nodes'], num_edge_type=R_)
+    m.load_state_dict(state)
+    opt = torch.optim.Adam(m.parameters(), lr=args.lr)
+    tr = TR.KGRetrainTrainer(args)
+    torch.manual_seed(int(rest['seed']))
+    tr.train(m, Data(data), opt, args)
+    np.testing.assert_allclose([s_['train_loss'] for s_ in tr.trainer_log['steps']], rest['train_loss'], rtol=2e-4)
+    final = {k[len('final::'):]: v for k, v in fx.items() if k.startswith('final::')}
+    for k, v in m.state_dict().items():
+        assert rel_l2(v.cpu(), final[k]) < 2e-4, k
+    vals = [r for r in tr.trainer_log['log'] if 'val_dt_aup' in r]
+    assert abs(vals[-1]['val_dt_aup'] - float(rest['val_dt_aup'][-1])) < 2e-3
+    assert os.path.exists(os.path.join(str(tmp_path), 'model_best.pt'))

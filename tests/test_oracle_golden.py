@@ -382,3 +382,23 @@ def test_original_minibatch_training_matches_reference_loops():
         assert rel_l2(v, final[k]) < 2e-5, k
     ev = R.eval_kg(m, data, 'val', unlearning_model='original')
     assert abs(ev['dt_aup'] - float(rest['val_dt_aup'][-1])) < 1e-6 and abs(ev['loss'] - float(rest['val_loss'][-1])) < 1e-4 * ev['loss']
+
+
+def test_kg_retrain_matches_reference_loop():
+    """KGRetrainTrainer.train (retrain.py:235-339) on the reference's own RGCN (21 relation types) with injected batches:
+    the oracle reproduces the per-step losses, the final weights (gradient clipping included) and the validation figures."""
+    fx = load_golden('retrain_kg_rgcn.npz')
+    state, data, rest = split_fixture(fx)
+    R_ = int(rest['num_edge_type'])
+    i, h, o = state['node_emb.weight'].shape[1], state['conv1.root'].shape[1], state['conv2.root'].shape[1]
+    m = R.TwoLayer('rgcn', i, h, o, num_nodes=data['num_nodes'], num_edge_type=R_)
+    m.load_state_dict(state)
+    assert int(data['df_mask'].sum()) > 0 and not bool((data['df_mask'] & data['dr_mask']).any())
+    torch.manual_seed(int(rest['seed']))
+    losses = R.kg_retrain_minibatch(m, data, _fixture_lists(fx, 'batch', 'n_batches'), R_, int(rest['epochs']), float(rest['lr']))
+    np.testing.assert_allclose(losses, rest['train_loss'], rtol=5e-5)
+    final = {k[len('final::'):]: v for k, v in fx.items() if k.startswith('final::')}
+    for k, v in m.state_dict().items():
+        assert rel_l2(v, final[k]) < 2e-5, k
+    ev = R.eval_kg(m, data, 'val', unlearning_model='retrain')
+    assert abs(ev['dt_aup'] - float(rest['val_dt_aup'][-1])) < 1e-6 and abs(ev['loss'] - float(rest['val_loss'][-1])) < 1e-4 * ev['loss']
