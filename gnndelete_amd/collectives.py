@@ -29,6 +29,7 @@ class DirectComm:
         import ctypes
         from . import _lib
         self.rank, self.world, self.device = rank, world, torch.device(device)
+        self._bootstrap = bootstrap_group
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             _lib.check(_lib.lib().gd_comm_unique_id(uid.data_ptr()), 'gd_comm_unique_id')
@@ -42,7 +43,15 @@ class DirectComm:
 
     def all_reduce(self, buf):
         from . import _lib
-        assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
+        if buf.dtype != torch.float32:
+            # set-up values only (the fp64 constants of the folded losses, once per request): over the host-side
+            # bootstrap group - the data path of a step is fp32 and goes through gd_allreduce_f32
+            if self.world > 1:
+                host = buf.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self._bootstrap)
+                buf.copy_(host)
+            return
+        assert buf.is_cuda and buf.is_contiguous()
         _lib.check(_lib.lib().gd_allreduce_f32(buf.data_ptr(), buf.numel(), self._comm, _lib.stream_ptr(buf.device)),
                    'gd_allreduce_f32')
 
