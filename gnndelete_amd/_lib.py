@@ -83,6 +83,9 @@ PROTOTYPES = {
     'gd_pairs_sigmoid_mse_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _i32, _p, _i64, _f32, _p, _p, _p, _p]),
     'gd_adam_at_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _p]),
     'gd_adam_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _p]),
+    'gd_segment_softmax_f32': (ctypes.c_int, [_p, _p, _i32, _p, _p]),
+    'gd_segment_softmax_bwd_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p]),
+    'gd_rowpair_dot_f32': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
     'gd_comm_unique_id': (ctypes.c_int, [_p]),
     'gd_comm_init': (ctypes.c_int, [_p, _i32, _i32, ctypes.POINTER(ctypes.c_void_p)]),
     'gd_comm_destroy': (ctypes.c_int, [_p]),

@@ -180,8 +180,11 @@ class RGATConv(nn.Module):
 
     The attention logit of an edge (j -> i, r) is  leaky_relu(x_i W_r q + x_j W_r k) = A[i, r] + B[j, r]  with
     A = x (W q)^T, B = x (W k)^T two [N, R] tables (one small GEMM each) instead of two per-edge transforms;
+    the softmax across the relations of a target node is gd_segment_softmax_f32 (forward and backward);
     the aggregation  y_i = sum_e alpha_e x_j W_r  is the typed conv kernel with alpha as edge weights under
-    no_grad (evaluation), and a per-relation autograd loop otherwise (training runs on sampled subgraphs)."""
+    no_grad (evaluation) and, with gradients, a weighted typed SpMM over the relation-major CSR (rows r * n + i,
+    differentiable in x and in alpha: ops.typed_weighted_sum) followed by the relation-wise transform - no Python
+    loop over relations, no host synchronisation."""
 
     def __init__(self, in_channels, out_channels, num_relations, num_blocks=None, negative_slope=0.2):
         super().__init__()
@@ -216,27 +219,59 @@ class RGATConv(nn.Module):
         vb = v.view(self.num_blocks, -1)
         return torch.einsum('rbio,bo->rbi', self.weight, vb).reshape(self.num_relations, self.in_channels)
 
+    def _edge_orders(self, edge_index, edge_type, n):
+        """Index structure of one (edge_index, edge_type) pair, built once on the device and cached: the edges grouped by
+        target (softmax segments), the relation-major typed CSR (rows r * n + i) and its transpose by source."""
+        c, key = getattr(self, '_orders', None), (_tensor_key(edge_index, edge_type), n)
+        if c is not None and c[0] == key:
+            return c[1]
+        dev = edge_index.device
+        src, dst, et = edge_index[0].long(), edge_index[1].long(), edge_type.long()
+        r = self.num_relations
+        if r * n >= 2 ** 31:
+            raise ValueError('num_relations * num_nodes overflows int32')
+        ord_d = torch.argsort(dst, stable=True)
+        rowptr_d = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        rowptr_d[1:] = torch.cumsum(torch.bincount(dst, minlength=n), 0)
+        vrow = et * n + dst
+        ord_v = torch.argsort(vrow * n + src)
+        rowptr_v = torch.zeros(r * n + 1, dtype=torch.int64, device=dev)
+        rowptr_v[1:] = torch.cumsum(torch.bincount(vrow, minlength=r * n), 0)
+        ord_t = torch.argsort(src * (r * n) + vrow)
+        rowptr_t = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        rowptr_t[1:] = torch.cumsum(torch.bincount(src, minlength=n), 0)
+        pos_v = torch.empty_like(ord_v)
+        pos_v[ord_v] = torch.arange(ord_v.numel(), device=dev)
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        tc = dict(n=n, n_vrows=r * n, ord_d=ord_d, rowptr_d=i32(rowptr_d), ord_v=ord_v, rowptr_v=i32(rowptr_v),
+                  col_v=i32(src[ord_v]), vrow_v=i32(vrow[ord_v]), rowptr_t=i32(rowptr_t), col_t=i32(vrow[ord_t]),
+                  v_of_t=pos_v[ord_t], keep=(edge_index, edge_type))
+        inv_d = torch.empty_like(ord_d)
+        inv_d[ord_d] = torch.arange(ord_d.numel(), device=dev)
+        tc['inv_d'] = inv_d
+        self._orders = (key, tc)
+        return tc
+
     def forward(self, x, edge_index, edge_type):
         n = x.shape[0]
         src, dst, et = edge_index[0], edge_index[1], edge_type
         a = x @ self._relation_vectors(self.q).t()                      # [N, R]
         b = x @ self._relation_vectors(self.k).t()
         e = F.leaky_relu(a[dst, et] + b[src, et], self.negative_slope)
-        m = torch.full((n,), float('-inf'), dtype=e.dtype, device=e.device).index_reduce_(0, dst, e.detach(), 'amax')
-        ex = torch.exp(e - m[dst])
-        alpha = ex / (torch.zeros(n, dtype=e.dtype, device=e.device).index_add_(0, dst, ex)[dst] + 1e-16)
         nb = 1 if self.num_blocks is None else self.num_blocks
+        if not x.is_cuda or e.numel() == 0:
+            raise ops._lib.GnnDeleteHipError('RGATConv needs CUDA(HIP) tensors and a non-empty edge list (no CPU fallback)')
+        tc = self._edge_orders(edge_index, edge_type, n)
+        # softmax across ALL in-edges of a target node, whatever their relation (rgat.py: attention_mode
+        # 'additive-self-attention', across-relation): segments = the edges grouped by target
+        alpha = ops.segment_softmax(e[tc['ord_d']], tc['rowptr_d'])[tc['inv_d']]
         even = (self.in_channels // nb) % 2 == 0 and (self.out_channels // nb) % 2 == 0
         if not torch.is_grad_enabled() and even and self.in_channels <= 128 and self.out_channels <= 128:
             tg = self._typed_node_csr(edge_index, edge_type, n)
             return ops.rgat_aggregate_nograd(x, tg, alpha, self.weight, self.bias, nb, self.out_channels)
-        out = torch.zeros(n, self.out_channels, dtype=x.dtype, device=x.device)
-        for r in torch.unique(et).tolist():
-            sel = (et == r).nonzero().flatten()
-            xj = x[src[sel]]
-            if self.num_blocks is None:
-                msg = xj @ self.weight[r]
-            else:
-                msg = torch.einsum('ebi,bio->ebo', xj.view(sel.numel(), nb, -1), self.weight[r]).reshape(sel.numel(), -1)
-            out = out.index_add(0, dst[sel], alpha[sel, None] * msg)
+        m = ops.typed_weighted_sum(x, alpha[tc['ord_v']], tc).view(self.num_relations, n, self.in_channels)
+        if self.num_blocks is None:
+            out = torch.einsum('rni,rio->no', m, self.weight)
+        else:
+            out = torch.einsum('rnbi,rbio->nbo', m.view(self.num_relations, n, nb, -1), self.weight).reshape(n, self.out_channels)
         return out + self.bias

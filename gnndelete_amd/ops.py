@@ -674,6 +674,67 @@ def rgat_aggregate_nograd(x, tg, alpha, weight, bias, n_blocks, out_dim):
     return y
 
 
+class _SegmentSoftmax(torch.autograd.Function):
+    """alpha = softmax of e over the rows of a CSR (gd_segment_softmax_f32), differentiable in e."""
+
+    @staticmethod
+    def forward(ctx, e, rowptr):
+        e = e.contiguous().float()
+        alpha = torch.zeros_like(e)
+        check(_lib.lib().gd_segment_softmax_f32(ptr(rowptr), ptr(e), int(rowptr.numel()) - 1, ptr(alpha), stream_ptr(e.device)),
+              'gd_segment_softmax_f32')
+        ctx.save_for_backward(alpha, rowptr)
+        return alpha
+
+    @staticmethod
+    def backward(ctx, dalpha):
+        alpha, rowptr = ctx.saved_tensors
+        dalpha = dalpha.contiguous().float()
+        de = torch.zeros_like(alpha)
+        check(_lib.lib().gd_segment_softmax_bwd_f32(ptr(rowptr), ptr(alpha), ptr(dalpha), int(rowptr.numel()) - 1, ptr(de),
+                                                    stream_ptr(alpha.device)), 'gd_segment_softmax_bwd_f32')
+        return de, None
+
+
+def segment_softmax(e, rowptr):
+    """e [nnz] in CSR order, rowptr int32 [n + 1] -> alpha [nnz]."""
+    return _SegmentSoftmax.apply(e, rowptr)
+
+
+class _TypedWeightedSum(torch.autograd.Function):
+    """m[(r, i), :] = sum over the type-r in-edges e of i of alpha_e x[src_e, :] - the weighted typed aggregation of
+    RGATConv's messages (rgat.py:322-337) over a relation-major CSR (rows r * n + i), differentiable in x AND in the
+    edge weights: dx through the transposed CSR with the same weights, d alpha_e = <dm[row(e)], x[src(e)]> (gd_rowpair_dot_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha_v, tc):
+        x = _f32_rows(x)
+        alpha_v = alpha_v.contiguous().float()
+        m = _spmm_raw(tc['rowptr_v'], tc['col_v'], alpha_v, x, None, 0.0, tc['n_vrows'])
+        ctx.tc = tc
+        ctx.save_for_backward(x, alpha_v)
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        x, alpha_v = ctx.saved_tensors
+        tc = ctx.tc
+        dm = _f32_rows(dm)
+        dx = dalpha = None
+        if ctx.needs_input_grad[0]:
+            dx = _spmm_raw(tc['rowptr_t'], tc['col_t'], alpha_v[tc['v_of_t']].contiguous(), dm, None, 0.0, tc['n'])
+        if ctx.needs_input_grad[1]:
+            dalpha = torch.empty_like(alpha_v)
+            nnz = int(alpha_v.numel())
+            check(_lib.lib().gd_rowpair_dot_f32(ptr(dm), dm.stride(0), ptr(tc['vrow_v']), ptr(x), x.stride(0), ptr(tc['col_v']), nnz,
+                                                x.shape[1], ptr(dalpha), stream_ptr(x.device)), 'gd_rowpair_dot_f32')
+        return dx, dalpha, None
+
+
+def typed_weighted_sum(x, alpha_v, tc):
+    return _TypedWeightedSum.apply(x, alpha_v, tc)
+
+
 def rgcn_conv_frozen(x, tg, weight, root, bias, n_blocks):
     return _RgcnConvFrozen.apply(x, tg, weight, root, bias, n_blocks)
 

@@ -34,7 +34,7 @@ extern "C" {
 
 #define GD_ABI_VERSION 4   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
                               4: gd_spmm_csr_onepass_f32, gd_rows_gemm_wgrad_reduce_f32 (dw = NULL in the wgrad entries),
-                                 gd_comm_* / gd_allreduce_f32 / gd_exchange_rows_f32 */
+                                 gd_comm_* / gd_allreduce_f32 / gd_exchange_rows_f32, gd_segment_softmax_f32, gd_rowpair_dot_f32 */
 
 enum {
   GD_OK = 0,
@@ -514,6 +514,22 @@ int gd_adam_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_
 /* gd_adam_f32 with the step number read from a shared iteration counter (t = *iter + 1). */
 int gd_adam_at_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int32_t* iter,
                    int64_t n, double lr, double beta1, double beta2, double eps, void* stream);
+
+/* ---------------------------------------------------------------- relational attention -- */
+
+/* Softmax over the entries of every CSR row (torch_geometric.utils.softmax as the reference's RGATConv calls it across
+ * the relations of a target node, framework/models/rgat.py:322-337):
+ *     alpha[k] = exp(e[k] - max_row) / (sum_row exp(e - max_row) + 1e-16),   k in [rowptr[i], rowptr[i+1])
+ * and its backward  de[k] = alpha[k] (dalpha[k] - sum_row alpha dalpha).  Empty rows are skipped. */
+int gd_segment_softmax_f32(const int32_t* rowptr, const float* e, int32_t n_rows, float* alpha, void* stream);
+int gd_segment_softmax_bwd_f32(const int32_t* rowptr, const float* alpha, const float* dalpha, int32_t n_rows,
+                               float* de, void* stream);
+
+/* out[k] = < a[ia[k], :], b[ib[k], :] > for k < n: the gradient of an edge weight of a weighted typed aggregation,
+ * d alpha_e = < dm[(relation, target) row of e, :], x[source of e, :] > (autograd of the alpha_e x_j messages,
+ * rgat.py:322-337).  float4 path for d % 4 == 0 with 16-byte aligned rows, any d otherwise. */
+int gd_rowpair_dot_f32(const float* a, int64_t ld_a, const int32_t* ia, const float* b, int64_t ld_b, const int32_t* ib,
+                       int64_t n, int32_t d, float* out, void* stream);
 
 /* ---------------------------------------------------------------- collectives (RCCL) ---- */
 

@@ -1032,3 +1032,42 @@ def test_rowpair_loss_kernels_match_torch_forms(n, d):
         got.backward(up.cuda())
         assert rel_l2(got.detach().cpu(), want.detach()) < TOL, kind
         assert rel_l2(ag.grad.cpu(), ad.grad) < 10 * TOL, kind
+
+
+@pytest.mark.parametrize('n,m,R,d', [(60, 500, 5, 32), (300, 4000, 21, 128), (40, 0, 3, 8), (50, 700, 4, 10)])
+def test_segment_softmax_and_typed_weighted_sum_match_autograd(n, m, R, d):
+    """The RGAT attention pieces (framework/models/rgat.py:322-337): softmax over the in-edges of a target node across
+    relations (gd_segment_softmax_f32 fwd / bwd) and the alpha-weighted typed aggregation with gradients to x and to
+    alpha (SpMM over the relation-major CSR, its transpose, gd_rowpair_dot_f32) against dense fp64 autograd."""
+    from gnndelete_amd import nn as gnn, ops
+    g = torch.Generator().manual_seed(n + d)
+    src, dst = torch.randint(0, n, (m,), generator=g), torch.randint(0, n, (m,), generator=g)
+    et = torch.randint(0, R, (m,), generator=g)
+    x = torch.randn(n, d, generator=g)
+    e = torch.randn(m, generator=g)
+    up_a, up_m = torch.randn(m, generator=g), torch.randn(R * n, d, generator=g)
+    # fp64 reference
+    e64 = e.double().requires_grad_(True)
+    x64 = x.double().requires_grad_(True)
+    mx = torch.full((n,), float('-inf'), dtype=torch.float64).index_reduce(0, dst, e64.detach(), 'amax') if m else None
+    if m:
+        ex = torch.exp(e64 - mx[dst])
+        alpha64 = ex / (torch.zeros(n, dtype=torch.float64).index_add(0, dst, ex)[dst] + 1e-16)
+    else:
+        alpha64 = e64
+    m64 = torch.zeros(R * n, d, dtype=torch.float64).index_add(0, et * n + dst, alpha64[:, None] * x64[src])
+    ((alpha64 * up_a.double()).sum() + (m64 * up_m.double()).sum()).backward()
+    if m == 0:
+        return
+    conv = gnn.RGATConv(d, d, R)
+    ei, etc = torch.stack([src, dst]).cuda(), et.cuda()
+    tc = conv._edge_orders(ei, etc, n)
+    eg = e.cuda().requires_grad_(True)
+    xg = x.cuda().requires_grad_(True)
+    alpha = ops.segment_softmax(eg[tc['ord_d']], tc['rowptr_d'])[tc['inv_d']]
+    mm = ops.typed_weighted_sum(xg, alpha[tc['ord_v']], tc)
+    ((alpha * up_a.cuda()).sum() + (mm * up_m.cuda()).sum()).backward()
+    assert rel_l2(alpha.detach().cpu(), alpha64.detach()) < TOL
+    assert rel_l2(mm.detach().cpu(), m64.detach()) < TOL
+    assert rel_l2(xg.grad.cpu(), x64.grad) < TOL
+    assert rel_l2(eg.grad.cpu(), e64.grad) < 2e-5
