@@ -112,8 +112,10 @@ class PartitionedNodeembEngine:
         # constants of the folded losses are per-rank partial sums: reduce them (and the feasibility flag) once
         k = torch.cat([torch.tensor(self.t1.k_const + self.t2.k_const, dtype=torch.float64, device=dev), ok])
         all_reduce_sum(k, world, group)
-        if int(round(float(k[4]))) != world:
+        if int(round(float(k[4]))) != world and self._mode != 'rgcn':
             raise NotImplementedError('partitioned step: a loss row lies outside its Del row list on some rank')
+        if self._mode == 'rgcn' and not (self.t1.folded and self.t2.folded):
+            raise NotImplementedError('partitioned R-GCN step: a row carries both DEC and NI terms')
         self.k_const = k[:4].tolist()
         f32 = dict(dtype=torch.float32, device=dev)
 
@@ -186,6 +188,12 @@ class PartitionedNodeembEngine:
         if self._mode == 'rgcn':
             self.hbuf = torch.zeros(n, self.h, **f32)               # relu(z1 | pre1): own rows + received halo rows
             self.dxbuf = torch.zeros(n, self.h, **f32)              # conv2's input gradient on the own rows
+            # The KG trainer passes the NON-Df masks as Del masks (gnndelete_nodeemb.py:749-751) while its DEC rows are the
+            # Df endpoints: loss rows lie OUTSIDE the Del row lists, so this mode runs the general stages - in-place Del
+            # operators on copies of the conv outputs, the folded row-target loss kernel, explicit [N, d] gradients
+            self.dz1 = torch.zeros(n, self.h, **f32)
+            self.z2 = torch.zeros(n, self.o, **f32)
+            self.l_sums = torch.zeros(4, **f32)
         self.t1buf = torch.zeros(n, self.h, **f32)                  # x W1^T on the rows need1 (others never read)
         self.t1rbuf = torch.zeros(n, self.h, **f32) if self._mode == 'sage' else None
         self.aggbuf = torch.zeros(n, x.shape[1], **f32) if self._gin_agg_first else None
@@ -271,32 +279,61 @@ class PartitionedNodeembEngine:
 
     def _seg_a_rgcn(self):
         c1 = self.model.conv1
+        lo, hi = self.lo, self.hi
         self._rgcn_conv_own(c1, self.x, self.pre1, 0, self.own)          # x is replicated: layer 1 needs no halo
+        self.z1[lo:hi] = self.pre1[lo:hi]                                 # rows outside S1 pass through Del-1 unchanged
         if self.s1:
             ops.rows_gemm(self.pre1, self.idx1, self.wd1, out=self.z1, sign_bits=self.z1_pos)
+        self.l_sums.zero_()
+        if self.t1.n_rows:
+            self.t1.launch(self.z1, self.dz1, self.l_sums[0:2])          # layer-1 loss sums + dz1 on the loss rows
         if self.loss_type != 'only1':
-            lo, hi = self.lo, self.hi
-            torch.where(self._sel1[lo:hi].bool()[:, None], self.z1[lo:hi], self.pre1[lo:hi], out=self.hbuf[lo:hi])
-            self.hbuf[lo:hi].clamp_(min=0)
+            torch.clamp(self.z1[lo:hi], min=0, out=self.hbuf[lo:hi])
             if self.halo_f.n_send:
                 torch.index_select(self.hbuf, 0, self.halo_f.send_rows, out=self.send_f)
 
+    def _wgrad1_rgcn(self, g_add):
+        """p_g1 = pre1[S1]^T (dz1 [+ g_add])[S1] over the own S1 rows (dz1 = 0 on rows without loss terms)."""
+        if self.s1 == 0:
+            self.p_g1.zero_()
+            return
+        check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(self.pre1), self.pre1.stride(0), ptr(self.idx1), ptr(self.dz1),
+                                                self.dz1.stride(0), ptr(self.idx1), None, ptr(g_add), self.s1, self.h, self.h,
+                                                ptr(self.p_g1), 0, ptr(self.ws1), stream_ptr(self.x.device)), 'gd_rows_gemm_wgrad_f32')
+
+    def _layer1_partials_rgcn(self):
+        lt = self.loss_type
+        if lt == 'both_layerwise':
+            self._wgrad1_rgcn(self.dh)                    # dh = the PREVIOUS iteration's layer-2 gradient (SURVEY F6)
+        elif lt == 'only1':
+            self._wgrad1_rgcn(None)
+        else:
+            self.p_g1.zero_()
+
     def _seg_b_rgcn(self):
         lt = self.loss_type
+        lo, hi = self.lo, self.hi
         if lt == 'only1':
-            self._lp2.zero_()
             self.p_g2.zero_()
             return
         if self.halo_f.n_recv:
             self.hbuf.index_copy_(0, self.halo_f.recv_rows, self.recv_f)
         self._rgcn_conv_own(self.model.conv2, self.hbuf, self.p2, 0, self.own)
+        self.z2[lo:hi] = self.p2[lo:hi]
         if self.s2:
-            check(_lib.lib().gd_del_loss_bwd_f32(
-                ptr(self.p2), self.p2.stride(0), ptr(self.idx2), self.s2, ptr(self.wd2), self.o, ptr(self._slot2),
-                ptr(self._tm2), ptr(self._coef2), ptr(self._cnt_signed2), ptr(self.dz2c), self.dz2c.stride(0),
-                ptr(self.dz2), self.dz2.stride(0), ptr(self._lp2), stream_ptr(self.x.device)), 'gd_del_loss_bwd_f32')
+            ops.rows_gemm(self.p2, self.idx2, self.wd2, out=self.z2)
+        self.dz2[lo:hi].zero_()
+        if self.t2.n_rows:
+            self.t2.launch(self.z2, self.dz2, self.l_sums[2:4])           # dz2 on the loss rows
+        if self.s2:
+            check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(self.p2), self.p2.stride(0), ptr(self.idx2), ptr(self.dz2),
+                                                    self.dz2.stride(0), ptr(self.idx2), None, None, self.s2, self.o, self.o,
+                                                    ptr(self.p_g2), 0, ptr(self.ws2), stream_ptr(self.x.device)),
+                  'gd_rows_gemm_wgrad_f32')
+            if self.needs_l2_to_w1:
+                ops.rows_gemm(self.dz2, self.idx2, self.wd2, trans_w=True, out=self.dz2)     # dz2 -> dp2 on the Del'd rows
         else:
-            self._lp2.zero_()
+            self.p_g2.zero_()
         if self.needs_l2_to_w1 and self.halo_b.n_send:
             torch.index_select(self.dz2, 0, self.halo_b.send_rows, out=self.send_b)
 
@@ -309,13 +346,16 @@ class PartitionedNodeembEngine:
                 self._rgcn_conv_own(self.model.conv2, self.dz2, self.dxbuf, 1, self.own)
                 ops.gate_rows(self.dxbuf, self.idx1, self.z1_pos, self.dh)       # ReLU backward from the packed sign bits
             if lt == 'both_all':
-                self._wgrad1_partial(True, self.dh)
+                self._wgrad1_rgcn(self.dh)
             elif lt == 'only2_all':
-                lp1 = self._lp1.clone()
-                self._wgrad1_partial(False, self.dh) if self.s1 else self.p_g1.zero_()
-                self._lp1.copy_(lp1)
-        self.p_sums[0:2] = self._lp1.view(-1, 2)[:max(self._lp1_blocks, 1)].sum(0)
-        self.p_sums[2:4] = self._lp2.view(-1, 2)[:max(self._lp2_blocks, 1)].sum(0)
+                if self.s1:
+                    check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(self.pre1), self.pre1.stride(0), ptr(self.idx1), ptr(self.dh),
+                                                            self.dh.stride(0), ptr(self.idx1), None, None, self.s1, self.h, self.h,
+                                                            ptr(self.p_g1), 0, ptr(self.ws1), stream_ptr(self.x.device)),
+                          'gd_rows_gemm_wgrad_f32')
+                else:
+                    self.p_g1.zero_()
+        self.p_sums.copy_(self.l_sums)
 
     # ------------------------------------------------------------------ the four segments
     def _seg_a(self):
@@ -518,9 +558,8 @@ class PartitionedNodeembEngine:
             return [self._seg_a, ('x', 'halo_f', 'sync'), self._seg_b, self._seg_c_gat_edges, ('x', 'halo_r', 'sync'),
                     self._seg_c, ('x', 'reduce', 'sync'), self._seg_d]
         if self._mode == 'rgcn':          # the partial weight gradients run under the exchanges
-            return [self._seg_a_rgcn, ('x', 'halo_f', 'async'), self._layer1_partials, ('x', None, 'wait'), self._seg_b_rgcn,
-                    ('x', 'halo_b', 'async'), self._wgrad2_partial_if_used, ('x', None, 'wait'), self._seg_c_rgcn,
-                    ('x', 'reduce', 'sync'), self._seg_d]
+            return [self._seg_a_rgcn, ('x', 'halo_f', 'async'), self._layer1_partials_rgcn, ('x', None, 'wait'), self._seg_b_rgcn,
+                    ('x', 'halo_b', 'sync'), self._seg_c_rgcn, ('x', 'reduce', 'sync'), self._seg_d]
         return [self._seg_a, ('x', 'halo_f', 'async'), self._seg_a2, ('x', None, 'wait'), self._seg_b,
                 ('x', 'halo_b', 'async'), self._seg_b2, ('x', None, 'wait'), self._seg_c, ('x', 'reduce', 'sync'), self._seg_d]
 

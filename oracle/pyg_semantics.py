@@ -42,15 +42,15 @@ def gcn_norm(edge_index, num_nodes, dtype=torch.float32):
     (scatter over the target column) including the loop; multi-edges count."""
     ei = with_single_self_loops(edge_index, num_nodes)
     src, dst = ei[0], ei[1]
-    w = torch.ones(ei.shape[1], dtype=dtype)
-    deg = torch.zeros(num_nodes, dtype=dtype).index_add_(0, dst, w)
+    w = torch.ones(ei.shape[1], dtype=dtype, device=ei.device)
+    deg = torch.zeros(num_nodes, dtype=dtype, device=ei.device).index_add_(0, dst, w)
     dis = deg.pow(-0.5)
     dis[torch.isinf(dis)] = 0.0
     return ei, dis[src] * w * dis[dst]
 
 
 def scatter_rows(msg, dst, num_nodes):
-    out = torch.zeros(num_nodes, msg.shape[1], dtype=msg.dtype)
+    out = torch.zeros(num_nodes, msg.shape[1], dtype=msg.dtype, device=msg.device)
     return out.index_add(0, dst, msg)
 
 
