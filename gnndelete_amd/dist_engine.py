@@ -120,7 +120,8 @@ class PartitionedNodeembEngine:
         f32 = dict(dtype=torch.float32, device=dev)
 
         def slots(terms, idx, n_sel):
-            if terms.n_rows == 0:
+            # (R-GCN: the loss rows are not members of the Del row lists - no slots, the general loss stages are used)
+            if terms.n_rows == 0 or self._mode == 'rgcn':
                 return (torch.full((max(n_sel, 1),), -1, dtype=torch.int32, device=dev), torch.zeros(1, **f32))
             return _loss_slots(terms, idx, n_sel, dev)
         self._slot1, self._cnt_signed1 = slots(self.t1, self.idx1, self.s1)

@@ -1071,3 +1071,37 @@ def test_segment_softmax_and_typed_weighted_sum_match_autograd(n, m, R, d):
     assert rel_l2(mm.detach().cpu(), m64.detach()) < TOL
     assert rel_l2(xg.grad.cpu(), x64.grad) < TOL
     assert rel_l2(eg.grad.cpu(), e64.grad) < 2e-5
+
+
+@pytest.mark.parametrize('n,m,R,world', [(4000, 60000, 25, 2), (1000, 30000, 51, 3), (300, 2000, 25, 2)])
+def test_typed_conv_on_a_row_partition_matches_the_whole_graph(n, m, R, world):
+    """TypedNodeCSR(row_range=...): a rank's share of the typed graph - in-edges of its target rows forward, out-edges of
+    its source rows (with the GLOBAL mean weights) for the input gradient - through the (tile, relation) conv kernel
+    gives, on the rank's rows, exactly what the whole graph gives (same summation order per row)."""
+    from gnndelete_amd import ops
+    from gnndelete_amd.graph import TypedNodeCSR
+    g = torch.Generator().manual_seed(n + R)
+    src, dst = torch.randint(0, n, (m,), generator=g), torch.randint(0, n, (m,), generator=g)
+    et = torch.randint(0, R, (m,), generator=g)
+    ei = torch.stack([torch.cat([src, dst]), torch.cat([dst, src])]).cuda()
+    ety = torch.cat([et, et + R]).cuda()
+    nr, nb = 2 * R, 4
+    x = torch.randn(n, 128, generator=g).cuda()
+    dy = torch.randn(n, 64, generator=g).cuda()
+    w2 = (torch.randn(nr, nb, 32, 16, generator=g) * 0.2).cuda()
+    full = TypedNodeCSR(ei, ety, n, nr)
+    y = torch.zeros(n, 64, device='cuda')
+    ops.rgcn_typed_accumulate(full, x, w2, nb, 0, y)
+    dx = torch.zeros(n, 128, device='cuda')
+    ops.rgcn_typed_accumulate(full, dy, w2, nb, 1, dx)
+    chunk = (n + world - 1) // world
+    for rank in range(world):
+        lo, hi = min(n, rank * chunk), min(n, (rank + 1) * chunk)
+        part = TypedNodeCSR(ei, ety, n, nr, row_range=(lo, hi))
+        yr = torch.zeros(n, 64, device='cuda')
+        ops.rgcn_typed_accumulate(part, x, w2, nb, 0, yr)
+        dxr = torch.zeros(n, 128, device='cuda')
+        ops.rgcn_typed_accumulate(part, dy, w2, nb, 1, dxr)
+        torch.cuda.synchronize()
+        assert torch.equal(yr[lo:hi], y[lo:hi]) and torch.equal(dxr[lo:hi], dx[lo:hi]), rank
+        assert float(yr[:lo].abs().sum()) == 0 and float(yr[hi:].abs().sum()) == 0
