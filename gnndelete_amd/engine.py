@@ -187,7 +187,12 @@ class NodeembEngine:
             if any((c.in_channels // (c.num_blocks or 1)) % 2 or (c.out_channels // (c.num_blocks or 1)) % 2
                    or c.in_channels > 128 or c.out_channels > 128 for c in (conv1, conv2)):
                 raise NotImplementedError('NodeembEngine: R-GCN widths outside the typed conv kernel (<= 128, even blocks)')
-            reorder = cache_layer1 = affected_rows_only = False
+            # No locality order here (GD_RGCN_REORDER=1 turns it on): measured on the synth-biokg request, the degree-weighted
+            # label propagation of reorder.py cuts the typed conv's fabric reads by 10 % (FETCH_SIZE 4.41 -> 3.95 GB per
+            # layer-1 launch) and its time by nothing (1228 us either way, profiles/r03_rgcn_reorder_ab.txt): the kernel is
+            # bound by its per-step dependent chain, not by traffic.
+            cache_layer1 = affected_rows_only = False
+            reorder = os.environ.get('GD_RGCN_REORDER') == '1'
             x = model.node_emb.weight.detach()[x.to(model.node_emb.weight.device)]      # frozen embedding lookup, once
         dev = x.device
         if dev.type != 'cuda':
