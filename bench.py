@@ -157,15 +157,28 @@ def time_typed_conv(eng):
     n_pieces = plan.get('n_pieces', runs)
     nbytes = 4.0 * n * d * 3 + 8.0 * nnz + 8.0 * n_pieces + 8.0 * plan.get('n_steps', 0) + 4.0 * conv.weight.numel()
     tf = flops / dur / 1e12
+    traffic = None
+    try:            # PMC bytes per launch of the committed counter passes (same request only)
+        with open(os.path.join(ROOT, 'profiles', 'r03_rgcn_tile_traffic.json')) as f_:
+            rec_ = json.load(f_)
+        if (rec_['workload']['num_nodes'], rec_['workload']['typed_edges'], rec_['workload']['runs']) == (n, nnz, runs) and tiled:
+            traffic = rec_['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        pass
     return {'kernel': ('rgcn_tile_kernel<128,32,32> ((64-node tile, relation) steps: typed mean aggregation into a compact LDS tile, '
                        'block-diagonal transform on v_mfma_f32_16x16x4_f32, 128 -> 128)') if tiled else
                       'rgcn_conv_kernel (node-major typed mean aggregation + block-diagonal transform, 128 -> 128)',
             'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TFLOPS,
-            'traffic': None, 'algorithmic_flops': flops, 'avg_us': dur * 1e6,
+            'traffic': traffic, 'traffic_gbs': traffic / dur / 1e9 if traffic else None,
+            'traffic_unit': 'bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_rgcn_tile_traffic.json): the L2-miss side; '
+                            'it equals the gathered-row volume - the fabric carries every gathered row',
+            'algorithmic_flops': flops, 'avg_us': dur * 1e6,
             'hbm': {'compulsory_bytes': nbytes, 'gbs': nbytes / dur / 1e9, 'frac': nbytes / dur / 1e9 / HBM_PEAK_GBS},
             'gathered_rows_gbs': 4.0 * nnz * d / dur / 1e9,          # L2 / Infinity Cache side, informational
             'root_product_us': dur_root * 1e6, 'typed_edges': nnz, 'runs': runs,
-            'note': 'neither roof bounds it: the kernel is instruction-issue bound (DESIGN.md kernel table, profiles/r02_g_rgcn_tile_pmc.txt)',
+            'note': 'neither roof bounds it: 0.14 of the MFMA peak, 0.02 of HBM on compulsory bytes; its fabric traffic (the gathered rows, all L2 '
+                    'misses) runs at ~0.54 of the 6.5 TB/s fabric rate, and a 10 % traffic cut changes nothing - the per-step dependent '
+                    'chain bounds it (DESIGN.md kernel table, profiles/r03_rgcn_tile_traffic.json, profiles/r03_rgcn_reorder_ab.txt)',
             'tile_plan': {k: plan[k] for k in ('n_tiles', 'n_steps', 'n_pieces', 'n_hubs', 'n_slice_rows', 'max_steps') if k in plan}}
 
 
