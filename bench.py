@@ -437,7 +437,7 @@ def time_wgrad(eng):
     dur = _avg_seconds(lambda: eng._wgrad1(False, eng.dh))     # (steps the Del weights: the engine is discarded afterwards)
     flops = 2.0 * eng.s1 * eng.h * eng.h
     nbytes = 4.0 * 4 * eng.s1 * eng.h
-    return {'kernel': 'rows_wgrad_mfma_kernel<4,4,true,8> + split-K reduce with Adam (W_D1 gradient, S1 rows, d=128)',
+    return {'kernel': 'rows_wgrad_mfma_kernel<4,4,true,8> (W_D1 gradient partial products, S1 rows, d=128; the reduction is part of the step tail)',
             'avg_us': dur * 1e6, 'tflops': flops / dur / 1e12, 'frac_mfma': flops / dur / 1e12 / MFMA_F32_PEAK_TFLOPS,
             'hbm_gbs': nbytes / dur / 1e9, 'frac_hbm': nbytes / dur / 1e9 / HBM_PEAK_GBS, 'rows': eng.s1}
 
@@ -495,12 +495,12 @@ def stage_rooflines(eng, prof):
         ('spmm1', 'pre1 = A t1 + b1 (d=128)', lambda: ops._spmm_raw(g.rowptr, g.col, g.val, t1, c1.bias, 0.0, n, g.plan, out=y128), 2.0 * nnz * h, spmm_b(h)),
         ('del1', 'z1[S1] = pre1[S1] W_D1 + sign bits', lambda: ops.rows_gemm(eng.pre1, eng.idx1, eng.wd1, out=eng.z1, sign_bits=eng.z1_pos),
          2.0 * s1 * h * h, 4.0 * (2 * s1 * h + h * h) + 20.0 * s1),
-        ('wgrad1', 'dW_D1 = pre1[S1]^T (coef (z1 - t) + dh)[S1] + layer-1 loss sums (+ split-K reduce with Adam)',
+        ('wgrad1', 'dW_D1 partial products = pre1[S1]^T (coef (z1 - t) + dh)[S1] + layer-1 loss sums',
          lambda: eng._wgrad1(False, eng.dh), 2.0 * s1 * h * h, 4.0 * 4 * s1 * h),
         ('t2', 't2 = relu(z1 | pre1) W2^T', lambda: eng._linear_relu_z1(c2.lin.weight), 2.0 * n * h * o, 4.0 * (n * h + n * o + h * o) + n),
         ('spmm2', 'p2 = A t2 + b2 (d=64)', lambda: ops._spmm_raw(g.rowptr, g.col, g.val, t2, c2.bias, 0.0, n, g.plan, out=y64), 2.0 * nnz * o, spmm_b(o)),
         ('del2_loss_bwd', 'z2 = p2[S2] W_D2, layer-2 loss, dp2[S2] = dz2 W_D2^T', eng._del2_fused, 4.0 * s2 * o * o, 4.0 * 4 * s2 * o),
-        ('wgrad2', 'dW_D2 = p2[S2]^T dz2 (+ split-K reduce with Adam)',
+        ('wgrad2', 'dW_D2 partial products = p2[S2]^T dz2',
          lambda: eng._wgrad(eng.p2, eng.dz2c, None, s2, eng.g2, False, eng.ws2, a_idx=eng.idx2, adam=eng.adam2), 2.0 * s2 * o * o, 4.0 * 2 * s2 * o),
         ('spmm2_t', 'dt2 = A^T dp2 (d=64)', lambda: ops._spmm_raw(g.rowptr_t, g.col_t, g.val_t, eng.dz2, None, 0.0, n, g.plan_t, out=y64), 2.0 * nnz * o, spmm_b(o)),
         ('dh', 'dh[S1] = (dt2[S1] W2) * [z1[S1] > 0]', lambda: ops.rows_gemm(dt2, eng.idx1, c2.lin.weight, trans_w=False, out=eng.dh, gate_bits=eng.z1_pos),

@@ -31,6 +31,8 @@ PROTOTYPES = {
                                                 _i32, _i32, _p, _p]),
     'gd_spmm_csr_onepass_f32': (ctypes.c_int, [_p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _f32, _p, _i32, _i32, _i32, _p, _p]),
     'gd_rows_gemm_wgrad_reduce_f32': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _f64, _f64, _f64, _f64, _p]),
+    'gd_step_tail_f32': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _f64, _f64, _f64, _f64,
+                                        _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _p]),
     'gd_rgcn_conv_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _i32, _i32, _p, _i64, _i32, _i32, _p]),
     'gd_rowpair_loss_f32': (ctypes.c_int, [_i32, _p, _i64, _p, _p, _i64, _p, _i32, _i32, _p, _p, _i64, _p]),
     'gd_random_walk': (ctypes.c_int, [_p, _p, _i32, _p, _i32, _i32, ctypes.c_uint64, _p, _p]),

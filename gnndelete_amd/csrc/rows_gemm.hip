@@ -738,6 +738,97 @@ __global__ __launch_bounds__(256) void wgrad_reduce_adam_kernel(const float* __r
   }
 }
 
+// The launch-sized tail of a training step in ONE launch: the split-K reductions of both Del weights (block order, the
+// association of wgrad_reduce_adam_kernel - bit-identical results) each with its Adam update, and the loss finalize (per-block
+// loss partials -> history ring, ring position, iteration counter).  Three launches and two kernel boundaries less per step.
+// The Adam blocks need the step number t = *iter + 1 and the finalize block advances *iter in the same launch: every Adam block
+// reads the counter FIRST (a returning device-scope atomic) and then checks in on `arrive`; the finalize thread writes the counter
+// only after all of them have checked in, and resets `arrive` for the next launch.  The grid (n_elem / 64 blocks per weight + 1:
+// 321 at 128 x 128 + 64 x 64) is a fraction of the resident set, so every block is scheduled while the one thread waits.
+struct TailJob {
+  const float* partials; int32_t n_part, n_elem, accumulate;
+  float* dw; float* param; float* m; float* v;
+};
+struct TailFin {
+  const float* p1; int32_t n1; const float* p2; int32_t n2;
+  float* hist; int32_t capacity; int32_t* pos; int32_t* iter; int32_t* arrive;
+};
+
+__global__ __launch_bounds__(256) void step_tail_kernel(TailJob j1, TailJob j2, TailFin fin, double lr, double beta1, double beta2,
+                                                        double eps) {
+  __shared__ float4 red[16][16];
+  __shared__ float fred[4][256];
+  __shared__ int32_t t_sh;
+  const int nb1 = (j1.n_elem / 4 + 15) / 16, nb2 = (j2.n_elem / 4 + 15) / 16;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < nb1 + nb2) {
+    const bool first = (int)blockIdx.x < nb1;
+    const TailJob j = first ? j1 : j2;
+    const int blk = first ? blockIdx.x : blockIdx.x - nb1;
+    if (tid == 0) {
+      int32_t t = atomicAdd(fin.iter, 0);                 // the counter as the L2 holds it, before this block checks in
+      asm volatile("" : "+v"(t));
+      atomicAdd(fin.arrive + (t < 0 ? 1 : 0), 1);         // (address depends on t: the check-in cannot pass the read)
+      t_sh = t + 1;
+    }
+    const int vv = tid & 15, slice = tid >> 4;
+    const int e4 = blk * 16 + vv;
+    const int n4 = j.n_elem >> 2;
+    float4 s0 = f4_zero(), s1 = f4_zero(), s2 = f4_zero(), s3 = f4_zero();
+    if (e4 < n4) {
+      int b = slice;
+      for (; b + 48 < j.n_part; b += 64) {
+        const float4 p0 = reinterpret_cast<const float4*>(j.partials + (int64_t)b * j.n_elem)[e4];
+        const float4 p1 = reinterpret_cast<const float4*>(j.partials + (int64_t)(b + 16) * j.n_elem)[e4];
+        const float4 p2 = reinterpret_cast<const float4*>(j.partials + (int64_t)(b + 32) * j.n_elem)[e4];
+        const float4 p3 = reinterpret_cast<const float4*>(j.partials + (int64_t)(b + 48) * j.n_elem)[e4];
+        s0 = f4_add(s0, p0); s1 = f4_add(s1, p1); s2 = f4_add(s2, p2); s3 = f4_add(s3, p3);
+      }
+      for (; b < j.n_part; b += 16) s0 = f4_add(s0, reinterpret_cast<const float4*>(j.partials + (int64_t)b * j.n_elem)[e4]);
+    }
+    red[slice][vv] = f4_add(f4_add(s0, s1), f4_add(s2, s3));
+    __syncthreads();
+    if (slice == 0 && e4 < n4) {
+      float4 t4 = j.accumulate ? reinterpret_cast<float4*>(j.dw)[e4] : f4_zero();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t4 = f4_add(t4, red[i][vv]);
+      reinterpret_cast<float4*>(j.dw)[e4] = t4;
+      const AdamScalars sc = adam_scalars(lr, beta1, beta2, eps, t_sh);
+      float4 p4 = reinterpret_cast<float4*>(j.param)[e4], m4 = reinterpret_cast<float4*>(j.m)[e4],
+             v4 = reinterpret_cast<float4*>(j.v)[e4];
+      adam_update(p4.x, m4.x, v4.x, t4.x, sc);
+      adam_update(p4.y, m4.y, v4.y, t4.y, sc);
+      adam_update(p4.z, m4.z, v4.z, t4.z, sc);
+      adam_update(p4.w, m4.w, v4.w, t4.w, sc);
+      reinterpret_cast<float4*>(j.param)[e4] = p4;
+      reinterpret_cast<float4*>(j.m)[e4] = m4;
+      reinterpret_cast<float4*>(j.v)[e4] = v4;
+    }
+    return;
+  }
+  // ---- the finalize block (same arithmetic and order as loss_finalize_kernel)
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+  for (int i = tid; i < fin.n1; i += 256) { a += fin.p1[2 * i]; b += fin.p1[2 * i + 1]; }
+  for (int i = tid; i < fin.n2; i += 256) { c += fin.p2[2 * i]; d += fin.p2[2 * i + 1]; }
+  fred[0][tid] = a; fred[1][tid] = b; fred[2][tid] = c; fred[3][tid] = d;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fred[q][tid] += fred[q][tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid < 4) fin.hist[(int64_t)(*fin.pos) * 4 + tid] = fred[tid][0];
+  __syncthreads();
+  if (tid == 0) {
+    while (atomicAdd(fin.arrive, 0) < nb1 + nb2) __builtin_amdgcn_s_sleep(8);
+    *fin.arrive = 0;
+    *fin.pos = (*fin.pos + 1) % fin.capacity;
+    atomicAdd(fin.iter, 1);
+  }
+}
+
 // any n_elem (not a multiple of 4): one thread per element
 __global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* __restrict__ partials, int32_t n_part,
                                                                   int32_t n_elem, int32_t accumulate,
@@ -1032,6 +1123,32 @@ extern "C" int gd_rows_gemm_wgrad_reduce_f32(const float* partials, int32_t n_se
   // n_sel = 0 rows: no partials exist, dW (+)= 0 (wgrad_impl with nothing to launch but the reduction)
   return wgrad_impl(nullptr, nullptr, d_a, nullptr, nullptr, d_b, nullptr, nullptr, nullptr, n_sel, d_a, d_b, dw, accumulate,
                     const_cast<float*>(partials), param ? &adam : nullptr, stream, true);
+}
+
+extern "C" int gd_step_tail_f32(const float* partials1, int32_t n_sel1, int32_t d1, int32_t accumulate1, float* dw1, float* param1,
+                                float* exp_avg1, float* exp_avg_sq1, const float* partials2, int32_t n_sel2, int32_t d2,
+                                int32_t accumulate2, float* dw2, float* param2, float* exp_avg2, float* exp_avg_sq2, double lr,
+                                double beta1, double beta2, double eps, const float* loss_partials1, int32_t n1,
+                                const float* loss_partials2, int32_t n2, float* hist, int32_t capacity, int32_t* pos, int32_t* iter,
+                                int32_t* arrive, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(partials1 && dw1 && param1 && exp_avg1 && exp_avg_sq1 && partials2 && dw2 && param2 && exp_avg2 && exp_avg_sq2, GD_E_NULL,
+             "gd_step_tail_f32: null weight-gradient / optimizer pointer");
+  GD_REQUIRE(hist && pos && iter && arrive && capacity > 0 && (n1 == 0 || loss_partials1) && (n2 == 0 || loss_partials2), GD_E_NULL,
+             "gd_step_tail_f32: null bookkeeping pointer");
+  GD_REQUIRE(n_sel1 > 0 && n_sel2 > 0 && d1 > 0 && d2 > 0 && (d1 * d1) % 4 == 0 && (d2 * d2) % 4 == 0, GD_E_DIM,
+             "gd_step_tail_f32: both Del weights need rows and widths that are multiples of 2");
+  GD_REQUIRE(aligned16(partials1) && aligned16(dw1) && aligned16(partials2) && aligned16(dw2), GD_E_ALIGN, "gd_step_tail_f32: unaligned");
+  int nb1, nb2, rpb;
+  wgrad_geometry(n_sel1, &nb1, &rpb);
+  wgrad_geometry(n_sel2, &nb2, &rpb);
+  const TailJob j1{partials1, nb1, d1 * d1, accumulate1, dw1, param1, exp_avg1, exp_avg_sq1};
+  const TailJob j2{partials2, nb2, d2 * d2, accumulate2, dw2, param2, exp_avg2, exp_avg_sq2};
+  const TailFin fin{loss_partials1, n1, loss_partials2, n2, hist, capacity, pos, iter, arrive};
+  const int grid = (j1.n_elem / 4 + 15) / 16 + (j2.n_elem / 4 + 15) / 16 + 1;
+  GD_REQUIRE(grid <= 1024, GD_E_DIM, "gd_step_tail_f32: Del weights too large for the co-resident grid (%d blocks)", grid);
+  hipLaunchKernelGGL(step_tail_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, j1, j2, fin, lr, beta1, beta2, eps);
+  return launched("step_tail");
 }
 
 extern "C" int32_t gd_rows_gemm_wgrad_blocks(int32_t n_sel) {

@@ -306,6 +306,13 @@ class NodeembEngine:
                 self._lp1_blocks = _lib.lib().gd_rows_gemm_wgrad_blocks(self.s1)
                 self._lp1 = torch.zeros(2 * max(1, self._lp1_blocks), **f32)
                 self._fuse_loss1 = True
+        # The launch-sized tail of the step (two split-K reductions with Adam + the loss finalize) as ONE launch
+        # (gd_step_tail_f32) where both optimizers step in every iteration and both layers run their fused loss forms
+        self._tail = (self._fuse_loss1 and self._fuse_l2 and t1.folded and self.t2.folded and self.s1 > 0 and self.s2 > 0
+                      and loss_type in ('both_layerwise', 'both_all') and not self._overlap and self.h % 2 == 0 and self.o % 2 == 0
+                      and os.environ.get('GD_NO_STEP_TAIL') != '1')
+        self._tail_acc = [0, 0]
+        self._arrive = torch.zeros(1, dtype=torch.int32, device=dev)
         self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat', SAGEConv: 'sage', RGCNConv: 'rgcn'}[type(conv2)]
         self._gat_dots = os.environ.get('GD_NO_GAT_DOTS') != '1'      # attention logits from the GEMM epilogue
         self._gat_r1 = None                                            # (att_src W2, att_dst W2): constants of the frozen conv2
@@ -590,6 +597,15 @@ class NodeembEngine:
         """out (+)= a^T (g + g_add) over the selected rows; with `adam` the optimizer update of that Del
         weight is applied inside the split-K reduction (one launch less)."""
         d_a, d_b = a_compact.shape[1], g.shape[1]
+        if adam is not None and self._tail:
+            # partial products only: the reduction, the Adam update and the loss finalize are one launch at the end of the step
+            adam.applied += 1
+            self._tail_acc[0 if adam is self.adam1 else 1] = int(accumulate)
+            check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(a_compact), a_compact.stride(0), ptr(a_idx), ptr(g), g.stride(0),
+                                                    ptr(g_idx), None, ptr(g_add), n_sel, d_a, d_b, None,
+                                                    int(accumulate), ptr(ws), stream_ptr(g.device)),
+                  'gd_rows_gemm_wgrad_f32')
+            return
         if adam is not None and self._overlap:
             adam.applied += 1
             check(_lib.lib().gd_rows_gemm_wgrad_f32(ptr(a_compact), a_compact.stride(0), ptr(a_idx), ptr(g), g.stride(0),
@@ -635,7 +651,9 @@ class NodeembEngine:
             return
         a = self.adam1
         a.applied += 1
-        ov = self._overlap
+        ov = self._overlap or self._tail
+        if self._tail:
+            self._tail_acc[0] = int(accumulate)
         check(_lib.lib().gd_rows_gemm_wgrad_loss_f32(
             ptr(a1), a1.stride(0), ptr(a1_idx), ptr(self.z1), self.z1.stride(0), ptr(self.idx1),
             ptr(self._slot1), ptr(self.t1.tm), ptr(self.t1.coef), ptr(self._cnt_signed1), ptr(g_add), self.s1, self.h,
@@ -643,7 +661,7 @@ class NodeembEngine:
             None if ov else ptr(a.param), ptr(a.m), ptr(a.v),
             ptr(a.iter_ctr), a.lr, a.betas[0], a.betas[1], a.eps, stream_ptr(self.x.device)),
             'gd_rows_gemm_wgrad_loss_f32')
-        if ov:
+        if self._overlap:
             self._reduce_on_side(self.ws1, self.s1, self.h, self.h, self.g1, accumulate, a)
 
     def _iteration(self):
@@ -717,7 +735,14 @@ class NodeembEngine:
                     ptr(p2) if fused_fin else None, n2 if fused_fin else 0,
                     None if fused_fin else ptr(self.sums), ptr(self.hist), self.hist.shape[0], ptr(self.hist_pos),
                     ptr(self.iter_ctr), stream_ptr(self.x.device)), 'gd_loss_finalize_f32')
-            if self._overlap:
+            if self._tail:
+                a1, a2 = self.adam1, self.adam2
+                check(_lib.lib().gd_step_tail_f32(
+                    ptr(self.ws1), self.s1, self.h, self._tail_acc[0], ptr(self.g1), ptr(a1.param), ptr(a1.m), ptr(a1.v),
+                    ptr(self.ws2), self.s2, self.o, self._tail_acc[1], ptr(self.g2), ptr(a2.param), ptr(a2.m), ptr(a2.v),
+                    a1.lr, a1.betas[0], a1.betas[1], a1.eps, ptr(p1), n1, ptr(p2), n2, ptr(self.hist), self.hist.shape[0],
+                    ptr(self.hist_pos), ptr(self.iter_ctr), ptr(self._arrive), stream_ptr(self.x.device)), 'gd_step_tail_f32')
+            elif self._overlap:
                 with self._fork():
                     finalize()
                 torch.cuda.current_stream().wait_stream(self._side)       # join: the iteration ends when both branches have

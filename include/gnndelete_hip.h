@@ -34,7 +34,7 @@ extern "C" {
 
 #define GD_ABI_VERSION 4   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
                               4: gd_spmm_csr_onepass_f32, gd_rows_gemm_wgrad_reduce_f32 (dw = NULL in the wgrad entries),
-                                 gd_comm_* / gd_allreduce_f32 / gd_exchange_rows_f32, gd_segment_softmax_f32, gd_rowpair_dot_f32 */
+                                 gd_comm_* / gd_allreduce_f32 / gd_exchange_rows_f32, gd_segment_softmax_f32, gd_rowpair_dot_f32, gd_step_tail_f32 */
 
 enum {
   GD_OK = 0,
@@ -391,6 +391,21 @@ int gd_rows_gemm_wgrad_adam_f32(const float* a, int64_t ld_a, const int32_t* a_i
 int gd_rows_gemm_wgrad_reduce_f32(const float* partials, int32_t n_sel, int32_t d_a, int32_t d_b, float* dw,
                                   int32_t accumulate, float* param, float* exp_avg, float* exp_avg_sq,
                                   const int32_t* iter, double lr, double beta1, double beta2, double eps, void* stream);
+
+/* The launch-sized tail of a training step in ONE launch: gd_rows_gemm_wgrad_reduce_f32 (with Adam) for BOTH Del weights and
+ * gd_loss_finalize_f32 (per-block loss partials of the two layers -> hist[*pos], ring position, iteration counter).  Weight k
+ * (k = 1, 2): partials_k as left by a wgrad entry called with dw = NULL for n_sel_k rows of a [d_k, d_k] weight.  Same
+ * summation orders, same Adam arithmetic as the separate entries (t = *iter + 1 for both updates).  `arrive`: one device int32,
+ * zero before the first call, private to these calls - the blocks that update the weights check in on it after reading *iter,
+ * the finalize block advances *iter when all have (no block reads a counter another block of the launch has already written).
+ * Replaces, per iteration, optimizer[0].step(), optimizer[1].step() and the three .item() syncs of the logging block
+ * (framework/trainer/gnndelete_nodeemb.py:232-262, 304-311). */
+int gd_step_tail_f32(const float* partials1, int32_t n_sel1, int32_t d1, int32_t accumulate1, float* dw1, float* param1,
+                     float* exp_avg1, float* exp_avg_sq1, const float* partials2, int32_t n_sel2, int32_t d2,
+                     int32_t accumulate2, float* dw2, float* param2, float* exp_avg2, float* exp_avg_sq2, double lr,
+                     double beta1, double beta2, double eps, const float* loss_partials1, int32_t n1,
+                     const float* loss_partials2, int32_t n2, float* hist, int32_t capacity, int32_t* pos, int32_t* iter,
+                     int32_t* arrive, void* stream);
 
 /* Weight gradient whose upstream gradient is FORMED while it is fetched, from the folded DEC + NI
  * row-target terms of that layer (see gd_rowtarget_mse_f32): for selected row s with loss slot

@@ -7,7 +7,7 @@ TAG=${TAG:-r03_final}
 ARGS="bench.py --steps 40 --warmup 10 --repeats 1 --no_cpu_baseline --no_cached_rate --pretrain_epochs 0"
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pmc/kt -o p -- python $ARGS > /tmp/pmc/kt.log 2>&1
 python tools/rocpd_summary.py /tmp/pmc/kt/p_results.db gpurun_out/${TAG}_kernel_stats.md > /dev/null
-python tools/rocpd_timeline.py /tmp/pmc/kt/p_results.db loss_finalize 10 > gpurun_out/${TAG}_step_timeline.md 2>&1
+python tools/rocpd_timeline.py /tmp/pmc/kt/p_results.db step_tail 10 > gpurun_out/${TAG}_step_timeline.md 2>&1
 grep metric /tmp/pmc/kt.log > gpurun_out/${TAG}_bench_under_rocprof.json
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc/f -o p -- python $ARGS > /tmp/pmc/f.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc/w -o p -- python $ARGS > /tmp/pmc/w.log 2>&1

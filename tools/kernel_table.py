@@ -12,15 +12,13 @@ NEXT = {
     'spmm1': 'at the fabric rate (traffic 629 MB at 6.1-6.5 TB/s); ceiling 0.41 on this graph with per-XCD row ranges - nothing left but the order',
     'del1': 'as xw1; fusing it with wgrad1 does not fit the LDS (NOTES round 3)',
     'wgrad1': 'between the roofs (0.53 HBM / 0.44 MFMA): 2 blocks per CU alternate fetch and MFMA phases; a third block needs single-buffered tiles',
-    'reduce1': 'launch-sized; a side stream costs more than it saves (715 vs 683 us); could ride in the next aggregation launch',
     't2': 'HBM-side of the ridge at 128 -> 64 (181 MB): 3.5 TB/s',
     'spmm2': 'fabric rate (292 MB / 67 us = 4.3 TB/s in step, 5.2 TB/s back to back): the d = 64 launches are partly latency-bound (per-visit overhead 24 edge-equivalents)',
     'del2_loss_bwd': 'four row streams, 3.9 TB/s; candidate host for the W_D2 weight gradient (p2 and dz2 tiles are in registers): -1 launch, ~-12 us',
     'wgrad2': 'see del2_loss_bwd',
-    'reduce2': 'as reduce1; could share a launch with the finalize (two-counter scheme, NOTES)',
     'spmm2_t': 'as spmm2 (transposed CSR, S1 rows feed the next product)',
     'dh': 'MFMA / HBM (64 -> 128, gated): 168 MB at 3.6 TB/s',
-    'finalize': 'launch-sized',
+    'tail': 'both split-K reductions + Adam + loss finalize in one launch (gd_step_tail_f32); launch-sized',
 }
 EVID = 'profiles/r03_final_stages.json, r03_final_step_timeline.md'
 
@@ -56,7 +54,7 @@ def main():
                 f"{r['frac_in_step']:.2f} ({int(r['gbs_in_step'])} GB/s)") if r['frac_in_step'] is not None else '-'
         tr = f"{r['traffic_mb']} MB ({r['traffic_over_algorithmic']} x)" if r['traffic_over_algorithmic'] else (f"{r['traffic_mb']} MB" if r['traffic_mb'] else '-')
         print(f"| {r['stage']} | `{r['kernel'][:58]}` | {r['in_step_us']} | {work} | {r['bound']} | {frac} | {tr} | {r['next']} |")
-    print(f"\nsum of the 13 launches under rocprofv3: {st['sum_in_step_us']:.0f} us; bench (no profiler): {1e3 * line['ms_per_step']:.0f} us per step")
+    print(f"\nsum of the launches under rocprofv3: {st['sum_in_step_us']:.0f} us; bench (no profiler): {1e3 * line['ms_per_step']:.0f} us per step")
 
 
 if __name__ == '__main__':

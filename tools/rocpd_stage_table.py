@@ -11,8 +11,7 @@ import argparse
 import json
 import sqlite3
 
-GCN_STEP = ['xw1', 'spmm1', 'del1', 'wgrad1', 'reduce1', 't2', 'spmm2', 'del2_loss_bwd', 'wgrad2', 'reduce2', 'spmm2_t', 'dh',
-            'finalize']
+GCN_STEP = ['xw1', 'spmm1', 'del1', 'wgrad1', 't2', 'spmm2', 'del2_loss_bwd', 'wgrad2', 'spmm2_t', 'dh', 'tail']
 
 
 def kernels(db_path):
@@ -33,7 +32,7 @@ def main():
     ap.add_argument('db')
     ap.add_argument('--fetch')
     ap.add_argument('--write')
-    ap.add_argument('--marker', default='loss_finalize')
+    ap.add_argument('--marker', default='step_tail')
     ap.add_argument('--stages', default=','.join(GCN_STEP))
     ap.add_argument('--skip', type=int, default=8, help='leading steps left out (warm-up, eager capture passes)')
     ap.add_argument('--out')
