@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.skipif(os.environ.get('GNNDELETE_HIP_LIB') is not None, reason='already running against an alternative library')
 @pytest.mark.skipif(shutil.which('make') is None or not os.path.exists('/opt/rocm/bin/hipcc'), reason='needs make + hipcc')
 def test_layout_suite_passes_under_host_asan():
-    r = subprocess.run(['make', '-C', os.path.join(ROOT, 'gnndelete_amd', 'csrc'), '-j4', 'asan-check'], capture_output=True, text=True,
+    r = subprocess.run(['make', '-C', os.path.join(ROOT, 'gnndelete_amd', 'csrc'), '-j8', 'asan-check'], capture_output=True, text=True,
                        timeout=1500)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
