@@ -401,8 +401,11 @@ class PartitionedNodeembEngine:
             self._wgrad1_partial(True, self.dh)          # dh = the PREVIOUS iteration's layer-2 gradient
         elif lt == 'only1':
             self._wgrad1_partial(True, None)
-        elif lt in ('only2_layerwise', 'only2_all'):
-            self._layer1_loss_only()
+        elif lt == 'only2_layerwise':
+            self._layer1_loss_only()                     # its log line adds the layer-1 sums (loss_r = r1 + r2, loss_l = l1 + l2)
+        elif lt == 'only2_all':
+            self.p_g1.zero_()                            # neither the update nor the log line of only2_all reads layer 1
+            self._lp1.zero_()
 
     def _agg2(self, plan):
         """Layer-2 aggregation of the rows of `plan` (own rows, or their interior / boundary part)."""

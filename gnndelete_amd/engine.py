@@ -99,7 +99,7 @@ class _LayerTerms:
             self.term_o, self.term_w, self.term_kind = tgt.to(torch.int32), w, kind
             self.z_ori = z_ori
             ws = _lib.lib().gd_rowpair_mse_workspace(self.n_seg)
-        self.partials = torch.empty(max(2, ws), dtype=torch.float32, device=device)
+        self.partials = torch.zeros(max(2, ws), dtype=torch.float32, device=device)
 
     def n_partial_blocks(self):
         """Blocks of per-block loss partials the folded kernel writes (for gd_loss_finalize_f32)."""
@@ -692,7 +692,7 @@ class NodeembEngine:
             s1 = None if fused_fin else self.sums[0:2]
             s2 = None if fused_fin else self.sums[2:4]
             # ---- layer-1 loss (+ its W_D1 step for the layer-wise types)
-            if not self._fuse_loss1:
+            if not self._fuse_loss1 and lt != 'only2_all':      # (only2_all: neither its update nor its log line reads layer 1)
                 self.t1.launch(self.z1, self.dz1, s1)
             if lt == 'both_layerwise':
                 self._wgrad1(False, self.dh)
