@@ -200,61 +200,61 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
       for (int v = 0; v < VPL; ++v) acc[v] = *reinterpret_cast<const float4*>(sb0 + lo[v]);
     }
     for (;;) {       // 64-edge chunks of the item: one, except for the members of a hub row above 256 in-edges
-    const int cnt = min(kWave, d0.end - base);
-    const float w_cur = lane < cnt ? w_raw : 0.f;
-    const int trips = (cnt + G - 1) / G;
-    // Slot j of the item (j = trip * G + g) is fetched from lane j of (c_cur, w_cur) through the LDS
-    // crossbar (byte-addressed ds_bpermute, everything kept pre-multiplied by 4).  A wave64 x 16-byte load
-    // occupies the CU's texture addresser for 16 cycles whether or not its rows are useful, so trips past
-    // the end of the item are never issued (scalar trip control); only the last, partly filled trip pads:
-    // its extra lane groups re-read the item's last neighbour (cached) and take weight 0 from lane `cnt`.
-    const int last4 = 4 * cnt - 4, end4 = 4 * cnt;
-    auto fetch = [&](int t, float4(&xv)[VPL], float& wj) {
-      const int j4 = 4 * (t * G) + 4 * g;
-      const int cs = __builtin_amdgcn_ds_bpermute(min(j4, last4), c_cur);
-      wj = __int_as_float(__builtin_amdgcn_ds_bpermute(min(j4, end4), __float_as_int(w_cur)));
-      if (ADDR32) {   // row byte offset by one full-rate 24-bit multiply, 32-bit offset on a scalar base
-        const uint32_t ro = __umul24((uint32_t)cs, pitch_b);
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) xv[v] = *reinterpret_cast<const float4*>(xb + (ro + lo[v]));
-      } else {
-        const char* xr = reinterpret_cast<const char*>(x + (int64_t)cs * ldx);
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) xv[v] = *reinterpret_cast<const float4*>(xr + lo[v]);
+      const int cnt = min(kWave, d0.end - base);
+      const float w_cur = lane < cnt ? w_raw : 0.f;
+      const int trips = (cnt + G - 1) / G;
+      // Slot j of the item (j = trip * G + g) is fetched from lane j of (c_cur, w_cur) through the LDS
+      // crossbar (byte-addressed ds_bpermute, everything kept pre-multiplied by 4).  A wave64 x 16-byte load
+      // occupies the CU's texture addresser for 16 cycles whether or not its rows are useful, so trips past
+      // the end of the item are never issued (scalar trip control); only the last, partly filled trip pads:
+      // its extra lane groups re-read the item's last neighbour (cached) and take weight 0 from lane `cnt`.
+      const int last4 = 4 * cnt - 4, end4 = 4 * cnt;
+      auto fetch = [&](int t, float4(&xv)[VPL], float& wj) {
+        const int j4 = 4 * (t * G) + 4 * g;
+        const int cs = __builtin_amdgcn_ds_bpermute(min(j4, last4), c_cur);
+        wj = __int_as_float(__builtin_amdgcn_ds_bpermute(min(j4, end4), __float_as_int(w_cur)));
+        if (ADDR32) {   // row byte offset by one full-rate 24-bit multiply, 32-bit offset on a scalar base
+          const uint32_t ro = __umul24((uint32_t)cs, pitch_b);
+  #pragma unroll
+          for (int v = 0; v < VPL; ++v) xv[v] = *reinterpret_cast<const float4*>(xb + (ro + lo[v]));
+        } else {
+          const char* xr = reinterpret_cast<const char*>(x + (int64_t)cs * ldx);
+  #pragma unroll
+          for (int v = 0; v < VPL; ++v) xv[v] = *reinterpret_cast<const float4*>(xr + lo[v]);
+        }
+      };
+      int t0 = 0;
+      for (; t0 + U <= trips; t0 += U) {
+        float4 xv[U][VPL];
+        float wj[U];
+  #pragma unroll
+        for (int u = 0; u < U; ++u) fetch(t0 + u, xv[u], wj[u]);
+  #pragma unroll
+        for (int u = 0; u < U; ++u)
+  #pragma unroll
+          for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
       }
-    };
-    int t0 = 0;
-    for (; t0 + U <= trips; t0 += U) {
-      float4 xv[U][VPL];
-      float wj[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) fetch(t0 + u, xv[u], wj[u]);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
-    }
-    if (U > 1) {
-      const int rem = trips - t0;
-      if (rem > 0) {
-        float4 xv[U - 1 > 0 ? U - 1 : 1][VPL];
-        float wj[U - 1 > 0 ? U - 1 : 1];
-#pragma unroll
-        for (int u = 0; u < U - 1; ++u)
-          if (u < rem) fetch(t0 + u, xv[u], wj[u]);
-#pragma unroll
-        for (int u = 0; u < U - 1; ++u)
-          if (u < rem) {
-#pragma unroll
-            for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
-          }
+      if (U > 1) {
+        const int rem = trips - t0;
+        if (rem > 0) {
+          float4 xv[U - 1 > 0 ? U - 1 : 1][VPL];
+          float wj[U - 1 > 0 ? U - 1 : 1];
+  #pragma unroll
+          for (int u = 0; u < U - 1; ++u)
+            if (u < rem) fetch(t0 + u, xv[u], wj[u]);
+  #pragma unroll
+          for (int u = 0; u < U - 1; ++u)
+            if (u < rem) {
+  #pragma unroll
+              for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
+            }
+        }
       }
-    }
-    base += kWave;
-    if (base >= d0.end) break;
-    const int k2 = min(base + lane, nnz - 1);
-    c_cur = col[k2];
-    w_raw = val ? val[k2] : 1.0f;
+      base += kWave;
+      if (base >= d0.end) break;
+      const int k2 = min(base + lane, nnz - 1);
+      c_cur = col[k2];
+      w_raw = val ? val[k2] : 1.0f;
     }
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_group_sum<LPR>(acc[v]);

@@ -436,10 +436,6 @@ class PartitionedNodeembEngine:
         else:
             self.p_g2.zero_()
 
-    def _wgrad2_partial_if_used(self):
-        if self.loss_type != 'only1':
-            self._wgrad2_partial()
-
     def _seg_a2(self):
         """While exchange #1 is in flight: the layer-1 partials and the layer-2 aggregation of the interior rows."""
         self._layer1_partials()
