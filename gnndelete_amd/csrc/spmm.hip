@@ -180,13 +180,44 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
     kk = min(d1.start + lane, nnz - 1);
     c = col[kk];
     w = val ? val[kk] : 1.0f;
-    const bool whole = slot == -1 && row >= 0, self = whole && self_coef != 0.0f;
-    // the accumulators of lane group 0 start from the bias (requested with the gathers: no round trip of its
-    // own, no registers held across rows); the pieces of a split row get theirs in the fix-up / group sum
     float4 acc[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
-    if (bias && whole && g == 0) {
+    // MULTI-ROW item (slot <= -16; MAXR rows at most, by width): up to four CONSECUTIVE light rows (row .. row + nr - 1, adjacent
+    // in the CSR, <= 64 in-edges together) share this visit.  A visit is one dependent round trip however few rows it gathers
+    // and the sweep is latency-bound (7.7 in-edges per row on the bench graph, while a wave can keep U x G = 16 gathers of a
+    // 64-float row in flight), so packing rows multiplies the gathers in flight and divides the visits.  Every extra row costs
+    // an accumulator: 4 rows per item take this kernel from 64 to 88 VGPRs (8 -> 5 waves per SIMD), which costs the
+    // single-row items more than the packing gains (measured: 668 us per step either way); so the 128-float kernel, whose
+    // U x G = 8 is already reached by one average row, keeps one row per item at 8 waves, the 64-float kernel takes PAIRS
+    // (15 edges ~ its 16 gathers) for one more accumulator, narrower rows take four.
+    // v = -slot - 16 = cumulative edge counts after row 0 / 1 / 2 (7 bits each) | (nr - 1) << 21; slot j of the combined edge
+    // list belongs to row (j >= b1) + (j >= b2) + (j >= b3).  A row's edges are dealt to the lane groups by their position in
+    // the ITEM, so its sum is associated differently from the single-row form's - deterministic, equal to fp32 rounding.
+    constexpr int kFar = 1 << 20;
+    constexpr int MAXR = VPL > 1 ? 1 : (LPR >= 32 ? 1 : (LPR == 16 ? 2 : 4));
+    const bool multi = MAXR > 1 && slot <= -16;
+    int nr = 1, b1 = kFar, b2 = kFar, b3 = kFar;
+    if (multi) {
+      const int v = -slot - 16;
+      nr = ((v >> 21) & 3) + 1;
+      b1 = v & 127;
+      b2 = (MAXR > 2 && nr > 2) ? (v >> 7) & 127 : kFar;
+      b3 = (MAXR > 3 && nr > 3) ? (v >> 14) & 127 : kFar;
+    }
+    float4 mb[MAXR > 1 ? MAXR - 1 : 1];                // accumulators of rows 1 .. MAXR - 1 of a multi-row item (row 0: acc[0])
+#pragma unroll
+    for (int q = 0; q < (MAXR > 1 ? MAXR - 1 : 1); ++q) mb[q] = f4_zero();
+    auto add_multi = [&](int j, float wv, const float4& xr) {
+      const int r = (j >= b1) + (MAXR > 2 ? (j >= b2) + (j >= b3) : 0);
+      acc[0] = f4_fma(r == 0 ? wv : 0.f, xr, acc[0]);
+#pragma unroll
+      for (int q = 0; q < MAXR - 1; ++q) mb[q] = f4_fma(r == q + 1 ? wv : 0.f, xr, mb[q]);
+    };
+    const bool whole = (slot == -1 || multi) && row >= 0, self = whole && !multi && self_coef != 0.0f;
+    // the accumulators of lane group 0 start from the bias (requested with the gathers: no round trip of its
+    // own, no registers held across rows); the pieces of a split row get theirs in the fix-up / group sum
+    if (bias && whole && !multi && g == 0) {
 #pragma unroll
       for (int v = 0; v < VPL; ++v) acc[v] = *reinterpret_cast<const float4*>(bb + lo[v]);
     }
@@ -229,10 +260,15 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
         float wj[U];
   #pragma unroll
         for (int u = 0; u < U; ++u) fetch(t0 + u, xv[u], wj[u]);
+        if (!multi) {                              // (wave-uniform)
   #pragma unroll
-        for (int u = 0; u < U; ++u)
+          for (int u = 0; u < U; ++u)
   #pragma unroll
-          for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
+            for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
+        } else {
+  #pragma unroll
+          for (int u = 0; u < U; ++u) add_multi((t0 + u) * G + g, wj[u], xv[u][0]);
+        }
       }
       if (U > 1) {
         const int rem = trips - t0;
@@ -245,8 +281,12 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
   #pragma unroll
           for (int u = 0; u < U - 1; ++u)
             if (u < rem) {
+              if (!multi) {
   #pragma unroll
-              for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
+                for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
+              } else {
+                add_multi((t0 + u) * G + g, wj[u], xv[u][0]);
+              }
             }
         }
       }
@@ -255,6 +295,24 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
       const int k2 = min(base + lane, nnz - 1);
       c_cur = col[k2];
       w_raw = val ? val[k2] : 1.0f;
+    }
+    if (multi) {
+#pragma unroll
+      for (int q = 0; q < MAXR; ++q) {
+        if (q < nr) {                              // (wave-uniform)
+          float4 o = f4_group_sum<LPR>(q == 0 ? acc[0] : mb[(q > 0 && q < MAXR) ? q - 1 : 0]);
+          if (g == 0 && (EXACT || li < d4)) {
+            const int64_t rq = (int64_t)row + q;
+            if (self_coef != 0.0f)
+              o = f4_fma(self_coef, *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xs + rq * ldx) + lo[0]), o);
+            if (bias) o = f4_add(o, *reinterpret_cast<const float4*>(bb + lo[0]));
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(y + rq * ldy) + lo[0]) = o;
+          }
+        }
+      }
+      d0 = d1;
+      d1 = uniform(dv);
+      continue;
     }
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_group_sum<LPR>(acc[v]);

@@ -83,7 +83,7 @@ class SplitPlan:
             self._bounds[a] = b
         return b
 
-    def onepass(self, d):
+    def onepass(self, d, multirow=None):
         """(items int32 [n, 4], n, bounds int32 [9]) for gd_spmm_csr_onepass_f32 at width d.  The plan's rows are cut into
         eight contiguous ranges of equal cost (in-edges + the per-visit overhead of xcd_bounds, once per 64-edge piece),
         one per XCD.  A hub row (more than `chunk` in-edges) becomes a GROUP of four member items - the w-th contiguous
@@ -92,9 +92,19 @@ class SplitPlan:
         range the rows keep their order (the sweep's window of consecutive rows is what keeps gathered rows in the XCD's
         L2: with the hub groups moved to the front of the range the d = 128 launch fetched 6 % more, d = 64 11 % more);
         only the few rows above 4 pieces, whose members walk several chunks in sequence, go first, heaviest first, so
-        that they cannot end up as the tail of the sweep."""
+        that they cannot end up as the tail of the sweep.
+
+        multirow (rows per item; default by width unless GD_SPMM_MULTIROW=0: 1 above 64 floats, 2 for 33 .. 64, 4 below - what
+        the kernel of that width carries accumulators for, csrc/spmm.hip MAXR): that many CONSECUTIVE light rows - adjacent in
+        the plan and in the CSR, at most `chunk` in-edges together - share ONE item {first row, start, end, -(16 + v)}, v = the
+        cumulative edge counts after rows 0 / 1 / 2 (7 bits each) | (rows - 1) << 21: a visit of the sweep is one dependent
+        round trip however few rows it gathers, so packing rows multiplies the gathers in flight and divides the visits."""
+        if multirow is None:
+            multirow = 1 if (d > 64 or os.environ.get('GD_SPMM_MULTIROW') == '0') else (2 if d > 32 else 4)
+        multirow = int(multirow)
         a = int(min(48, max(8, 1536 // max(int(d), 1))))
-        hit = self._onepass.get(a)
+        key = (a, multirow)
+        hit = self._onepass.get(key)
         if hit is not None:
             return hit
         ids, r_start, r_end, deg, pieces = self._row_ids, self._row_start, self._row_end, self._row_deg, self._row_pieces
@@ -103,7 +113,7 @@ class SplitPlan:
         chunk = CHUNK
         if n == 0:
             hit = (torch.zeros(0, 4, dtype=torch.int32, device=dev), 0, torch.zeros(9, dtype=torch.int32, device=dev))
-            self._onepass[a] = hit
+            self._onepass[key] = hit
             return hit
         cost = torch.cumsum((deg + a * pieces).double(), 0)
         cuts = torch.searchsorted(cost, cost[-1] * torch.arange(1, 8, device=dev, dtype=torch.float64) / 8)
@@ -118,8 +128,51 @@ class SplitPlan:
             me = torch.minimum(ms + share[:, None], r_end[hub][:, None])
             ms = torch.minimum(ms, me)
             return torch.stack([ids[hub][:, None].expand(-1, 4), ms, me, torch.full_like(ms, -2)], 2).reshape(-1, 4)
+
+        def light_items(rl):
+            """rl: positions (ascending) of light rows -> (item rows [m, 4], index of every row's item)."""
+            m = int(rl.numel())
+            single = torch.stack([ids[rl], r_start[rl], r_end[rl], torch.full_like(rl, -1)], 1)
+            if multirow < 2 or m < 2:
+                return single, torch.arange(m, device=dev)
+            # runs of rows that follow each other in the plan, in node ids and in the CSR
+            adj = torch.zeros(m, dtype=torch.bool, device=dev)
+            adj[1:] = (rl[1:] == rl[:-1] + 1) & (ids[rl][1:] == ids[rl][:-1] + 1) & (r_start[rl][1:] == r_end[rl][:-1])
+            run = torch.cumsum((~adj).long(), 0) - 1
+            first_of_run = torch.zeros(int(run[-1]) + 1, dtype=torch.long, device=dev)
+            first_of_run[run[~adj]] = (~adj).nonzero().flatten()
+            k_in = torch.arange(m, device=dev) - first_of_run[run]
+            quad = run * (m + 1) + k_in // multirow               # fixed pairs / quadruples inside a run
+            uq, inv, size = torch.unique_consecutive(quad, return_inverse=True, return_counts=True)
+            dl = deg[rl]
+            tot = torch.zeros(uq.numel(), dtype=torch.long, device=dev).index_add_(0, inv, dl)
+            packed = ((tot <= chunk) & (size >= 2))[inv]                 # this row travels in a multi-row item
+            first = torch.ones(m, dtype=torch.bool, device=dev)
+            first[1:] = inv[1:] != inv[:-1]
+            # cumulative edge counts inside the quadruple
+            csum = torch.cumsum(dl, 0)
+            base = (csum - dl)[first][inv]                                # edges before the quadruple
+            cum_after = csum - base                                       # cumulative count after this row
+            pos_in = torch.arange(m, device=dev) - first.nonzero().flatten()[inv]
+            v = torch.zeros(uq.numel(), dtype=torch.long, device=dev)
+            for q in range(3):
+                sel = packed & (pos_in == q)
+                v.index_add_(0, inv[sel], cum_after[sel] << (7 * q))
+            v += (size - 1) << 21
+            # one item per packed quadruple (at its first row), one per unpacked row
+            is_item = (~packed) | first
+            item_of_row = torch.cumsum(is_item.long(), 0) - 1
+            fi = first & packed
+            rows4 = single[is_item].clone()
+            last_end = torch.zeros(uq.numel(), dtype=torch.long, device=dev).scatter_reduce(0, inv, r_end[rl], 'amax', include_self=True)
+            pk = item_of_row[fi]
+            rows4[pk, 2] = last_end[inv[fi]]
+            rows4[pk, 3] = -(16 + v[inv[fi]])
+            return rows4, item_of_row
+
         pad_item = torch.tensor([-1, 0, 0, -1], device=dev)
         parts, bounds, total = [], [0], 0
+        n_multi = 0
         for k in range(8):
             lo, hi = lim[k], lim[k + 1]
             pk = pieces[lo:hi]
@@ -131,20 +184,28 @@ class SplitPlan:
             rest = ((pk <= 4)).nonzero().flatten() + lo         # light rows and 2..4-piece hubs, in row order
             if rest.numel():
                 is_hub = pieces[rest] > 1
-                # light rows since the previous hub (or the start of the sweep, which is 4-aligned): a group needs
-                # (-that) % 4 padding items in front, after which the position is a multiple of 4 again
-                light_run = torch.cumsum((~is_hub).long(), 0)
+                lt = (~is_hub).nonzero().flatten()
+                l_items, item_of_light = light_items(rest[lt])
+                n_multi += int((l_items[:, 3] <= -16).sum()) if l_items.numel() else 0
+                # item slots per position of `rest`: a light row that opens an item 1, one that rides in a multi-row item 0,
+                # a hub group 4 + its alignment padding
+                opens = torch.zeros(rest.numel(), dtype=torch.long, device=dev)
+                if lt.numel():
+                    op = torch.ones(lt.numel(), dtype=torch.bool, device=dev)
+                    op[1:] = item_of_light[1:] != item_of_light[:-1]
+                    opens[lt] = op.long()
+                light_run = torch.cumsum(opens, 0)
                 hub_pos = is_hub.nonzero().flatten()
                 prev = torch.cat([light_run.new_zeros(1), light_run[hub_pos][:-1]]) if hub_pos.numel() else light_run.new_zeros(0)
                 pad = (-(light_run[hub_pos] - prev)) % 4
-                slots = torch.ones(rest.numel(), dtype=torch.long, device=dev)
+                slots = opens.clone()
                 slots[hub_pos] = 4 + pad
                 off = torch.cumsum(slots, 0) - slots
                 m = int(slots.sum())
                 blk = pad_item.expand(m, 4).clone()
-                lt = (~is_hub).nonzero().flatten()
-                r_l = rest[lt]
-                blk[off[lt]] = torch.stack([ids[r_l], r_start[r_l], r_end[r_l], torch.full_like(r_l, -1)], 1)
+                if lt.numel():
+                    opening = lt[op]
+                    blk[off[opening]] = l_items
                 if hub_pos.numel():
                     first = off[hub_pos] + pad
                     blk[(first[:, None] + q4[None, :]).reshape(-1)] = members(rest[hub_pos])
@@ -157,7 +218,8 @@ class SplitPlan:
             bounds.append(total)
         items = torch.cat(parts, 0).to(torch.int32).contiguous()
         hit = (items, total, torch.tensor(bounds, dtype=torch.int32, device=dev))
-        self._onepass[a] = hit
+        self._onepass[key] = hit
+        self.n_multirow_items = n_multi
         return hit
 
     def scratch_flat(self, tag, n_floats, device):

@@ -136,14 +136,22 @@ int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_
                              const int32_t* xcd_bounds, void* stream);
 
 /* One-launch form of gd_spmm_csr_balanced_f32 (same arithmetic, same call sites): no scratch rows, no fix-up kernel.
- *   items [n_items, 4], n_items a multiple of 4, in three flavours:
+ *   items [n_items, 4], n_items a multiple of 4, in four flavours:
  *     {row, start, end, -1}  a row of at most 64 in-edges (one wave);
  *     {row, start, end, -2}  a GROUP member: a row above 64 in-edges is laid out as four consecutive items at a
  *                            4-aligned position, member w = the w-th contiguous share [start, end) of the row's
  *                            in-edges (shares are multiples of 64 edges, trailing shares may be empty); the block's
  *                            four waves take one member each, the four partial rows are added in LDS in member order and
  *                            written once - deterministic, no atomics;
- *     {-1, 0, 0, -1}         padding.
+ *     {-1, 0, 0, -1}         padding;
+ *     {row, start, end, -(16 + v)}  MULTI-ROW: up to MAXR CONSECUTIVE light rows row .. row + nr - 1 whose in-edges
+ *                            [start, end) are adjacent in the CSR and at most 64 together, summed in ONE visit of a wave (the
+ *                            sweep is bound by dependent round trips per visit, not by bytes).  v = c1 | c2 << 7 | c3 << 14 |
+ *                            (nr - 1) << 21, c_q = the number of edges of rows 0 .. q - 1 of the item; edge j of the item
+ *                            belongs to row (j >= c1) + (j >= c2) + (j >= c3) (fields past nr - 1 are ignored).  MAXR follows
+ *                            the width the kernel carries accumulators for: 1 (no such items) for d > 64, 2 for 33 .. 64,
+ *                            4 for d <= 32; more rows than MAXR in an item is a caller error (the extra rows are not written).
+ *                            A row's sum is associated by edge position in the ITEM: equal to fp32 rounding to its one-row form.
  *   xcd_bounds (required, 9 ascending item indices, all multiples of 4, [0] = 0, [8] = n_items): the item range each of
  *   the 8 XCDs sweeps.  Groups may sit anywhere in a range (the planner puts a range's hub rows first, heaviest first).
  * The sum of a hub row is associated differently from the balanced form's (piece partials in slot order), so the two

@@ -469,13 +469,25 @@ def test_onepass_spmm_sums_hub_rows_inside_the_launch(d, self_coef, monkeypatch)
     assert rel_l2(y.cpu(), y2.cpu()) < 1e-6
     light = (gr.rowptr[1:] - gr.rowptr[:-1]) <= 64
     assert int((~light).sum()) == gr.plan.n_split
-    assert torch.equal(y[light], y2[light])                         # rows of <= 64 in-edges: the same sum, bit for bit
+    # (light rows travel in multi-row items at d <= 64: their edges are dealt to the lane groups by position in the item,
+    #  so the two forms agree to fp32 rounding there too, not bit for bit)
+    assert rel_l2(y[light].cpu(), y2[light].cpu()) < 1e-6
+    monkeypatch.setenv('GD_SPMM_MULTIROW', '0')
+    plan1 = SplitPlan(gr.rowptr)
+    y3 = ops._spmm_raw(gr.rowptr, gr.col, None, xc, bc, self_coef, n, plan1)
+    monkeypatch.delenv('GD_SPMM_MULTIROW')
+    assert torch.equal(y3[light], y2[light])                        # one light row per item: the same sum, bit for bit
+    assert d > 64 or int((items[:, 3] <= -16).sum()) > 1000
     # a row subset (the rows a request can influence): only those rows are written
     rows = torch.cat([torch.tensor([0, 7, 12, 11999]), torch.randperm(n, generator=g)[:9000]]).unique().cuda()
     plan = SplitPlan(gr.rowptr, rows=rows)
     out = torch.full((n, d), 7.0, device='cuda')
     ops._spmm_raw(gr.rowptr, gr.col, None, xc, bc, self_coef, n, plan, out=out)
-    assert torch.equal(out[rows], y[rows])
+    # (a subset pairs different light rows into items at d <= 64, so those sums are associated differently: equal to rounding;
+    #  hub rows and one-row items bit for bit)
+    assert rel_l2(out[rows].cpu(), y[rows].cpu()) < 1e-6
+    hub_rows = rows[~light[rows]]
+    assert torch.equal(out[hub_rows], y[hub_rows]) and (d <= 64 or torch.equal(out[rows], y[rows]))
     rest = torch.ones(n, dtype=torch.bool, device='cuda')
     rest[rows] = False
     assert bool((out[rest] == 7.0).all())

@@ -8,9 +8,13 @@ task-level contract of north_star: post-deletion AUC within +-0.002.
 
   distances = rel-L2 to the fp64 run of (W_D1, W_D2, z1 on the 1-hop S_Df nodes, z2 on the 2-hop S_Df nodes), embeddings
   taken on the retained edges (evaluation semantics, framework/trainer/base.py:238-242)
-  assert  d(HIP, fp64) <= RATIO * d(fp32 oracle, fp64) + FLOOR   for every quantity, at epochs 100 / 300 / 600
-          (RATIO = 2: both fp32 runs are one sample each of a chaotic map - the fp32 oracle on the GPU is not even
-          deterministic - so "as close" is asserted within a factor of two; measured: profiles/r03_long_parity.txt)
+  assert  d(HIP, fp64) <= RATIO * max over the fp32 ENSEMBLE of d(member, fp64) + FLOOR   for every quantity, at epochs
+          100 / 300 / 600.  The ensemble = the fp32 oracle as is + the same oracle with its edge lists permuted (a different
+          summation order in every scatter: another correct fp32 implementation).  One member is not enough: the distance
+          grows in JUMPS (the first ReLU flip takes it from 3e-7 to 2e-4 in one epoch) and WHICH run flips first is chance -
+          with one-row SpMM items the fp32 oracle had flipped by epoch 100 and HIP had not (1.9e-4 vs 3.4e-7), with two-row
+          items (another association of the same sums) it was the other way round (3.8e-7 vs 2.2e-4); both are in
+          profiles/r03_long_parity.txt.  RATIO = 2: every run is one sample of a chaotic map.
   assert  |AUC(HIP) - AUC(fp64)| <= 0.002 and |AUC(HIP) - AUC(fp32 oracle)| <= 0.002 (test edges; Df vs Dr)
 
 The oracles run as plain torch ops: fp64 on the GPU (fast fp64 units), fp32 on the CPU at synth-small (fixed summation
@@ -25,7 +29,8 @@ from helpers import rel_l2
 pytestmark = pytest.mark.gpu
 
 EPOCHS, CHECK = 600, (100, 300, 600)
-RATIO, FLOOR = 2.0, 2e-6      # measured ratios: 0.002 - 0.2 (synth-small, fp32 oracle on the CPU), 1.0 - 1.5 (synth-collab, fp32 oracle on the GPU)
+RATIO, FLOOR = 2.0, 2e-6      # measured ratios: profiles/r03_long_parity.txt
+PERMS = {'synth-small': (None, 1, 2, 3), 'synth-collab': (None, 1)}      # fp32 ensemble: edge-order seeds (None = as given)
 
 
 def _auc(z, pos, neg):
@@ -51,12 +56,16 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
     e_dr, e_sdf, pos = E[:, data.dr_mask], E[:, data.sdf_mask], E[:, data.df_mask]
     lt, alpha, lr = 'both_layerwise', 0.5, 1e-3
 
-    def oracle(dtype, device):
+    def oracle(dtype, device, perm=None):
         ref = R.TwoLayerDelete('gcn', f, 128, 64, m1, m2)
         ref.load_state_dict(state, strict=False)
         ref = ref.to(dtype).to(device)
         x = data.x.to(dtype).to(device)
         ed, es = e_dr.to(device), e_sdf.to(device)
+        if perm is not None:
+            gp = torch.Generator().manual_seed(perm)
+            ed = ed[:, torch.randperm(ed.shape[1], generator=gp).to(device)]
+            es = es[:, torch.randperm(es.shape[1], generator=gp).to(device)]
         with torch.no_grad():
             z1o, z2o = ref.get_original_embeddings(x, ed, return_all_emb=True)
         tg = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=pos.to(device), neg_edge=neg.to(device), ni_mask1=ni1.to(device),
@@ -74,7 +83,8 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
         return step, snapshot, (z1o, z2o)
     torch.set_num_threads(min(32, torch.get_num_threads()))
     step64, snap64, _ = oracle(torch.float64, dev)
-    step32, snap32, (z1o, z2o) = oracle(torch.float32, torch.device(f32_device))
+    ens = [oracle(torch.float32, torch.device(f32_device), perm) for perm in PERMS[workload]]
+    step32, snap32, (z1o, z2o) = ens[0]
     model.load_state_dict(state)
     hip = model.to(dev)
     xg, edg = data.x.to(dev), e_dr.to(dev).contiguous()
@@ -91,16 +101,19 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
     for upto in CHECK:
         for _ in range(upto - done):
             step64()
-            step32()
+            for member in ens:
+                member[0]()
         eng.run(upto - done)
         done = upto
         torch.cuda.synchronize()
         s64, s32, sh = snap64(), snap32(), snap_hip()
-        d32 = [rel_l2(s32[i], s64[i]) for i in range(4)]
+        d_ens = [[rel_l2(member[1]()[i], s64[i]) for i in range(4)] for member in ens]
+        d32 = [max(d[i] for d in d_ens) for i in range(4)]
         dh = [rel_l2(sh[i], s64[i]) for i in range(4)]
-        print(f'[{workload}] epoch {upto}: ' + ', '.join(f'{n} fp32 {a:.2e} / HIP {b:.2e}' for n, a, b in zip(names, d32, dh)))
+        print(f'[{workload}] epoch {upto}: ' + ', '.join(
+            f'{n} fp32 ' + ' '.join(f'{d[i]:.2e}' for d in d_ens) + f' / HIP {dh[i]:.2e}' for i, n in enumerate(names)))
         for n, a, b in zip(names, d32, dh):
-            assert b <= RATIO * a + FLOOR, (workload, upto, n, 'fp32 oracle', a, 'HIP', b)
+            assert b <= RATIO * a + FLOOR, (workload, upto, n, 'fp32 ensemble max', a, 'HIP', b)
     tp, tn = data.test_pos_edge_index, data.test_neg_edge_index
     k = data.directed_df_edge_index.shape[1]
     gen = torch.Generator().manual_seed(0)

@@ -13,7 +13,7 @@ NEXT = {
     'del1': 'as xw1; fusing it with wgrad1 does not fit the LDS (NOTES round 3)',
     'wgrad1': 'between the roofs (0.53 HBM / 0.44 MFMA): 2 blocks per CU alternate fetch and MFMA phases; a third block needs single-buffered tiles',
     't2': 'HBM-side of the ridge at 128 -> 64 (181 MB): 3.5 TB/s',
-    'spmm2': 'fabric rate (292 MB / 67 us = 4.3 TB/s in step, 5.2 TB/s back to back): the d = 64 launches are partly latency-bound (per-visit overhead 24 edge-equivalents)',
+    'spmm2': 'latency-bound: two light rows per visit (multi-row items) took it 72 -> 67 us; four rows cost a fifth wave slot per SIMD and gave it back (NOTES round 3)',
     'del2_loss_bwd': 'four row streams, 3.9 TB/s; candidate host for the W_D2 weight gradient (p2 and dz2 tiles are in registers): -1 launch, ~-12 us',
     'wgrad2': 'see del2_loss_bwd',
     'spmm2_t': 'as spmm2 (transposed CSR, S1 rows feed the next product)',
