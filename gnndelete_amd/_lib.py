@@ -14,7 +14,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'gnndelete_hip.h')
 _i32, _i64, _f32, _f64, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
 # name -> (restype, argtypes); must list every symbol the header declares
-ABI_VERSION = 4          # GD_ABI_VERSION of include/gnndelete_hip.h this binding was written against
+ABI_VERSION = 5          # GD_ABI_VERSION of include/gnndelete_hip.h this binding was written against
 
 PROTOTYPES = {
     'gd_abi_version': (ctypes.c_int, []),
@@ -79,6 +79,7 @@ PROTOTYPES = {
                                                    _p, _p, _p, _p, _p, _p, _f64, _f64, _f64, _f64, _p]),
     'gd_del_loss_bwd_blocks': (_i32, [_i32]),
     'gd_del_loss_bwd_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
+    'gd_del_loss_bwd_wgrad_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p]),
     'gd_rowtarget_mse_blocks': (_i32, [_i32]),
     'gd_loss_finalize_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p]),
     'gd_pairs_sigmoid_mse_workspace': (_i64, [_i32, _i32]),

@@ -16,6 +16,17 @@
 // feature as MFMA k slot (r, kh) of the second product - both operands agree on the permutation - the
 // accumulator registers ARE its "B" operand, and its "A" operand W_D[c][i] comes out of the same LDS image
 // read along the other axis.
+//
+// WG form (gd_del_loss_bwd_wgrad_f32): the Del weight's gradient  dW_D = p[idx,:]^T dz  in the same pass - the third product
+// of the tile, K = its 32 samples.  Both operands are in this wave's registers already, but sample-major (a lane owns a
+// sample); the product wants them feature-major (lane = feature, K slot = sample), so each goes once through a wave-private
+// 32 x (D + 4) LDS tile: p right after its fetch (its transposed view is read back into the registers the row-major copy
+// leaves after the forward product), dz over the same tile after the loss.  The wave keeps the D x D sums of all its tiles in
+// registers (D^2 / 64 per lane); at the end the block adds its four waves' sums in wave order and writes ONE partial matrix,
+// laid out and counted like gd_rows_gemm_wgrad_f32's (grid = gd_rows_gemm_wgrad_blocks(n_sel)), so the same reduction
+// (gd_step_tail_f32 / gd_rows_gemm_wgrad_reduce_f32) finishes it.  No dz buffer, no second pass over p: the separate
+// weight-gradient launch read 97 MB and took 26 us of the bench step.  To make room for the sums the targets are no
+// longer fetched a tile ahead but at the top of their own tile (the forward product's 2 us cover them).
 #include "common.h"
 
 namespace gd {
@@ -30,14 +41,16 @@ struct DelLoss {
   float* partials;          // [2 * gridDim.x]
 };
 
-template <int NT>
+template <int NT, bool WG>
 __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __restrict__ p, int64_t ld_p,
                                                               const int32_t* __restrict__ idx, int32_t n_sel,
                                                               const float* __restrict__ w, DelLoss loss,
                                                               float* __restrict__ dz, int64_t ld_dz,
-                                                              float* __restrict__ dp, int64_t ld_dp) {
+                                                              float* __restrict__ dp, int64_t ld_dp,
+                                                              float* __restrict__ wg_partials) {
   constexpr int D = 32 * NT;
   constexpr int PB = D + 4;                                      // pitch of the row-major image (16-byte rows, conflict-free b128)
+  constexpr int PT = D + 4;                                      // pitch of the wave's transposition tile (WG)
   // two images of W_D, one per product, so that the NT (4) operands of consecutive MFMAs are ONE vector read:
   //   fw[(k * 32 + n % 32) * NT + n / 32] = W_D[k][n]   forward:  the NT output tiles of one k step
   //   bw[k * PB + n]                      = W_D[k][n]   backward: four consecutive k slots of one output tile
@@ -57,6 +70,16 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
 
   const float* w_fwd = fw + (kh * (D / 2) * 32 + lo) * NT;        // per-lane bases of the two read patterns
   const float* w_bwd = bw + lo * PB + 4 * kh;
+  float* const tb = wl + D * D + D * PB + wave * (32 * PT);       // (WG) this wave's 32-sample tile
+  float* const tb_row = tb + lo * PT + 4 * kh;                    // sample-major side: my sample's row
+  const float* const tb_col = tb + kh * PT + lo;                  // feature-major side: K slot (st, kh) = sample 2 st + kh
+  f32x16 gacc[WG ? NT * NT : 1];                                  // (WG) dW_D[32 mt + (r&3) + 8(r>>2) + 4kh][32 nt + lo] in gacc[mt * NT + nt][r]
+  if (WG) {
+#pragma unroll
+    for (int i = 0; i < NT * NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gacc[i][r] = 0.f;
+  }
   float ls0 = 0.f, ls1 = 0.f;
   const int n_tiles = (n_sel + 31) >> 5;
   // Operands of one tile: sample row index, loss slot, this lane's half of the p row, its target runs.
@@ -79,11 +102,13 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
     const int uc = max(n_u, 0);
     n_cf = loss.coef[uc];
     n_cn = loss.cnt_signed[uc];
-    const float* trow = loss.tm + (int64_t)uc * D + 4 * kh;
+    if (!WG) {
+      const float* trow = loss.tm + (int64_t)uc * D + 4 * kh;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) n_tv[t * 4 + q] = *reinterpret_cast<const float4*>(trow + 32 * t + 8 * q);
+        for (int q = 0; q < 4; ++q) n_tv[t * 4 + q] = *reinterpret_cast<const float4*>(trow + 32 * t + 8 * q);
+    }
   };
   const int stride = gridDim.x * 4;
   int tile = blockIdx.x * 4 + wave;
@@ -100,8 +125,18 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
     float4 c_pa[D / 8], c_tv[NT * 4];
 #pragma unroll
     for (int c4 = 0; c4 < D / 8; ++c4) c_pa[c4] = n_pa[c4];
+    if (WG) {                                                     // this tile's targets: asked for now, needed after the forward product
+      const float* trow = loss.tm + (int64_t)max(u, 0) * D + 4 * kh;
 #pragma unroll
-    for (int q = 0; q < NT * 4; ++q) c_tv[q] = n_tv[q];
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c_tv[t * 4 + q] = *reinterpret_cast<const float4*>(trow + 32 * t + 8 * q);
+#pragma unroll
+      for (int c4 = 0; c4 < D / 8; ++c4) *reinterpret_cast<float4*>(tb_row + kh * (D / 2 - 4) + 4 * c4) = c_pa[c4];   // p, sample-major
+    } else {
+#pragma unroll
+      for (int q = 0; q < NT * 4; ++q) c_tv[q] = n_tv[q];
+    }
     if (tile + stride < n_tiles) fetch(tile + stride);
     // ---- z^T tile = W_D^T x^T : lane (sample lo, half kh) feeds features [kh*D/2, kh*D/2 + D/2) of its row
     f32x16 acc[NT];
@@ -123,6 +158,14 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[t], av[e], acc[t], 0, 0, 0);
       }
     }
+    // (WG) the transposed view of p: a_op[st * NT + mt] = p[sample 2 st + kh][feature 32 mt + lo]
+    float a_op[WG ? 16 * NT : 1];
+    if (WG) {
+#pragma unroll
+      for (int st = 0; st < 16; ++st)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) a_op[st * NT + mt] = tb_col[2 * st * PT + 32 * mt];
+    }
     // ---- loss gradient in place: acc[t][r] (feature 32t + (r&3) + 8(r>>2) + 4kh of sample lo) -> dz
     if (u >= 0) {
       const float cf = c_cf, cn = c_cn;
@@ -138,7 +181,8 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
           sq = fmaf(df.x, df.x, sq); sq = fmaf(df.y, df.y, sq); sq = fmaf(df.z, df.z, sq); sq = fmaf(df.w, df.w, sq);
           const float4 g4 = make_float4(cf * df.x, cf * df.y, cf * df.z, cf * df.w);
           acc[t][4 * q] = g4.x; acc[t][4 * q + 1] = g4.y; acc[t][4 * q + 2] = g4.z; acc[t][4 * q + 3] = g4.w;
-          *reinterpret_cast<float4*>(drow + 32 * t + 8 * q) = g4;
+          if (!WG || dz) *reinterpret_cast<float4*>(drow + 32 * t + 8 * q) = g4;
+          if (WG) *reinterpret_cast<float4*>(tb_row + 32 * t + 8 * q) = g4;
         }
       if (cn >= 0.f) ls0 = fmaf(cn, sq, ls0); else ls1 = fmaf(-cn, sq, ls1);
     } else {
@@ -146,13 +190,31 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-      if (live) {
+      if (live && (!WG || dz)) {
         float* drow = dz + (int64_t)s * ld_dz + 4 * kh;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(drow + 32 * t + 8 * q) = f4_zero();
       }
+      if (WG) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(tb_row + 32 * t + 8 * q) = f4_zero();
+      }
+    }
+    // ---- (WG) dW_D += p^T dz over the tile's 32 samples: A = p (registers, feature-major), B = dz (the tile, feature-major)
+    if (WG) {
+#pragma unroll
+      for (int st = 0; st < 16; ++st)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float b = tb_col[2 * st * PT + 32 * nt];
+#pragma unroll
+          for (int mt = 0; mt < NT; ++mt)
+            gacc[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op[st * NT + mt], b, gacc[mt * NT + nt], 0, 0, 0);
+        }
     }
     // ---- dp^T tile = W_D dz^T : k slot (kk, kh) of feature tile t <-> feature i = 32t + (kk&3) + 8(kk>>2) + 4kh
     f32x16 dacc[NT];
@@ -182,6 +244,20 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
               make_float4(dacc[c][4 * q], dacc[c][4 * q + 1], dacc[c][4 * q + 2], dacc[c][4 * q + 3]);
     }
   }
+  if (WG) {
+    __syncthreads();                                              // nobody reads the weight images or a tile any more
+    float* const red = wl;                                        // [4 waves][D x D]
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          red[wave * D * D + (32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh) * D + 32 * nt + lo] = gacc[mt * NT + nt][r];
+    __syncthreads();
+    float* const out = wg_partials + (int64_t)blockIdx.x * D * D;
+    for (int e = tid; e < D * D; e += 256) out[e] = (red[e] + red[D * D + e]) + (red[2 * D * D + e] + red[3 * D * D + e]);
+  }
   ls0 = wave_sum(ls0);
   ls1 = wave_sum(ls1);
   if (lane == 0) { lred[0][wave] = ls0; lred[1][wave] = ls1; }
@@ -203,26 +279,65 @@ static inline int del_fused_grid(int32_t n_sel) {
 
 extern "C" int32_t gd_del_loss_bwd_blocks(int32_t n_sel) { return n_sel > 0 ? gd::del_fused_grid(n_sel) : 0; }
 
+extern "C" int32_t gd_rows_gemm_wgrad_blocks(int32_t n_sel);
+
+static int del_loss_bwd_impl(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w,
+                             int32_t d, const int32_t* loss_slot, const float* tm, const float* coef,
+                             const float* cnt_signed, float* dz, int64_t ld_dz, float* dp, int64_t ld_dp,
+                             float* loss_partials, float* wgrad_partials, bool with_wgrad, void* stream) {
+  using namespace gd;
+  const char* name = with_wgrad ? "gd_del_loss_bwd_wgrad_f32" : "gd_del_loss_bwd_f32";
+  if (n_sel == 0) return GD_OK;
+  GD_REQUIRE(p && idx && w && loss_slot && tm && coef && cnt_signed && dp && loss_partials && (with_wgrad ? wgrad_partials != nullptr : dz != nullptr),
+             GD_E_NULL, "%s: null pointer", name);
+  GD_REQUIRE(d == 32 || d == 64, GD_E_DIM, "%s: d=%d must be 32 or 64", name, d);
+  GD_REQUIRE(ld_p >= d && (!dz || ld_dz >= d) && ld_dp >= d && ld_p % 4 == 0 && (!dz || ld_dz % 4 == 0) && ld_dp % 4 == 0, GD_E_DIM,
+             "%s: bad row strides", name);
+  GD_REQUIRE(aligned16(p) && aligned16(tm) && (!dz || aligned16(dz)) && aligned16(dp) && (!with_wgrad || aligned16(wgrad_partials)), GD_E_ALIGN,
+             "%s: unaligned", name);
+  GD_REQUIRE(p != dp && p != dz && dz != dp, GD_E_DIM, "%s: buffers must not alias", name);
+  hipStream_t s = (hipStream_t)stream;
+  const DelLoss loss{loss_slot, tm, coef, cnt_signed, loss_partials};
+  if (!with_wgrad) {
+    const dim3 grid(del_fused_grid(n_sel));
+    const size_t lds = ((size_t)d * d + (size_t)d * (d + 4)) * sizeof(float);     // the two weight images
+    switch (d / 32) {
+      case 1: hipLaunchKernelGGL((del_loss_bwd_kernel<1, false>), grid, dim3(256), lds, s, p, ld_p, idx, n_sel, w, loss, dz, ld_dz, dp, ld_dp, nullptr); break;
+      default: hipLaunchKernelGGL((del_loss_bwd_kernel<2, false>), grid, dim3(256), lds, s, p, ld_p, idx, n_sel, w, loss, dz, ld_dz, dp, ld_dp, nullptr); break;
+    }
+    return launched("del_loss_bwd");
+  }
+  // one block per partial matrix of the weight-gradient reduction; + the four waves' transposition tiles (the block sum of
+  // the D x D accumulators reuses the whole allocation: 4 D^2 floats <= what is there)
+  const dim3 grid(gd_rows_gemm_wgrad_blocks(n_sel));
+#define GD_DF_CASE(NT_)                                                                                                        \
+  do {                                                                                                                         \
+    constexpr int kD = 32 * NT_;                                                                                               \
+    constexpr int kLds = (kD * kD + kD * (kD + 4) + 4 * 32 * (kD + 4)) * 4;                                                    \
+    static_assert(kLds >= 4 * kD * kD * 4, "block sum needs 4 D^2 floats");                                                    \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&del_loss_bwd_kernel<NT_, true>),         \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds);                      \
+    if (attr != hipSuccess) return fail(-(int)attr, "gd_del_loss_bwd_wgrad_f32: %s", hipGetErrorString(attr));                 \
+    hipLaunchKernelGGL((del_loss_bwd_kernel<NT_, true>), grid, dim3(256), kLds, s, p, ld_p, idx, n_sel, w, loss, dz, ld_dz,    \
+                       dp, ld_dp, wgrad_partials);                                                                             \
+  } while (0)
+  if (d == 32) GD_DF_CASE(1); else GD_DF_CASE(2);
+#undef GD_DF_CASE
+  return launched("del_loss_bwd_wgrad");
+}
+
 extern "C" int gd_del_loss_bwd_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w,
                                    int32_t d, const int32_t* loss_slot, const float* tm, const float* coef,
                                    const float* cnt_signed, float* dz, int64_t ld_dz, float* dp, int64_t ld_dp,
                                    float* loss_partials, void* stream) {
-  using namespace gd;
-  if (n_sel == 0) return GD_OK;
-  GD_REQUIRE(p && idx && w && loss_slot && tm && coef && cnt_signed && dz && dp && loss_partials, GD_E_NULL,
-             "gd_del_loss_bwd_f32: null pointer");
-  GD_REQUIRE(d == 32 || d == 64, GD_E_DIM, "gd_del_loss_bwd_f32: d=%d must be 32 or 64", d);
-  GD_REQUIRE(ld_p >= d && ld_dz >= d && ld_dp >= d && ld_p % 4 == 0 && ld_dz % 4 == 0 && ld_dp % 4 == 0, GD_E_DIM,
-             "gd_del_loss_bwd_f32: bad row strides");
-  GD_REQUIRE(aligned16(p) && aligned16(tm) && aligned16(dz) && aligned16(dp), GD_E_ALIGN, "gd_del_loss_bwd_f32: unaligned");
-  GD_REQUIRE(p != dp && p != dz && dz != dp, GD_E_DIM, "gd_del_loss_bwd_f32: buffers must not alias");
-  hipStream_t s = (hipStream_t)stream;
-  const DelLoss loss{loss_slot, tm, coef, cnt_signed, loss_partials};
-  const dim3 grid(del_fused_grid(n_sel));
-  const size_t lds = ((size_t)d * d + (size_t)d * (d + 4)) * sizeof(float);     // the two weight images
-  switch (d / 32) {
-    case 1: hipLaunchKernelGGL((del_loss_bwd_kernel<1>), grid, dim3(256), lds, s, p, ld_p, idx, n_sel, w, loss, dz, ld_dz, dp, ld_dp); break;
-    default: hipLaunchKernelGGL((del_loss_bwd_kernel<2>), grid, dim3(256), lds, s, p, ld_p, idx, n_sel, w, loss, dz, ld_dz, dp, ld_dp); break;
-  }
-  return launched("del_loss_bwd");
+  return del_loss_bwd_impl(p, ld_p, idx, n_sel, w, d, loss_slot, tm, coef, cnt_signed, dz, ld_dz, dp, ld_dp, loss_partials, nullptr,
+                           false, stream);
+}
+
+extern "C" int gd_del_loss_bwd_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w,
+                                         int32_t d, const int32_t* loss_slot, const float* tm, const float* coef,
+                                         const float* cnt_signed, float* dz, int64_t ld_dz, float* dp, int64_t ld_dp,
+                                         float* loss_partials, float* wgrad_partials, void* stream) {
+  return del_loss_bwd_impl(p, ld_p, idx, n_sel, w, d, loss_slot, tm, coef, cnt_signed, dz, ld_dz, dp, ld_dp, loss_partials,
+                           wgrad_partials, true, stream);
 }

@@ -313,6 +313,12 @@ class NodeembEngine:
                       and os.environ.get('GD_NO_STEP_TAIL') != '1')
         self._tail_acc = [0, 0]
         self._arrive = torch.zeros(1, dtype=torch.int32, device=dev)
+        # ... and with the tail launch doing the reduction, the W_D2 weight gradient's partial sums come out of the fused Del-2
+        # kernel itself (gd_del_loss_bwd_wgrad_f32: p2 and dz2 are in its registers) - no weight-gradient launch, no dz2 buffer
+        self._fuse_wg2 = self._tail and os.environ.get('GD_NO_FUSED_WGRAD2') != '1'
+        if self._fuse_wg2:
+            self._lp2_blocks = _lib.lib().gd_rows_gemm_wgrad_blocks(self.s2)
+            self._lp2 = torch.zeros(2 * max(1, self._lp2_blocks), **f32)
         self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat', SAGEConv: 'sage', RGCNConv: 'rgcn'}[type(conv2)]
         self._gat_dots = os.environ.get('GD_NO_GAT_DOTS') != '1'      # attention logits from the GEMM epilogue
         self._gat_r1 = None                                            # (att_src W2, att_dst W2): constants of the frozen conv2
@@ -750,7 +756,15 @@ class NodeembEngine:
                 finalize()
 
     def _del2_fused(self):
-        """Del-2 forward + folded layer-2 loss + Del-2 input gradient in one kernel (csrc/del_fused.hip)."""
+        """Del-2 forward + folded layer-2 loss + Del-2 input gradient (+ the W_D2 weight gradient's partial sums) in one
+        kernel (csrc/del_fused.hip)."""
+        if self._fuse_wg2:
+            check(_lib.lib().gd_del_loss_bwd_wgrad_f32(
+                ptr(self.p2), self.p2.stride(0), ptr(self.idx2), self.s2, ptr(self.wd2), self.o, ptr(self._slot2),
+                ptr(self.t2.tm), ptr(self.t2.coef), ptr(self._cnt_signed2), None, self.o,
+                ptr(self.dz2), self.dz2.stride(0), ptr(self._lp2), ptr(self.ws2), stream_ptr(self.x.device)),
+                'gd_del_loss_bwd_wgrad_f32')
+            return
         check(_lib.lib().gd_del_loss_bwd_f32(
             ptr(self.p2), self.p2.stride(0), ptr(self.idx2), self.s2, ptr(self.wd2), self.o, ptr(self._slot2),
             ptr(self.t2.tm), ptr(self.t2.coef), ptr(self._cnt_signed2), ptr(self.dz2c), self.dz2c.stride(0),
@@ -758,7 +772,10 @@ class NodeembEngine:
 
     def _layer2_backward(self, to_w1=True, g2_accumulate=False):
         """g2 (+)= dW_D2; with to_w1 also dh[S1] = d loss2 / d z1[S1] (ReLU-gated)."""
-        if self._fuse_l2:          # dz2 (compact) and dp2 (in self.dz2) were produced by the fused Del-2 kernel,
+        if self._fuse_wg2:         # the partial sums are in ws2 already (fused Del-2 kernel); the tail launch reduces them
+            self.adam2.applied += 1
+            self._tail_acc[1] = int(g2_accumulate)
+        elif self._fuse_l2:        # dz2 (compact) and dp2 (in self.dz2) were produced by the fused Del-2 kernel,
             # so nothing reads W_D2 any more this iteration: its Adam step rides on the split-K reduction
             self._wgrad(self.p2, self.dz2c, None, self.s2, self.g2, g2_accumulate, self.ws2, a_idx=self.idx2,
                         adam=self.adam2)

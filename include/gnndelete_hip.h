@@ -32,9 +32,10 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 4   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
+#define GD_ABI_VERSION 5   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
                               4: gd_spmm_csr_onepass_f32, gd_rows_gemm_wgrad_reduce_f32 (dw = NULL in the wgrad entries),
-                                 gd_comm_* / gd_allreduce_f32 / gd_exchange_rows_f32, gd_segment_softmax_f32, gd_rowpair_dot_f32, gd_step_tail_f32 */
+                                 gd_comm_* / gd_allreduce_f32 / gd_exchange_rows_f32, gd_segment_softmax_f32, gd_rowpair_dot_f32, gd_step_tail_f32;
+                              5: gd_del_loss_bwd_wgrad_f32, multi-row items of gd_spmm_csr_onepass_f32 */
 
 enum {
   GD_OK = 0,
@@ -444,6 +445,16 @@ int32_t gd_del_loss_bwd_blocks(int32_t n_sel);
 int gd_del_loss_bwd_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w, int32_t d,
                         const int32_t* loss_slot, const float* tm, const float* coef, const float* cnt_signed,
                         float* dz, int64_t ld_dz, float* dp, int64_t ld_dp, float* loss_partials, void* stream);
+
+/* The same pass + the Del weight's gradient (autograd's  p[idx,:]^T dz  for DeletionLayer.deletion_weight, deletion.py:17-29):
+ *     wgrad_partials[b, :, :] (b < gd_rows_gemm_wgrad_blocks(n_sel), each [d, d] row-major) = per-block sums of p[idx[s],:]^T dz[s,:],
+ * laid out and counted like the partials of gd_rows_gemm_wgrad_f32 (dw = NULL), so gd_rows_gemm_wgrad_reduce_f32 / gd_step_tail_f32
+ * finish it (fixed order: bit-reproducible).  The launch has that many blocks, so loss_partials holds
+ * 2 * gd_rows_gemm_wgrad_blocks(n_sel) floats here.  dz may be NULL (nothing else reads it once the gradient is formed here). */
+int gd_del_loss_bwd_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w, int32_t d,
+                              const int32_t* loss_slot, const float* tm, const float* coef, const float* cnt_signed,
+                              float* dz, int64_t ld_dz, float* dp, int64_t ld_dp, float* loss_partials,
+                              float* wgrad_partials, void* stream);
 
 /* ---------------------------------------------------------------- losses --------------- */
 

@@ -648,7 +648,8 @@ def test_rgcn_tile_conv_matches_oracle_and_node_major(n, m, R, din, dout, nb, mo
     assert rel_l2(got.cpu(), ref.cpu()) < 1e-5 and rel_l2(dx.cpu(), dref.cpu()) < 1e-5
 
 
-@pytest.mark.parametrize('n,d,frac,loss_frac', [(500, 64, 0.6, 0.8), (300, 32, 1.0, 1.0), (4000, 64, 0.9, 0.5), (70, 64, 0.3, 0.0)])
+@pytest.mark.parametrize('n,d,frac,loss_frac', [(500, 64, 0.6, 0.8), (300, 32, 1.0, 1.0), (4000, 64, 0.9, 0.5), (70, 64, 0.3, 0.0),
+                                                (300000, 64, 0.8, 0.7), (90000, 32, 0.5, 0.9)])
 def test_del_loss_bwd_fused_matches_separate_steps(n, d, frac, loss_frac):
     """Fused last-layer kernel (Del forward + folded MSE terms + Del input gradient) vs the same three steps in
     float64: dz on the Del rows, dp scattered to the full matrix, the two loss sums; rows with no loss slot."""
@@ -690,6 +691,30 @@ def test_del_loss_bwd_fused_matches_separate_steps(n, d, frac, loss_frac):
     assert rel_l2(dp.cpu(), dp_want) < TOL or float(dp_want.abs().max()) == 0
     got_s = parts.view(-1, 2).double().sum(0).cpu()
     np.testing.assert_allclose(got_s.numpy(), want_s, rtol=1e-5, atol=1e-7)
+    # the same pass + the Del weight's gradient (gd_del_loss_bwd_wgrad_f32): per-block partial sums of p[idx]^T dz in the layout
+    # of gd_rows_gemm_wgrad_f32, finished by gd_rows_gemm_wgrad_reduce_f32; with and without the dz buffer; same dp and sums
+    nbw = L.gd_rows_gemm_wgrad_blocks(s)
+    assert L.gd_rows_gemm_wgrad_workspace(s, d, d) == max(nbw, 0) * d * d
+    dw_want = p.double()[idx].t() @ dz_want
+    for with_dz in (True, False):
+        dz2 = torch.full((max(s, 1), d), 7.0, device='cuda')
+        dp2 = torch.zeros(n, d, device='cuda')
+        parts2 = torch.zeros(2 * max(nbw, 1), device='cuda')
+        ws = torch.full((max(nbw, 1) * d * d,), 3.0, device='cuda')
+        st = torch.cuda.current_stream().cuda_stream
+        check(L.gd_del_loss_bwd_wgrad_f32(ptr(args[0]), d, ptr(args[1]), s, ptr(args[2]), d, ptr(args[3]), ptr(args[4]), ptr(args[5]),
+                                          ptr(args[6]), ptr(dz2) if with_dz else None, d, ptr(dp2), d, ptr(parts2), ptr(ws), st))
+        assert torch.equal(dp2, dp)                                 # the same products in the same order
+        if with_dz:
+            assert torch.equal(dz2, dz)
+        np.testing.assert_allclose(parts2.view(-1, 2).double().sum(0).cpu().numpy(), want_s, rtol=1e-5, atol=1e-7)
+        dw = ws.view(max(nbw, 1), d, d).double().sum(0).cpu()
+        assert rel_l2(dw, dw_want) < TOL or float(dw_want.abs().max()) == 0
+        # against the separate weight-gradient launch on the same operands (another summation order: fp32 rounding apart)
+        dw_sep = torch.zeros(d, d, device='cuda')
+        ws_sep = torch.zeros(max(nbw, 1) * d * d, device='cuda')
+        check(L.gd_rows_gemm_wgrad_f32(ptr(args[0]), d, ptr(args[1]), ptr(dz), d, None, None, None, s, d, d, ptr(dw_sep), 0, ptr(ws_sep), st))
+        assert rel_l2(dw.float(), dw_sep.cpu()) < 1e-5 or float(dw_want.abs().max()) == 0
 
 
 def _csr_reference(src, dst, n):
