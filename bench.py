@@ -499,9 +499,14 @@ def stage_rooflines(eng, prof):
          lambda: eng._wgrad1(False, eng.dh), 2.0 * s1 * h * h, 4.0 * 4 * s1 * h),
         ('t2', 't2 = relu(z1 | pre1) W2^T', lambda: eng._linear_relu_z1(c2.lin.weight), 2.0 * n * h * o, 4.0 * (n * h + n * o + h * o) + n),
         ('spmm2', 'p2 = A t2 + b2 (d=64)', lambda: ops._spmm_raw(g.rowptr, g.col, g.val, t2, c2.bias, 0.0, n, g.plan, out=y64), 2.0 * nnz * o, spmm_b(o)),
-        ('del2_loss_bwd', 'z2 = p2[S2] W_D2, layer-2 loss, dp2[S2] = dz2 W_D2^T', eng._del2_fused, 4.0 * s2 * o * o, 4.0 * 4 * s2 * o),
+        # (three products and three row streams - p2 read, targets read, dp2 written - when the W_D2 weight gradient's partial
+        #  sums come out of the same kernel; otherwise two products, four streams and a weight-gradient launch of its own)
+        ('del2_loss_bwd', 'z2 = p2[S2] W_D2, layer-2 loss, dp2[S2] = dz2 W_D2^T' + (', dW_D2 partial sums = p2[S2]^T dz2' if eng._fuse_wg2 else ''),
+         eng._del2_fused, (6.0 if eng._fuse_wg2 else 4.0) * s2 * o * o, 4.0 * (3 if eng._fuse_wg2 else 4) * s2 * o),
+    ] + ([] if eng._fuse_wg2 else [
         ('wgrad2', 'dW_D2 partial products = p2[S2]^T dz2',
          lambda: eng._wgrad(eng.p2, eng.dz2c, None, s2, eng.g2, False, eng.ws2, a_idx=eng.idx2, adam=eng.adam2), 2.0 * s2 * o * o, 4.0 * 2 * s2 * o),
+    ]) + [
         ('spmm2_t', 'dt2 = A^T dp2 (d=64)', lambda: ops._spmm_raw(g.rowptr_t, g.col_t, g.val_t, eng.dz2, None, 0.0, n, g.plan_t, out=y64), 2.0 * nnz * o, spmm_b(o)),
         ('dh', 'dh[S1] = (dt2[S1] W2) * [z1[S1] > 0]', lambda: ops.rows_gemm(dt2, eng.idx1, c2.lin.weight, trans_w=False, out=eng.dh, gate_bits=eng.z1_pos),
          2.0 * s1 * o * h, 4.0 * (s1 * o + s1 * h) + 16.0 * s1),

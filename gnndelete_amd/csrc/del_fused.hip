@@ -96,9 +96,11 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
     const int sc = min(s_, n_sel - 1);
     n_row = idx[sc];
     n_u = n_live ? loss.slot[sc] : -1;
-    const float4* src = reinterpret_cast<const float4*>(p + (int64_t)n_row * ld_p + kh * (D / 2));
+    if (!WG) {
+      const float4* src = reinterpret_cast<const float4*>(p + (int64_t)n_row * ld_p + kh * (D / 2));
 #pragma unroll
-    for (int c4 = 0; c4 < D / 8; ++c4) n_pa[c4] = src[c4];
+      for (int c4 = 0; c4 < D / 8; ++c4) n_pa[c4] = src[c4];
+    }
     const int uc = max(n_u, 0);
     n_cf = loss.coef[uc];
     n_cn = loss.cnt_signed[uc];
@@ -110,9 +112,20 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
         for (int q = 0; q < 4; ++q) n_tv[t * 4 + q] = *reinterpret_cast<const float4*>(trow + 32 * t + 8 * q);
     }
   };
+  // (WG) the next tile's p rows are asked for only after this tile's weight-gradient product, when the registers of the
+  // transposed p operand are free again: the row-major copy, its transposed view, the D x D sums and a prefetched tile do not
+  // fit 256 registers together (56 B/lane of scratch when they were tried to); the Del-backward product covers the fetch
+  auto fetch_rows = [&]() {
+    const float4* src = reinterpret_cast<const float4*>(p + (int64_t)n_row * ld_p + kh * (D / 2));
+#pragma unroll
+    for (int c4 = 0; c4 < D / 8; ++c4) n_pa[c4] = src[c4];
+  };
   const int stride = gridDim.x * 4;
   int tile = blockIdx.x * 4 + wave;
-  if (tile < n_tiles) fetch(tile);
+  if (tile < n_tiles) {
+    fetch(tile);
+    if (WG) fetch_rows();
+  }
   for (; tile < n_tiles; tile += stride) {
     // the weight fragments a lane reads from LDS are the same for every tile; left alone the compiler hoists
     // all 2 NT D/2 of them out of this loop and spills - keep them as loads inside the loop
@@ -215,6 +228,8 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
           for (int mt = 0; mt < NT; ++mt)
             gacc[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op[st * NT + mt], b, gacc[mt * NT + nt], 0, 0, 0);
         }
+      asm volatile("" ::: "memory");                              // (the compiler would issue the fetch at the top of the tile)
+      if (tile + stride < n_tiles) fetch_rows();
     }
     // ---- dp^T tile = W_D dz^T : k slot (kk, kh) of feature tile t <-> feature i = 32t + (kk&3) + 8(kk>>2) + 4kh
     f32x16 dacc[NT];

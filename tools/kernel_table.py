@@ -14,8 +14,7 @@ NEXT = {
     'wgrad1': 'between the roofs (0.53 HBM / 0.44 MFMA): 2 blocks per CU alternate fetch and MFMA phases; a third block needs single-buffered tiles',
     't2': 'HBM-side of the ridge at 128 -> 64 (181 MB): 3.5 TB/s',
     'spmm2': 'latency-bound: two light rows per visit (multi-row items) took it 72 -> 67 us; four rows cost a fifth wave slot per SIMD and gave it back (NOTES round 3)',
-    'del2_loss_bwd': 'four row streams, 3.9 TB/s; candidate host for the W_D2 weight gradient (p2 and dz2 tiles are in registers): -1 launch, ~-12 us',
-    'wgrad2': 'see del2_loss_bwd',
+    'del2_loss_bwd': 'three products on three row streams since the W_D2 weight gradient moved in (was 50 + 26 us in two launches); 256 VGPRs + 56 B/lane of scratch at 2 waves per SIMD',
     'spmm2_t': 'as spmm2 (transposed CSR, S1 rows feed the next product)',
     'dh': 'MFMA / HBM (64 -> 128, gated): 168 MB at 3.6 TB/s',
     'tail': 'both split-K reductions + Adam + loss finalize in one launch (gd_step_tail_f32); launch-sized',

@@ -11,7 +11,7 @@ import argparse
 import json
 import sqlite3
 
-GCN_STEP = ['xw1', 'spmm1', 'del1', 'wgrad1', 't2', 'spmm2', 'del2_loss_bwd', 'wgrad2', 'spmm2_t', 'dh', 'tail']
+GCN_STEP = ['xw1', 'spmm1', 'del1', 'wgrad1', 't2', 'spmm2', 'del2_loss_bwd', 'spmm2_t', 'dh', 'tail']
 
 
 def kernels(db_path):
