@@ -532,6 +532,14 @@ class TypedNodeCSR:
         base_key, base_np = torch.unique_consecutive(piece_key // tile, return_counts=True)
         base_first = torch.cumsum(base_np, 0) - base_np
         base_of_piece = torch.repeat_interleave(torch.arange(base_key.numel(), device=dev), base_np)
+        if os.environ.get('GD_RGCN_SORT_PIECES', '1') == '1':
+            # inside a (tile, relation, pass) the pieces go longest first: the kernel gives a wave the pieces w, w + 8 (first
+            # round, its two lane groups side by side) and w + 16, w + 24 (second round), a round lasts as long as its longer
+            # piece, and the step's barrier waits for the slowest wave - sorted, the long pieces sit side by side in the first
+            # round of different waves and the second round holds the short ones.  (The pieces of a step belong to distinct
+            # rows: their order does not touch any sum.)
+            by_len = torch.argsort(base_of_piece * (cap + 1) + (cap - piece_len), stable=True)
+            piece_e0, piece_row, piece_len = piece_e0[by_len], piece_row[by_len], piece_len[by_len]
         sub = (torch.arange(piece_key.numel(), device=dev) - base_first[base_of_piece]) // max_pieces
         n_sub = int(sub.max()) + 1
         step_key, step_np = torch.unique_consecutive(base_key[base_of_piece] * n_sub + sub, return_counts=True)
