@@ -72,6 +72,26 @@ def test_engine_reproduces_wide_reference_trajectory(gnn, loss_type, use_graph, 
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < 1e-4
 
 
+@pytest.mark.parametrize('knob', [None, 'GD_NO_FUSED_WGRAD2', 'GD_NO_STEP_TAIL'])
+@pytest.mark.parametrize('gnn,loss_type', [('gcn', 'both_all'), ('gat', 'both_layerwise')])
+def test_wide_trajectory_with_and_without_the_tail_launch_and_the_fused_weight_gradient(monkeypatch, knob, gnn, loss_type):
+    """At 32 -> 128 -> 64 the step ends in ONE tail launch (both split-K reductions + Adam + loss finalize, gd_step_tail_f32) and
+    the W_D2 weight gradient's partial sums come out of the fused Del-2 kernel (gd_del_loss_bwd_wgrad_f32) - asserted; with
+    either switched off (the separate weight-gradient launch / the three separate tail launches) the reference trajectory
+    comes out as well."""
+    if knob:
+        monkeypatch.setenv(knob, '1')
+    eng, m, rest = make_engine(gnn, loss_type, True, load_golden(f'traj_wide_{gnn}_{loss_type}.npz'))
+    assert eng._tail == (knob != 'GD_NO_STEP_TAIL') and eng._fuse_wg2 == (knob is None)
+    for _ in range(int(rest['epochs'])):
+        eng.step()
+    hist = eng.loss_history().numpy()
+    for col, key in enumerate(['train_loss', 'loss_r', 'loss_l']):
+        np.testing.assert_allclose(hist[:, col], rest[key], rtol=1e-4, atol=1e-8, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), rest['final_w1']) < 1e-4
+    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < 1e-4
+
+
 @pytest.mark.parametrize('gnn,loss_type', [('gcn', 'both_layerwise'), ('gat', 'both_layerwise')])
 def test_graph_replay_is_bit_identical_to_eager(gnn, loss_type):
     fx = load_golden(f'traj_gat_{loss_type}.npz') if gnn == 'gat' else load_golden('traj_gcn_both_all.npz')
