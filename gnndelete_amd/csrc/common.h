@@ -13,6 +13,11 @@ constexpr int kWave = 64;  // CDNA wavefront width (hard-coded on purpose: gfx95
 
 char* error_buffer();  // thread-local, defined in api.cpp
 int matrix_split();    // 0 / 6 / 9, see gd_set_matrix_split (api.cpp)
+int ws_cu_count();     // compute units of the current device (rows_gemm_ws.hip)
+// weight-stationary row GEMM (rows_gemm_ws.hip): GD_OK / error when it took the call, 1 when the shape / mode is not covered
+int rows_gemm_ws_try(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t d_in, int32_t d_out,
+                     int32_t trans_w, const float* bias, int32_t relu_in, const uint32_t* gate_bits, uint32_t* sign_out, float* out,
+                     int64_t ld_out, float* save_in, void* stream, const float* in_alt, const uint8_t* sel, bool has_dots);
 
 inline int fail(int code, const char* fmt, ...) {
   va_list ap;

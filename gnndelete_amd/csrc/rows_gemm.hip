@@ -869,6 +869,11 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
   GD_REQUIRE(in != out || d_in == d_out, GD_E_DIM, "gd_rows_gemm_f32: in-place needs d_in == d_out");
   GD_REQUIRE(!(gate_bits && sign_out), GD_E_DIM, "gd_rows_gemm_f32: gate and sign output are exclusive");
   if (n_sel == 0) return GD_OK;
+  {   // the Del operator's widths at step size: weight-stationary register form (rows_gemm_ws.hip)
+    const int rc = rows_gemm_ws_try(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, bias, relu_in, gate_bits, sign_out, out, ld_out,
+                                    save_in, stream, in_alt, sel, dots.u1 != nullptr);
+    if (rc != 1) return rc;
+  }
   hipStream_t s = (hipStream_t)stream;
   size_t lds = (size_t)d_in * 32 * (d_out / 32 == 3 ? 4 : d_out / 32) * sizeof(float);   // NT = 3 is padded to 4
   const int np = matrix_split();

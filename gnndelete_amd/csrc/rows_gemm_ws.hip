@@ -1,0 +1,277 @@
+// Weight-stationary row GEMM for the Del operator's widths (d_in, d_out in {64, 128}):
+//
+//     out[row(s), :] = act(in[row(s), :]) @ W        s over an index list (or all rows)
+//
+// The LDS-operand form (rows_gemm.hip: four waves per SIMD, the weight operand of every matrix instruction read from a 64 KB
+// LDS image) holds the fp32 matrix pipe 50-57 % busy; its knock-outs put a quarter of the time on that LDS operand (NOTES,
+// rounds 1-3).  Here ONE wave per SIMD keeps the WHOLE weight as MFMA A-fragments in its registers (128 x 128 = 256 of the 512
+// registers a lone wave owns) and nothing but matrix instructions sits between a row tile's loads and its stores:
+//
+//   v_mfma_f32_16x16x4_f32, work unit = 16 rows.  lane (r = lane & 15, kq = lane >> 4) holds x[row r][kq KQ + s], s = 0 .. KQ-1
+//   (KQ = d_in / 4: contiguous -> 16-byte loads); step s multiplies A = W[kq KQ + s][16 t + r] (register wr[t][s]) with it - the
+//   k order is permuted, both operands agree; D: lane (r, kq) ends with outputs 16 t + 4 kq + c of ITS row: float4 stores, a
+//   store instruction writes 64 contiguous bytes of 16 rows.
+//   Ring: as soon as the matrix instructions of a k chunk are issued its row registers are reloaded with the same chunk of the
+//   NEXT unit (a whole unit, ~3.5 us, to land); row ids / selectors are requested two units ahead.  Results go to shadow
+//   registers at the end of a unit and are stored one output tile per k chunk UNDER the next unit's matrix instructions (a
+//   lone wave that stalls on a store queue idles its matrix pipe: stores at the end of a tile cost 10 %).
+//   No branch in the loop: a load or store under a branch makes every wait of the loop a vmcnt(0) (measured in the lab:
+//   tools/experiments/ws_gemm_lab.hip).  Rows past the end are clamped to the last row: those lanes recompute it and rewrite
+//   it with identical values.  On its first trip a wave stores zeros to its first unit's rows, overwritten a trip later by the
+//   results (same wave, same addresses: program order).
+//   The weight reaches the registers through LDS once per block (coalesced pass over W, then conflict-free 4-byte reads).
+//
+// Measured (lab, 178,921 x 128 -> 128, back to back): 59.7 us against 75.8 us for the LDS-operand form; 235,868 x 128 -> 128:
+// 73.6 against 95.8 us; 128 -> 64: 39.8 against 51.0 us.  Steady state 9.0-9.1 k cycles per unit (8,192 = matrix pipe only).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace gd {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// v[l] | v[l ^ 16] | v[l ^ 32] | v[l ^ 48] in every lane (the four lanes of a row), VALU only
+__device__ __forceinline__ uint32_t or_row_lanes(uint32_t v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = a[0] | a[1];
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return b[0] | b[1];
+}
+
+// MODE 0: plain, 1: also emit the packed [out > 0] pattern of each row, 2: gate the output by such a pattern
+// SEL: row r comes from in_alt where sel[r] != 0 (dense only)
+template <int DIN, int DOUT, int MODE, bool HASIDX, bool SEL, bool RELU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rows_gemm_ws_kernel(
+    const float* __restrict__ in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel, const float* __restrict__ w,
+    int32_t trans_w, float* __restrict__ out, int64_t ld_out, const uint32_t* __restrict__ gate_bits,
+    uint32_t* __restrict__ sign_out, const float* __restrict__ in_alt, const uint8_t* __restrict__ sel) {
+  constexpr int KQ = DIN / 4, NT = DOUT / 16, XV = KQ / 4, NW = DOUT / 32;
+  static_assert(!(HASIDX && SEL), "the selector form is dense");
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar loop control)
+  const int r = lane & 15, kq = lane >> 4;
+  const int n_units = (n_sel + 15) >> 4;
+  const int n_waves = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
+  // contiguous unit range per wave (the index lists are sorted: a wave's rows are neighbours)
+  const int u_lo = (int)((int64_t)n_units * wid / n_waves), u_hi = (int)((int64_t)n_units * (wid + 1) / n_waves);
+  const int u_first = min(u_lo, n_units - 1);
+
+  // what a unit's row loads need and cannot compute: the row id (index list) or the row's selector byte
+  auto slot_of = [&](int u) -> int { return min(u * 16 + r, n_sel - 1); };
+  auto desc_of = [&](int u) -> int32_t {
+    const int s_ = slot_of(min(u, n_units - 1));
+    return HASIDX ? idx[s_] : (SEL ? (int32_t)sel[s_] : 0);
+  };
+  auto src_of = [&](int u, int32_t desc) -> const float4* {
+    const int64_t row = HASIDX ? (int64_t)desc : (int64_t)slot_of(min(u, n_units - 1));
+    const float* base = (SEL && desc) ? in_alt : in;
+    return reinterpret_cast<const float4*>(base + row * ld_in + kq * KQ);
+  };
+  int32_t d_cur = desc_of(u_first), d_nxt = desc_of(u_first + 1);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- weight image wl[k DOUT + n + 16 (k / KQ)]: the two k quarters one 32-lane LDS access touches sit 16 banks apart
+  constexpr int FV = DIN * DOUT / 4 / 256;                 // float4 per thread
+  float4 fill[FV];
+  if (!trans_w) {
+#pragma unroll
+    for (int q = 0; q < FV; ++q) fill[q] = reinterpret_cast<const float4*>(w)[tid + 256 * q];
+  } else {                                                 // [n][k] weights: thread -> (k4, n), 16 bytes along k
+#pragma unroll
+    for (int q = 0; q < FV; ++q) {
+      const int e = tid + 256 * q, n = e % DOUT, k4 = e / DOUT;
+      fill[q] = *reinterpret_cast<const float4*>(w + (int64_t)n * DIN + 4 * k4);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // the first unit's rows: in flight under the weight fill
+  float4 x[XV];
+  {
+    const float4* src = src_of(u_first, d_cur);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) x[i] = src[i];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (!trans_w) {
+#pragma unroll
+    for (int q = 0; q < FV; ++q) {
+      const int e = tid + 256 * q, k = e / (DOUT / 4), n4 = e % (DOUT / 4);
+      *reinterpret_cast<float4*>(wl + k * DOUT + 4 * n4 + 16 * (k / KQ)) = fill[q];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < FV; ++q) {
+      const int e = tid + 256 * q, n = e % DOUT, k4 = e / DOUT;
+      const float v[4] = {fill[q].x, fill[q].y, fill[q].z, fill[q].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wl[(4 * k4 + c) * DOUT + n + 16 * ((4 * k4 + c) / KQ)] = v[c];
+    }
+  }
+  __syncthreads();
+  float wr[NT][KQ];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s = 0; s < KQ; ++s) wr[t][s] = wl[(kq * KQ + s) * DOUT + 16 * t + r + 16 * kq];
+  if (u_lo >= u_hi) return;
+
+  // shadow of the previous unit's results (stored one output tile per k chunk under this unit's matrix instructions)
+  f32x4v sh[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) sh[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  float* dst_prev = out + (HASIDX ? (int64_t)d_cur : (int64_t)slot_of(u_lo)) * ld_out + 4 * kq;
+  int sa_prev = slot_of(u_lo);
+  uint32_t sg[NW], gsh[NW];
+#pragma unroll
+  for (int q = 0; q < NW; ++q) sg[q] = gsh[q] = 0;
+
+  auto store_tile = [&](int t) {
+    float4 v = make_float4(sh[t][0], sh[t][1], sh[t][2], sh[t][3]);
+    // bit b of word q of a row's packed pattern is output 32 q + b: this lane owns bits 16 (t & 1) + 4 kq + c of word t >> 1
+    if (MODE == 2) {
+      const uint32_t m = gsh[t >> 1] >> (16 * (t & 1) + 4 * kq);
+      v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f;
+      v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+    }
+    if (MODE == 1) {
+      const uint32_t b = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+      sg[t >> 1] |= b << (16 * (t & 1) + 4 * kq);
+    }
+    *reinterpret_cast<float4*>(dst_prev + 16 * t) = v;
+  };
+  auto store_signs = [&]() {          // the four lanes of a row merge their bits; lane kq writes word kq (mod NW)
+    uint32_t mine = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const uint32_t v = or_row_lanes(sg[q]);
+      if ((kq & (NW - 1)) == q) mine = v;
+      sg[q] = 0;
+    }
+    sign_out[(int64_t)sa_prev * NW + (kq & (NW - 1))] = mine;
+  };
+
+  for (int u = u_lo; u < u_hi; ++u) {
+    const int32_t d_nn = desc_of(u + 2);                     // used a unit from now
+    const float4* nsrc = src_of(u + 1, d_nxt);
+    uint32_t gcur[NW];
+    if (MODE == 2) {
+      const uint32_t* gp = gate_bits + (int64_t)slot_of(u) * NW;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) gcur[q] = gp[q];
+    }
+    f32x4v acc[NT];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      float xv[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
+      if (RELU) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xv[c] = fmaxf(xv[c], 0.f);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (i == 0 && c == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][0], xv[0], f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][4 * i + c], xv[c], acc[t], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      x[i] = nsrc[i];                                        // the registers just consumed: same chunk of the next unit
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (t * XV / NT == i) store_tile(t);
+      if (MODE == 1 && i == XV - 1) store_signs();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sh[t] = acc[t];
+    if (MODE == 2) {
+#pragma unroll
+      for (int q = 0; q < NW; ++q) gsh[q] = gcur[q];
+    }
+    dst_prev = out + (HASIDX ? (int64_t)d_cur : (int64_t)slot_of(u)) * ld_out + 4 * kq;
+    sa_prev = slot_of(u);
+    d_cur = d_nxt;
+    d_nxt = d_nn;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) store_tile(t);
+  if (MODE == 1) store_signs();
+}
+
+int ws_cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
+template <int DIN, int DOUT, int MODE, bool HASIDX, bool SEL, bool RELU>
+static int ws_launch(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t trans_w, float* out,
+                     int64_t ld_out, const uint32_t* gate_bits, uint32_t* sign_out, const float* in_alt, const uint8_t* sel,
+                     hipStream_t s) {
+  auto kern = rows_gemm_ws_kernel<DIN, DOUT, MODE, HASIDX, SEL, RELU>;
+  constexpr size_t lds = (size_t)(DIN * DOUT + 64) * sizeof(float);
+  static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  GD_REQUIRE(once == hipSuccess, -(int)once, "gd_rows_gemm_f32: cannot raise the LDS limit of the weight-stationary kernel");
+  hipLaunchKernelGGL(kern, dim3(ws_cu_count()), dim3(256), lds, s, in, ld_in, idx, n_sel, w, trans_w, out, ld_out, gate_bits,
+                     sign_out, in_alt, sel);
+  return launched("rows_gemm_ws");
+}
+
+template <int DIN, int DOUT>
+static int ws_dispatch(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t trans_w,
+                       int32_t relu_in, float* out, int64_t ld_out, const uint32_t* gate_bits, uint32_t* sign_out,
+                       const float* in_alt, const uint8_t* sel, hipStream_t s) {
+#define GD_WS(MODE, HASIDX, SELV, RELU) \
+  return ws_launch<DIN, DOUT, MODE, HASIDX, SELV, RELU>(in, ld_in, idx, n_sel, w, trans_w, out, ld_out, gate_bits, sign_out, in_alt, sel, s)
+  if (gate_bits) { if (idx) GD_WS(2, true, false, false); else GD_WS(2, false, false, false); }
+  if (sign_out) { if (idx) GD_WS(1, true, false, false); else GD_WS(1, false, false, false); }
+  if (sel) { if (relu_in) GD_WS(0, false, true, true); else GD_WS(0, false, true, false); }
+  if (idx) { if (relu_in) GD_WS(0, true, false, true); else GD_WS(0, true, false, false); }
+  if (relu_in) GD_WS(0, false, false, true);
+  GD_WS(0, false, false, false);
+#undef GD_WS
+}
+
+static bool ws_on() {
+  static const bool on = [] { const char* e = getenv("GD_ROWS_GEMM_WS"); return !(e && atoi(e) == 0); }();
+  return on;
+}
+static int ws_min_rows() {
+  static const int v = [] { const char* e = getenv("GD_ROWS_GEMM_WS_MIN_ROWS"); return e && atoi(e) > 0 ? atoi(e) : 65536; }();
+  return v;
+}
+
+// -> GD_OK / error when the weight-stationary kernel took the call, 1 when it does not cover it (the caller goes on with
+// the LDS-operand form).  Covered: widths in {64, 128}, no bias, no saved input, no row dots, out not aliasing an input,
+// enough rows that every wave gets units; ReLU on the input only in the plain mode; the selector form only dense.
+int rows_gemm_ws_try(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t d_in, int32_t d_out,
+                     int32_t trans_w, const float* bias, int32_t relu_in, const uint32_t* gate_bits, uint32_t* sign_out, float* out,
+                     int64_t ld_out, float* save_in, void* stream, const float* in_alt, const uint8_t* sel, bool has_dots) {
+  if (!ws_on() || matrix_split() != 0 || bias || save_in || has_dots || n_sel < ws_min_rows()) return 1;
+  if (!((d_in == 64 || d_in == 128) && (d_out == 64 || d_out == 128))) return 1;
+  if (in == out || in_alt == out || (sel && idx) || (relu_in && (gate_bits || sign_out)) || (sel && (gate_bits || sign_out))) return 1;
+  if (!aligned16(in) || !aligned16(out) || !aligned16(w) || (in_alt && !aligned16(in_alt)) || ld_in % 4 || ld_out % 4) return 1;
+  hipStream_t s = (hipStream_t)stream;
+#define GD_WS_SHAPE(DI, DO) \
+  return ws_dispatch<DI, DO>(in, ld_in, idx, n_sel, w, trans_w, relu_in, out, ld_out, gate_bits, sign_out, in_alt, sel, s)
+  if (d_in == 128 && d_out == 128) GD_WS_SHAPE(128, 128);
+  if (d_in == 128 && d_out == 64) GD_WS_SHAPE(128, 64);
+  if (d_in == 64 && d_out == 128) GD_WS_SHAPE(64, 128);
+  GD_WS_SHAPE(64, 64);
+#undef GD_WS_SHAPE
+}
+
+}  // namespace gd
+
+extern "C" int gd_rows_gemm_ws_covers(int32_t n_sel, int32_t d_in, int32_t d_out) {
+  return gd::ws_on() && gd::matrix_split() == 0 && n_sel >= gd::ws_min_rows() && (d_in == 64 || d_in == 128) &&
+                 (d_out == 64 || d_out == 128)
+             ? 1
+             : 0;
+}

@@ -21,7 +21,7 @@
  *   - re-entrant per stream.  Process-wide state is limited to: the thread-local error string; the opt-in
  *     gd_set_matrix_split() switch (initialised from the environment, read at launch time; leave it alone and every
  *     call is a pure function of its arguments); tuning knobs read ONCE from the environment at first use
- *     (GD_SPMM_GRID_CAP, GD_ROWS_GEMM_GRID, GD_ROWS_GEMM_QUEUE); the lazily resolved RCCL entry points.
+ *     (GD_SPMM_GRID_CAP, GD_ROWS_GEMM_GRID, GD_ROWS_GEMM_QUEUE, GD_ROWS_GEMM_WS, GD_ROWS_GEMM_WS_MIN_ROWS); the lazily resolved RCCL entry points.
  */
 #ifndef GNNDELETE_HIP_H
 #define GNNDELETE_HIP_H
@@ -32,10 +32,11 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 5   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
+#define GD_ABI_VERSION 6   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
                               4: gd_spmm_csr_onepass_f32, gd_rows_gemm_wgrad_reduce_f32 (dw = NULL in the wgrad entries),
                                  gd_comm_* / gd_allreduce_f32 / gd_exchange_rows_f32, gd_segment_softmax_f32, gd_rowpair_dot_f32, gd_step_tail_f32;
-                              5: gd_del_loss_bwd_wgrad_f32, multi-row items of gd_spmm_csr_onepass_f32 */
+                              5: gd_del_loss_bwd_wgrad_f32, multi-row items of gd_spmm_csr_onepass_f32;
+                              6: gd_rows_gemm_ws_covers (weight-stationary form of the row GEMMs) */
 
 enum {
   GD_OK = 0,
@@ -307,7 +308,12 @@ int gd_rowpair_loss_f32(int32_t kind, const float* a, int64_t ld_a, const int64_
  *   bias (optional, [d_out]) is added.
  * With idx = S_Df node list and W = deletion_weight this is DeletionLayer.forward
  * (framework/models/deletion.py:17-29: clone + boolean gather + matmul + index_put); with
- * trans_w it is its input-gradient; with idx = NULL it is a dense Linear. */
+ * trans_w it is its input-gradient; with idx = NULL it is a dense Linear.
+ * Two kernel forms, same results to fp32 rounding (the k order of the accumulation differs):
+ *   - weight-stationary (rows_gemm_ws.hip, v_mfma_f32_16x16x4_f32): one wave per SIMD keeps W in its registers; taken
+ *     where gd_rows_gemm_ws_covers() says so - widths in {64, 128}, >= 65,536 rows, no bias / save_in, out not
+ *     aliasing in, fp32 products (GD_ROWS_GEMM_WS=0 in the environment turns it off);
+ *   - LDS-operand (rows_gemm.hip): everything else, down to a scalar kernel for odd widths. */
 int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel,
                      const float* w, int32_t d_in, int32_t d_out, int32_t trans_w,
                      const float* bias, int32_t relu_in,
@@ -316,6 +322,8 @@ int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t
 /* gd_rows_gemm_f32 over a matrix whose rows live in two buffers of the same shape: row r is read from
  * in_alt where sel[r] != 0 and from in otherwise (e.g. z1 = Del-1 output on the S_Df rows, conv1 output
  * elsewhere: deletion.py:17-29 clones the whole matrix to get this; here neither copy is made). */
+int gd_rows_gemm_ws_covers(int32_t n_sel, int32_t d_in, int32_t d_out);   /* 1: plain / sign / gate calls of this size run weight-stationary */
+
 int gd_rows_gemm_select_f32(const float* in, const float* in_alt, const uint8_t* sel, int64_t ld_in,
                             const int32_t* idx, int32_t n_sel, const float* w, int32_t d_in, int32_t d_out,
                             int32_t trans_w, const float* bias, int32_t relu_in,

@@ -160,6 +160,64 @@ def test_rows_gemm_forward_transpose_and_inplace(n, d_in, d_out, frac, matrix_sp
         assert rel_l2(z.cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize('d_in,d_out', [(128, 128), (128, 64), (64, 128), (64, 64)])
+def test_rows_gemm_weight_stationary_form(d_in, d_out):
+    """The register-resident-weight form (csrc/rows_gemm_ws.hip) that the Del operator's widths take from 65,536 rows up:
+    every mode it covers - index list / dense, [k][n] / [n][k] weights, ReLU on the input, rows from two buffers, packed
+    sign pattern out, gate pattern in - against fp64 products; n is not a multiple of the 16-row work unit; rows outside
+    the index list stay untouched; what it does not cover (bias, saved input, in place) still runs (LDS-operand form)."""
+    from gnndelete_amd import _lib, ops
+    n = 80_003
+    assert _lib.lib().gd_rows_gemm_ws_covers(n - 7000, d_in, d_out) == 1 and _lib.lib().gd_rows_gemm_ws_covers(5000, d_in, d_out) == 0
+    g = torch.Generator().manual_seed(d_in + 3 * d_out)
+    x = torch.randn(n, d_in, generator=g).cuda()
+    x2 = torch.randn(n, d_in, generator=g).cuda()
+    w = (torch.randn(d_in, d_out, generator=g) * 0.2).cuda()
+    mask = torch.rand(n, generator=g) < 0.93
+    mask[-1] = True
+    if int(mask.sum()) % 16 == 0:
+        mask[int(mask.nonzero()[0])] = False
+    maskg = mask.cuda()
+    idx = mask.nonzero().flatten().int().cuda()
+    assert idx.numel() >= 65536 and idx.numel() % 16 != 0
+    xd, wd = x.double(), w.double()
+    want = xd @ wd
+    # index list, out of place, untouched rows
+    out = torch.full((n, d_out), 7.0, device='cuda')
+    ops.rows_gemm(x, idx, w, out=out)
+    assert rel_l2(out[maskg], want[maskg]) < TOL
+    assert bool((out[~maskg] == 7.0).all())
+    # dense, [n][k] weight, ReLU on the input
+    out2 = ops.rows_gemm(x, None, w.t().contiguous(), trans_w=True, relu_in=True)
+    assert rel_l2(out2, xd.clamp(min=0) @ wd) < TOL
+    # rows from two buffers
+    sel = (torch.rand(n, generator=g) < 0.4).cuda()
+    out3 = ops.rows_gemm_select(x, x2, sel.to(torch.uint8), w, relu_in=True)
+    assert rel_l2(out3, torch.where(sel[:, None], x2.double(), xd).clamp(min=0) @ wd) < TOL
+    # sign pattern out (bit b of word q = output 32 q + b), gate pattern in
+    n_words = d_out // 32
+    bits = torch.zeros(idx.numel(), n_words, dtype=torch.int32, device='cuda')
+    out4 = ops.rows_gemm(x, idx, w, out=torch.zeros(n, d_out, device='cuda'), sign_bits=bits)
+    assert torch.equal(out4[maskg], out[maskg])
+    got_bits = ((bits[:, :, None] >> torch.arange(32, dtype=torch.int32, device='cuda')) & 1).reshape(idx.numel(), d_out).bool()
+    assert torch.equal(got_bits, out4[maskg] > 0)
+    out5 = ops.rows_gemm(x, idx, w * 1.5, out=torch.full((n, d_out), 3.0, device='cuda'), gate_bits=bits)
+    assert rel_l2(out5[maskg], 1.5 * want[maskg] * (out4[maskg] > 0)) < TOL
+    assert bool((out5[~maskg] == 3.0).all())
+    # bit-reproducible
+    assert torch.equal(ops.rows_gemm(x, idx, w, out=torch.full((n, d_out), 7.0, device='cuda')), out)
+    # not covered by this form: bias, and (square widths) the in-place call
+    b = torch.randn(d_out, generator=g).cuda()
+    out6 = ops.rows_gemm(x, None, w, bias=b)
+    assert rel_l2(out6, want + b.double()) < TOL
+    if d_in == d_out:
+        z = x.clone()
+        ops.rows_gemm(z, idx, w, out=z)
+        ref = xd.clone()
+        ref[maskg] = want[maskg]
+        assert rel_l2(z, ref) < TOL
+
+
 @pytest.mark.parametrize('n,d_a,d_b,frac', [(300, 128, 128, 0.5), (300, 64, 64, 0.8), (100, 128, 64, 1.0),
                                             (50, 12, 12, 0.5), (60, 128, 4, 0.6), (20, 64, 64, 0.0),
                                             (70000, 128, 128, 0.7)])
