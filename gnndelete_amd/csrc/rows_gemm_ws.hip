@@ -12,8 +12,8 @@
 //   k order is permuted, both operands agree; D: lane (r, kq) ends with outputs 16 t + 4 kq + c of ITS row: float4 stores, a
 //   store instruction writes 64 contiguous bytes of 16 rows.
 //   Ring: as soon as the matrix instructions of a k chunk are issued its row registers are reloaded with the same chunk of the
-//   NEXT unit (a whole unit, ~3.5 us, to land); row ids / selectors are requested two units ahead.  Results go to shadow
-//   registers at the end of a unit and are stored one output tile per k chunk UNDER the next unit's matrix instructions (a
+//   NEXT unit (a whole unit, ~3.5 us, to land); row ids / selectors are requested two units ahead.  Two accumulator sets take
+//   alternate units: a unit's results are stored one output tile per k chunk UNDER the next unit's matrix instructions (a
 //   lone wave that stalls on a store queue idles its matrix pipe: stores at the end of a tile cost 10 %).
 //   No branch in the loop: a load or store under a branch makes every wait of the loop a vmcnt(0) (measured in the lab:
 //   tools/experiments/ws_gemm_lab.hip).  Rows past the end are clamped to the last row: those lanes recompute it and rewrite
@@ -117,18 +117,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int s = 0; s < KQ; ++s) wr[t][s] = wl[(kq * KQ + s) * DOUT + 16 * t + r + 16 * kq];
   if (u_lo >= u_hi) return;
 
-  // shadow of the previous unit's results (stored one output tile per k chunk under this unit's matrix instructions)
-  f32x4v sh[NT];
+  // Two accumulator sets take alternate units: while one receives a unit's products the other one's - the previous unit's
+  // results - are stored, one output tile per k chunk, under the matrix instructions (no copies; the loop body is two units,
+  // an odd unit is peeled off in front).
+  f32x4v acc_a[NT], acc_b[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) sh[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t) acc_a[t] = acc_b[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
   float* dst_prev = out + (HASIDX ? (int64_t)d_cur : (int64_t)slot_of(u_lo)) * ld_out + 4 * kq;
   int sa_prev = slot_of(u_lo);
   uint32_t sg[NW], gsh[NW];
 #pragma unroll
   for (int q = 0; q < NW; ++q) sg[q] = gsh[q] = 0;
 
-  auto store_tile = [&](int t) {
-    float4 v = make_float4(sh[t][0], sh[t][1], sh[t][2], sh[t][3]);
+  auto store_tile = [&](const f32x4v& a, int t) {
+    float4 v = make_float4(a[0], a[1], a[2], a[3]);
     // bit b of word q of a row's packed pattern is output 32 q + b: this lane owns bits 16 (t & 1) + 4 kq + c of word t >> 1
     if (MODE == 2) {
       const uint32_t m = gsh[t >> 1] >> (16 * (t & 1) + 4 * kq);
@@ -151,8 +153,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     sign_out[(int64_t)sa_prev * NW + (kq & (NW - 1))] = mine;
   };
-
-  for (int u = u_lo; u < u_hi; ++u) {
+  // one unit: products into acc, the previous unit's results (old) out, the next unit's rows in
+  auto unit = [&](int u, f32x4v (&acc)[NT], const f32x4v (&old)[NT]) {
     const int32_t d_nn = desc_of(u + 2);                     // used a unit from now
     const float4* nsrc = src_of(u + 1, d_nxt);
     uint32_t gcur[NW];
@@ -161,7 +163,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int q = 0; q < NW; ++q) gcur[q] = gp[q];
     }
-    f32x4v acc[NT];
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
       float xv[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
@@ -170,22 +171,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int c = 0; c < 4; ++c) xv[c] = fmaxf(xv[c], 0.f);
       }
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int c = 0; c < 4; ++c) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           if (i == 0 && c == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][0], xv[0], f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][4 * i + c], xv[c], acc[t], 0, 0, 0);
         }
+        if (c == 1) {                                        // mid-chunk: the stores of this slot
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            if (t * XV / NT == i) store_tile(old[t], t);
+          if (MODE == 1 && i == XV - 1) store_signs();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       x[i] = nsrc[i];                                        // the registers just consumed: same chunk of the next unit
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (t * XV / NT == i) store_tile(t);
-      if (MODE == 1 && i == XV - 1) store_signs();
       __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) sh[t] = acc[t];
     if (MODE == 2) {
 #pragma unroll
       for (int q = 0; q < NW; ++q) gsh[q] = gcur[q];
@@ -194,9 +198,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     sa_prev = slot_of(u);
     d_cur = d_nxt;
     d_nxt = d_nn;
+  };
+  int u = u_lo;
+  if ((u_hi - u_lo) & 1) {
+    unit(u, acc_a, acc_b);
+    ++u;
   }
+  for (; u < u_hi; u += 2) {
+    unit(u, acc_b, acc_a);
+    unit(u + 1, acc_a, acc_b);
+  }
+  // the last unit's results are in acc_a either way
 #pragma unroll
-  for (int t = 0; t < NT; ++t) store_tile(t);
+  for (int t = 0; t < NT; ++t) store_tile(acc_a[t], t);
   if (MODE == 1) store_signs();
 }
 

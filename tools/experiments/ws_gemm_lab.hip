@@ -250,12 +250,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     *reinterpret_cast<float4*>(wl + k * DOUT + 4 * n4 + 16 * (k / KQ)) = reinterpret_cast<const float4*>(w)[e];
   }
   __syncthreads();
+  const unsigned long long cA = __builtin_readcyclecounter();
   float wr[NT][KQ];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int s = 0; s < KQ; ++s) wr[t][s] = wl[(kq * KQ + s) * DOUT + 16 * t + r + 16 * kq];
 
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const unsigned long long c1 = __builtin_readcyclecounter();
   const int n_units = (n_sel + 15) >> 4;
   const int n_waves = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
@@ -341,7 +343,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (stamps && lane == 0) {
     stamps[3 * wid + 0] = __builtin_readcyclecounter() - c0;
     stamps[3 * wid + 1] = wall_clock64() - w0;
-    stamps[3 * wid + 2] = (unsigned long long)(u_hi - u_lo) | ((c1 - c0) << 32);
+    stamps[3 * wid + 2] = (unsigned long long)(u_hi - u_lo) | ((c1 - c0) << 32) | ((cA - c0) << 48 >> 32 << 16 >> 16 << 0) * 0;
+    stamps[3 * 1024 + wid] = cA - c0;
   }
 }
 
@@ -380,7 +383,7 @@ static unsigned long long* g_stamps = nullptr;
 template <int NT, int DIN, int NCH, bool SIGNS, int KO = 0>
 static float run_ring(const char* name, const float* in, const int32_t* idx, int n_sel, const float* w, float* out, uint32_t* signs,
                       int reps, int grid) {
-  if (!g_stamps) CK(hipMalloc(&g_stamps, 3 * 8 * 4096));
+  if (!g_stamps) CK(hipMalloc(&g_stamps, 8 * 8 * 4096));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto launch = [&]() {
@@ -416,7 +419,7 @@ static float run_ring(const char* name, const float* in, const int32_t* idx, int
 template <int DIN, int DOUT, bool SIGNS, int KO = 0>
 static float run16(const char* name, const float* in, const int32_t* idx, int n_sel, const float* w, float* out, uint32_t* signs,
                    int reps, int grid) {
-  if (!g_stamps) CK(hipMalloc(&g_stamps, 3 * 8 * 4096));
+  if (!g_stamps) CK(hipMalloc(&g_stamps, 8 * 8 * 4096));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const size_t lds = (size_t)(DIN * DOUT + 64) * 4;
@@ -444,14 +447,20 @@ static float run16(const char* name, const float* in, const int32_t* idx, int n_
   std::vector<unsigned long long> st(3 * grid * 4);
   CK(hipMemcpy(st.data(), g_stamps, st.size() * 8, hipMemcpyDeviceToHost));
   double cyc = 0, wall = 0, tiles = 0, wmax = 0, wmin = 1e18;
-  double pro = 0;
+  double pro = 0, fillc = 0;
+  {
+    std::vector<unsigned long long> st2(1024);
+    CK(hipMemcpy(st2.data(), g_stamps + 3 * 1024, 1024 * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 1024; ++i) fillc += (double)st2[i];
+    fillc /= 1024;
+  }
   for (int i = 0; i < grid * 4; ++i) {
     cyc += st[3 * i]; wall += st[3 * i + 1]; tiles += (double)(st[3 * i + 2] & 0xffffffffull); pro += (double)(st[3 * i + 2] >> 32);
     wmax = fmax(wmax, (double)st[3 * i + 1]); wmin = fmin(wmin, (double)st[3 * i + 1]);
   }
   const double gf = 2.0 * n_sel * DIN * DOUT * 1e-9;
-  printf("%-34s rows %7d  %3d->%3d  KO %d : best %7.1f us  mean %7.1f us  = %6.1f TF | clock %.2f GHz, prologue %.0f cycles, %.0f cycles/unit after it, wave life %.1f .. %.1f us\n",
-         name, n_sel, DIN, DOUT, KO, best * 1e3, sum / reps * 1e3, gf / best, cyc / wall * 0.1, pro / (grid * 4), (cyc - pro) / tiles, wmin / 100., wmax / 100.);
+  printf("%-34s rows %7d  %3d->%3d  KO %d : best %7.1f us  mean %7.1f us  = %6.1f TF | clock %.2f GHz, fill+barrier %.0f, prologue %.0f cycles, %.0f cycles/unit after it, wave life %.1f .. %.1f us\n",
+         name, n_sel, DIN, DOUT, KO, best * 1e3, sum / reps * 1e3, gf / best, cyc / wall * 0.1, fillc, pro / (grid * 4), (cyc - pro) / tiles, wmin / 100., wmax / 100.);
   return best;
 }
 
