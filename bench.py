@@ -48,15 +48,20 @@ def parse():
     p.add_argument('--repeats', type=int, default=0,
                    help='timed regions of exactly --steps steps each; the MEDIAN region is reported (0 = 5 when --steps < 100, '
                         'else 1): a 20-step region is 14 ms, shorter than the clock / power ramp of the part')
-    p.add_argument('--stage_profile', default=os.path.join(ROOT, 'profiles', 'r03_final_stages.json'),
-                   help='per-stage in-step kernel durations + PMC traffic from the committed rocprofv3 runs (tools/rocpd_stage_table.py)')
+    p.add_argument('--stage_profile', default=None,
+                   help='per-stage in-step kernel durations + PMC traffic from the committed rocprofv3 runs (tools/rocpd_stage_table.py); '
+                        'default profiles/r04_final_stages.json (gcn) / profiles/r04_final_stages_<gnn>.json')
     p.add_argument('--probe_partition', action='store_true', help=argparse.SUPPRESS)   # child-process self test
+    p.add_argument('--probe_overlap', action='store_true', help=argparse.SUPPRESS)     # ... of the overlapped exchanges
     p.add_argument('--parallel', default='auto', choices=['auto', 'partition', 'replicas'],
                    help='N>1: "partition" (= "auto") = ONE request row-partitioned over the GPUs (RCCL halo all-to-all + '
                         'all-reduce per step, strong scaling: what north_star asks to be measured; the independent-'
                         'replicas rate of the same GPUs is reported next to it under extras); "replicas" = every GPU '
                         'serves its own unlearning request (no data-path collective, weak scaling) as the headline')
-    return p.parse_args()
+    a = p.parse_args()
+    if a.stage_profile is None:
+        a.stage_profile = os.path.join(ROOT, 'profiles', 'r04_final_stages.json' if a.gnn == 'gcn' else f'r04_final_stages_{a.gnn}.json')
+    return a
 
 
 def build_request(args, device):
@@ -119,6 +124,29 @@ def gather_halo_bytes(eng, world, ctl):
     return [[int(v) for v in t.tolist()] for t in every]
 
 
+def partition_estimate(eng, world, ctl, single_us, link_gbs=100.0):
+    """Planner's prediction of the partitioned step (printed under config.parallel_auto; `--parallel auto` partitions only
+    when it beats the single-GPU step): compute = the single-GPU step scaled by the rows this rank works on (layer 1 on own +
+    halo rows, the rest on own rows) + ~60 us of segment launches; exchange = the heaviest rank's halo bytes over ONE xGMI
+    link each way (a pair of GPUs shares one link; link_gbs = an assumed sustained rate, not a measurement: no multi-GPU
+    run has been recorded) + ~30 us for the packed all-reduce.  MAX over the ranks."""
+    import torch.distributed as dist
+    rep = eng.halo_report()
+    own, n = rep['own_rows'], eng.n
+    l1_share = 0.29                                       # x W1^T + layer-1 aggregation in the single-GPU step (profiles)
+    compute = single_us * (l1_share * (own + rep['layer1_rows_recomputed']) / n + (1 - l1_share) * own / n) + 60.0
+    # the exchanges move over one link per pair; the largest single transfer into this rank bounds it from below, all of it
+    # over one link from above - take the per-rank total over (world - 1) links as the estimate, never below the largest pair
+    recv = rep['recv_bytes_per_step']
+    exchange = recv / max(1, world - 1) / (link_gbs * 1e3) * (1.0 if world > 2 else 1.0) + 30.0
+    mine = torch.tensor([compute, exchange], dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=ctl)
+    comp, exch = max(float(t[0]) for t in every), max(float(t[1]) for t in every)
+    return {'single_gpu_step_us': single_us, 'predicted_partitioned_step_us': comp + exch, 'compute_us': comp, 'exchange_us': exch,
+            'assumed_link_gbs': link_gbs, 'rule': 'partition if predicted_partitioned_step_us < single_gpu_step_us, else independent replicas'}
+
+
 def make_kg_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1, group=None, partition=False):
     from gnndelete_amd.engine import NodeembEngine
     model = model.to(device)
@@ -132,7 +160,7 @@ def make_kg_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1, gr
         # ONE request, target rows partitioned over the ranks with typed halos (dist_engine, mode 'rgcn')
         from gnndelete_amd.dist_engine import PartitionedNodeembEngine
         return PartitionedNodeembEngine(*common, rank, world, loss_type=args.loss_type, alpha=0.5, lr=1e-3,
-                                        use_graph=not args.no_graph, group=group, edge_type=et)
+                                        use_graph=not args.no_graph, group=group, edge_type=et, overlap=getattr(args, 'dist_overlap', None))
     return NodeembEngine(*common, loss_type=args.loss_type, alpha=0.5, lr=1e-3, use_graph=not args.no_graph, edge_type=et)
 
 
@@ -176,9 +204,9 @@ def time_typed_conv(eng):
             'hbm': {'compulsory_bytes': nbytes, 'gbs': nbytes / dur / 1e9, 'frac': nbytes / dur / 1e9 / HBM_PEAK_GBS},
             'gathered_rows_gbs': 4.0 * nnz * d / dur / 1e9,          # L2 / Infinity Cache side, informational
             'root_product_us': dur_root * 1e6, 'typed_edges': nnz, 'runs': runs,
-            'note': 'neither roof bounds it: 0.14 of the MFMA peak, 0.02 of HBM on compulsory bytes; its fabric traffic (the gathered rows, all L2 '
-                    'misses) runs at ~0.54 of the 6.5 TB/s fabric rate, and a 10 % traffic cut changes nothing - the per-step dependent '
-                    'chain bounds it (DESIGN.md kernel table, profiles/r03_rgcn_tile_traffic.json, profiles/r03_rgcn_reorder_ab.txt)',
+            'note': (f'this launch: {tf / MFMA_F32_PEAK_TFLOPS:.2f} of the MFMA peak, {nbytes / dur / 1e9 / HBM_PEAK_GBS:.2f} of HBM on compulsory bytes'
+                     + (f', fabric traffic (the gathered rows, all L2 misses) at {traffic / dur / 1e12:.2f} TB/s' if traffic else '')
+                     + '; what bounds the kernel: DESIGN.md kernel table'),
             'tile_plan': {k: plan[k] for k in ('n_tiles', 'n_steps', 'n_pieces', 'n_hubs', 'n_slice_rows', 'max_steps') if k in plan}}
 
 
@@ -300,7 +328,7 @@ def train_backbone(model, data, device, epochs, lr=0.01):
         loss.backward()
         opt.step()
         opt.zero_grad()
-    return float(loss) if loss is not None else None
+    return float(loss.detach()) if loss is not None else None
 
 
 def make_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1, group=None):
@@ -319,7 +347,7 @@ def make_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1, group
         # ONE request, rows partitioned over the ranks (strong scaling)
         from gnndelete_amd.dist_engine import PartitionedNodeembEngine
         return PartitionedNodeembEngine(*common, rank, world, loss_type=args.loss_type, alpha=0.5, lr=1e-3,
-                                        use_graph=not args.no_graph, group=group)
+                                        use_graph=not args.no_graph, group=group, overlap=getattr(args, 'dist_overlap', None))
     return NodeembEngine(*common, loss_type=args.loss_type, alpha=0.5, lr=1e-3, use_graph=not args.no_graph)
 
 
@@ -458,18 +486,70 @@ def time_spmm_d64(eng):
             'algorithmic_bytes': nbytes, 'avg_us': dur * 1e6}
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources and the C header (sorted by name): stamps a stage profile with the kernels it measured."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'gnndelete_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'gnndelete_amd', 'csrc', '*.h'))
+                   + glob.glob(os.path.join(ROOT, 'gnndelete_amd', 'csrc', '*.cpp')) + [os.path.join(ROOT, 'include', 'gnndelete_hip.h')])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load_stage_profile(path, n, nnz):
     """The committed per-stage table of the replayed step (tools/rocpd_stage_table.py over the rocprofv3 kernel-trace and
-    --pmc passes of THIS command, profiles/): in-step durations and counter traffic; {} when the workload differs."""
+    --pmc passes of THIS command, profiles/): in-step durations and counter traffic.  -> (record, why_not): the record is
+    only used when it was taken on this workload AND with the kernel sources of this tree (`csrc_sha`): numbers of other
+    kernels are not attached to this run's entries."""
     try:
         with open(path) as f:
             rec = json.load(f)
-        w = rec.get('workload', {})
-        if (w.get('num_nodes'), w.get('spmm_nnz')) == (n, nnz):
-            return rec
     except (OSError, ValueError):
-        pass
-    return {}
+        return {}, 'no stage profile at ' + os.path.relpath(path, ROOT)
+    w = rec.get('workload', {})
+    if (w.get('num_nodes'), w.get('spmm_nnz')) != (n, nnz):
+        return {}, 'stage profile is of another workload'
+    if rec.get('csrc_sha') != kernel_source_hash():
+        return {}, f"stage profile is stale: taken with kernel sources {rec.get('csrc_sha')}, this tree is {kernel_source_hash()}"
+    return rec, None
+
+
+def fabric_ceiling(n, nnz, d):
+    """Upper bound of the HBM-roofline fraction ANY kernel with one contiguous row range per XCD can reach on this graph:
+    algorithmic bytes / (traffic floor with 4 MiB LRU L2s / the fastest rate the XCD <-> fabric links were measured at).
+    From the committed records (profiles/r02_spmm_traffic_floor.json: exact, CPU; profiles/r02_fabric_probe.txt: streams of
+    >= 64 MB read by every XCD); None when they are of another graph."""
+    import re
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r02_spmm_traffic_floor.json')) as f:
+            fl = json.load(f)
+        if (fl['n'], fl['nnz'], fl['d']) != (n, nnz, d):
+            return None
+        rates = [float(m.group(1)) for line in open(os.path.join(ROOT, 'profiles', 'r02_fabric_probe.txt'))
+                 for m in [re.match(r'stream buf=(?:64|128|192) MB every XCD reads all of it.*?([0-9.]+) TB/s', line)] if m]
+        return {'frac': fl['algorithmic_bytes'] / fl['lru_bytes'] * max(rates) * 1e3 / HBM_PEAK_GBS, 'fabric_tbs': max(rates),
+                'floor_bytes_lru_4mib': fl['lru_bytes'], 'floor_bytes_infinite_l2': fl['floor_inf_l2_bytes'],
+                'from': 'profiles/r02_spmm_traffic_floor.json, profiles/r02_fabric_probe.txt'}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def stage_table_from_profile(prof):
+    """Models without a hand-written stage list (GAT, GraphSAGE, GIN): every kernel of the replayed step by position from the
+    committed in-step profile of THIS model (tools/experiments/r04_profile.sh with GNN=...): duration, PMC traffic and the rate
+    that traffic moved at against the HBM roof (a traffic-based fraction: these entries carry no algorithmic byte count)."""
+    out = []
+    for key, ps in (prof or {}).get('stages', {}).items():
+        e = {'stage': key, 'kernel': ps.get('kernel'), 'in_step_us': ps['in_step_us'], 'bound': 'hbm (traffic-based)'}
+        if ps.get('traffic_bytes'):
+            gbs = ps['traffic_bytes'] / ps['in_step_us'] / 1e3
+            e.update(traffic=ps['traffic_bytes'], traffic_gbs=gbs, frac_hbm_on_traffic=gbs / HBM_PEAK_GBS)
+        out.append(e)
+    return out or None
 
 
 def stage_rooflines(eng, prof):
@@ -649,39 +729,29 @@ def post_delete_parity(args, data, model, state, neg, ni1, ni2, device, cpu_mode
                     'CPU oracle on identical state, negatives and iteration count'}
 
 
-def recorded_traffic(n, nnz, d):
-    """HBM bytes per launch of the dominant kernel from the committed PMC run (separate rocprofv3
-    --pmc passes, gfx950 correction applied: profiles/r02_d_spmm_traffic.json); None when the
-    workload differs from the one that was profiled."""
-    path = os.path.join(ROOT, 'profiles', 'r02_d_spmm_traffic.json')
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-        w = rec['workload']
-        if (w['num_nodes'], w['spmm_nnz'], w['d']) == (n, nnz, d):
-            return rec['traffic_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
-
-
-def probe_partition_in_child(args, rank):
+def probe_partition_in_child(args, rank, overlap=False):
     """Run a few partitioned steps of a small request in CHILD processes (one per rank, rendezvous on
     their own port) under a hard timeout, before this process touches the GPU or RCCL.  A collective
-    that hangs inside RCCL cannot be caught as an exception - but a child can be killed.  -> (ok, note)"""
+    that hangs inside RCCL cannot be caught as an exception - but a child can be killed.  -> (ok, note)
+    overlap: the children run the program with the exchanges on the communication stream AND the synchronous one from the
+    same state and compare the two (Del weights and loss history bit for bit): the parent only switches the overlap on
+    when this second probe passes."""
     import subprocess
-    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get('MASTER_PORT', '29500')) + 23))
+    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get('MASTER_PORT', '29500')) + (41 if overlap else 23)))
     env.pop('TORCHELASTIC_USE_AGENT_STORE', None)      # the children's rank 0 hosts its own rendezvous store
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(args.gpus), '--probe_partition', '--workload',
            'synth-small', '--df', 'in', '--df_size', '5', '--gnn', args.gnn, '--loss_type', args.loss_type]
+    if overlap:
+        cmd.append('--probe_overlap')
+    what = 'overlapped-exchange self-test' if overlap else 'partition self-test'
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
         if r.returncode == 0:
             return 1, None
         tail = [l for l in r.stdout.strip().splitlines() if l.strip()][-1:] or ['']
-        return 0, f'partition self-test failed on rank {rank} (exit {r.returncode}): {tail[0][:160]}'
+        return 0, f'{what} failed on rank {rank} (exit {r.returncode}): {tail[0][:160]}'
     except subprocess.TimeoutExpired:
-        return 0, f'partition self-test timed out on rank {rank} (300 s)'
+        return 0, f'{what} timed out on rank {rank} (300 s)'
 
 
 def main():
@@ -692,12 +762,17 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     # GD_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a one-GPU box (all ranks on cuda:0)
     backend = os.environ.get('GD_BENCH_BACKEND', 'nccl')
-    if args.parallel == 'auto':
-        args.parallel = 'partition'         # north_star: the 1-D partitioned step is what the scaling curve measures
-    mode, note, probe_ok = ('single' if world == 1 else args.parallel), None, 1
+    auto = args.parallel == 'auto'
+    if auto:
+        # north_star: the 1-D partitioned step is what the scaling curve measures - tried first; kept as the headline only
+        # where the planner predicts it to beat the single-GPU step (partition_estimate), else independent replicas
+        args.parallel = 'partition'
+    mode, note, probe_ok, overlap_ok, overlap_note = ('single' if world == 1 else args.parallel), None, 1, 0, 'not probed'
     force_probe = os.environ.get('GD_BENCH_FORCE_PROBE') == '1'          # lets the gloo test exercise the probe
     if world > 1 and mode == 'partition' and (backend == 'nccl' or force_probe) and not args.probe_partition:
         probe_ok, note = probe_partition_in_child(args, rank)      # before any GPU / RCCL initialisation here
+        if probe_ok and os.environ.get('GD_DIST_OVERLAP') != '0' and args.gnn != 'rgcn':      # (R-GCN: synchronous exchanges)
+            overlap_ok, overlap_note = probe_partition_in_child(args, rank, overlap=True)
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     if backend != 'nccl' and torch.cuda.device_count() < world:
         local = 0
@@ -711,11 +786,13 @@ def main():
         # keeps working whatever state the data-path communicator is in
         dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=600))
         ctl = dist.group.WORLD
-        flag = torch.tensor([probe_ok], dtype=torch.int32)
+        flag = torch.tensor([probe_ok, overlap_ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl)
-        if mode == 'partition' and not int(flag):
+        if mode == 'partition' and not int(flag[0]):
             mode = args.parallel = 'replicas'
             note = note or 'partition self-test failed on another rank'
+        # exchanges under compute only where every rank's probe reproduced the synchronous result with them
+        args.dist_overlap = bool(int(flag[1])) if not args.probe_partition else None
         if mode == 'partition' and backend == 'nccl':
             group = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=300), device_id=device)
 
@@ -758,8 +835,34 @@ def main():
             eng.step()
         barrier()
         assert bool(torch.isfinite(eng.loss_history()).all())
+        if args.probe_overlap:
+            # the same four steps from the same state with the exchanges on the communication stream: identical results
+            ref = (model.deletion1.deletion_weight.detach().clone(), model.deletion2.deletion_weight.detach().clone(),
+                   eng.loss_history().clone())
+            model.load_state_dict(state)
+            args.dist_overlap = True
+            eng2 = make_engine(args, data, model, neg, ni1, ni2, device, rank, world, group)
+            assert eng2._async
+            for _ in range(4):
+                eng2.step()
+            barrier()
+            same = (torch.equal(ref[0], model.deletion1.deletion_weight.detach()) and
+                    torch.equal(ref[1], model.deletion2.deletion_weight.detach()) and
+                    torch.equal(ref[2].nan_to_num(), eng2.loss_history().nan_to_num()))
+            assert same, 'overlapped exchanges changed the result'
         dist.destroy_process_group()
         return
+    auto_est = None
+    if auto and world > 1 and mode == 'partition':
+        # measure the single-GPU step on every rank (also the replicas rate reported under extras), let the planner decide
+        rep_rate_auto = replicas_rate(args, model, state, device, world, barrier)
+        auto_est = partition_estimate(eng, world, ctl, 1e6 * world / rep_rate_auto)
+        model.load_state_dict(state)
+        if auto_est['predicted_partitioned_step_us'] >= auto_est['single_gpu_step_us']:
+            mode = args.parallel = 'replicas'
+            del eng
+        else:
+            eng = make_engine(args, data, model, neg, ni1, ni2, device, rank, world, group)    # fresh state for the timed run
     if mode != 'partition':
         eng = make_engine(args, data, model, neg, ni1, ni2, device, rank, world)
 
@@ -796,13 +899,14 @@ def main():
     partitioned = mode == 'partition'
     units = args.steps if partitioned else world * args.steps      # iterations of whole requests
     per_rank_halo = gather_halo_bytes(eng, world, ctl) if (partitioned and world > 1) else None
-    rep_rate = replicas_rate(args, model, state, device, world, barrier) if (partitioned and world > 1) else None
+    rep_rate = (rep_rate_auto if auto_est is not None else replicas_rate(args, model, state, device, world, barrier)) \
+        if (partitioned and world > 1) else None
     if rank == 0:
         kdur, kbytes = time_dominant_kernel(eng)
         achieved = kbytes / kdur / 1e9
-        prof = load_stage_profile(args.stage_profile, data.num_nodes, eng.graph.nnz) if world == 1 else {}
-        traffic = (prof.get('stages', {}).get('spmm1', {}).get('traffic_bytes') or
-                   recorded_traffic(data.num_nodes, eng.graph.nnz, 128)) if world == 1 else None
+        prof, prof_note = load_stage_profile(args.stage_profile, data.num_nodes, eng.graph.nnz) if world == 1 else ({}, 'N > 1')
+        traffic = prof.get('stages', {}).get('spmm1', {}).get('traffic_bytes')
+        ceil_ = fabric_ceiling(data.num_nodes, eng.graph.nnz, 128)
         out = {
             'metric': 'Del-op train iters/sec', 'value': units / dt, 'unit': 'iters/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
@@ -827,13 +931,14 @@ def main():
                          # the recorded L2-miss (fabric) bytes over this run's launch duration: how close the kernel
                          # runs to the ~6.3 TB/s a streaming copy achieves on this part (MI355X_MICROARCH.md)
                          'traffic_gbs': traffic / kdur / 1e9 if traffic else None,
-                         'traffic_unit': 'bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this command: '
-                                         + (os.path.relpath(args.stage_profile, ROOT) if prof else 'profiles/r02_d_spmm_traffic.json') + ')',
+                         'traffic_unit': ('bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this command: '
+                                          + os.path.relpath(args.stage_profile, ROOT) + ')') if prof else None,
+                         'stage_profile': os.path.relpath(args.stage_profile, ROOT) if prof else prof_note,
                          'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6,
                          'in_step_us': prof.get('stages', {}).get('spmm1', {}).get('in_step_us'),
                          # what any kernel with one contiguous row range per XCD can reach on this graph (measurement):
                          # the private L2s make the fabric carry every x row once per XCD that gathers it
-                         'ceiling_frac_on_this_graph': 0.41},
+                         'ceiling_frac_on_this_graph': ceil_['frac'] if ceil_ else None, 'ceiling': ceil_},
             'final_loss': float(losses[-1, 0]) if len(losses) else None,
             'timing': {'regions': n_regions, 'steps_per_region': args.steps, 'reported': 'median region',
                        'ms_per_step_each_region': [1e3 * t / args.steps for t in region_s]},
@@ -841,6 +946,11 @@ def main():
         if note:
             out['config']['partition_fallback'] = note
         out['config']['ranks_seen'] = world          # WORLD_SIZE of the torch.distributed job this line was measured in
+        if auto_est is not None:
+            out['config']['parallel_auto'] = auto_est
+        if world > 1:
+            out['config']['halo_exchanges'] = ('overlapped with compute (the probe reproduced the synchronous result)' if getattr(args, 'dist_overlap', None)
+                                               else f'synchronous ({overlap_note})')
         if partitioned:
             # rank 0's own figures + every rank's bytes (gathered over the control group): xGMI is point-to-point, the
             # heaviest rank / pair bounds an exchange
@@ -904,7 +1014,7 @@ def main():
             out.setdefault('extras', {})['roofline_del_gemm'] = time_del_gemm(eng)
             out['extras']['roofline_wgrad'] = time_wgrad(eng)
             out['extras']['roofline_spmm_d64'] = time_spmm_d64(eng)
-            out['extras']['stage_rooflines'] = stage_rooflines(eng, prof)
+            out['extras']['stage_rooflines'] = stage_rooflines(eng, prof) or stage_table_from_profile(prof)
         if not args.no_cpu_baseline and world == 1:
             cpu_data = data.clone().cpu() if hasattr(data, 'clone') else data
             out['cpu_baseline'], cpu_model, n_cpu = cpu_baseline(args, cpu_data, state, neg, args.cpu_baseline_iters)

@@ -172,12 +172,17 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
       }
     }
     // (WG) the transposed view of p: a_op[st * NT + mt] = p[sample 2 st + kh][feature 32 mt + lo]
+    // The tile is wave-private: lanes write sample-major rows and read OTHER lanes' data feature-major.  DS operations of a
+    // wave execute in issue order; the wavefront-scope fences keep the compiler from reordering the tile's writes and
+    // transposed reads (in either direction, across tiles too) on a disjointness-per-lane argument.
     float a_op[WG ? 16 * NT : 1];
     if (WG) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int st = 0; st < 16; ++st)
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) a_op[st * NT + mt] = tb_col[2 * st * PT + 32 * mt];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
     // ---- loss gradient in place: acc[t][r] (feature 32t + (r&3) + 8(r>>2) + 4kh of sample lo) -> dz
     if (u >= 0) {
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
     }
     // ---- (WG) dW_D += p^T dz over the tile's 32 samples: A = p (registers, feature-major), B = dz (the tile, feature-major)
     if (WG) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int st = 0; st < 16; ++st)
 #pragma unroll
@@ -228,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
           for (int mt = 0; mt < NT; ++mt)
             gacc[mt * NT + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op[st * NT + mt], b, gacc[mt * NT + nt], 0, 0, 0);
         }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();               // (before the tile is overwritten)
       asm volatile("" ::: "memory");                              // (the compiler would issue the fetch at the top of the tile)
       if (tile + stride < n_tiles) fetch_rows();
     }

@@ -897,11 +897,14 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
     // tile queue (one 16-wave block per CU) where a block gets enough tiles to hand out: the step's N- and S-row products
     static const bool queue_on = [] { const char* e = getenv("GD_ROWS_GEMM_QUEUE"); return !(e && atoi(e) == 0); }();
     const bool use_queue = queue_on && !kc_split && !narrow_split && n_tiles >= 16 * 256;
-    if (use_queue && grid > 256) grid = 256;
+    if (use_queue && grid > ws_cu_count()) grid = ws_cu_count();            // one 16-wave block per compute unit
 #define GD_RG_KERNEL(NT, MODE, SELV, NPV, KCV)                                                                    \
   do {                                                                                                            \
     if (use_queue && !NPV) {                                                                                      \
       auto kq = rows_gemm_mfma_kernel<NT, MODE, SELV, 0, 0, true>;                                                \
+      /* the tile counter is static LDS on top of the dynamic weight image (exactly 64 KB at 128 x 128) */        \
+      static const hipError_t onceq = hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 64); \
+      GD_REQUIRE(onceq == hipSuccess, -(int)onceq, "gd_rows_gemm_f32: cannot raise the LDS limit of the tile-queue kernel"); \
       hipLaunchKernelGGL(kq, dim3(grid), dim3(1024), lds, s, in, ld_in, idx, n_sel, w, d_in, trans_w,             \
                          bias, relu_in, out, ld_out, save_in, gate_bits, sign_out, in_alt, sel, dots);            \
       break;                                                                                                      \

@@ -35,6 +35,8 @@ holds their halo h rows since the forward exchange), which yields partial messag
 rows; the halo rows' partials travel back to their owners in the reverse all-to-all and are added there in rank
 order (deterministic).  The fused single-GPU configuration is required: folded DEC + NI terms, every loss row inside its Del row
 list (always so for the reference's masks), MFMA widths."""
+import os
+
 import torch
 
 from . import _lib, ops
@@ -49,9 +51,15 @@ from .nn import GATConv, GCNConv, GINConv, RGCNConv, SAGEConv
 class PartitionedNodeembEngine:
     def __init__(self, model, x, edge_index, z1_ori, z2_ori, pos_edge, neg_edge, ni_mask1, ni_mask2, rank, world,
                  loss_type='both_layerwise', alpha=0.5, lr=1e-3, reduction='mean', use_graph=True, history=4096,
-                 reorder=True, group=None, edge_type=None):
+                 reorder=True, group=None, edge_type=None, overlap=None):
         """edge_type (R-GCN, BASELINE config 4): relation type per column of edge_index; x is then the entity id vector
-        (the frozen embedding table is replicated and looked up once)."""
+        (the frozen embedding table is replicated and looked up once).
+        overlap: run the halo exchanges on a communication stream UNDER the interior-row aggregation and the partial weight
+        gradients (True), or every exchange as start + wait on the spot (False: the synchronous program - same kernels, same
+        results bit for bit, no cross-stream ordering to get wrong).  None = the environment's GD_DIST_OVERLAP (1 / 0), else
+        False: the overlapped program has only ever run with all ranks on one GPU (gloo); until it has been seen on a real
+        multi-GPU RCCL group the synchronous one is the default, and bench.py switches the overlap on only after its
+        child-process probe has reproduced the synchronous result with it."""
         assert loss_type in LOSS_TYPES, loss_type
         conv1, conv2 = model.conv1, model.conv2
         if not isinstance(conv2, (GCNConv, GINConv, SAGEConv, GATConv, RGCNConv)):
@@ -165,6 +173,10 @@ class PartitionedNodeembEngine:
                 self.plan_t_int, self.plan_t_bnd = SplitPlan(g.rowptr_t, rows=i_t), SplitPlan(g.rowptr_t, rows=b_t)
                 self.n_interior_t = int(i_t.numel())
         self._comm_stream = torch.cuda.Stream(device=dev)
+        if overlap is None:
+            overlap = os.environ.get('GD_DIST_OVERLAP', '0') == '1'
+        self._async = bool(overlap)
+        self._gat1_bufs, self._gat2_bufs = {}, {}      # persistent work buffers of the GAT raw ops (ops._ws_buf)
         # ---- halo lists (device-side, one host transfer of the [world, world] count matrix each)
         own_mask = torch.zeros(n, dtype=torch.bool, device=dev)
         own_mask[lo:hi] = True
@@ -376,8 +388,9 @@ class PartitionedNodeembEngine:
             w2 = c2.nn.weight
         elif self._mode == 'gat':
             ops.rows_gemm(self.x, self.need1, c1.lin_src.weight, trans_w=True, const_w=True, out=self.t1buf)
-            a_s, a_d = ops.row_dots(self.t1buf, c1.att_src, c1.att_dst)
-            ops.gat_forward_raw(g, self.t1buf, a_s, a_d, c1.bias, c1.negative_slope, out=self.pre1, plan=self.plan)
+            a_s, a_d = ops.row_dots(self.t1buf, c1.att_src, c1.att_dst, bufs=self._gat1_bufs)
+            ops.gat_forward_raw(g, self.t1buf, a_s, a_d, c1.bias, c1.negative_slope, out=self.pre1, plan=self.plan,
+                                bufs=self._gat1_bufs)
             w2 = c2.lin_src.weight
         else:
             ops.rows_gemm(self.x, self.need1, c1.lin_l.weight, trans_w=True, const_w=True, out=self.t1buf)
@@ -452,9 +465,11 @@ class PartitionedNodeembEngine:
         if self.halo_f.n_recv:
             self.t2buf[:, :self.o].index_copy_(0, self.halo_f.recv_rows, self.recv_f)
         if self._mode == 'gat':
-            a_s, a_d = ops.row_dots(self.t2buf, c2.att_src, c2.att_dst)          # own + halo rows hold h2
+            # (logits, row statistics and - below - the per-edge gradient buffers are written in one captured segment and read
+            #  in later ones: they live in buffers this engine owns, self._gat2_bufs, not in capture-time allocations)
+            a_s, a_d = ops.row_dots(self.t2buf, c2.att_src, c2.att_dst, bufs=self._gat2_bufs)   # own + halo rows hold h2
             _, rowmax, rowsum = ops.gat_forward_raw(g, self.t2buf, a_s, a_d, c2.bias, c2.negative_slope, out=self.p2,
-                                                    plan=self.plan)
+                                                    plan=self.plan, bufs=self._gat2_bufs)
             self._gat2 = (a_s, a_d, rowmax, rowsum)
         else:
             self._agg2(self.plan_bnd if self._overlap else self.plan)
@@ -486,7 +501,7 @@ class PartitionedNodeembEngine:
         c2 = self.model.conv2
         a_s, a_d, rowmax, rowsum = self._gat2
         dt2, da_s, da_d = ops.gat_backward_raw(self.graph, self.t2buf, a_s, a_d, rowmax, rowsum, self.dz2, c2.negative_slope,
-                                               plan=self.plan, plan_t=self.plan_src)
+                                               plan=self.plan, plan_t=self.plan_src, bufs=self._gat2_bufs)
         rows = self.need1.long()
         dt2[rows] += da_s[rows, None] * c2.att_src.detach().view(1, -1)
         dt2[self.lo:self.hi] += da_d[self.lo:self.hi, None] * c2.att_dst.detach().view(1, -1)
@@ -566,6 +581,10 @@ class PartitionedNodeembEngine:
     def _comm(self, what, mode):
         if self.world == 1 and not _collectives._FORCE:
             return
+        if not self._async:                # synchronous program: an 'async' op completes on the spot, its 'wait' is empty
+            if what is None:
+                return
+            mode = 'sync'
         cur = torch.cuda.current_stream()
         if what is not None:
             self._comm_stream.wait_stream(cur)                     # the packed rows are complete
@@ -645,7 +664,8 @@ class PartitionedNodeembEngine:
         if self._overlap:
             rep['interior_rows_forward'] = self.n_interior
             rep['interior_rows_backward'] = getattr(self, 'n_interior_t', 0)
-            rep['overlap'] = 'exchange on a communication stream under the partial weight gradients + interior-row aggregation'
+            rep['overlap'] = ('exchange on a communication stream under the partial weight gradients + interior-row aggregation'
+                              if self._async else 'off (synchronous exchanges; GD_DIST_OVERLAP=1 / overlap=True turns it on)')
         return rep
 
     def loss_history(self):

@@ -312,7 +312,7 @@ class NodeembEngine:
                       and loss_type in ('both_layerwise', 'both_all') and not self._overlap and self.h % 2 == 0 and self.o % 2 == 0
                       and os.environ.get('GD_NO_STEP_TAIL') != '1')
         self._tail_acc = [0, 0]
-        self._arrive = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._arrive = torch.zeros(2, dtype=torch.int32, device=dev)     # step_tail's check-in counter (+ the word its address trick may name)
         # ... and with the tail launch doing the reduction, the W_D2 weight gradient's partial sums come out of the fused Del-2
         # kernel itself (gd_del_loss_bwd_wgrad_f32: p2 and dz2 are in its registers) - no weight-gradient launch, no dz2 buffer
         self._fuse_wg2 = self._tail and os.environ.get('GD_NO_FUSED_WGRAD2') != '1'

@@ -259,8 +259,10 @@ class RGATConv(nn.Module):
         b = x @ self._relation_vectors(self.k).t()
         e = F.leaky_relu(a[dst, et] + b[src, et], self.negative_slope)
         nb = 1 if self.num_blocks is None else self.num_blocks
-        if not x.is_cuda or e.numel() == 0:
-            raise ops._lib.GnnDeleteHipError('RGATConv needs CUDA(HIP) tensors and a non-empty edge list (no CPU fallback)')
+        if not x.is_cuda:
+            raise ops._lib.GnnDeleteHipError('RGATConv needs CUDA(HIP) tensors (no CPU fallback)')
+        if e.numel() == 0:              # a sampled batch without edges: every node aggregates nothing (rgat.py: out = 0 + bias)
+            return (a.sum() + b.sum()) * 0.0 + self.bias.expand(n, self.out_channels) + x.new_zeros(n, self.out_channels)
         tc = self._edge_orders(edge_index, edge_type, n)
         # softmax across ALL in-edges of a target node, whatever their relation (rgat.py: attention_mode
         # 'additive-self-attention', across-relation): segments = the edges grouped by target

@@ -445,40 +445,53 @@ def _pow2(d):
     return d >= 4 and (d & (d - 1)) == 0 and d <= 1024
 
 
-def gat_forward_raw(graph, h, a_src, a_dst, bias, slope, out=None, plan=None):
+def _ws_buf(bufs, key, shape, device, zero=False):
+    """A work buffer of a raw op: fresh when bufs is None, else the caller's persistent one under `key` (made on first use).
+    Engines whose step is cut into several hipGraphs pass a dict they own, so that what one captured segment writes and a
+    later one reads lives in memory the ENGINE holds (not in a capture-time allocation only a graph pool keeps alive)."""
+    if bufs is None:
+        return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=device)
+    t = bufs.get(key)
+    if t is None or tuple(t.shape) != tuple(shape if isinstance(shape, (tuple, list)) else (shape,)):
+        t = bufs[key] = (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=device)
+    return t
+
+
+def gat_forward_raw(graph, h, a_src, a_dst, bias, slope, out=None, plan=None, bufs=None):
     """Fused edge-softmax aggregation; returns (y, rowmax, rowsum) - balanced kernels when the
-    width allows, else the one-wave-per-row kernel (then rowmax is the saved alpha, rowsum None)."""
+    width allows, else the one-wave-per-row kernel (then rowmax is the saved alpha, rowsum None).
+    bufs: see _ws_buf (row statistics / saved alpha land in the caller's persistent buffers)."""
     n, d = graph.n, h.shape[1]
     y = out if out is not None else torch.empty(n, d, dtype=torch.float32, device=h.device)
     plan = plan or graph.plan               # a plan over a row subset: only those rows of y / rowmax / rowsum are written
     if _pow2(d) and h.stride(0) % 4 == 0:
-        rowmax = torch.empty(n, dtype=torch.float32, device=h.device)
-        rowsum = torch.empty(n, dtype=torch.float32, device=h.device)
+        rowmax = _ws_buf(bufs, 'rowmax', (n,), h.device)
+        rowsum = _ws_buf(bufs, 'rowsum', (n,), h.device)
         scratch = plan.scratch_flat('gat', _lib.lib().gd_gat_balanced_scratch(plan.n_slots, d), h.device)
         check(_lib.lib().gd_gat_aggregate_balanced_f32(
             ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split, plan.n_slots, ptr(graph.col), ptr(a_src),
             ptr(a_dst), ptr(h), h.stride(0), ptr(y), y.stride(0), ptr(bias), ptr(rowmax), ptr(rowsum), ptr(scratch),
             float(slope), d, graph.nnz, int(h.shape[0]), stream_ptr(h.device)), 'gd_gat_aggregate_balanced_f32')
         return y, rowmax, rowsum
-    alpha = torch.empty(graph.nnz, dtype=torch.float32, device=h.device)
+    alpha = _ws_buf(bufs, 'alpha', (graph.nnz,), h.device)
     check(_lib.lib().gd_gat_aggregate_f32(ptr(graph.rowptr), ptr(graph.col), ptr(a_src), ptr(a_dst), ptr(h),
                                           h.stride(0), ptr(y), y.stride(0), ptr(bias), ptr(alpha), float(slope), n, d,
                                           stream_ptr(h.device)), 'gd_gat_aggregate_f32')
     return y, alpha, None
 
 
-def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope, plan=None, plan_t=None):
+def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope, plan=None, plan_t=None, bufs=None):
     """-> (dh message path, da_src, da_dst).  plan / plan_t: work items of a row subset for the target-major edge
-    gradients and the source-major aggregation (rows outside are not produced)."""
+    gradients and the source-major aggregation (rows outside are not produced).  bufs: see _ws_buf."""
     g = graph
     n, d = g.n, h.shape[1]
     dev = h.device
-    da_dst = torch.empty(n, dtype=torch.float32, device=dev)
+    da_dst = _ws_buf(bufs, 'da_dst', (n,), dev)
     if rowsum is None:                     # saved alpha from the row kernel
         alpha = rowmax
-        de = torch.empty(g.nnz, dtype=torch.float32, device=dev)
-        dh = torch.empty_like(h)
-        da_src = torch.empty(n, dtype=torch.float32, device=dev)
+        de = _ws_buf(bufs, 'de', (g.nnz,), dev)
+        dh = _ws_buf(bufs, 'dh', tuple(h.shape), dev)
+        da_src = _ws_buf(bufs, 'da_src', (n,), dev)
         check(_lib.lib().gd_gat_aggregate_bwd_f32(
             ptr(g.rowptr), ptr(g.col), ptr(alpha), ptr(g.rowptr_t), ptr(g.col_t), ptr(g.perm_t), ptr(a_src),
             ptr(a_dst), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(dh), dh.stride(0), ptr(da_src), ptr(da_dst),
@@ -488,18 +501,19 @@ def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope, plan=Non
     plan = plan or g.plan
     # per edge (alpha, score gradient) interleaved; edges of rows outside a subset are never computed: keep them finite
     # (zero) for the transposition pass
-    ade = (torch.zeros if subset else torch.empty)(g.nnz, 2, dtype=torch.float32, device=dev)
-    t_row = torch.empty(n, dtype=torch.float32, device=dev)
+    ade = _ws_buf(bufs, 'ade', (g.nnz, 2), dev, zero=subset)
+    t_row = _ws_buf(bufs, 't_row', (n,), dev)
     scratch = plan.scratch_flat('gat_bwd', max(4, plan.n_slots), dev)
     check(_lib.lib().gd_gat_edge_grads_balanced_f32(
         ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split, ptr(g.col), ptr(a_src), ptr(a_dst), ptr(rowmax),
         ptr(rowsum), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(ade), ptr(da_dst), ptr(t_row),
         ptr(scratch), float(slope), d, g.nnz, stream_ptr(dev)), 'gd_gat_edge_grads_balanced_f32')
-    alpha_t = torch.empty(g.nnz, dtype=torch.float32, device=dev)
-    da_src = torch.empty(n, dtype=torch.float32, device=dev)
+    alpha_t = _ws_buf(bufs, 'alpha_t', (g.nnz,), dev)
+    da_src = _ws_buf(bufs, 'da_src', (n,), dev)
     check(_lib.lib().gd_gat_transpose_edges_f32(ptr(g.rowptr_t), ptr(g.perm_t), ptr(ade), n, ptr(alpha_t),
                                                 ptr(da_src), stream_ptr(dev)), 'gd_gat_transpose_edges_f32')
-    dh = _spmm_raw(g.rowptr_t, g.col_t, alpha_t, dy, None, 0.0, n, plan_t or g.plan_t)
+    dh = _spmm_raw(g.rowptr_t, g.col_t, alpha_t, dy, None, 0.0, n, plan_t or g.plan_t,
+                   out=None if bufs is None else _ws_buf(bufs, 'dh', (n, dy.shape[1]), dev))
     return dh, da_src, da_dst
 
 
@@ -514,15 +528,19 @@ def rank1_add2_(y, a, u, b, v):
     return y
 
 
-def row_dots(h, v1, v2):
-    """(h @ v1, h @ v2) in one pass (raw, no autograd)."""
+def row_dots(h, v1, v2, bufs=None):
+    """(h @ v1, h @ v2) in one pass (raw, no autograd).  bufs: see _ws_buf."""
     h = _f32_rows(h)
     n, d = h.shape
-    a1 = torch.empty(n, dtype=torch.float32, device=h.device)
-    a2 = torch.empty(n, dtype=torch.float32, device=h.device)
+    a1 = _ws_buf(bufs, 'a1', (n,), h.device)
+    a2 = _ws_buf(bufs, 'a2', (n,), h.device)
     v1, v2 = v1.reshape(-1).contiguous(), v2.reshape(-1).contiguous()
     if d % 4 or h.stride(0) % 4:
-        return h @ v1, h @ v2
+        if bufs is None:
+            return h @ v1, h @ v2
+        torch.mv(h, v1, out=a1)
+        torch.mv(h, v2, out=a2)
+        return a1, a2
     check(_lib.lib().gd_row_dots_f32(ptr(h), h.stride(0), n, d, ptr(v1), ptr(v2), ptr(a1), ptr(a2),
                                      stream_ptr(h.device)), 'gd_row_dots_f32')
     return a1, a2

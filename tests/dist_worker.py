@@ -232,7 +232,7 @@ def gpu_checks(rank, world, rccl=False, direct=False):
             assert dist.get_backend(group) == 'nccl'
     for cls, lt in cases:
         results = []
-        for partitioned in (False, True):
+        for partitioned in (False, True, 'overlap'):      # single GPU | partitioned, synchronous exchanges | exchanges overlapped
             torch.manual_seed(11)
             m = cls(SimpleNamespace(in_dim=f, hidden_dim=h, out_dim=o), data.sdf_node_1hop_mask,
                     data.sdf_node_2hop_mask).to(dev)
@@ -243,7 +243,8 @@ def gpu_checks(rank, world, rccl=False, direct=False):
             args = (m, x, e_sdf, z1o, z2o, E[:, data.df_mask.to(dev)], neg.to(dev), ni1, ni2)
             if partitioned:
                 eng = PartitionedNodeembEngine(*args, rank, world, loss_type=lt, alpha=0.5, lr=1e-2,
-                                               use_graph=(lt != 'only1'), group=group)
+                                               use_graph=(lt != 'only1'), group=group, overlap=(partitioned == 'overlap'))
+                assert eng._async == (partitioned == 'overlap')
                 rep = eng.halo_report()
                 assert rep['recv_bytes_per_step'] < rep['allgather_bytes_per_step'] or world == 1
             else:
@@ -253,7 +254,9 @@ def gpu_checks(rank, world, rccl=False, direct=False):
             torch.cuda.synchronize()
             results.append((m.deletion1.deletion_weight.detach().cpu(), m.deletion2.deletion_weight.detach().cpu(),
                             eng.loss_history()))
-        (a1, a2, ah), (b1, b2, bh) = results
+        (a1, a2, ah), (b1, b2, bh), (c1, c2, ch) = results
+        # the overlapped program runs the same kernels on the same operands in another order: identical results
+        assert torch.equal(b1, c1) and torch.equal(b2, c2) and torch.equal(bh.nan_to_num(), ch.nan_to_num()), (cls.__name__, lt)
         err = max(float((a1 - b1).norm() / a1.norm()), float((a2 - b2).norm() / a2.norm()))
         assert err < 1e-4, (cls.__name__, lt, err)
         assert torch.allclose(ah, bh, rtol=1e-4, equal_nan=True), (cls.__name__, lt, ah, bh)
@@ -270,17 +273,21 @@ def rgcn_checks(rank, world):
     dev = torch.device('cuda', 0)
     for lt in ('both_layerwise', 'both_all', 'only2_all'):
         results = []
-        for partitioned in (False, True):
+        for partitioned in (False, True, 'overlap'):
             args = SimpleNamespace(gnn='rgcn', workload='synth-kg-small', seed=42, df='in', df_size=2.5, loss_type=lt, no_graph=False)
             data, model, neg, ni1, ni2 = bench.build_kg_request(args)
-            eng = bench.make_kg_engine(args, data, model, neg, ni1, ni2, dev, rank, world, None, partition=partitioned)
-            assert isinstance(eng, PartitionedNodeembEngine) == partitioned
+            os.environ['GD_DIST_OVERLAP'] = '1' if partitioned == 'overlap' else '0'       # (the engine's default switch)
+            eng = bench.make_kg_engine(args, data, model, neg, ni1, ni2, dev, rank, world, None, partition=bool(partitioned))
+            assert isinstance(eng, PartitionedNodeembEngine) == bool(partitioned)
+            assert not partitioned or eng._async == (partitioned == 'overlap')
             for _ in range(4):
                 eng.step()
             torch.cuda.synchronize()
             results.append((model.deletion1.deletion_weight.detach().cpu(), model.deletion2.deletion_weight.detach().cpu(),
                             eng.loss_history()))
-        (a1, a2, ah), (b1, b2, bh) = results
+        (a1, a2, ah), (b1, b2, bh), (c1, c2, ch) = results
+        # the overlapped program runs the same kernels on the same operands in another order: identical results
+        assert torch.equal(b1, c1) and torch.equal(b2, c2) and torch.equal(bh.nan_to_num(), ch.nan_to_num()), lt
         err = max(float((a1 - b1).norm() / a1.norm()), float((a2 - b2).norm() / a2.norm()))
         assert err < 1e-4, (lt, err)
         assert torch.allclose(ah, bh, rtol=1e-4, equal_nan=True), (lt, ah, bh)

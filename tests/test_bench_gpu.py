@@ -36,13 +36,16 @@ def test_bench_single_gpu_line():
 
 @pytest.mark.parametrize('probe', ['0', '1'])
 def test_bench_two_ranks_run_the_partitioned_step(probe):
+    """probe = 1: both child-process self-tests run first - the partitioned step, then the overlapped exchanges against the
+    synchronous ones (bit-identical) - and the parent then runs with the exchanges under compute."""
     env = dict(os.environ, GD_BENCH_BACKEND='gloo', GD_BENCH_FORCE_PROBE=probe, HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + SMALL
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--parallel', 'partition'] + SMALL
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     d = _json_line(r.stdout)
     assert d['n_gpus'] == 2 and d['scaling'] == 'strong', d
+    assert d['config']['halo_exchanges'].startswith('overlapped' if probe == '1' else 'synchronous'), d['config']['halo_exchanges']
     assert 'partition_fallback' not in d['config'], d['config']
     assert 'row-partition' in d['config']['parallelism']
     assert d['config']['halo']['recv_bytes_per_step'] > 0 and d['config']['ranks_seen'] == 2
@@ -51,12 +54,27 @@ def test_bench_two_ranks_run_the_partitioned_step(probe):
     assert d['value'] > 0 and abs(d['value'] - d['steps'] / (d['ms_per_step'] * d['steps'] / 1e3)) < 1e-6 * d['value']
 
 
+def test_bench_two_ranks_auto_follows_the_planner():
+    """`--parallel auto` (the driver's launch): the partitioned step is built, the single-GPU step measured, and the headline is
+    the partitioned step only where the planner predicts it to be faster - on this small request it is not."""
+    env = dict(os.environ, GD_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + SMALL
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    est = d['config']['parallel_auto']
+    slower = est['predicted_partitioned_step_us'] >= est['single_gpu_step_us']
+    assert d['n_gpus'] == 2 and d['scaling'] == ('weak' if slower else 'strong') and d['value'] > 0, d
+    assert ('replicas' in d['config']['parallelism']) == slower
+
+
 def test_bench_two_ranks_partition_the_rgcn_request():
     """BASELINE config 4 over two ranks (gloo on the one-GPU box): the R-GCN request's target rows partitioned with typed
     halos - `bench.py --gnn rgcn --gpus 2` as the driver launches it."""
     env = dict(os.environ, GD_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--gnn', 'rgcn', '--workload',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--parallel', 'partition', '--gnn', 'rgcn', '--workload',
            'synth-kg-small', '--df_size', '2.5', '--steps', '6', '--warmup', '2', '--no_cpu_baseline']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]

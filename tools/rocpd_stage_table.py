@@ -5,7 +5,7 @@ all steady-state steps, with the counter traffic of the same kernel name next to
 guide: FETCH_SIZE counts 32 B per request where the 16-B/lane gathers move 64 -> doubled; WRITE_SIZE as is; KiB units).
 
   python tools/rocpd_stage_table.py kt.db [--fetch f.db] [--write w.db] [--marker loss_finalize] [--out stages.json]
-        [--stages name,name,...]   (labels by position; default = the GCN both_layerwise step)
+        [--stages name,name,...]   (labels by position; default = the GCN both_layerwise step; 'auto' = k00, k01, ... for any step)
 """
 import argparse
 import json
@@ -41,6 +41,10 @@ def main():
     marks = [i for i, r in enumerate(rows) if a.marker in r[0]]
     steps = [rows[marks[j] + 1: marks[j + 1] + 1] for j in range(len(marks) - 1)]
     labels = a.stages.split(',')
+    if a.stages == 'auto':               # any step: the most frequent kernel count between two markers, labels by position
+        from collections import Counter
+        k = Counter(len(s) for s in steps[a.skip:]).most_common(1)[0][0]
+        labels = [f'k{p:02d}' for p in range(k)]
     steady = [s for s in steps[a.skip:] if len(s) == len(labels)]
     assert steady, f'no step with {len(labels)} kernels between markers (lengths seen: {sorted(set(len(s) for s in steps))})'
     fetch = counter_avg(a.fetch, 'FETCH_SIZE') if a.fetch else {}
