@@ -30,6 +30,7 @@ PROTOTYPES = {
     'gd_spmm_csr_balanced_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _f32, _p, _p, _i32,
                                                 _i32, _i32, _p, _p]),
     'gd_spmm_csr_onepass_f32': (ctypes.c_int, [_p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _f32, _p, _i32, _i32, _i32, _p, _p]),
+    'gd_spmm_csr_rowgroup_f32': (ctypes.c_int, [_p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _f32, _p, _i32, _i32, _i32, _p, _p]),
     'gd_rows_gemm_wgrad_reduce_f32': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _f64, _f64, _f64, _f64, _p]),
     'gd_step_tail_f32': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _f64, _f64, _f64, _f64,
                                         _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _p]),

@@ -17,6 +17,9 @@ from . import _lib
 
 
 CHUNK = 64   # in-edges per SpMM work item (one coalesced (col, val) fetch of a 64-lane wave)
+# GD_SPMM_ROWGROUP=1: 64-float aggregations on the row-per-lane-group kernel (gd_spmm_csr_rowgroup_f32) - opt-in: measured no
+# faster than the item kernel in the step (profiles/NOTES.md, round 4)
+ROWGROUP = os.environ.get('GD_SPMM_ROWGROUP') == '1'
 
 
 class SplitPlan:
@@ -60,9 +63,12 @@ class SplitPlan:
         self._row_ids, self._row_start, self._row_end = ids, r_start, r_end
         self._row_deg, self._row_pieces = deg, pieces
         self._onepass = {}
+        self._rowgroup = None
         for d in (64, 128):          # the path's widths, ahead of any hipGraph capture (the tables are built lazily)
             self.xcd_bounds(d)
             self.onepass(d)
+        if ROWGROUP:
+            self.rowgroup()
 
     def xcd_bounds(self, d):
         """Item range of each of the 8 XCDs for a width-d SpMM (int32 [9] on the device, None for small plans),
@@ -221,6 +227,81 @@ class SplitPlan:
         self._onepass[key] = hit
         self.n_multirow_items = n_multi
         return hit
+
+    def rowgroup(self):
+        """(items int32 [4 n, 4], n, bounds int32 [9]) for gd_spmm_csr_rowgroup_f32 (64-float rows: every lane group of a wave
+        owns one row, csrc/spmm.hip).  The plan's rows are cut into eight contiguous ranges of equal cost (one per XCD, as
+        onepass); inside a range, in this order:
+          - rows above 512 in-edges, heaviest first: four consecutive items (kind 2) - sixteen contiguous shares of the row,
+            one per lane group of the four waves of a block;
+          - rows of 65 .. 512 in-edges (kind 1): one item, four contiguous shares;
+          - the light rows in row order (the sweep's window of consecutive rows is what keeps gathered rows in the XCD's L2),
+            in windows of 64: inside a window sorted by in-degree and packed four to an item (kind 0), so that the four lane
+            groups of a visit walk rows of the same length; the last pack of a range repeats its last row;
+          - padding items (kind 3) up to a multiple of 4.
+        items[4 i + g] = {row, start, end, meta}; meta of group 0 = kind << 24 | trips (longest group)."""
+        if self._rowgroup is not None:
+            return self._rowgroup
+        ids, r_start, r_end, deg = self._row_ids, self._row_start, self._row_end, self._row_deg
+        dev = ids.device
+        n = int(ids.numel())
+        if n == 0:
+            self._rowgroup = (torch.zeros(0, 4, dtype=torch.int32, device=dev), 0, torch.zeros(9, dtype=torch.int32, device=dev))
+            return self._rowgroup
+        light_max, mid_max, win = 64, 512, 64
+        cost = torch.cumsum((deg + 24).double(), 0)
+        cuts = torch.searchsorted(cost, cost[-1] * torch.arange(1, 8, device=dev, dtype=torch.float64) / 8)
+        lim = [0] + [int(c) for c in cuts.tolist()] + [n]
+        for k in range(1, 9):
+            lim[k] = max(lim[k], lim[k - 1])
+        q4 = torch.arange(4, device=dev)
+
+        def shares(rows, parts, kind):
+            """rows (positions) -> [len(rows) * parts, 4] group records: `parts` contiguous shares of each row."""
+            share = (deg[rows] + parts - 1) // parts
+            k = torch.arange(parts, device=dev)
+            s_ = r_start[rows][:, None] + share[:, None] * k[None, :]
+            e_ = torch.minimum(s_ + share[:, None], r_end[rows][:, None])
+            s_ = torch.minimum(s_, e_)
+            meta = ((kind << 24) | share)[:, None].expand(-1, parts)
+            return torch.stack([ids[rows][:, None].expand(-1, parts), s_, e_, meta], 2).reshape(-1, 4)
+
+        parts, bounds, total = [], [0], 0
+        pad_grp = torch.tensor([0, 0, 0, 3 << 24], device=dev)
+        for k in range(8):
+            lo, hi = lim[k], lim[k + 1]
+            dk = deg[lo:hi]
+            heavy = (dk > mid_max).nonzero().flatten() + lo
+            if heavy.numel():
+                heavy = heavy[torch.argsort(deg[heavy], descending=True, stable=True)]
+                parts.append(shares(heavy, 16, 2))
+                total += 4 * int(heavy.numel())
+            mid = ((dk > light_max) & (dk <= mid_max)).nonzero().flatten() + lo
+            if mid.numel():
+                parts.append(shares(mid, 4, 1))
+                total += int(mid.numel())
+            lp = (dk <= light_max).nonzero().flatten() + lo
+            m = int(lp.numel())
+            if m:
+                w_id = torch.arange(m, device=dev) // win
+                order = torch.argsort(w_id * 128 + deg[lp], stable=True)
+                lp = lp[order]
+                nq = (m + 3) // 4
+                rows4 = lp[torch.clamp(torch.arange(nq * 4, device=dev), max=m - 1)].view(nq, 4)       # short last pack: last row repeated
+                trips = deg[rows4].max(1).values
+                meta = torch.zeros(nq, 4, dtype=torch.long, device=dev)
+                meta[:, 0] = trips
+                parts.append(torch.stack([ids[rows4], r_start[rows4], r_end[rows4], meta], 2).reshape(-1, 4))
+                total += nq
+            tail = (-total) % 4
+            if tail:
+                parts.append(pad_grp.expand(4 * tail, 4))
+                total += tail
+            bounds.append(total)
+        items = torch.cat(parts, 0).to(torch.int32).contiguous()
+        assert items.shape[0] == 4 * total
+        self._rowgroup = (items, total, torch.tensor(bounds, dtype=torch.int32, device=dev))
+        return self._rowgroup
 
     def scratch_flat(self, tag, n_floats, device):
         """Named flat work buffers (e.g. the GAT kernels' merge scratch), kept per plan."""

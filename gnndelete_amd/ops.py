@@ -38,6 +38,15 @@ def _spmm_raw(rowptr, col, val, x, bias, self_coef, n_rows, plan=None, out=None,
     if x_self is not None:
         assert plan is not None and x_self.stride(0) == x.stride(0) and x_self.shape[1] == d
     y = out if out is not None else torch.empty(n_rows, d, dtype=torch.float32, device=x.device)
+    if (plan is not None and d == 64 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and getattr(plan, '_rowgroup', None) is not None
+            and max(int(x.shape[0]), int(y.shape[0])) * x.stride(0) * 4 < 2 ** 32 and x.stride(0) * 4 < 2 ** 24):
+        # 64-float rows: one row per lane group of a wave (a third of the item kernel's instructions per row)
+        items, n_items, bounds = plan.rowgroup()
+        check(_lib.lib().gd_spmm_csr_rowgroup_f32(ptr(items), n_items, ptr(col), ptr(val), ptr(x), x.stride(0), ptr(y),
+                                                  y.stride(0), ptr(bias), float(self_coef), ptr(x_self), d, int(col.shape[0]),
+                                                  max(int(x.shape[0]), int(y.shape[0])), ptr(bounds), stream_ptr(x.device)),
+              'gd_spmm_csr_rowgroup_f32')
+        return y
     if (plan is not None and d % 4 == 0 and d <= 1024 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
             and os.environ.get('GD_SPMM_TWO_LAUNCH') != '1'):
         # hub rows summed by the four waves of a block inside the same launch (no scratch rows, no fix-up kernel)

@@ -36,7 +36,7 @@ extern "C" {
                               4: gd_spmm_csr_onepass_f32, gd_rows_gemm_wgrad_reduce_f32 (dw = NULL in the wgrad entries),
                                  gd_comm_* / gd_allreduce_f32 / gd_exchange_rows_f32, gd_segment_softmax_f32, gd_rowpair_dot_f32, gd_step_tail_f32;
                               5: gd_del_loss_bwd_wgrad_f32, multi-row items of gd_spmm_csr_onepass_f32;
-                              6: gd_rows_gemm_ws_covers (weight-stationary form of the row GEMMs) */
+                              6: gd_rows_gemm_ws_covers (weight-stationary form of the row GEMMs), gd_spmm_csr_rowgroup_f32 */
 
 enum {
   GD_OK = 0,
@@ -162,6 +162,22 @@ int gd_spmm_csr_onepass_f32(const int32_t* items, int32_t n_items, const int32_t
                             const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias, float self_coef,
                             const float* x_self, int32_t d, int32_t nnz, int32_t x_rows, const int32_t* xcd_bounds,
                             void* stream);
+
+/* The same aggregation for 64-float rows with one ROW per lane group of a wave (16 lanes x 16 bytes): a group walks its row's
+ * in-edges in order into one accumulator - no dealing of edges to groups, no cross-group sum, one 1 KB store for four rows.
+ * The item kernel behind gd_spmm_csr_onepass_f32 saturates the instruction issue of its SIMDs at this width (8 in-edges per
+ * row on average); this one issues about a third of its instructions per row.
+ *   items [4 n_items, 4] int32: items[4 i + g] = {row, start, end, meta} of lane group g of item i; meta of group 0 =
+ *     kind << 24 | trips (the longest group's edge count).  kind 0: four rows (a short pack repeats its last row);
+ *     1: one row of 65 .. 512 in-edges in four contiguous shares; 2: four consecutive 4-aligned items = one heavier row in
+ *     sixteen shares, summed by the four waves of a block; 3: padding.  n_items and every xcd_bounds entry: multiples of 4
+ *     (gnndelete_amd/graph.py: SplitPlan.rowgroup builds them).
+ * d must be 64; x below 4 GiB.  Sums are sequential over a row's in-edges (fixed order; another association than the item
+ * kernel's).  Replaces the same upstream ops as gd_spmm_csr_f32. */
+int gd_spmm_csr_rowgroup_f32(const int32_t* items, int32_t n_items, const int32_t* col, const float* val,
+                             const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias,
+                             float self_coef, const float* x_self, int32_t d, int32_t nnz, int32_t x_rows,
+                             const int32_t* xcd_bounds, void* stream);
 
 /* Per-relation mean aggregation of R-GCN ("typed SpMM") over a relation-major CSR:
  *   rowptr[(r*n_rows + i) .. +1] delimit the in-edges of type r into node i;

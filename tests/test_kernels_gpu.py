@@ -498,6 +498,57 @@ def test_balanced_spmm_splits_hub_rows_and_matches_plain_kernel(d):
     assert rel_l2(yt.cpu(), want_t) < TOL
 
 
+@pytest.mark.parametrize('self_coef,with_bias', [(0.0, True), (1.0, False), (0.5, True)])
+def test_rowgroup_spmm_one_row_per_lane_group(self_coef, with_bias):
+    """gd_spmm_csr_rowgroup_f32 (64-float rows, csrc/spmm.hip): every item kind of its planner - packs of four light rows
+    sorted by in-degree inside windows of 64 (incl. rows without in-edges and a repeated last row), rows of 65 .. 512
+    in-edges in four shares, heavier rows in sixteen shares over the four waves of a block - against the dense fp64
+    product, the transposed graph, a row-subset plan, and the item kernel on the same plan; bit-reproducible."""
+    from gnndelete_amd import ops
+    from gnndelete_amd.graph import SplitPlan, build_csr
+    n, d = 6_001, 64
+    g = torch.Generator().manual_seed(11)
+    ei = torch.cat([random_graph(n, 42_000, seed=3, isolate=40),
+                    torch.stack([torch.randint(0, n, (700,), generator=g), torch.full((700,), 5)]),          # 700 in-edges: sixteen shares
+                    torch.stack([torch.randint(0, n, (3000,), generator=g), torch.full((3000,), 77)]),       # 3,000
+                    torch.stack([torch.randint(0, n, (200,), generator=g), torch.full((200,), 9)]),          # 200: four shares
+                    torch.stack([torch.full((900,), 123), torch.randint(0, n, (900,), generator=g)])], 1)    # a hub of the transposed graph
+    x = torch.randn(n, d, generator=g)
+    b = torch.randn(d, generator=g) if with_bias else None
+    gr = build_csr(ei.cuda(), n, 'sum')
+    items, n_items, bounds = gr.plan.rowgroup()
+    kinds = (items.view(-1, 4, 4)[:, 0, 3] >> 24).cpu()
+    assert n_items % 4 == 0 and all(int(v) % 4 == 0 for v in bounds.tolist()) and int(bounds[-1]) == n_items
+    assert (kinds == 0).any() and (kinds == 1).any() and int((kinds == 2).sum()) >= 8
+    a = dense_adj(ei, n)
+    xg, bg = x.cuda(), (b.cuda() if with_bias else None)
+    want = a @ x.double() + self_coef * x.double() + (b.double() if with_bias else 0.0)
+    y = ops._spmm_raw(gr.rowptr, gr.col, None, xg, bg, self_coef, n, gr.plan)
+    assert rel_l2(y.cpu(), want) < TOL
+    assert torch.equal(y, ops._spmm_raw(gr.rowptr, gr.col, None, xg, bg, self_coef, n, gr.plan))
+    # the item kernel on the same plan: another association of the same sums
+    plan_items = SplitPlan(gr.rowptr)
+    plan_items._rowgroup = None
+    y_items = ops._spmm_raw(gr.rowptr, gr.col, None, xg, bg, self_coef, n, plan_items)
+    assert rel_l2(y, y_items) < 1e-6
+    # transposed graph, weighted
+    val_t = torch.rand(gr.col_t.numel(), generator=g).cuda()
+    gr.plan_t.rowgroup()
+    yt = ops._spmm_raw(gr.rowptr_t, gr.col_t, val_t, xg, None, 0.0, n, gr.plan_t)
+    at = torch.zeros(n, n, dtype=torch.float64)
+    rows_t = torch.repeat_interleave(torch.arange(n), (gr.rowptr_t[1:] - gr.rowptr_t[:-1]).long().cpu())
+    at.index_put_((rows_t, gr.col_t.long().cpu()), val_t.double().cpu(), accumulate=True)
+    assert rel_l2(yt.cpu(), at @ x.double()) < TOL
+    # a plan over a row subset writes those rows only
+    rows = torch.unique(torch.cat([torch.randint(0, n, (1500,), generator=g), torch.tensor([5, 9, 77])])).int().cuda()
+    sub = SplitPlan(gr.rowptr, rows=rows)
+    sub.rowgroup()
+    ys = ops._spmm_raw(gr.rowptr, gr.col, None, xg, bg, self_coef, n, sub, out=torch.full((n, d), 7.0, device='cuda'))
+    keep = torch.zeros(n, dtype=torch.bool)
+    keep[rows.long().cpu()] = True
+    assert rel_l2(ys.cpu()[keep], want[keep]) < TOL and bool((ys.cpu()[~keep] == 7.0).all())
+
+
 @pytest.mark.parametrize('d,self_coef', [(128, 0.0), (64, 1.0), (32, 0.5), (8, 0.0), (260, 0.0)])
 def test_onepass_spmm_sums_hub_rows_inside_the_launch(d, self_coef, monkeypatch):
     """gd_spmm_csr_onepass_f32: hub rows (65 ... 5,000 in-edges) summed by whole blocks in the same launch that sweeps
