@@ -213,6 +213,8 @@ def gpu_checks(rank, world, rccl=False, direct=False):
     cases = [(GCNDelete, 'both_layerwise'), (GINDelete, 'both_all'), (GCNDelete, 'only2_all'), (SAGEDelete, 'both_layerwise'),
              (SAGEDelete, 'both_all'), (GCNDelete, 'only1'), (GINDelete, 'only2_layerwise'), (GATDelete, 'both_layerwise'),
              (GATDelete, 'both_all')]
+    if world > 2:             # three ranks time-share the box's one GPU (10 x the two-rank run): one case per backbone
+        cases = [(GCNDelete, 'both_layerwise'), (SAGEDelete, 'both_all'), (GINDelete, 'only2_layerwise'), (GATDelete, 'both_layerwise')]
     group = None
     if rccl:                  # a world of one over RCCL: the data-path communicator the GPU node uses
         cases = [(GCNDelete, 'both_layerwise'), (SAGEDelete, 'both_all'), (GATDelete, 'both_layerwise')]

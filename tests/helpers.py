@@ -90,3 +90,42 @@ def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(('127.0.0.1', 0))
         return s.getsockname()[1]
+
+
+def oracle_runner(gnn, data, state, neg, ni1, ni2, dtype, device, loss_type='both_layerwise', alpha=0.5, lr=1e-3, perm=None,
+                  hidden=128, out=64):
+    """The oracle (oracle/gnndelete_ref.py) as plain torch ops in `dtype` on `device`, one Del-training request:
+    -> (step(), snapshot(), (z1_ori, z2_ori)).  perm = a seed: the edge lists are permuted first - a different summation order
+    in every scatter, i.e. ANOTHER correct implementation of the same arithmetic (the members of an fp32 ensemble).
+    snapshot() = (W_D1, W_D2, z1 on the 1-hop S_Df nodes, z2 on the 2-hop S_Df nodes, z2) with the embeddings taken on the
+    retained edges (evaluation semantics, framework/trainer/base.py:238-242); the first four as fp64 CPU tensors."""
+    from oracle import gnndelete_ref as R
+    f, m1, m2 = data.x.shape[1], data.sdf_node_1hop_mask, data.sdf_node_2hop_mask
+    E = data.train_pos_edge_index
+    e_dr, e_sdf, pos = E[:, data.dr_mask], E[:, data.sdf_mask], E[:, data.df_mask]
+    ref = R.TwoLayerDelete(gnn, f, hidden, out, m1, m2)
+    ref.load_state_dict(state, strict=False)
+    ref = ref.to(dtype).to(device)
+    x = data.x.to(dtype).to(device)
+    ed, es = e_dr.to(device), e_sdf.to(device)
+    if perm is not None:
+        gp = torch.Generator().manual_seed(perm)
+        ed = ed[:, torch.randperm(ed.shape[1], generator=gp).to(device)]
+        es = es[:, torch.randperm(es.shape[1], generator=gp).to(device)]
+    with torch.no_grad():
+        z1o, z2o = ref.get_original_embeddings(x, ed, return_all_emb=True)
+    tg = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=pos.to(device), neg_edge=neg.to(device), ni_mask1=ni1.to(device),
+              ni_mask2=ni2.to(device))
+    opt = R.make_optimizer(ref, loss_type, lr)
+    logs = []
+
+    def step():
+        logs.append(R.nodeemb_epoch(ref, lambda: ref(x, es, return_all_emb=True), tg, opt, loss_type, alpha, R.LOSSES['mse_mean']))
+
+    def snapshot():
+        with torch.no_grad():
+            z1, z2 = ref(x, ed, return_all_emb=True)
+        return (ref.deletion1.deletion_weight.detach().double().cpu(), ref.deletion2.deletion_weight.detach().double().cpu(),
+                z1[m1.to(device)].double().cpu(), z2[m2.to(device)].double().cpu(), z2.detach())
+    step.logs = logs
+    return step, snapshot, (z1o, z2o)

@@ -33,9 +33,10 @@ def test_partitioned_step_algebra_and_collectives_over_gloo(world):
 def test_partitioned_engine_matches_single_gpu_engine(world):
     """Ranks sharing cuda:0 over gloo (the box has one GPU): the real partitioned HIP engine (fused stages, halo
     exchanges packed / unpacked inside the hipGraph segments) vs the single-GPU engine, GCN / GIN / GraphSAGE / GAT, every
-    --loss_type."""
+    --loss_type (two ranks; one case per backbone at three), each partitioned run with synchronous and with overlapped
+    exchanges (bit-identical)."""
     out = launch('gpu', world, timeout=900)
-    assert out.count('partitioned == single') == 9
+    assert out.count('partitioned == single') == (9 if world == 2 else 4)
 
 
 @pytest.mark.gpu

@@ -16,11 +16,11 @@ from types import SimpleNamespace
 import pytest
 import torch
 
-from helpers import rel_l2
+from helpers import oracle_runner, rel_l2
 
 pytestmark = pytest.mark.gpu
 
-ITERS = 3
+ITERS = 20          # the embedding bar of north_star (1e-4 rel-L2) is asserted after this many Del iterations
 
 
 def _request(workload, gnn, df, df_size, seed=42):
@@ -38,6 +38,7 @@ def _auc(z, pos, neg):
 
 
 @pytest.mark.parametrize('workload,gnn,df,df_size', [('synth-cora', 'gcn', 'out', 0.5), ('synth-dblp', 'gcn', 'out', 2.5),
+                                                     ('synth-collab', 'gcn', 'in', 5.0),       # the metric's own model
                                                      ('synth-collab', 'sage', 'in', 5.0), ('synth-collab', 'gat', 'in', 5.0)])
 def test_full_size_training_parity(workload, gnn, df, df_size):
     from gnndelete_amd.engine import NodeembEngine
@@ -66,12 +67,26 @@ def test_full_size_training_parity(workload, gnn, df, df_size):
     hist = eng.loss_history()
     for i, log in enumerate(logs):
         assert abs(float(hist[i, 0]) - log['train_loss']) <= 1e-4 * abs(log['train_loss']), (i, float(hist[i, 0]), log)
-    # The Del WEIGHTS after a few Adam steps are a looser observable than the embeddings north_star bounds: the first
-    # updates are lr * m / sqrt(v) ~ +-lr per entry whatever the gradient's size, so the fp32 summation-order noise of a
-    # 180k-row weight-gradient reduction (cancelling terms: ~1e-4 of an entry) shows up undamped in the weight, while
-    # the embeddings see it scaled by lr.  1e-3 here; the embeddings below carry the 1e-4 bar.
-    assert rel_l2(hip.deletion1.deletion_weight.detach().cpu(), ref.deletion1.deletion_weight.detach()) < 1e-3
-    assert rel_l2(hip.deletion2.deletion_weight.detach().cpu(), ref.deletion2.deletion_weight.detach()) < 1e-3
+    # The Del WEIGHTS are a looser observable than the embeddings north_star bounds: Adam's first updates are
+    # lr * m / sqrt(v) ~ +-lr per entry whatever the gradient's size, so the fp32 summation-order noise of a 180k-row
+    # weight-gradient reduction shows up undamped in the weight, while the embeddings see it scaled by lr.  So they are held
+    # to what fp32 arithmetic itself can deliver: HIP's distance to the fp64 oracle's weights <= 2 x the largest distance of
+    # an fp32 ENSEMBLE (this CPU oracle + the same oracle as torch ops on the GPU with three scatter orders) to them.
+    wts = lambda m_: (m_.deletion1.deletion_weight.detach().double().cpu(), m_.deletion2.deletion_weight.detach().double().cpu())
+    step64, snap64, _ = oracle_runner(gnn, data, state, neg, ni1, ni2, torch.float64, dev)
+    members = [oracle_runner(gnn, data, state, neg, ni1, ni2, torch.float32, dev, perm=p) for p in (None, 1, 2)]
+    for _ in range(ITERS):
+        step64()
+        for mem in members:
+            mem[0]()
+    w64 = snap64()[:2]
+    ens = [wts(ref)] + [mem[1]()[:2] for mem in members]
+    for k, name in enumerate(('W_D1', 'W_D2')):
+        d_ens = [rel_l2(e[k], w64[k]) for e in ens]
+        d_hip = rel_l2(wts(hip)[k], w64[k])
+        print(f'[{workload} {gnn}] {name} after {ITERS} iterations, rel-L2 to the fp64 oracle: fp32 ensemble '
+              + ' '.join(f'{v:.2e}' for v in d_ens) + f' / HIP {d_hip:.2e}')
+        assert d_hip <= 2.0 * max(d_ens) + 1e-7, (name, d_hip, d_ens)
     with torch.no_grad():
         r1, r2 = ref(data.x, e_dr, return_all_emb=True)
         h1, h2 = hip(data.x.to(dev), e_dr.to(dev).contiguous(), return_all_emb=True)

@@ -17,20 +17,20 @@ task-level contract of north_star: post-deletion AUC within +-0.002.
           profiles/r03_long_parity.txt.  RATIO = 2: every run is one sample of a chaotic map.
   assert  |AUC(HIP) - AUC(fp64)| <= 0.002 and |AUC(HIP) - AUC(fp32 oracle)| <= 0.002 (test edges; Df vs Dr)
 
-The oracles run as plain torch ops: fp64 on the GPU (fast fp64 units), fp32 on the CPU at synth-small (fixed summation
-order) and on the GPU at the bench's size (600 CPU epochs would take 15 minutes)."""
+All oracles run as plain torch ops on the GPU (fp64: fast fp64 units; 600 CPU epochs at the bench's size would take 15
+minutes); four fp32 members at every size; GCN at synth-small and at the bench's size, GAT at synth-small."""
 from types import SimpleNamespace
 
 import pytest
 import torch
 
-from helpers import rel_l2
+from helpers import oracle_runner, rel_l2
 
 pytestmark = pytest.mark.gpu
 
 EPOCHS, CHECK = 600, (100, 300, 600)
-RATIO, FLOOR = 2.0, 2e-6      # measured ratios: profiles/r03_long_parity.txt
-PERMS = {'synth-small': (None, 1, 2, 3), 'synth-collab': (None, 1, 2)}      # fp32 ensemble: edge-order seeds (None = as given)
+RATIO, FLOOR = 2.0, 2e-6      # measured ratios: profiles/r03_long_parity.txt, profiles/r04_long_parity.txt
+PERMS = (None, 1, 2, 3)       # fp32 ensemble: edge-order seeds (None = as given); four members at every size
 
 
 def _auc(z, pos, neg):
@@ -41,49 +41,22 @@ def _auc(z, pos, neg):
     return float(batched_roc_auc(score.float(), label)[0])
 
 
-@pytest.mark.parametrize('workload,f32_device', [('synth-small', 'cpu'), ('synth-collab', 'cuda')])
-def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, f32_device):
+@pytest.mark.parametrize('workload,gnn', [('synth-small', 'gcn'), ('synth-collab', 'gcn'), ('synth-small', 'gat')])
+def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, gnn):
     import bench
     from gnndelete_amd.engine import NodeembEngine
-    from oracle import gnndelete_ref as R
     dev = torch.device('cuda')
-    args = SimpleNamespace(workload=workload, gnn='gcn', df='in', df_size=5.0, seed=42)
+    args = SimpleNamespace(workload=workload, gnn=gnn, df='in', df_size=5.0, seed=42)
     data, model, neg, ni1, ni2 = bench.build_request(args, dev)
     bench.train_backbone(model, data, dev, 30)                      # a backbone with signal (set-up)
     state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    f, m1, m2 = data.x.shape[1], data.sdf_node_1hop_mask, data.sdf_node_2hop_mask
+    m1, m2 = data.sdf_node_1hop_mask, data.sdf_node_2hop_mask
     E = data.train_pos_edge_index
     e_dr, e_sdf, pos = E[:, data.dr_mask], E[:, data.sdf_mask], E[:, data.df_mask]
     lt, alpha, lr = 'both_layerwise', 0.5, 1e-3
-
-    def oracle(dtype, device, perm=None):
-        ref = R.TwoLayerDelete('gcn', f, 128, 64, m1, m2)
-        ref.load_state_dict(state, strict=False)
-        ref = ref.to(dtype).to(device)
-        x = data.x.to(dtype).to(device)
-        ed, es = e_dr.to(device), e_sdf.to(device)
-        if perm is not None:
-            gp = torch.Generator().manual_seed(perm)
-            ed = ed[:, torch.randperm(ed.shape[1], generator=gp).to(device)]
-            es = es[:, torch.randperm(es.shape[1], generator=gp).to(device)]
-        with torch.no_grad():
-            z1o, z2o = ref.get_original_embeddings(x, ed, return_all_emb=True)
-        tg = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=pos.to(device), neg_edge=neg.to(device), ni_mask1=ni1.to(device),
-                  ni_mask2=ni2.to(device))
-        opt = R.make_optimizer(ref, lt, lr)
-
-        def step():
-            R.nodeemb_epoch(ref, lambda: ref(x, es, return_all_emb=True), tg, opt, lt, alpha, R.LOSSES['mse_mean'])
-
-        def snapshot():
-            with torch.no_grad():
-                z1, z2 = ref(x, ed, return_all_emb=True)
-            return (ref.deletion1.deletion_weight.detach().double().cpu(), ref.deletion2.deletion_weight.detach().double().cpu(),
-                    z1[m1.to(device)].double().cpu(), z2[m2.to(device)].double().cpu(), z2.detach())
-        return step, snapshot, (z1o, z2o)
-    torch.set_num_threads(min(32, torch.get_num_threads()))
-    step64, snap64, _ = oracle(torch.float64, dev)
-    ens = [oracle(torch.float32, torch.device(f32_device), perm) for perm in PERMS[workload]]
+    # every oracle as torch ops on the GPU (fp64: fast fp64 units; the fp32 members differ in their scatter order)
+    step64, snap64, _ = oracle_runner(gnn, data, state, neg, ni1, ni2, torch.float64, dev, lt, alpha, lr)
+    ens = [oracle_runner(gnn, data, state, neg, ni1, ni2, torch.float32, dev, lt, alpha, lr, perm=perm) for perm in PERMS]
     step32, snap32, (z1o, z2o) = ens[0]
     model.load_state_dict(state)
     hip = model.to(dev)
@@ -110,10 +83,10 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
         d_ens = [[rel_l2(member[1]()[i], s64[i]) for i in range(4)] for member in ens]
         d32 = [max(d[i] for d in d_ens) for i in range(4)]
         dh = [rel_l2(sh[i], s64[i]) for i in range(4)]
-        print(f'[{workload}] epoch {upto}: ' + ', '.join(
+        print(f'[{workload} {gnn}] epoch {upto}: ' + ', '.join(
             f'{n} fp32 ' + ' '.join(f'{d[i]:.2e}' for d in d_ens) + f' / HIP {dh[i]:.2e}' for i, n in enumerate(names)))
-        for n, a, b in zip(names, d32, dh):
-            assert b <= RATIO * a + FLOOR, (workload, upto, n, 'fp32 ensemble max', a, 'HIP', b)
+        for n, a_, b_ in zip(names, d32, dh):
+            assert b_ <= RATIO * a_ + FLOOR, (workload, gnn, upto, n, 'fp32 ensemble max', a_, 'HIP', b_)
     tp, tn = data.test_pos_edge_index, data.test_neg_edge_index
     k = data.directed_df_edge_index.shape[1]
     gen = torch.Generator().manual_seed(0)
@@ -122,6 +95,6 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
     for name, snap in (('fp64', s64), ('fp32', s32), ('hip', sh)):
         z2 = snap[4]
         aucs[name] = (_auc(z2, tp, tn), _auc(z2, dr_sub, data.directed_df_edge_index))
-    print(f'[{workload}] AUC (test edges, Df vs Dr): ' + ', '.join(f'{k_} {v[0]:.6f} / {v[1]:.6f}' for k_, v in aucs.items()))
+    print(f'[{workload} {gnn}] AUC (test edges, Df vs Dr): ' + ', '.join(f'{k_} {v[0]:.6f} / {v[1]:.6f}' for k_, v in aucs.items()))
     for other in ('fp64', 'fp32'):
         assert abs(aucs['hip'][0] - aucs[other][0]) <= 0.002 and abs(aucs['hip'][1] - aucs[other][1]) <= 0.002, aucs
