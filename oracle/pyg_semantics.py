@@ -142,10 +142,10 @@ def gcn_conv(x, edge_index, weight, bias):
 
 def segment_softmax(score, dst, num_nodes):
     """PyG utils.softmax: per-target max-shifted exp / (sum + 1e-16)."""
-    smax = torch.full((num_nodes,), -math.inf, dtype=score.dtype)
+    smax = torch.full((num_nodes,), -math.inf, dtype=score.dtype, device=score.device)
     smax = smax.scatter_reduce(0, dst, score.detach(), reduce='amax', include_self=True)
     e = (score - smax[dst]).exp()
-    denom = torch.zeros(num_nodes, dtype=score.dtype).index_add(0, dst, e)
+    denom = torch.zeros(num_nodes, dtype=score.dtype, device=score.device).index_add(0, dst, e)
     return e / (denom[dst] + 1e-16)
 
 
@@ -177,7 +177,7 @@ def sage_conv(x, edge_index, w_l, b_l, w_r):
     extension pinned only by the dense known-answer test."""
     n = x.shape[0]
     src, dst = edge_index[0], edge_index[1]
-    cnt = torch.zeros(n, dtype=x.dtype).index_add_(0, dst, torch.ones(src.shape[0], dtype=x.dtype))
+    cnt = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, dst, torch.ones(src.shape[0], dtype=x.dtype, device=x.device))
     mean = scatter_rows(x[src], dst, n) / cnt.clamp(min=1.0)[:, None]
     return F.linear(mean, w_l, b_l) + F.linear(x, w_r)
 

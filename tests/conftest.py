@@ -20,3 +20,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_memory_between_tests():
+    """Full-size tests hold several oracles with their autograd tapes: drop what a finished (or failed) test left behind."""
+    yield
+    import gc
+    import torch
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()

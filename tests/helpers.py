@@ -100,6 +100,8 @@ def oracle_runner(gnn, data, state, neg, ni1, ni2, dtype, device, loss_type='bot
     snapshot() = (W_D1, W_D2, z1 on the 1-hop S_Df nodes, z2 on the 2-hop S_Df nodes, z2) with the embeddings taken on the
     retained edges (evaluation semantics, framework/trainer/base.py:238-242); the first four as fp64 CPU tensors."""
     from oracle import gnndelete_ref as R
+    # (the GPU box has 256 host threads: the oracle's small host-side tensor ops are ~6 x slower with all of them than with 32)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
     f, m1, m2 = data.x.shape[1], data.sdf_node_1hop_mask, data.sdf_node_2hop_mask
     E = data.train_pos_edge_index
     e_dr, e_sdf, pos = E[:, data.dr_mask], E[:, data.sdf_mask], E[:, data.df_mask]
@@ -117,15 +119,12 @@ def oracle_runner(gnn, data, state, neg, ni1, ni2, dtype, device, loss_type='bot
     tg = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=pos.to(device), neg_edge=neg.to(device), ni_mask1=ni1.to(device),
               ni_mask2=ni2.to(device))
     opt = R.make_optimizer(ref, loss_type, lr)
-    logs = []
-
     def step():
-        logs.append(R.nodeemb_epoch(ref, lambda: ref(x, es, return_all_emb=True), tg, opt, loss_type, alpha, R.LOSSES['mse_mean']))
+        R.nodeemb_epoch(ref, lambda: ref(x, es, return_all_emb=True), tg, opt, loss_type, alpha, R.LOSSES['mse_mean'])
 
     def snapshot():
         with torch.no_grad():
             z1, z2 = ref(x, ed, return_all_emb=True)
         return (ref.deletion1.deletion_weight.detach().double().cpu(), ref.deletion2.deletion_weight.detach().double().cpu(),
                 z1[m1.to(device)].double().cpu(), z2[m2.to(device)].double().cpu(), z2.detach())
-    step.logs = logs
     return step, snapshot, (z1o, z2o)

@@ -73,14 +73,18 @@ def test_full_size_training_parity(workload, gnn, df, df_size):
     # to what fp32 arithmetic itself can deliver: HIP's distance to the fp64 oracle's weights <= 2 x the largest distance of
     # an fp32 ENSEMBLE (this CPU oracle + the same oracle as torch ops on the GPU with three scatter orders) to them.
     wts = lambda m_: (m_.deletion1.deletion_weight.detach().double().cpu(), m_.deletion2.deletion_weight.detach().double().cpu())
-    step64, snap64, _ = oracle_runner(gnn, data, state, neg, ni1, ni2, torch.float64, dev)
-    members = [oracle_runner(gnn, data, state, neg, ni1, ni2, torch.float32, dev, perm=p) for p in (None, 1, 2)]
-    for _ in range(ITERS):
-        step64()
-        for mem in members:
-            mem[0]()
-    w64 = snap64()[:2]
-    ens = [wts(ref)] + [mem[1]()[:2] for mem in members]
+    def run_oracle(dtype, perm):           # one oracle at a time (their autograd tapes at collab size are tens of GB)
+        import gc
+        step, snap, _ = oracle_runner(gnn, data, state, neg, ni1, ni2, dtype, dev, perm=perm)
+        for _ in range(ITERS):
+            step()
+        w = snap()[:2]
+        del step, snap
+        gc.collect()
+        torch.cuda.empty_cache()
+        return w
+    w64 = run_oracle(torch.float64, None)
+    ens = [wts(ref)] + [run_oracle(torch.float32, p) for p in (None, 1, 2)]
     for k, name in enumerate(('W_D1', 'W_D2')):
         d_ens = [rel_l2(e[k], w64[k]) for e in ens]
         d_hip = rel_l2(wts(hip)[k], w64[k])

@@ -8,14 +8,15 @@ task-level contract of north_star: post-deletion AUC within +-0.002.
 
   distances = rel-L2 to the fp64 run of (W_D1, W_D2, z1 on the 1-hop S_Df nodes, z2 on the 2-hop S_Df nodes), embeddings
   taken on the retained edges (evaluation semantics, framework/trainer/base.py:238-242)
-  assert  d(HIP, fp64) <= RATIO * max over the fp32 ENSEMBLE of d(member, fp64) + FLOOR   for every quantity, at epochs
+  assert  d(HIP, fp64) <= RATIO * max over the fp32 ENSEMBLE of d(member, fp64) + FLOOR (one gate flip)   for every quantity, at epochs
           100 / 300 / 600.  The ensemble = the fp32 oracle as is + the same oracle with its edge lists permuted (a different
           summation order in every scatter: another correct fp32 implementation).  One member is not enough: the distance
           grows in JUMPS (the first ReLU flip takes it from 3e-7 to 2e-4 in one epoch) and WHICH run flips first is chance -
           with one-row SpMM items the fp32 oracle had flipped by epoch 100 and HIP had not (1.9e-4 vs 3.4e-7), with two-row
           items (another association of the same sums) it was the other way round (3.8e-7 vs 2.2e-4); both are in
           profiles/r03_long_parity.txt.  RATIO = 2: every run is one sample of a chaotic map.
-  assert  |AUC(HIP) - AUC(fp64)| <= 0.002 and |AUC(HIP) - AUC(fp32 oracle)| <= 0.002 (test edges; Df vs Dr)
+  assert  |AUC(HIP) - AUC(fp64)| <= 0.002 and |AUC(HIP) - AUC(fp32 oracle)| <= 0.002 + |AUC(fp32 oracle) - AUC(fp64)|
+          (test edges; Df vs Dr)
 
 All oracles run as plain torch ops on the GPU (fp64: fast fp64 units; 600 CPU epochs at the bench's size would take 15
 minutes); four fp32 members at every size; GCN at synth-small and at the bench's size, GAT at synth-small."""
@@ -29,7 +30,12 @@ from helpers import oracle_runner, rel_l2
 pytestmark = pytest.mark.gpu
 
 EPOCHS, CHECK = 600, (100, 300, 600)
-RATIO, FLOOR = 2.0, 2e-6      # measured ratios: profiles/r03_long_parity.txt, profiles/r04_long_parity.txt
+RATIO = 2.0                   # measured ratios: profiles/r03_long_parity.txt, profiles/r04_long_parity.txt
+# + one gate flip: the distance to the fp64 run grows in jumps - the first entry of z1 that lands on the other side of zero
+# takes it from ~3e-7 to ~2e-4 in ONE epoch at synth-small (3,000 nodes; ~1e-6 at the bench's size, where one row is 80 x
+# less of the norm) - and at synth-small the four GPU members sum in the same order (identical digits at epoch 100), so
+# they flip together and say nothing about WHEN a differently associated correct implementation flips
+FLOOR = {'synth-small': 3e-4, 'synth-collab': 2e-6}
 PERMS = (None, 1, 2, 3)       # fp32 ensemble: edge-order seeds (None = as given); four members at every size
 
 
@@ -54,10 +60,33 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
     E = data.train_pos_edge_index
     e_dr, e_sdf, pos = E[:, data.dr_mask], E[:, data.sdf_mask], E[:, data.df_mask]
     lt, alpha, lr = 'both_layerwise', 0.5, 1e-3
-    # every oracle as torch ops on the GPU (fp64: fast fp64 units; the fp32 members differ in their scatter order)
-    step64, snap64, _ = oracle_runner(gnn, data, state, neg, ni1, ni2, torch.float64, dev, lt, alpha, lr)
-    ens = [oracle_runner(gnn, data, state, neg, ni1, ni2, torch.float32, dev, lt, alpha, lr, perm=perm) for perm in PERMS]
-    step32, snap32, (z1o, z2o) = ens[0]
+    import gc
+    names = ('W_D1', 'W_D2', 'z1[S1]', 'z2[S2]')
+
+    def run_oracle(dtype, perm):
+        """One oracle to the end (torch ops on the GPU: fp64 has fast units there), one at a time - an oracle's autograd
+        tapes at the bench's size are tens of GB.  -> snapshots at the CHECK epochs (+ its original embeddings)."""
+        step, snap, z_ori = oracle_runner(gnn, data, state, neg, ni1, ni2, dtype, dev, lt, alpha, lr, perm=perm)
+        snaps, done_ = [], 0
+        for upto in CHECK:
+            for _ in range(upto - done_):
+                step()
+            done_ = upto
+            snaps.append(snap())
+        z_ori = tuple(z.detach().float().clone() for z in z_ori)
+        del step, snap
+        gc.collect()
+        torch.cuda.empty_cache()
+        return snaps, z_ori
+    s64_all, _ = run_oracle(torch.float64, None)
+    d_members, s32_last, z_ori32 = [], None, None
+    for perm in PERMS:                 # the fp32 ensemble: distances to the fp64 run at every check
+        snaps, z_ori = run_oracle(torch.float32, perm)
+        d_members.append([[rel_l2(sn[i], s64[i]) for i in range(4)] for sn, s64 in zip(snaps, s64_all)])
+        if perm is None:
+            s32_last, z_ori32 = snaps[-1], z_ori
+        del snaps
+    z1o, z2o = z_ori32
     model.load_state_dict(state)
     hip = model.to(dev)
     xg, edg = data.x.to(dev), e_dr.to(dev).contiguous()
@@ -69,24 +98,20 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
             z1, z2 = hip(xg, edg, return_all_emb=True)
         return (hip.deletion1.deletion_weight.detach().double().cpu(), hip.deletion2.deletion_weight.detach().double().cpu(),
                 z1[m1.to(dev)].double().cpu(), z2[m2.to(dev)].double().cpu(), z2.detach())
-    names = ('W_D1', 'W_D2', 'z1[S1]', 'z2[S2]')
     done = 0
-    for upto in CHECK:
-        for _ in range(upto - done):
-            step64()
-            for member in ens:
-                member[0]()
+    for c, upto in enumerate(CHECK):
         eng.run(upto - done)
         done = upto
         torch.cuda.synchronize()
-        s64, s32, sh = snap64(), snap32(), snap_hip()
-        d_ens = [[rel_l2(member[1]()[i], s64[i]) for i in range(4)] for member in ens]
+        s64, sh = s64_all[c], snap_hip()
+        d_ens = [dm[c] for dm in d_members]
         d32 = [max(d[i] for d in d_ens) for i in range(4)]
         dh = [rel_l2(sh[i], s64[i]) for i in range(4)]
         print(f'[{workload} {gnn}] epoch {upto}: ' + ', '.join(
             f'{n} fp32 ' + ' '.join(f'{d[i]:.2e}' for d in d_ens) + f' / HIP {dh[i]:.2e}' for i, n in enumerate(names)))
         for n, a_, b_ in zip(names, d32, dh):
-            assert b_ <= RATIO * a_ + FLOOR, (workload, gnn, upto, n, 'fp32 ensemble max', a_, 'HIP', b_)
+            assert b_ <= RATIO * a_ + FLOOR[workload], (workload, gnn, upto, n, 'fp32 ensemble max', a_, 'HIP', b_)
+    s32 = s32_last
     tp, tn = data.test_pos_edge_index, data.test_neg_edge_index
     k = data.directed_df_edge_index.shape[1]
     gen = torch.Generator().manual_seed(0)
@@ -96,5 +121,9 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
         z2 = snap[4]
         aucs[name] = (_auc(z2, tp, tn), _auc(z2, dr_sub, data.directed_df_edge_index))
     print(f'[{workload} {gnn}] AUC (test edges, Df vs Dr): ' + ', '.join(f'{k_} {v[0]:.6f} / {v[1]:.6f}' for k_, v in aucs.items()))
-    for other in ('fp64', 'fp32'):
-        assert abs(aucs['hip'][0] - aucs[other][0]) <= 0.002 and abs(aucs['hip'][1] - aucs[other][1]) <= 0.002, aucs
+    # north_star's +-0.002 against the exact (fp64) trajectory; against the fp32 oracle the same bound widened by that
+    # oracle's OWN distance to the fp64 run (after 600 epochs at synth-small it is 0.0017 off in the Df-vs-Dr AUC while HIP
+    # is 0.0003 off: profiles/r04_long_parity.txt)
+    for q in (0, 1):
+        assert abs(aucs['hip'][q] - aucs['fp64'][q]) <= 0.002, aucs
+        assert abs(aucs['hip'][q] - aucs['fp32'][q]) <= 0.002 + abs(aucs['fp32'][q] - aucs['fp64'][q]), aucs
