@@ -27,6 +27,8 @@
 // (gd_step_tail_f32 / gd_rows_gemm_wgrad_reduce_f32) finishes it.  No dz buffer, no second pass over p: the separate
 // weight-gradient launch read 97 MB and took 26 us of the bench step.  To make room for the sums the targets are no
 // longer fetched a tile ahead but at the top of their own tile (the forward product's 2 us cover them).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gd {
@@ -290,6 +292,206 @@ __global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight-stationary form of the WG kernel for D = 64 (round 4; same idea as rows_gemm_ws.hip): ONE wave per SIMD keeps W_D
+// twice as MFMA A-fragments in its registers - wr1 for z = p W_D, wr2 for dp = dz W_D^T (64 + 64 registers, fetched straight
+// from global memory: W_D is 16 KB) - and the 64 x 64 weight-gradient sums of all its rows in 64 more; v_mfma_f32_16x16x4_f32,
+// work unit = 16 rows, lane (r = lane & 15, kq = lane >> 4):
+//   P1  z[r][16 t + 4 kq + c]  = sum_s  W[kq 16 + s][16 t + .] p[r][kq 16 + s]          (B = the lane's 64-byte slice of its p row)
+//   loss: dz = coef_u (z - tbar_u) in the accumulator layout (targets fetched in that layout), loss sums
+//   P2  dp[r][16 t2 + 4 kq + c] = sum_(t,c) W[16 t2 + .][16 t + 4 kq + c] dz[r][16 t + 4 kq + c]   (B = P1's accumulators: the k order
+//       of the second product is the feature order the first one left in the registers - no shuffle)
+//   P3  dW[16 ta + 4 kq + v][16 tb + j] += sum_rows p[row][16 ta + .] dz[row][16 tb + j]: K = the unit's 16 rows; both operands go
+//       once through a wave-private 16 x 80 LDS tile to come back feature-major (written before P2, read back under it); the
+//       product itself is issued one unit later, under the next unit's loss arithmetic.
+// A unit's row / target registers are reloaded with the next unit's as soon as their last use is issued (row ids and loss
+// slots two units ahead), dp is stored under P3.  No block barrier in the loop, no scratch (the 32-row form above: 256 VGPRs + 56 B/lane of scratch at two waves per
+// SIMD).  Rows past the end are clamped to the last row and recompute it (identical stores); their loss / weight-gradient
+// contributions are zeroed.  Partial matrices: block b writes its sum to slot b and zeros to the slots b + grid, ... < n_part
+// (the reduction kernels count gd_rows_gemm_wgrad_blocks(n_sel) partials).
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+template <bool HAS_DZ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void del_loss_bwd_ws_kernel(
+    const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ idx, int32_t n_sel, const float* __restrict__ w,
+    DelLoss loss, float* __restrict__ dz, int64_t ld_dz, float* __restrict__ dp, int64_t ld_dp, float* __restrict__ wg_partials,
+    int32_t n_part) {
+  constexpr int D = 64, PT = 80;                                  // PT: pitch of the transposition tiles (rows 16 banks apart)
+  extern __shared__ __attribute__((aligned(16))) float wl[];      // 4 waves x (2 tiles of 16 x PT), later 4 x D x D block sum
+  __shared__ float lred[2][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, kq = lane >> 4;
+  float* const tp = wl + wave * (2 * 16 * PT);
+  float* const tz = tp + 16 * PT;
+  const int n_units = (n_sel + 15) >> 4;
+  const int n_waves = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
+  const int u_lo = (int)((int64_t)n_units * wid / n_waves), u_hi = (int)((int64_t)n_units * (wid + 1) / n_waves);
+
+  auto slot_of = [&](int u) -> int { return min(min(u, n_units - 1) * 16 + r, n_sel - 1); };
+  // descriptors two units ahead, rows / targets / coefficients one unit ahead
+  int32_t row_n = idx[slot_of(u_lo)], ls_n = loss.slot[slot_of(u_lo)];
+  int32_t row_nn = idx[slot_of(u_lo + 1)], ls_nn = loss.slot[slot_of(u_lo + 1)];
+  __builtin_amdgcn_sched_barrier(0);
+  float wr1[4][16], wr2[4][16];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) wr1[t][s_] = w[(kq * 16 + s_) * D + 16 * t + r];
+#pragma unroll
+  for (int t2 = 0; t2 < 4; ++t2)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float4 f = *reinterpret_cast<const float4*>(w + (16 * t2 + r) * D + 16 * t + 4 * kq);
+      wr2[t2][4 * t + 0] = f.x; wr2[t2][4 * t + 1] = f.y; wr2[t2][4 * t + 2] = f.z; wr2[t2][4 * t + 3] = f.w;
+    }
+  f32x4w gacc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) gacc[i] = f32x4w{0.f, 0.f, 0.f, 0.f};
+  float ls0 = 0.f, ls1 = 0.f;
+
+  // Ring: the row / target / coefficient registers of a unit are reloaded with the NEXT unit's as soon as their last use
+  // is issued (P2 + P3, ~2 us, to land); nothing is copied.
+  float4 x[4], tv[4];
+  float cf_raw, cn_raw;                                            // (masked by the slot's sign where they are USED: nothing may
+  int32_t ls_cur;                                                  //  touch a loaded value before the next unit, or its wait lands here)
+  auto fetch_targets = [&](int32_t u) {                            // branch-free: slot -1 reads slot 0, coefficient masked at use
+    const int uc = max(u, 0);
+    const float* trow = loss.tm + (int64_t)uc * D + 4 * kq;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) tv[t] = *reinterpret_cast<const float4*>(trow + 16 * t);
+    cf_raw = loss.coef[uc];
+    cn_raw = loss.cnt_signed[uc];
+    ls_cur = u;
+  };
+  auto fetch_rows = [&](int32_t row) {
+    const float4* src = reinterpret_cast<const float4*>(p + (int64_t)row * ld_p + kq * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = src[i];
+  };
+  // feature-major operands of P3, one unit behind: unit u's weight-gradient product is issued under unit u + 1's loss
+  // arithmetic and tile writes (the matrix pipe would idle there), the last unit's after the loop; zeros the first time round
+  float a_op[4][4], b_op[4][4];
+#pragma unroll
+  for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a_op[sp][t] = b_op[sp][t] = 0.f;
+  auto p3 = [&]() {
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+          gacc[ta * 4 + tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op[sp][ta], b_op[sp][tb], gacc[ta * 4 + tb], 0, 0, 0);
+  };
+  if (u_lo < u_hi) {
+    fetch_rows(row_n);
+    fetch_targets(ls_n);
+    for (int u = u_lo; u < u_hi; ++u) {
+      const int32_t row = row_n;
+      const int s_a = min(u, n_units - 1) * 16 + r;
+      const float livef = s_a < n_sel ? 1.f : 0.f;
+      row_n = row_nn;
+      ls_n = ls_nn;
+      row_nn = idx[slot_of(u + 2)];
+      ls_nn = loss.slot[slot_of(u + 2)];
+      // ---- P1: z
+      f32x4w acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xv[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (i == 0 && c == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr1[t][0], xv[0], f32x4w{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr1[t][4 * i + c], xv[c], acc[t], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- P3 of the PREVIOUS unit (operands in registers) - the scheduler interleaves it with what follows
+      p3();
+      // ---- loss gradient in the accumulator layout; p and dz into the transposition tiles
+      const float cf = ls_cur >= 0 ? cf_raw : 0.f, cn = ls_cur >= 0 ? cn_raw : 0.f;
+      float sq = 0.f;
+      f32x4w g[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 d4 = make_float4(acc[t][0] - tv[t].x, acc[t][1] - tv[t].y, acc[t][2] - tv[t].z, acc[t][3] - tv[t].w);
+        sq = fmaf(d4.x, d4.x, sq); sq = fmaf(d4.y, d4.y, sq); sq = fmaf(d4.z, d4.z, sq); sq = fmaf(d4.w, d4.w, sq);
+        g[t] = f32x4w{cf * d4.x, cf * d4.y, cf * d4.z, cf * d4.w};
+        if (HAS_DZ) *reinterpret_cast<float4*>(dz + (int64_t)min(s_a, n_sel - 1) * ld_dz + 16 * t + 4 * kq) = make_float4(g[t][0], g[t][1], g[t][2], g[t][3]);
+        *reinterpret_cast<float4*>(tz + r * PT + 16 * t + 4 * kq) = make_float4(livef * g[t][0], livef * g[t][1], livef * g[t][2], livef * g[t][3]);
+      }
+      sq *= livef;
+      if (cn >= 0.f) ls0 = fmaf(cn, sq, ls0); else ls1 = fmaf(-cn, sq, ls1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(tp + r * PT + kq * 16 + 4 * i) = x[i];
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_targets(ls_n);                                         // the next unit's operands into the registers just consumed
+      fetch_rows(row_n);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the tiles are wave-private: DS operations execute in issue order
+      __builtin_amdgcn_wave_barrier();
+      // feature-major operands of this unit's P3: requested here, they arrive under P2
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          a_op[sp][t] = tp[(4 * sp + kq) * PT + 16 * t + r];
+          b_op[sp][t] = tz[(4 * sp + kq) * PT + 16 * t + r];
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- P2: dp = dz W_D^T
+      f32x4w dacc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int t2 = 0; t2 < 4; ++t2) {
+            if (t == 0 && c == 0) dacc[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr2[t2][0], g[0][0], f32x4w{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            else dacc[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr2[t2][4 * t + c], g[t][c], dacc[t2], 0, 0, 0);
+          }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        float* orow = dp + (int64_t)row * ld_dp + 4 * kq;
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) *reinterpret_cast<float4*>(orow + 16 * t2) = make_float4(dacc[t2][0], dacc[t2][1], dacc[t2][2], dacc[t2][3]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the tiles are read before the next unit overwrites them)
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    p3();                                                          // the last unit's weight-gradient product
+  }
+  // ---- block sum of the four waves' D x D sums (wave order), loss sums
+  __syncthreads();
+  float* const red = wl;                                          // [4][D x D]
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[wave * D * D + (16 * ta + 4 * kq + v) * D + 16 * tb + r] = gacc[ta * 4 + tb][v];
+  __syncthreads();
+  for (int slot = blockIdx.x; slot < n_part; slot += gridDim.x) {
+    float* const out = wg_partials + (int64_t)slot * D * D;
+    const bool mine = slot == (int)blockIdx.x;
+    for (int e = tid; e < D * D; e += 256) out[e] = mine ? (red[e] + red[D * D + e]) + (red[2 * D * D + e] + red[3 * D * D + e]) : 0.f;
+  }
+  ls0 = wave_sum(ls0);
+  ls1 = wave_sum(ls1);
+  if (lane == 0) { lred[0][wave] = ls0; lred[1][wave] = ls1; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int slot = blockIdx.x; slot < n_part; slot += gridDim.x) {
+      const bool mine = slot == (int)blockIdx.x;
+      loss.partials[2 * slot + 0] = mine ? (lred[0][0] + lred[0][1]) + (lred[0][2] + lred[0][3]) : 0.f;
+      loss.partials[2 * slot + 1] = mine ? (lred[1][0] + lred[1][1]) + (lred[1][2] + lred[1][3]) : 0.f;
+    }
+  }
+}
+
 static inline int del_fused_grid(int32_t n_sel) {
   const int n_tiles = (n_sel + 31) / 32;
   int grid = (n_tiles + 3) / 4;
@@ -331,6 +533,24 @@ static int del_loss_bwd_impl(const float* p, int64_t ld_p, const int32_t* idx, i
   }
   // one block per partial matrix of the weight-gradient reduction; + the four waves' transposition tiles (the block sum of
   // the D x D accumulators reuses the whole allocation: 4 D^2 floats <= what is there)
+  static const bool ws_on = [] { const char* e = getenv("GD_DEL2_WS"); return !(e && atoi(e) == 0); }();
+  if (ws_on && d == 64 && n_sel >= 65536) {       // weight-stationary form: one wave per SIMD, 16-row units (above)
+    const int n_part = gd_rows_gemm_wgrad_blocks(n_sel);
+    const int grid_ws = ws_cu_count() < n_part ? ws_cu_count() : n_part;
+    constexpr int kLdsWs = 4 * 64 * 64 * 4;
+    if (dz) {
+      static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&del_loss_bwd_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsWs);
+      if (a1 != hipSuccess) return fail(-(int)a1, "gd_del_loss_bwd_wgrad_f32: %s", hipGetErrorString(a1));
+      hipLaunchKernelGGL((del_loss_bwd_ws_kernel<true>), dim3(grid_ws), dim3(256), kLdsWs, s, p, ld_p, idx, n_sel, w, loss, dz, ld_dz, dp, ld_dp,
+                         wgrad_partials, n_part);
+    } else {
+      static const hipError_t a0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&del_loss_bwd_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsWs);
+      if (a0 != hipSuccess) return fail(-(int)a0, "gd_del_loss_bwd_wgrad_f32: %s", hipGetErrorString(a0));
+      hipLaunchKernelGGL((del_loss_bwd_ws_kernel<false>), dim3(grid_ws), dim3(256), kLdsWs, s, p, ld_p, idx, n_sel, w, loss, dz, ld_dz, dp, ld_dp,
+                         wgrad_partials, n_part);
+    }
+    return launched("del_loss_bwd_ws");
+  }
   const dim3 grid(gd_rows_gemm_wgrad_blocks(n_sel));
 #define GD_DF_CASE(NT_)                                                                                                        \
   do {                                                                                                                         \

@@ -1,6 +1,8 @@
 """HIP kernels (through the C ABI / ctypes) vs the CPU oracle and closed-form fp64 math.
 Tolerance: fp32 kernels, rel-L2 <= 1e-5 against fp64 closed forms (north_star allows 1e-4)."""
 import pytest
+import os
+
 import numpy as np
 import torch
 
@@ -813,9 +815,14 @@ def test_del_loss_bwd_fused_matches_separate_steps(n, d, frac, loss_frac):
         st = torch.cuda.current_stream().cuda_stream
         check(L.gd_del_loss_bwd_wgrad_f32(ptr(args[0]), d, ptr(args[1]), s, ptr(args[2]), d, ptr(args[3]), ptr(args[4]), ptr(args[5]),
                                           ptr(args[6]), ptr(dz2) if with_dz else None, d, ptr(dp2), d, ptr(parts2), ptr(ws), st))
-        assert torch.equal(dp2, dp)                                 # the same products in the same order
-        if with_dz:
-            assert torch.equal(dz2, dz)
+        ws_form = d == 64 and s >= 65536 and os.environ.get('GD_DEL2_WS') != '0'       # the weight-stationary kernel (16-row units)
+        if ws_form:                                                 # another k order of the same products: fp32 rounding apart
+            assert rel_l2(dp2, dp) < 1e-6 and rel_l2(dp2.cpu(), dp_want) < TOL
+            assert not with_dz or rel_l2(dz2[:s], dz[:s]) < 1e-6
+        else:
+            assert torch.equal(dp2, dp)                             # the same products in the same order
+            if with_dz:
+                assert torch.equal(dz2, dz)
         np.testing.assert_allclose(parts2.view(-1, 2).double().sum(0).cpu().numpy(), want_s, rtol=1e-5, atol=1e-7)
         dw = ws.view(max(nbw, 1), d, d).double().sum(0).cpu()
         assert rel_l2(dw, dw_want) < TOL or float(dw_want.abs().max()) == 0
