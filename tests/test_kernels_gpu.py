@@ -220,6 +220,57 @@ def test_rows_gemm_weight_stationary_form(d_in, d_out):
         assert rel_l2(z, ref) < TOL
 
 
+@pytest.mark.parametrize('n,frac,with_add', [(90_000, 0.85, True), (70_001, 1.0, False), (3000, 0.6, True)])
+def test_wgrad_with_loss_formed_in_the_fetch(n, frac, with_add):
+    """gd_rows_gemm_wgrad_loss_f32 at 128 x 128: dW = a[ia]^T (coef_u (z[iz] - tbar_u) + g_add[iz]) and the two loss sums
+    against fp64: rows without a loss slot, a row count that is not a multiple of the tile height, partial matrices counted
+    by gd_rows_gemm_wgrad_blocks.  With GD_WGRAD_WS=1 in the environment the large cases run the opt-in output-stationary
+    register form (csrc/rows_wgrad_ws.hip: a pair of waves per row range, half of dW each) - same test, same tolerance."""
+    from gnndelete_amd import _lib
+    from gnndelete_amd._lib import check, ptr
+    L = _lib.lib()
+    d = 128
+    g = torch.Generator().manual_seed(n)
+    a = torch.randn(n, d, generator=g)
+    z = torch.randn(n, d, generator=g)
+    add = torch.randn(n, d, generator=g) * 0.1
+    mask = torch.rand(n, generator=g) < frac
+    if int(mask.sum()) % 16 == 0:
+        mask[int(mask.nonzero()[0])] = False
+    idx = mask.nonzero().flatten()
+    s = idx.numel()
+    has = torch.rand(s, generator=g) < 0.8
+    n_slots = int(has.sum())
+    slot = torch.full((s,), -1, dtype=torch.int32)
+    slot[has] = torch.arange(n_slots, dtype=torch.int32)[torch.randperm(n_slots, generator=g)]
+    tm = torch.randn(n_slots, d, generator=g)
+    coef = torch.rand(n_slots, generator=g) + 0.1
+    cnt = torch.randint(1, 4, (n_slots,), generator=g).float() * torch.where(torch.rand(n_slots, generator=g) < 0.5, -1.0, 1.0)
+    sl = slot[has].long()
+    gm = torch.zeros(s, d, dtype=torch.float64)
+    df = z.double()[idx][has] - tm.double()[sl]
+    gm[has] = coef.double()[sl][:, None] * df
+    if with_add:
+        gm += add.double()[idx]
+    dw_want = a.double()[idx].t() @ gm
+    sq = (df * df).sum(1) * cnt.double()[sl].abs()
+    want_s = [float(sq[cnt[sl] >= 0].sum()), float(sq[cnt[sl] < 0].sum())]
+    nb = L.gd_rows_gemm_wgrad_blocks(s)
+    ws = torch.full((nb * d * d,), 3.0, device='cuda')
+    lp = torch.full((2 * nb,), 5.0, device='cuda')
+    dev = lambda t_: t_.cuda()
+    ag, zg, addg, ig = dev(a), dev(z), dev(add), dev(idx.int())
+    sg, tg, cg, ng = dev(slot), dev(tm), dev(coef), dev(cnt)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):                      # twice: the second call overwrites every partial (no accumulation, no stale slot)
+        check(L.gd_rows_gemm_wgrad_loss_f32(ptr(ag), d, ptr(ig), ptr(zg), d, ptr(ig), ptr(sg), ptr(tg), ptr(cg), ptr(ng),
+                                            ptr(addg) if with_add else None, s, d, d, None, 0, ptr(ws), ptr(lp), None, None, None, None,
+                                            1e-3, 0.9, 0.999, 1e-8, st), 'gd_rows_gemm_wgrad_loss_f32')
+    dw = ws.view(nb, d, d).double().sum(0).cpu()
+    assert rel_l2(dw, dw_want) < TOL
+    np.testing.assert_allclose(lp.view(-1, 2).double().sum(0).cpu().numpy(), want_s, rtol=1e-5)
+
+
 @pytest.mark.parametrize('n,d_a,d_b,frac', [(300, 128, 128, 0.5), (300, 64, 64, 0.8), (100, 128, 64, 1.0),
                                             (50, 12, 12, 0.5), (60, 128, 4, 0.6), (20, 64, 64, 0.0),
                                             (70000, 128, 128, 0.7)])
