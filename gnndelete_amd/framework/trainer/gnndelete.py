@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from ... import ops
 from ..graph_utils import negative_sampling
-from .base import Trainer, _require_gpu, device
+from .base import Trainer, _require_gpu, device, is_large
 
 
 def sdf_pair_mask(num_nodes, sdf_node_mask, df_edges):
@@ -39,7 +39,75 @@ def sdf_pair_mask(num_nodes, sdf_node_mask, df_edges):
 class GNNDeleteTrainer(Trainer):
 
     def train(self, model, data, optimizer, args, logits_ori=None, attack_model_all=None, attack_model_sub=None):
+        # upstream sends ogbl-* / Physics to the mini-batch loop (gnndelete.py:130-136) to fit its GPUs; one MI355X holds
+        # these graphs whole, so - as for the other trainers - it is taken on request (--minibatch)
+        if is_large(self.args.dataset) and getattr(args, 'minibatch', False):
+            return self.train_minibatch(model, data, optimizer, args, logits_ori, attack_model_all, attack_model_sub)
         return self.train_fullbatch(model, data, optimizer, args, logits_ori, attack_model_all, attack_model_sub)
+
+    def train_minibatch(self, model, data, optimizer, args, logits_ori=None, attack_model_all=None, attack_model_sub=None):
+        """The edge-probability mini-batch loop (framework/trainer/gnndelete.py:312-450) on GraphSAINT random-walk batches
+        cut on the device.  Upstream this loop cannot run: Trainer.get_embedding reads data.dtrain_mask (base.py:59), which
+        delete_gnn.py never sets (:124, :190 commented out).  Here dtrain_mask defaults to dr_mask - what those lines
+        assigned - and the loop is the reference's, quirks included: z_ori (the model's embedding of the whole graph, once,
+        under no_grad) is indexed with the BATCH-LOCAL node ids in the locality term (:378-386), and the epoch log divides
+        by the last enumerate index twice with the two terms' names swapped (:401-423).  Pinned by
+        tests/golden/traj_edgeprob_minibatch_*.npz (the reference's loop run with dtrain_mask injected)."""
+        from . import sampler as S
+        _require_gpu()
+        model = model.to(device)
+        data = data.to('cpu')
+        if not hasattr(data, 'dtrain_mask'):
+            data.dtrain_mask = data.dr_mask
+        with torch.no_grad():
+            dd = data.clone().to(device) if hasattr(data, 'clone') else data.to(device)
+            z_ori = self.get_embedding(model, dd)
+        data.edge_index = data.train_pos_edge_index
+        data.node_id = torch.arange(data.x.shape[0])
+        loader = S.make_sampler(data, args.batch_size, args.num_steps)
+        best_metric = 0
+        self.trainer_log['steps'] = []
+        for epoch in range(args.epochs):
+            model.train()
+            step_logs = []
+            start = time.time()
+            for batch in loader:
+                batch = batch.to(device)
+                ei = batch.edge_index
+                e_sdf = ei[:, batch.sdf_mask].contiguous()
+                z = model(batch.x, e_sdf, batch.sdf_node_1hop_mask, batch.sdf_node_2hop_mask)
+                pos = ei[:, batch.df_mask]
+                k = pos.shape[1]
+                neg = S.negative_sampling(ei, batch.x.shape[0], k)
+                df_logits = model.decode(z, pos, neg)
+                loss_e = F.mse_loss(df_logits[:k], df_logits[k:])
+                lower = e_sdf[0] < e_sdf[1]
+                row, col = e_sdf[0][lower], e_sdf[1][lower]
+                logits_ori = (z_ori[row] * z_ori[col]).sum(-1)         # (batch-local ids into the global embedding: upstream)
+                logits = (z[row] * z[col]).sum(-1)
+                loss_l = F.mse_loss(logits, logits_ori)
+                loss = 0.5 * loss_e + 0.5 * loss_l
+                loss.backward()
+                S.sync_gradients(optimizer)
+                optimizer.step()
+                optimizer.zero_grad()
+                step_logs.append({'loss': loss.item(), 'loss_e': loss_e.item(), 'loss_l': loss_l.item()})
+            self.trainer_log['steps'].extend(step_logs)
+            if (epoch + 1) % args.valid_freq == 0:
+                valid_loss, dt_auc, dt_aup, df_auc, df_aup, df_logit, _, valid_log = self.eval(model, data, 'val')
+                step = max(len(step_logs) - 1, 1)                       # upstream divides by the last enumerate index, twice
+                tot = {k_: sum(s_[k_] for s_ in step_logs) / step for k_ in ('loss', 'loss_e', 'loss_l')}
+                self._record({'epoch': epoch, 'train_loss': tot['loss'] / step, 'train_loss_l': tot['loss_e'] / step,
+                              'train_loss_e': tot['loss_l'] / step, 'train_time': (time.time() - start) / step / step}, valid_log)
+                if dt_auc + df_auc > best_metric:
+                    best_metric = dt_auc + df_auc
+                    print(f'Save best checkpoint at epoch {epoch:04d}. Valid loss = {valid_loss:.4f}')
+                    torch.save({'model_state': model.state_dict(), 'optimizer_state': optimizer.state_dict()},
+                               os.path.join(args.checkpoint_dir, 'model_best.pt'))
+                    torch.save(z.detach(), os.path.join(args.checkpoint_dir, 'node_embeddings.pt'))
+                data = data.to('cpu')
+        torch.save({'model_state': {k_: v.to('cpu') for k_, v in model.state_dict().items()},
+                    'optimizer_state': optimizer.state_dict()}, os.path.join(args.checkpoint_dir, 'model_final.pt'))
 
     def train_fullbatch(self, model, data, optimizer, args, logits_ori=None, attack_model_all=None,
                         attack_model_sub=None):

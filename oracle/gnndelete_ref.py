@@ -461,6 +461,57 @@ def nodeemb_minibatch(model, data, node_sets, negs, epochs, alpha, lr):
     return logs
 
 
+def edgeprob_minibatch(model, data, node_sets, negs, epochs, lr):
+    """GNNDeleteTrainer.train_minibatch (framework/trainer/gnndelete.py:312-450) without validation, with the
+    data.dtrain_mask upstream never sets (base.py:59; delete_gnn.py:124,190 commented out) taken as dr_mask: z_ori = the
+    model's embedding of the whole graph on those edges, once (:330); per batch the Del forward on the batch's S_Df edges
+    (:355), negatives per batch (``negs``, consumed in order, :360-364), loss_e = MSE(Df logits, negative logits)
+    (:366-367), loss_l = MSE of the dot products over the batch's S_Df edges with row < col against z_ori indexed with
+    the BATCH-LOCAL node ids (:378-386 - upstream's quirk, kept), 0.5 / 0.5 (:391-399), single Adam, zero_grad after the
+    step.  -> per-step dicts(loss, loss_e, loss_l); the epoch logs upstream prints divide the epoch sums by the last
+    enumerate index TWICE and swap the names of the two terms (:411-423): `edgeprob_minibatch_epoch_log`."""
+    d = dict(data)
+    d['edge_index'] = d['train_pos_edge_index']
+    with torch.no_grad():
+        z_ori = model(d['x'], d['train_pos_edge_index'][:, d['dr_mask']])
+    opt = make_optimizer(model, 'both_all', lr)
+    fct = nn.MSELoss()
+    negs = iter(negs)
+    logs = []
+    for _ in range(epochs):
+        model.train()
+        for nodes in node_sets:
+            b = pyg.saint_subgraph(d, nodes)
+            ei = b['edge_index']
+            z = model(b['x'], ei[:, b['sdf_mask']], None, b['sdf_node_1hop_mask'], b['sdf_node_2hop_mask'])
+            pos = ei[:, b['df_mask']]
+            neg = next(negs)
+            k = pos.shape[1]
+            assert neg.shape[1] == k
+            df_logits = model.decode(z, pos, neg)
+            loss_e = fct(df_logits[:k], df_logits[k:])
+            edge = ei[:, b['sdf_mask']]
+            lower = edge[0] < edge[1]
+            row, col = edge[0][lower], edge[1][lower]
+            logits_ori = (z_ori[row] * z_ori[col]).sum(-1)
+            logits = (z[row] * z[col]).sum(-1)
+            loss_l = fct(logits, logits_ori)
+            loss = 0.5 * loss_e + 0.5 * loss_l
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            logs.append(dict(loss=loss.item(), loss_e=loss_e.item(), loss_l=loss_l.item()))
+    return logs
+
+
+def edgeprob_minibatch_epoch_log(step_logs):
+    """What gnndelete.py:401-423 prints for one epoch from its per-step values: sums divided by step = the LAST enumerate
+    index (n - 1), then by step again in the log dict, with the names of the two terms swapped."""
+    step = max(len(step_logs) - 1, 1)
+    tot = {k: sum(s_[k] for s_ in step_logs) / step for k in ('loss', 'loss_e', 'loss_l')}
+    return {'train_loss': tot['loss'] / step, 'train_loss_l': tot['loss_e'] / step, 'train_loss_e': tot['loss_l'] / step}
+
+
 def kg_nodeemb_minibatch(model, data, node_sets, num_edge_type, epochs, alpha, lr, loss_fct='mse_mean'):
     """KGGNNDeleteNodeembTrainer.train (gnndelete_nodeemb.py:734-800) without validation: message passing on the
     batch's Dr edges with the S_Df-minus-Df node masks as the Del masks (:749-751), DEC on the forward-direction Df

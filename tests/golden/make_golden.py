@@ -683,6 +683,64 @@ def golden_minibatch(D, T, A):
     np.savez_compressed(os.path.join(HERE, 'traj_minibatch_gat.npz'), **out)
 
 
+def golden_edgeprob_minibatch(D, TE, A):
+    """The edge-probability MINI-BATCH loop GNNDeleteTrainer.train_minibatch (framework/trainer/gnndelete.py:312-450) on
+    injected GraphSAINT batches.  Upstream this loop is dead code: Trainer.get_embedding (base.py:52-63) reads
+    data.dtrain_mask, which delete_gnn.py never sets (:124, :190 are commented out) -> AttributeError.  The fixture injects
+    dtrain_mask = dr_mask (what the commented lines assigned) and runs the real loop: z_ori = the model's embedding of the
+    whole graph on the Dr edges (computed once), per batch the Del forward on the batch's S_Df edges, fresh negatives
+    (recorded), loss_e = MSE(df logits, negative logits), loss_l = MSE of the dot products of the batch's S_Df edges
+    (row < col) against z_ori INDEXED WITH THE BATCH-LOCAL ids (an upstream quirk, kept), 0.5 / 0.5, single Adam.
+    `logits_ori.to('cuda')` inside the loop (:383) is neutralised for this CPU run by a Tensor.to shim (environment,
+    not reference code)."""
+    _to = torch.Tensor.to
+
+    def to_(self, *a, **k):
+        if a and isinstance(a[0], str) and a[0] == 'cuda':
+            return self
+        return _to(self, *a, **k)
+    for gnn in ['gcn', 'gat']:
+        g = synth_graph(140, 620, 10, seed=61)
+        d, _ = prepare_deletion(g, 24, seed=9)
+        d['dtrain_mask'] = d['dr_mask']
+        model, _ = build_ref_model(D, A, gnn, d, 10, seed=7)
+        with torch.no_grad():
+            model.deletion1.deletion_weight.fill_(1 / 1000)
+            model.deletion2.deletion_weight.fill_(1 / 1000)
+        init = state_np(model)
+        model.to = lambda *a, **k: model
+        args = make_args(A, ['--gnn', gnn, '--unlearning_model', 'gnndelete', '--epochs', '3', '--valid_freq', '3',
+                             '--checkpoint_dir', tempfile.mkdtemp(), '--dataset', 'Cora', '--lr', '0.01',
+                             '--batch_size', '40', '--num_steps', '3'])
+        opt = torch.optim.Adam([{'params': [p for n_, p in model.named_parameters() if 'del' in n_], 'weight_decay': 0.0}], lr=args.lr)
+        STATE['batches'] = _node_sets(140, 3, 90, seed=3)
+        STATE['neg_gen'], STATE['neg_log'], STATE['wandb'] = torch.Generator().manual_seed(17), [], []
+        torch.manual_seed(81)
+        torch.Tensor.to = to_
+        try:
+            TE.GNNDeleteTrainer(args).train_minibatch(model, d, opt, args)
+        finally:
+            STATE['neg_gen'] = None
+            torch.Tensor.to = _to
+        logs = [w for w in STATE['wandb'] if 'train_loss' in w]
+        vals = [w for w in STATE['wandb'] if 'val_loss' in w]
+        out = dict(init)
+        d2 = Bag({k: v for k, v in d.items() if k not in ('node_id', 'edge_index')})
+        out.update(data_np(d2, torch.zeros(2, 0, dtype=torch.long)))
+        for i, b in enumerate(STATE['batches']):
+            out[f'batch::{i}'] = np_(b)
+        for i, ng in enumerate(STATE['neg_log']):
+            out[f'negs::{i}'] = np_(ng)
+        out.update(n_batches=np.int64(len(STATE['batches'])), n_negs=np.int64(len(STATE['neg_log'])),
+                   log_train_loss=np.array([l_['train_loss'] for l_ in logs]),
+                   log_train_loss_l=np.array([l_['train_loss_l'] for l_ in logs]),
+                   log_train_loss_e=np.array([l_['train_loss_e'] for l_ in logs]),
+                   final_w1=np_(model.deletion1.deletion_weight), final_w2=np_(model.deletion2.deletion_weight),
+                   val_dt_auc=np.array([v['val_dt_auc'] for v in vals]), val_df_auc=np.array([v['val_df_auc'] for v in vals]),
+                   lr=np.float64(args.lr), epochs=np.int64(3), eval_seed=np.int64(81))
+        np.savez_compressed(os.path.join(HERE, f'traj_edgeprob_minibatch_{gnn}.npz'), **out)
+
+
 def kg_request(n, m, R, seed, df_count):
     """delete_gnn.py:85-171 (KG branch) on a synthetic relational graph: directed training triples, Df by index,
     k-hop masks on the directed list, reverse edges with type + R appended, masks repeat(2)."""
@@ -1288,6 +1346,10 @@ def main():
         golden_original_minibatch(B, A)
         write_manifest(None)
         return
+    if sys.argv[1:] == ['edgeprob_minibatch']:  # round 4
+        golden_edgeprob_minibatch(D, TE, A)
+        write_manifest(None)
+        return
     golden_del_layer(D)
     golden_losses(T)
     golden_wiring(D, A)
@@ -1297,6 +1359,7 @@ def main():
     golden_nodecls_trajectory(D, T, A)
     golden_rgat(D, A)
     golden_minibatch(D, T, A)
+    golden_edgeprob_minibatch(D, TE, A)
     golden_kg(D, T, A, B)
     golden_retrain(A)
     golden_retrain_kg(A)

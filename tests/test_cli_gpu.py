@@ -361,6 +361,41 @@ def test_minibatch_trainer_reproduces_reference_trajectory(tmp_path, monkeypatch
     assert abs(vals[-1]['val_df_auc'] - float(rest['val_df_auc'][-1])) < 2e-3
 
 
+@pytest.mark.parametrize('gnn', ['gcn', 'gat'])
+def test_edgeprob_minibatch_trainer_reproduces_reference_trajectory(gnn, tmp_path, monkeypatch):
+    """The edge-probability mini-batch loop (framework/trainer/gnndelete.py:312-450) on the HIP path, on the node sets and
+    negatives the reference's loop consumed (run with the data.dtrain_mask upstream never sets injected as dr_mask): the
+    epoch log with upstream's double division and swapped names, final Del weights, validation AUCs."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework.data import Data
+    from gnndelete_amd.framework.trainer import gnndelete as TG
+    from gnndelete_amd.framework.trainer import sampler as S
+    fx = load_golden(f'traj_edgeprob_minibatch_{gnn}.npz')
+    state, data, rest = split_fixture(fx)
+    m = hip_model(gnn, state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    sets, negs = _lists(fx, 'batch', 'n_batches'), iter(_lists(fx, 'negs', 'n_negs'))
+    monkeypatch.setattr(S, 'make_sampler', lambda d, batch_size, num_steps, walk_length=2: S.FixedNodeSets(d, sets))
+    monkeypatch.setattr(S, 'negative_sampling', lambda ei, n, k: next(negs).to(ei.device))
+    epochs = int(rest['epochs'])
+    args = SimpleNamespace(unlearning_model='gnndelete', dataset='ogbl-synth', checkpoint_dir=str(tmp_path), eval_on_cpu=False,
+                           epochs=epochs, valid_freq=epochs, lr=float(rest['lr']), gnn=gnn, batch_size=40, num_steps=len(sets),
+                           minibatch=True)
+    opt = torch.optim.Adam([{'params': [p for n_, p in m.named_parameters() if 'del' in n_], 'weight_decay': 0.0}], lr=args.lr)
+    tr = TG.GNNDeleteTrainer(args)
+    torch.manual_seed(int(rest['eval_seed']))
+    data.pop('dtrain_mask', None)                                     # the trainer defaults it to dr_mask
+    tr.train(m, Data(data), opt, args)
+    assert len(tr.trainer_log['steps']) == epochs * len(sets)
+    logged = [r for r in tr.trainer_log['log'] if 'train_loss' in r][-1]
+    for key in ['train_loss', 'train_loss_l', 'train_loss_e']:
+        np.testing.assert_allclose(logged[key], rest['log_' + key][-1], rtol=1e-4, atol=1e-9, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), rest['final_w1']) < 1e-4
+    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), rest['final_w2']) < 1e-4
+    vals = [r for r in tr.trainer_log['log'] if 'val_dt_auc' in r]
+    assert abs(vals[-1]['val_dt_auc'] - float(rest['val_dt_auc'][-1])) < 2e-3
+    assert abs(vals[-1]['val_df_auc'] - float(rest['val_df_auc'][-1])) < 2e-3
+
+
 def _kg_fixture(name):
     from gnndelete_amd.framework.data import Data
     fx = load_golden(name)

@@ -259,6 +259,24 @@ def test_minibatch_trajectory_matches_reference_loop():
     assert rel_l2(m.deletion2.deletion_weight.detach(), rest['final_w2']) < 1e-5
 
 
+@pytest.mark.parametrize('gnn', ['gcn', 'gat'])
+def test_edgeprob_minibatch_trajectory_matches_reference_loop(gnn):
+    """GNNDeleteTrainer.train_minibatch (framework/trainer/gnndelete.py:312-450; dead upstream for want of data.dtrain_mask,
+    recorded with dtrain_mask = dr_mask injected) on the injected batches and negatives: the epoch log upstream prints (sums
+    divided by the last enumerate index twice, the two terms' names swapped) and the final Del weights."""
+    fx = load_golden(f'traj_edgeprob_minibatch_{gnn}.npz')
+    state, data, rest = split_fixture(fx)
+    m = oracle_model(gnn, state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    sets, epochs = _fixture_lists(fx, 'batch', 'n_batches'), int(rest['epochs'])
+    logs = R.edgeprob_minibatch(m, data, sets, _fixture_lists(fx, 'negs', 'n_negs'), epochs, float(rest['lr']))
+    assert len(logs) == epochs * len(sets)
+    last = R.edgeprob_minibatch_epoch_log(logs[-len(sets):])          # valid_freq = epochs: the last epoch is the one logged
+    for key in ['train_loss', 'train_loss_l', 'train_loss_e']:
+        np.testing.assert_allclose(last[key], rest['log_' + key][-1], rtol=2e-5, atol=1e-10, err_msg=key)
+    assert rel_l2(m.deletion1.deletion_weight.detach(), rest['final_w1']) < 1e-5
+    assert rel_l2(m.deletion2.deletion_weight.detach(), rest['final_w2']) < 1e-5
+
+
 def test_kg_trajectory_matches_reference_loop():
     """KGGNNDeleteNodeembTrainer.train (gnndelete_nodeemb.py:659-846) with RGCNDelete at 21 relation types
     (block-diagonal weights): per-step losses and final Del weights, negatives re-drawn from the recorded seed."""
