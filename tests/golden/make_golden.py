@@ -699,9 +699,19 @@ def golden_edgeprob_minibatch(D, TE, A):
         if a and isinstance(a[0], str) and a[0] == 'cuda':
             return self
         return _to(self, *a, **k)
+    upstream_error = None
     for gnn in ['gcn', 'gat']:
         g = synth_graph(140, 620, 10, seed=61)
         d, _ = prepare_deletion(g, 24, seed=9)
+        if upstream_error is None:               # as delete_gnn.py hands the data over: no dtrain_mask -> the loop cannot start
+            try:
+                m0, _ = build_ref_model(D, A, gnn, d, 10, seed=7)
+                a0 = make_args(A, ['--gnn', gnn, '--unlearning_model', 'gnndelete', '--epochs', '1', '--valid_freq', '1',
+                                   '--checkpoint_dir', tempfile.mkdtemp(), '--dataset', 'Cora'])
+                TE.GNNDeleteTrainer(a0).train_minibatch(m0, d, None, a0)
+                upstream_error = 'no error'
+            except Exception as e:               # noqa: BLE001
+                upstream_error = f'{type(e).__name__}: {e}'
         d['dtrain_mask'] = d['dr_mask']
         model, _ = build_ref_model(D, A, gnn, d, 10, seed=7)
         with torch.no_grad():
@@ -739,6 +749,7 @@ def golden_edgeprob_minibatch(D, TE, A):
                    val_dt_auc=np.array([v['val_dt_auc'] for v in vals]), val_df_auc=np.array([v['val_df_auc'] for v in vals]),
                    lr=np.float64(args.lr), epochs=np.int64(3), eval_seed=np.int64(81))
         np.savez_compressed(os.path.join(HERE, f'traj_edgeprob_minibatch_{gnn}.npz'), **out)
+    STATE['edgeprob_minibatch_upstream_error'] = upstream_error
 
 
 def kg_request(n, m, R, seed, df_count):
@@ -1301,9 +1312,16 @@ def write_manifest(crash):
     if crash is None:                                            # keep the recorded upstream error text
         with open(path) as f:
             crash = json.load(f).get('gcn_both_layerwise_upstream_error')
+    prev = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            prev = json.load(f)
     with open(path, 'w') as f:
         json.dump({'generated_by': 'tests/golden/make_golden.py', 'reference': REF, 'torch': torch.__version__,
                    'gcn_both_layerwise_upstream_error': crash,
+                   # GNNDeleteTrainer.train_minibatch as delete_gnn.py calls it (no data.dtrain_mask); the
+                   # traj_edgeprob_minibatch_* fixtures were recorded with dtrain_mask = dr_mask injected
+                   'edgeprob_minibatch_upstream_error': STATE.get('edgeprob_minibatch_upstream_error') or prev.get('edgeprob_minibatch_upstream_error'),
                    'files': sorted(x for x in os.listdir(HERE) if x.endswith(('.npz', '.json')))}, f, indent=1)
 
 
