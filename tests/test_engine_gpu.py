@@ -537,9 +537,12 @@ def _kg_request(n, m, nr, seed, n_df):
     return data
 
 
-@pytest.mark.parametrize('use_graph', [False, True])
-@pytest.mark.parametrize('dims,nr,loss_type', [((32, 32, 16), 21, 'both_layerwise'), ((128, 128, 64), 51, 'both_layerwise'),
-                                               ((128, 128, 64), 51, 'both_all'), ((64, 128, 64), 5, 'only2_layerwise')])
+# (eager AND replayed at the two small shapes; the 51-relation shapes - 20-30 s of CPU oracle each - replayed only, eager
+#  once: the suite has a time limit)
+@pytest.mark.parametrize('dims,nr,loss_type,use_graph', [
+    ((32, 32, 16), 21, 'both_layerwise', False), ((32, 32, 16), 21, 'both_layerwise', True),
+    ((128, 128, 64), 51, 'both_layerwise', True), ((128, 128, 64), 51, 'both_all', True), ((128, 128, 64), 51, 'both_all', False),
+    ((64, 128, 64), 5, 'only2_layerwise', False), ((64, 128, 64), 5, 'only2_layerwise', True)])
 def test_rgcn_engine_matches_oracle_training(dims, nr, loss_type, use_graph):
     """The fused step on an R-GCN backbone (BASELINE config 4's model): typed conv kernel forward and transposed,
     Del operators on the S_Df-minus-Df node masks (what KGGNNDeleteNodeembTrainer passes, gnndelete_nodeemb.py:749-751),

@@ -19,7 +19,7 @@ task-level contract of north_star: post-deletion AUC within +-0.002.
           (test edges; Df vs Dr)
 
 All oracles run as plain torch ops on the GPU (fp64: fast fp64 units; 600 CPU epochs at the bench's size would take 15
-minutes); four fp32 members at every size; GCN at synth-small and at the bench's size, GAT at synth-small."""
+minutes); four fp32 members at synth-small, three at the bench's size; GCN at both sizes, GAT at synth-small."""
 from types import SimpleNamespace
 
 import pytest
@@ -36,7 +36,9 @@ RATIO = 2.0                   # measured ratios: profiles/r03_long_parity.txt, p
 # less of the norm) - and at synth-small the four GPU members sum in the same order (identical digits at epoch 100), so
 # they flip together and say nothing about WHEN a differently associated correct implementation flips
 FLOOR = {'synth-small': 3e-4, 'synth-collab': 2e-6}
-PERMS = (None, 1, 2, 3)       # fp32 ensemble: edge-order seeds (None = as given); four members at every size
+# fp32 ensemble: edge-order seeds (None = as given).  Four members at synth-small; three at the bench's size, where an oracle run
+# costs 20 s of the suite's time limit (the full-size test adds the CPU oracle + three more GPU members at its 20-iteration horizon)
+PERMS = {'synth-small': (None, 1, 2, 3), 'synth-collab': (None, 1, 2)}
 
 
 def _auc(z, pos, neg):
@@ -80,7 +82,7 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
         return snaps, z_ori
     s64_all, _ = run_oracle(torch.float64, None)
     d_members, s32_last, z_ori32 = [], None, None
-    for perm in PERMS:                 # the fp32 ensemble: distances to the fp64 run at every check
+    for perm in PERMS[workload]:       # the fp32 ensemble: distances to the fp64 run at every check
         snaps, z_ori = run_oracle(torch.float32, perm)
         d_members.append([[rel_l2(sn[i], s64[i]) for i in range(4)] for sn, s64 in zip(snaps, s64_all)])
         if perm is None:
