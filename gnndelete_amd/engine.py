@@ -841,8 +841,11 @@ class NodeembEngine:
             self._graph_k = (unroll, graph)
 
     def _mutable_state(self):
-        return [self.wd1.data, self.wd2.data, self.g1, self.g2, self.adam1.m, self.adam1.v, self.iter_ctr,
-                self.adam2.m, self.adam2.v, self.hist, self.hist_pos, self.dz1, self.dz2, self.dh]
+        state = [self.wd1.data, self.wd2.data, self.g1, self.g2, self.adam1.m, self.adam1.v, self.iter_ctr,
+                 self.adam2.m, self.adam2.v, self.hist, self.hist_pos, self.dz1, self.dz2, self.dh]
+        if getattr(self, '_arrive', None) is not None:      # step_tail's check-in counter: a launch that did not finish must not
+            state.append(self._arrive)                       # leave it non-zero for the replays
+        return state
 
     def _capture(self):
         saved = [t.clone() for t in self._mutable_state()]
