@@ -859,6 +859,22 @@ def main():
         auto_est = partition_estimate(eng, world, ctl, 1e6 * world / rep_rate_auto)
         model.load_state_dict(state)
         if auto_est['predicted_partitioned_step_us'] >= auto_est['single_gpu_step_us']:
+            # the partitioned engine is built already: time it too, so that the line carries the measured partitioned step
+            # next to the estimate that turned it down (the scaling curve of the partitioned engine at every N)
+            for _ in range(args.warmup):
+                eng.step()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.step()
+            torch.cuda.synchronize()
+            barrier()
+            tpart = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(tpart, op=dist.ReduceOp.MAX, group=ctl)
+            auto_est['measured_partitioned_step_us'] = 1e6 * float(tpart) / args.steps
+            auto_est['chosen'] = 'replicas'
+            model.load_state_dict(state)
             mode = args.parallel = 'replicas'
             del eng
         else:

@@ -67,6 +67,8 @@ def test_bench_two_ranks_auto_follows_the_planner():
     slower = est['predicted_partitioned_step_us'] >= est['single_gpu_step_us']
     assert d['n_gpus'] == 2 and d['scaling'] == ('weak' if slower else 'strong') and d['value'] > 0, d
     assert ('replicas' in d['config']['parallelism']) == slower
+    if slower:      # the partitioned step that was turned down is still measured and reported next to the estimate
+        assert est['measured_partitioned_step_us'] > 0 and est['chosen'] == 'replicas', est
 
 
 def test_bench_two_ranks_partition_the_rgcn_request():
