@@ -14,7 +14,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'gnndelete_hip.h')
 _i32, _i64, _f32, _f64, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
 # name -> (restype, argtypes); must list every symbol the header declares
-ABI_VERSION = 6          # GD_ABI_VERSION of include/gnndelete_hip.h this binding was written against
+ABI_VERSION = 7          # GD_ABI_VERSION of include/gnndelete_hip.h this binding was written against
 
 PROTOTYPES = {
     'gd_abi_version': (ctypes.c_int, []),
@@ -39,6 +39,8 @@ PROTOTYPES = {
     'gd_random_walk': (ctypes.c_int, [_p, _p, _i32, _p, _i32, _i32, ctypes.c_uint64, _p, _p]),
     'gd_rgcn_tile_kl': (ctypes.c_int32, [_i32, _i32, _i32, _i32]),
     'gd_rgcn_pack_weight_f32': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    'gd_rgcn_wave_covers': (ctypes.c_int32, [_i32, _i32, _i32]),
+    'gd_rgcn_wave_conv_f32': (ctypes.c_int, [_p, _i32, _i32, _p, _p, _p, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _i32, _i32, _p]),
     'gd_rgcn_tile_conv_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _p, _i64, _i32, _p, _i32, _i32, _p, _i64, _i32,
                                              _i32, _p, _p, _i32, _p, _p]),
     'gd_rgcn_mean_f32': (ctypes.c_int, [_p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p]),

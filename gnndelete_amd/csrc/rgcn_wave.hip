@@ -1,0 +1,233 @@
+// R-GCN typed message passing, wave-private form (PyG RGCNConv aggr='mean' with constant BLOCK-DIAGONAL relation weights,
+// framework/models/rgcn.py:16-38; same contract as gd_rgcn_conv_f32 / gd_rgcn_tile_conv_f32):
+//
+//     y[i,:] += sum_r ( sum_{e in run(i,r)} w_e x[col_e,:] ) @ W_r
+//
+// The tile kernel (rgcn_tile.hip) walks (64-node tile, relation) steps with a block of 8 waves and two block barriers
+// per step: every step is a dependent chain descriptor -> edge list -> gathered rows -> LDS tile -> barrier -> matrix
+// instructions -> barrier, and the waves wait 67 % of their cycles (profiles/r03_rgcn_tile_issue_pmc.txt).  With the
+// reference's four diagonal blocks, output block t of a node depends on input features [KL t, KL t + KL) only - so the
+// FOUR BLOCKS ARE FOUR INDEPENDENT PROBLEMS and a single wave can own one of them for a whole tile:
+//
+//   job    = (tile of TILE consecutive nodes, diagonal block t); one wave, no barrier, no atomics on global memory; the
+//            job's outputs [TILE x OW] live in a wave-private LDS accumulator across all relations of the tile;
+//   unit   = 16 pieces of ONE relation of the tile, piece = up to 4 in-edges of one (node, relation) run, in a fixed
+//            shape: 16 slots x 4 (source, weight) pairs, unused pairs point one row past x (the buffer descriptor
+//            returns zeros for them without touching memory) - so that every unit issues the SAME number of loads and
+//            every wait in the loop is an exact count;
+//   gather   LPR = KL / 4 lanes take the 16-byte pieces of one source row's [KL t, KL t + KL) slice (128 B = one cache
+//            line at KL = 32), 64 / LPR slots per load instruction, 4 loads per slot; the weighted sum of a slot is the
+//            compact row q of a [16 x KL] tile in LDS;
+//   product  D[out][slot] = W_r^T[out][k] A^T[k][slot] on v_mfma_f32_16x16x4_f32 with the relation's block from
+//            gd_rgcn_pack_weight_f32 (the same packed image the tile kernel reads).  A run longer than 4 edges is several
+//            CONSECUTIVE slots with the same node row; the slots of a unit are the 16 lanes of a DPP row of D, so a
+//            segmented scan over those lanes (four v_fmac_dpp steps per register, the segment flags come with the plan)
+//            leaves a row's total in its LAST slot, and only that lane adds it to the node row of the accumulator: a plain
+//            LDS read-modify-write without two lanes on one address.  (LDS float atomics would not need the scan - and were
+//            measured at ~180 cycles per instruction: the LDS pipe 86 % busy, 3.9 ms per launch.)
+//   pipeline the rows, the weight fragments and the row map of unit u + 1 and the edge pairs of unit u + 2 are in flight
+//            while unit u is summed and multiplied (two register sets, the loop is unrolled by two; the plan pads every
+//            tile to an even number of units).
+//
+// The gathered volume (every source row once per edge: 4.3 GB at ogbl-biokg size, all of it fabric traffic) is what
+// bounds this form; the matrix instructions take less than half of that time.
+#include "common.h"
+
+namespace gd {
+
+using f32x4w = __attribute__((ext_vector_type(4))) float;
+using u32x4w = __attribute__((ext_vector_type(4))) unsigned int;
+
+template <int KL, int OW, int TILE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void rgcn_wave_kernel(
+    const int32_t* __restrict__ job_tile, int32_t n_tiles, const int32_t* __restrict__ tile_unit_ptr,
+    const int32_t* __restrict__ unit_rel, const int4* __restrict__ unit_edges, const int32_t* __restrict__ unit_row,
+    const float* __restrict__ x, int64_t ldx, const float4* __restrict__ wpk4, float* __restrict__ y, int64_t ldy,
+    int32_t n_nodes, int64_t n_x_bytes) {
+  constexpr int LPR = KL / 4, GROUPS = 64 / LPR, ROUNDS = 16 / GROUPS, AP = KL + 4, NOH = OW / 16, NMM = KL / 16, CP = OW + 4;
+  __shared__ __attribute__((aligned(16))) float a_tile[16 * AP];
+  __shared__ __attribute__((aligned(16))) float acc[TILE * CP];      // [node row][output], pitch OW + 4
+  const int lane = threadIdx.x, b = blockIdx.x;
+  // b = 32 q + 8 t + xcd: the four blocks of a tile run on the same XCD (workgroups go round the XCDs), next to each other
+  const int ot = (b >> 3) & 3, ti = ((b >> 5) << 3) + (b & 7);
+  if (ti >= n_tiles) return;
+  const int tile = __builtin_amdgcn_readfirstlane(job_tile ? job_tile[ti] : ti);
+  const int u0 = __builtin_amdgcn_readfirstlane(tile_unit_ptr[tile]), u1 = __builtin_amdgcn_readfirstlane(tile_unit_ptr[tile + 1]);
+  if (u0 >= u1) return;
+  const int g = lane / LPR, gl = lane % LPR, j = lane & 15, kq = lane >> 4;
+  for (int i = lane; i < TILE * CP / 4; i += 64) reinterpret_cast<float4*>(acc)[i] = f4_zero();
+
+  const uint32_t row_bytes = (uint32_t)(ldx * 4), feat_off = (uint32_t)(4 * (ot * KL + 4 * gl));
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (uint32_t)n_x_bytes, 0x00020000);
+  auto load_edges = [&](int u, int4 (&e)[ROUNDS][2]) {
+    const int4* base = unit_edges + ((int64_t)u * 16 + g) * 2;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      e[r][0] = base[GROUPS * r * 2];
+      e[r][1] = base[GROUPS * r * 2 + 1];
+    }
+  };
+  // rel = the unit's relation, read a unit ahead (a scalar load: its latency must not sit in front of the weight loads)
+  auto issue = [&](int rel, const int4 (&e)[ROUNDS][2], float4 (&rows)[ROUNDS][4], float (&wt)[ROUNDS][4], float4 (&wf)[NOH][NMM]) {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int cc[4] = {e[r][0].x, e[r][0].z, e[r][1].x, e[r][1].z};
+      wt[r][0] = __int_as_float(e[r][0].y);
+      wt[r][1] = __int_as_float(e[r][0].w);
+      wt[r][2] = __int_as_float(e[r][1].y);
+      wt[r][3] = __int_as_float(e[r][1].w);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, __umul24((uint32_t)cc[k], row_bytes) + feat_off, 0, 0);
+        rows[r][k] = __builtin_bit_cast(float4, v);
+      }
+    }
+    const float4* wp = wpk4 + ((int64_t)(rel * 4 + ot) * (NOH * NMM)) * 64 + lane;
+#pragma unroll
+    for (int oh = 0; oh < NOH; ++oh)
+#pragma unroll
+      for (int mm = 0; mm < NMM; ++mm) wf[oh][mm] = wp[(oh * NMM + mm) * 64];
+  };
+  auto compute = [&](const float4 (&rows)[ROUNDS][4], const float (&wt)[ROUNDS][4], const float4 (&wf)[NOH][NMM], int nrow) {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      float4 s = make_float4(wt[r][0] * rows[r][0].x, wt[r][0] * rows[r][0].y, wt[r][0] * rows[r][0].z, wt[r][0] * rows[r][0].w);
+#pragma unroll
+      for (int k = 1; k < 4; ++k) s = f4_fma(wt[r][k], rows[r][k], s);
+      *reinterpret_cast<float4*>(a_tile + (GROUPS * r + g) * AP + 4 * gl) = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // lane (j, kq) feeds k = 16 mm + 4 kq + c of slot j and ends with the outputs 16 oh + 4 kq + c of that slot
+    float4 bv[NMM];
+#pragma unroll
+    for (int mm = 0; mm < NMM; ++mm) bv[mm] = *reinterpret_cast<const float4*>(a_tile + j * AP + 16 * mm + 4 * kq);
+    f32x4w d[NOH];
+#pragma unroll
+    for (int oh = 0; oh < NOH; ++oh) d[oh] = f32x4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mm = 0; mm < NMM; ++mm) {
+#pragma unroll
+      for (int oh = 0; oh < NOH; ++oh) {
+        d[oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[oh][mm].x, bv[mm].x, d[oh], 0, 0, 0);
+        d[oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[oh][mm].y, bv[mm].y, d[oh], 0, 0, 0);
+        d[oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[oh][mm].z, bv[mm].z, d[oh], 0, 0, 0);
+        d[oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[oh][mm].w, bv[mm].w, d[oh], 0, 0, 0);
+      }
+    }
+    // nrow = node row | segment flags << 8 | last-of-its-row << 12.  Flag bit b: the slot 2^b to the left holds the same
+    // node row (same-row slots are consecutive) - Hillis-Steele steps 1, 2, 4, 8 inside the 16-lane DPP row
+    const float f1 = (float)((nrow >> 8) & 1), f2 = (float)((nrow >> 9) & 1), f4 = (float)((nrow >> 10) & 1), f8 = (float)((nrow >> 11) & 1);
+#pragma unroll
+    for (int oh = 0; oh < NOH; ++oh)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = d[oh][c];
+        v = fmaf(f1, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true)), v);
+        v = fmaf(f2, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true)), v);
+        v = fmaf(f4, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true)), v);
+        v = fmaf(f8, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true)), v);
+        d[oh][c] = v;
+      }
+    if (nrow & (1 << 12)) {
+      float* dst = acc + (nrow & 255) * CP + 4 * kq;
+#pragma unroll
+      for (int oh = 0; oh < NOH; ++oh) {
+        float4 v = *reinterpret_cast<float4*>(dst + 16 * oh);
+        v.x += d[oh][0]; v.y += d[oh][1]; v.z += d[oh][2]; v.w += d[oh][3];
+        *reinterpret_cast<float4*>(dst + 16 * oh) = v;
+      }
+    }
+  };
+
+  int4 e_a[ROUNDS][2], e_b[ROUNDS][2];
+  float4 rows_a[ROUNDS][4], rows_b[ROUNDS][4], wf_a[NOH][NMM], wf_b[NOH][NMM];
+  float wt_a[ROUNDS][4], wt_b[ROUNDS][4];
+  const int ul = u1 - 1;
+  // Order inside a half: the row map of the next unit FIRST (the packed FMAs of the sums read register PAIRS; when the
+  // allocator pairs a weight with the target of a load in flight, the wait in front of that FMA covers everything issued up
+  // to that load - first in the half, that is only what the sums need anyway), then the edge pairs two units ahead, then
+  // the next unit's rows and weight fragments.
+  int nrow_a = unit_row[u0 * 16 + j], nrow_b;
+  int rel_n = __builtin_amdgcn_readfirstlane(unit_rel[u0]), rel_nn = __builtin_amdgcn_readfirstlane(unit_rel[min(u0 + 1, ul)]);
+  load_edges(u0, e_a);
+  load_edges(min(u0 + 1, ul), e_b);
+  issue(rel_n, e_a, rows_a, wt_a, wf_a);
+  for (int u = u0; u < u1; u += 2) {                       // the plan pads every tile to an even number of units
+    nrow_b = unit_row[(u + 1) * 16 + j];
+    rel_n = rel_nn;
+    rel_nn = __builtin_amdgcn_readfirstlane(unit_rel[min(u + 2, ul)]);
+    load_edges(min(u + 2, ul), e_a);
+    issue(rel_n, e_b, rows_b, wt_b, wf_b);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(rows_a, wt_a, wf_a, nrow_a);
+    __builtin_amdgcn_sched_barrier(0);
+    nrow_a = unit_row[min(u + 2, ul) * 16 + j];
+    rel_n = rel_nn;
+    rel_nn = __builtin_amdgcn_readfirstlane(unit_rel[min(u + 3, ul)]);
+    load_edges(min(u + 3, ul), e_b);
+    issue(rel_n, e_a, rows_a, wt_a, wf_a);                 // past the tile's end: the last unit once more, never used
+    __builtin_amdgcn_sched_barrier(0);
+    compute(rows_b, wt_b, wf_b, nrow_b);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // the tile's rows of this block's outputs: y += accumulators (OW / 4 lanes per row)
+  constexpr int C4 = OW / 4;
+  for (int i = lane; i < TILE * C4; i += 64) {
+    const int r = i / C4, c4 = i % C4, node = tile * TILE + r;
+    if (node < n_nodes) {
+      const float4 a = *reinterpret_cast<const float4*>(acc + r * CP + 4 * c4);
+      float4* dst = reinterpret_cast<float4*>(y + (int64_t)node * ldy + OW * ot) + c4;
+      *dst = f4_add(*dst, a);
+    }
+  }
+}
+
+static bool wave_geometry(int32_t d_in, int32_t d_out, int32_t n_blocks) {
+  return n_blocks == 4 && (d_in == 64 || d_in == 128) && (d_out == 64 || d_out == 128);
+}
+
+}  // namespace gd
+
+extern "C" int32_t gd_rgcn_wave_covers(int32_t d_in, int32_t d_out, int32_t n_blocks) {
+  return gd::wave_geometry(d_in, d_out, n_blocks) ? 1 : 0;
+}
+
+extern "C" int gd_rgcn_wave_conv_f32(const int32_t* job_tile, int32_t n_tiles, int32_t tile, const int32_t* tile_unit_ptr,
+                                     const int32_t* unit_rel, const int32_t* unit_edges, const int32_t* unit_row, const float* x,
+                                     int64_t ldx, int32_t d_in, const float* packed_w, int32_t n_blocks, float* y, int64_t ldy,
+                                     int32_t d_out, int32_t n_nodes, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(tile_unit_ptr && unit_rel && unit_edges && unit_row && x && packed_w && y, GD_E_NULL, "gd_rgcn_wave_conv_f32: null pointer");
+  GD_REQUIRE(wave_geometry(d_in, d_out, n_blocks), GD_E_DIM,
+             "gd_rgcn_wave_conv_f32: needs 4 diagonal blocks and widths in {64, 128} (d_in=%d d_out=%d blocks=%d); use gd_rgcn_tile_conv_f32",
+             d_in, d_out, n_blocks);
+  GD_REQUIRE(tile == 64 && n_tiles == (n_nodes + tile - 1) / tile && ldx >= d_in && ldy >= d_out && ldx % 4 == 0 && ldy % 4 == 0, GD_E_DIM,
+             "gd_rgcn_wave_conv_f32: tile must be 64, n_tiles = ceil(n_nodes / tile), row pitches multiples of 4");
+  GD_REQUIRE(aligned16(x) && aligned16(y) && aligned16(packed_w) && aligned16(unit_edges) && x != y, GD_E_ALIGN,
+             "gd_rgcn_wave_conv_f32: unaligned or aliasing pointer");
+  // 24 x 24-bit row offsets; the pad source n_nodes (one row past x) must stay below 4 GB as well
+  GD_REQUIRE(n_nodes < (1 << 24) && ldx * 4 < (1 << 24) && ((int64_t)n_nodes + 1) * ldx * 4 < ((int64_t)1 << 32), GD_E_DIM,
+             "gd_rgcn_wave_conv_f32: x beyond 4 GB / 2^24 rows; use gd_rgcn_conv_f32");
+  if (n_tiles == 0) return GD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((n_tiles + 7) / 8) * 32);
+  const int64_t n_x_bytes = ((int64_t)(n_nodes - 1) * ldx + d_in) * 4;
+#define GD_RW_CASE(KL, OW)                                                                                                   \
+  hipLaunchKernelGGL((rgcn_wave_kernel<KL, OW, 64>), grid, dim3(64), 0, s, job_tile, n_tiles, tile_unit_ptr, unit_rel,       \
+                     reinterpret_cast<const int4*>(unit_edges), unit_row, x, ldx, reinterpret_cast<const float4*>(packed_w), y, ldy, \
+                     n_nodes, n_x_bytes)
+  switch (d_in * 1000 + d_out) {
+    case 128128: GD_RW_CASE(32, 32); break;
+    case 128064: GD_RW_CASE(32, 16); break;
+    case 64128: GD_RW_CASE(16, 32); break;
+    case 64064: GD_RW_CASE(16, 16); break;
+    default: return fail(GD_E_DIM, "gd_rgcn_wave_conv_f32: no kernel for d_in=%d d_out=%d", d_in, d_out);
+  }
+#undef GD_RW_CASE
+  return launched("rgcn_wave_conv");
+}

@@ -149,7 +149,10 @@ class PartitionedNodeembEngine:
             self.typed = TypedNodeCSR(edge_index, edge_type.to(dev), n, conv2.num_relations, row_range=(lo, hi))
             for c_, din, dout, tr in ((conv1, x.shape[1], self.h, 0), (conv2, self.h, self.o, 0), (conv2, self.o, self.h, 1)):
                 if int(_lib.lib().gd_rgcn_tile_kl(din, dout, c_.num_blocks or 1, tr)) > 0:
-                    self.typed.tile_plan(bool(tr))
+                    if ops.rgcn_wave_form(din, dout, c_.num_blocks or 1):
+                        self.typed.wave_plan(bool(tr))
+                    else:
+                        self.typed.tile_plan(bool(tr))
                     ops.rgcn_packed_weight(c_.weight.detach(), c_.num_blocks or 1, din, dout, tr)
         self.plan = SplitPlan(g.rowptr, row_range=(lo, hi))                    # forward aggregations: own rows
         self.plan_t = SplitPlan(g.rowptr_t, rows=self.idx1) if self.s1 else None   # transposed: own S1 rows only

@@ -638,6 +638,96 @@ class TypedNodeCSR:
                     n_steps=n_steps, n_pieces=int(piece_key.numel()), n_hubs=n_hubs, hub_node=i32(hub_node) if n_hubs else z,
                     hub_ptr=i32(hub_ptr), n_slice_rows=(n_tiles - n_real) * tile, max_steps=int(steps_per_tile.max()))
 
+    def wave_plan(self, trans=False):
+        """The (tile, relation) UNITS gd_rgcn_wave_conv_f32 walks (include/gnndelete_hip.h): every (node, relation) run cut
+        into pieces of <= 4 edges, the pieces of a (64-node tile, relation) laid 16 to a unit in a fixed shape.  Built once
+        per direction with sorts / uniques on the device."""
+        key = 'bwd' if trans else 'fwd'
+        cache = self.__dict__.setdefault('_wave_plans', {})
+        if key not in cache:
+            cache[key] = self._build_wave_plan(self.bwd if trans else self.fwd, self.n, self.num_relations)
+        return cache[key]
+
+    @staticmethod
+    def _build_wave_plan(arrays, n, r, tile=64, cap=4, slots=16):
+        """-> tile_unit_ptr [T + 1] (every tile holds an EVEN number of units: the kernel's loop is unrolled by two; an odd
+        tile gets one empty unit), unit_rel [U], unit_row [U, 16] (slot word: node % tile | same-row flags | last; 0 for an
+        unused slot),
+        unit_edges [U, 16, 4, 2] int32 = (source, weight bits) pairs, unused pairs = (n, 0.0): one row past x, for which
+        the kernel's buffer loads return zeros without a memory access; job_tile [T] = tiles by unit count, heaviest first."""
+        node_ptr, seg_ptr, seg_rel, col, w = arrays
+        dev = col.device
+        n_tiles = (n + tile - 1) // tile
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        e = int(col.numel())
+        if e == 0:
+            return dict(n_tiles=n_tiles, tile=tile, tile_unit_ptr=torch.zeros(n_tiles + 1, dtype=torch.int32, device=dev),
+                        unit_rel=torch.zeros(1, dtype=torch.int32, device=dev), unit_row=torch.zeros(1, slots, dtype=torch.int32, device=dev),
+                        unit_edges=torch.zeros(1, slots, cap, 2, dtype=torch.int32, device=dev),
+                        job_tile=i32(torch.arange(n_tiles, device=dev)), n_units=0, n_pieces=0, max_units=0)
+        seg_len = (seg_ptr[1:] - seg_ptr[:-1]).long()
+        n_runs = int(seg_len.numel())
+        run_of_edge = torch.repeat_interleave(torch.arange(n_runs, device=dev), seg_len)
+        runs_per_node = (node_ptr[1:] - node_ptr[:-1]).long()
+        node_of_run = torch.repeat_interleave(torch.arange(n, device=dev), runs_per_node)
+        pos = torch.arange(e, device=dev) - seg_ptr.long()[run_of_edge]          # position inside the run
+        # pieces, in (tile, relation, node, piece) order: the node-major arrays are (node, relation, source) already
+        piece_start = pos % cap == 0
+        piece_of_edge = torch.cumsum(piece_start, 0) - 1
+        p_run = run_of_edge[piece_start]
+        p_node, p_rel = node_of_run[p_run], seg_rel.long()[p_run]
+        gkey = (p_node // tile) * r + p_rel                                     # group = (tile, relation)
+        order = torch.argsort(gkey, stable=True)                                # keeps (node, piece) order inside a group
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(order.numel(), device=dev)                   # piece -> its place in group order
+        gk_sorted = gkey[order]
+        groups, g_np = torch.unique_consecutive(gk_sorted, return_counts=True)
+        g_first = torch.cumsum(g_np, 0) - g_np
+        g_units = (g_np + slots - 1) // slots
+        g_tile = groups // r
+        units_per_tile = torch.zeros(n_tiles, dtype=torch.int64, device=dev).scatter_add_(0, g_tile, g_units)
+        padded = units_per_tile + (units_per_tile & 1)
+        tile_unit_ptr = torch.zeros(n_tiles + 1, dtype=torch.int64, device=dev)
+        tile_unit_ptr[1:] = torch.cumsum(padded, 0)
+        n_units = int(tile_unit_ptr[-1])
+        g_excl = torch.cumsum(g_units, 0) - g_units                             # units before the group, unpadded
+        tile_excl = torch.cumsum(units_per_tile, 0) - units_per_tile
+        g_unit0 = tile_unit_ptr[:-1][g_tile] + (g_excl - tile_excl[g_tile])     # first unit of the group
+        unit_rel = torch.zeros(max(n_units, 1), dtype=torch.int64, device=dev)
+        unit_of_g = torch.repeat_interleave(torch.arange(groups.numel(), device=dev), g_units)
+        u_idx = g_unit0[unit_of_g] + (torch.arange(unit_of_g.numel(), device=dev) - g_excl[unit_of_g])
+        unit_rel[u_idx] = groups[unit_of_g] % r
+        # piece -> (unit, slot)
+        group_of_sorted = torch.repeat_interleave(torch.arange(groups.numel(), device=dev), g_np)
+        in_group = torch.arange(order.numel(), device=dev) - g_first[group_of_sorted]
+        unit_sorted = g_unit0[group_of_sorted] + in_group // slots
+        slot_sorted = in_group % slots
+        # slot word = node % tile | flags << 8 | last << 12.  The slots of one node row inside a unit are consecutive
+        # ((node, piece) order); flag bit b says the slot 2^b to the left holds the same row (the kernel's segmented scan
+        # over the 16 slots), `last` marks the slot that ends up with the row's total and adds it to the accumulator
+        run_sorted = p_run[order]
+        word = p_node[order] % tile
+        for b in range(4):
+            sh = 1 << b
+            same = torch.zeros_like(word, dtype=torch.bool)
+            same[sh:] = (run_sorted[sh:] == run_sorted[:-sh]) & (slot_sorted[sh:] >= sh)
+            word = word | (same.long() << (8 + b))
+        last = torch.ones_like(word, dtype=torch.bool)
+        last[:-1] = (run_sorted[1:] != run_sorted[:-1]) | (unit_sorted[1:] != unit_sorted[:-1])
+        word = word | (last.long() << 12)
+        unit_row = torch.zeros(max(n_units, 1) * slots, dtype=torch.int64, device=dev)
+        unit_row[unit_sorted * slots + slot_sorted] = word
+        p_unit, p_slot = unit_sorted[rank], slot_sorted[rank]                   # back in piece order
+        unit_edges = torch.zeros(max(n_units, 1) * slots * cap, 2, dtype=torch.int32, device=dev)
+        unit_edges[:, 0] = n
+        at = (p_unit[piece_of_edge] * slots + p_slot[piece_of_edge]) * cap + pos % cap
+        unit_edges[at, 0] = col.to(torch.int32)
+        unit_edges[at, 1] = w.to(torch.float32).view(torch.int32)
+        return dict(n_tiles=n_tiles, tile=tile, tile_unit_ptr=i32(tile_unit_ptr), unit_rel=i32(unit_rel),
+                    unit_row=i32(unit_row).view(-1, slots), unit_edges=unit_edges.view(-1, slots, cap, 2).contiguous(),
+                    job_tile=i32(torch.argsort(padded, descending=True, stable=True)), n_units=n_units,
+                    n_pieces=int(order.numel()), max_units=int(padded.max()))
+
     @staticmethod
     def _runs(run_sorted, col_sorted, r, n, w):
         dev = run_sorted.device

@@ -623,6 +623,11 @@ def rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans):
     return _note_constant(_lru_get(_RGCN_PACK_CACHE, key, 16, build)[0])
 
 
+def rgcn_wave_form(d_in, d_out, n_blocks):
+    """Whether the typed conv of these widths runs on the wave-private kernel (GD_RGCN_WAVE=0: the tile kernel instead)."""
+    return os.environ.get('GD_RGCN_WAVE', '1') != '0' and int(_lib.lib().gd_rgcn_wave_covers(d_in, d_out, n_blocks)) > 0
+
+
 def rgcn_typed_accumulate(tg, x, weight, n_blocks, trans, y, edge_w=None):
     """y += sum_r (weighted mean over the relation-r in-edges of x) @ W_r (trans: the input gradient on the transposed
     graph with W_r^T) - raw, no autograd.  The (tile, relation) kernel where the widths allow, the node-major one
@@ -633,6 +638,15 @@ def rgcn_typed_accumulate(tg, x, weight, n_blocks, trans, y, edge_w=None):
         return y
     tiled = (edge_w is None and x.stride(0) % 4 == 0 and y.stride(0) % 4 == 0 and os.environ.get('GD_RGCN_NODE_MAJOR') != '1'
              and int(_lib.lib().gd_rgcn_tile_kl(d_in, d_out, n_blocks, int(trans))) > 0)
+    if tiled and rgcn_wave_form(d_in, d_out, n_blocks):
+        # four diagonal blocks: the wave-private kernel (one wave per (64-node tile, block), csrc/rgcn_wave.hip)
+        p = tg.wave_plan(bool(trans))
+        packed = rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans)
+        check(_lib.lib().gd_rgcn_wave_conv_f32(ptr(p['job_tile']), p['n_tiles'], p['tile'], ptr(p['tile_unit_ptr']), ptr(p['unit_rel']),
+                                               ptr(p['unit_edges']), ptr(p['unit_row']), ptr(x), x.stride(0), d_in, ptr(packed),
+                                               n_blocks, ptr(y), y.stride(0), d_out, tg.n, stream_ptr(x.device)),
+              'gd_rgcn_wave_conv_f32')
+        return y
     if tiled:
         p = tg.tile_plan(bool(trans))
         packed = rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans)

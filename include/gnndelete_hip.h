@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 6   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
+#define GD_ABI_VERSION 7   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
                               4: gd_spmm_csr_onepass_f32, gd_rows_gemm_wgrad_reduce_f32 (dw = NULL in the wgrad entries),
                                  gd_comm_* / gd_allreduce_f32 / gd_exchange_rows_f32, gd_segment_softmax_f32, gd_rowpair_dot_f32, gd_step_tail_f32;
                               5: gd_del_loss_bwd_wgrad_f32, multi-row items of gd_spmm_csr_onepass_f32;
@@ -296,6 +296,30 @@ int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* tile_step_pt
                           int32_t d_in, const float* packed_w, int32_t n_blocks, int32_t trans, float* y, int64_t ldy,
                           int32_t d_out, int32_t n_nodes, const int32_t* hub_node, const int32_t* hub_ptr, int32_t n_hubs,
                           float* y_ext, void* stream);
+
+/* The same conv for the reference's FOUR diagonal blocks (weight = [R, 4, ib, ob], framework/models/rgcn.py:17-22; d_in,
+ * d_out in {64, 128}; gd_rgcn_wave_covers() = 1), wave-private form (csrc/rgcn_wave.hip): output block t of a node depends on
+ * the input features [t d_in / 4, (t + 1) d_in / 4) only, so one WAVE owns (64-node tile, block t) - no block barrier, the
+ * outputs of the job in a wave-private LDS accumulator, the next unit's gathers in flight while this one is multiplied.
+ * packed_w as for gd_rgcn_tile_conv_f32 (gd_rgcn_pack_weight_f32 of the direction; the transposed direction is this entry
+ * on the transposed plan with the transposed pack, d_in / d_out those of the direction).
+ *
+ * Unit plan of a typed graph (node-major; every (node, relation) run cut into pieces of <= 4 edges; the pieces of one
+ * (tile = node / 64, relation), in (node, piece) order, 16 to a unit):
+ *     tile_unit_ptr[n_tiles + 1]   units of a tile, relations ascending; EVERY TILE HOLDS AN EVEN NUMBER OF UNITS (an odd
+ *                                  tile ends with one empty unit)          unit_rel[U]   relation of a unit
+ *     unit_row[U][16]              slot word: node % 64 | flags << 8 | last << 12 (0 for an unused slot).  The slots of one
+ *                                  node inside a unit are consecutive; flag bit b = the slot 2^b to the left exists and holds
+ *                                  the same node; last = no further slot of this node follows in the unit
+ *     unit_edges[U][16][4][2]      (source node, weight as float bits) per edge of a slot; unused pairs = (n_nodes, 0.0f)
+ *     job_tile[n_tiles]            launch order of the tiles (most units first) or NULL
+ * tile must be 64.  y must hold the root / bias term (or zeros) on entry; relations are accumulated in ascending order,
+ * the slots of a node by a fixed scan tree: bit-reproducible. */
+int32_t gd_rgcn_wave_covers(int32_t d_in, int32_t d_out, int32_t n_blocks);
+int gd_rgcn_wave_conv_f32(const int32_t* job_tile, int32_t n_tiles, int32_t tile, const int32_t* tile_unit_ptr,
+                          const int32_t* unit_rel, const int32_t* unit_edges, const int32_t* unit_row, const float* x,
+                          int64_t ldx, int32_t d_in, const float* packed_w, int32_t n_blocks, float* y, int64_t ldy,
+                          int32_t d_out, int32_t n_nodes, void* stream);
 
 /* Random walks for GraphSAINT mini-batches (torch_geometric GraphSAINTRandomWalkSampler / torch_sparse random_walk as
  * used at framework/trainer/gnndelete_nodeemb.py:379-381, :734-736): out[s * n_walks + w] = node of walker w after s

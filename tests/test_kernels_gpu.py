@@ -774,6 +774,7 @@ def test_rgcn_tile_conv_matches_oracle_and_node_major(n, m, R, din, dout, nb, mo
     from gnndelete_amd import _lib, ops
     from gnndelete_amd.graph import TypedNodeCSR
     from oracle import pyg_semantics as pyg
+    monkeypatch.setenv('GD_RGCN_WAVE', '0')                # the 4-block cases would take the wave-private kernel (next test)
     g = torch.Generator().manual_seed(n + m + R)
     ei = torch.randint(0, n, (2, m), generator=g)
     et = torch.randint(0, max(1, R - 1), (m,), generator=g)
@@ -806,6 +807,56 @@ def test_rgcn_tile_conv_matches_oracle_and_node_major(n, m, R, din, dout, nb, mo
     got2, dx2 = run()
     assert torch.equal(got, got2) and torch.equal(dx, dx2)
     monkeypatch.setenv('GD_RGCN_NODE_MAJOR', '1')
+    ref, dref = run()
+    assert rel_l2(got.cpu(), ref.cpu()) < 1e-5 and rel_l2(dx.cpu(), dref.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize('n,m,R,din,dout', [(200, 20000, 7, 128, 128), (1000, 30000, 102, 128, 64), (130, 9000, 5, 64, 64),
+                                            (300, 5000, 4, 64, 128), (64, 40, 3, 128, 128), (5000, 400000, 51, 128, 128)])
+def test_rgcn_wave_conv_matches_oracle_and_tile_kernel(n, m, R, din, dout, monkeypatch):
+    """gd_rgcn_wave_conv_f32 (one wave per (64-node tile, diagonal block), units of 16 slots x 4 edges, LDS accumulators):
+    forward and input gradient against the float64 oracle and against the tile kernel; a hub whose runs span many slots of
+    one unit and many units (the slots of one node are ADDED in the accumulator), relations that occur in no tile, a last
+    tile with fewer than 64 nodes, tiles with an odd number of units (padded), all four width pairs; bit-reproducible."""
+    from gnndelete_amd import _lib, ops
+    from gnndelete_amd.graph import TypedNodeCSR
+    from oracle import pyg_semantics as pyg
+    g = torch.Generator().manual_seed(n + m + R + din)
+    ei = torch.randint(0, n, (2, m), generator=g)
+    et = torch.randint(0, max(1, R - 1), (m,), generator=g)
+    ei[1, :m // 5] = 5                                     # a hub: one node with m / 5 in-edges ...
+    et[:m // 10] = 2 % R                                   # ... half of them of one relation
+    ei[0, m // 5:m // 4] = 9                               # and a hub source (long runs in the transposed graph)
+    nb = 4
+    x = torch.randn(n, din, generator=g, dtype=torch.float64)
+    w = torch.randn(R, nb, din // nb, dout // nb, generator=g, dtype=torch.float64) * 0.2
+    root = torch.randn(din, dout, generator=g, dtype=torch.float64) * 0.2
+    bias = torch.randn(dout, generator=g, dtype=torch.float64)
+    up = torch.randn(n, dout, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    want = pyg.rgcn_conv(xr, ei, et, w, root, bias, nb)
+    want.backward(up)
+    assert _lib.lib().gd_rgcn_wave_covers(din, dout, nb) == 1 and _lib.lib().gd_rgcn_wave_covers(din, dout, 1) == 0
+    tg = TypedNodeCSR(ei.cuda(), et.cuda(), n, R)
+    for trans in (False, True):
+        plan = tg.wave_plan(trans)
+        per_tile = (plan['tile_unit_ptr'][1:] - plan['tile_unit_ptr'][:-1])
+        assert plan['n_units'] > 0 and int((per_tile % 2).sum()) == 0 and plan['n_tiles'] == (n + 63) // 64
+        used = plan['unit_edges'][..., 0] != n
+        assert int(used.sum()) == m                                          # every typed edge sits in exactly one pair
+        assert int((plan['unit_row'] & 255).max()) < 64 and int(plan['unit_rel'].max()) < R
+
+    def run():
+        xg = x.float().cuda().requires_grad_(True)
+        got = ops.rgcn_conv_frozen(xg, tg, w.float().cuda(), root.float().cuda(), bias.float().cuda(), nb)
+        got.backward(up.float().cuda())
+        return got.detach(), xg.grad
+    got, dx = run()
+    assert rel_l2(got.cpu(), want.detach()) < TOL
+    assert rel_l2(dx.cpu(), xr.grad) < TOL
+    got2, dx2 = run()
+    assert torch.equal(got, got2) and torch.equal(dx, dx2)
+    monkeypatch.setenv('GD_RGCN_WAVE', '0')
     ref, dref = run()
     assert rel_l2(got.cpu(), ref.cpu()) < 1e-5 and rel_l2(dx.cpu(), dref.cpu()) < 1e-5
 
