@@ -180,25 +180,36 @@ def time_typed_conv(eng):
     dur = _avg_seconds(lambda: ops.rgcn_typed_accumulate(tg, eng.x, conv.weight.detach(), nb, 0, out), reps=10)
     dur_root = _avg_seconds(lambda: ops.rows_gemm(eng.x, None, conv.root.detach(), trans_w=False, bias=conv.bias.detach(), out=out), reps=10)
     tiled = os.environ.get('GD_RGCN_NODE_MAJOR') != '1'
-    plan = tg.tile_plan(False) if tiled else {}
+    wave = tiled and ops.rgcn_wave_form(d, d, nb)
+    plan = (tg.wave_plan(False) if wave else tg.tile_plan(False)) if tiled else {}
     flops = 2.0 * runs * d * d / nb
     n_pieces = plan.get('n_pieces', runs)
-    nbytes = 4.0 * n * d * 3 + 8.0 * nnz + 8.0 * n_pieces + 8.0 * plan.get('n_steps', 0) + 4.0 * conv.weight.numel()
+    if wave:      # x once, y read-modify-written, the unit plan (512 B of (source, weight) pairs + 64 B of slot words + 4 B per unit), weights
+        nbytes = 4.0 * n * d * 3 + 580.0 * plan['n_units'] + 4.0 * conv.weight.numel()
+    else:
+        nbytes = 4.0 * n * d * 3 + 8.0 * nnz + 8.0 * n_pieces + 8.0 * plan.get('n_steps', 0) + 4.0 * conv.weight.numel()
     tf = flops / dur / 1e12
-    traffic = None
-    try:            # PMC bytes per launch of the committed counter passes (same request only)
-        with open(os.path.join(ROOT, 'profiles', 'r03_rgcn_tile_traffic.json')) as f_:
+    traffic, traffic_file = None, 'profiles/r04_rgcn_wave_traffic.json' if wave else 'profiles/r03_rgcn_tile_traffic.json'
+    try:            # PMC bytes per launch of the committed counter passes (same request, same kernel form only)
+        with open(os.path.join(ROOT, traffic_file)) as f_:
             rec_ = json.load(f_)
         if (rec_['workload']['num_nodes'], rec_['workload']['typed_edges'], rec_['workload']['runs']) == (n, nnz, runs) and tiled:
             traffic = rec_['traffic_bytes_per_launch']
     except (OSError, KeyError, ValueError):
         pass
-    return {'kernel': ('rgcn_tile_kernel<128,32,32> ((64-node tile, relation) steps: typed mean aggregation into a compact LDS tile, '
-                       'block-diagonal transform on v_mfma_f32_16x16x4_f32, 128 -> 128)') if tiled else
-                      'rgcn_conv_kernel (node-major typed mean aggregation + block-diagonal transform, 128 -> 128)',
+    if wave:
+        kernel = ('rgcn_wave_kernel<32,32,64,1> (one wave per (64-node tile, diagonal block): units of 16 slots x 4 edges gathered a unit '
+                  'ahead, typed mean aggregation into a wave-private LDS tile, block-diagonal transform on v_mfma_f32_16x16x4_f32, 128 -> 128)')
+    elif tiled:
+        kernel = ('rgcn_tile_kernel<128,32,32> ((64-node tile, relation) steps: typed mean aggregation into a compact LDS tile, '
+                  'block-diagonal transform on v_mfma_f32_16x16x4_f32, 128 -> 128)')
+    else:
+        kernel = 'rgcn_conv_kernel (node-major typed mean aggregation + block-diagonal transform, 128 -> 128)'
+    plan_keys = ('n_tiles', 'n_units', 'n_pieces', 'max_units') if wave else ('n_tiles', 'n_steps', 'n_pieces', 'n_hubs', 'n_slice_rows', 'max_steps')
+    return {'kernel': kernel,
             'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TFLOPS,
             'traffic': traffic, 'traffic_gbs': traffic / dur / 1e9 if traffic else None,
-            'traffic_unit': 'bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_rgcn_tile_traffic.json): the L2-miss side; '
+            'traffic_unit': f'bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {traffic_file}): the L2-miss side; '
                             'it equals the gathered-row volume - the fabric carries every gathered row',
             'algorithmic_flops': flops, 'avg_us': dur * 1e6,
             'hbm': {'compulsory_bytes': nbytes, 'gbs': nbytes / dur / 1e9, 'frac': nbytes / dur / 1e9 / HBM_PEAK_GBS},
@@ -207,7 +218,7 @@ def time_typed_conv(eng):
             'note': (f'this launch: {tf / MFMA_F32_PEAK_TFLOPS:.2f} of the MFMA peak, {nbytes / dur / 1e9 / HBM_PEAK_GBS:.2f} of HBM on compulsory bytes'
                      + (f', fabric traffic (the gathered rows, all L2 misses) at {traffic / dur / 1e12:.2f} TB/s' if traffic else '')
                      + '; what bounds the kernel: DESIGN.md kernel table'),
-            'tile_plan': {k: plan[k] for k in ('n_tiles', 'n_steps', 'n_pieces', 'n_hubs', 'n_slice_rows', 'max_steps') if k in plan}}
+            'plan': {k: plan[k] for k in plan_keys if k in plan}}
 
 
 def kg_cpu_baseline(args, data, state, neg, ni1, ni2, iters):

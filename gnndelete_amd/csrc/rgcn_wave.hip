@@ -25,12 +25,14 @@
 //            leaves a row's total in its LAST slot, and only that lane adds it to the node row of the accumulator: a plain
 //            LDS read-modify-write without two lanes on one address.  (LDS float atomics would not need the scan - and were
 //            measured at ~180 cycles per instruction: the LDS pipe 86 % busy, 3.9 ms per launch.)
-//   pipeline the rows, the weight fragments and the row map of unit u + 1 and the edge pairs of unit u + 2 are in flight
-//            while unit u is summed and multiplied (two register sets, the loop is unrolled by two; the plan pads every
-//            tile to an even number of units).
+//   pipeline the rows of the units u + 1 .. u + DEPTH, the weight fragments and slot words of unit u + 1 and the edge pairs of
+//            unit u + DEPTH + 1 are in flight while unit u is summed and multiplied (DEPTH + 1 register sets, the loop is
+//            unrolled DEPTH + 1 times; past the tile's end the passes run on the plan's empty unit).
 //
 // The gathered volume (every source row once per edge: 4.3 GB at ogbl-biokg size, all of it fabric traffic) is what
 // bounds this form; the matrix instructions take less than half of that time.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gd {
@@ -38,15 +40,16 @@ namespace gd {
 using f32x4w = __attribute__((ext_vector_type(4))) float;
 using u32x4w = __attribute__((ext_vector_type(4))) unsigned int;
 
-template <int KL, int OW, int TILE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void rgcn_wave_kernel(
+template <int KL, int OW, int TILE, int DEPTH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEPTH == 1 ? 3 : 2))) void rgcn_wave_kernel(
     const int32_t* __restrict__ job_tile, int32_t n_tiles, const int32_t* __restrict__ tile_unit_ptr,
     const int32_t* __restrict__ unit_rel, const int4* __restrict__ unit_edges, const int32_t* __restrict__ unit_row,
     const float* __restrict__ x, int64_t ldx, const float4* __restrict__ wpk4, float* __restrict__ y, int64_t ldy,
-    int32_t n_nodes, int64_t n_x_bytes) {
+    int32_t n_nodes, int64_t n_x_bytes, int32_t empty_unit) {
   constexpr int LPR = KL / 4, GROUPS = 64 / LPR, ROUNDS = 16 / GROUPS, AP = KL + 4, NOH = OW / 16, NMM = KL / 16, CP = OW + 4;
   __shared__ __attribute__((aligned(16))) float a_tile[16 * AP];
   __shared__ __attribute__((aligned(16))) float acc[TILE * CP];      // [node row][output], pitch OW + 4
+  __shared__ __attribute__((aligned(16))) int e_lds[128];             // one unit's 64 (source, weight) pairs
   const int lane = threadIdx.x, b = blockIdx.x;
   // b = 32 q + 8 t + xcd: the four blocks of a tile run on the same XCD (workgroups go round the XCDs), next to each other
   const int ot = (b >> 3) & 3, ti = ((b >> 5) << 3) + (b & 7);
@@ -59,16 +62,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void rg
 
   const uint32_t row_bytes = (uint32_t)(ldx * 4), feat_off = (uint32_t)(4 * (ot * KL + 4 * gl));
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (uint32_t)n_x_bytes, 0x00020000);
-  auto load_edges = [&](int u, int4 (&e)[ROUNDS][2]) {
-    const int4* base = unit_edges + ((int64_t)u * 16 + g) * 2;
+  // Edge pairs of a unit: ONE 8-byte load per lane (the unit's 64 pairs in slot order: 512 contiguous bytes, 8 cycles of the
+  // texture addresser) staged through a wave-private LDS image, from which lane group g reads the four pairs of its slot
+  // of each round (two broadcast 16-byte reads).  Fetching them as 16-byte global loads cost 4 x 16 addresser cycles per
+  // unit - the addresser was 73 % busy and bounded the kernel (profiles/r04_rgcn_wave_pmc.txt).
+  auto fetch_edges = [&](int u) -> int2 { return reinterpret_cast<const int2*>(unit_edges)[(int64_t)u * 64 + lane]; };
+  auto stage_edges = [&](int2 ge, int4 (&e)[ROUNDS][2]) {
+    reinterpret_cast<int2*>(e_lds)[lane] = ge;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-      e[r][0] = base[GROUPS * r * 2];
-      e[r][1] = base[GROUPS * r * 2 + 1];
+      const int4* src = reinterpret_cast<const int4*>(e_lds) + (GROUPS * r + g) * 2;
+      e[r][0] = src[0];
+      e[r][1] = src[1];
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   };
-  // rel = the unit's relation, read a unit ahead (a scalar load: its latency must not sit in front of the weight loads)
-  auto issue = [&](int rel, const int4 (&e)[ROUNDS][2], float4 (&rows)[ROUNDS][4], float (&wt)[ROUNDS][4], float4 (&wf)[NOH][NMM]) {
+  auto issue_rows = [&](const int4 (&e)[ROUNDS][2], float4 (&rows)[ROUNDS][4], float (&wt)[ROUNDS][4]) {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       const int cc[4] = {e[r][0].x, e[r][0].z, e[r][1].x, e[r][1].z};
@@ -82,13 +95,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void rg
         rows[r][k] = __builtin_bit_cast(float4, v);
       }
     }
+  };
+  // rel = the unit's relation, read a unit ahead (a scalar load: its latency must not sit in front of the weight loads)
+  auto load_wf = [&](int rel, float4 (&wf)[NOH][NMM]) {
     const float4* wp = wpk4 + ((int64_t)(rel * 4 + ot) * (NOH * NMM)) * 64 + lane;
 #pragma unroll
     for (int oh = 0; oh < NOH; ++oh)
 #pragma unroll
       for (int mm = 0; mm < NMM; ++mm) wf[oh][mm] = wp[(oh * NMM + mm) * 64];
   };
-  auto compute = [&](const float4 (&rows)[ROUNDS][4], const float (&wt)[ROUNDS][4], const float4 (&wf)[NOH][NMM], int nrow) {
+  // rel_next: the next unit's relation - its weight fragments are fetched into wf as soon as this unit's products are issued
+  // rel_cur / rel_next: unit_rel words (relation | scan steps << 16) of this and the next unit
+  auto compute = [&](const float4 (&rows)[ROUNDS][4], const float (&wt)[ROUNDS][4], float4 (&wf)[NOH][NMM], int nrow, int rel_cur, int rel_next) {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       float4 s = make_float4(wt[r][0] * rows[r][0].x, wt[r][0] * rows[r][0].y, wt[r][0] * rows[r][0].z, wt[r][0] * rows[r][0].w);
@@ -116,20 +134,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void rg
         d[oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[oh][mm].w, bv[mm].w, d[oh], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next unit's weight fragments replace this unit's - unless it is the same relation (2.2 units per (tile, relation)
+    // on the biokg request: more than half of the reloads, 4 x 16 addresser cycles each, fall away)
+    if ((rel_next & 0xffff) != (rel_cur & 0xffff)) load_wf(rel_next & 0xffff, wf);
+    __builtin_amdgcn_sched_barrier(0);
     // nrow = node row | segment flags << 8 | last-of-its-row << 12.  Flag bit b: the slot 2^b to the left holds the same
-    // node row (same-row slots are consecutive) - Hillis-Steele steps 1, 2, 4, 8 inside the 16-lane DPP row
-    const float f1 = (float)((nrow >> 8) & 1), f2 = (float)((nrow >> 9) & 1), f4 = (float)((nrow >> 10) & 1), f8 = (float)((nrow >> 11) & 1);
-#pragma unroll
-    for (int oh = 0; oh < NOH; ++oh)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float v = d[oh][c];
-        v = fmaf(f1, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true)), v);
-        v = fmaf(f2, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true)), v);
-        v = fmaf(f4, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true)), v);
-        v = fmaf(f8, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true)), v);
-        d[oh][c] = v;
-      }
+    // node row (same-row slots are consecutive) - Hillis-Steele steps 1, 2, 4, 8 inside the 16-lane DPP row; the unit's
+    // word says which steps any of its slots needs (bit 16 + b): most units need the first one or two only
+#define GD_RW_SCAN_STEP(B, CTRL)                                                                                   \
+    if (rel_cur & (1 << (16 + B))) {                                                                                 \
+      const float f = (float)((nrow >> (8 + B)) & 1);                                                                \
+      _Pragma("unroll") for (int oh = 0; oh < NOH; ++oh)                                                             \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                \
+          d[oh][c] = fmaf(f, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d[oh][c]), CTRL, 0xF, 0xF, true)), d[oh][c]); \
+    }
+    GD_RW_SCAN_STEP(0, 0x111)
+    GD_RW_SCAN_STEP(1, 0x112)
+    GD_RW_SCAN_STEP(2, 0x114)
+    GD_RW_SCAN_STEP(3, 0x118)
+#undef GD_RW_SCAN_STEP
     if (nrow & (1 << 12)) {
       float* dst = acc + (nrow & 255) * CP + 4 * kq;
 #pragma unroll
@@ -141,36 +165,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void rg
     }
   };
 
-  int4 e_a[ROUNDS][2], e_b[ROUNDS][2];
-  float4 rows_a[ROUNDS][4], rows_b[ROUNDS][4], wf_a[NOH][NMM], wf_b[NOH][NMM];
-  float wt_a[ROUNDS][4], wt_b[ROUNDS][4];
-  const int ul = u1 - 1;
-  // Order inside a half: the row map of the next unit FIRST (the packed FMAs of the sums read register PAIRS; when the
-  // allocator pairs a weight with the target of a load in flight, the wait in front of that FMA covers everything issued up
-  // to that load - first in the half, that is only what the sums need anyway), then the edge pairs two units ahead, then
-  // the next unit's rows and weight fragments.
-  int nrow_a = unit_row[u0 * 16 + j], nrow_b;
-  int rel_n = __builtin_amdgcn_readfirstlane(unit_rel[u0]), rel_nn = __builtin_amdgcn_readfirstlane(unit_rel[min(u0 + 1, ul)]);
-  load_edges(u0, e_a);
-  load_edges(min(u0 + 1, ul), e_b);
-  issue(rel_n, e_a, rows_a, wt_a, wf_a);
-  for (int u = u0; u < u1; u += 2) {                       // the plan pads every tile to an even number of units
-    nrow_b = unit_row[(u + 1) * 16 + j];
-    rel_n = rel_nn;
-    rel_nn = __builtin_amdgcn_readfirstlane(unit_rel[min(u + 2, ul)]);
-    load_edges(min(u + 2, ul), e_a);
-    issue(rel_n, e_b, rows_b, wt_b, wf_b);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(rows_a, wt_a, wf_a, nrow_a);
-    __builtin_amdgcn_sched_barrier(0);
-    nrow_a = unit_row[min(u + 2, ul) * 16 + j];
-    rel_n = rel_nn;
-    rel_nn = __builtin_amdgcn_readfirstlane(unit_rel[min(u + 3, ul)]);
-    load_edges(min(u + 3, ul), e_b);
-    issue(rel_n, e_a, rows_a, wt_a, wf_a);                 // past the tile's end: the last unit once more, never used
-    __builtin_amdgcn_sched_barrier(0);
-    compute(rows_b, wt_b, wf_b, nrow_b);
-    __builtin_amdgcn_sched_barrier(0);
+  // DEPTH units of rows in flight per wave (DEPTH + 1 register sets, the loop unrolled DEPTH + 1 times; DEPTH odd so that
+  // the two edge sets alternate consistently).  Units past the tile's end are the plan's EMPTY unit (all pairs one row
+  // past x, slot words 0): they cost a pass of the loop body and add nothing.
+  constexpr int NS = DEPTH + 1;
+  static_assert(DEPTH % 2 == 1, "DEPTH must be odd");
+  int4 e[2][ROUNDS][2];
+  float4 rows[NS][ROUNDS][4], wf[NOH][NMM];
+  float wt[NS][ROUNDS][4];
+  int nrow[2];
+  auto uid = [&](int v) { return v < u1 ? v : empty_unit; };
+  // Order inside a pass (unit u): the slot words of unit u + 1 FIRST (the packed FMAs of the sums read register PAIRS; when
+  // the allocator pairs a weight with the target of a load in flight, the wait in front of that FMA covers everything issued
+  // up to that load - first in the pass, that is only what the sums need anyway), then the edge pairs of unit u + DEPTH + 2
+  // (global -> register), the pairs of unit u + DEPTH + 1 (fetched a pass ago) through LDS into their register set, then
+  // the rows of unit u + DEPTH; the next unit's weight fragments replace this unit's right after its products.
+  nrow[0] = unit_row[u0 * 16 + j];
+  int rel_c = __builtin_amdgcn_readfirstlane(unit_rel[u0]), rel_n = __builtin_amdgcn_readfirstlane(unit_rel[uid(u0 + 1)]);
+  load_wf(rel_c & 0xffff, wf);
+  {
+    int2 g0 = fetch_edges(u0);
+    stage_edges(g0, e[0]);
+  }
+#pragma unroll
+  for (int k = 0; k < DEPTH; ++k) {
+    int2 gk = fetch_edges(uid(u0 + k + 1));
+    issue_rows(e[k & 1], rows[k], wt[k]);
+    stage_edges(gk, e[(k + 1) & 1]);
+  }
+  int2 ge = fetch_edges(uid(u0 + DEPTH + 1));                // e[DEPTH & 1] holds unit u0 + DEPTH, ge unit u0 + DEPTH + 1
+  for (int u = u0; u < u1; u += NS) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      nrow[(i + 1) & 1] = unit_row[uid(u + i + 1) * 16 + j];
+      const int rel_nn = __builtin_amdgcn_readfirstlane(unit_rel[uid(u + i + 2)]);
+      const int2 ge_new = fetch_edges(uid(u + i + DEPTH + 2));
+      issue_rows(e[(i + 1) & 1], rows[(i + DEPTH) % NS], wt[(i + DEPTH) % NS]);
+      stage_edges(ge, e[i & 1]);                             // unit u + i + DEPTH + 1, for the next pass
+      ge = ge_new;
+      __builtin_amdgcn_sched_barrier(0);
+      compute(rows[i], wt[i], wf, nrow[i & 1], rel_c, rel_n);
+      __builtin_amdgcn_sched_barrier(0);
+      rel_c = rel_n;
+      rel_n = rel_nn;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -198,29 +236,40 @@ extern "C" int32_t gd_rgcn_wave_covers(int32_t d_in, int32_t d_out, int32_t n_bl
 }
 
 extern "C" int gd_rgcn_wave_conv_f32(const int32_t* job_tile, int32_t n_tiles, int32_t tile, const int32_t* tile_unit_ptr,
-                                     const int32_t* unit_rel, const int32_t* unit_edges, const int32_t* unit_row, const float* x,
-                                     int64_t ldx, int32_t d_in, const float* packed_w, int32_t n_blocks, float* y, int64_t ldy,
-                                     int32_t d_out, int32_t n_nodes, void* stream) {
+                                     int32_t n_units, const int32_t* unit_rel, const int32_t* unit_edges, const int32_t* unit_row,
+                                     const float* x, int64_t ldx, int32_t d_in, const float* packed_w, int32_t n_blocks, float* y,
+                                     int64_t ldy, int32_t d_out, int32_t n_nodes, void* stream) {
   using namespace gd;
   GD_REQUIRE(tile_unit_ptr && unit_rel && unit_edges && unit_row && x && packed_w && y, GD_E_NULL, "gd_rgcn_wave_conv_f32: null pointer");
   GD_REQUIRE(wave_geometry(d_in, d_out, n_blocks), GD_E_DIM,
              "gd_rgcn_wave_conv_f32: needs 4 diagonal blocks and widths in {64, 128} (d_in=%d d_out=%d blocks=%d); use gd_rgcn_tile_conv_f32",
              d_in, d_out, n_blocks);
-  GD_REQUIRE(tile == 64 && n_tiles == (n_nodes + tile - 1) / tile && ldx >= d_in && ldy >= d_out && ldx % 4 == 0 && ldy % 4 == 0, GD_E_DIM,
+  GD_REQUIRE(tile == 64 && n_tiles == (n_nodes + tile - 1) / tile && n_units >= 0 && ldx >= d_in && ldy >= d_out && ldx % 4 == 0 &&
+                 ldy % 4 == 0, GD_E_DIM,
              "gd_rgcn_wave_conv_f32: tile must be 64, n_tiles = ceil(n_nodes / tile), row pitches multiples of 4");
   GD_REQUIRE(aligned16(x) && aligned16(y) && aligned16(packed_w) && aligned16(unit_edges) && x != y, GD_E_ALIGN,
              "gd_rgcn_wave_conv_f32: unaligned or aliasing pointer");
   // 24 x 24-bit row offsets; the pad source n_nodes (one row past x) must stay below 4 GB as well
   GD_REQUIRE(n_nodes < (1 << 24) && ldx * 4 < (1 << 24) && ((int64_t)n_nodes + 1) * ldx * 4 < ((int64_t)1 << 32), GD_E_DIM,
              "gd_rgcn_wave_conv_f32: x beyond 4 GB / 2^24 rows; use gd_rgcn_conv_f32");
-  if (n_tiles == 0) return GD_OK;
+  if (n_tiles == 0 || n_units == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)((n_tiles + 7) / 8) * 32);
   const int64_t n_x_bytes = ((int64_t)(n_nodes - 1) * ldx + d_in) * 4;
-#define GD_RW_CASE(KL, OW)                                                                                                   \
-  hipLaunchKernelGGL((rgcn_wave_kernel<KL, OW, 64>), grid, dim3(64), 0, s, job_tile, n_tiles, tile_unit_ptr, unit_rel,       \
+  // units of gathered rows in flight per wave: 1 (three waves per SIMD) for 128-float sources, 3 for 64-float sources (their
+  // units carry half the bytes; measured on the biokg request: 724 vs 783 us and 468 vs 475 us); GD_RGCN_WAVE_DEPTH = 1 | 3
+  // overrides (read per call: an A/B switch, not a tuning cache)
+  const char* env_depth = getenv("GD_RGCN_WAVE_DEPTH");
+  const int depth = env_depth ? (atoi(env_depth) == 1 ? 1 : 3) : (d_in == 128 ? 1 : 3);
+#define GD_RW_LAUNCH(KL, OW, DEPTH)                                                                                          \
+  hipLaunchKernelGGL((rgcn_wave_kernel<KL, OW, 64, DEPTH>), grid, dim3(64), 0, s, job_tile, n_tiles, tile_unit_ptr, unit_rel, \
                      reinterpret_cast<const int4*>(unit_edges), unit_row, x, ldx, reinterpret_cast<const float4*>(packed_w), y, ldy, \
-                     n_nodes, n_x_bytes)
+                     n_nodes, n_x_bytes, n_units)
+#define GD_RW_CASE(KL, OW)               \
+  do {                                   \
+    if (depth == 1) GD_RW_LAUNCH(KL, OW, 1); \
+    else GD_RW_LAUNCH(KL, OW, 3);        \
+  } while (0)
   switch (d_in * 1000 + d_out) {
     case 128128: GD_RW_CASE(32, 32); break;
     case 128064: GD_RW_CASE(32, 16); break;
@@ -229,5 +278,6 @@ extern "C" int gd_rgcn_wave_conv_f32(const int32_t* job_tile, int32_t n_tiles, i
     default: return fail(GD_E_DIM, "gd_rgcn_wave_conv_f32: no kernel for d_in=%d d_out=%d", d_in, d_out);
   }
 #undef GD_RW_CASE
+#undef GD_RW_LAUNCH
   return launched("rgcn_wave_conv");
 }

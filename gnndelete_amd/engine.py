@@ -187,12 +187,12 @@ class NodeembEngine:
             if any((c.in_channels // (c.num_blocks or 1)) % 2 or (c.out_channels // (c.num_blocks or 1)) % 2
                    or c.in_channels > 128 or c.out_channels > 128 for c in (conv1, conv2)):
                 raise NotImplementedError('NodeembEngine: R-GCN widths outside the typed conv kernel (<= 128, even blocks)')
-            # No locality order here (GD_RGCN_REORDER=1 turns it on): measured on the synth-biokg request, the degree-weighted
-            # label propagation of reorder.py cuts the typed conv's fabric reads by 10 % (FETCH_SIZE 4.41 -> 3.95 GB per
-            # layer-1 launch) and its time by nothing (1228 us either way, profiles/r03_rgcn_reorder_ab.txt): the kernel is
-            # bound by its per-step dependent chain, not by traffic.
+            # Locality order (GD_RGCN_REORDER=0 turns it off): the degree-weighted label propagation of reorder.py cuts the typed
+            # conv's fabric reads by ~10 % (FETCH_SIZE 4.41 -> 3.95 GB per layer-1 launch, profiles/r03_rgcn_reorder_ab.txt).
+            # With the tile kernel that bought nothing (bound by its per-step dependent chain); the wave-private kernel runs
+            # at the fabric rate, where bytes are time: 2.01 -> 1.89 ms per step on the synth-biokg request (round 4).
             cache_layer1 = affected_rows_only = False
-            reorder = os.environ.get('GD_RGCN_REORDER') == '1'
+            reorder = os.environ.get('GD_RGCN_REORDER', '1') != '0'
             x = model.node_emb.weight.detach()[x.to(model.node_emb.weight.device)]      # frozen embedding lookup, once
         dev = x.device
         if dev.type != 'cuda':

@@ -650,21 +650,22 @@ class TypedNodeCSR:
 
     @staticmethod
     def _build_wave_plan(arrays, n, r, tile=64, cap=4, slots=16):
-        """-> tile_unit_ptr [T + 1] (every tile holds an EVEN number of units: the kernel's loop is unrolled by two; an odd
-        tile gets one empty unit), unit_rel [U], unit_row [U, 16] (slot word: node % tile | same-row flags | last; 0 for an
-        unused slot),
-        unit_edges [U, 16, 4, 2] int32 = (source, weight bits) pairs, unused pairs = (n, 0.0): one row past x, for which
-        the kernel's buffer loads return zeros without a memory access; job_tile [T] = tiles by unit count, heaviest first."""
+        """-> tile_unit_ptr [T + 1], n_units = U, unit_rel [U + 1], unit_row [U + 1, 16] (slot word: node % tile | same-row
+        flags | last; 0 for an unused slot), unit_edges [U + 1, 16, 4, 2] int32 = (source, weight bits) pairs, unused pairs =
+        (n, 0.0): one row past x, for which the kernel's buffer loads return zeros without a memory access; unit U is EMPTY
+        (what the kernel's pipeline runs on past a tile's end); unit_rel = relation | scan steps any slot of the unit needs << 16;
+        job_tile [T] = tiles by unit count, heaviest first."""
         node_ptr, seg_ptr, seg_rel, col, w = arrays
         dev = col.device
         n_tiles = (n + tile - 1) // tile
         i32 = lambda t: t.to(torch.int32).contiguous()
         e = int(col.numel())
         if e == 0:
+            empty = torch.zeros(1, slots, cap, 2, dtype=torch.int32, device=dev)
+            empty[..., 0] = n
             return dict(n_tiles=n_tiles, tile=tile, tile_unit_ptr=torch.zeros(n_tiles + 1, dtype=torch.int32, device=dev),
                         unit_rel=torch.zeros(1, dtype=torch.int32, device=dev), unit_row=torch.zeros(1, slots, dtype=torch.int32, device=dev),
-                        unit_edges=torch.zeros(1, slots, cap, 2, dtype=torch.int32, device=dev),
-                        job_tile=i32(torch.arange(n_tiles, device=dev)), n_units=0, n_pieces=0, max_units=0)
+                        unit_edges=empty, job_tile=i32(torch.arange(n_tiles, device=dev)), n_units=0, n_pieces=0, max_units=0)
         seg_len = (seg_ptr[1:] - seg_ptr[:-1]).long()
         n_runs = int(seg_len.numel())
         run_of_edge = torch.repeat_interleave(torch.arange(n_runs, device=dev), seg_len)
@@ -686,14 +687,14 @@ class TypedNodeCSR:
         g_units = (g_np + slots - 1) // slots
         g_tile = groups // r
         units_per_tile = torch.zeros(n_tiles, dtype=torch.int64, device=dev).scatter_add_(0, g_tile, g_units)
-        padded = units_per_tile + (units_per_tile & 1)
+        padded = units_per_tile                                                 # (no per-tile padding: the kernel runs on the empty unit)
         tile_unit_ptr = torch.zeros(n_tiles + 1, dtype=torch.int64, device=dev)
         tile_unit_ptr[1:] = torch.cumsum(padded, 0)
         n_units = int(tile_unit_ptr[-1])
         g_excl = torch.cumsum(g_units, 0) - g_units                             # units before the group, unpadded
         tile_excl = torch.cumsum(units_per_tile, 0) - units_per_tile
         g_unit0 = tile_unit_ptr[:-1][g_tile] + (g_excl - tile_excl[g_tile])     # first unit of the group
-        unit_rel = torch.zeros(max(n_units, 1), dtype=torch.int64, device=dev)
+        unit_rel = torch.zeros(n_units + 1, dtype=torch.int64, device=dev)
         unit_of_g = torch.repeat_interleave(torch.arange(groups.numel(), device=dev), g_units)
         u_idx = g_unit0[unit_of_g] + (torch.arange(unit_of_g.numel(), device=dev) - g_excl[unit_of_g])
         unit_rel[u_idx] = groups[unit_of_g] % r
@@ -715,10 +716,16 @@ class TypedNodeCSR:
         last = torch.ones_like(word, dtype=torch.bool)
         last[:-1] = (run_sorted[1:] != run_sorted[:-1]) | (unit_sorted[1:] != unit_sorted[:-1])
         word = word | (last.long() << 12)
-        unit_row = torch.zeros(max(n_units, 1) * slots, dtype=torch.int64, device=dev)
+        unit_row = torch.zeros((n_units + 1) * slots, dtype=torch.int64, device=dev)
         unit_row[unit_sorted * slots + slot_sorted] = word
+        # which scan steps any slot of a unit needs: bits 16 .. 19 of the unit's relation word
+        step_bits = torch.zeros(n_units + 1, dtype=torch.int64, device=dev)
+        for b in range(4):
+            has = torch.zeros(n_units + 1, dtype=torch.int64, device=dev).scatter_reduce_(0, unit_sorted, (word >> (8 + b)) & 1, 'amax', include_self=True)
+            step_bits |= has << b
+        unit_rel = unit_rel | (step_bits << 16)
         p_unit, p_slot = unit_sorted[rank], slot_sorted[rank]                   # back in piece order
-        unit_edges = torch.zeros(max(n_units, 1) * slots * cap, 2, dtype=torch.int32, device=dev)
+        unit_edges = torch.zeros((n_units + 1) * slots * cap, 2, dtype=torch.int32, device=dev)
         unit_edges[:, 0] = n
         at = (p_unit[piece_of_edge] * slots + p_slot[piece_of_edge]) * cap + pos % cap
         unit_edges[at, 0] = col.to(torch.int32)

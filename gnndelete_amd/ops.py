@@ -642,7 +642,7 @@ def rgcn_typed_accumulate(tg, x, weight, n_blocks, trans, y, edge_w=None):
         # four diagonal blocks: the wave-private kernel (one wave per (64-node tile, block), csrc/rgcn_wave.hip)
         p = tg.wave_plan(bool(trans))
         packed = rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans)
-        check(_lib.lib().gd_rgcn_wave_conv_f32(ptr(p['job_tile']), p['n_tiles'], p['tile'], ptr(p['tile_unit_ptr']), ptr(p['unit_rel']),
+        check(_lib.lib().gd_rgcn_wave_conv_f32(ptr(p['job_tile']), p['n_tiles'], p['tile'], ptr(p['tile_unit_ptr']), p['n_units'], ptr(p['unit_rel']),
                                                ptr(p['unit_edges']), ptr(p['unit_row']), ptr(x), x.stride(0), d_in, ptr(packed),
                                                n_blocks, ptr(y), y.stride(0), d_out, tg.n, stream_ptr(x.device)),
               'gd_rgcn_wave_conv_f32')

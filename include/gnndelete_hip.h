@@ -306,20 +306,22 @@ int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* tile_step_pt
  *
  * Unit plan of a typed graph (node-major; every (node, relation) run cut into pieces of <= 4 edges; the pieces of one
  * (tile = node / 64, relation), in (node, piece) order, 16 to a unit):
- *     tile_unit_ptr[n_tiles + 1]   units of a tile, relations ascending; EVERY TILE HOLDS AN EVEN NUMBER OF UNITS (an odd
- *                                  tile ends with one empty unit)          unit_rel[U]   relation of a unit
- *     unit_row[U][16]              slot word: node % 64 | flags << 8 | last << 12 (0 for an unused slot).  The slots of one
+ *     tile_unit_ptr[n_tiles + 1]   units of a tile, relations ascending;  unit_rel[U + 1]   relation of a unit | s << 16, s = the
+ *                                  OR of the slot flags of the unit (which steps of the same-node scan it needs)
+ *     n_units = U; EVERY UNIT ARRAY HOLDS ONE MORE, EMPTY UNIT AT INDEX U (relation 0, slot words 0, all pairs unused):
+ *                                  what the kernel's software pipeline runs on past the end of a tile
+ *     unit_row[U + 1][16]          slot word: node % 64 | flags << 8 | last << 12 (0 for an unused slot).  The slots of one
  *                                  node inside a unit are consecutive; flag bit b = the slot 2^b to the left exists and holds
  *                                  the same node; last = no further slot of this node follows in the unit
- *     unit_edges[U][16][4][2]      (source node, weight as float bits) per edge of a slot; unused pairs = (n_nodes, 0.0f)
+ *     unit_edges[U + 1][16][4][2]  (source node, weight as float bits) per edge of a slot; unused pairs = (n_nodes, 0.0f)
  *     job_tile[n_tiles]            launch order of the tiles (most units first) or NULL
  * tile must be 64.  y must hold the root / bias term (or zeros) on entry; relations are accumulated in ascending order,
  * the slots of a node by a fixed scan tree: bit-reproducible. */
 int32_t gd_rgcn_wave_covers(int32_t d_in, int32_t d_out, int32_t n_blocks);
 int gd_rgcn_wave_conv_f32(const int32_t* job_tile, int32_t n_tiles, int32_t tile, const int32_t* tile_unit_ptr,
-                          const int32_t* unit_rel, const int32_t* unit_edges, const int32_t* unit_row, const float* x,
-                          int64_t ldx, int32_t d_in, const float* packed_w, int32_t n_blocks, float* y, int64_t ldy,
-                          int32_t d_out, int32_t n_nodes, void* stream);
+                          int32_t n_units, const int32_t* unit_rel, const int32_t* unit_edges, const int32_t* unit_row,
+                          const float* x, int64_t ldx, int32_t d_in, const float* packed_w, int32_t n_blocks, float* y,
+                          int64_t ldy, int32_t d_out, int32_t n_nodes, void* stream);
 
 /* Random walks for GraphSAINT mini-batches (torch_geometric GraphSAINTRandomWalkSampler / torch_sparse random_walk as
  * used at framework/trainer/gnndelete_nodeemb.py:379-381, :734-736): out[s * n_walks + w] = node of walker w after s

@@ -817,7 +817,8 @@ def test_rgcn_wave_conv_matches_oracle_and_tile_kernel(n, m, R, din, dout, monke
     """gd_rgcn_wave_conv_f32 (one wave per (64-node tile, diagonal block), units of 16 slots x 4 edges, LDS accumulators):
     forward and input gradient against the float64 oracle and against the tile kernel; a hub whose runs span many slots of
     one unit and many units (the slots of one node are ADDED in the accumulator), relations that occur in no tile, a last
-    tile with fewer than 64 nodes, tiles with an odd number of units (padded), all four width pairs; bit-reproducible."""
+    tile with fewer than 64 nodes, tiles whose unit count is no multiple of the kernel's unroll (it runs on the plan's empty
+    unit past their end), all four width pairs, both pipeline depths; bit-reproducible."""
     from gnndelete_amd import _lib, ops
     from gnndelete_amd.graph import TypedNodeCSR
     from oracle import pyg_semantics as pyg
@@ -840,11 +841,12 @@ def test_rgcn_wave_conv_matches_oracle_and_tile_kernel(n, m, R, din, dout, monke
     tg = TypedNodeCSR(ei.cuda(), et.cuda(), n, R)
     for trans in (False, True):
         plan = tg.wave_plan(trans)
-        per_tile = (plan['tile_unit_ptr'][1:] - plan['tile_unit_ptr'][:-1])
-        assert plan['n_units'] > 0 and int((per_tile % 2).sum()) == 0 and plan['n_tiles'] == (n + 63) // 64
+        assert plan['n_units'] == int(plan['tile_unit_ptr'][-1]) > 0 and plan['n_tiles'] == (n + 63) // 64
+        assert plan['unit_row'].shape[0] == plan['unit_edges'].shape[0] == plan['unit_rel'].numel() == plan['n_units'] + 1
+        assert int(plan['unit_row'][-1].abs().sum()) == 0 and bool((plan['unit_edges'][-1, :, :, 0] == n).all())   # the empty unit
         used = plan['unit_edges'][..., 0] != n
         assert int(used.sum()) == m                                          # every typed edge sits in exactly one pair
-        assert int((plan['unit_row'] & 255).max()) < 64 and int(plan['unit_rel'].max()) < R
+        assert int((plan['unit_row'] & 255).max()) < 64 and int((plan['unit_rel'] & 0xffff).max()) < R
 
     def run():
         xg = x.float().cuda().requires_grad_(True)
@@ -856,6 +858,9 @@ def test_rgcn_wave_conv_matches_oracle_and_tile_kernel(n, m, R, din, dout, monke
     assert rel_l2(dx.cpu(), xr.grad) < TOL
     got2, dx2 = run()
     assert torch.equal(got, got2) and torch.equal(dx, dx2)
+    monkeypatch.setenv('GD_RGCN_WAVE_DEPTH', '1')          # one unit of rows in flight instead of three: the same sums
+    got1, dx1 = run()
+    assert torch.equal(got, got1) and torch.equal(dx, dx1)
     monkeypatch.setenv('GD_RGCN_WAVE', '0')
     ref, dref = run()
     assert rel_l2(got.cpu(), ref.cpu()) < 1e-5 and rel_l2(dx.cpu(), dref.cpu()) < 1e-5
@@ -1328,13 +1333,17 @@ def test_segment_softmax_and_typed_weighted_sum_match_autograd(n, m, R, d):
     assert rel_l2(eg.grad.cpu(), e64.grad) < 2e-5
 
 
+@pytest.mark.parametrize('form', ['wave', 'tile'])
 @pytest.mark.parametrize('n,m,R,world', [(4000, 60000, 25, 2), (1000, 30000, 51, 3), (300, 2000, 25, 2)])
-def test_typed_conv_on_a_row_partition_matches_the_whole_graph(n, m, R, world):
+def test_typed_conv_on_a_row_partition_matches_the_whole_graph(n, m, R, world, form, monkeypatch):
     """TypedNodeCSR(row_range=...): a rank's share of the typed graph - in-edges of its target rows forward, out-edges of
-    its source rows (with the GLOBAL mean weights) for the input gradient - through the (tile, relation) conv kernel
-    gives, on the rank's rows, exactly what the whole graph gives (same summation order per row)."""
+    its source rows (with the GLOBAL mean weights) for the input gradient - gives, on the rank's rows, what the whole
+    graph gives: exactly through the (tile, relation) kernel (same summation order per row); through the wave-private
+    kernel to fp32 rounding (a run of several slots is summed by a scan tree that depends on where the slots fall in their
+    unit, and a tile cut by the partition holds other slots in front of them)."""
     from gnndelete_amd import ops
     from gnndelete_amd.graph import TypedNodeCSR
+    monkeypatch.setenv('GD_RGCN_WAVE', '1' if form == 'wave' else '0')
     g = torch.Generator().manual_seed(n + R)
     src, dst = torch.randint(0, n, (m,), generator=g), torch.randint(0, n, (m,), generator=g)
     et = torch.randint(0, R, (m,), generator=g)
@@ -1358,5 +1367,8 @@ def test_typed_conv_on_a_row_partition_matches_the_whole_graph(n, m, R, world):
         dxr = torch.zeros(n, 128, device='cuda')
         ops.rgcn_typed_accumulate(part, dy, w2, nb, 1, dxr)
         torch.cuda.synchronize()
-        assert torch.equal(yr[lo:hi], y[lo:hi]) and torch.equal(dxr[lo:hi], dx[lo:hi]), rank
+        if form == 'tile':
+            assert torch.equal(yr[lo:hi], y[lo:hi]) and torch.equal(dxr[lo:hi], dx[lo:hi]), rank
+        else:
+            assert rel_l2(yr[lo:hi].cpu(), y[lo:hi].cpu()) < 1e-6 and rel_l2(dxr[lo:hi].cpu(), dx[lo:hi].cpu()) < 1e-6, rank
         assert float(yr[:lo].abs().sum()) == 0 and float(yr[hi:].abs().sum()) == 0

@@ -54,16 +54,32 @@ def main():
         w = conv.weight.detach()
         nb = conv.num_blocks or 1
         res = {}
-        for form in ('1', '0'):
-            os.environ['GD_RGCN_WAVE'] = form
+        for form, depth in (('1', '3'), ('1', '1'), ('0', '3')):
+            os.environ['GD_RGCN_WAVE'], os.environ['GD_RGCN_WAVE_DEPTH'] = form, depth
             y = torch.zeros(n, dout, device=dev)
             ops.rgcn_typed_accumulate(tg, x, w, nb, tr, y)
-            res[form] = (y.clone(), avg_us(lambda: ops.rgcn_typed_accumulate(tg, x, w, nb, tr, y)))
-        d = float((res['1'][0] - res['0'][0]).norm() / res['0'][0].norm())
+            res[form + depth] = (y.clone(), avg_us(lambda: ops.rgcn_typed_accumulate(tg, x, w, nb, tr, y)))
+        d = float((res['13'][0] - res['03'][0]).norm() / res['03'][0].norm())
         runs = int(tg.fwd[1].numel()) - 1
         fl = 2.0 * runs * din * dout / nb
-        print(f"{name}: wave {res['1'][1]:.1f} us ({fl / res['1'][1] / 1e6:.1f} TF), tile {res['0'][1]:.1f} us ({fl / res['0'][1] / 1e6:.1f} TF), rel-L2 apart {d:.2e}")
+        print(f"{name}: wave depth 3 {res['13'][1]:.1f} us ({fl / res['13'][1] / 1e6:.1f} TF), depth 1 {res['11'][1]:.1f} us, "
+              f"tile {res['03'][1]:.1f} us ({fl / res['03'][1] / 1e6:.1f} TF), rel-L2 apart {d:.2e}")
     os.environ.pop('GD_RGCN_WAVE', None)
+    os.environ.pop('GD_RGCN_WAVE_DEPTH', None)
+    # knock-out: every source row from a 1,024-row window (L2-resident) - what the kernel costs without the fabric
+    p = tg.wave_plan(False)
+    keep = p['unit_edges'].clone()
+    used = keep[..., 0] != n
+    p['unit_edges'][..., 0] = torch.where(used, keep[..., 0] % 1024, keep[..., 0])
+    x = torch.randn(n, 128, generator=g).to(dev)
+    y = torch.zeros(n, 128, device=dev)
+    w = model.conv1.weight.detach()
+    for depth in ('3', '1'):
+        os.environ['GD_RGCN_WAVE_DEPTH'] = depth
+        t = avg_us(lambda: ops.rgcn_typed_accumulate(tg, x, w, 4, 0, y))
+        print(f'layer 1 forward, sources folded into 1,024 rows (cache-resident), depth {depth}: {t:.1f} us')
+    p['unit_edges'].copy_(keep)
+    os.environ.pop('GD_RGCN_WAVE_DEPTH', None)
 
 
 if __name__ == '__main__':
