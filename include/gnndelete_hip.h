@@ -36,7 +36,8 @@ extern "C" {
                               4: gd_spmm_csr_onepass_f32, gd_rows_gemm_wgrad_reduce_f32 (dw = NULL in the wgrad entries),
                                  gd_comm_* / gd_allreduce_f32 / gd_exchange_rows_f32, gd_segment_softmax_f32, gd_rowpair_dot_f32, gd_step_tail_f32;
                               5: gd_del_loss_bwd_wgrad_f32, multi-row items of gd_spmm_csr_onepass_f32;
-                              6: gd_rows_gemm_ws_covers (weight-stationary form of the row GEMMs), gd_spmm_csr_rowgroup_f32 */
+                              6: gd_rows_gemm_ws_covers (weight-stationary form of the row GEMMs), gd_spmm_csr_rowgroup_f32;
+                             7: gd_rgcn_wave_conv_f32 / gd_rgcn_wave_covers */
 
 enum {
   GD_OK = 0,
