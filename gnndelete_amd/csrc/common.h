@@ -21,7 +21,8 @@ int rows_wgrad_loss_ws_try(const float* a, int64_t ld_a, const int32_t* a_idx, c
 // weight-stationary row GEMM (rows_gemm_ws.hip): GD_OK / error when it took the call, 1 when the shape / mode is not covered
 int rows_gemm_ws_try(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t d_in, int32_t d_out,
                      int32_t trans_w, const float* bias, int32_t relu_in, const uint32_t* gate_bits, uint32_t* sign_out, float* out,
-                     int64_t ld_out, float* save_in, void* stream, const float* in_alt, const uint8_t* sel, bool has_dots);
+                     int64_t ld_out, float* save_in, void* stream, const float* in_alt, const uint8_t* sel, const float* u1,
+                     const float* u2, float* o1, float* o2);
 
 inline int fail(int code, const char* fmt, ...) {
   va_list ap;

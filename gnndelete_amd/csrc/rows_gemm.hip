@@ -871,7 +871,7 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
   if (n_sel == 0) return GD_OK;
   {   // the Del operator's widths at step size: weight-stationary register form (rows_gemm_ws.hip)
     const int rc = rows_gemm_ws_try(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, bias, relu_in, gate_bits, sign_out, out, ld_out,
-                                    save_in, stream, in_alt, sel, dots.u1 != nullptr);
+                                    save_in, stream, in_alt, sel, dots.u1, dots.u2, dots.o1, dots.o2);
     if (rc != 1) return rc;
   }
   hipStream_t s = (hipStream_t)stream;

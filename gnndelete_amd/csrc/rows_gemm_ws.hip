@@ -39,14 +39,19 @@ __device__ __forceinline__ uint32_t or_row_lanes(uint32_t v) {
   return b[0] | b[1];
 }
 
-// MODE 0: plain, 1: also emit the packed [out > 0] pattern of each row, 2: gate the output by such a pattern
+// MODE 0: plain, 1: also emit the packed [out > 0] pattern of each row, 2: gate the output by such a pattern,
+//      3: plain + the two row dot products o1[row] = <out[row], u1>, o2[row] = <out[row], u2> (GATConv's attention logits,
+//         gd_rows_gemm_dots_f32), 4: gated like 2 after the rank-1 correction out[row, n] += o1[row] u1[n] + o2[row] u2[n]
+//         (gd_rows_gemm_gated_rank1_f32: o1 / o2 are per-row scalars READ by row id)
 // SEL: row r comes from in_alt where sel[r] != 0 (dense only)
 template <int DIN, int DOUT, int MODE, bool HASIDX, bool SEL, bool RELU>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rows_gemm_ws_kernel(
     const float* __restrict__ in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel, const float* __restrict__ w,
     int32_t trans_w, float* __restrict__ out, int64_t ld_out, const uint32_t* __restrict__ gate_bits,
-    uint32_t* __restrict__ sign_out, const float* __restrict__ in_alt, const uint8_t* __restrict__ sel) {
+    uint32_t* __restrict__ sign_out, const float* __restrict__ in_alt, const uint8_t* __restrict__ sel,
+    const float* __restrict__ u1, const float* __restrict__ u2, float* o1, float* o2) {
   constexpr int KQ = DIN / 4, NT = DOUT / 16, XV = KQ / 4, NW = DOUT / 32;
+  constexpr bool GATE = MODE == 2 || MODE == 4, DOTS = MODE == 3, RANK1 = MODE == 4;
   static_assert(!(HASIDX && SEL), "the selector form is dense");
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -125,14 +130,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int t = 0; t < NT; ++t) acc_a[t] = acc_b[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
   float* dst_prev = out + (HASIDX ? (int64_t)d_cur : (int64_t)slot_of(u_lo)) * ld_out + 4 * kq;
   int sa_prev = slot_of(u_lo);
+  int row_prev = HASIDX ? d_cur : slot_of(u_lo);            // row id of the unit whose results are stored next (MODE 3 / 4)
   uint32_t sg[NW], gsh[NW];
 #pragma unroll
   for (int q = 0; q < NW; ++q) sg[q] = gsh[q] = 0;
+  // MODE 3 / 4: u1 / u2 at this lane's output columns 16 t + 4 kq + c; MODE 3: the partial dots of the unit being stored;
+  // MODE 4: the row scalars of the unit being stored
+  float4 uv1[(DOTS || RANK1) ? NT : 1], uv2[(DOTS || RANK1) ? NT : 1];
+  float dp1 = 0.f, dp2 = 0.f, ra_prev = 0.f, rb_prev = 0.f;
+  if (DOTS || RANK1) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      uv1[t] = *reinterpret_cast<const float4*>(u1 + 16 * t + 4 * kq);
+      uv2[t] = *reinterpret_cast<const float4*>(u2 + 16 * t + 4 * kq);
+    }
+  }
+  if (RANK1) {
+    ra_prev = o1[row_prev];
+    rb_prev = o2[row_prev];
+  }
 
   auto store_tile = [&](const f32x4v& a, int t) {
     float4 v = make_float4(a[0], a[1], a[2], a[3]);
+    if (RANK1) {
+      v.x = fmaf(ra_prev, uv1[t].x, fmaf(rb_prev, uv2[t].x, v.x)); v.y = fmaf(ra_prev, uv1[t].y, fmaf(rb_prev, uv2[t].y, v.y));
+      v.z = fmaf(ra_prev, uv1[t].z, fmaf(rb_prev, uv2[t].z, v.z)); v.w = fmaf(ra_prev, uv1[t].w, fmaf(rb_prev, uv2[t].w, v.w));
+    }
     // bit b of word q of a row's packed pattern is output 32 q + b: this lane owns bits 16 (t & 1) + 4 kq + c of word t >> 1
-    if (MODE == 2) {
+    if (GATE) {
       const uint32_t m = gsh[t >> 1] >> (16 * (t & 1) + 4 * kq);
       v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f;
       v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
@@ -141,7 +166,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const uint32_t b = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
       sg[t >> 1] |= b << (16 * (t & 1) + 4 * kq);
     }
+    if (DOTS) {
+      dp1 = fmaf(v.x, uv1[t].x, fmaf(v.y, uv1[t].y, fmaf(v.z, uv1[t].z, fmaf(v.w, uv1[t].w, dp1))));
+      dp2 = fmaf(v.x, uv2[t].x, fmaf(v.y, uv2[t].y, fmaf(v.z, uv2[t].z, fmaf(v.w, uv2[t].w, dp2))));
+    }
     *reinterpret_cast<float4*>(dst_prev + 16 * t) = v;
+  };
+  // MODE 3: the four lanes of a row add their partial dots (VALU permlane swaps); every lane stores - lane kq the value
+  // kq & 1 - so that no store sits under a branch (kq 2 / 3 rewrite what kq 0 / 1 wrote)
+  auto store_dots = [&]() {
+    const float s1 = xor32_sum(xor16_sum(dp1)), s2 = xor32_sum(xor16_sum(dp2));
+    float* dst = (kq & 1) ? o2 : o1;
+    dst[row_prev] = (kq & 1) ? s2 : s1;
+    dp1 = dp2 = 0.f;
   };
   auto store_signs = [&]() {          // the four lanes of a row merge their bits; lane kq writes word kq (mod NW)
     uint32_t mine = 0;
@@ -158,10 +195,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int32_t d_nn = desc_of(u + 2);                     // used a unit from now
     const float4* nsrc = src_of(u + 1, d_nxt);
     uint32_t gcur[NW];
-    if (MODE == 2) {
+    if (GATE) {
       const uint32_t* gp = gate_bits + (int64_t)slot_of(u) * NW;
 #pragma unroll
       for (int q = 0; q < NW; ++q) gcur[q] = gp[q];
+    }
+    const int row_cur = HASIDX ? d_cur : slot_of(u);
+    float ra_cur = 0.f, rb_cur = 0.f;
+    if (RANK1) {
+      ra_cur = o1[row_cur];
+      rb_cur = o2[row_cur];
     }
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
@@ -183,6 +226,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int t = 0; t < NT; ++t)
             if (t * XV / NT == i) store_tile(old[t], t);
           if (MODE == 1 && i == XV - 1) store_signs();
+          if (DOTS && i == XV - 1) store_dots();
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -190,10 +234,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       x[i] = nsrc[i];                                        // the registers just consumed: same chunk of the next unit
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (MODE == 2) {
+    if (GATE) {
 #pragma unroll
       for (int q = 0; q < NW; ++q) gsh[q] = gcur[q];
     }
+    if (RANK1) {
+      ra_prev = ra_cur;
+      rb_prev = rb_cur;
+    }
+    row_prev = row_cur;
     dst_prev = out + (HASIDX ? (int64_t)d_cur : (int64_t)slot_of(u)) * ld_out + 4 * kq;
     sa_prev = slot_of(u);
     d_cur = d_nxt;
@@ -212,6 +261,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int t = 0; t < NT; ++t) store_tile(acc_a[t], t);
   if (MODE == 1) store_signs();
+  if (DOTS) store_dots();
 }
 
 int ws_cu_count() {
@@ -224,25 +274,42 @@ int ws_cu_count() {
   return n;
 }
 
+struct WsEpi { const float* u1; const float* u2; float* o1; float* o2; };     // MODE 3 / 4 operands (RowDots of rows_gemm.hip)
+
 template <int DIN, int DOUT, int MODE, bool HASIDX, bool SEL, bool RELU>
 static int ws_launch(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t trans_w, float* out,
                      int64_t ld_out, const uint32_t* gate_bits, uint32_t* sign_out, const float* in_alt, const uint8_t* sel,
-                     hipStream_t s) {
+                     WsEpi epi, hipStream_t s) {
   auto kern = rows_gemm_ws_kernel<DIN, DOUT, MODE, HASIDX, SEL, RELU>;
   constexpr size_t lds = (size_t)(DIN * DOUT + 64) * sizeof(float);
   static const hipError_t once = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   GD_REQUIRE(once == hipSuccess, -(int)once, "gd_rows_gemm_f32: cannot raise the LDS limit of the weight-stationary kernel");
   hipLaunchKernelGGL(kern, dim3(ws_cu_count()), dim3(256), lds, s, in, ld_in, idx, n_sel, w, trans_w, out, ld_out, gate_bits,
-                     sign_out, in_alt, sel);
+                     sign_out, in_alt, sel, epi.u1, epi.u2, epi.o1, epi.o2);
   return launched("rows_gemm_ws");
 }
 
 template <int DIN, int DOUT>
 static int ws_dispatch(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t trans_w,
                        int32_t relu_in, float* out, int64_t ld_out, const uint32_t* gate_bits, uint32_t* sign_out,
-                       const float* in_alt, const uint8_t* sel, hipStream_t s) {
+                       const float* in_alt, const uint8_t* sel, WsEpi epi, hipStream_t s) {
 #define GD_WS(MODE, HASIDX, SELV, RELU) \
-  return ws_launch<DIN, DOUT, MODE, HASIDX, SELV, RELU>(in, ld_in, idx, n_sel, w, trans_w, out, ld_out, gate_bits, sign_out, in_alt, sel, s)
+  return ws_launch<DIN, DOUT, MODE, HASIDX, SELV, RELU>(in, ld_in, idx, n_sel, w, trans_w, out, ld_out, gate_bits, sign_out, in_alt, sel, epi, s)
+  if (epi.u1) {
+    // the epilogue forms exist where the GAT step uses them: row dots behind a 128-wide input, the rank-1 + gate form in front
+    // of a 128-wide output (everything else: the LDS-operand kernel)
+    if (gate_bits) {
+      if constexpr (DOUT == 128) { if (idx) GD_WS(4, true, false, false); else GD_WS(4, false, false, false); }
+      return 1;
+    }
+    if constexpr (DIN == 128) {
+      if (sel) { if (relu_in) GD_WS(3, false, true, true); else GD_WS(3, false, true, false); }
+      if (idx) { if (relu_in) GD_WS(3, true, false, true); else GD_WS(3, true, false, false); }
+      if (relu_in) GD_WS(3, false, false, true);
+      GD_WS(3, false, false, false);
+    }
+    return 1;
+  }
   if (gate_bits) { if (idx) GD_WS(2, true, false, false); else GD_WS(2, false, false, false); }
   if (sign_out) { if (idx) GD_WS(1, true, false, false); else GD_WS(1, false, false, false); }
   if (sel) { if (relu_in) GD_WS(0, false, true, true); else GD_WS(0, false, true, false); }
@@ -256,24 +323,32 @@ static bool ws_on() {
   static const bool on = [] { const char* e = getenv("GD_ROWS_GEMM_WS"); return !(e && atoi(e) == 0); }();
   return on;
 }
+static bool epi_on() {        // GD_ROWS_GEMM_WS_EPI=0: the row-dots / rank-1 calls stay on the LDS-operand kernel (A/B switch)
+  static const bool on = [] { const char* e = getenv("GD_ROWS_GEMM_WS_EPI"); return !(e && atoi(e) == 0); }();
+  return on;
+}
 static int ws_min_rows() {
   static const int v = [] { const char* e = getenv("GD_ROWS_GEMM_WS_MIN_ROWS"); return e && atoi(e) > 0 ? atoi(e) : 65536; }();
   return v;
 }
 
 // -> GD_OK / error when the weight-stationary kernel took the call, 1 when it does not cover it (the caller goes on with
-// the LDS-operand form).  Covered: widths in {64, 128}, no bias, no saved input, no row dots, out not aliasing an input,
-// enough rows that every wave gets units; ReLU on the input only in the plain mode; the selector form only dense.
+// the LDS-operand form).  Covered: widths in {64, 128}, no bias, no saved input, out not aliasing an input, enough rows that
+// every wave gets units; ReLU on the input only in the plain / dots modes; the selector form only dense; row dots (u1 .. o2,
+// no gate) behind a 128-wide input, the rank-1 + gate form (u1 .. o2 with gate_bits) in front of a 128-wide output.
 int rows_gemm_ws_try(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t d_in, int32_t d_out,
                      int32_t trans_w, const float* bias, int32_t relu_in, const uint32_t* gate_bits, uint32_t* sign_out, float* out,
-                     int64_t ld_out, float* save_in, void* stream, const float* in_alt, const uint8_t* sel, bool has_dots) {
-  if (!ws_on() || matrix_split() != 0 || bias || save_in || has_dots || n_sel < ws_min_rows()) return 1;
+                     int64_t ld_out, float* save_in, void* stream, const float* in_alt, const uint8_t* sel, const float* u1,
+                     const float* u2, float* o1, float* o2) {
+  if (!ws_on() || matrix_split() != 0 || bias || save_in || n_sel < ws_min_rows()) return 1;
   if (!((d_in == 64 || d_in == 128) && (d_out == 64 || d_out == 128))) return 1;
   if (in == out || in_alt == out || (sel && idx) || (relu_in && (gate_bits || sign_out)) || (sel && (gate_bits || sign_out))) return 1;
   if (!aligned16(in) || !aligned16(out) || !aligned16(w) || (in_alt && !aligned16(in_alt)) || ld_in % 4 || ld_out % 4) return 1;
+  if (u1 && (!u2 || !o1 || !o2 || sign_out || !aligned16(u1) || !aligned16(u2) || !epi_on())) return 1;
   hipStream_t s = (hipStream_t)stream;
+  const WsEpi epi{u1, u2, o1, o2};
 #define GD_WS_SHAPE(DI, DO) \
-  return ws_dispatch<DI, DO>(in, ld_in, idx, n_sel, w, trans_w, relu_in, out, ld_out, gate_bits, sign_out, in_alt, sel, s)
+  return ws_dispatch<DI, DO>(in, ld_in, idx, n_sel, w, trans_w, relu_in, out, ld_out, gate_bits, sign_out, in_alt, sel, epi, s)
   if (d_in == 128 && d_out == 128) GD_WS_SHAPE(128, 128);
   if (d_in == 128 && d_out == 64) GD_WS_SHAPE(128, 64);
   if (d_in == 64 && d_out == 128) GD_WS_SHAPE(64, 128);

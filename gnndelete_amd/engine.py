@@ -471,7 +471,7 @@ class NodeembEngine:
             if self._rows_only and self._split1 and self._mfma_weight(wsrc):
                 h1 = ops.rows_gemm(self.x, self.idx2, wsrc, trans_w=True, const_w=True, out=self._t1buf)       # rows outside stay 0
                 a_src, a_dst = ops.row_dots(h1, c.att_src, c.att_dst)
-            elif self._gat_dots and ops.rows_gemm_dots_ok(wsrc.shape[1], wsrc.shape[0]):
+            elif self._gat_dots and ops.rows_gemm_dots_ok(wsrc.shape[1], wsrc.shape[0], self.n):
                 h1, a_src, a_dst = ops.rows_gemm_dots(self.x, wsrc, c.att_src, c.att_dst, const_w=True)   # logits from the epilogue
             else:
                 h1 = self._linear(self.x, wsrc)
@@ -534,7 +534,7 @@ class NodeembEngine:
             self._spmm(False, self.graph.val, t2[:, :self.o], self.p2, c.lin_l.bias, 1.0, x_self=t2[:, self.o:])
         else:   # gat
             wsrc = c.lin_src.weight
-            if self._gat_dots and self._split1 and ops.rows_gemm_dots_ok(wsrc.shape[1], wsrc.shape[0]):
+            if self._gat_dots and self._split1 and ops.rows_gemm_dots_ok(wsrc.shape[1], wsrc.shape[0], self.n, selected=self._rows_only):
                 ro = self._rows_only
                 h2, self._a_src, self._a_dst = ops.rows_gemm_dots(
                     self.pre1, wsrc, c.att_src, c.att_dst, inp_alt=self.z1, sel=self._sel1, relu_in=True, const_w=True,

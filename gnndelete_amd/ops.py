@@ -234,9 +234,15 @@ def rows_gemm_select(inp, inp_alt, sel, w, trans_w=False, bias=None, relu_in=Fal
     return out
 
 
-def rows_gemm_dots_ok(d_in, d_out):
-    """Whether fusing the row dots into the GEMM epilogue pays (the engine's choice; the entry itself takes 128 too)."""
-    # d_out <= 64: the 128-wide variant runs out of registers (spills: measured 7 % slower than the separate pass)
+def rows_gemm_dots_ok(d_in, d_out, n_rows=0, selected=False):
+    """Whether fusing the row dots into the GEMM epilogue pays (the engine's choice; the entry itself takes 128 too).
+    n_rows / selected (rows from two buffers AND an index list): what decides whether the weight-stationary kernel takes the
+    call - it carries the dots at 128 outputs as well (csrc/rows_gemm_ws.hip, MODE 3)."""
+    if (d_in == 128 and d_out in (64, 128) and not selected and os.environ.get('GD_ROWS_GEMM_WS_EPI', '1') != '0'
+            and _lib.lib().gd_rows_gemm_ws_covers(int(n_rows), d_in, d_out)):
+        return True
+    # d_out <= 64: the 128-wide variant of the LDS-operand kernel runs out of registers (spills: measured 7 % slower than
+    # the separate pass)
     return d_in % 32 == 0 and d_out % 32 == 0 and d_out <= 64 and d_in * d_out * 4 <= 64 * 1024
 
 

@@ -208,6 +208,30 @@ def test_rows_gemm_weight_stationary_form(d_in, d_out):
     assert bool((out5[~maskg] == 3.0).all())
     # bit-reproducible
     assert torch.equal(ops.rows_gemm(x, idx, w, out=torch.full((n, d_out), 7.0, device='cuda')), out)
+    # row dots from the epilogue (GAT's attention logits; behind a 128-wide input): dense, rows from two buffers + ReLU, index list
+    u1, u2 = torch.randn(d_out, generator=g).cuda(), torch.randn(d_out, generator=g).cuda()
+    wt = w.t().contiguous()
+    if d_in == 128:
+        assert ops.rows_gemm_dots_ok(d_in, d_out, n)
+        o, a1, a2 = ops.rows_gemm_dots(x, wt, u1, u2)
+        assert rel_l2(o, want) < TOL and rel_l2(a1, want @ u1.double()) < TOL and rel_l2(a2, want @ u2.double()) < TOL
+        o_, a1_, a2_ = ops.rows_gemm_dots(x, wt, u1, u2)
+        assert torch.equal(o, o_) and torch.equal(a1, a1_) and torch.equal(a2, a2_)
+        o, a1, a2 = ops.rows_gemm_dots(x, wt, u1, u2, inp_alt=x2, sel=sel.to(torch.uint8), relu_in=True)
+        w3 = torch.where(sel[:, None], x2.double(), xd).clamp(min=0) @ wd
+        assert rel_l2(o, w3) < TOL and rel_l2(a1, w3 @ u1.double()) < TOL and rel_l2(a2, w3 @ u2.double()) < TOL
+        dots_out = (torch.full((n,), 5.0, device='cuda'), torch.full((n,), 6.0, device='cuda'))
+        o, a1, a2 = ops.rows_gemm_dots(x, wt, u1, u2, out=torch.full((n, d_out), 7.0, device='cuda'), idx=idx, dots_out=dots_out)
+        assert rel_l2(o[maskg], want[maskg]) < TOL and bool((o[~maskg] == 7.0).all())
+        assert rel_l2(a1[maskg], want[maskg] @ u1.double()) < TOL and rel_l2(a2[maskg], want[maskg] @ u2.double()) < TOL
+        assert bool((a1[~maskg] == 5.0).all()) and bool((a2[~maskg] == 6.0).all())
+    # the gated product after a rank-1 correction (GAT's input gradient; in front of a 128-wide output)
+    if d_out == 128:
+        ra, rb = torch.randn(n, generator=g).cuda(), torch.randn(n, generator=g).cuda()
+        o7 = ops.rows_gemm(x, idx, w, out=torch.full((n, d_out), 3.0, device='cuda'), gate_bits=bits, rank1=(ra, u1, rb, u2))
+        w7 = (want + ra.double()[:, None] * u1.double() + rb.double()[:, None] * u2.double())[maskg] * (out4[maskg] > 0)
+        assert rel_l2(o7[maskg], w7) < TOL and bool((o7[~maskg] == 3.0).all())
+        assert torch.equal(ops.rows_gemm(x, idx, w, out=torch.full((n, d_out), 3.0, device='cuda'), gate_bits=bits, rank1=(ra, u1, rb, u2)), o7)
     # not covered by this form: bias, and (square widths) the in-place call
     b = torch.randn(d_out, generator=g).cuda()
     out6 = ops.rows_gemm(x, None, w, bias=b)
