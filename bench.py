@@ -778,11 +778,15 @@ def main():
         # north_star: the 1-D partitioned step is what the scaling curve measures - tried first; kept as the headline only
         # where the planner predicts it to beat the single-GPU step (partition_estimate), else independent replicas
         args.parallel = 'partition'
-    mode, note, probe_ok, overlap_ok, overlap_note = ('single' if world == 1 else args.parallel), None, 1, 0, 'not probed'
+    mode, note, probe_ok, overlap_ok, overlap_note = (('single' if world == 1 else args.parallel), None, 1, 0,
+                                                      'the default; GD_DIST_OVERLAP=1 asks for the overlapped program, which then has to pass a self-test')
     force_probe = os.environ.get('GD_BENCH_FORCE_PROBE') == '1'          # lets the gloo test exercise the probe
     if world > 1 and mode == 'partition' and (backend == 'nccl' or force_probe) and not args.probe_partition:
         probe_ok, note = probe_partition_in_child(args, rank)      # before any GPU / RCCL initialisation here
-        if probe_ok and os.environ.get('GD_DIST_OVERLAP') != '0' and args.gnn != 'rgcn':      # (R-GCN: synchronous exchanges)
+        # The exchanges run under compute only on request (GD_DIST_OVERLAP=1) AND when a child-process self-test reproduces the
+        # synchronous program's results bit for bit.  Not by default: in round 4 one run in about a dozen of that self-test
+        # (two ranks over gloo on one GPU) reported a difference whose cause was not found - a timed line must not depend on it.
+        if probe_ok and os.environ.get('GD_DIST_OVERLAP') == '1' and args.gnn != 'rgcn':      # (R-GCN: synchronous exchanges)
             overlap_ok, overlap_note = probe_partition_in_child(args, rank, overlap=True)
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     if backend != 'nccl' and torch.cuda.device_count() < world:
