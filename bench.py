@@ -784,8 +784,8 @@ def main():
     if world > 1 and mode == 'partition' and (backend == 'nccl' or force_probe) and not args.probe_partition:
         probe_ok, note = probe_partition_in_child(args, rank)      # before any GPU / RCCL initialisation here
         # The exchanges run under compute only on request (GD_DIST_OVERLAP=1) AND when a child-process self-test reproduces the
-        # synchronous program's results bit for bit.  Not by default: in round 4 one run in about a dozen of that self-test
-        # (two ranks over gloo on one GPU) reported a difference whose cause was not found - a timed line must not depend on it.
+        # synchronous program's results bit for bit.  Not by default: in round 4 that self-test (two ranks over gloo on one GPU)
+        # reported a difference in 2 of 88 runs whose cause was not found - a timed line must not depend on it.
         if probe_ok and os.environ.get('GD_DIST_OVERLAP') == '1' and args.gnn != 'rgcn':      # (R-GCN: synchronous exchanges)
             overlap_ok, overlap_note = probe_partition_in_child(args, rank, overlap=True)
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
@@ -861,10 +861,11 @@ def main():
             for _ in range(4):
                 eng2.step()
             barrier()
-            same = (torch.equal(ref[0], model.deletion1.deletion_weight.detach()) and
-                    torch.equal(ref[1], model.deletion2.deletion_weight.detach()) and
-                    torch.equal(ref[2].nan_to_num(), eng2.loss_history().nan_to_num()))
-            assert same, 'overlapped exchanges changed the result'
+            got = (model.deletion1.deletion_weight.detach(), model.deletion2.deletion_weight.detach(), eng2.loss_history())
+            same = all(torch.equal(a.nan_to_num(), b.nan_to_num()) for a, b in zip(ref, got))
+            worst = max(float((a.nan_to_num().double() - b.nan_to_num().double()).norm() / a.nan_to_num().double().norm().clamp(min=1e-30))
+                        for a, b in zip(ref, got))
+            assert same, f'overlapped exchanges changed the result (largest rel-L2 difference {worst:.2e} over W_D1, W_D2, loss history)'
         dist.destroy_process_group()
         return
     auto_est = None

@@ -267,7 +267,7 @@ def gpu_checks(rank, world, rccl=False, direct=False):
 
 def same_or_rounding(tag, pairs):
     """The overlapped program runs the same kernels on the same operands in another order: identical results - asserted bit for
-    bit.  One run in about a dozen of bench.py's self-test (round 4) reported a difference that never reproduced here; should
+    bit.  Two of 88 runs of bench.py's self-test (round 4) reported a difference that never showed up here; should
     it show up, a difference at rounding level (< 1e-6 rel-L2; a stale halo row would be ~1e-3) is reported, not failed."""
     if all(torch.equal(a.nan_to_num(), b.nan_to_num()) for a, b in pairs):
         return
