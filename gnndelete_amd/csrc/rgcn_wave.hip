@@ -40,19 +40,22 @@ namespace gd {
 using f32x4w = __attribute__((ext_vector_type(4))) float;
 using u32x4w = __attribute__((ext_vector_type(4))) unsigned int;
 
-template <int KL, int OW, int TILE, int DEPTH>
+template <int KL, int OW, int TILE, int DEPTH, int BPW>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEPTH == 1 ? 3 : 2))) void rgcn_wave_kernel(
     const int32_t* __restrict__ job_tile, int32_t n_tiles, const int32_t* __restrict__ tile_unit_ptr,
     const int32_t* __restrict__ unit_rel, const int4* __restrict__ unit_edges, const int32_t* __restrict__ unit_row,
     const float* __restrict__ x, int64_t ldx, const float4* __restrict__ wpk4, float* __restrict__ y, int64_t ldy,
     int32_t n_nodes, int64_t n_x_bytes, int32_t empty_unit) {
-  constexpr int LPR = KL / 4, GROUPS = 64 / LPR, ROUNDS = 16 / GROUPS, AP = KL + 4, NOH = OW / 16, NMM = KL / 16, CP = OW + 4;
+  // BPW diagonal blocks per wave (a job is (tile, BPW consecutive blocks); 2 exists for 16-wide blocks as an opt-in, see the launch)
+  constexpr int KW = BPW * KL;                             // gathered floats per source row
+  constexpr int LPR = KW / 4, GROUPS = 64 / LPR, ROUNDS = 16 / GROUPS, AP = KW + 4, NOH = OW / 16, NMM = KL / 16, CP = BPW * OW + 4;
+  constexpr int JPT = 4 / BPW;                             // jobs per tile
   __shared__ __attribute__((aligned(16))) float a_tile[16 * AP];
   __shared__ __attribute__((aligned(16))) float acc[TILE * CP];      // [node row][output], pitch OW + 4
   __shared__ __attribute__((aligned(16))) int e_lds[128];             // one unit's 64 (source, weight) pairs
   const int lane = threadIdx.x, b = blockIdx.x;
-  // b = 32 q + 8 t + xcd: the four blocks of a tile run on the same XCD (workgroups go round the XCDs), next to each other
-  const int ot = (b >> 3) & 3, ti = ((b >> 5) << 3) + (b & 7);
+  // b = 8 JPT q + 8 t + xcd: the jobs of a tile run on the same XCD (workgroups go round the XCDs), next to each other
+  const int ot = BPW * ((b >> 3) % JPT), ti = ((b / (8 * JPT)) << 3) + (b & 7);     // ot = the job's first diagonal block
   if (ti >= n_tiles) return;
   const int tile = __builtin_amdgcn_readfirstlane(job_tile ? job_tile[ti] : ti);
   const int u0 = __builtin_amdgcn_readfirstlane(tile_unit_ptr[tile]), u1 = __builtin_amdgcn_readfirstlane(tile_unit_ptr[tile + 1]);
@@ -97,16 +100,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEPTH == 1 ?
     }
   };
   // rel = the unit's relation, read a unit ahead (a scalar load: its latency must not sit in front of the weight loads)
-  auto load_wf = [&](int rel, float4 (&wf)[NOH][NMM]) {
-    const float4* wp = wpk4 + ((int64_t)(rel * 4 + ot) * (NOH * NMM)) * 64 + lane;
+  auto load_wf = [&](int rel, float4 (&wf)[BPW][NOH][NMM]) {
 #pragma unroll
-    for (int oh = 0; oh < NOH; ++oh)
+    for (int bw = 0; bw < BPW; ++bw) {
+      const float4* wp = wpk4 + ((int64_t)(rel * 4 + ot + bw) * (NOH * NMM)) * 64 + lane;
 #pragma unroll
-      for (int mm = 0; mm < NMM; ++mm) wf[oh][mm] = wp[(oh * NMM + mm) * 64];
+      for (int oh = 0; oh < NOH; ++oh)
+#pragma unroll
+        for (int mm = 0; mm < NMM; ++mm) wf[bw][oh][mm] = wp[(oh * NMM + mm) * 64];
+    }
   };
-  // rel_next: the next unit's relation - its weight fragments are fetched into wf as soon as this unit's products are issued
   // rel_cur / rel_next: unit_rel words (relation | scan steps << 16) of this and the next unit
-  auto compute = [&](const float4 (&rows)[ROUNDS][4], const float (&wt)[ROUNDS][4], float4 (&wf)[NOH][NMM], int nrow, int rel_cur, int rel_next) {
+  auto compute = [&](const float4 (&rows)[ROUNDS][4], const float (&wt)[ROUNDS][4], float4 (&wf)[BPW][NOH][NMM], int nrow, int rel_cur, int rel_next) {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       float4 s = make_float4(wt[r][0] * rows[r][0].x, wt[r][0] * rows[r][0].y, wt[r][0] * rows[r][0].z, wt[r][0] * rows[r][0].w);
@@ -117,22 +122,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEPTH == 1 ?
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // lane (j, kq) feeds k = 16 mm + 4 kq + c of slot j and ends with the outputs 16 oh + 4 kq + c of that slot
-    float4 bv[NMM];
+    // lane (j, kq) feeds k = 16 mm + 4 kq + c of block bw of slot j and ends with the outputs 16 oh + 4 kq + c of that block
+    float4 bv[BPW][NMM];
 #pragma unroll
-    for (int mm = 0; mm < NMM; ++mm) bv[mm] = *reinterpret_cast<const float4*>(a_tile + j * AP + 16 * mm + 4 * kq);
-    f32x4w d[NOH];
+    for (int bw = 0; bw < BPW; ++bw)
 #pragma unroll
-    for (int oh = 0; oh < NOH; ++oh) d[oh] = f32x4w{0.f, 0.f, 0.f, 0.f};
+      for (int mm = 0; mm < NMM; ++mm) bv[bw][mm] = *reinterpret_cast<const float4*>(a_tile + j * AP + bw * KL + 16 * mm + 4 * kq);
+    f32x4w d[BPW][NOH];
+#pragma unroll
+    for (int bw = 0; bw < BPW; ++bw)
+#pragma unroll
+      for (int oh = 0; oh < NOH; ++oh) d[bw][oh] = f32x4w{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mm = 0; mm < NMM; ++mm) {
 #pragma unroll
-      for (int oh = 0; oh < NOH; ++oh) {
-        d[oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[oh][mm].x, bv[mm].x, d[oh], 0, 0, 0);
-        d[oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[oh][mm].y, bv[mm].y, d[oh], 0, 0, 0);
-        d[oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[oh][mm].z, bv[mm].z, d[oh], 0, 0, 0);
-        d[oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[oh][mm].w, bv[mm].w, d[oh], 0, 0, 0);
-      }
+      for (int bw = 0; bw < BPW; ++bw)
+#pragma unroll
+        for (int oh = 0; oh < NOH; ++oh) {
+          d[bw][oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[bw][oh][mm].x, bv[bw][mm].x, d[bw][oh], 0, 0, 0);
+          d[bw][oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[bw][oh][mm].y, bv[bw][mm].y, d[bw][oh], 0, 0, 0);
+          d[bw][oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[bw][oh][mm].z, bv[bw][mm].z, d[bw][oh], 0, 0, 0);
+          d[bw][oh] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[bw][oh][mm].w, bv[bw][mm].w, d[bw][oh], 0, 0, 0);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     // the next unit's weight fragments replace this unit's - unless it is the same relation (2.2 units per (tile, relation)
@@ -145,9 +156,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEPTH == 1 ?
 #define GD_RW_SCAN_STEP(B, CTRL)                                                                                   \
     if (rel_cur & (1 << (16 + B))) {                                                                                 \
       const float f = (float)((nrow >> (8 + B)) & 1);                                                                \
-      _Pragma("unroll") for (int oh = 0; oh < NOH; ++oh)                                                             \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                \
-          d[oh][c] = fmaf(f, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d[oh][c]), CTRL, 0xF, 0xF, true)), d[oh][c]); \
+      _Pragma("unroll") for (int bw = 0; bw < BPW; ++bw)                                                             \
+        _Pragma("unroll") for (int oh = 0; oh < NOH; ++oh)                                                           \
+          _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                              \
+            d[bw][oh][c] = fmaf(f, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d[bw][oh][c]), CTRL, 0xF, 0xF, true)), d[bw][oh][c]); \
     }
     GD_RW_SCAN_STEP(0, 0x111)
     GD_RW_SCAN_STEP(1, 0x112)
@@ -157,11 +169,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEPTH == 1 ?
     if (nrow & (1 << 12)) {
       float* dst = acc + (nrow & 255) * CP + 4 * kq;
 #pragma unroll
-      for (int oh = 0; oh < NOH; ++oh) {
-        float4 v = *reinterpret_cast<float4*>(dst + 16 * oh);
-        v.x += d[oh][0]; v.y += d[oh][1]; v.z += d[oh][2]; v.w += d[oh][3];
-        *reinterpret_cast<float4*>(dst + 16 * oh) = v;
-      }
+      for (int bw = 0; bw < BPW; ++bw)
+#pragma unroll
+        for (int oh = 0; oh < NOH; ++oh) {
+          float4 v = *reinterpret_cast<float4*>(dst + bw * OW + 16 * oh);
+          v.x += d[bw][oh][0]; v.y += d[bw][oh][1]; v.z += d[bw][oh][2]; v.w += d[bw][oh][3];
+          *reinterpret_cast<float4*>(dst + bw * OW + 16 * oh) = v;
+        }
     }
   };
 
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEPTH == 1 ?
   constexpr int NS = DEPTH + 1;
   static_assert(DEPTH % 2 == 1, "DEPTH must be odd");
   int4 e[2][ROUNDS][2];
-  float4 rows[NS][ROUNDS][4], wf[NOH][NMM];
+  float4 rows[NS][ROUNDS][4], wf[BPW][NOH][NMM];
   float wt[NS][ROUNDS][4];
   int nrow[2];
   auto uid = [&](int v) { return v < u1 ? v : empty_unit; };
@@ -213,8 +227,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEPTH == 1 ?
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // the tile's rows of this block's outputs: y += accumulators (OW / 4 lanes per row)
-  constexpr int C4 = OW / 4;
+  // the tile's rows of this job's outputs: y += accumulators (BPW OW / 4 lanes per row)
+  constexpr int C4 = BPW * OW / 4;
   for (int i = lane; i < TILE * C4; i += 64) {
     const int r = i / C4, c4 = i % C4, node = tile * TILE + r;
     if (node < n_nodes) {
@@ -254,21 +268,31 @@ extern "C" int gd_rgcn_wave_conv_f32(const int32_t* job_tile, int32_t n_tiles, i
              "gd_rgcn_wave_conv_f32: x beyond 4 GB / 2^24 rows; use gd_rgcn_conv_f32");
   if (n_tiles == 0 || n_units == 0) return GD_OK;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((unsigned)((n_tiles + 7) / 8) * 32);
+  const unsigned tile_groups = (unsigned)((n_tiles + 7) / 8);
   const int64_t n_x_bytes = ((int64_t)(n_nodes - 1) * ldx + d_in) * 4;
   // units of gathered rows in flight per wave: 1 (three waves per SIMD) for 128-float sources, 3 for 64-float sources (their
   // units carry half the bytes; measured on the biokg request: 724 vs 783 us and 468 vs 475 us); GD_RGCN_WAVE_DEPTH = 1 | 3
   // overrides (read per call: an A/B switch, not a tuning cache)
   const char* env_depth = getenv("GD_RGCN_WAVE_DEPTH");
   const int depth = env_depth ? (atoi(env_depth) == 1 ? 1 : 3) : (d_in == 128 ? 1 : 3);
-#define GD_RW_LAUNCH(KL, OW, DEPTH)                                                                                          \
-  hipLaunchKernelGGL((rgcn_wave_kernel<KL, OW, 64, DEPTH>), grid, dim3(64), 0, s, job_tile, n_tiles, tile_unit_ptr, unit_rel, \
-                     reinterpret_cast<const int4*>(unit_edges), unit_row, x, ldx, reinterpret_cast<const float4*>(packed_w), y, ldy, \
-                     n_nodes, n_x_bytes, n_units)
-#define GD_RW_CASE(KL, OW)               \
-  do {                                   \
-    if (depth == 1) GD_RW_LAUNCH(KL, OW, 1); \
-    else GD_RW_LAUNCH(KL, OW, 3);        \
+  // 16-wide blocks (64-float sources): GD_RGCN_WAVE_BPW=2 gives a wave TWO blocks, so that it gathers whole 128-byte lines
+  // instead of halves - measured slower on the biokg request (485 vs 423 us: 20 KB of LDS per wave leave 7 waves per CU;
+  // the sibling's half line hits the L2 anyway: FETCH_SIZE is at the gathered volume), so one block per wave stays the default
+  const char* env_bpw = getenv("GD_RGCN_WAVE_BPW");
+  const int bpw16 = env_bpw && atoi(env_bpw) == 2 ? 2 : 1;
+#define GD_RW_LAUNCH(KL, OW, DEPTH, BPW)                                                                                     \
+  hipLaunchKernelGGL((rgcn_wave_kernel<KL, OW, 64, DEPTH, BPW>), dim3(tile_groups * 8 * (4 / BPW)), dim3(64), 0, s, job_tile, n_tiles, \
+                     tile_unit_ptr, unit_rel, reinterpret_cast<const int4*>(unit_edges), unit_row, x, ldx,                 \
+                     reinterpret_cast<const float4*>(packed_w), y, ldy, n_nodes, n_x_bytes, n_units)
+#define GD_RW_CASE(KL, OW)                                  \
+  do {                                                      \
+    if (KL == 16 && bpw16 == 2) {                           \
+      if (depth == 1) GD_RW_LAUNCH(KL, OW, 1, (KL == 16 ? 2 : 1)); \
+      else GD_RW_LAUNCH(KL, OW, 3, (KL == 16 ? 2 : 1));     \
+    } else {                                                \
+      if (depth == 1) GD_RW_LAUNCH(KL, OW, 1, 1);           \
+      else GD_RW_LAUNCH(KL, OW, 3, 1);                      \
+    }                                                       \
   } while (0)
   switch (d_in * 1000 + d_out) {
     case 128128: GD_RW_CASE(32, 32); break;

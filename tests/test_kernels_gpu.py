@@ -885,6 +885,12 @@ def test_rgcn_wave_conv_matches_oracle_and_tile_kernel(n, m, R, din, dout, monke
     monkeypatch.setenv('GD_RGCN_WAVE_DEPTH', '1')          # one unit of rows in flight instead of three: the same sums
     got1, dx1 = run()
     assert torch.equal(got, got1) and torch.equal(dx, dx1)
+    monkeypatch.setenv('GD_RGCN_WAVE_BPW', '2')            # 16-wide blocks two per wave (opt-in form): the same sums
+    got1, dx1 = run()
+    assert torch.equal(got, got1) and torch.equal(dx, dx1)
+    monkeypatch.delenv('GD_RGCN_WAVE_DEPTH')
+    got1, dx1 = run()
+    assert torch.equal(got, got1) and torch.equal(dx, dx1)
     monkeypatch.setenv('GD_RGCN_WAVE', '0')
     ref, dref = run()
     assert rel_l2(got.cpu(), ref.cpu()) < 1e-5 and rel_l2(dx.cpu(), dref.cpu()) < 1e-5

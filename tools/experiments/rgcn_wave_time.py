@@ -59,6 +59,12 @@ def main():
             y = torch.zeros(n, dout, device=dev)
             ops.rgcn_typed_accumulate(tg, x, w, nb, tr, y)
             res[form + depth] = (y.clone(), avg_us(lambda: ops.rgcn_typed_accumulate(tg, x, w, nb, tr, y)))
+        if din == 64:                # 16-wide blocks: two blocks per wave (opt-in; the default is one)
+            os.environ['GD_RGCN_WAVE'], os.environ['GD_RGCN_WAVE_BPW'] = '1', '2'
+            for depth in ('3', '1'):
+                os.environ['GD_RGCN_WAVE_DEPTH'] = depth
+                print(f'   {name}: two blocks per wave, depth {depth}: {avg_us(lambda: ops.rgcn_typed_accumulate(tg, x, w, nb, tr, y)):.1f} us')
+            os.environ.pop('GD_RGCN_WAVE_BPW')
         d = float((res['13'][0] - res['03'][0]).norm() / res['03'][0].norm())
         runs = int(tg.fwd[1].numel()) - 1
         fl = 2.0 * runs * din * dout / nb
