@@ -657,6 +657,7 @@ class TypedNodeCSR:
         job_tile [T] = tiles by unit count, heaviest first."""
         node_ptr, seg_ptr, seg_rel, col, w = arrays
         dev = col.device
+        assert r < 65536, 'the unit plan keeps relation | scan steps << 16 in one word'
         n_tiles = (n + tile - 1) // tile
         i32 = lambda t: t.to(torch.int32).contiguous()
         e = int(col.numel())

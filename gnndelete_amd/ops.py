@@ -644,7 +644,7 @@ def rgcn_typed_accumulate(tg, x, weight, n_blocks, trans, y, edge_w=None):
         return y
     tiled = (edge_w is None and x.stride(0) % 4 == 0 and y.stride(0) % 4 == 0 and os.environ.get('GD_RGCN_NODE_MAJOR') != '1'
              and int(_lib.lib().gd_rgcn_tile_kl(d_in, d_out, n_blocks, int(trans))) > 0)
-    if tiled and rgcn_wave_form(d_in, d_out, n_blocks):
+    if tiled and rgcn_wave_form(d_in, d_out, n_blocks) and tg.num_relations < 65536:      # (relation | scan steps << 16 per unit)
         # four diagonal blocks: the wave-private kernel (one wave per (64-node tile, block), csrc/rgcn_wave.hip)
         p = tg.wave_plan(bool(trans))
         packed = rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans)

@@ -208,3 +208,54 @@ def test_ogbl_biokg_reader_reproduces_reference_process_kg(tmp_path):
     saved = Data.load(str(tmp_path / 'ogbl-biokg' / 'd_42.pt'))
     assert torch.equal(saved.train_pos_edge_index, t(fx['out::train_pos_edge_index']))
     assert torch.equal(torch.load(tmp_path / 'ogbl-biokg' / 'df_42.pt')['in'], t(fx['out::in_mask']))
+
+
+def test_rgcn_wave_plan_reproduces_the_typed_mean_aggregation():
+    """TypedNodeCSR.wave_plan (pure torch, runs on the CPU): walking the unit plan the way gd_rgcn_wave_conv_f32 does - 16 slots x 4
+    (source, weight) pairs per unit, unused pairs pointing one row past x, the segmented scan over the slots with the plan's
+    same-node flags, only a node's LAST slot added to its accumulator row - gives the per-(node, relation) weighted sums of
+    the node-major arrays; every typed edge sits in exactly one pair; the unit arrays end with the empty unit; the scan-step
+    mask of a unit is the OR of its slots' flags.  A hub node (runs of many slots, across units) and an empty graph included."""
+    import torch
+    from gnndelete_amd.graph import TypedNodeCSR
+    g = torch.Generator().manual_seed(0)
+    n, m, R = 300, 20000, 7
+    ei = torch.randint(0, n, (2, m), generator=g)
+    et = torch.randint(0, R, (m,), generator=g)
+    ei[1, :m // 5] = 5
+    et[:m // 10] = 2
+    tg = TypedNodeCSR(ei, et, n, R)
+    for trans in (False, True):
+        p = tg.wave_plan(trans)
+        node_ptr, seg_ptr, seg_rel, col, w = tg.bwd if trans else tg.fwd
+        assert p['n_units'] == int(p['tile_unit_ptr'][-1]) and p['unit_rel'].numel() == p['n_units'] + 1
+        assert int((p['unit_edges'][..., 0] != n).sum()) == m
+        assert int(p['unit_row'][-1].abs().sum()) == 0 and bool((p['unit_edges'][-1, :, :, 0] == n).all())
+        x = torch.randn(n + 1, 8, dtype=torch.float64, generator=g)
+        x[n] = 0
+        runs = (seg_ptr[1:] - seg_ptr[:-1]).long()
+        run_of_edge = torch.repeat_interleave(torch.arange(runs.numel()), runs)
+        node_of_run = torch.repeat_interleave(torch.arange(n), (node_ptr[1:] - node_ptr[:-1]).long())
+        want = torch.zeros(n, R, 8, dtype=torch.float64)
+        want.index_put_((node_of_run[run_of_edge], seg_rel.long()[run_of_edge]), w.double()[:, None] * x[col.long()], accumulate=True)
+        got = torch.zeros(n, R, 8, dtype=torch.float64)
+        tup, T = p['tile_unit_ptr'], p['tile']
+        for t in range(p['n_tiles']):
+            for u in range(int(tup[t]), int(tup[t + 1])):
+                word_u, ed, wd = int(p['unit_rel'][u]), p['unit_edges'][u], p['unit_row'][u].long()
+                v = (x[ed[:, :, 0].long()] * ed[:, :, 1].contiguous().view(torch.float32).double()[..., None]).sum(1)
+                steps = 0
+                for b in range(4):
+                    sh = 1 << b
+                    sv = torch.zeros_like(v)
+                    sv[sh:] = v[:-sh]
+                    flag = (wd >> (8 + b)) & 1
+                    steps |= int(flag.max()) << b
+                    v = v + flag.double()[:, None] * sv
+                assert word_u >> 16 == steps
+                for q in range(16):
+                    if (int(wd[q]) >> 12) & 1:
+                        got[t * T + (int(wd[q]) & 255), word_u & 0xffff] += v[q]
+        assert float((got - want).abs().max()) < 1e-12
+    empty = TypedNodeCSR(torch.zeros(2, 0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 100, 3).wave_plan(False)
+    assert empty['n_units'] == 0 and bool((empty['unit_edges'][..., 0] == 100).all())
