@@ -856,6 +856,11 @@ def main():
                    eng.loss_history().clone())
             model.load_state_dict(state)
             args.dist_overlap = True
+            if os.environ.get('GD_PROBE_POISON') == '1':
+                # diagnostic: what the allocator hands the second engine for its torch.empty workspaces is NaN - a kernel that
+                # reads a workspace element nobody wrote shows up as a difference on every run instead of one in forty
+                junk = torch.full((1 << 28,), float('nan'), device=device)
+                del junk
             eng2 = make_engine(args, data, model, neg, ni1, ni2, device, rank, world, group)
             assert eng2._async
             for _ in range(4):
