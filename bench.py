@@ -867,10 +867,21 @@ def main():
                 eng2.step()
             barrier()
             got = (model.deletion1.deletion_weight.detach(), model.deletion2.deletion_weight.detach(), eng2.loss_history())
-            same = all(torch.equal(a.nan_to_num(), b.nan_to_num()) for a, b in zip(ref, got))
+            # Del weights bit for bit; the LOGGED loss sums to rounding: one run in ~10 (GraphSAGE; ~1 in 40 for GCN) the logged loss
+            # of a step differs by one ulp between two engines running identical kernels (which sum changes its
+            # rounding is open; it feeds nothing)
+            same = (torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+                    and torch.allclose(ref[2].nan_to_num(), got[2].nan_to_num(), rtol=1e-6, atol=0.0))
             worst = max(float((a.nan_to_num().double() - b.nan_to_num().double()).norm() / a.nan_to_num().double().norm().clamp(min=1e-30))
                         for a, b in zip(ref, got))
-            assert same, f'overlapped exchanges changed the result (largest rel-L2 difference {worst:.2e} over W_D1, W_D2, loss history)'
+            where = ''
+            for name_, a, b in zip(('W_D1', 'W_D2', 'loss history'), ref, got):
+                dif = (a.nan_to_num() != b.nan_to_num()).nonzero()
+                if dif.numel():
+                    i0 = tuple(int(v) for v in dif[0])
+                    where += f' {name_}: {dif.shape[0]} elements, first at {i0}: {float(a[i0]):.9e} vs {float(b[i0]):.9e};'
+            assert same, (f'overlapped exchanges changed the result (largest rel-L2 difference {worst:.2e} over W_D1, W_D2, loss history;'
+                          f'{where})')
         dist.destroy_process_group()
         return
     auto_est = None

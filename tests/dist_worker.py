@@ -266,14 +266,15 @@ def gpu_checks(rank, world, rccl=False, direct=False):
 
 
 def same_or_rounding(tag, pairs):
-    """The overlapped program runs the same kernels on the same operands in another order: identical results - asserted bit for
-    bit.  Two of 88 runs of bench.py's self-test (round 4) reported a difference that never showed up here; should
-    it show up, a difference at rounding level (< 1e-6 rel-L2; a stale halo row would be ~1e-3) is reported, not failed."""
-    if all(torch.equal(a.nan_to_num(), b.nan_to_num()) for a, b in pairs):
-        return
-    worst = max(float((a.nan_to_num().double() - b.nan_to_num().double()).norm() / a.nan_to_num().double().norm().clamp(min=1e-30)) for a, b in pairs)
-    print(f'WARNING {tag}: overlapped and synchronous programs differ by {worst:.2e} rel-L2', flush=True)
-    assert worst < 1e-6, (tag, worst)
+    """The overlapped program runs the same kernels on the same operands in another order: identical Del weights, bit for bit
+    (the first two pairs).  The LOGGED loss sums (last pair) to rounding: in round 4 bench.py's self-test saw the logged loss of
+    one step differ by one ulp in ~1 of 10 GraphSAGE runs (1 of 40 for GCN) between two engines running identical kernels, Del
+    weights identical - which sum changes its rounding is open; the log feeds nothing."""
+    *weights, (ha, hb) = pairs
+    assert all(torch.equal(a, b) for a, b in weights), tag
+    if not torch.equal(ha.nan_to_num(), hb.nan_to_num()):
+        print(f'NOTE {tag}: the loss logs of the overlapped and the synchronous program differ in the last bits', flush=True)
+    assert torch.allclose(ha.nan_to_num(), hb.nan_to_num(), rtol=1e-6, atol=0.0), tag
 
 
 def rgcn_checks(rank, world):
