@@ -8,7 +8,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NEXT = {
-    'xw1': 'weight-stationary register form (rows_gemm_ws.hip, round 4: 88.5 -> 72 us); at the 1.95-2.2 GHz the part sustains here the matrix pipe alone needs 59 us - left: the tail (14.4 -> 15 units per wave), the launch and drain (a one-unit launch takes 8.8 us; the weight prologue itself is hidden behind the first unit's row loads - a packed operand image that skips it changes nothing, NOTES round 4)',
+    'xw1': 'weight-stationary register form (rows_gemm_ws.hip, round 4: 88.5 -> 72 us); at the 1.95-2.2 GHz the part sustains here the matrix pipe alone needs 59 us - left: the tail (14.4 -> 15 units per wave), the launch and drain (a one-unit launch takes 8.8 us; the weight prologue itself is hidden behind the row loads of the first unit - a packed operand image that skips it changes nothing, NOTES round 4)',
     'spmm1': 'at the fabric rate (traffic 628 MB at 6.0-6.4 TB/s); ceiling 0.41 on this graph with per-XCD row ranges (computed from the committed floor / probe records)',
     'del1': 'as xw1 (+ packed sign bits merged with v_permlane swaps): 68.7 -> 62 us',
     'wgrad1': 'memory-side (366 MB algorithmic = 61 us at the fabric rate): 2 blocks per CU alternate fetch and MFMA phases; the output-stationary register form measured SLOWER (93 us, NOTES round 4) - it needs more rows in flight per CU, not fewer waves',
