@@ -72,10 +72,19 @@ class _LayerTerms:
         self.folded = not mixed
         if self.folded:
             uniq, inv, c = torch.unique(rows, return_inverse=True, return_counts=True)
-            o64 = z_ori[tgt].double()
-            tbar = torch.zeros(uniq.numel(), d, dtype=torch.float64, device=device).index_add_(0, inv, o64)
-            tbar /= c[:, None].double()
-            q = torch.zeros(uniq.numel(), dtype=torch.float64, device=device).index_add_(0, inv, (o64 * o64).sum(1))
+            # per-row sums over the row's loss terms in a FIXED order (terms sorted by row, original order inside a row; one
+            # sequential sum per row): index_add_ adds with atomics in arrival order, and the constants of the loss LOG below
+            # (q - c |tbar|^2, a cancellation) then change in their last bits from one engine to the next - found in round 4
+            # as a one-ulp difference between the logs of two engines that ran identical kernels
+            order = torch.argsort(inv, stable=True)
+            o64 = z_ori[tgt[order]].double()
+            if uniq.numel():
+                tbar = torch.segment_reduce(o64, 'sum', lengths=c, axis=0)
+                tbar /= c[:, None].double()
+                q = torch.segment_reduce((o64 * o64).sum(1), 'sum', lengths=c, axis=0)
+            else:                                   # (a rank of a row partition without loss terms)
+                tbar = torch.zeros(0, d, dtype=torch.float64, device=device)
+                q = torch.zeros(0, dtype=torch.float64, device=device)
             k_row = (q - c.double() * (tbar * tbar).sum(1)).clamp_(min=0.0)
             kind_u = torch.zeros(uniq.numel(), dtype=torch.int32, device=device)
             kind_u[inv] = kind

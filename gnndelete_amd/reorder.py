@@ -27,8 +27,11 @@ def _weighted_label_propagation(src, dst, n, iters, seed, power=0.5):
     wv = deg[src].pow(-power)
     for it in range(iters):
         key = dst * n + labels[src]
-        uniq, inv = torch.unique(key, return_inverse=True)
-        score = torch.zeros(uniq.numel(), dtype=torch.float64, device=dev).index_add_(0, inv, wv)
+        uniq, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
+        # votes summed in a fixed order (sorted by (node, label), original order inside): index_add_'s atomics would let the last
+        # bits of a score - and with them a tie between two labels, the order, the summation order of every aggregation - vary
+        score = (torch.segment_reduce(wv[torch.argsort(inv, stable=True)], 'sum', lengths=cnt, axis=0) if uniq.numel()
+                 else torch.zeros(0, dtype=torch.float64, device=dev))
         node, lab = uniq // n, uniq % n
         order = torch.argsort(score, descending=True, stable=True)            # heaviest label first, ties -> smaller label
         order = order[torch.argsort(node[order], stable=True)]

@@ -155,6 +155,33 @@ def test_engine_handles_rows_that_carry_both_loss_kinds():
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
 
 
+@pytest.mark.parametrize('gnn', ['gcn', 'sage'])
+def test_engine_instances_from_one_state_log_the_same_bits(gnn):
+    """Two engines built from the same state run the same kernels on the same operands: identical Del weights AND identical
+    loss logs, bit for bit, instance after instance.  (Round 4: the constants that the log adds to the kernels' sums were
+    summed with index_add_'s atomics at set-up - 28 of 39 GCN instances logged a loss one ulp off the first one's.)"""
+    from types import SimpleNamespace
+    import bench
+    dev = torch.device('cuda')
+    args = SimpleNamespace(workload='synth-small', gnn=gnn, df='in', df_size=5.0, seed=42, loss_type='both_layerwise', no_graph=False, unroll=1)
+    data, model, neg, ni1, ni2 = bench.build_request(args, dev)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = None
+    for _ in range(8):
+        model.load_state_dict(state)
+        eng = bench.make_engine(args, data, model, neg, ni1, ni2, dev, 0, 1)
+        for _ in range(3):
+            eng.step()
+        torch.cuda.synchronize()
+        got = (model.deletion1.deletion_weight.detach().clone(), model.deletion2.deletion_weight.detach().clone(), eng.loss_history().clone(),
+               torch.tensor(eng.t1.k_const + eng.t2.k_const, dtype=torch.float64))
+        if ref is None:
+            ref = got
+        for a, b in zip(ref, got):
+            assert torch.equal(a.nan_to_num(), b.nan_to_num())
+        del eng
+
+
 def test_internal_reordering_does_not_change_the_result():
     """The engine's locality renumbering (label propagation) is invisible outside: with and
     without it the learnt Del weights and the logged losses agree to fp32 rounding."""
