@@ -232,9 +232,12 @@ def gpu_checks(rank, world, rccl=False, direct=False):
         else:
             group = dist.new_group(backend='nccl', device_id=dev)
             assert dist.get_backend(group) == 'nccl'
-    for cls, lt in cases:
+    for ci, (cls, lt) in enumerate(cases):
         results = []
-        for partitioned in (False, True, 'overlap'):      # single GPU | partitioned, synchronous exchanges | exchanges overlapped
+        # single GPU | partitioned, synchronous exchanges | exchanges overlapped (at three ranks for the first case only: two
+        # ranks run every case both ways, and the suite has a time limit)
+        variants = (False, True, 'overlap') if (world == 2 or ci == 0) else (False, True)
+        for partitioned in variants:
             torch.manual_seed(11)
             m = cls(SimpleNamespace(in_dim=f, hidden_dim=h, out_dim=o), data.sdf_node_1hop_mask,
                     data.sdf_node_2hop_mask).to(dev)
@@ -256,8 +259,10 @@ def gpu_checks(rank, world, rccl=False, direct=False):
             torch.cuda.synchronize()
             results.append((m.deletion1.deletion_weight.detach().cpu(), m.deletion2.deletion_weight.detach().cpu(),
                             eng.loss_history()))
-        (a1, a2, ah), (b1, b2, bh), (c1, c2, ch) = results
-        same_or_rounding(f'{cls.__name__} {lt}', ((b1, c1), (b2, c2), (bh, ch)))
+        (a1, a2, ah), (b1, b2, bh) = results[:2]
+        if len(results) == 3:
+            c1, c2, ch = results[2]
+            same_or_rounding(f'{cls.__name__} {lt}', ((b1, c1), (b2, c2), (bh, ch)))
         err = max(float((a1 - b1).norm() / a1.norm()), float((a2 - b2).norm() / a2.norm()))
         assert err < 1e-4, (cls.__name__, lt, err)
         assert torch.allclose(ah, bh, rtol=1e-4, equal_nan=True), (cls.__name__, lt, ah, bh)

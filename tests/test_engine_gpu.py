@@ -167,7 +167,7 @@ def test_engine_instances_from_one_state_log_the_same_bits(gnn):
     data, model, neg, ni1, ni2 = bench.build_request(args, dev)
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     ref = None
-    for _ in range(8):
+    for _ in range(6):
         model.load_state_dict(state)
         eng = bench.make_engine(args, data, model, neg, ni1, ni2, dev, 0, 1)
         for _ in range(3):
