@@ -21,16 +21,21 @@
 //   product  D[out][slot] = W_r^T[out][k] A^T[k][slot] on v_mfma_f32_16x16x4_f32 with the relation's block from
 //            gd_rgcn_pack_weight_f32 (the same packed image the tile kernel reads).  A run longer than 4 edges is several
 //            CONSECUTIVE slots with the same node row; the slots of a unit are the 16 lanes of a DPP row of D, so a
-//            segmented scan over those lanes (four v_fmac_dpp steps per register, the segment flags come with the plan)
+//            segmented scan over those lanes (v_mov_dpp row_shr:1 / 2 / 4 / 8 + FMA per register; the segment flags come with
+//            the plan, which also says per unit WHICH of the four steps any of its slots needs - most need one or two)
 //            leaves a row's total in its LAST slot, and only that lane adds it to the node row of the accumulator: a plain
 //            LDS read-modify-write without two lanes on one address.  (LDS float atomics would not need the scan - and were
 //            measured at ~180 cycles per instruction: the LDS pipe 86 % busy, 3.9 ms per launch.)
-//   pipeline the rows of the units u + 1 .. u + DEPTH, the weight fragments and slot words of unit u + 1 and the edge pairs of
-//            unit u + DEPTH + 1 are in flight while unit u is summed and multiplied (DEPTH + 1 register sets, the loop is
-//            unrolled DEPTH + 1 times; past the tile's end the passes run on the plan's empty unit).
+//   pipeline the rows of the units u + 1 .. u + DEPTH, the slot words of unit u + 1 and the edge pairs of unit u + DEPTH + 2
+//            (ONE 8-byte load per lane, staged through LDS a pass later) are in flight while unit u is summed and multiplied
+//            (DEPTH + 1 register sets, the loop is unrolled DEPTH + 1 times; past the tile's end the passes run on the plan's
+//            empty unit); the weight fragments of unit u + 1 replace unit u's right after its products - only when the
+//            relation changes (a uniform branch around four loads: the waits stay exact counts).
 //
-// The gathered volume (every source row once per edge: 4.3 GB at ogbl-biokg size, all of it fabric traffic) is what
-// bounds this form; the matrix instructions take less than half of that time.
+// Measured (layer-1 launch of the biokg request, NOTES round 4): LDS atomics 3.9 ms -> scan 0.94 ms -> edge pairs through LDS,
+// conditional weight reload, per-unit scan steps 0.72 ms (tile kernel: 1.22 ms).  The texture addresser was the limiter on the way
+// (17 loads x 16 cycles per unit); now the gathered volume (every source row once per edge: 4.0-4.5 GB, all of it fabric traffic,
+// moved at 5.5-6 TB/s) bounds the launch, with the on-CU work ~10 % behind (650 us with cache-resident sources).
 #include <stdlib.h>
 
 #include "common.h"
