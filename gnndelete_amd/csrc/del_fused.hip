@@ -43,8 +43,10 @@ struct DelLoss {
   float* partials;          // [2 * gridDim.x]
 };
 
+// (the 64-wide form WITH the weight-gradient sums needs 270 registers: one wave per SIMD for that instantiation instead of 56 B of
+//  scratch per lane at two - it only runs below 65,536 rows, where the launch is latency-sized; the step's form is the kernel below)
 template <int NT, bool WG>
-__global__ __launch_bounds__(256, 2) void del_loss_bwd_kernel(const float* __restrict__ p, int64_t ld_p,
+__global__ __launch_bounds__(256, (NT == 2 && WG) ? 1 : 2) void del_loss_bwd_kernel(const float* __restrict__ p, int64_t ld_p,
                                                               const int32_t* __restrict__ idx, int32_t n_sel,
                                                               const float* __restrict__ w, DelLoss loss,
                                                               float* __restrict__ dz, int64_t ld_dz,

@@ -42,7 +42,8 @@ __device__ __forceinline__ uint32_t or_row_lanes(uint32_t v) {
 // MODE 0: plain, 1: also emit the packed [out > 0] pattern of each row, 2: gate the output by such a pattern,
 //      3: plain + the two row dot products o1[row] = <out[row], u1>, o2[row] = <out[row], u2> (GATConv's attention logits,
 //         gd_rows_gemm_dots_f32), 4: gated like 2 after the rank-1 correction out[row, n] += o1[row] u1[n] + o2[row] u2[n]
-//         (gd_rows_gemm_gated_rank1_f32: o1 / o2 are per-row scalars READ by row id)
+//         (gd_rows_gemm_gated_rank1_f32: o1 / o2 are per-row scalars READ by row id), 5: plain + bias (u1 = the bias vector: the
+//         accumulators of a unit start from it instead of from zero)
 // SEL: row r comes from in_alt where sel[r] != 0 (dense only)
 template <int DIN, int DOUT, int MODE, bool HASIDX, bool SEL, bool RELU>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rows_gemm_ws_kernel(
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     uint32_t* __restrict__ sign_out, const float* __restrict__ in_alt, const uint8_t* __restrict__ sel,
     const float* __restrict__ u1, const float* __restrict__ u2, float* o1, float* o2) {
   constexpr int KQ = DIN / 4, NT = DOUT / 16, XV = KQ / 4, NW = DOUT / 32;
-  constexpr bool GATE = MODE == 2 || MODE == 4, DOTS = MODE == 3, RANK1 = MODE == 4;
+  constexpr bool GATE = MODE == 2 || MODE == 4, DOTS = MODE == 3, RANK1 = MODE == 4, BIAS = MODE == 5;
   static_assert(!(HASIDX && SEL), "the selector form is dense");
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -138,6 +139,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // MODE 4: the row scalars of the unit being stored
   float4 uv1[(DOTS || RANK1) ? NT : 1], uv2[(DOTS || RANK1) ? NT : 1];
   float dp1 = 0.f, dp2 = 0.f, ra_prev = 0.f, rb_prev = 0.f;
+  f32x4v bz[BIAS ? NT : 1];                                 // MODE 5: the bias at this lane's output columns
+  if (BIAS) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float4 b4 = *reinterpret_cast<const float4*>(u1 + 16 * t + 4 * kq);
+      bz[t] = f32x4v{b4.x, b4.y, b4.z, b4.w};
+    }
+  }
   if (DOTS || RANK1) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int c = 0; c < 4; ++c) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (i == 0 && c == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][0], xv[0], f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          if (i == 0 && c == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][0], xv[0], BIAS ? bz[t] : f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][4 * i + c], xv[c], acc[t], 0, 0, 0);
         }
         if (c == 1) {                                        // mid-chunk: the stores of this slot
@@ -292,7 +301,7 @@ static int ws_launch(const float* in, int64_t ld_in, const int32_t* idx, int32_t
 template <int DIN, int DOUT>
 static int ws_dispatch(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t trans_w,
                        int32_t relu_in, float* out, int64_t ld_out, const uint32_t* gate_bits, uint32_t* sign_out,
-                       const float* in_alt, const uint8_t* sel, WsEpi epi, hipStream_t s) {
+                       const float* in_alt, const uint8_t* sel, WsEpi epi, const float* bias, hipStream_t s) {
 #define GD_WS(MODE, HASIDX, SELV, RELU) \
   return ws_launch<DIN, DOUT, MODE, HASIDX, SELV, RELU>(in, ld_in, idx, n_sel, w, trans_w, out, ld_out, gate_bits, sign_out, in_alt, sel, epi, s)
   if (epi.u1) {
@@ -312,6 +321,13 @@ static int ws_dispatch(const float* in, int64_t ld_in, const int32_t* idx, int32
   }
   if (gate_bits) { if (idx) GD_WS(2, true, false, false); else GD_WS(2, false, false, false); }
   if (sign_out) { if (idx) GD_WS(1, true, false, false); else GD_WS(1, false, false, false); }
+  if (bias) {                                              // (dense or index list; the selector form has no biased caller)
+    epi.u1 = bias;
+    if (sel) return 1;
+    if (idx) { if (relu_in) GD_WS(5, true, false, true); else GD_WS(5, true, false, false); }
+    if (relu_in) GD_WS(5, false, false, true);
+    GD_WS(5, false, false, false);
+  }
   if (sel) { if (relu_in) GD_WS(0, false, true, true); else GD_WS(0, false, true, false); }
   if (idx) { if (relu_in) GD_WS(0, true, false, true); else GD_WS(0, true, false, false); }
   if (relu_in) GD_WS(0, false, false, true);
@@ -333,14 +349,15 @@ static int ws_min_rows() {
 }
 
 // -> GD_OK / error when the weight-stationary kernel took the call, 1 when it does not cover it (the caller goes on with
-// the LDS-operand form).  Covered: widths in {64, 128}, no bias, no saved input, out not aliasing an input, enough rows that
+// the LDS-operand form).  Covered: widths in {64, 128}, bias only in the plain mode, no saved input, out not aliasing an input, enough rows that
 // every wave gets units; ReLU on the input only in the plain / dots modes; the selector form only dense; row dots (u1 .. o2,
 // no gate) behind a 128-wide input, the rank-1 + gate form (u1 .. o2 with gate_bits) in front of a 128-wide output.
 int rows_gemm_ws_try(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t d_in, int32_t d_out,
                      int32_t trans_w, const float* bias, int32_t relu_in, const uint32_t* gate_bits, uint32_t* sign_out, float* out,
                      int64_t ld_out, float* save_in, void* stream, const float* in_alt, const uint8_t* sel, const float* u1,
                      const float* u2, float* o1, float* o2) {
-  if (!ws_on() || matrix_split() != 0 || bias || save_in || n_sel < ws_min_rows()) return 1;
+  if (!ws_on() || matrix_split() != 0 || save_in || n_sel < ws_min_rows()) return 1;
+  if (bias && (gate_bits || sign_out || u1 || !aligned16(bias) || !epi_on())) return 1;
   if (!((d_in == 64 || d_in == 128) && (d_out == 64 || d_out == 128))) return 1;
   if (in == out || in_alt == out || (sel && idx) || (relu_in && (gate_bits || sign_out)) || (sel && (gate_bits || sign_out))) return 1;
   if (!aligned16(in) || !aligned16(out) || !aligned16(w) || (in_alt && !aligned16(in_alt)) || ld_in % 4 || ld_out % 4) return 1;
@@ -348,7 +365,7 @@ int rows_gemm_ws_try(const float* in, int64_t ld_in, const int32_t* idx, int32_t
   hipStream_t s = (hipStream_t)stream;
   const WsEpi epi{u1, u2, o1, o2};
 #define GD_WS_SHAPE(DI, DO) \
-  return ws_dispatch<DI, DO>(in, ld_in, idx, n_sel, w, trans_w, relu_in, out, ld_out, gate_bits, sign_out, in_alt, sel, epi, s)
+  return ws_dispatch<DI, DO>(in, ld_in, idx, n_sel, w, trans_w, relu_in, out, ld_out, gate_bits, sign_out, in_alt, sel, epi, bias, s)
   if (d_in == 128 && d_out == 128) GD_WS_SHAPE(128, 128);
   if (d_in == 128 && d_out == 64) GD_WS_SHAPE(128, 64);
   if (d_in == 64 && d_out == 128) GD_WS_SHAPE(64, 128);

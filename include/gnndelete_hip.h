@@ -354,7 +354,7 @@ int gd_rowpair_loss_f32(int32_t kind, const float* a, int64_t ld_a, const int64_
  * trans_w it is its input-gradient; with idx = NULL it is a dense Linear.
  * Two kernel forms, same results to fp32 rounding (the k order of the accumulation differs):
  *   - weight-stationary (rows_gemm_ws.hip, v_mfma_f32_16x16x4_f32): one wave per SIMD keeps W in its registers; taken
- *     where gd_rows_gemm_ws_covers() says so - widths in {64, 128}, >= 65,536 rows, no bias / save_in, out not
+ *     where gd_rows_gemm_ws_covers() says so - widths in {64, 128}, >= 65,536 rows, no save_in (bias: plain calls only), out not
  *     aliasing in, fp32 products (GD_ROWS_GEMM_WS=0 in the environment turns it off);
  *   - LDS-operand (rows_gemm.hip): everything else, down to a scalar kernel for odd widths. */
 int gd_rows_gemm_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel,

@@ -232,10 +232,13 @@ def test_rows_gemm_weight_stationary_form(d_in, d_out):
         w7 = (want + ra.double()[:, None] * u1.double() + rb.double()[:, None] * u2.double())[maskg] * (out4[maskg] > 0)
         assert rel_l2(o7[maskg], w7) < TOL and bool((o7[~maskg] == 3.0).all())
         assert torch.equal(ops.rows_gemm(x, idx, w, out=torch.full((n, d_out), 3.0, device='cuda'), gate_bits=bits, rank1=(ra, u1, rb, u2)), o7)
-    # not covered by this form: bias, and (square widths) the in-place call
+    # bias (the accumulators of a unit start from it): dense, index list + ReLU on the input
     b = torch.randn(d_out, generator=g).cuda()
     out6 = ops.rows_gemm(x, None, w, bias=b)
     assert rel_l2(out6, want + b.double()) < TOL
+    out6i = ops.rows_gemm(x, idx, w, bias=b, relu_in=True, out=torch.full((n, d_out), 7.0, device='cuda'))
+    assert rel_l2(out6i[maskg], (xd.clamp(min=0) @ wd + b.double())[maskg]) < TOL and bool((out6i[~maskg] == 7.0).all())
+    # not covered by this form: (square widths) the in-place call
     if d_in == d_out:
         z = x.clone()
         ops.rows_gemm(z, idx, w, out=z)
