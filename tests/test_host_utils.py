@@ -259,3 +259,40 @@ def test_rgcn_wave_plan_reproduces_the_typed_mean_aggregation():
         assert float((got - want).abs().max()) < 1e-12
     empty = TypedNodeCSR(torch.zeros(2, 0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 100, 3).wave_plan(False)
     assert empty['n_units'] == 0 and bool((empty['unit_edges'][..., 0] == 100).all())
+
+
+def test_bench_attaches_a_stage_profile_only_to_the_kernels_it_was_taken_with(tmp_path):
+    """bench.py's hygiene (host logic, no GPU): the stage table of the replayed step is stamped with a hash of the kernel sources
+    and the C header; load_stage_profile hands it out only for the same workload AND the same sources and says why not otherwise;
+    the committed tables of this tree (GCN / GAT / GraphSAGE) carry the hash of this tree; the fabric ceiling of the SpMM's
+    roofline entry is computed from the committed floor / probe records (not a literal) and only for the graph they were taken
+    on; the algorithmic bytes of SURVEY 8(d); a traffic-based stage table for models without a hand-written one."""
+    import json
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sha = bench.kernel_source_hash()
+    assert len(sha) == 16 and sha == bench.kernel_source_hash()
+    for name in ('r04_final_stages.json', 'r04_final_stages_gat.json', 'r04_final_stages_sage.json'):
+        path = os.path.join(root, 'profiles', name)
+        rec = json.load(open(path))
+        assert rec['csrc_sha'] == sha, f'{name} was taken with other kernel sources: rerun tools/experiments/r04_final.sh'
+        n, nnz = rec['workload']['num_nodes'], rec['workload']['spmm_nnz']
+        got, why = bench.load_stage_profile(path, n, nnz)
+        assert why is None and got['stages'] and all(v['in_step_us'] > 0 for v in got['stages'].values())
+        got, why = bench.load_stage_profile(path, n + 1, nnz)
+        assert got == {} and 'another workload' in why
+        stale = dict(rec, csrc_sha='0' * 16)
+        p2 = tmp_path / name
+        p2.write_text(json.dumps(stale))
+        got, why = bench.load_stage_profile(str(p2), n, nnz)
+        assert got == {} and 'stale' in why and sha in why
+        table = bench.stage_table_from_profile(rec)
+        assert len(table) == len(rec['stages']) and all(e['in_step_us'] > 0 for e in table)
+    got, why = bench.load_stage_profile(str(tmp_path / 'missing.json'), 1, 1)
+    assert got == {} and 'no stage profile' in why
+    fl = json.load(open(os.path.join(root, 'profiles', 'r02_spmm_traffic_floor.json')))
+    c = bench.fabric_ceiling(fl['n'], fl['nnz'], fl['d'])
+    assert 0.35 < c['frac'] < 0.5 and abs(c['frac'] - fl['algorithmic_bytes'] / fl['lru_bytes'] * c['fabric_tbs'] * 1e3 / bench.HBM_PEAK_GBS) < 1e-12
+    assert bench.fabric_ceiling(fl['n'] + 1, fl['nnz'], fl['d']) is None
+    assert bench.spmm_algorithmic_bytes(10, 50, 64) == 4 * 11 + 4 * 50 + 4 * 50 + 2 * 4 * 10 * 64
