@@ -54,10 +54,12 @@ def parse():
     p.add_argument('--probe_partition', action='store_true', help=argparse.SUPPRESS)   # child-process self test
     p.add_argument('--probe_overlap', action='store_true', help=argparse.SUPPRESS)     # ... of the overlapped exchanges
     p.add_argument('--parallel', default='auto', choices=['auto', 'partition', 'replicas'],
-                   help='N>1: "partition" (= "auto") = ONE request row-partitioned over the GPUs (RCCL halo all-to-all + '
-                        'all-reduce per step, strong scaling: what north_star asks to be measured; the independent-'
-                        'replicas rate of the same GPUs is reported next to it under extras); "replicas" = every GPU '
-                        'serves its own unlearning request (no data-path collective, weak scaling) as the headline')
+                   help='N>1: "auto" and "partition" = ONE request row-partitioned over the GPUs (RCCL halo all-to-all + '
+                        'all-reduce per step) is the headline at every N, "scaling": "strong" - what north_star asks to be '
+                        'measured; "auto" additionally reports the independent-replicas rate of the same GPUs and the '
+                        "planner's estimate under extras / config.parallel_auto (it never changes the headline: a curve "
+                        'must not mix strong- and weak-scaling points); "replicas" = every GPU serves its own unlearning '
+                        'request (no data-path collective, "scaling": "weak") as the headline, on explicit request only')
     a = p.parse_args()
     if a.stage_profile is None:
         a.stage_profile = os.path.join(ROOT, 'profiles', 'r04_final_stages.json' if a.gnn == 'gcn' else f'r04_final_stages_{a.gnn}.json')
@@ -124,16 +126,29 @@ def gather_halo_bytes(eng, world, ctl):
     return [[int(v) for v in t.tolist()] for t in every]
 
 
-def partition_estimate(eng, world, ctl, single_us, link_gbs=100.0):
-    """Planner's prediction of the partitioned step (printed under config.parallel_auto; `--parallel auto` partitions only
-    when it beats the single-GPU step): compute = the single-GPU step scaled by the rows this rank works on (layer 1 on own +
+def layer1_share(stage_profile, default=0.29):
+    """Share of the single-GPU step spent in layer 1 (the frozen product + its aggregation: the stages a partitioned rank
+    recomputes on its halo rows), from the committed stage profile of THIS model (profiles/r*_final_stages[_gnn].json)."""
+    try:
+        with open(stage_profile) as f:
+            st = json.load(f)['stages']
+        tot = sum(v['in_step_us'] for v in st.values())
+        names = list(st)
+        l1 = sum(st[k]['in_step_us'] for k in names[:names.index('del1')]) if 'del1' in st else sum(st[k]['in_step_us'] for k in names[:2])
+        return (l1 / tot, os.path.relpath(stage_profile, ROOT)) if tot > 0 else (default, 'default')
+    except Exception:                                            # noqa: BLE001
+        return default, 'default (no stage profile of this model)'
+
+
+def partition_estimate(eng, world, ctl, single_us, link_gbs=100.0, l1_share=0.29, l1_source='default'):
+    """Planner's prediction of the partitioned step (printed under config.parallel_auto, informational: the headline of
+    `--parallel auto` is the partitioned step whatever it says): compute = the single-GPU step scaled by the rows this rank works on (layer 1 on own +
     halo rows, the rest on own rows) + ~60 us of segment launches; exchange = the heaviest rank's halo bytes over ONE xGMI
     link each way (a pair of GPUs shares one link; link_gbs = an assumed sustained rate, not a measurement: no multi-GPU
     run has been recorded) + ~30 us for the packed all-reduce.  MAX over the ranks."""
     import torch.distributed as dist
     rep = eng.halo_report()
     own, n = rep['own_rows'], eng.n
-    l1_share = 0.29                                       # x W1^T + layer-1 aggregation in the single-GPU step (profiles)
     compute = single_us * (l1_share * (own + rep['layer1_rows_recomputed']) / n + (1 - l1_share) * own / n) + 60.0
     # the exchanges move over one link per pair; the largest single transfer into this rank bounds it from below, all of it
     # over one link from above - take the per-rank total over (world - 1) links as the estimate, never below the largest pair
@@ -144,7 +159,8 @@ def partition_estimate(eng, world, ctl, single_us, link_gbs=100.0):
     dist.all_gather(every, mine, group=ctl)
     comp, exch = max(float(t[0]) for t in every), max(float(t[1]) for t in every)
     return {'single_gpu_step_us': single_us, 'predicted_partitioned_step_us': comp + exch, 'compute_us': comp, 'exchange_us': exch,
-            'assumed_link_gbs': link_gbs, 'rule': 'partition if predicted_partitioned_step_us < single_gpu_step_us, else independent replicas'}
+            'assumed_link_gbs': link_gbs, 'layer1_share_of_step': l1_share, 'layer1_share_from': l1_source,
+            'note': 'informational: the partitioned step is the headline at every N; link rate and launch overheads are assumptions, no multi-GPU run has been recorded'}
 
 
 def make_kg_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1, group=None, partition=False):
@@ -765,12 +781,36 @@ def probe_partition_in_child(args, rank, overlap=False):
         return 0, f'{what} timed out on rank {rank} (300 s)'
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a torch.distributed environment: start the N ranks ourselves, exactly as the
+    driver does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), as a CHILD
+    process started before this process has made any GPU call (never an exec of a process that has touched the GPU);
+    its output is relayed and its exit code returned."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    print(f'bench.py: --gpus {n} without WORLD_SIZE in the environment - launching {n} ranks: {" ".join(cmd[1:8])} ...', file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (start one rank per GPU, or drop WORLD_SIZE and let bench.py launch them)'
     # GD_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a one-GPU box (all ranks on cuda:0)
     backend = os.environ.get('GD_BENCH_BACKEND', 'nccl')
     auto = args.parallel == 'auto'
@@ -882,31 +922,15 @@ def main():
         return
     auto_est = None
     if auto and world > 1 and mode == 'partition':
-        # measure the single-GPU step on every rank (also the replicas rate reported under extras), let the planner decide
+        # measure the single-GPU step on every rank (= the replicas rate reported under extras) and print the planner's estimate
+        # next to the measured partitioned step.  The HEADLINE stays the partitioned step at every N (a curve whose
+        # points switch between strong and weak scaling cannot be read); `--parallel replicas` asks for the other headline.
         rep_rate_auto = replicas_rate(args, model, state, device, world, barrier)
-        auto_est = partition_estimate(eng, world, ctl, 1e6 * world / rep_rate_auto)
+        share, share_src = layer1_share(args.stage_profile)
+        auto_est = partition_estimate(eng, world, ctl, 1e6 * world / rep_rate_auto, l1_share=share, l1_source=share_src)
+        auto_est['chosen'] = 'partition'
         model.load_state_dict(state)
-        if auto_est['predicted_partitioned_step_us'] >= auto_est['single_gpu_step_us']:
-            # the partitioned engine is built already: time it too, so that the line carries the measured partitioned step
-            # next to the estimate that turned it down (the scaling curve of the partitioned engine at every N)
-            for _ in range(args.warmup):
-                eng.step()
-            barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                eng.step()
-            torch.cuda.synchronize()
-            barrier()
-            tpart = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-            dist.all_reduce(tpart, op=dist.ReduceOp.MAX, group=ctl)
-            auto_est['measured_partitioned_step_us'] = 1e6 * float(tpart) / args.steps
-            auto_est['chosen'] = 'replicas'
-            model.load_state_dict(state)
-            mode = args.parallel = 'replicas'
-            del eng
-        else:
-            eng = make_engine(args, data, model, neg, ni1, ni2, device, rank, world, group)    # fresh state for the timed run
+        eng = make_engine(args, data, model, neg, ni1, ni2, device, rank, world, group)    # fresh state for the timed run
     if mode != 'partition':
         eng = make_engine(args, data, model, neg, ni1, ni2, device, rank, world)
 

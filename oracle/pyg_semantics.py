@@ -189,11 +189,11 @@ def rgcn_conv(x, edge_index, edge_type, weight, root, bias, num_blocks=None):
     n = x.shape[0]
     num_rel = weight.shape[0]
     out_dim = root.shape[1]
-    out = torch.zeros(n, out_dim, dtype=x.dtype)
+    out = torch.zeros(n, out_dim, dtype=x.dtype, device=x.device)
     for r in range(num_rel):
         sel = edge_type == r
         src, dst = edge_index[0, sel], edge_index[1, sel]
-        cnt = torch.zeros(n, dtype=x.dtype).index_add_(0, dst, torch.ones(src.shape[0], dtype=x.dtype))
+        cnt = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, dst, torch.ones(src.shape[0], dtype=x.dtype, device=x.device))
         h = scatter_rows(x[src], dst, n) / cnt.clamp(min=1.0)[:, None]
         if num_blocks is not None:
             hb = h.view(n, num_blocks, -1)

@@ -93,38 +93,57 @@ def free_port():
 
 
 def oracle_runner(gnn, data, state, neg, ni1, ni2, dtype, device, loss_type='both_layerwise', alpha=0.5, lr=1e-3, perm=None,
-                  hidden=128, out=64):
+                  hidden=128, out=64, edges=None, edge_type=None, pos=None, num_edge_type=None, del_masks=None, train_mask=None):
     """The oracle (oracle/gnndelete_ref.py) as plain torch ops in `dtype` on `device`, one Del-training request:
     -> (step(), snapshot(), (z1_ori, z2_ori)).  perm = a seed: the edge lists are permuted first - a different summation order
     in every scatter, i.e. ANOTHER correct implementation of the same arithmetic (the members of an fp32 ensemble).
+    step() runs one iteration and returns the oracle's log of it (train_loss, loss_r, loss_l).
     snapshot() = (W_D1, W_D2, z1 on the 1-hop S_Df nodes, z2 on the 2-hop S_Df nodes, z2) with the embeddings taken on the
-    retained edges (evaluation semantics, framework/trainer/base.py:238-242); the first four as fp64 CPU tensors."""
+    retained edges (evaluation semantics, framework/trainer/base.py:238-242); the first four as fp64 CPU tensors.
+    edges / edge_type / pos override the link-prediction defaults (data.train_pos_edge_index, no types, the Df columns):
+    the knowledge-graph request trains on data.edge_index with data.edge_type and decodes data.kg_dec_edge
+    (gnndelete_nodeemb.py:745-800; del_masks = the masks its Del operators were built with, train_mask = data.dr_mask: that
+    trainer's forward runs on the retained edges, not on S_Df), the node-deletion request on
+    the undirected data.edge_index (:498-657)."""
     from oracle import gnndelete_ref as R
     # (the GPU box has 256 host threads: the oracle's small host-side tensor ops are ~6 x slower with all of them than with 32)
     torch.set_num_threads(min(32, torch.get_num_threads()))
-    f, m1, m2 = data.x.shape[1], data.sdf_node_1hop_mask, data.sdf_node_2hop_mask
-    E = data.train_pos_edge_index
-    e_dr, e_sdf, pos = E[:, data.dr_mask], E[:, data.sdf_mask], E[:, data.df_mask]
-    ref = R.TwoLayerDelete(gnn, f, hidden, out, m1, m2)
+    m1, m2 = del_masks if del_masks is not None else (data.sdf_node_1hop_mask, data.sdf_node_2hop_mask)
+    relational = gnn in ('rgcn', 'rgat')
+    E = data.train_pos_edge_index if edges is None else edges
+    if pos is None:
+        pos = E[:, data.df_mask]
+    tm = data.sdf_mask if train_mask is None else train_mask
+    e_dr, e_sdf = E[:, data.dr_mask], E[:, tm]
+    t_dr, t_sdf = (edge_type[data.dr_mask], edge_type[tm]) if relational else (None, None)
+    if relational:
+        ref = R.TwoLayerDelete(gnn, hidden, hidden, out, m1, m2, num_nodes=data.num_nodes, num_edge_type=num_edge_type)
+    else:
+        ref = R.TwoLayerDelete(gnn, data.x.shape[1], hidden, out, m1, m2)
     ref.load_state_dict(state, strict=False)
     ref = ref.to(dtype).to(device)
-    x = data.x.to(dtype).to(device)
+    x = (data.x if relational else data.x.to(dtype)).to(device)
     ed, es = e_dr.to(device), e_sdf.to(device)
+    if relational:
+        t_dr, t_sdf = t_dr.to(device), t_sdf.to(device)
     if perm is not None:
         gp = torch.Generator().manual_seed(perm)
-        ed = ed[:, torch.randperm(ed.shape[1], generator=gp).to(device)]
-        es = es[:, torch.randperm(es.shape[1], generator=gp).to(device)]
+        pd, ps = torch.randperm(ed.shape[1], generator=gp).to(device), torch.randperm(es.shape[1], generator=gp).to(device)
+        ed, es = ed[:, pd], es[:, ps]
+        if relational:
+            t_dr, t_sdf = t_dr[pd], t_sdf[ps]
     with torch.no_grad():
-        z1o, z2o = ref.get_original_embeddings(x, ed, return_all_emb=True)
+        z1o, z2o = ref.get_original_embeddings(x, ed, t_dr, return_all_emb=True)
     tg = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=pos.to(device), neg_edge=neg.to(device), ni_mask1=ni1.to(device),
               ni_mask2=ni2.to(device))
     opt = R.make_optimizer(ref, loss_type, lr)
     def step():
-        R.nodeemb_epoch(ref, lambda: ref(x, es, return_all_emb=True), tg, opt, loss_type, alpha, R.LOSSES['mse_mean'])
+        log = R.nodeemb_epoch(ref, lambda: ref(x, es, t_sdf, return_all_emb=True), tg, opt, loss_type, alpha, R.LOSSES['mse_mean'])
+        return {k: log[k] for k in ('train_loss', 'loss_r', 'loss_l')}
 
     def snapshot():
         with torch.no_grad():
-            z1, z2 = ref(x, ed, return_all_emb=True)
+            z1, z2 = ref(x, ed, t_dr, return_all_emb=True)
         return (ref.deletion1.deletion_weight.detach().double().cpu(), ref.deletion2.deletion_weight.detach().double().cpu(),
                 z1[m1.to(device)].double().cpu(), z2[m2.to(device)].double().cpu(), z2.detach())
     return step, snapshot, (z1o, z2o)

@@ -8,9 +8,13 @@ task-level contract of north_star: post-deletion AUC within +-0.002.
 
   distances = rel-L2 to the fp64 run of (W_D1, W_D2, z1 on the 1-hop S_Df nodes, z2 on the 2-hop S_Df nodes), embeddings
   taken on the retained edges (evaluation semantics, framework/trainer/base.py:238-242)
-  assert  d(HIP, fp64) <= RATIO * max over the fp32 ENSEMBLE of d(member, fp64) + FLOOR (one gate flip)   for every quantity, at epochs
-          100 / 300 / 600.  The ensemble = the fp32 oracle as is + the same oracle with its edge lists permuted (a different
-          summation order in every scatter: another correct fp32 implementation).  One member is not enough: the distance
+  assert  d(HIP, fp64) <= RATIO * max over the fp32 ENSEMBLE of d(member, fp64) + (max - min over the ensemble)   for every
+          quantity, at epochs 100 / 300 / 600.  The ensemble = the fp32 oracle as is + the same oracle with its edge lists
+          permuted (a different summation order in every scatter: another correct fp32 implementation) - at synth-small as
+          CPU runs (index_add_ adds in edge order there, so a permutation really is another association; torch's GPU scatter
+          sums a 3,000-node graph in the same order whatever the permutation - four GPU members had identical digits,
+          ADVICE r4), plus one GPU member.  The allowance is the ensemble's OWN measured spread, not a constant: members that
+          have and have not passed their first gate flip at a check are (max - min) apart.  One member is not enough: the distance
           grows in JUMPS (the first ReLU flip takes it from 3e-7 to 2e-4 in one epoch) and WHICH run flips first is chance -
           with one-row SpMM items the fp32 oracle had flipped by epoch 100 and HIP had not (1.9e-4 vs 3.4e-7), with two-row
           items (another association of the same sums) it was the other way round (3.8e-7 vs 2.2e-4); both are in
@@ -19,7 +23,8 @@ task-level contract of north_star: post-deletion AUC within +-0.002.
           (test edges; Df vs Dr)
 
 All oracles run as plain torch ops on the GPU (fp64: fast fp64 units; 600 CPU epochs at the bench's size would take 15
-minutes); four fp32 members at synth-small, three at the bench's size; GCN at both sizes, GAT at synth-small."""
+minutes); at synth-small the fp32 ensemble is six CPU runs + one GPU run, at the bench's size three GPU runs (its scatters do
+sum in different orders there: the members differ in every digit); GCN at both sizes, GAT at synth-small."""
 from types import SimpleNamespace
 
 import pytest
@@ -31,14 +36,11 @@ pytestmark = pytest.mark.gpu
 
 EPOCHS, CHECK = 600, (100, 300, 600)
 RATIO = 2.0                   # measured ratios: profiles/r03_long_parity.txt, profiles/r04_long_parity.txt
-# + one gate flip: the distance to the fp64 run grows in jumps - the first entry of z1 that lands on the other side of zero
-# takes it from ~3e-7 to ~2e-4 in ONE epoch at synth-small (3,000 nodes; ~1e-6 at the bench's size, where one row is 80 x
-# less of the norm) - and at synth-small the four GPU members sum in the same order (identical digits at epoch 100), so
-# they flip together and say nothing about WHEN a differently associated correct implementation flips
-FLOOR = {'synth-small': 3e-4, 'synth-collab': 2e-6}
-# fp32 ensemble: edge-order seeds (None = as given).  Four members at synth-small; three at the bench's size, where an oracle run
-# costs 20 s of the suite's time limit (the full-size test adds the CPU oracle + three more GPU members at its 20-iteration horizon)
-PERMS = {'synth-small': (None, 1, 2, 3), 'synth-collab': (None, 1, 2)}
+# fp32 ensemble: (device, edge-order seed; None = as given).  At synth-small the CPU members are the ones whose association really
+# differs (a 600-epoch CPU run takes seconds there); at the bench's size an oracle run costs 20 s of the suite's time limit (the
+# full-size test adds the CPU oracle + three more GPU members at its 20-iteration horizon)
+PERMS = {'synth-small': (('cuda', None), ('cpu', None), ('cpu', 1), ('cpu', 2), ('cpu', 3), ('cpu', 4), ('cpu', 5)),
+         'synth-collab': (('cuda', None), ('cuda', 1), ('cuda', 2))}
 
 
 def _auc(z, pos, neg):
@@ -65,10 +67,10 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
     import gc
     names = ('W_D1', 'W_D2', 'z1[S1]', 'z2[S2]')
 
-    def run_oracle(dtype, perm):
+    def run_oracle(dtype, perm, where='cuda'):
         """One oracle to the end (torch ops on the GPU: fp64 has fast units there), one at a time - an oracle's autograd
         tapes at the bench's size are tens of GB.  -> snapshots at the CHECK epochs (+ its original embeddings)."""
-        step, snap, z_ori = oracle_runner(gnn, data, state, neg, ni1, ni2, dtype, dev, lt, alpha, lr, perm=perm)
+        step, snap, z_ori = oracle_runner(gnn, data, state, neg, ni1, ni2, dtype, torch.device(where), lt, alpha, lr, perm=perm)
         snaps, done_ = [], 0
         for upto in CHECK:
             for _ in range(upto - done_):
@@ -82,10 +84,10 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
         return snaps, z_ori
     s64_all, _ = run_oracle(torch.float64, None)
     d_members, s32_last, z_ori32 = [], None, None
-    for perm in PERMS[workload]:       # the fp32 ensemble: distances to the fp64 run at every check
-        snaps, z_ori = run_oracle(torch.float32, perm)
+    for where, perm in PERMS[workload]:       # the fp32 ensemble: distances to the fp64 run at every check
+        snaps, z_ori = run_oracle(torch.float32, perm, where)
         d_members.append([[rel_l2(sn[i], s64[i]) for i in range(4)] for sn, s64 in zip(snaps, s64_all)])
-        if perm is None:
+        if perm is None and where == 'cuda':
             s32_last, z_ori32 = snaps[-1], z_ori
         del snaps
     z1o, z2o = z_ori32
@@ -108,11 +110,12 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
         s64, sh = s64_all[c], snap_hip()
         d_ens = [dm[c] for dm in d_members]
         d32 = [max(d[i] for d in d_ens) for i in range(4)]
+        spread = [d32[i] - min(d[i] for d in d_ens) for i in range(4)]
         dh = [rel_l2(sh[i], s64[i]) for i in range(4)]
         print(f'[{workload} {gnn}] epoch {upto}: ' + ', '.join(
             f'{n} fp32 ' + ' '.join(f'{d[i]:.2e}' for d in d_ens) + f' / HIP {dh[i]:.2e}' for i, n in enumerate(names)))
-        for n, a_, b_ in zip(names, d32, dh):
-            assert b_ <= RATIO * a_ + FLOOR[workload], (workload, gnn, upto, n, 'fp32 ensemble max', a_, 'HIP', b_)
+        for n, a_, sp_, b_ in zip(names, d32, spread, dh):
+            assert b_ <= RATIO * a_ + sp_, (workload, gnn, upto, n, 'fp32 ensemble max', a_, 'spread', sp_, 'HIP', b_)
     s32 = s32_last
     tp, tn = data.test_pos_edge_index, data.test_neg_edge_index
     k = data.directed_df_edge_index.shape[1]

@@ -13,7 +13,14 @@ engine's own node order:
                 generator, each needing its source row in the gathering XCD, counted by distinct (XCD, source) pairs
                 under the BEST case that every community edge is free
 
-Prints JSON; DESIGN.md section 7 and profiles/r02_spmm_bound.md quote it next to the PMC counters of the kernel."""
+  --layouts   (round 5) the same two figures for a ROW-RANGE x COLUMN-SLICE assignment of the XCDs:
+              "RxC" = R contiguous row ranges, each worked on by C XCDs that own d / C feature columns of every row
+              (8x1 = what the kernel does; 4x2 and 2x4 trade wider row ranges - fewer distinct (XCD, source) pairs, rows of
+              d / C floats so the 4 MiB hold C x as many of them - against reading the index arrays C times and gathering
+              shorter pieces: 4 d / C bytes, a 128-byte line at d = 128 / C = 4 and at d = 64 / C = 2)
+
+Prints JSON; DESIGN.md section 7 and profiles/r02_spmm_bound.md quote it next to the PMC counters of the kernel;
+profiles/r05_spmm_2d_floor.json holds the --layouts runs."""
 import argparse
 import json
 import os
@@ -36,6 +43,7 @@ def main():
     p.add_argument('--d', type=int, default=128)
     p.add_argument('--l2_mib', type=float, default=4.0)
     p.add_argument('--no_lru', action='store_true')
+    p.add_argument('--layouts', default='', help='comma list of RxC (R x C = 8), e.g. 8x1,4x2,2x4')
     args = p.parse_args()
 
     from gnndelete_amd.framework.data import prepare_edge_deletion, resolve_df_size
@@ -117,6 +125,45 @@ def main():
         out['lru_x_miss_rows'] = int(misses_x)
         out['lru_bytes'] = int(misses_x) * row_bytes + fixed
         out['lru_over_algorithmic'] = round(out['lru_bytes'] / out['algorithmic_bytes'], 3)
+    if args.layouts:
+        out['layouts'] = {}
+        for lay in args.layouts.split(','):
+            R, C = (int(v) for v in lay.split('x'))
+            assert R * C == 8 and args.d % (4 * C) == 0
+            slice_bytes = row_bytes // C
+            per_r = (n_items + R - 1) // R
+            edge_rr = edge_item // per_r
+            pair = np.unique(edge_rr.astype(np.int64) * n + src)
+            distinct_r = np.bincount((pair // n).astype(np.int64), minlength=R)
+            # every one of the C XCDs of a row range fetches its slice of each distinct source row; indices and item records are
+            # read by all C of them; y is written once (in slices)
+            fixed_c = C * (4 * (n + 1) + 8 * nnz + 16 * n_items) + 4 * n * args.d
+            rec = {'row_ranges': R, 'column_slices': C, 'gathered_piece_bytes': slice_bytes,
+                   'distinct_source_rows_per_range': distinct_r.tolist(),
+                   'floor_inf_l2_bytes': int(distinct_r.sum()) * slice_bytes * C + fixed_c}
+            rec['floor_inf_l2_over_algorithmic'] = round(rec['floor_inf_l2_bytes'] / out['algorithmic_bytes'], 3)
+            if not args.no_lru:
+                cap = int(args.l2_mib * 1048576 // slice_bytes)
+                miss = 0
+                for rr in range(R):                         # the C XCDs of a range see the same access stream: simulate one
+                    i0, i1 = rr * per_r, min(n_items, (rr + 1) * per_r)
+                    cache = OrderedDict()
+                    for i in range(i0, i1):
+                        for c in src[it_start[i]:it_end[i]]:
+                            if c in cache:
+                                cache.move_to_end(c)
+                            else:
+                                miss += 1
+                                cache[c] = None
+                                if len(cache) > cap:
+                                    cache.popitem(last=False)
+                        cache[-1 - int(item_row[i])] = None
+                        if len(cache) > cap:
+                            cache.popitem(last=False)
+                rec['lru_x_miss_pieces'] = int(miss) * C
+                rec['lru_bytes'] = int(miss) * slice_bytes * C + fixed_c
+                rec['lru_over_algorithmic'] = round(rec['lru_bytes'] / out['algorithmic_bytes'], 3)
+            out['layouts'][lay] = rec
     print(json.dumps(out, indent=1))
 
 
