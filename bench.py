@@ -50,7 +50,7 @@ def parse():
                         'else 1): a 20-step region is 14 ms, shorter than the clock / power ramp of the part')
     p.add_argument('--stage_profile', default=None,
                    help='per-stage in-step kernel durations + PMC traffic from the committed rocprofv3 runs (tools/rocpd_stage_table.py); '
-                        'default profiles/r04_final_stages.json (gcn) / profiles/r04_final_stages_<gnn>.json')
+                        'default profiles/r05_final_stages.json (gcn) / profiles/r05_final_stages_<gnn>.json')
     p.add_argument('--probe_partition', action='store_true', help=argparse.SUPPRESS)   # child-process self test
     p.add_argument('--probe_overlap', action='store_true', help=argparse.SUPPRESS)     # ... of the overlapped exchanges
     p.add_argument('--parallel', default='auto', choices=['auto', 'partition', 'replicas'],
@@ -62,7 +62,7 @@ def parse():
                         'request (no data-path collective, "scaling": "weak") as the headline, on explicit request only')
     a = p.parse_args()
     if a.stage_profile is None:
-        a.stage_profile = os.path.join(ROOT, 'profiles', 'r04_final_stages.json' if a.gnn == 'gcn' else f'r04_final_stages_{a.gnn}.json')
+        a.stage_profile = os.path.join(ROOT, 'profiles', 'r05_final_stages.json' if a.gnn == 'gcn' else f'r05_final_stages_{a.gnn}.json')
     return a
 
 
@@ -514,17 +514,10 @@ def time_spmm_d64(eng):
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources and the C header (sorted by name): stamps a stage profile with the kernels it measured."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(ROOT, 'gnndelete_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'gnndelete_amd', 'csrc', '*.h'))
-                   + glob.glob(os.path.join(ROOT, 'gnndelete_amd', 'csrc', '*.cpp')) + [os.path.join(ROOT, 'include', 'gnndelete_hip.h')])
-    for f in files:
-        h.update(os.path.basename(f).encode())
-        with open(f, 'rb') as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    """sha256 over the kernel sources and the C header (gnndelete_amd/source_hash.py): stamps a stage profile with the kernels it
+    measured; the same hash is stamped into the library at build time (gd_build_source_hash)."""
+    from gnndelete_amd.source_hash import source_hash
+    return source_hash()
 
 
 def load_stage_profile(path, n, nnz):
@@ -567,7 +560,7 @@ def fabric_ceiling(n, nnz, d):
 
 def stage_table_from_profile(prof):
     """Models without a hand-written stage list (GAT, GraphSAGE, GIN): every kernel of the replayed step by position from the
-    committed in-step profile of THIS model (tools/experiments/r04_profile.sh with GNN=...): duration, PMC traffic and the rate
+    committed in-step profile of THIS model (tools/experiments/r05_profile.sh with GNN=...): duration, PMC traffic and the rate
     that traffic moved at against the HBM roof (a traffic-based fraction: these entries carry no algorithmic byte count)."""
     out = []
     for key, ps in (prof or {}).get('stages', {}).items():

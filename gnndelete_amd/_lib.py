@@ -14,11 +14,12 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'gnndelete_hip.h')
 _i32, _i64, _f32, _f64, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
 # name -> (restype, argtypes); must list every symbol the header declares
-ABI_VERSION = 7          # GD_ABI_VERSION of include/gnndelete_hip.h this binding was written against
+ABI_VERSION = 8          # GD_ABI_VERSION of include/gnndelete_hip.h this binding was written against
 
 PROTOTYPES = {
     'gd_abi_version': (ctypes.c_int, []),
     'gd_last_error_string': (ctypes.c_char_p, []),
+    'gd_build_source_hash': (ctypes.c_char_p, []),
     'gd_matrix_split': (ctypes.c_int, []),
     'gd_set_matrix_split': (ctypes.c_int, [ctypes.c_int]),
     'gd_csr_from_coo_workspace': (_i64, [_i32, _i64]),
@@ -114,6 +115,16 @@ def declared_symbols():
     return sorted(set(re.findall(r'\b(gd_[a-z0-9_]+)\s*\(', text)))
 
 
+def _sources_hash():
+    from .source_hash import source_files, source_hash
+    return source_hash() if all(os.path.exists(f) for f in source_files()) and os.path.isdir(os.path.join(_HERE, 'csrc')) else None
+
+
+def build_stamp():
+    """(stamp of the loaded library, hash of the sources next to it or None)."""
+    return lib().gd_build_source_hash().decode(), _sources_hash()
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -131,6 +142,13 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if handle.gd_abi_version() != ABI_VERSION:
             raise GnnDeleteHipError(f'libgnndelete_hip.so ABI version {handle.gd_abi_version()}, this package binds version {ABI_VERSION}: rebuild (make -C gnndelete_amd/csrc)')
+        # the library must have been built from the sources next to it: a stale .so next to newer sources
+        # would run kernels nobody is looking at.  GNNDELETE_HIP_LIB (an A/B build of the same ABI) and GD_ALLOW_STALE_LIB=1
+        # switch the check off; an installed copy without its sources has nothing to compare with.
+        built, here = handle.gd_build_source_hash().decode(), _sources_hash()
+        if here is not None and built != here and not os.environ.get('GNNDELETE_HIP_LIB') and os.environ.get('GD_ALLOW_STALE_LIB') != '1':
+            raise GnnDeleteHipError(f'{LIB_PATH} was built from other sources (stamp {built}, sources here {here}): run '
+                                    '`make -C gnndelete_amd/csrc` (or set GD_ALLOW_STALE_LIB=1 to load it anyway)')
         _lib = handle
     return _lib
 

@@ -19,7 +19,9 @@ static int g_matrix_split = [] {
 int matrix_split() { return g_matrix_split; }
 }  // namespace gd
 
+#include "build_stamp.inc"
 extern "C" int gd_abi_version(void) { return GD_ABI_VERSION; }
+extern "C" const char* gd_build_source_hash(void) { return GD_BUILD_SOURCE_HASH; }
 extern "C" const char* gd_last_error_string(void) { return gd::error_buffer(); }
 extern "C" int gd_matrix_split(void) { return gd::g_matrix_split; }
 extern "C" int gd_set_matrix_split(int n_products) {

@@ -149,7 +149,7 @@ class PartitionedNodeembEngine:
             self.typed = TypedNodeCSR(edge_index, edge_type.to(dev), n, conv2.num_relations, row_range=(lo, hi))
             for c_, din, dout, tr in ((conv1, x.shape[1], self.h, 0), (conv2, self.h, self.o, 0), (conv2, self.o, self.h, 1)):
                 if int(_lib.lib().gd_rgcn_tile_kl(din, dout, c_.num_blocks or 1, tr)) > 0:
-                    if ops.rgcn_wave_form(din, dout, c_.num_blocks or 1) and self.typed.num_relations < 65536:
+                    if ops.rgcn_wave_form(din, dout, c_.num_blocks or 1, n, din) and self.typed.num_relations < 65536:
                         self.typed.wave_plan(bool(tr))
                     else:
                         self.typed.tile_plan(bool(tr))

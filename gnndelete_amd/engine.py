@@ -344,7 +344,7 @@ class NodeembEngine:
             # tile plans and packed relation weights are made here, outside any graph capture
             for c_, din, dout, tr in ((conv1, self.x.shape[1], self.h, 0), (conv2, self.h, self.o, 0), (conv2, self.o, self.h, 1)):
                 if int(_lib.lib().gd_rgcn_tile_kl(din, dout, c_.num_blocks or 1, tr)) > 0 and os.environ.get('GD_RGCN_NODE_MAJOR') != '1':
-                    if ops.rgcn_wave_form(din, dout, c_.num_blocks or 1) and self.typed.num_relations < 65536:
+                    if ops.rgcn_wave_form(din, dout, c_.num_blocks or 1, n, din) and self.typed.num_relations < 65536:
                         self.typed.wave_plan(bool(tr))
                     else:
                         self.typed.tile_plan(bool(tr))

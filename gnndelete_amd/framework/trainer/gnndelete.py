@@ -55,6 +55,15 @@ class GNNDeleteTrainer(Trainer):
         tests/golden/traj_edgeprob_minibatch_*.npz (the reference's loop run with dtrain_mask injected)."""
         from . import sampler as S
         _require_gpu()
+        # the loop's variants (gnndelete.py:314-317, :391-398): BoundedKLD for '...kld...' models, the two ablations by name
+        um = getattr(args, 'unlearning_model', 'gnndelete')
+        if 'kld' in um:
+            loss_fct = lambda logits, truth: 1 - torch.exp(-F.kl_div(F.log_softmax(logits, -1), truth.softmax(-1), None, None, 'batchmean'))
+        else:
+            loss_fct = F.mse_loss
+        if attack_model_all is not None or attack_model_sub is not None:
+            raise NotImplementedError('membership-inference attacks before / after unlearning (gnndelete.py:320-328) are outside the '
+                                      'Del path (SURVEY.md section 2): pass attack_model_all = attack_model_sub = None')
         model = model.to(device)
         data = data.to('cpu')
         if not hasattr(data, 'dtrain_mask'):
@@ -80,13 +89,20 @@ class GNNDeleteTrainer(Trainer):
                 k = pos.shape[1]
                 neg = S.negative_sampling(ei, batch.x.shape[0], k)
                 df_logits = model.decode(z, pos, neg)
-                loss_e = F.mse_loss(df_logits[:k], df_logits[k:])
+                loss_e = loss_fct(df_logits[:k], df_logits[k:])
                 lower = e_sdf[0] < e_sdf[1]
                 row, col = e_sdf[0][lower], e_sdf[1][lower]
                 logits_ori = (z_ori[row] * z_ori[col]).sum(-1)         # (batch-local ids into the global embedding: upstream)
                 logits = (z[row] * z[col]).sum(-1)
-                loss_l = F.mse_loss(logits, logits_ori)
-                loss = 0.5 * loss_e + 0.5 * loss_l
+                loss_l = loss_fct(logits, logits_ori)
+                if 'ablation_random' in um:                            # (gnndelete.py:391-398)
+                    loss_l = torch.tensor(0)
+                    loss = loss_e
+                elif 'ablation_locality' in um:
+                    loss_e = torch.tensor(0)
+                    loss = loss_l
+                else:
+                    loss = 0.5 * loss_e + 0.5 * loss_l
                 loss.backward()
                 S.sync_gradients(optimizer)
                 optimizer.step()

@@ -31,6 +31,8 @@ def _f32_rows(t):
     return t
 
 
+
+
 def _spmm_raw(rowptr, col, val, x, bias, self_coef, n_rows, plan=None, out=None, x_self=None):
     """y = self_coef * x_self + A x + bias (x_self = x unless given; same row pitch).  With a SplitPlan
     (and a float4-able width) the load-balanced kernel is used, otherwise the one-wave-per-row kernel."""
@@ -629,9 +631,16 @@ def rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans):
     return _note_constant(_lru_get(_RGCN_PACK_CACHE, key, 16, build)[0])
 
 
-def rgcn_wave_form(d_in, d_out, n_blocks):
-    """Whether the typed conv of these widths runs on the wave-private kernel (GD_RGCN_WAVE=0: the tile kernel instead)."""
-    return os.environ.get('GD_RGCN_WAVE', '1') != '0' and int(_lib.lib().gd_rgcn_wave_covers(d_in, d_out, n_blocks)) > 0
+def rgcn_wave_form(d_in, d_out, n_blocks, n_nodes=None, ldx=None):
+    """Whether the typed conv of these widths runs on the wave-private kernel (GD_RGCN_WAVE=0: the tile kernel instead).
+    n_nodes / ldx (elements): the kernel addresses source rows with 24-bit row ids and pitches inside a 4 GiB buffer
+    (gd_rgcn_wave_conv_f32 returns GD_E_DIM beyond that, e.g. > 8.3 M entities at 128 floats) - a graph that exceeds them
+    falls through to the tile / node-major kernels instead of raising."""
+    if os.environ.get('GD_RGCN_WAVE', '1') == '0' or int(_lib.lib().gd_rgcn_wave_covers(d_in, d_out, n_blocks)) <= 0:
+        return False
+    if n_nodes is not None and (n_nodes >= 2 ** 24 or (ldx is not None and (ldx * 4 >= 2 ** 24 or (n_nodes + 1) * ldx * 4 >= 2 ** 32))):
+        return False
+    return True
 
 
 def rgcn_typed_accumulate(tg, x, weight, n_blocks, trans, y, edge_w=None):
@@ -644,7 +653,7 @@ def rgcn_typed_accumulate(tg, x, weight, n_blocks, trans, y, edge_w=None):
         return y
     tiled = (edge_w is None and x.stride(0) % 4 == 0 and y.stride(0) % 4 == 0 and os.environ.get('GD_RGCN_NODE_MAJOR') != '1'
              and int(_lib.lib().gd_rgcn_tile_kl(d_in, d_out, n_blocks, int(trans))) > 0)
-    if tiled and rgcn_wave_form(d_in, d_out, n_blocks) and tg.num_relations < 65536:      # (relation | scan steps << 16 per unit)
+    if tiled and rgcn_wave_form(d_in, d_out, n_blocks, tg.n, x.stride(0)) and tg.num_relations < 65536:      # (relation | scan steps << 16 per unit)
         # four diagonal blocks: the wave-private kernel (one wave per (64-node tile, block), csrc/rgcn_wave.hip)
         p = tg.wave_plan(bool(trans))
         packed = rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans)

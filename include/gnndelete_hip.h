@@ -32,12 +32,13 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 7   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
+#define GD_ABI_VERSION 8   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
                               4: gd_spmm_csr_onepass_f32, gd_rows_gemm_wgrad_reduce_f32 (dw = NULL in the wgrad entries),
                                  gd_comm_* / gd_allreduce_f32 / gd_exchange_rows_f32, gd_segment_softmax_f32, gd_rowpair_dot_f32, gd_step_tail_f32;
                               5: gd_del_loss_bwd_wgrad_f32, multi-row items of gd_spmm_csr_onepass_f32;
                               6: gd_rows_gemm_ws_covers (weight-stationary form of the row GEMMs), gd_spmm_csr_rowgroup_f32;
-                             7: gd_rgcn_wave_conv_f32 / gd_rgcn_wave_covers */
+                             7: gd_rgcn_wave_conv_f32 / gd_rgcn_wave_covers;
+                             8: gd_build_source_hash (the library carries a stamp of the sources it was built from) */
 
 enum {
   GD_OK = 0,
@@ -49,6 +50,10 @@ enum {
 
 int gd_abi_version(void);
 const char* gd_last_error_string(void);
+/* sha256 (first 16 hex digits) over the kernel sources (the .hip, .h and .cpp files of csrc) and this header the library was BUILT from,
+ * stamped at build time by the Makefile; gnndelete_amd/_lib.py refuses a library whose stamp differs from the sources next
+ * to it (a stale .so travelling with newer sources).  Replaces nothing upstream. */
+const char* gd_build_source_hash(void);
 
 /* How the dense fp32 products of the row GEMMs are formed (process-wide switch; initial value from the environment
  * variable GD_MATRIX_SPLIT, else GD_MATRIX_SPLIT_DEFAULT):

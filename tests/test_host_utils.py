@@ -273,10 +273,10 @@ def test_bench_attaches_a_stage_profile_only_to_the_kernels_it_was_taken_with(tm
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sha = bench.kernel_source_hash()
     assert len(sha) == 16 and sha == bench.kernel_source_hash()
-    for name in ('r04_final_stages.json', 'r04_final_stages_gat.json', 'r04_final_stages_sage.json'):
+    for name in ('r05_final_stages.json', 'r05_final_stages_gat.json', 'r05_final_stages_sage.json'):
         path = os.path.join(root, 'profiles', name)
         rec = json.load(open(path))
-        assert rec['csrc_sha'] == sha, f'{name} was taken with other kernel sources: rerun tools/experiments/r04_final.sh'
+        assert rec['csrc_sha'] == sha, f'{name} was taken with other kernel sources: rerun tools/experiments/r05_final.sh'
         n, nnz = rec['workload']['num_nodes'], rec['workload']['spmm_nnz']
         got, why = bench.load_stage_profile(path, n, nnz)
         assert why is None and got['stages'] and all(v['in_step_us'] > 0 for v in got['stages'].values())

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """The per-kernel state table of DESIGN.md section 4, generated from the committed measurements:
-  profiles/r04_bench_default.json   (extras.stage_rooflines: algorithmic work, live timing, in-step timing, traffic)
-  profiles/r04_final_stages.json    (tools/rocpd_stage_table.py over the rocprofv3 kernel-trace + PMC passes)
--> markdown on stdout, profiles/r04_kernel_table.json (the same rows, machine-checkable).  No GPU needed."""
+  profiles/r05_bench_default.json   (extras.stage_rooflines: algorithmic work, live timing, in-step timing, traffic)
+  profiles/r05_final_stages.json    (tools/rocpd_stage_table.py over the rocprofv3 kernel-trace + PMC passes)
+-> markdown on stdout, profiles/r05_kernel_table.json (the same rows, machine-checkable).  No GPU needed."""
 import json
 import os
 
@@ -19,13 +19,13 @@ NEXT = {
     'dh': 'weight-stationary form with the gate bits fetched a unit ahead: 47.2 -> 41 us; 148 MB at 3.6 TB/s',
     'tail': 'both split-K reductions + Adam + loss finalize in one launch (gd_step_tail_f32); launch-sized',
 }
-EVID = 'profiles/r04_final_stages.json, r04_final_step_timeline.md'
+EVID = 'profiles/r05_final_stages.json, r05_final_step_timeline.md'
 
 
 def main():
-    with open(os.path.join(ROOT, 'profiles', 'r04_bench_default.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r05_bench_default.json')) as f:
         line = json.loads(f.read().strip().splitlines()[-1])
-    with open(os.path.join(ROOT, 'profiles', 'r04_final_stages.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r05_final_stages.json')) as f:
         st = json.load(f)
     roof = {e['stage']: e for e in line['extras']['stage_rooflines']}
     rows = []
@@ -43,7 +43,7 @@ def main():
                      'traffic_mb': round(ps['traffic_bytes'] / 1e6, 1) if ps.get('traffic_bytes') else None,
                      'traffic_over_algorithmic': round(e['traffic_over_algorithmic'], 2) if e.get('traffic_over_algorithmic') else None,
                      'evidence': EVID, 'next': NEXT.get(key, '')})
-    with open(os.path.join(ROOT, 'profiles', 'r04_kernel_table.json'), 'w') as f:
+    with open(os.path.join(ROOT, 'profiles', 'r05_kernel_table.json'), 'w') as f:
         json.dump({'step_us_under_rocprof': st['step_span_us'], 'ms_per_step_bench': line['ms_per_step'], 'rows': rows}, f, indent=1)
     print('| stage | kernel | in step us | GF / MB (algorithmic) | bound | fraction in step | PMC traffic (x algorithmic) | state / next |')
     print('|---|---|---|---|---|---|---|---|')
