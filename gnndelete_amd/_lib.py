@@ -24,14 +24,11 @@ PROTOTYPES = {
     'gd_set_matrix_split': (ctypes.c_int, [ctypes.c_int]),
     'gd_csr_from_coo_workspace': (_i64, [_i32, _i64]),
     'gd_csr_from_coo': (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i64, _p]),
-    'gd_agg_gemm_f32': (ctypes.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _i32, _p, _i32, _i32, _i32, _p, _p, _p, _i64, _i32,
-                                       _p, _p, _i32, _i32, _p]),
     'gd_gcn_norm_f32': (ctypes.c_int, [_p, _p, _i32, _p, _p]),
     'gd_spmm_csr_f32': (ctypes.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _f32, _i32, _i32, _p]),
     'gd_spmm_csr_balanced_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _f32, _p, _p, _i32,
                                                 _i32, _i32, _p, _p]),
     'gd_spmm_csr_onepass_f32': (ctypes.c_int, [_p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _f32, _p, _i32, _i32, _i32, _p, _p]),
-    'gd_spmm_csr_rowgroup_f32': (ctypes.c_int, [_p, _i32, _p, _p, _p, _i64, _p, _i64, _p, _f32, _p, _i32, _i32, _i32, _p, _p]),
     'gd_rows_gemm_wgrad_reduce_f32': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _f64, _f64, _f64, _f64, _p]),
     'gd_step_tail_f32': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _f64, _f64, _f64, _f64,
                                         _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _p]),
@@ -94,6 +91,8 @@ PROTOTYPES = {
     'gd_segment_softmax_f32': (ctypes.c_int, [_p, _p, _i32, _p, _p]),
     'gd_segment_softmax_bwd_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p]),
     'gd_rowpair_dot_f32': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
+    'gd_typed_wgrad_f32': (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p]),
+    'gd_typed_edge_dot_f32': (ctypes.c_int, [_p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _p]),
     'gd_comm_unique_id': (ctypes.c_int, [_p]),
     'gd_comm_init': (ctypes.c_int, [_p, _i32, _i32, ctypes.POINTER(ctypes.c_void_p)]),
     'gd_comm_destroy': (ctypes.c_int, [_p]),

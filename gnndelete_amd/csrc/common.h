@@ -14,10 +14,6 @@ constexpr int kWave = 64;  // CDNA wavefront width (hard-coded on purpose: gfx95
 char* error_buffer();  // thread-local, defined in api.cpp
 int matrix_split();    // 0 / 6 / 9, see gd_set_matrix_split (api.cpp)
 int ws_cu_count();     // compute units of the current device (rows_gemm_ws.hip)
-// output-stationary 128 x 128 weight gradient with the loss formed in the fetch (rows_wgrad_ws.hip): GD_OK / error, 1 = not covered
-int rows_wgrad_loss_ws_try(const float* a, int64_t ld_a, const int32_t* a_idx, const float* z, int64_t ld_z, const int32_t* z_idx,
-                           const int32_t* loss_slot, const float* tm, const float* coef, const float* cnt_signed, const float* g_add,
-                           int32_t n_sel, int32_t d_a, int32_t d_b, float* partials, float* loss_partials, int32_t n_part, void* stream);
 // weight-stationary row GEMM (rows_gemm_ws.hip): GD_OK / error when it took the call, 1 when the shape / mode is not covered
 int rows_gemm_ws_try(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t d_in, int32_t d_out,
                      int32_t trans_w, const float* bias, int32_t relu_in, const uint32_t* gate_bits, uint32_t* sign_out, float* out,

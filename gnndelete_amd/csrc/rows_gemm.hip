@@ -1036,18 +1036,10 @@ static int wgrad_impl(const gd::WgradLoss* loss, const float* a, int64_t ld_a, c
   if (n_sel > 0 && !reduce_only) {
     wgrad_geometry(n_sel, &nb, &rpb);
     const int ta = d_a / 32, tb = d_b / 32;
-    // the step's W_D1 gradient (128 x 128, loss formed in the fetch): output-stationary register form (rows_wgrad_ws.hip)
-    int ws_rc = 1;
-    if (loss && !relu_mask && matrix_split() == 0)
-      ws_rc = rows_wgrad_loss_ws_try(a, ld_a, a_idx, g, ld_g, g_idx, loss->slot, loss->tm, loss->coef, loss->cnt_signed, g_add, n_sel, d_a,
-                                     d_b, partials, loss->partials, nb, stream);
-    if (ws_rc != GD_OK && ws_rc != 1) return ws_rc;
-    const bool mfma_ok = ws_rc == 1 && (d_a % 32 == 0) && (d_b % 32 == 0) && ta <= 4 && tb <= 4 && ta != 3 && tb != 3 &&
+    const bool mfma_ok = (d_a % 32 == 0) && (d_b % 32 == 0) && ta <= 4 && tb <= 4 && ta != 3 && tb != 3 &&
                          aligned16(a) && aligned16(g) && ld_a % 4 == 0 && ld_g % 4 == 0 &&
                          (!relu_mask || aligned16(relu_mask)) && (!g_add || aligned16(g_add));
-    if (ws_rc == GD_OK) {
-      // (partials and loss partials are written; the reduction below finishes as for the LDS-tile form)
-    } else if (mfma_ok) {
+    if (mfma_ok) {
     const WgradLoss no_loss{nullptr, nullptr, nullptr, nullptr, nullptr};
     // 128 x 128: 8 waves share the LDS tiles (2 output tiles each, 4 waves / SIMD at 2 blocks per CU) - measured
     // +3 % on the whole step over 4 waves with 4 tiles each; the smaller shapes keep 4 waves

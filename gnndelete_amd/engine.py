@@ -393,20 +393,6 @@ class NodeembEngine:
                 self.p2.zero_()
                 self._rows_only = True
         self.cache_layer1 = cache_layer1
-        # GCN layer 1 as ONE kernel, (A x) W1^T + b1 (= A (x W1^T) + b1 by linearity): the gather-bound
-        # aggregation and the MFMA-bound transform share the CUs instead of following each other
-        # (csrc/agg_gemm.hip).  Needs widths the kernel has (64 / 128) and an input no wider than the output.
-        # OPT-IN (GD_FUSED_L1=1): parity-green and +0.7 % on the bench line (1426 vs 1416 it/s); off by default so
-        # that the step the bench profiles keeps the layer-1 SpMM its roofline entry is about.  DESIGN.md section 7
-        # has what bounds the fused form.
-        w1 = getattr(getattr(self.model.conv1, 'lin', None), 'weight', None)
-        self._fused_l1 = (self._mode == 'gcn' and w1 is not None and w1.shape[1] in (64, 128) and w1.shape[0] in (64, 128)
-                          and w1.shape[1] <= w1.shape[0] and self._split1 and os.environ.get('GD_FUSED_L1') == '1')
-        if self._fused_l1:
-            # the kernel works on the balanced SpMM's items; the products of a hub row's pieces go to extra rows
-            # behind the n real ones
-            self._pre1_ext = torch.empty(n + self.graph.plan.n_slots, self.h, **f32)
-            self.pre1 = self._pre1_ext[:n]
         if cache_layer1:
             with torch.no_grad():
                 self._conv1_forward()
@@ -447,8 +433,6 @@ class NodeembEngine:
         g = self.graph
         if self._mode == 'rgcn':
             self._rgcn_conv(c, self.x, self.pre1, 0)
-        elif self._mode == 'gcn' and self._fused_l1:
-            ops.agg_gemm_items(g, self.x, c.lin.weight, c.bias, self._pre1_ext)
         elif self._mode == 'gcn' and self._rows_only and self._split1 and self._mfma_weight(c.lin.weight):
             ops.rows_gemm(self.x, self.idx2, c.lin.weight, trans_w=True, const_w=True, out=self._t1buf)
             self._spmm(False, g.val, self._t1buf, self.pre1, c.bias, 0.0, plan=self._plan2)

@@ -17,9 +17,6 @@ from . import _lib
 
 
 CHUNK = 64   # in-edges per SpMM work item (one coalesced (col, val) fetch of a 64-lane wave)
-# GD_SPMM_ROWGROUP=1: 64-float aggregations on the row-per-lane-group kernel (gd_spmm_csr_rowgroup_f32) - opt-in: measured no
-# faster than the item kernel in the step (profiles/NOTES.md, round 4)
-ROWGROUP = os.environ.get('GD_SPMM_ROWGROUP') == '1'
 
 
 class SplitPlan:
@@ -63,12 +60,9 @@ class SplitPlan:
         self._row_ids, self._row_start, self._row_end = ids, r_start, r_end
         self._row_deg, self._row_pieces = deg, pieces
         self._onepass = {}
-        self._rowgroup = None
         for d in (64, 128):          # the path's widths, ahead of any hipGraph capture (the tables are built lazily)
             self.xcd_bounds(d)
             self.onepass(d)
-        if ROWGROUP:
-            self.rowgroup()
 
     def xcd_bounds(self, d):
         """Item range of each of the 8 XCDs for a width-d SpMM (int32 [9] on the device, None for small plans),
@@ -228,81 +222,6 @@ class SplitPlan:
         self.n_multirow_items = n_multi
         return hit
 
-    def rowgroup(self):
-        """(items int32 [4 n, 4], n, bounds int32 [9]) for gd_spmm_csr_rowgroup_f32 (64-float rows: every lane group of a wave
-        owns one row, csrc/spmm.hip).  The plan's rows are cut into eight contiguous ranges of equal cost (one per XCD, as
-        onepass); inside a range, in this order:
-          - rows above 512 in-edges, heaviest first: four consecutive items (kind 2) - sixteen contiguous shares of the row,
-            one per lane group of the four waves of a block;
-          - rows of 65 .. 512 in-edges (kind 1): one item, four contiguous shares;
-          - the light rows in row order (the sweep's window of consecutive rows is what keeps gathered rows in the XCD's L2),
-            in windows of 64: inside a window sorted by in-degree and packed four to an item (kind 0), so that the four lane
-            groups of a visit walk rows of the same length; the last pack of a range repeats its last row;
-          - padding items (kind 3) up to a multiple of 4.
-        items[4 i + g] = {row, start, end, meta}; meta of group 0 = kind << 24 | trips (longest group)."""
-        if self._rowgroup is not None:
-            return self._rowgroup
-        ids, r_start, r_end, deg = self._row_ids, self._row_start, self._row_end, self._row_deg
-        dev = ids.device
-        n = int(ids.numel())
-        if n == 0:
-            self._rowgroup = (torch.zeros(0, 4, dtype=torch.int32, device=dev), 0, torch.zeros(9, dtype=torch.int32, device=dev))
-            return self._rowgroup
-        light_max, mid_max, win = 64, 512, 64
-        cost = torch.cumsum((deg + 24).double(), 0)
-        cuts = torch.searchsorted(cost, cost[-1] * torch.arange(1, 8, device=dev, dtype=torch.float64) / 8)
-        lim = [0] + [int(c) for c in cuts.tolist()] + [n]
-        for k in range(1, 9):
-            lim[k] = max(lim[k], lim[k - 1])
-        q4 = torch.arange(4, device=dev)
-
-        def shares(rows, parts, kind):
-            """rows (positions) -> [len(rows) * parts, 4] group records: `parts` contiguous shares of each row."""
-            share = (deg[rows] + parts - 1) // parts
-            k = torch.arange(parts, device=dev)
-            s_ = r_start[rows][:, None] + share[:, None] * k[None, :]
-            e_ = torch.minimum(s_ + share[:, None], r_end[rows][:, None])
-            s_ = torch.minimum(s_, e_)
-            meta = ((kind << 24) | share)[:, None].expand(-1, parts)
-            return torch.stack([ids[rows][:, None].expand(-1, parts), s_, e_, meta], 2).reshape(-1, 4)
-
-        parts, bounds, total = [], [0], 0
-        pad_grp = torch.tensor([0, 0, 0, 3 << 24], device=dev)
-        for k in range(8):
-            lo, hi = lim[k], lim[k + 1]
-            dk = deg[lo:hi]
-            heavy = (dk > mid_max).nonzero().flatten() + lo
-            if heavy.numel():
-                heavy = heavy[torch.argsort(deg[heavy], descending=True, stable=True)]
-                parts.append(shares(heavy, 16, 2))
-                total += 4 * int(heavy.numel())
-            mid = ((dk > light_max) & (dk <= mid_max)).nonzero().flatten() + lo
-            if mid.numel():
-                parts.append(shares(mid, 4, 1))
-                total += int(mid.numel())
-            lp = (dk <= light_max).nonzero().flatten() + lo
-            m = int(lp.numel())
-            if m:
-                w_id = torch.arange(m, device=dev) // win
-                order = torch.argsort(w_id * 128 + deg[lp], stable=True)
-                lp = lp[order]
-                nq = (m + 3) // 4
-                rows4 = lp[torch.clamp(torch.arange(nq * 4, device=dev), max=m - 1)].view(nq, 4)       # short last pack: last row repeated
-                trips = deg[rows4].max(1).values
-                meta = torch.zeros(nq, 4, dtype=torch.long, device=dev)
-                meta[:, 0] = trips
-                parts.append(torch.stack([ids[rows4], r_start[rows4], r_end[rows4], meta], 2).reshape(-1, 4))
-                total += nq
-            tail = (-total) % 4
-            if tail:
-                parts.append(pad_grp.expand(4 * tail, 4))
-                total += tail
-            bounds.append(total)
-        items = torch.cat(parts, 0).to(torch.int32).contiguous()
-        assert items.shape[0] == 4 * total
-        self._rowgroup = (items, total, torch.tensor(bounds, dtype=torch.int32, device=dev))
-        return self._rowgroup
-
     def scratch_flat(self, tag, n_floats, device):
         """Named flat work buffers (e.g. the GAT kernels' merge scratch), kept per plan."""
         buf = self._scratch.get(tag)
@@ -335,52 +254,6 @@ class CSRGraph:
     @property
     def device(self):
         return self.col.device
-
-
-class CappedCSR:
-    """A CSR whose rows have at most CAP in-edges, for gd_agg_gemm_f32: every heavier (hub) row h is replaced by
-    ONE edge of weight 1 to an extra operand row n + h, which `aggregate_hubs` fills with the hub's weighted
-    neighbour sum (the balanced SpMM over the hub rows only).  The operand therefore has n + n_hub rows."""
-
-    CAP = 64       # heaviest row the fused kernel walks itself (one wave; 256 measured the same: fewer hub rows, longer tail)
-
-    def __init__(self, rowptr, col, val, n, cap=None):
-        dev = rowptr.device
-        rp = rowptr.long()
-        deg = rp[1:] - rp[:-1]
-        hub_mask = deg > (self.CAP if cap is None else cap)
-        self.hub = hub_mask.nonzero().flatten()
-        self.n, self.n_hub = n, int(self.hub.numel())
-        edge_row = torch.repeat_interleave(torch.arange(n, device=dev), deg)
-        keep = ~hub_mask[edge_row]
-        new_deg = torch.where(hub_mask, torch.ones_like(deg), deg)
-        rpc = torch.zeros(n + 1, dtype=torch.long, device=dev)
-        rpc[1:] = torch.cumsum(new_deg, 0)
-        nnz_c = int(rpc[-1])
-        colc = torch.empty(nnz_c, dtype=torch.int32, device=dev)
-        valc = torch.ones(nnz_c, dtype=torch.float32, device=dev)
-        k = torch.arange(col.numel(), device=dev)[keep]
-        pos = rpc[edge_row[keep]] + (k - rp[edge_row[keep]])
-        colc[pos] = col[keep]
-        if val is not None:
-            valc[pos] = val[keep]
-        colc[rpc[self.hub]] = (n + torch.arange(self.n_hub, device=dev)).to(torch.int32)
-        self.rowptr, self.col = rpc.to(torch.int32), colc
-        self.val = valc
-        # the hub rows' own edges as a small CSR (rows 0 .. n_hub - 1) + its balanced plan
-        if self.n_hub:
-            rph = torch.zeros(self.n_hub + 1, dtype=torch.long, device=dev)
-            rph[1:] = torch.cumsum(deg[self.hub], 0)
-            self.rowptr_h = rph.to(torch.int32)
-            self.col_h = col[~keep].contiguous()
-            self.val_h = val[~keep].contiguous() if val is not None else None
-            self.plan_h = SplitPlan(self.rowptr_h)
-
-    def operand(self, x):
-        """x [n, d] -> a [n + n_hub, d] buffer whose first n rows are x (the hub rows are filled per call)."""
-        buf = torch.empty(self.n + self.n_hub, x.shape[1], dtype=torch.float32, device=x.device)
-        buf[:self.n] = x
-        return buf
 
 
 def csr_from_coo(src, dst, n):
@@ -539,6 +412,44 @@ class TypedNodeCSR:
         run_b = src * r + et
         order_b = torch.argsort(run_b * n + dst)
         self.bwd, _ = self._runs(run_b[order_b], dst[order_b], r, n, w_edge[order_b])
+        self.bwd_order = order_b if row_range is None else None    # bwd edge k = input edge bwd_order[k] (whole graphs only)
+
+    def rel_major(self):
+        """The forward edges in RELATION-major order for the gradients of trainable relation weights (gd_typed_wgrad_f32):
+        -> dict(rel_ptr int32 [R + 1], src, dst int32 [E], w float32 [E] (the mean weights 1 / |N_r(i)|), from_fwd int64 [E]:
+        position in the `fwd` arrays of every entry - per-edge coefficients given in fwd order are permuted with it), built
+        once on the device (a stable sort by relation of the node-major arrays: inside a relation the edges keep their
+        (target, source) order, so the sums are added in a fixed order)."""
+        c = self.__dict__.get('_rel_major')
+        if c is None:
+            node_ptr, seg_ptr, seg_rel, col, w = self.fwd
+            dev = col.device
+            seg_len = (seg_ptr[1:] - seg_ptr[:-1]).long()
+            runs_per_node = (node_ptr[1:] - node_ptr[:-1]).long()
+            node_of_run = torch.repeat_interleave(torch.arange(self.n, device=dev), runs_per_node)
+            rel_e = torch.repeat_interleave(seg_rel.long(), seg_len)
+            dst_e = torch.repeat_interleave(node_of_run, seg_len)
+            order = torch.argsort(rel_e, stable=True)
+            rel_ptr = torch.zeros(self.num_relations + 1, dtype=torch.int64, device=dev)
+            rel_ptr[1:] = torch.cumsum(torch.bincount(rel_e, minlength=self.num_relations), 0)
+            i32 = lambda t: t.to(torch.int32).contiguous()
+            c = dict(rel_ptr=i32(rel_ptr), src=i32(col.long()[order]), dst=i32(dst_e[order]), w=w[order].contiguous(), from_fwd=order)
+            self.__dict__['_rel_major'] = c
+        return c
+
+    def fwd_edges(self):
+        """(src, dst, rel) int32 [E] of the forward edges in `fwd` order (gd_typed_edge_dot_f32)."""
+        c = self.__dict__.get('_fwd_edges')
+        if c is None:
+            node_ptr, seg_ptr, seg_rel, col, _ = self.fwd
+            dev = col.device
+            seg_len = (seg_ptr[1:] - seg_ptr[:-1]).long()
+            runs_per_node = (node_ptr[1:] - node_ptr[:-1]).long()
+            node_of_run = torch.repeat_interleave(torch.arange(self.n, device=dev), runs_per_node)
+            i32 = lambda t: t.to(torch.int32).contiguous()
+            c = (col, i32(torch.repeat_interleave(node_of_run, seg_len)), i32(torch.repeat_interleave(seg_rel.long(), seg_len)))
+            self.__dict__['_fwd_edges'] = c
+        return c
 
     def tile_plan(self, trans=False):
         """The (64-node tile, relation) regrouping gd_rgcn_tile_conv_f32 walks (include/gnndelete_hip.h): runs cut into

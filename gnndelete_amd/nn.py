@@ -159,6 +159,13 @@ class RGCNConv(nn.Module):
         if frozen and even and self.in_channels <= 128 and self.out_channels <= 128:
             tg = self._typed_node_csr(edge_index, edge_type, n)
             return ops.rgcn_conv_frozen(x, tg, self.weight, self.root, self.bias, nb)
+        if even and self.in_channels <= 128 and self.out_channels <= 128:
+            # trainable relation weights (original-model / retrain training, base.py:394-493, retrain.py:235-339): the same
+            # typed conv kernels forward and for the input gradient, the weight gradient straight from the relation-major
+            # edge list (gd_typed_wgrad_f32) - no [R, n, in] tensor of per-relation means, no torch.einsum
+            tg = self._typed_node_csr(edge_index, edge_type, n)
+            return ops.typed_conv(x, tg, self.weight, nb) + ops.dense(x, self.root.t(), self.bias)
+        # widths the typed kernels do not have (odd block widths, above 128): per-relation means + einsum
         typed = self._typed_csr(edge_index, edge_type, n)
         m = ops.rgcn_mean(x, typed, self.num_relations, n)                  # [R, n, in]
         if self.num_blocks is None:
@@ -181,10 +188,11 @@ class RGATConv(nn.Module):
     The attention logit of an edge (j -> i, r) is  leaky_relu(x_i W_r q + x_j W_r k) = A[i, r] + B[j, r]  with
     A = x (W q)^T, B = x (W k)^T two [N, R] tables (one small GEMM each) instead of two per-edge transforms;
     the softmax across the relations of a target node is gd_segment_softmax_f32 (forward and backward);
-    the aggregation  y_i = sum_e alpha_e x_j W_r  is the typed conv kernel with alpha as edge weights under
-    no_grad (evaluation) and, with gradients, a weighted typed SpMM over the relation-major CSR (rows r * n + i,
-    differentiable in x and in alpha: ops.typed_weighted_sum) followed by the relation-wise transform - no Python
-    loop over relations, no host synchronisation."""
+    the aggregation  y_i = sum_e alpha_e x_j W_r  is the typed conv kernel with alpha as edge weights - under no_grad
+    (evaluation) directly, with gradients through ops.typed_conv (input gradient = the transposed typed conv, relation-weight
+    gradient and alpha's gradient straight from the edge lists: gd_typed_wgrad_f32 / gd_typed_edge_dot_f32); widths the typed
+    kernels do not have fall back to a weighted typed SpMM over the relation-major CSR + the relation-wise transform.
+    No Python loop over relations, no host synchronisation."""
 
     def __init__(self, in_channels, out_channels, num_relations, num_blocks=None, negative_slope=0.2):
         super().__init__()
@@ -255,8 +263,8 @@ class RGATConv(nn.Module):
     def forward(self, x, edge_index, edge_type):
         n = x.shape[0]
         src, dst, et = edge_index[0], edge_index[1], edge_type
-        a = x @ self._relation_vectors(self.q).t()                      # [N, R]
-        b = x @ self._relation_vectors(self.k).t()
+        a = ops.dense(x, self._relation_vectors(self.q))                # [N, R]: x (W_r q) for every relation, the library's GEMM
+        b = ops.dense(x, self._relation_vectors(self.k))
         e = F.leaky_relu(a[dst, et] + b[src, et], self.negative_slope)
         nb = 1 if self.num_blocks is None else self.num_blocks
         if not x.is_cuda:
@@ -271,6 +279,11 @@ class RGATConv(nn.Module):
         if not torch.is_grad_enabled() and even and self.in_channels <= 128 and self.out_channels <= 128:
             tg = self._typed_node_csr(edge_index, edge_type, n)
             return ops.rgat_aggregate_nograd(x, tg, alpha, self.weight, self.bias, nb, self.out_channels)
+        if even and self.in_channels <= 128 and self.out_channels <= 128:
+            # with gradients: the typed conv with alpha as per-edge coefficients, differentiable in x, in the relation weights
+            # (gd_typed_wgrad_f32) and in alpha (gd_typed_edge_dot_f32) - no [R, n, in] tensor, no torch.einsum
+            tg = self._typed_node_csr(edge_index, edge_type, n)
+            return ops.typed_conv(x, tg, self.weight, nb, alpha) + self.bias
         m = ops.typed_weighted_sum(x, alpha[tc['ord_v']], tc).view(self.num_relations, n, self.in_channels)
         if self.num_blocks is None:
             out = torch.einsum('rni,rio->no', m, self.weight)

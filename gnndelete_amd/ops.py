@@ -40,15 +40,6 @@ def _spmm_raw(rowptr, col, val, x, bias, self_coef, n_rows, plan=None, out=None,
     if x_self is not None:
         assert plan is not None and x_self.stride(0) == x.stride(0) and x_self.shape[1] == d
     y = out if out is not None else torch.empty(n_rows, d, dtype=torch.float32, device=x.device)
-    if (plan is not None and d == 64 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and getattr(plan, '_rowgroup', None) is not None
-            and max(int(x.shape[0]), int(y.shape[0])) * x.stride(0) * 4 < 2 ** 32 and x.stride(0) * 4 < 2 ** 24):
-        # 64-float rows: one row per lane group of a wave (a third of the item kernel's instructions per row)
-        items, n_items, bounds = plan.rowgroup()
-        check(_lib.lib().gd_spmm_csr_rowgroup_f32(ptr(items), n_items, ptr(col), ptr(val), ptr(x), x.stride(0), ptr(y),
-                                                  y.stride(0), ptr(bias), float(self_coef), ptr(x_self), d, int(col.shape[0]),
-                                                  max(int(x.shape[0]), int(y.shape[0])), ptr(bounds), stream_ptr(x.device)),
-              'gd_spmm_csr_rowgroup_f32')
-        return y
     if (plan is not None and d % 4 == 0 and d <= 1024 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
             and os.environ.get('GD_SPMM_TWO_LAUNCH') != '1'):
         # hub rows summed by the four waves of a block inside the same launch (no scratch rows, no fix-up kernel)
@@ -791,6 +782,59 @@ def typed_weighted_sum(x, alpha_v, tc):
     return _TypedWeightedSum.apply(x, alpha_v, tc)
 
 
+class _TypedConv(torch.autograd.Function):
+    """y_i = sum over the in-edges e = (j -> i, r) of  c_e x_j W_r  with TRAINABLE relation weights: c_e = the mean weight
+    1 / |N_r(i)| (RGCNConv, rgcn.py:17-38 when the conv trains: base.py:394-493, retrain.py:235-339) or a given per-edge
+    coefficient in input edge order (RGATConv's attention, rgat.py:322-337).  Forward and input gradient = the typed conv
+    kernels the frozen path runs; the weight gradient and the coefficients' gradient come straight from the edge lists
+    (gd_typed_wgrad_f32, gd_typed_edge_dot_f32) - no [R, N, d] tensor of per-relation aggregates, no torch.einsum."""
+
+    @staticmethod
+    def forward(ctx, x, tg, weight, n_blocks, coef):
+        x = _f32_rows(x)
+        w = weight.detach().contiguous().float()
+        n, d_out = x.shape[0], int(w.shape[-1]) * n_blocks
+        y = torch.zeros(n, d_out, dtype=torch.float32, device=x.device)
+        cf = None if coef is None else coef.detach().float().contiguous()
+        rgcn_typed_accumulate(tg, x, w, n_blocks, 0, y, edge_w=None if cf is None else cf[tg.fwd_order].contiguous())
+        ctx.tg, ctx.n_blocks, ctx.has_coef = tg, n_blocks, cf is not None
+        ctx.save_for_backward(x, w, cf if cf is not None else x.new_zeros(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, cf = ctx.saved_tensors
+        tg, nb = ctx.tg, ctx.n_blocks
+        dy = _f32_rows(dy)
+        d_in, d_out = x.shape[1], dy.shape[1]
+        dx = dw = dcoef = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros_like(x)
+            if ctx.has_coef and tg.bwd_order is None:
+                raise _lib.GnnDeleteHipError('per-edge coefficients on a row partition of the typed graph are not supported')
+            rgcn_typed_accumulate(tg, dy, w, nb, 1, dx, edge_w=cf[tg.bwd_order].contiguous() if ctx.has_coef else None)
+        if ctx.needs_input_grad[2]:
+            rm = tg.rel_major()
+            wts = rm['w'] if not ctx.has_coef else cf[tg.fwd_order][rm['from_fwd']].contiguous()
+            dw = torch.empty_like(w)
+            check(_lib.lib().gd_typed_wgrad_f32(ptr(rm['rel_ptr']), tg.num_relations, ptr(rm['src']), ptr(rm['dst']), ptr(wts), ptr(x),
+                                                x.stride(0), ptr(dy), dy.stride(0), nb, d_in, d_out, ptr(dw), stream_ptr(x.device)),
+                  'gd_typed_wgrad_f32')
+        if ctx.has_coef and ctx.needs_input_grad[4]:
+            src, dst, rel = tg.fwd_edges()
+            g_fwd = torch.empty(src.numel(), dtype=torch.float32, device=x.device)
+            check(_lib.lib().gd_typed_edge_dot_f32(ptr(src), ptr(dst), ptr(rel), int(src.numel()), ptr(x), x.stride(0), ptr(dy),
+                                                   dy.stride(0), ptr(w), nb, d_in, d_out, ptr(g_fwd), stream_ptr(x.device)),
+                  'gd_typed_edge_dot_f32')
+            dcoef = torch.empty_like(g_fwd)
+            dcoef[tg.fwd_order] = g_fwd
+        return dx, None, dw, None, dcoef
+
+
+def typed_conv(x, tg, weight, n_blocks, coef=None):
+    return _TypedConv.apply(x, tg, weight, n_blocks, coef)
+
+
 def rgcn_conv_frozen(x, tg, weight, root, bias, n_blocks):
     return _RgcnConvFrozen.apply(x, tg, weight, root, bias, n_blocks)
 
@@ -876,44 +920,6 @@ class _EdgeDot(torch.autograd.Function):
 
 def edge_dot(z, e0, e1, rel=None, etype=None):
     return _EdgeDot.apply(z, rel, e0, e1, etype)
-
-
-def aggregate_hubs(capped, x_ext):
-    """Fill the extra operand rows x_ext[n:] with the hub rows' weighted neighbour sums (balanced SpMM)."""
-    if capped.n_hub:
-        _spmm_raw(capped.rowptr_h, capped.col_h, capped.val_h, x_ext, None, 0.0, capped.n_hub, capped.plan_h,
-                  out=x_ext[capped.n:])
-
-
-def agg_gemm(capped, x_ext, w, bias=None, rows=None, gate_bits=None, out=None, w_out_in=True):
-    """out[r] = (sum_k val[k] x_ext[col[k]]) @ (w^T if w_out_in else w) (+ bias / gated) for r in rows (all rows of
-    the capped CSR when rows is None) - gd_agg_gemm_f32, raw call.  x_ext = capped.operand(x) after
-    aggregate_hubs.  Output rows are indexed by row id."""
-    d_in = x_ext.shape[1]
-    d_out = w.shape[0] if w_out_in else w.shape[1]
-    n_rows = capped.n if rows is None else int(rows.shape[0])
-    if out is None:
-        out = torch.empty(capped.n, d_out, dtype=torch.float32, device=x_ext.device)
-    w = w.contiguous()
-    check(_lib.lib().gd_agg_gemm_f32(ptr(capped.rowptr), ptr(capped.col), ptr(capped.val), ptr(x_ext), x_ext.stride(0),
-                                     int(x_ext.shape[0]), ptr(rows), n_rows, ptr(w), d_in, d_out, 1 if w_out_in else 0,
-                                     ptr(bias), ptr(gate_bits), ptr(out), out.stride(0), int(capped.col.shape[0]),
-                                     None, None, 0, 0, stream_ptr(x_ext.device)), 'gd_agg_gemm_f32')
-    return out
-
-
-def agg_gemm_items(graph, x, w, bias, out_ext, transposed=False):
-    """out_ext[:n] = (A x) @ w^T + bias over the work items of the balanced SpMM (gd_agg_gemm_f32, work-item form):
-    out_ext has graph.n + plan.n_slots rows, the extra ones hold the hub rows' piece products."""
-    plan = graph.plan_t if transposed else graph.plan
-    col, val = (graph.col_t, graph.val_t) if transposed else (graph.col, graph.val)
-    assert out_ext.shape[0] >= graph.n + plan.n_slots and val is not None
-    w = w.contiguous()
-    check(_lib.lib().gd_agg_gemm_f32(None, ptr(col), ptr(val), ptr(x), x.stride(0), int(x.shape[0]), None, plan.n_items,
-                                     ptr(w), x.shape[1], w.shape[0], 1, ptr(bias), None, ptr(out_ext), out_ext.stride(0),
-                                     int(col.shape[0]), ptr(plan.items), ptr(plan.split), plan.n_split, graph.n,
-                                     stream_ptr(x.device)), 'gd_agg_gemm_f32')
-    return out_ext[:graph.n]
 
 
 # ------------------------------------------------------------------------------ edge-probability NI term

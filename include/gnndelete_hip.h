@@ -38,7 +38,8 @@ extern "C" {
                               5: gd_del_loss_bwd_wgrad_f32, multi-row items of gd_spmm_csr_onepass_f32;
                               6: gd_rows_gemm_ws_covers (weight-stationary form of the row GEMMs), gd_spmm_csr_rowgroup_f32;
                              7: gd_rgcn_wave_conv_f32 / gd_rgcn_wave_covers;
-                             8: gd_build_source_hash (the library carries a stamp of the sources it was built from) */
+                             8: gd_build_source_hash (the library carries a stamp of the sources it was built from), gd_typed_wgrad_f32,
+                                gd_typed_edge_dot_f32; gd_agg_gemm_f32 and gd_spmm_csr_rowgroup_f32 removed (opt-in forms nobody defaulted) */
 
 enum {
   GD_OK = 0,
@@ -86,26 +87,6 @@ int gd_csr_from_coo(const int64_t* src, const int64_t* dst, int64_t n_edges, int
                     int32_t* col, int32_t* order, int32_t* status, void* workspace, int64_t workspace_bytes,
                     void* stream);
 
-/* Aggregate-then-transform in one kernel:  y[r,:] = (sum_{k in row r} val[k] x[col[k],:]) @ W (+ bias), r in rows.
- *   rowptr/col/val  CSR over target rows (val required: ones for a plain sum); a row is walked by one wave, so rows above a few hundred
- *                   in-edges should be pre-aggregated by gd_spmm_csr_balanced_f32 into extra rows of x and given one edge
- *   x [x_rows, d_in], d_in in {64, 128}; rows [n_rows] int32 row ids or NULL for 0..n_rows-1
- *   w: w_out_in = 1 -> [d_out, d_in] (a Linear weight, y = agg @ w^T), 0 -> [d_in, d_out]; d_out in {64, 128}
- *   bias [d_out] or NULL;  gate_bits [n_rows, d_out/32] or NULL: zero the outputs whose bit is clear (packed
- *   [z > 0] of gd_rows_gemm_signs_f32, indexed by position in `rows`) - exclusive with bias
- * By linearity this is GCNConv / GINConv with in_dim <= out_dim (framework/models/gcn.py:11-24, gin.py:26-34:
- * propagate(lin(x)) = lin(propagate(x))) and, on the transposed CSR with the gate, relu's and conv2's backward
- * into the S1 rows (framework/models/deletion.py:66-68).  The gather-bound aggregation and the MFMA-bound
- * transform overlap inside the CUs; the aggregated rows never reach HBM. */
-int gd_agg_gemm_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* x, int64_t ldx,
-                    int32_t x_rows, const int32_t* rows, int32_t n_rows, const float* w, int32_t d_in, int32_t d_out,
-                    int32_t w_out_in, const float* bias, const uint32_t* gate_bits, float* y, int64_t ldy,
-                    int32_t nnz /* length of col */,
-                    const int32_t* items /* NULL, or the [n_rows, 4] work items {row, start, end, slot} of
-                                            gd_spmm_csr_balanced_f32 instead of rowptr / rows: a piece (slot >= 0) writes its
-                                            un-biased product to row piece_base + slot of y, which must have those rows */,
-                    const int32_t* split, int32_t n_split /* the items' split rows: summed (+ bias) by a fix-up */,
-                    int32_t piece_base, void* stream);
 
 /* GCN symmetric normalisation on a CSR that already contains exactly one self loop per node:
  *   val[k] = deg[i]^-1/2 * deg[col[k]]^-1/2,  deg[i] = rowptr[i+1]-rowptr[i]  (k in row i)
@@ -169,21 +150,6 @@ int gd_spmm_csr_onepass_f32(const int32_t* items, int32_t n_items, const int32_t
                             const float* x_self, int32_t d, int32_t nnz, int32_t x_rows, const int32_t* xcd_bounds,
                             void* stream);
 
-/* The same aggregation for 64-float rows with one ROW per lane group of a wave (16 lanes x 16 bytes): a group walks its row's
- * in-edges in order into one accumulator - no dealing of edges to groups, no cross-group sum, one 1 KB store for four rows.
- * The item kernel behind gd_spmm_csr_onepass_f32 saturates the instruction issue of its SIMDs at this width (8 in-edges per
- * row on average); this one issues about a third of its instructions per row.
- *   items [4 n_items, 4] int32: items[4 i + g] = {row, start, end, meta} of lane group g of item i; meta of group 0 =
- *     kind << 24 | trips (the longest group's edge count).  kind 0: four rows (a short pack repeats its last row);
- *     1: one row of 65 .. 512 in-edges in four contiguous shares; 2: four consecutive 4-aligned items = one heavier row in
- *     sixteen shares, summed by the four waves of a block; 3: padding.  n_items and every xcd_bounds entry: multiples of 4
- *     (gnndelete_amd/graph.py: SplitPlan.rowgroup builds them).
- * d must be 64; x below 4 GiB.  Sums are sequential over a row's in-edges (fixed order; another association than the item
- * kernel's).  Replaces the same upstream ops as gd_spmm_csr_f32. */
-int gd_spmm_csr_rowgroup_f32(const int32_t* items, int32_t n_items, const int32_t* col, const float* val,
-                             const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias,
-                             float self_coef, const float* x_self, int32_t d, int32_t nnz, int32_t x_rows,
-                             const int32_t* xcd_bounds, void* stream);
 
 /* Per-relation mean aggregation of R-GCN ("typed SpMM") over a relation-major CSR:
  *   rowptr[(r*n_rows + i) .. +1] delimit the in-edges of type r into node i;
@@ -620,6 +586,24 @@ int gd_segment_softmax_bwd_f32(const int32_t* rowptr, const float* alpha, const 
  * rgat.py:322-337).  float4 path for d % 4 == 0 with 16-byte aligned rows, any d otherwise. */
 int gd_rowpair_dot_f32(const float* a, int64_t ld_a, const int32_t* ia, const float* b, int64_t ld_b, const int32_t* ib,
                        int64_t n, int32_t d, float* out, void* stream);
+
+/* Gradients of TRAINABLE relation weights and of per-edge coefficients, straight from relation-major edge lists (no [R, N, d]
+ * tensor of per-relation aggregates; ABI 8):
+ *   gd_typed_wgrad_f32     dW[r, b] = sum over the edges e of relation r (rel_ptr[r] <= e < rel_ptr[r + 1] of src / dst / w) of
+ *                          w[e] * x[src[e], block b]^T dy[dst[e], block b];  dW is [n_rel, n_blocks, d_in / n_blocks, d_out / n_blocks]
+ *                          (n_blocks = 1: dense [d_in, d_out] per relation); w = NULL: weight 1.  Edges of a relation are added
+ *                          in array order by ONE workgroup per 16 x 16 output tile: bit-reproducible, no atomics.
+ *   gd_typed_edge_dot_f32  out[e] = < x[src[e], :], dy[dst[e], :] W_(rel[e])^T > (the gradient of an edge's coefficient when
+ *                          the message is coefficient * x_src W_rel), weight as for gd_typed_wgrad_f32's dW.
+ * Replace torch.einsum('rnbi,rbio->nbo') over the [R, N, in] mean aggregates and its autograd in the reference's trainable
+ * RGCNConv (framework/models/rgcn.py:17-38 under trainer/base.py:394-493, retrain.py:235-339) and the per-edge
+ * transforms of RGATConv (framework/models/rgat.py:188-206, :322-337). */
+int gd_typed_wgrad_f32(const int32_t* rel_ptr, int32_t n_rel, const int32_t* src, const int32_t* dst, const float* w,
+                       const float* x, int64_t ldx, const float* dy, int64_t ldy, int32_t n_blocks, int32_t d_in, int32_t d_out,
+                       float* dw, void* stream);
+int gd_typed_edge_dot_f32(const int32_t* src, const int32_t* dst, const int32_t* rel, int64_t n_edges, const float* x, int64_t ldx,
+                          const float* dy, int64_t ldy, const float* weight, int32_t n_blocks, int32_t d_in, int32_t d_out,
+                          float* out, void* stream);
 
 /* ---------------------------------------------------------------- collectives (RCCL) ---- */
 

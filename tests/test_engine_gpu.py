@@ -317,45 +317,6 @@ def test_fused_stages_are_active_on_the_reference_masks():
 
 
 
-@pytest.mark.parametrize('use_graph', [False, True])
-def test_fused_layer1_kernel_matches_oracle_training(monkeypatch, use_graph):
-    """GD_FUSED_L1=1 (opt-in): GCN layer 1 through gd_agg_gemm_f32, (A x) W1^T + b1 in one kernel, on the graph /
-    request of a golden fixture with features widened to a width the kernel has (64 -> 128 -> 64): same
-    trajectory as autograd on the CPU oracle (the sum is re-associated, not changed)."""
-    from gnndelete_amd.engine import NodeembEngine
-    from oracle import gnndelete_ref as R
-    monkeypatch.setenv('GD_FUSED_L1', '1')
-    fx = load_golden('traj_gcn_both_all.npz')
-    _, data, rest = split_fixture(fx)
-    n = data['x'].shape[0]
-    torch.manual_seed(5)
-    data = dict(data, x=torch.randn(n, 64))
-    mo = R.TwoLayerDelete('gcn', 64, 128, 64, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
-    with torch.no_grad():
-        for name, p in mo.named_parameters():
-            if name.endswith('bias'):
-                p.copy_(torch.randn_like(p) * 0.1)
-    state = {k: v.clone() for k, v in mo.state_dict().items()}
-    m = hip_model('gcn', state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
-    logs, _ = R.nodeemb_fullbatch(mo, data, 6, 'both_all', 0.4, 'mse_mean', 0.01, neg_edge=t(rest['neg']))
-
-    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
-    E = dev['train_pos_edge_index']
-    ni1, ni2 = R.non_df_masks(n, data['directed_df_edge_index'], data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
-    with torch.no_grad():
-        z1o, z2o = m.get_original_embeddings(dev['x'], E[:, dev['dr_mask']], return_all_emb=True)
-    eng = NodeembEngine(m, dev['x'], E[:, dev['sdf_mask']].contiguous(), z1o, z2o, E[:, dev['df_mask']],
-                        t(rest['neg']).cuda(), ni1, ni2, loss_type='both_all', alpha=0.4, lr=0.01, use_graph=use_graph)
-    assert eng._fused_l1
-    for _ in range(6):
-        eng.step()
-    hist = eng.loss_history().numpy()
-    for col, key in enumerate(['train_loss', 'loss_r', 'loss_l']):
-        np.testing.assert_allclose(hist[:, col], [l[key] for l in logs], rtol=1e-4, atol=1e-8, err_msg=key)
-    assert rel_l2(m.deletion1.deletion_weight.detach().cpu(), mo.deletion1.deletion_weight.detach()) < 1e-4
-    assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
-
-
 def test_unrolled_graph_runs_the_same_iterations():
     """engine.run(n, unroll=k) - k iterations per hipGraph launch plus a step-by-step remainder - must leave exactly
     the state that n single steps leave (bit-identical: same kernels, same order)."""

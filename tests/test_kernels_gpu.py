@@ -251,8 +251,7 @@ def test_rows_gemm_weight_stationary_form(d_in, d_out):
 def test_wgrad_with_loss_formed_in_the_fetch(n, frac, with_add):
     """gd_rows_gemm_wgrad_loss_f32 at 128 x 128: dW = a[ia]^T (coef_u (z[iz] - tbar_u) + g_add[iz]) and the two loss sums
     against fp64: rows without a loss slot, a row count that is not a multiple of the tile height, partial matrices counted
-    by gd_rows_gemm_wgrad_blocks.  With GD_WGRAD_WS=1 in the environment the large cases run the opt-in output-stationary
-    register form (csrc/rows_wgrad_ws.hip: a pair of waves per row range, half of dW each) - same test, same tolerance."""
+    by gd_rows_gemm_wgrad_blocks."""
     from gnndelete_amd import _lib
     from gnndelete_amd._lib import check, ptr
     L = _lib.lib()
@@ -576,57 +575,6 @@ def test_balanced_spmm_splits_hub_rows_and_matches_plain_kernel(d):
     yt = ops._spmm_raw(gr.rowptr_t, gr.col_t, gr.val_t, x.cuda(), None, 0.5, n, gr.plan_t)
     want_t = (a / deg.sqrt()[:, None] / deg.sqrt()[None, :]).t() @ x.double() + 0.5 * x.double()
     assert rel_l2(yt.cpu(), want_t) < TOL
-
-
-@pytest.mark.parametrize('self_coef,with_bias', [(0.0, True), (1.0, False), (0.5, True)])
-def test_rowgroup_spmm_one_row_per_lane_group(self_coef, with_bias):
-    """gd_spmm_csr_rowgroup_f32 (64-float rows, csrc/spmm.hip): every item kind of its planner - packs of four light rows
-    sorted by in-degree inside windows of 64 (incl. rows without in-edges and a repeated last row), rows of 65 .. 512
-    in-edges in four shares, heavier rows in sixteen shares over the four waves of a block - against the dense fp64
-    product, the transposed graph, a row-subset plan, and the item kernel on the same plan; bit-reproducible."""
-    from gnndelete_amd import ops
-    from gnndelete_amd.graph import SplitPlan, build_csr
-    n, d = 6_001, 64
-    g = torch.Generator().manual_seed(11)
-    ei = torch.cat([random_graph(n, 42_000, seed=3, isolate=40),
-                    torch.stack([torch.randint(0, n, (700,), generator=g), torch.full((700,), 5)]),          # 700 in-edges: sixteen shares
-                    torch.stack([torch.randint(0, n, (3000,), generator=g), torch.full((3000,), 77)]),       # 3,000
-                    torch.stack([torch.randint(0, n, (200,), generator=g), torch.full((200,), 9)]),          # 200: four shares
-                    torch.stack([torch.full((900,), 123), torch.randint(0, n, (900,), generator=g)])], 1)    # a hub of the transposed graph
-    x = torch.randn(n, d, generator=g)
-    b = torch.randn(d, generator=g) if with_bias else None
-    gr = build_csr(ei.cuda(), n, 'sum')
-    items, n_items, bounds = gr.plan.rowgroup()
-    kinds = (items.view(-1, 4, 4)[:, 0, 3] >> 24).cpu()
-    assert n_items % 4 == 0 and all(int(v) % 4 == 0 for v in bounds.tolist()) and int(bounds[-1]) == n_items
-    assert (kinds == 0).any() and (kinds == 1).any() and int((kinds == 2).sum()) >= 8
-    a = dense_adj(ei, n)
-    xg, bg = x.cuda(), (b.cuda() if with_bias else None)
-    want = a @ x.double() + self_coef * x.double() + (b.double() if with_bias else 0.0)
-    y = ops._spmm_raw(gr.rowptr, gr.col, None, xg, bg, self_coef, n, gr.plan)
-    assert rel_l2(y.cpu(), want) < TOL
-    assert torch.equal(y, ops._spmm_raw(gr.rowptr, gr.col, None, xg, bg, self_coef, n, gr.plan))
-    # the item kernel on the same plan: another association of the same sums
-    plan_items = SplitPlan(gr.rowptr)
-    plan_items._rowgroup = None
-    y_items = ops._spmm_raw(gr.rowptr, gr.col, None, xg, bg, self_coef, n, plan_items)
-    assert rel_l2(y, y_items) < 1e-6
-    # transposed graph, weighted
-    val_t = torch.rand(gr.col_t.numel(), generator=g).cuda()
-    gr.plan_t.rowgroup()
-    yt = ops._spmm_raw(gr.rowptr_t, gr.col_t, val_t, xg, None, 0.0, n, gr.plan_t)
-    at = torch.zeros(n, n, dtype=torch.float64)
-    rows_t = torch.repeat_interleave(torch.arange(n), (gr.rowptr_t[1:] - gr.rowptr_t[:-1]).long().cpu())
-    at.index_put_((rows_t, gr.col_t.long().cpu()), val_t.double().cpu(), accumulate=True)
-    assert rel_l2(yt.cpu(), at @ x.double()) < TOL
-    # a plan over a row subset writes those rows only
-    rows = torch.unique(torch.cat([torch.randint(0, n, (1500,), generator=g), torch.tensor([5, 9, 77])])).int().cuda()
-    sub = SplitPlan(gr.rowptr, rows=rows)
-    sub.rowgroup()
-    ys = ops._spmm_raw(gr.rowptr, gr.col, None, xg, bg, self_coef, n, sub, out=torch.full((n, d), 7.0, device='cuda'))
-    keep = torch.zeros(n, dtype=torch.bool)
-    keep[rows.long().cpu()] = True
-    assert rel_l2(ys.cpu()[keep], want[keep]) < TOL and bool((ys.cpu()[~keep] == 7.0).all())
 
 
 @pytest.mark.parametrize('d,self_coef', [(128, 0.0), (64, 1.0), (32, 0.5), (8, 0.0), (260, 0.0)])
@@ -1014,53 +962,6 @@ def test_csr_from_coo_rejects_out_of_range_endpoints():
         csr_from_coo(torch.tensor([0, -1], device='cuda'), torch.tensor([1, 2], device='cuda'), 5)
 
 
-@pytest.mark.parametrize('n,m,d_in,d_out,hub', [(300, 3000, 128, 128, 150), (300, 3000, 64, 128, 0), (130, 900, 128, 64, 100),
-                                                (1000, 9000, 64, 64, 400), (17, 40, 128, 128, 0), (5000, 60000, 128, 128, 900)])
-def test_agg_gemm_matches_dense_closed_form(n, m, d_in, d_out, hub):
-    """gd_agg_gemm_f32: (A x) W^T + b in one kernel, hub rows (> 64 in-edges) through the pre-aggregated extra
-    operand rows; also a row subset with the packed ReLU gate (the layer-2 input-gradient form)."""
-    from gnndelete_amd import ops
-    from gnndelete_amd.graph import build_csr, CappedCSR
-    ei = random_graph(n, m, seed=n + d_in, isolate=3)
-    if hub:
-        src = torch.randperm(n)[:hub]
-        ei = torch.cat([ei, torch.stack([src, torch.full_like(src, 5)]), torch.stack([torch.full_like(src, 5), src])], 1)
-    g = torch.Generator().manual_seed(2)
-    x = torch.randn(n, d_in, generator=g)
-    w = torch.randn(d_out, d_in, generator=g) / d_in ** 0.5
-    b = torch.randn(d_out, generator=g)
-    gr = build_csr(ei.cuda(), n, 'gcn')
-    a = torch.zeros(n, n, dtype=torch.float64)
-    rp, col, val = gr.rowptr.cpu().long(), gr.col.cpu().long(), gr.val.cpu().double()
-    for i in range(n):
-        a[i].index_add_(0, col[rp[i]:rp[i + 1]], val[rp[i]:rp[i + 1]])
-    want = a @ x.double() @ w.double().t() + b.double()
-    cap = CappedCSR(gr.rowptr, gr.col, gr.val, n, cap=64 if n % 2 else 256)      # both: hub rows / long rows walked in segments
-    assert cap.n_hub == int(((rp[1:] - rp[:-1]) > (64 if n % 2 else 256)).sum())
-    xe = cap.operand(x.cuda())
-    ops.aggregate_hubs(cap, xe)
-    y = ops.agg_gemm(cap, xe, w.cuda(), bias=b.cuda())
-    assert rel_l2(y.cpu(), want) < TOL
-    # work-item form: the balanced SpMM's items, hub pieces summed by the fix-up, no operand copy
-    y_ext = torch.full((n + gr.plan.n_slots, d_out), float('nan'), device='cuda')
-    y2 = ops.agg_gemm_items(gr, x.cuda(), w.cuda(), b.cuda(), y_ext)
-    assert rel_l2(y2.cpu(), want) < TOL
-    # subset of rows + gate bits, weight given as [d_in, d_out]
-    rows = torch.randperm(n, generator=g)[: max(1, n // 3)].sort().values.int()
-    gate = torch.randint(0, 2, (rows.numel(), d_out), generator=g).bool()
-    bits = torch.zeros(rows.numel(), d_out // 32, dtype=torch.int64)
-    for f in range(d_out):
-        bits[:, f // 32] |= gate[:, f].long() << (f % 32)
-    bits = bits.to(torch.int32) if d_out < 32 else (bits & 0xFFFFFFFF).to(torch.int64).to(torch.int32)
-    out = torch.zeros(n, d_out, device='cuda')
-    ops.agg_gemm(cap, xe, w.t().contiguous().cuda(), rows=rows.cuda(), gate_bits=bits.cuda(), out=out, w_out_in=False)
-    want_g = (a @ x.double() @ w.double().t())[rows.long()] * gate.double()
-    assert rel_l2(out.cpu()[rows.long()], want_g) < TOL
-    untouched = torch.ones(n, dtype=torch.bool)
-    untouched[rows.long()] = False
-    assert float(out.cpu()[untouched].abs().max()) == 0.0 if untouched.any() else True
-
-
 @pytest.mark.parametrize('n,d_in,d_out,select', [(500, 128, 64, False), (500, 128, 64, True), (77, 64, 32, True),
                                                  (300, 128, 128, False), (1, 32, 64, False)])
 def test_rows_gemm_dots_matches_fp64(n, d_in, d_out, select, matrix_split):
@@ -1364,6 +1265,58 @@ def test_segment_softmax_and_typed_weighted_sum_match_autograd(n, m, R, d):
     assert rel_l2(mm.detach().cpu(), m64.detach()) < TOL
     assert rel_l2(xg.grad.cpu(), x64.grad) < TOL
     assert rel_l2(eg.grad.cpu(), e64.grad) < 2e-5
+
+
+@pytest.mark.parametrize('n,m,R,din,dout,nb,coef', [(60, 500, 5, 128, 64, 4, False), (300, 4000, 21, 128, 128, 4, True), (40, 0, 3, 8, 8, None, True),
+                                                    (50, 700, 4, 24, 12, None, False), (1000, 30000, 102, 128, 64, 4, True)])
+def test_typed_conv_with_trainable_relation_weights_matches_fp64_autograd(n, m, R, din, dout, nb, coef):
+    """ops.typed_conv: y_i = sum_e c_e x_j W_r with TRAINABLE relation weights (block-diagonal or dense) - c_e the mean weights
+    of RGCNConv or given per-edge coefficients (RGATConv's attention) - forward, input gradient (the typed conv kernels),
+    relation-weight gradient (gd_typed_wgrad_f32) and coefficient gradient (gd_typed_edge_dot_f32) against fp64 autograd over
+    the plain per-edge formula; relations without edges get a zero gradient; bit-reproducible."""
+    from gnndelete_amd import ops
+    from gnndelete_amd.graph import TypedNodeCSR
+    g = torch.Generator().manual_seed(n + R)
+    ei = torch.randint(0, n, (2, m), generator=g)
+    et = torch.randint(0, max(R - 1, 1), (m,), generator=g)               # the last relation has no edge
+    x = torch.randn(n, din, generator=g)
+    blocks = nb or 1
+    w = torch.randn(R, blocks, din // blocks, dout // blocks, generator=g) * 0.2
+    c = torch.rand(m, generator=g) + 0.1 if coef else None
+    gy = torch.randn(n, dout, generator=g)
+    # ---- fp64 reference
+    x64, w64 = x.double().requires_grad_(), w.double().requires_grad_()
+    c64 = c.double().requires_grad_() if coef else None
+    if m:
+        if coef:
+            ce = c64
+        else:
+            cnt = torch.zeros(R * n, dtype=torch.float64).index_add_(0, et * n + ei[1], torch.ones(m, dtype=torch.float64))
+            ce = 1.0 / cnt[et * n + ei[1]]
+        msg = torch.einsum('ebi,ebio->ebo', x64[ei[0]].view(m, blocks, -1), w64[et]).reshape(m, dout) * ce[:, None]
+        y64 = torch.zeros(n, dout, dtype=torch.float64).index_add(0, ei[1], msg)
+    else:
+        y64 = (x64.sum() + w64.sum()) * 0.0 + torch.zeros(n, dout, dtype=torch.float64)
+    (y64 * gy.double()).sum().backward()
+    # ---- kernels
+    tg = TypedNodeCSR(ei.cuda(), et.cuda(), n, R)
+    wk = (w if nb else w.view(R, din, dout)).cuda().requires_grad_()
+    xk = x.cuda().requires_grad_()
+    ck = c.cuda().requires_grad_() if coef else None
+    y = ops.typed_conv(xk, tg, wk, blocks, ck)
+    (y * gy.cuda()).sum().backward()
+    tol = 2e-5
+    assert rel_l2(y.detach().cpu(), y64.detach()) < tol or m == 0
+    assert rel_l2(xk.grad.cpu(), x64.grad) < tol or m == 0
+    assert rel_l2(wk.grad.cpu().view_as(w), w64.grad) < tol or m == 0
+    assert float(wk.grad.view(R, -1)[R - 1].abs().max()) == 0.0
+    if coef and m:
+        assert rel_l2(ck.grad.cpu(), c64.grad) < tol
+    if m:
+        xk2, wk2 = x.cuda().requires_grad_(), wk.detach().clone().requires_grad_()
+        y2 = ops.typed_conv(xk2, tg, wk2, blocks, c.cuda() if coef else None)
+        (y2 * gy.cuda()).sum().backward()
+        assert torch.equal(y2, y) and torch.equal(wk2.grad, wk.grad) and torch.equal(xk2.grad, xk.grad)
 
 
 @pytest.mark.parametrize('form', ['wave', 'tile'])
