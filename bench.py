@@ -163,7 +163,7 @@ def partition_estimate(eng, world, ctl, single_us, link_gbs=100.0, l1_share=0.29
             'note': 'informational: the partitioned step is the headline at every N; link rate and launch overheads are assumptions, no multi-GPU run has been recorded'}
 
 
-def make_kg_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1, group=None, partition=False):
+def make_kg_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1, group=None, partition=False, **engine_opts):
     from gnndelete_amd.engine import NodeembEngine
     model = model.to(device)
     ei = data.edge_index[:, data.dr_mask].to(device).contiguous()
@@ -177,7 +177,7 @@ def make_kg_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1, gr
         from gnndelete_amd.dist_engine import PartitionedNodeembEngine
         return PartitionedNodeembEngine(*common, rank, world, loss_type=args.loss_type, alpha=0.5, lr=1e-3,
                                         use_graph=not args.no_graph, group=group, edge_type=et, overlap=getattr(args, 'dist_overlap', None))
-    return NodeembEngine(*common, loss_type=args.loss_type, alpha=0.5, lr=1e-3, use_graph=not args.no_graph, edge_type=et)
+    return NodeembEngine(*common, loss_type=args.loss_type, alpha=0.5, lr=1e-3, use_graph=not args.no_graph, edge_type=et, **engine_opts)
 
 
 def time_typed_conv(eng):
@@ -321,6 +321,35 @@ def kg_main(args, device, rank=0, world=1, group=None, barrier=lambda: None, ctl
                       'S1': int(ni1.sum()), 'S2': int(ni2.sum()), 'hip_graph': not args.no_graph,
                       'matrix_products': matrix_products_label(), 'parallelism': 'single'},
            'roofline': time_typed_conv(eng), 'final_loss': float(eng.loss_history()[-1, 0])}
+    if not args.no_cached_rate:
+        # informational only (never `value`): the epoch as delete_gnn.py --fullgraph runs it by default - the frozen conv1 output
+        # computed once, conv2's input gradient only on the Del-1 rows that read it (identical Del weights, tests/test_engine_gpu.py)
+        out['extras'] = {}
+
+        def after_ten(**opts):             # the Del weights ten iterations from the request's state
+            model.load_state_dict(state)
+            e_ = make_kg_engine(args, data, model, neg, ni1, ni2, device, **opts)
+            for _ in range(10):
+                e_.step()
+            torch.cuda.synchronize()
+            return model.deletion1.deletion_weight.detach().clone(), model.deletion2.deletion_weight.detach().clone()
+        w_full = after_ten()
+        rel_ = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        for key, opts in (('iters_per_s_affected_rows_only', dict(affected_rows_only=True)),
+                          ('iters_per_s_trainer_default', dict(affected_rows_only=True, cache_layer1=True))):
+            w_opt = after_ten(**opts)
+            out['extras'][key + '_W_rel_l2_vs_full_step_after_10_iterations'] = [rel_(w_opt[0], w_full[0]), rel_(w_opt[1], w_full[1])]
+            model.load_state_dict(state)
+            e2 = make_kg_engine(args, data, model, neg, ni1, ni2, device, **opts)
+            for _ in range(args.warmup):
+                e2.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            e2.run(args.steps, unroll=args.unroll)
+            torch.cuda.synchronize()
+            out['extras'][key] = args.steps / (time.perf_counter() - t1)
+            del e2
+        model.load_state_dict(state)
     if not args.no_cpu_baseline:
         iters = max(1, min(args.cpu_baseline_iters, 2))
         cpu_data = data.clone().cpu() if hasattr(data, 'clone') else data

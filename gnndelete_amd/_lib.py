@@ -38,7 +38,7 @@ PROTOTYPES = {
     'gd_rgcn_tile_kl': (ctypes.c_int32, [_i32, _i32, _i32, _i32]),
     'gd_rgcn_pack_weight_f32': (ctypes.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     'gd_rgcn_wave_covers': (ctypes.c_int32, [_i32, _i32, _i32]),
-    'gd_rgcn_wave_conv_f32': (ctypes.c_int, [_p, _i32, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _i32, _i32, _p]),
+    'gd_rgcn_wave_conv_f32': (ctypes.c_int, [_p, _i32, _i32, _p, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i32, _p, _i64, _i32, _i32, _i32, _p]),
     'gd_rgcn_tile_conv_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _p, _i64, _i32, _p, _i32, _i32, _p, _i64, _i32,
                                              _i32, _p, _p, _i32, _p, _p]),
     'gd_rgcn_mean_f32': (ctypes.c_int, [_p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p]),
@@ -91,6 +91,7 @@ PROTOTYPES = {
     'gd_segment_softmax_f32': (ctypes.c_int, [_p, _p, _i32, _p, _p]),
     'gd_segment_softmax_bwd_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p]),
     'gd_rowpair_dot_f32': (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
+    'gd_spmm_csr_onepass_aux_f32': (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _p]),
     'gd_typed_wgrad_f32': (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _p]),
     'gd_typed_edge_dot_f32': (ctypes.c_int, [_p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i32, _i32, _i32, _p, _p]),
     'gd_comm_unique_id': (ctypes.c_int, [_p]),

@@ -45,12 +45,12 @@ namespace gd {
 using f32x4w = __attribute__((ext_vector_type(4))) float;
 using u32x4w = __attribute__((ext_vector_type(4))) unsigned int;
 
-template <int KL, int OW, int TILE, int DEPTH, int BPW>
+template <int KL, int OW, int TILE, int DEPTH, int BPW, bool RELU>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEPTH == 1 ? 3 : 2))) void rgcn_wave_kernel(
     const int32_t* __restrict__ job_tile, int32_t n_tiles, const int32_t* __restrict__ tile_unit_ptr,
     const int32_t* __restrict__ unit_rel, const int4* __restrict__ unit_edges, const int32_t* __restrict__ unit_row,
     const float* __restrict__ x, int64_t ldx, const float4* __restrict__ wpk4, float* __restrict__ y, int64_t ldy,
-    int32_t n_nodes, int64_t n_x_bytes, int32_t empty_unit) {
+    int32_t n_nodes, int64_t n_x_bytes, int32_t empty_unit, int32_t xcd_blocks) {
   // BPW diagonal blocks per wave (a job is (tile, BPW consecutive blocks); 2 exists for 16-wide blocks as an opt-in, see the launch)
   constexpr int KW = BPW * KL;                             // gathered floats per source row
   constexpr int LPR = KW / 4, GROUPS = 64 / LPR, ROUNDS = 16 / GROUPS, AP = KW + 4, NOH = OW / 16, NMM = KL / 16, CP = BPW * OW + 4;
@@ -60,7 +60,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEPTH == 1 ?
   __shared__ __attribute__((aligned(16))) int e_lds[128];             // one unit's 64 (source, weight) pairs
   const int lane = threadIdx.x, b = blockIdx.x;
   // b = 8 JPT q + 8 t + xcd: the jobs of a tile run on the same XCD (workgroups go round the XCDs), next to each other
-  const int ot = BPW * ((b >> 3) % JPT), ti = ((b / (8 * JPT)) << 3) + (b & 7);     // ot = the job's first diagonal block
+  int ot = BPW * ((b >> 3) % JPT), ti = ((b / (8 * JPT)) << 3) + (b & 7);     // ot = the job's first diagonal block
+  if (BPW == 1 && xcd_blocks) {
+    // lab mapping (GD_RGCN_WAVE_XCD_BLOCKS=1): diagonal block t on the XCD pair (2 t, 2 t + 1), so that an L2
+    // serves the 128-byte column slice t of the source rows (a quarter of the table) - against reading every tile's unit plan
+    // on four XCDs instead of one.  Measured on the biokg request: see NOTES round 5.
+    const int xcd = b & 7;
+    ot = xcd >> 1;
+    ti = ((b >> 3) << 1) + (xcd & 1);
+  }
   if (ti >= n_tiles) return;
   const int tile = __builtin_amdgcn_readfirstlane(job_tile ? job_tile[ti] : ti);
   const int u0 = __builtin_amdgcn_readfirstlane(tile_unit_ptr[tile]), u1 = __builtin_amdgcn_readfirstlane(tile_unit_ptr[tile + 1]);
@@ -119,9 +127,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEPTH == 1 ?
   auto compute = [&](const float4 (&rows)[ROUNDS][4], const float (&wt)[ROUNDS][4], float4 (&wf)[BPW][NOH][NMM], int nrow, int rel_cur, int rel_next) {
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-      float4 s = make_float4(wt[r][0] * rows[r][0].x, wt[r][0] * rows[r][0].y, wt[r][0] * rows[r][0].z, wt[r][0] * rows[r][0].w);
+      // RELU: the conv reads relu(x) (RGCN's layer 2 reads relu(z1), rgcn.py:36-37) - formed here, where the rows land, instead
+      // of in a pass of its own over [n, d] (a torch clamp kernel, 15 us of the biokg step; the launch is fabric-bound)
+      auto in = [&](const float4& v) { return RELU ? make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)) : v; };
+      const float4 v0 = in(rows[r][0]);
+      float4 s = make_float4(wt[r][0] * v0.x, wt[r][0] * v0.y, wt[r][0] * v0.z, wt[r][0] * v0.w);
 #pragma unroll
-      for (int k = 1; k < 4; ++k) s = f4_fma(wt[r][k], rows[r][k], s);
+      for (int k = 1; k < 4; ++k) s = f4_fma(wt[r][k], in(rows[r][k]), s);
       *reinterpret_cast<float4*>(a_tile + (GROUPS * r + g) * AP + 4 * gl) = s;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -257,7 +269,7 @@ extern "C" int32_t gd_rgcn_wave_covers(int32_t d_in, int32_t d_out, int32_t n_bl
 extern "C" int gd_rgcn_wave_conv_f32(const int32_t* job_tile, int32_t n_tiles, int32_t tile, const int32_t* tile_unit_ptr,
                                      int32_t n_units, const int32_t* unit_rel, const int32_t* unit_edges, const int32_t* unit_row,
                                      const float* x, int64_t ldx, int32_t d_in, const float* packed_w, int32_t n_blocks, float* y,
-                                     int64_t ldy, int32_t d_out, int32_t n_nodes, void* stream) {
+                                     int64_t ldy, int32_t d_out, int32_t n_nodes, int32_t relu_in, void* stream) {
   using namespace gd;
   GD_REQUIRE(tile_unit_ptr && unit_rel && unit_edges && unit_row && x && packed_w && y, GD_E_NULL, "gd_rgcn_wave_conv_f32: null pointer");
   GD_REQUIRE(wave_geometry(d_in, d_out, n_blocks), GD_E_DIM,
@@ -285,10 +297,19 @@ extern "C" int gd_rgcn_wave_conv_f32(const int32_t* job_tile, int32_t n_tiles, i
   // the sibling's half line hits the L2 anyway: FETCH_SIZE is at the gathered volume), so one block per wave stays the default
   const char* env_bpw = getenv("GD_RGCN_WAVE_BPW");
   const int bpw16 = env_bpw && atoi(env_bpw) == 2 ? 2 : 1;
-#define GD_RW_LAUNCH(KL, OW, DEPTH, BPW)                                                                                     \
-  hipLaunchKernelGGL((rgcn_wave_kernel<KL, OW, 64, DEPTH, BPW>), dim3(tile_groups * 8 * (4 / BPW)), dim3(64), 0, s, job_tile, n_tiles, \
+  const char* env_xb = getenv("GD_RGCN_WAVE_XCD_BLOCKS");
+  const int xcd_blocks = env_xb && atoi(env_xb) == 1 ? 1 : 0;
+  const unsigned pair_groups = (unsigned)((n_tiles + 1) / 2);
+#define GD_RW_LAUNCH1(KL, OW, DEPTH, BPW, RELU)                                                                              \
+  hipLaunchKernelGGL((rgcn_wave_kernel<KL, OW, 64, DEPTH, BPW, RELU>),                                                        \
+                     dim3((BPW == 1 && xcd_blocks) ? pair_groups * 8 : tile_groups * 8 * (4 / BPW)), dim3(64), 0, s, job_tile, n_tiles, \
                      tile_unit_ptr, unit_rel, reinterpret_cast<const int4*>(unit_edges), unit_row, x, ldx,                 \
-                     reinterpret_cast<const float4*>(packed_w), y, ldy, n_nodes, n_x_bytes, n_units)
+                     reinterpret_cast<const float4*>(packed_w), y, ldy, n_nodes, n_x_bytes, n_units, xcd_blocks)
+#define GD_RW_LAUNCH(KL, OW, DEPTH, BPW)              \
+  do {                                                \
+    if (relu_in) GD_RW_LAUNCH1(KL, OW, DEPTH, BPW, true); \
+    else GD_RW_LAUNCH1(KL, OW, DEPTH, BPW, false);    \
+  } while (0)
 #define GD_RW_CASE(KL, OW)                                  \
   do {                                                      \
     if (KL == 16 && bpw16 == 2) {                           \
@@ -308,5 +329,6 @@ extern "C" int gd_rgcn_wave_conv_f32(const int32_t* job_tile, int32_t n_tiles, i
   }
 #undef GD_RW_CASE
 #undef GD_RW_LAUNCH
+#undef GD_RW_LAUNCH1
   return launched("rgcn_wave_conv");
 }

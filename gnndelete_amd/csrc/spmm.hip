@@ -112,14 +112,20 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(const int32_t* __restrict
 // xcd_bounds (optional, 9 ints): XCD k sweeps the items [xcd_bounds[k], xcd_bounds[k+1]) instead of an equal eighth -
 // the host balances the ranges by bytes moved (a self-loop-only row costs two row transfers, a 64-edge piece 65),
 // so that no XCD's fabric link idles while another still has a third of its traffic to go.
-template <int LPR, int VPL, int U, bool EXACT, bool ADDR32>
+// AUX (GATConv's backward, gat.hip): the edge values are not read from `val` but THROUGH a permutation from an interleaved
+// (weight, addend) array in another edge order - w[k] = aux[perm[k]].x - and the addends of a row's entries are summed into
+// aux_sum[row]: the transposition pass that used to make both (gat_transpose_edge_kernel, 33 us of the 775 us GAT step: 1.84 M
+// random 8-byte gathers at 8 lanes per row) disappears into this kernel, where the same gather is one more load per visit
+// that arrives behind the row gathers.  perm is fetched a visit ahead with the indices, aux at the top of the visit.
+template <int LPR, int VPL, int U, bool EXACT, bool ADDR32, bool AUX = false>
 __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items, int32_t n_items,
                                                   const int32_t* __restrict__ xcd_bounds,
                                                   const int32_t* __restrict__ col, const float* __restrict__ val,
                                                   const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
                                                   int64_t ldy, const float* __restrict__ bias, float self_coef,
                                                   const float* __restrict__ xs, float* __restrict__ scratch, int32_t d4,
-                                                  int32_t nnz) {
+                                                  int32_t nnz, const int32_t* __restrict__ perm = nullptr,
+                                                  const float2* __restrict__ aux = nullptr, float* __restrict__ aux_sum = nullptr) {
   constexpr int G = kWave / LPR;
   constexpr int kXcd = 8;
   const int lane = threadIdx.x & 63;
@@ -162,7 +168,8 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
   Desc d0 = uniform(dv), d1 = uniform(dv1);
   int kk = min(d0.start + lane, nnz - 1);
   int c = col[kk];
-  float w = val ? val[kk] : 1.0f;
+  float w = AUX ? 0.f : (val ? val[kk] : 1.0f);
+  int pk = AUX ? perm[kk] : 0;
   // One-launch form (gd_spmm_csr_onepass_f32): slot == -2 marks a GROUP member - the four waves of a block visit four
   // consecutive, 4-aligned items at the same time, and a hub row (more than 64 in-edges) is laid out as such a
   // quadruple, member w = wave w's own contiguous share [start, end) of the row's edges (walked 64 at a time: the
@@ -170,16 +177,25 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
   // fetched in place).  The four partial rows meet in LDS and wave 0 adds them in wave order (+ self term + bias) and
   // writes the row: no scratch rows, no fix-up launch, no atomics, a fixed summation order.  row < 0 = padding.
   __shared__ float4 grp_red[4][LPR * VPL];
+  __shared__ float grp_aux[4];
   for (; i < i1; i += stride) {
     const int row = d0.row, slot = d0.slot;
     int base = d0.start;
     int c_cur = c;
     float w_raw = w;
+    float a_raw = 0.f;                                   // AUX: this lane's addend
+    if (AUX) {
+      const float2 ad = aux[pk];
+      w_raw = ad.x;
+      a_raw = ad.y;
+    }
     // prefetch (clamped, branch-free): descriptor of the visit after next, indices of the next visit
     if (lane == 0) dv = items[min(i + 2 * stride, i1 - 1)];
     kk = min(d1.start + lane, nnz - 1);
     c = col[kk];
-    w = val ? val[kk] : 1.0f;
+    if (AUX) pk = perm[kk];
+    else w = val ? val[kk] : 1.0f;
+    float a_sum = 0.f;                                   // AUX: sum of the addends of a group member's chunks
     float4 acc[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_zero();
@@ -290,13 +306,28 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
             }
         }
       }
+      if (AUX && slot == -2) a_sum += wave_sum(lane < cnt ? a_raw : 0.f);
       base += kWave;
       if (base >= d0.end) break;
       const int k2 = min(base + lane, nnz - 1);
       c_cur = col[k2];
-      w_raw = val ? val[k2] : 1.0f;
+      if (AUX) {
+        const float2 ad = aux[perm[k2]];
+        w_raw = ad.x;
+        a_raw = ad.y;
+      } else {
+        w_raw = val ? val[k2] : 1.0f;
+      }
     }
     if (multi) {
+      if (AUX) {                                   // (two rows at most where AUX is built: 64 floats and wider)
+        const int cnt0 = d0.end - d0.start;
+        const float s0 = wave_sum(lane < min(b1, cnt0) ? a_raw : 0.f), s1 = wave_sum((lane >= b1 && lane < cnt0) ? a_raw : 0.f);
+        if (lane == 0) {
+          aux_sum[row] = s0;
+          if (nr > 1) aux_sum[row + 1] = s1;
+        }
+      }
 #pragma unroll
       for (int q = 0; q < MAXR; ++q) {
         if (q < nr) {                              // (wave-uniform)
@@ -316,13 +347,19 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
     }
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = f4_group_sum<LPR>(acc[v]);
+    if (AUX && slot == -1 && row >= 0) {          // a whole row in one item: its addends' sum
+      const float s1 = wave_sum(lane < d0.end - d0.start ? a_raw : 0.f);
+      if (lane == 0) aux_sum[row] = s1;
+    }
     if (slot == -2) {          // group member (block-uniform: the planner aligns the quadruples and the XCD ranges to 4)
       const int wave = threadIdx.x >> 6;
       if (g == 0) {
 #pragma unroll
         for (int v = 0; v < VPL; ++v) grp_red[wave][li + v * LPR] = acc[v];
       }
+      if (AUX && lane == 0) grp_aux[wave] = a_sum;
       __syncthreads();
+      if (AUX && wave == 0 && lane == 0 && row >= 0) aux_sum[row] = ((grp_aux[0] + grp_aux[1]) + grp_aux[2]) + grp_aux[3];
       if (wave == 0 && g == 0) {
         char* ob = reinterpret_cast<char*>(y + (int64_t)row * ldy);
         const char* sb = reinterpret_cast<const char*>(xs + (int64_t)row * ldx);
@@ -366,6 +403,22 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
                                                            float* __restrict__ scratch, int32_t d4, int32_t nnz) {
   spmm_persist_body<LPR, VPL, U, EXACT, ADDR32>(items, n_items, xcd_bounds, col, val, x, ldx, y, ldy, bias, self_coef, xs,
                                                 scratch, d4, nnz);
+}
+
+// spmm_persist_body with edge values read through a permutation (AUX above): the source-major aggregation of GATConv's backward
+// (val / bias / xs / scratch stay kernel arguments although the host passes NULL / x: with constants in their place this
+//  instantiation crashes the inliner of ROCm 7.2's clang - updateCGAndAnalysisManagerForPass)
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_persist_aux_kernel(const int4* __restrict__ items, int32_t n_items,
+                                                               const int32_t* __restrict__ xcd_bounds,
+                                                               const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                               const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                                               int64_t ldy, const float* __restrict__ bias, float self_coef,
+                                                               const float* __restrict__ xs, float* __restrict__ scratch, int32_t d4,
+                                                               int32_t nnz, const int32_t* __restrict__ perm,
+                                                               const float2* __restrict__ aux, float* __restrict__ aux_sum) {
+  spmm_persist_body<LPR, 1, 4, true, true, true>(items, n_items, xcd_bounds, col, val, x, ldx, y, ldy, bias, self_coef, xs, scratch, d4,
+                                                 nnz, perm, aux, aux_sum);
 }
 
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(const int4* __restrict__ split, int32_t n_split,
@@ -598,4 +651,33 @@ extern "C" int gd_spmm_csr_onepass_f32(const int32_t* items, int32_t n_items, co
   GD_REQUIRE(aligned16(xs) && xs != y, GD_E_ALIGN, "gd_spmm_csr_onepass_f32: bad x_self");
   return launch_persist(items, n_items, col, val, x, ldx, y, ldy, bias, self_coef, xs, nullptr, d, nnz, x_rows,
                         xcd_bounds, (hipStream_t)stream);
+}
+
+extern "C" int gd_spmm_csr_onepass_aux_f32(const int32_t* items, int32_t n_items, const int32_t* col, const int32_t* perm,
+                                           const float* aux, const float* x, int64_t ldx, float* y, int64_t ldy, float* aux_sum,
+                                           int32_t d, int32_t nnz, int32_t x_rows, const int32_t* xcd_bounds, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(col && perm && aux && x && y && aux_sum && xcd_bounds && (items || n_items == 0), GD_E_NULL,
+             "gd_spmm_csr_onepass_aux_f32: null pointer");
+  GD_REQUIRE(n_items >= 0 && n_items % 4 == 0 && (d == 64 || d == 128) && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= d && ldy >= d, GD_E_DIM,
+             "gd_spmm_csr_onepass_aux_f32: d must be 64 or 128 (got %d), 16-byte row strides, n_items a multiple of 4", d);
+  GD_REQUIRE(aligned16(x) && aligned16(y) && aligned16(items) && (reinterpret_cast<uintptr_t>(aux) & 7u) == 0, GD_E_ALIGN,
+             "gd_spmm_csr_onepass_aux_f32: unaligned pointer");
+  GD_REQUIRE(x != y, GD_E_DIM, "gd_spmm_csr_onepass_aux_f32: x and y must not alias");
+  GD_REQUIRE(x_rows > 0 && x_rows <= (1 << 24) && ldx * 4 < (1 << 24) && ldy * 4 < (1 << 24) &&
+                 (int64_t)x_rows * ldx * 4 < (1ll << 32) && (int64_t)x_rows * ldy * 4 < (1ll << 32), GD_E_DIM,
+             "gd_spmm_csr_onepass_aux_f32: x and y must be smaller than 4 GiB with row ids and pitches below 2^24");
+  if (n_items == 0) return GD_OK;
+  int nblk = (n_items + 3) / 4;
+  if (nblk > 8192) nblk = 8192;
+  nblk = (nblk + 7) / 8 * 8;
+  const int4* it = reinterpret_cast<const int4*>(items);
+  const float2* a2 = reinterpret_cast<const float2*>(aux);
+  if (d == 64)
+    hipLaunchKernelGGL((spmm_persist_aux_kernel<16>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, it, n_items, xcd_bounds, col, (const float*)nullptr,
+                       x, ldx, y, ldy, (const float*)nullptr, 0.0f, x, (float*)nullptr, d / 4, nnz, perm, a2, aux_sum);
+  else
+    hipLaunchKernelGGL((spmm_persist_aux_kernel<32>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, it, n_items, xcd_bounds, col, (const float*)nullptr,
+                       x, ldx, y, ldy, (const float*)nullptr, 0.0f, x, (float*)nullptr, d / 4, nnz, perm, a2, aux_sum);
+  return launched("spmm_persist_aux");
 }

@@ -200,7 +200,11 @@ class NodeembEngine:
             # conv's fabric reads by ~10 % (FETCH_SIZE 4.41 -> 3.95 GB per layer-1 launch, profiles/r03_rgcn_reorder_ab.txt).
             # With the tile kernel that bought nothing (bound by its per-step dependent chain); the wave-private kernel runs
             # at the fabric rate, where bytes are time: 2.01 -> 1.89 ms per step on the synth-biokg request (round 4).
-            cache_layer1 = affected_rows_only = False
+            # (cache_layer1: as for the other backbones - conv1's output is loop-invariant; affected_rows_only: conv2's INPUT
+            #  GRADIENT is formed for the Del-1 rows only, the only rows that read it - see _conv2_backward_to_s1; the forward
+            #  stays whole: the DEC rows of a knowledge-graph request are the Df endpoints, most of the graph)
+            self._rgcn_rows_only = bool(affected_rows_only)
+            affected_rows_only = False
             reorder = os.environ.get('GD_RGCN_REORDER', '1') != '0'
             x = model.node_emb.weight.detach()[x.to(model.node_emb.weight.device)]      # frozen embedding lookup, once
         dev = x.device
@@ -317,14 +321,21 @@ class NodeembEngine:
                 self._fuse_loss1 = True
         # The launch-sized tail of the step (two split-K reductions with Adam + the loss finalize) as ONE launch
         # (gd_step_tail_f32) where both optimizers step in every iteration and both layers run their fused loss forms
-        self._tail = (self._fuse_loss1 and self._fuse_l2 and t1.folded and self.t2.folded and self.s1 > 0 and self.s2 > 0
+        # (round 5: also where a layer runs its UNFUSED loss / weight-gradient stages - the knowledge-graph request, whose
+        #  DEC rows lie outside the Del masks: the weight-gradient launches then leave their partial products, the loss kernels
+        #  their per-block partials, and four launch-sized kernels - two reductions, Adam, finalize - become this one)
+        self._tail = (t1.folded and self.t2.folded and self.s1 > 0 and self.s2 > 0
                       and loss_type in ('both_layerwise', 'both_all') and not self._overlap and self.h % 2 == 0 and self.o % 2 == 0
-                      and os.environ.get('GD_NO_STEP_TAIL') != '1')
+                      and os.environ.get('GD_NO_STEP_TAIL') != '1'
+                      and ((self._fuse_loss1 and self._fuse_l2)
+                           # (unfused stages: only where the weight-gradient launches are the split-K matrix kernels, whose partial
+                           #  products the tail reduces - widths of 32 / 64 / 128)
+                           or (self.h in (32, 64, 128) and self.o in (32, 64, 128) and os.environ.get('GD_TAIL_FUSED_ONLY') != '1')))
         self._tail_acc = [0, 0]
         self._arrive = torch.zeros(2, dtype=torch.int32, device=dev)     # step_tail's check-in counter (+ the word its address trick may name)
         # ... and with the tail launch doing the reduction, the W_D2 weight gradient's partial sums come out of the fused Del-2
         # kernel itself (gd_del_loss_bwd_wgrad_f32: p2 and dz2 are in its registers) - no weight-gradient launch, no dz2 buffer
-        self._fuse_wg2 = self._tail and os.environ.get('GD_NO_FUSED_WGRAD2') != '1'
+        self._fuse_wg2 = self._tail and self._fuse_l2 and os.environ.get('GD_NO_FUSED_WGRAD2') != '1'
         if self._fuse_wg2:
             self._lp2_blocks = _lib.lib().gd_rows_gemm_wgrad_blocks(self.s2)
             self._lp2 = torch.zeros(2 * max(1, self._lp2_blocks), **f32)
@@ -338,16 +349,22 @@ class NodeembEngine:
         if self._mode == 'rgcn':
             from .graph import TypedNodeCSR
             self.typed = TypedNodeCSR(edge_index, edge_type.to(dev), n, conv2.num_relations)
+            self.typed_s1 = None
+            if getattr(self, '_rgcn_rows_only', False) and self.s1 > 0:
+                in1 = torch.zeros(n, dtype=torch.bool, device=dev)
+                in1[self.idx1.long()] = True
+                self.typed_s1 = self.typed.restrict_bwd(in1)
             self.graph = None
             self._hbuf = torch.zeros(n, self.h, **f32)                # relu(z1) as the typed conv reads it
             self._dxbuf = torch.zeros(n, self.h, **f32)               # conv2's input gradient
             # tile plans and packed relation weights are made here, outside any graph capture
             for c_, din, dout, tr in ((conv1, self.x.shape[1], self.h, 0), (conv2, self.h, self.o, 0), (conv2, self.o, self.h, 1)):
                 if int(_lib.lib().gd_rgcn_tile_kl(din, dout, c_.num_blocks or 1, tr)) > 0 and os.environ.get('GD_RGCN_NODE_MAJOR') != '1':
+                    tg_ = self.typed_s1 if (tr and self.typed_s1 is not None) else self.typed
                     if ops.rgcn_wave_form(din, dout, c_.num_blocks or 1, n, din) and self.typed.num_relations < 65536:
-                        self.typed.wave_plan(bool(tr))
+                        tg_.wave_plan(bool(tr))
                     else:
-                        self.typed.tile_plan(bool(tr))
+                        tg_.tile_plan(bool(tr))
                     ops.rgcn_packed_weight(c_.weight.detach(), c_.num_blocks or 1, din, dout, tr)
         else:
             gmode = {'gcn': 'gcn', 'gin': 'sum', 'gat': 'gat', 'sage': 'mean'}[self._mode]
@@ -472,13 +489,15 @@ class NodeembEngine:
             ops.gat_forward_raw(g, h1, a_src, a_dst, c.bias, c.negative_slope, out=self.pre1,
                                 plan=self._plan2 if (self._rows_only and self._split1) else None)
 
-    def _rgcn_conv(self, conv, inp, out, trans):
+    def _rgcn_conv(self, conv, inp, out, trans, relu_in=False):
         """out = inp @ root (+ bias) + sum_r mean_{N_r} inp W_r (forward), or the input gradient with trans = 1:
-        out = inp @ root^T + the typed kernel on the transposed graph with W_r^T.  Raw kernel calls, no tape."""
+        out = inp @ root^T + the typed kernel on the transposed graph with W_r^T.  Raw kernel calls, no tape.
+        relu_in: both products read relu(inp), formed in their operand paths (no relu'd copy of inp)."""
         tg = self.typed
         nb = conv.num_blocks or 1
-        ops.rows_gemm(inp, None, conv.root.detach(), trans_w=bool(trans), bias=None if trans else conv.bias.detach(), out=out)
-        ops.rgcn_typed_accumulate(tg, inp, conv.weight.detach(), nb, int(trans), out)
+        ops.rows_gemm(inp, None, conv.root.detach(), trans_w=bool(trans), bias=None if trans else conv.bias.detach(), out=out,
+                      relu_in=relu_in)
+        ops.rgcn_typed_accumulate(tg, inp, conv.weight.detach(), nb, int(trans), out, relu_in=relu_in)
 
     def _conv2_forward(self):
         c = self.model.conv2
@@ -486,9 +505,14 @@ class NodeembEngine:
             if self._split1:
                 torch.where(self._sel1.bool()[:, None], self.z1, self.pre1, out=self._hbuf)
                 self._hbuf.clamp_(min=0)
+                self._rgcn_conv(c, self._hbuf, self.p2, 0)
+            elif ops.rgcn_wave_relu_ok(self.typed, self.z1, self.p2, c.num_blocks or 1) and os.environ.get('GD_RGCN_RELU_PASS') != '1':
+                # relu(z1) is formed where the two products read z1 (the typed conv's gathered rows, the root product's
+                # operand path): no clamp pass over [n, h], no torch op in the step
+                self._rgcn_conv(c, self.z1, self.p2, 0, relu_in=True)
             else:
                 torch.clamp(self.z1, min=0, out=self._hbuf)
-            self._rgcn_conv(c, self._hbuf, self.p2, 0)
+                self._rgcn_conv(c, self._hbuf, self.p2, 0)
         elif self._mode == 'gcn' and self._rows_only:
             if self._split1:
                 t2 = ops.rows_gemm_select(self.pre1, self.z1, self._sel1, c.lin.weight, trans_w=True, const_w=True, relu_in=True,
@@ -546,7 +570,13 @@ class NodeembEngine:
         c = self.model.conv2
         g = self.graph
         if self._mode == 'rgcn':
-            self._rgcn_conv(c, self.dz2, self._dxbuf, 1)
+            if self.typed_s1 is not None:
+                # affected rows only: the input gradient of conv2 on the Del-1 rows (root product on the index list, the typed
+                # kernel on the out-edges of those rows); identical dh, a sixth of the gathered rows on the biokg request
+                ops.rows_gemm(self.dz2, self.idx1, c.root.detach(), trans_w=True, out=self._dxbuf)
+                ops.rgcn_typed_accumulate(self.typed_s1, self.dz2, c.weight.detach(), c.num_blocks or 1, 1, self._dxbuf)
+            else:
+                self._rgcn_conv(c, self.dz2, self._dxbuf, 1)
             # dh[S1] = dx[S1] * [z1[S1] > 0]  (ReLU backward from the packed sign bits of the Del-1 output)
             ops.gate_rows(self._dxbuf, self.idx1, self.z1_pos, self.dh)
             return
@@ -710,22 +740,22 @@ class NodeembEngine:
             # ---- backward + update
             if lt == 'both_layerwise':
                 self._layer2_backward()                          # leaves dh for the next iteration
-                if not self._fuse_l2:
+                if not self._fuse_l2 and not self._tail:
                     self.adam2.apply(self.g2)
             elif lt == 'both_all':
                 self._layer2_backward(g2_accumulate=True)
                 self._wgrad1(True, self.dh)
-                if not self._fuse_l2:
+                if not self._fuse_l2 and not self._tail:
                     self.adam2.apply(self.g2)
             elif lt == 'only2_layerwise':
                 self._layer2_backward(to_w1=False)
-                if not self._fuse_l2:
+                if not self._fuse_l2 and not self._tail:
                     self.adam2.apply(self.g2)
             elif lt == 'only2_all':
                 self._layer2_backward()
                 a1, a1_idx = (self.pre1, self.idx1) if self._split1 else (self.xs1, None)
                 self._wgrad(a1, self.dh, self.idx1, self.s1, self.g1, False, self.ws1, adam=self.adam1, a_idx=a1_idx)
-                if not self._fuse_l2:
+                if not self._fuse_l2 and not self._tail:
                     self.adam2.apply(self.g2)
             # ---- loss sums -> history ring, advance the iteration counter (Adam's step number)
             p1, n1 = (self._lp1, self._lp1_blocks) if self._fuse_loss1 else (self.t1.partials, self.t1.n_partial_blocks())
@@ -776,9 +806,11 @@ class NodeembEngine:
             self._wgrad(self.p2, self.dz2c, None, self.s2, self.g2, g2_accumulate, self.ws2, a_idx=self.idx2,
                         adam=self.adam2)
         elif self._split2:
-            self._wgrad(self.p2, self.dz2, self.idx2, self.s2, self.g2, g2_accumulate, self.ws2, a_idx=self.idx2)
+            self._wgrad(self.p2, self.dz2, self.idx2, self.s2, self.g2, g2_accumulate, self.ws2, a_idx=self.idx2,
+                        adam=self.adam2 if self._tail else None)
         else:
-            self._wgrad(self.xs2, self.dz2, self.idx2, self.s2, self.g2, g2_accumulate, self.ws2)
+            self._wgrad(self.xs2, self.dz2, self.idx2, self.s2, self.g2, g2_accumulate, self.ws2,
+                        adam=self.adam2 if self._tail else None)
         if not to_w1:
             return
         if not self._fuse_l2:

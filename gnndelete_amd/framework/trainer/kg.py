@@ -212,7 +212,12 @@ class KGGNNDeleteNodeembTrainer(KGTrainer):
         lr, betas, eps = _adam_hyper(optimizer)
         engine = NodeembEngine(model, data.x, ei, z1_ori, z2_ori, dec, neg, m1, m2, loss_type=self.args.loss_type,
                                alpha=self.args.alpha, lr=lr, reduction='mean' if self.args.loss_fct == 'mse_mean' else 'sum',
-                               mask_1hop=m1, mask_2hop=m2, history=max(16, args.epochs), edge_type=et)
+                               mask_1hop=m1, mask_2hop=m2, history=max(16, args.epochs), edge_type=et,
+                               # as the link-prediction trainer: the frozen conv1 output is computed once and conv2's input
+                               # gradient only on the Del-1 rows that read it (identical Del weights; --no_layer1_cache /
+                               # --all_rows restore the epoch as upstream would run it)
+                               cache_layer1=not getattr(args, 'no_layer1_cache', False),
+                               affected_rows_only=not getattr(args, 'all_rows', False))
         engine.adam1.betas = engine.adam2.betas = betas
         engine.adam1.eps = engine.adam2.eps = eps
         best_metric = 0

@@ -414,6 +414,30 @@ class TypedNodeCSR:
         self.bwd, _ = self._runs(run_b[order_b], dst[order_b], r, n, w_edge[order_b])
         self.bwd_order = order_b if row_range is None else None    # bwd edge k = input edge bwd_order[k] (whole graphs only)
 
+    def restrict_bwd(self, node_mask):
+        """A view of this graph whose TRANSPOSED side keeps only the out-edges of the source nodes in node_mask (bool [n]): the
+        input gradient of a typed conv is then formed for those rows only (rows outside get nothing added).  The engine's
+        affected-rows option uses it for conv2's input gradient, which only the Del-1 rows read (S1: 16 % of the nodes of the
+        biokg request).  The forward side is shared; plans are cached per view."""
+        node_ptr, seg_ptr, seg_rel, col, w = self.bwd
+        dev = col.device
+        runs_per_node = (node_ptr[1:] - node_ptr[:-1]).long()
+        node_of_run = torch.repeat_interleave(torch.arange(self.n, device=dev), runs_per_node)
+        keep_run = node_mask.to(dev)[node_of_run]
+        seg_len = (seg_ptr[1:] - seg_ptr[:-1]).long()
+        keep_edge = torch.repeat_interleave(keep_run, seg_len)
+        new_len = seg_len[keep_run]
+        new_seg_ptr = torch.zeros(int(new_len.numel()) + 1, dtype=torch.int64, device=dev)
+        new_seg_ptr[1:] = torch.cumsum(new_len, 0)
+        new_node_ptr = torch.zeros(self.n + 1, dtype=torch.int64, device=dev)
+        new_node_ptr[1:] = torch.cumsum(torch.where(node_mask.to(dev), runs_per_node, torch.zeros_like(runs_per_node)), 0)
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        view = object.__new__(TypedNodeCSR)
+        view.n, view.num_relations = self.n, self.num_relations
+        view.fwd, view.fwd_order, view.bwd_order = self.fwd, self.fwd_order, None
+        view.bwd = (i32(new_node_ptr), i32(new_seg_ptr), seg_rel[keep_run].contiguous(), col[keep_edge].contiguous(), w[keep_edge].contiguous())
+        return view
+
     def rel_major(self):
         """The forward edges in RELATION-major order for the gradients of trainable relation weights (gd_typed_wgrad_f32):
         -> dict(rel_ptr int32 [R + 1], src, dst int32 [E], w float32 [E] (the mean weights 1 / |N_r(i)|), from_fwd int64 [E]:

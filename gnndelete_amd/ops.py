@@ -516,12 +516,26 @@ def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope, plan=Non
         ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split, ptr(g.col), ptr(a_src), ptr(a_dst), ptr(rowmax),
         ptr(rowsum), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(ade), ptr(da_dst), ptr(t_row),
         ptr(scratch), float(slope), d, g.nnz, stream_ptr(dev)), 'gd_gat_edge_grads_balanced_f32')
-    alpha_t = _ws_buf(bufs, 'alpha_t', (g.nnz,), dev)
     da_src = _ws_buf(bufs, 'da_src', (n,), dev)
+    pt = plan_t or g.plan_t
+    dh = None if bufs is None else _ws_buf(bufs, 'dh', (n, dy.shape[1]), dev)
+    if (d in (64, 128) and dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and n < 2 ** 24 and dy.stride(0) * 4 < 2 ** 24
+            and n * dy.stride(0) * 4 < 2 ** 32 and os.environ.get('GD_GAT_TRANSPOSE_PASS') != '1'):
+        # the source-major aggregation reads (alpha, score gradient) through the transpose permutation itself and sums the score
+        # gradients per source row: no transposition pass (gd_spmm_csr_onepass_aux_f32)
+        if dh is None:
+            dh = torch.empty(n, d, dtype=torch.float32, device=dev)
+        if plan_t is not None:
+            da_src.zero_()                  # (rows outside a subset are not visited)
+        items, n_items, bounds = pt.onepass(d)
+        check(_lib.lib().gd_spmm_csr_onepass_aux_f32(ptr(items), n_items, ptr(g.col_t), ptr(g.perm_t), ptr(ade), ptr(dy), dy.stride(0),
+                                                     ptr(dh), dh.stride(0), ptr(da_src), d, g.nnz, n, ptr(bounds), stream_ptr(dev)),
+              'gd_spmm_csr_onepass_aux_f32')
+        return dh, da_src, da_dst
+    alpha_t = _ws_buf(bufs, 'alpha_t', (g.nnz,), dev)
     check(_lib.lib().gd_gat_transpose_edges_f32(ptr(g.rowptr_t), ptr(g.perm_t), ptr(ade), n, ptr(alpha_t),
                                                 ptr(da_src), stream_ptr(dev)), 'gd_gat_transpose_edges_f32')
-    dh = _spmm_raw(g.rowptr_t, g.col_t, alpha_t, dy, None, 0.0, n, plan_t or g.plan_t,
-                   out=None if bufs is None else _ws_buf(bufs, 'dh', (n, dy.shape[1]), dev))
+    dh = _spmm_raw(g.rowptr_t, g.col_t, alpha_t, dy, None, 0.0, n, pt, out=dh)
     return dh, da_src, da_dst
 
 
@@ -634,10 +648,19 @@ def rgcn_wave_form(d_in, d_out, n_blocks, n_nodes=None, ldx=None):
     return True
 
 
-def rgcn_typed_accumulate(tg, x, weight, n_blocks, trans, y, edge_w=None):
+def rgcn_wave_relu_ok(tg, x, y, n_blocks, trans=0):
+    """Whether rgcn_typed_accumulate(..., relu_in=True) is available for this call (the wave-private kernel takes it)."""
+    d_in, d_out = x.shape[1], y.shape[1]
+    return (x.stride(0) % 4 == 0 and y.stride(0) % 4 == 0 and os.environ.get('GD_RGCN_NODE_MAJOR') != '1'
+            and int(_lib.lib().gd_rgcn_tile_kl(d_in, d_out, n_blocks, int(trans))) > 0
+            and rgcn_wave_form(d_in, d_out, n_blocks, tg.n, x.stride(0)) and tg.num_relations < 65536 and tg.fwd[3].numel() > 0)
+
+
+def rgcn_typed_accumulate(tg, x, weight, n_blocks, trans, y, edge_w=None, relu_in=False):
     """y += sum_r (weighted mean over the relation-r in-edges of x) @ W_r (trans: the input gradient on the transposed
     graph with W_r^T) - raw, no autograd.  The (tile, relation) kernel where the widths allow, the node-major one
-    otherwise or when GD_RGCN_NODE_MAJOR=1; edge_w (per edge of tg.fwd, in its order) replaces the mean weights."""
+    otherwise or when GD_RGCN_NODE_MAJOR=1; edge_w (per edge of tg.fwd, in its order) replaces the mean weights;
+    relu_in: the conv reads relu(x) - only the wave-private kernel forms it on the fly (rgcn_wave_relu_ok)."""
     d_in, d_out = x.shape[1], y.shape[1]
     arrays = tg.bwd if trans else tg.fwd
     if arrays[3].numel() == 0:
@@ -650,9 +673,11 @@ def rgcn_typed_accumulate(tg, x, weight, n_blocks, trans, y, edge_w=None):
         packed = rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans)
         check(_lib.lib().gd_rgcn_wave_conv_f32(ptr(p['job_tile']), p['n_tiles'], p['tile'], ptr(p['tile_unit_ptr']), p['n_units'], ptr(p['unit_rel']),
                                                ptr(p['unit_edges']), ptr(p['unit_row']), ptr(x), x.stride(0), d_in, ptr(packed),
-                                               n_blocks, ptr(y), y.stride(0), d_out, tg.n, stream_ptr(x.device)),
+                                               n_blocks, ptr(y), y.stride(0), d_out, tg.n, int(bool(relu_in)), stream_ptr(x.device)),
               'gd_rgcn_wave_conv_f32')
         return y
+    if relu_in:
+        raise _lib.GnnDeleteHipError('rgcn_typed_accumulate(relu_in=True) needs the wave-private kernel (check rgcn_wave_relu_ok)')
     if tiled:
         p = tg.tile_plan(bool(trans))
         packed = rgcn_packed_weight(weight, n_blocks, d_in, d_out, trans)

@@ -39,7 +39,7 @@ extern "C" {
                               6: gd_rows_gemm_ws_covers (weight-stationary form of the row GEMMs), gd_spmm_csr_rowgroup_f32;
                              7: gd_rgcn_wave_conv_f32 / gd_rgcn_wave_covers;
                              8: gd_build_source_hash (the library carries a stamp of the sources it was built from), gd_typed_wgrad_f32,
-                                gd_typed_edge_dot_f32; gd_agg_gemm_f32 and gd_spmm_csr_rowgroup_f32 removed (opt-in forms nobody defaulted) */
+                                gd_typed_edge_dot_f32, gd_spmm_csr_onepass_aux_f32; gd_agg_gemm_f32 and gd_spmm_csr_rowgroup_f32 removed (opt-in forms nobody defaulted) */
 
 enum {
   GD_OK = 0,
@@ -149,6 +149,17 @@ int gd_spmm_csr_onepass_f32(const int32_t* items, int32_t n_items, const int32_t
                             const float* x, int64_t ldx, float* y, int64_t ldy, const float* bias, float self_coef,
                             const float* x_self, int32_t d, int32_t nnz, int32_t x_rows, const int32_t* xcd_bounds,
                             void* stream);
+
+/* gd_spmm_csr_onepass_f32 with the edge values read THROUGH a permutation from an interleaved (weight, addend) array kept in
+ * another edge order (ABI 8): w[k] = aux[2 perm[k]], and aux_sum[row] = the sum of aux[2 perm[k] + 1] over the row's entries
+ * (fixed order).  GATConv's backward forms the attention weights and the logit gradients per edge in TARGET-major order and
+ * needs them SOURCE-major for the message gradient dh = A_alpha^T dy and for d a_src: this entry is that aggregation, the
+ * transposition pass (gd_gat_transpose_edges_f32) disappears into it.  d in {64, 128}; x and y below 4 GiB with row ids /
+ * pitches below 2^24; no bias / self term; items / xcd_bounds as for gd_spmm_csr_onepass_f32 (rows per item <= 2).
+ * Replaces the index_select / scatter chain of torch_geometric's GATConv backward (framework/models/gat.py:11-24). */
+int gd_spmm_csr_onepass_aux_f32(const int32_t* items, int32_t n_items, const int32_t* col, const int32_t* perm, const float* aux,
+                                const float* x, int64_t ldx, float* y, int64_t ldy, float* aux_sum, int32_t d, int32_t nnz,
+                                int32_t x_rows, const int32_t* xcd_bounds, void* stream);
 
 
 /* Per-relation mean aggregation of R-GCN ("typed SpMM") over a relation-major CSR:
@@ -288,12 +299,14 @@ int gd_rgcn_tile_conv_f32(const int32_t* tile_order, const int32_t* tile_step_pt
  *     unit_edges[U + 1][16][4][2]  (source node, weight as float bits) per edge of a slot; unused pairs = (n_nodes, 0.0f)
  *     job_tile[n_tiles]            launch order of the tiles (most units first) or NULL
  * tile must be 64.  y must hold the root / bias term (or zeros) on entry; relations are accumulated in ascending order,
- * the slots of a node by a fixed scan tree: bit-reproducible. */
+ * the slots of a node by a fixed scan tree: bit-reproducible. 
+ * relu_in != 0 (ABI 8): the conv reads relu(x) - RGCN's second layer reads relu(z1) (framework/models/rgcn.py:36-37) - formed
+ * where the gathered rows land instead of in a pass of its own over [n_nodes, d_in]. */
 int32_t gd_rgcn_wave_covers(int32_t d_in, int32_t d_out, int32_t n_blocks);
 int gd_rgcn_wave_conv_f32(const int32_t* job_tile, int32_t n_tiles, int32_t tile, const int32_t* tile_unit_ptr,
                           int32_t n_units, const int32_t* unit_rel, const int32_t* unit_edges, const int32_t* unit_row,
                           const float* x, int64_t ldx, int32_t d_in, const float* packed_w, int32_t n_blocks, float* y,
-                          int64_t ldy, int32_t d_out, int32_t n_nodes, void* stream);
+                          int64_t ldy, int32_t d_out, int32_t n_nodes, int32_t relu_in, void* stream);
 
 /* Random walks for GraphSAINT mini-batches (torch_geometric GraphSAINTRandomWalkSampler / torch_sparse random_walk as
  * used at framework/trainer/gnndelete_nodeemb.py:379-381, :734-736): out[s * n_walks + w] = node of walker w after s

@@ -583,3 +583,45 @@ def test_rgcn_engine_matches_oracle_training(dims, nr, loss_type, use_graph):
     tol = 1e-3 if loss_type == 'both_all' else 1e-4
     assert rel_l2(hip.deletion1.deletion_weight.detach().cpu(), ref.deletion1.deletion_weight.detach()) < tol
     assert rel_l2(hip.deletion2.deletion_weight.detach().cpu(), ref.deletion2.deletion_weight.detach()) < tol
+
+
+@pytest.mark.parametrize('dims,nr', [((128, 128, 64), 51), ((32, 32, 16), 21)])
+def test_rgcn_engine_trainer_defaults_give_the_same_step(dims, nr):
+    """What delete_gnn.py --fullgraph runs on a knowledge graph by default: the frozen conv1 output computed once
+    (cache_layer1) and conv2's INPUT GRADIENT formed only on the Del-1 rows that read it (affected_rows_only: the typed
+    kernel on the out-edges of those rows, TypedNodeCSR.restrict_bwd; the root product on the index list) - against the
+    whole step from the same state: same loss log, same Del weights (the restricted plan packs other units: fp32 rounding)."""
+    from types import SimpleNamespace
+    from gnndelete_amd.engine import NodeembEngine
+    from gnndelete_amd.framework.models import RGCNDelete
+    from oracle import gnndelete_ref as R
+    i, h, o = dims
+    data = _kg_request(700, 5000, nr, seed=3, n_df=60)
+    n = data.num_nodes
+    ni1, ni2 = R.non_df_masks(n, data.directed_df_edge_index, data.sdf_node_1hop_mask, data.sdf_node_2hop_mask)
+    torch.manual_seed(5)
+    hip = RGCNDelete(SimpleNamespace(in_dim=i, hidden_dim=h, out_dim=o), n, nr, ni1, ni2).cuda()
+    state = {k: v.clone() for k, v in hip.state_dict().items()}
+    ei, et = data.edge_index[:, data.dr_mask].cuda().contiguous(), data.edge_type[data.dr_mask].cuda().contiguous()
+    pos, pt = data.edge_index[:, data.df_mask], data.edge_type[data.df_mask]
+    fw = pt < nr
+    dec = pos[:, fw].cuda()
+    torch.manual_seed(9)
+    neg = R.negative_sampling_kg(pos[:, fw], pt[fw]).cuda()
+    with torch.no_grad():
+        z1o, z2o = hip.get_original_embeddings(data.x.cuda(), ei, et, return_all_emb=True)
+
+    def run(**opts):
+        hip.load_state_dict(state)
+        eng = NodeembEngine(hip, data.x.cuda(), ei, z1o, z2o, dec, neg, ni1, ni2, loss_type='both_layerwise', alpha=0.4, lr=1e-2,
+                            use_graph=True, edge_type=et, **opts)
+        for _ in range(5):
+            eng.step()
+        return eng, eng.loss_history().clone(), hip.deletion1.deletion_weight.detach().clone(), hip.deletion2.deletion_weight.detach().clone()
+    e0, h0, a0, b0 = run()
+    assert e0.typed_s1 is None and not e0.cache_layer1
+    e1, h1, a1, b1 = run(cache_layer1=True, affected_rows_only=True)
+    assert e1.typed_s1 is not None and e1.cache_layer1
+    assert int(e1.typed_s1.bwd[3].numel()) < int(e1.typed.bwd[3].numel())          # fewer out-edges walked
+    np.testing.assert_allclose(h1.numpy(), h0.numpy(), rtol=1e-5)
+    assert rel_l2(a1.cpu(), a0.cpu()) < 1e-5 and rel_l2(b1.cpu(), b0.cpu()) < 1e-5

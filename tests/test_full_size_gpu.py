@@ -199,11 +199,22 @@ def test_full_size_rgcn_fused_engine_matches_oracle():
         gc.collect()
         torch.cuda.empty_cache()
         return logs, out
+    # the epoch as delete_gnn.py --fullgraph runs it by default (conv1's output computed once, conv2's input gradient only on the
+    # Del-1 rows): the same ten iterations from the same state, held to the same bounds below
+    model.load_state_dict(state)
+    eng_t = bench.make_kg_engine(args, data, model, neg, ni1, ni2, dev, cache_layer1=True, affected_rows_only=True)
+    assert eng_t.typed_s1 is not None and eng_t.cache_layer1
+    for _ in range(iters):
+        eng_t.step()
+    hist_t = eng_t.loss_history()
+    trainer_w = (model.deletion1.deletion_weight.detach().double().cpu(), model.deletion2.deletion_weight.detach().double().cpu())
     logs64, (w1, w2, r1, r2) = run_oracle(torch.float64, None)
     for i, log in enumerate(logs64):
         assert abs(float(hist[i, 0]) - log['train_loss']) <= 1e-4 * abs(log['train_loss']), (i, float(hist[i, 0]), log)
+        assert abs(float(hist_t[i, 0]) - log['train_loss']) <= 1e-4 * abs(log['train_loss']), ('trainer defaults', i, float(hist_t[i, 0]), log)
     ens = [run_oracle(torch.float32, p)[1] for p in (None, 1, 2)]
     _assert_del_weights_within_fp32_spread('synth-biokg rgcn', hip_w, (w1, w2), [e[:2] for e in ens], iters)
+    _assert_del_weights_within_fp32_spread('synth-biokg rgcn, trainer defaults', trainer_w, (w1, w2), [e[:2] for e in ens], iters)
     # affected-node embeddings: north_star's 1e-4 wherever fp32 arithmetic delivers it - after ten both_layerwise iterations of
     # THIS request a correct fp32 implementation is itself ~2e-4 from the fp64 run in z1 (the ReLU between the layers gates the
     # layer-2 gradient with [z1 > 0]), so the bound is the larger of 1e-4 and twice the ensemble's distance

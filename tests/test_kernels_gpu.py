@@ -842,6 +842,15 @@ def test_rgcn_wave_conv_matches_oracle_and_tile_kernel(n, m, R, din, dout, monke
     monkeypatch.delenv('GD_RGCN_WAVE_DEPTH')
     got1, dx1 = run()
     assert torch.equal(got, got1) and torch.equal(dx, dx1)
+    # relu_in: the conv reads relu(x), formed where the gathered rows land - the same bits as the conv of a relu'd copy
+    xc = x.float().cuda()
+    wv = w.float().cuda()
+    y_a = torch.zeros(n, dout, device='cuda')
+    y_b = torch.zeros(n, dout, device='cuda')
+    assert ops.rgcn_wave_relu_ok(tg, xc, y_a, nb)
+    ops.rgcn_typed_accumulate(tg, xc, wv, nb, 0, y_a, relu_in=True)
+    ops.rgcn_typed_accumulate(tg, xc.clamp(min=0), wv, nb, 0, y_b)
+    assert torch.equal(y_a, y_b) and float(y_a.abs().max()) > 0
     monkeypatch.setenv('GD_RGCN_WAVE', '0')
     ref, dref = run()
     assert rel_l2(got.cpu(), ref.cpu()) < 1e-5 and rel_l2(dx.cpu(), dref.cpu()) < 1e-5
@@ -1021,6 +1030,45 @@ def test_gat_hub_row_with_more_pieces_than_feature_lanes(d, hub_degree):
     assert rel_l2(out.detach().cpu(), want.detach()) < TOL
     out.backward(up.float().cuda())
     assert rel_l2(xg.grad.cpu(), xr.grad) < 5e-5
+
+
+@pytest.mark.parametrize('d', [64, 128])
+def test_gat_backward_without_the_transposition_pass(d, monkeypatch):
+    """gd_spmm_csr_onepass_aux_f32: the source-major aggregation of GATConv's backward reads (attention weight, score
+    gradient) through the transpose permutation itself and sums the score gradients per source row - against the form with
+    the separate transposition pass (gd_gat_transpose_edges_f32 + gd_spmm_csr_onepass_f32): the message gradient bit for
+    bit (same weights, same summation order), d a_src to fp32 rounding (64-lane against 8-lane sums), on a graph with hub
+    rows in BOTH directions (group items), two-row items (d = 64), >= 8 k items, and on a row subset."""
+    from gnndelete_amd import ops
+    from gnndelete_amd.graph import SplitPlan, build_csr
+    n = 30000
+    g = torch.Generator().manual_seed(d)
+    hubs = [(5, 3000), (77, 300), (29990, 70)]
+    star_in = [torch.stack([torch.randint(0, n, (k,), generator=g), torch.full((k,), h)]) for h, k in hubs]
+    star_out = [torch.stack([torch.full((k,), h + 1), torch.randint(0, n, (k,), generator=g)]) for h, k in hubs]
+    ei = torch.cat([random_graph(n, 200000, seed=d)] + star_in + star_out, 1)
+    gr = build_csr(ei.cuda(), n, 'gat')
+    h = torch.randn(n, d, generator=g).cuda()
+    a_src, a_dst = torch.randn(n, generator=g).cuda(), torch.randn(n, generator=g).cuda()
+    dy = torch.randn(n, d, generator=g).cuda()
+    _, rowmax, rowsum = ops.gat_forward_raw(gr, h, a_src, a_dst, None, 0.2)
+    got = [t.clone() for t in ops.gat_backward_raw(gr, h, a_src, a_dst, rowmax, rowsum, dy, 0.2)]
+    again = ops.gat_backward_raw(gr, h, a_src, a_dst, rowmax, rowsum, dy, 0.2)
+    assert all(torch.equal(a, b) for a, b in zip(got, again))                      # bit-reproducible
+    monkeypatch.setenv('GD_GAT_TRANSPOSE_PASS', '1')
+    ref = [t.clone() for t in ops.gat_backward_raw(gr, h, a_src, a_dst, rowmax, rowsum, dy, 0.2)]
+    monkeypatch.delenv('GD_GAT_TRANSPOSE_PASS')
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])
+    assert rel_l2(got[1].cpu(), ref[1].cpu()) < 1e-6 and float((got[1] - ref[1]).abs().max()) < 1e-4 * float(ref[1].abs().max())
+    # source rows of a subset only (the rows a request can influence): the others keep a zero score gradient
+    rows = torch.cat([torch.tensor([6, 78, 0]), torch.randperm(n, generator=g)[:12000]]).unique().cuda()
+    plan_t = SplitPlan(gr.rowptr_t, rows=rows)
+    sub = ops.gat_backward_raw(gr, h, a_src, a_dst, rowmax, rowsum, dy, 0.2, plan_t=plan_t)
+    # (a subset pairs different light rows into two-row items at d = 64: another association of the same sums)
+    assert rel_l2(sub[0][rows].cpu(), got[0][rows].cpu()) < 1e-6 and rel_l2(sub[1][rows].cpu(), got[1][rows].cpu()) < 1e-6
+    other = torch.ones(n, dtype=torch.bool, device='cuda')
+    other[rows] = False
+    assert float(sub[1][other].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize('d', [64, 128, 16, 10])
