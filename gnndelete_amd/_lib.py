@@ -49,7 +49,7 @@ PROTOTYPES = {
     'gd_gat_aggregate_balanced_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p,
                                                      _p, _f32, _i32, _i32, _i32, _p]),
     'gd_gat_edge_grads_balanced_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _p,
-                                                      _p, _p, _p, _f32, _i32, _i32, _p]),
+                                                      _p, _p, _p, _f32, _i32, _i32, _p, _p]),
     'gd_row_dots_f32': (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
     'gd_gat_transpose_edges_f32': (ctypes.c_int, [_p, _p, _p, _i32, _p, _p, _p]),
     'gd_rank1_add2_f32': (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),

@@ -433,12 +433,13 @@ __global__ __launch_bounds__(256) void gat_fixup_fwd_kernel(const int4* __restri
 // indices one visit ahead): the neighbour rows are requested from the indices alone, the attention weights
 // (logits, row statistics) and the dy row arrive behind them.
 template <int LPR, int VPL, bool EXACT>
-__global__ __launch_bounds__(256) void gat_items_bwd_dalpha_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 1 ? (LPR >= 16 ? 8 : 7) : 1, 8))) void gat_items_bwd_dalpha_kernel(
     const int4* __restrict__ items, int32_t n_items, const int32_t* __restrict__ col,
     const float* __restrict__ a_src, const float* __restrict__ a_dst, const float* __restrict__ rowmax,
     const float* __restrict__ rowsum, const float* __restrict__ h, int64_t ldh, const float* __restrict__ dy,
     int64_t lddy, float2* __restrict__ ade, float* __restrict__ t_row,
-    float* __restrict__ da_dst, float* __restrict__ scratch_t, float slope, int32_t d4, int32_t nnz) {
+    float* __restrict__ da_dst, float* __restrict__ scratch_t, float slope, int32_t d4, int32_t nnz,
+    const int32_t* __restrict__ xcd_bounds) {
   constexpr int G = kWave / LPR;
   constexpr int U = 4;                                             // neighbour rows in flight per lane group
   constexpr int kXcd = 8;
@@ -448,11 +449,16 @@ __global__ __launch_bounds__(256) void gat_items_bwd_dalpha_kernel(
   const int stride = (gridDim.x / kXcd) * 4;                        // waves per XCD
   const int wx = (blockIdx.x / kXcd) * 4 + (threadIdx.x >> 6);
   const int per = (n_items + kXcd - 1) / kXcd;
-  const int i0 = xcd * per, i1 = min(n_items, i0 + per);
+  const int i0 = xcd_bounds ? xcd_bounds[xcd] : xcd * per, i1 = xcd_bounds ? xcd_bounds[xcd + 1] : min(n_items, i0 + per);
   int i = i0 + wx;
   if (i >= i1) return;
   __shared__ float pbuf[4][kWave];
+  __shared__ float grp_t[4], grp_v[4];
   float* pw = pbuf[threadIdx.x >> 6];
+  // One-launch form (SplitPlan.onepass items, one row per item): slot == -2 = member of a GROUP (a hub row as four consecutive,
+  // 4-aligned items): every member parks (alpha, <dy, h>) of its share and sums its part of t = sum alpha <dy, h>; the four
+  // parts meet in LDS, and each member then finishes the score gradients of ITS edges with the row's t and sums them for
+  // d a_dst - what took the pieces of a split row two more launches and two fix-up launches.  row < 0 = padding.
 
   uint32_t lo[VPL];
 #pragma unroll
@@ -475,21 +481,26 @@ __global__ __launch_bounds__(256) void gat_items_bwd_dalpha_kernel(
   Desc d0 = uniform(dv), d1 = uniform(dv1);
   int c_next = col[min(d0.start + lane, nnz - 1)];
   for (; i < i1; i += stride) {
-    const int row = d0.row, start = d0.start, slot = d0.slot, cnt = d0.end - d0.start;
-    const int c = c_next;
+    const int row = d0.row, slot = d0.slot, rowc = max(row, 0);
+    const bool member = slot == -2;
+    int start = d0.start;
+    int cnt = row < 0 ? 0 : min(kWave, d0.end - start);
+    int c = c_next;
     if (lane == 0) dv = items[min(i + 2 * stride, i1 - 1)];
     c_next = col[min(d1.start + lane, nnz - 1)];
     // weights of the item's edges and the dy row: requested now, consumed behind the first gathers
     float as = 0.f;
     if (lane < cnt) as = a_src[c];
-    const float ad = a_dst[row], rm = rowmax[row], rs = rowsum[row];
+    const float ad = a_dst[rowc], rm = rowmax[rowc], rs = rowsum[rowc];
     float4 dyr[VPL];
-    const char* dyb = reinterpret_cast<const char*>(dy + (int64_t)row * lddy);
+    const char* dyb = reinterpret_cast<const char*>(dy + (int64_t)rowc * lddy);
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       dyr[v] = *reinterpret_cast<const float4*>(dyb + lo[v]);
       if (!EXACT && li + v * LPR >= d4) dyr[v] = f4_zero();
     }
+    float t_acc = 0.f;                                  // a member's part of t over its chunks
+    for (;;) {                                          // 64-edge chunks: one, except for the members of rows above 256 in-edges
     const int trips = (cnt + G - 1) / G;
     const int last4 = 4 * cnt - 4;
     auto gather = [&](int t, float4(&hv)[VPL]) {
@@ -538,18 +549,55 @@ __global__ __launch_bounds__(256) void gat_items_bwd_dalpha_kernel(
     const float pj = lane < cnt ? pw[lane] : 0.f;
     float tpart = al * pj;
     tpart = wave_sum(tpart);
-    if (slot < 0) {
+    if (slot == -1) {
       // the item is the whole row: t_i = sum_j alpha_ij <dy_i, h_j> is complete, so the score gradient
       // de_ij = alpha_ij (<dy_i, h_j> - t_i) leaky'(s_ij) and da_dst_i = sum_j de_ij are finished here
       float v = lane < cnt ? al * (pj - tpart) * (as + ad > 0.f ? 1.0f : slope) : 0.f;
       if (lane < cnt) ade[start + lane] = make_float2(al, v);
       v = wave_sum(v);
-      if (lane == 0) { t_row[row] = tpart; da_dst[row] = v; }
-    } else {
+      if (lane == 0 && row >= 0) { t_row[row] = tpart; da_dst[row] = v; }
+      break;
+    }
+    if (!member) {
       // a piece of a split row: park <dy_i, h_j> and the partial t; gat_items_bwd_de_kernel finishes the
       // pieces once the row's t is summed
       if (lane < cnt) ade[start + lane] = make_float2(al, pj);
       if (lane == 0) scratch_t[slot] = tpart;
+      break;
+    }
+    // a group member: park this chunk, go on with the next one of its share
+    if (lane < cnt) ade[start + lane] = make_float2(al, pj);
+    t_acc += __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tpart)));   // (wave-uniform: a scalar register)
+    start += kWave;
+    if (start >= d0.end) break;
+    cnt = min(kWave, d0.end - start);
+    c = col[min(start + lane, nnz - 1)];
+    as = lane < cnt ? a_src[c] : 0.f;
+    }
+    if (member) {              // (block-uniform: the planner aligns the quadruples and the XCD ranges to 4)
+      const int wave = threadIdx.x >> 6;
+      if (lane == 0) grp_t[wave] = t_acc;
+      __syncthreads();
+      const float t = ((grp_t[0] + grp_t[1]) + grp_t[2]) + grp_t[3];
+      float vs = 0.f;
+      for (int b = d0.start; b < d0.end; b += kWave) {           // this member's edges again: (alpha, <dy, h>) -> (alpha, de)
+        const int cn = min(kWave, d0.end - b), k = min(b + lane, nnz - 1);
+        float v = 0.f;
+        if (lane < cn) {
+          const float2 a2 = ade[k];
+          const float sc = a_src[col[k]] + ad;
+          v = a2.x * (a2.y - t) * (sc > 0.f ? 1.0f : slope);
+          ade[k] = make_float2(a2.x, v);
+        }
+        vs += wave_sum(v);
+      }
+      if (lane == 0) grp_v[wave] = vs;
+      __syncthreads();
+      if (wave == 0 && lane == 0 && row >= 0) {
+        t_row[row] = t;
+        da_dst[row] = ((grp_v[0] + grp_v[1]) + grp_v[2]) + grp_v[3];
+      }
+      __syncthreads();
     }
     d0 = d1;
     d1 = uniform(dv);
@@ -837,10 +885,12 @@ extern "C" int gd_gat_edge_grads_balanced_f32(const int32_t* items, int32_t n_it
                                               const float* a_dst, const float* rowmax, const float* rowsum,
                                               const float* h, int64_t ldh, const float* dy, int64_t lddy,
                                               float* ade, float* da_dst, float* t_row, float* scratch,
-                                              float slope, int32_t d, int32_t nnz, void* stream) {
+                                              float slope, int32_t d, int32_t nnz, const int32_t* xcd_bounds, void* stream) {
   using namespace gd;
   GD_REQUIRE(items && col && a_src && a_dst && rowmax && rowsum && h && dy && ade && da_dst && t_row, GD_E_NULL,
              "gd_gat_edge_grads_balanced_f32: null pointer");
+  GD_REQUIRE(!xcd_bounds || (n_split == 0 && n_items % 4 == 0), GD_E_DIM,
+             "gd_gat_edge_grads_balanced_f32: xcd_bounds go with one-launch items (groups, n_items a multiple of 4) and no split list");
   GD_REQUIRE(n_split == 0 || (split && scratch), GD_E_NULL, "gd_gat_edge_grads_balanced_f32: split rows need scratch");
   GD_REQUIRE(d > 0 && d % 4 == 0 && d <= 1024 && ldh % 4 == 0 && lddy % 4 == 0 && (d & (d - 1)) == 0, GD_E_DIM,
              "gd_gat_edge_grads_balanced_f32: d=%d must be a power of two in [4,1024]", d);
@@ -855,7 +905,7 @@ extern "C" int gd_gat_edge_grads_balanced_f32(const int32_t* items, int32_t n_it
   const int4* it = reinterpret_cast<const int4*>(items);
   const int4* sp = reinterpret_cast<const int4*>(split);
   GD_GAT_ITEMS(gat_items_bwd_dalpha_kernel, it, n_items, col, a_src, a_dst, rowmax, rowsum, h, ldh, dy, lddy,
-               reinterpret_cast<float2*>(ade), t_row, da_dst, scratch, slope, d4, nnz);
+               reinterpret_cast<float2*>(ade), t_row, da_dst, scratch, slope, d4, nnz, xcd_bounds);
   int rc = launched("gat_items_bwd_dalpha");
   if (rc) return rc;
   if (n_split) {

@@ -62,9 +62,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DEPTH == 1 ?
   // b = 8 JPT q + 8 t + xcd: the jobs of a tile run on the same XCD (workgroups go round the XCDs), next to each other
   int ot = BPW * ((b >> 3) % JPT), ti = ((b / (8 * JPT)) << 3) + (b & 7);     // ot = the job's first diagonal block
   if (BPW == 1 && xcd_blocks) {
-    // lab mapping (GD_RGCN_WAVE_XCD_BLOCKS=1): diagonal block t on the XCD pair (2 t, 2 t + 1), so that an L2
-    // serves the 128-byte column slice t of the source rows (a quarter of the table) - against reading every tile's unit plan
-    // on four XCDs instead of one.  Measured on the biokg request: see NOTES round 5.
+    // diagonal block t on the XCD pair (2 t, 2 t + 1): an L2 then serves the 128-byte column slice t of
+    // the source rows - a quarter of the table - against reading every tile's unit plan on four XCDs instead of one.
+    // Measured on the biokg request (profiles/r05_rgcn_xcd_blocks.txt): -22 % / -19 % fabric traffic for the two launches
+    // with 128-float sources, +57 % for the 64-float one (the launch code picks per width).
     const int xcd = b & 7;
     ot = xcd >> 1;
     ti = ((b >> 3) << 1) + (xcd & 1);
@@ -297,8 +298,11 @@ extern "C" int gd_rgcn_wave_conv_f32(const int32_t* job_tile, int32_t n_tiles, i
   // the sibling's half line hits the L2 anyway: FETCH_SIZE is at the gathered volume), so one block per wave stays the default
   const char* env_bpw = getenv("GD_RGCN_WAVE_BPW");
   const int bpw16 = env_bpw && atoi(env_bpw) == 2 ? 2 : 1;
+  // diagonal block t on the XCD pair (2 t, 2 t + 1): default for 128-float sources (a wave gathers whole 128-byte lines of its
+  // column slice; FETCH_SIZE of the biokg layer-1 launch 3.99 -> 3.10 GB), not for 64-float sources (64-byte half lines whose
+  // other half the sibling wave on the same XCD used to share: 1.99 -> 3.14 GB).  GD_RGCN_WAVE_XCD_BLOCKS = 0 | 1 overrides (A/B).
   const char* env_xb = getenv("GD_RGCN_WAVE_XCD_BLOCKS");
-  const int xcd_blocks = env_xb && atoi(env_xb) == 1 ? 1 : 0;
+  const int xcd_blocks = env_xb ? (atoi(env_xb) == 1 ? 1 : 0) : (d_in == 128 ? 1 : 0);
   const unsigned pair_groups = (unsigned)((n_tiles + 1) / 2);
 #define GD_RW_LAUNCH1(KL, OW, DEPTH, BPW, RELU)                                                                              \
   hipLaunchKernelGGL((rgcn_wave_kernel<KL, OW, 64, DEPTH, BPW, RELU>),                                                        \

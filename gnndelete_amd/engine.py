@@ -432,7 +432,10 @@ class NodeembEngine:
         if ops.mfma_out_width(out_f):
             xin = torch.relu(x) if relu_in else x
             return ops.gemm_wide(xin, ops._const_weight(weight, True)[0], const_x=not relu_in, const_w=True)
-        return torch.nn.functional.linear(torch.relu(x) if relu_in else x, weight)
+        if in_f <= 1024:
+            return ops.rows_gemm(x, None, weight, trans_w=True, const_w=True, relu_in=relu_in)      # any widths: one wave per row
+        raise NotImplementedError(f'NodeembEngine: a {in_f} -> {out_f} Linear has no kernel (inputs above 1,024 floats need an output '
+                                  'width in {32, 64, 96, 128}); there is no vendor-BLAS fallback')
 
     def _linear_relu_z1(self, weight):
         """relu(z1) @ weight^T where z1 = Del-1 output on the S1 rows and conv1 output elsewhere."""
@@ -442,7 +445,7 @@ class NodeembEngine:
         if in_f % 32 == 0 and out_f % 32 == 0 and out_f <= 128 and in_f * out_f * 4 <= 64 * 1024:
             return ops.rows_gemm_select(self.pre1, self.z1, self._sel1, weight, trans_w=True, const_w=True, relu_in=True)
         z = torch.where(self._sel1.bool()[:, None], self.z1, self.pre1)
-        return torch.nn.functional.linear(torch.relu(z), weight)
+        return self._linear(z, weight, relu_in=True)
 
     def _conv1_forward(self):
         """Frozen layer 1, recomputed every step exactly as upstream does, written into z1."""

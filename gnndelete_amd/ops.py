@@ -333,7 +333,8 @@ class _Dense(torch.autograd.Function):
     """y = x @ weight^T (+ bias), weight [out, in] as torch.nn.Linear / torch_geometric's Linear store it
     (framework/models/gcn.py:11-12 ...): every product on the HIP matrix-core kernels where the widths allow -
     forward (whole weight in LDS for in <= 128, K-tiled for wider inputs), input gradient, weight gradient (row
-    reduction kernel; for a wide input the K-tiled kernel on a cached x^T) - and torch's matmul otherwise."""
+    reduction kernel; for a wide input the K-tiled kernel on a cached x^T); odd widths run the generic kernels, and a shape
+    without a kernel raises - no torch matmul anywhere."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, const_x):
@@ -353,7 +354,8 @@ class _Dense(torch.autograd.Function):
             return gemm_wide(x, wt, b, const_x=const_x)
         if in_f <= 1024:
             return rows_gemm(x, None, w, trans_w=True, bias=b)            # any widths: the one-wave-per-row kernel
-        return torch.nn.functional.linear(x, w, b)
+        raise NotImplementedError(f'ops.dense: a {in_f} -> {out_f} product has no kernel (inputs above 1,024 floats need an output width '
+                                  'in {32, 64, 96, 128}); there is no vendor-BLAS fallback')
 
     @staticmethod
     def backward(ctx, dy):
@@ -365,8 +367,11 @@ class _Dense(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if _small_weight(out_f, in_f) or (out_f <= 1024 and in_f <= 1024):
                 dx = rows_gemm(dy, None, w, trans_w=False)                  # dy [*, out] @ W [out, in]
+            elif mfma_out_width(in_f):
+                dx = gemm_wide(dy, w)                                       # [*, out] @ [out, in], the K-tiled kernel
             else:
-                dx = dy @ w
+                raise NotImplementedError(f'ops.dense: the input gradient of a {in_f} -> {out_f} product has no kernel; there is no '
+                                          'vendor-BLAS fallback (the reference never asks for it: its wide inputs are the node features)')
         if ctx.needs_input_grad[1]:
             m = x.shape[0]
             if out_f % 32 == 0 and in_f % 32 == 0 and out_f <= 128 and in_f <= 128 and out_f != 96 and in_f != 96:
@@ -383,7 +388,7 @@ class _Dense(torch.autograd.Function):
                 dyp[:m] = dy
                 dw = gemm_wide(xt, dyp).t()
             else:
-                dw = dy.t() @ x
+                dw = rows_gemm_wgrad(dy, None, x, None, m)                  # any widths (one thread per element of dW, split over row blocks)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db, None
@@ -465,6 +470,12 @@ def _ws_buf(bufs, key, shape, device, zero=False):
     return t
 
 
+def _gat_onepass():
+    """GATConv's edge-gradient pass on the one-launch items (hub rows as groups inside the launch); GD_GAT_PIECES=1: the piece form
+    with its second edge pass and fix-up launches (A/B switch, read per call).  The forward keeps the piece form."""
+    return os.environ.get('GD_GAT_PIECES') != '1'
+
+
 def gat_forward_raw(graph, h, a_src, a_dst, bias, slope, out=None, plan=None, bufs=None):
     """Fused edge-softmax aggregation; returns (y, rowmax, rowsum) - balanced kernels when the
     width allows, else the one-wave-per-row kernel (then rowmax is the saved alpha, rowsum None).
@@ -511,11 +522,20 @@ def gat_backward_raw(graph, h, a_src, a_dst, rowmax, rowsum, dy, slope, plan=Non
     # (zero) for the transposition pass
     ade = _ws_buf(bufs, 'ade', (g.nnz, 2), dev, zero=subset)
     t_row = _ws_buf(bufs, 't_row', (n,), dev)
-    scratch = plan.scratch_flat('gat_bwd', max(4, plan.n_slots), dev)
-    check(_lib.lib().gd_gat_edge_grads_balanced_f32(
-        ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split, ptr(g.col), ptr(a_src), ptr(a_dst), ptr(rowmax),
-        ptr(rowsum), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(ade), ptr(da_dst), ptr(t_row),
-        ptr(scratch), float(slope), d, g.nnz, stream_ptr(dev)), 'gd_gat_edge_grads_balanced_f32')
+    if _gat_onepass():
+        # one launch: a hub row's four members sum t in LDS and finish the score gradients of their own edges (no second edge
+        # pass, no fix-up launches)
+        items, n_items, bounds = plan.onepass(d, multirow=1)
+        check(_lib.lib().gd_gat_edge_grads_balanced_f32(
+            ptr(items), n_items, None, 0, ptr(g.col), ptr(a_src), ptr(a_dst), ptr(rowmax), ptr(rowsum), ptr(h), h.stride(0),
+            ptr(dy), dy.stride(0), ptr(ade), ptr(da_dst), ptr(t_row), None, float(slope), d, g.nnz, ptr(bounds), stream_ptr(dev)),
+            'gd_gat_edge_grads_balanced_f32')
+    else:
+        scratch = plan.scratch_flat('gat_bwd', max(4, plan.n_slots), dev)
+        check(_lib.lib().gd_gat_edge_grads_balanced_f32(
+            ptr(plan.items), plan.n_items, ptr(plan.split), plan.n_split, ptr(g.col), ptr(a_src), ptr(a_dst), ptr(rowmax),
+            ptr(rowsum), ptr(h), h.stride(0), ptr(dy), dy.stride(0), ptr(ade), ptr(da_dst), ptr(t_row),
+            ptr(scratch), float(slope), d, g.nnz, None, stream_ptr(dev)), 'gd_gat_edge_grads_balanced_f32')
     da_src = _ws_buf(bufs, 'da_src', (n,), dev)
     pt = plan_t or g.plan_t
     dh = None if bufs is None else _ws_buf(bufs, 'dh', (n, dy.shape[1]), dev)
@@ -558,10 +578,10 @@ def row_dots(h, v1, v2, bufs=None):
     a2 = _ws_buf(bufs, 'a2', (n,), h.device)
     v1, v2 = v1.reshape(-1).contiguous(), v2.reshape(-1).contiguous()
     if d % 4 or h.stride(0) % 4:
-        if bufs is None:
-            return h @ v1, h @ v2
-        torch.mv(h, v1, out=a1)
-        torch.mv(h, v2, out=a2)
+        # odd widths: the two dots as a [n, d] x [d, 2] product on the one-wave-per-row kernel
+        both = rows_gemm(h, None, torch.stack([v1, v2]), trans_w=True)
+        a1.copy_(both[:, 0])
+        a2.copy_(both[:, 1])
         return a1, a2
     check(_lib.lib().gd_row_dots_f32(ptr(h), h.stride(0), n, d, ptr(v1), ptr(v2), ptr(a1), ptr(a2),
                                      stream_ptr(h.device)), 'gd_row_dots_f32')
@@ -713,8 +733,9 @@ class _RgcnConvFrozen(torch.autograd.Function):
         x = _f32_rows(x)
         weight = weight.detach().contiguous()
         # root is [in, out]: the row kernel takes it as is (any widths up to 1024: MFMA where they allow)
-        y = rows_gemm(x, None, root.detach(), trans_w=False, bias=bias.detach() if bias is not None else None) \
-            if x.shape[1] <= 1024 else (torch.addmm(bias.detach(), x, root.detach()) if bias is not None else x @ root.detach())
+        if x.shape[1] > 1024:
+            raise NotImplementedError('RGCNConv: inputs above 1,024 floats have no kernel (no vendor-BLAS fallback)')
+        y = rows_gemm(x, None, root.detach(), trans_w=False, bias=bias.detach() if bias is not None else None)
         rgcn_typed_accumulate(tg, x, weight, n_blocks, 0, y)
         ctx.tg, ctx.n_blocks = tg, n_blocks
         ctx.save_for_backward(weight, root.detach())
@@ -724,7 +745,7 @@ class _RgcnConvFrozen(torch.autograd.Function):
     def backward(ctx, dy):
         weight, root = ctx.saved_tensors
         dy = _f32_rows(dy)
-        dx = rows_gemm(dy, None, root, trans_w=True) if dy.shape[1] <= 1024 else dy @ root.t()
+        dx = rows_gemm(dy, None, root, trans_w=True)
         rgcn_typed_accumulate(ctx.tg, dy, weight, ctx.n_blocks, 1, dx)
         return dx, None, None, None, None, None
 

@@ -199,7 +199,13 @@ int gd_gat_aggregate_bwd_f32(const int32_t* rowptr, const int32_t* col, const fl
  * (alpha rebuilt, d loss / d score) interleaved - the source-major half gathers both through the edge
  * permutation, one sector per edge this way -, da_dst[n]; t_row[n] and scratch (n_slots floats) are work
  * space.  The source-major half (dh = sum alpha dy, da_src = sum de) is gd_gat_transpose_edges_f32 +
- * gd_spmm_csr_balanced_f32 on the transposed CSR with val = alpha_t. */
+ * gd_spmm_csr_balanced_f32 on the transposed CSR with val = alpha_t. 
+ * gd_gat_edge_grads_balanced_f32 with xcd_bounds (ABI 8; NULL = the piece form above): `items` are then the ONE-LAUNCH items of
+ * SplitPlan.onepass(d, multirow=1) - slot -1 = a whole row, slot -2 = member of a group (a hub row as four consecutive,
+ * 4-aligned items, one share per wave of a block), row -1 = padding - with the nine item-range limits of the eight XCDs; split
+ * must be empty: the members sum the row's t in LDS and each finishes the score gradients of its own edges - no second edge
+ * pass, no fix-up launches.  (The forward keeps the piece form: its kernel runs at 64 registers / eight waves per SIMD and a
+ * member path with several chunks spills there - measured +200 us on the GAT step, NOTES round 5.) */
 int64_t gd_gat_balanced_scratch(int32_t n_slots, int32_t d);
 int gd_gat_aggregate_balanced_f32(const int32_t* items, int32_t n_items, const int32_t* split, int32_t n_split,
                                   int32_t n_slots, const int32_t* col, const float* a_src, const float* a_dst,
@@ -210,7 +216,8 @@ int gd_gat_edge_grads_balanced_f32(const int32_t* items, int32_t n_items, const 
                                    const int32_t* col, const float* a_src, const float* a_dst,
                                    const float* rowmax, const float* rowsum, const float* h, int64_t ldh,
                                    const float* dy, int64_t lddy, float* ade, float* da_dst,
-                                   float* t_row, float* scratch, float slope, int32_t d, int32_t nnz, void* stream);
+                                   float* t_row, float* scratch, float slope, int32_t d, int32_t nnz, const int32_t* xcd_bounds,
+        void* stream);
 
 /* GAT attention logits: a1[i] = <h[i,:], v1>, a2[i] = <h[i,:], v2> in one pass over h
  * (alpha_src / alpha_dst of GATConv.forward, framework/models/gat.py:11-12). */

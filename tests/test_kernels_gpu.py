@@ -994,15 +994,20 @@ def test_rows_gemm_dots_matches_fp64(n, d_in, d_out, select, matrix_split):
     assert rel_l2(a2.cpu(), want @ u2.double().reshape(-1)) < TOL
 
 
+@pytest.mark.parametrize('pieces', ['0', '1'])
 @pytest.mark.parametrize('d,hub_degree', [(64, 1500), (16, 700), (128, 2500), (64, 5000)])
-def test_gat_hub_row_with_more_pieces_than_feature_lanes(d, hub_degree):
-    """A hub row is cut into pieces of 64 in-edges that the fix-up merges flash-attention style.  With more pieces
+def test_gat_hub_row_with_more_pieces_than_feature_lanes(d, hub_degree, pieces, monkeypatch):
+    """pieces = 0 (default): the one-launch form - the hub row is a GROUP of four member items, each walking its share of
+    the in-edges 64 at a time with an online softmax, merged in LDS by the block (forward), its score gradients finished by
+    the members once the row's t is summed in LDS (backward).  pieces = 1 (GD_GAT_PIECES=1): the piece form with fix-up launches:
+    A hub row is cut into pieces of 64 in-edges that the fix-up merges flash-attention style.  With more pieces
     than d/4 (the lanes that carry features in the fix-up) the merge used to drop the tail pieces' rescale factors
     (LDS-crossbar shuffle from masked-off lanes reads 0); > 64 pieces take the serial branch.  Forward and backward
     of the balanced GAT kernels on a graph with one such hub vs the fp64 oracle."""
     from gnndelete_amd import ops
     from gnndelete_amd.graph import build_csr
     from oracle import pyg_semantics as pyg
+    monkeypatch.setenv('GD_GAT_PIECES', pieces)
     n = hub_degree + 200
     g = torch.Generator().manual_seed(d + hub_degree)
     hub = 17
