@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void rowtarget_mse_kernel(
           const float4 df = make_float4(zv[u][v].x - tv[u][v].x, zv[u][v].y - tv[u][v].y,
                                         zv[u][v].z - tv[u][v].z, zv[u][v].w - tv[u][v].w);
           sq = fmaf(df.x, df.x, sq); sq = fmaf(df.y, df.y, sq); sq = fmaf(df.z, df.z, sq); sq = fmaf(df.w, df.w, sq);
-          if (ok[u] && vec < d4)
+          if (dz && ok[u] && vec < d4)                 // dz == NULL: the loss value only (rows whose gradient feeds nothing)
             reinterpret_cast<float4*>(drow)[vec] = make_float4(cf[u] * df.x, cf[u] * df.y, cf[u] * df.z, cf[u] * df.w);
         }
         if (cn[u] >= 0.f) s0 = fmaf(cn[u], sq, s0); else s1 = fmaf(-cn[u], sq, s1);
@@ -385,10 +385,10 @@ extern "C" int gd_rowtarget_mse_f32(const float* z, int64_t ld_z, const float* t
   using namespace gd;
   GD_REQUIRE(partials, GD_E_NULL, "gd_rowtarget_mse_f32: null partials");
   if (n_rows == 0) return GD_OK;
-  GD_REQUIRE(z && tm && row_idx && coef && cnt && kind && dz, GD_E_NULL, "gd_rowtarget_mse_f32: null pointer");
+  GD_REQUIRE(z && tm && row_idx && coef && cnt && kind, GD_E_NULL, "gd_rowtarget_mse_f32: null pointer");
   GD_REQUIRE(d > 0 && d % 4 == 0 && d <= 1024 && ld_z % 4 == 0 && ld_dz % 4 == 0, GD_E_DIM,
              "gd_rowtarget_mse_f32: d=%d must be a multiple of 4 (<=1024) with 16-byte row strides", d);
-  GD_REQUIRE(aligned16(z) && aligned16(tm) && aligned16(dz), GD_E_ALIGN, "gd_rowtarget_mse_f32: unaligned matrix");
+  GD_REQUIRE(aligned16(z) && aligned16(tm) && aligned16(dz), GD_E_ALIGN, "gd_rowtarget_mse_f32: unaligned matrix");      // (dz may be NULL)
   hipStream_t s = (hipStream_t)stream;
   const int d4 = d / 4;
   const int lpr = lanes_per_row(d4);

@@ -114,6 +114,39 @@ class _LayerTerms:
         """Blocks of per-block loss partials the folded kernel writes (for gd_loss_finalize_f32)."""
         return _lib.lib().gd_rowtarget_mse_blocks(self.n_rows) if self.folded and self.n_rows else 0
 
+    def order_inside_first(self, idx, n_sel):
+        """Reorder the folded loss rows: members of the sorted Del row list idx first (in their order), the others behind them.
+        Sets n_in (their number) and returns it; the suffix [n_in:] is then what launch_outside() walks."""
+        assert self.folded
+        self.n_in = self.n_rows
+        if self.n_rows == 0 or n_sel == 0:
+            self.n_in = 0 if n_sel == 0 else self.n_rows
+            return self.n_in
+        pos = torch.searchsorted(idx, self.row_idx)
+        inside = (pos < n_sel) & (idx[pos.clamp(max=n_sel - 1)] == self.row_idx)
+        order = torch.argsort((~inside).to(torch.int8), stable=True)
+        self.row_idx, self.cnt = self.row_idx[order].contiguous(), self.cnt[order].contiguous()
+        self.coef, self.kind = self.coef[order].contiguous(), self.kind[order].contiguous()
+        self.tm = self.tm[order].contiguous()
+        self.n_in = int(inside.sum())
+        return self.n_in
+
+    def outside_blocks(self):
+        n_out = self.n_rows - getattr(self, 'n_in', self.n_rows)
+        return _lib.lib().gd_rowtarget_mse_blocks(n_out) if n_out else 0
+
+    def launch_outside(self, z, dz, partials):
+        """The loss rows outside the Del rows (after order_inside_first): z there is the conv output itself.  dz = None: the
+        loss sums only.  partials: 2 floats per block, outside_blocks() of them."""
+        k, n_out = self.n_in, self.n_rows - self.n_in
+        if n_out == 0:
+            return
+        d = z.shape[1]
+        check(_lib.lib().gd_rowtarget_mse_f32(ptr(z), z.stride(0), ptr(self.tm[k:]), d, ptr(self.row_idx[k:]), ptr(self.coef[k:]),
+                                              ptr(self.cnt[k:]), ptr(self.kind[k:]), n_out, ptr(dz) if dz is not None else None,
+                                              dz.stride(0) if dz is not None else 0, None, ptr(partials), stream_ptr(z.device)),
+              'gd_rowtarget_mse_f32')
+
     def launch(self, z, dz, sums):
         """sums = None (folded form only): leave the partials for gd_loss_finalize_f32."""
         d = z.shape[1]
@@ -173,7 +206,8 @@ def _loss_slots(terms, idx, n_sel, device):
     slot = torch.full((n_sel,), -1, dtype=torch.int32, device=device)
     if terms.n_rows:
         pos = torch.searchsorted(idx, terms.row_idx)
-        slot[pos] = torch.arange(terms.n_rows, dtype=torch.int32, device=device)
+        inside = (pos < n_sel) & (idx[pos.clamp(max=n_sel - 1)] == terms.row_idx)      # (loss rows outside the Del rows: no slot)
+        slot[pos[inside]] = torch.arange(terms.n_rows, dtype=torch.int32, device=device)[inside]
     return slot, torch.where(terms.kind == 1, -terms.cnt, terms.cnt).contiguous()
 
 
@@ -253,7 +287,18 @@ class NodeembEngine:
         # operand from p2 - no [S2, O] copy of the Del input per step.  z2 rows outside S2 are then never
         # formed, which training only tolerates when every layer-2 loss row lies in S2 (always so for the
         # reference's masks); otherwise the in-place form with its saved input is used.
-        self._split2 = _rows_inside(self.t2, self.idx2, self.s2) and os.environ.get('GD_NO_SPLIT') != '1'
+        # (round 5) Knowledge-graph requests: upstream hands the NI masks to the Del operators (S minus the Df endpoints), so the
+        # DEC rows lie OUTSIDE the Del rows.  The fused forms then take the loss rows inside the Del rows (the NI rows) and one
+        # stand-alone loss launch per layer the rest, reading the conv output (Del is the identity there): layer 2 writes their
+        # dz2 rows (= dp2, conv2's backward reads them), layer 1 the loss sums only (no trainable weight lies upstream of them).
+        self._out1 = self._out2 = 0
+        mixed_ok = (self.t1.folded and self.t2.folded and os.environ.get('GD_NO_SPLIT_LOSS') != '1' and os.environ.get('GD_NO_SPLIT') != '1')
+        inside2 = _rows_inside(self.t2, self.idx2, self.s2)
+        if (not inside2 and mixed_ok and self.s2 > 0 and self.o in (32, 64) and self.t2.n_rows > 0
+                and os.environ.get('GD_NO_FUSED_L2') != '1'):
+            self._out2 = self.t2.n_rows - self.t2.order_inside_first(self.idx2, self.s2)
+            inside2 = True
+        self._split2 = inside2 and os.environ.get('GD_NO_SPLIT') != '1'
         self.p2 = torch.empty(n, self.o, **f32) if self._split2 else self.z2
         self.xs2 = None if self._split2 else torch.empty(max(1, self.s2), self.o, **f32)
         # ... and with that, Del-2 forward + layer-2 loss + Del-2 input gradient are ONE kernel (csrc/del_fused.hip)
@@ -262,7 +307,7 @@ class NodeembEngine:
         if self._fuse_l2:
             self._slot2, self._cnt_signed2 = _loss_slots(self.t2, self.idx2, self.s2, dev)
             self._lp2_blocks = _lib.lib().gd_del_loss_bwd_blocks(self.s2)
-            self._lp2 = torch.zeros(2 * max(1, self._lp2_blocks), **f32)
+            self._lp2 = torch.zeros(2 * max(1, self._lp2_blocks + self.t2.outside_blocks()), **f32)
             self.dz2c = torch.zeros(self.s2, self.o, **f32)          # dz2 on the S2 rows (compact)
         # Same for layer 1 (not with the cached layer-1 output, which is a fixed buffer already): conv1 writes
         # pre1, Del-1 writes z1[S1] from pre1[S1]; conv2's Linear reads row r from z1 if r is in S1, else from
@@ -311,13 +356,12 @@ class NodeembEngine:
                 and self.h in (32, 64, 128) and t1.n_rows > 0 and os.environ.get('GD_NO_FUSED_LOSS1') != '1'):
             pos = torch.searchsorted(self.idx1, t1.row_idx)
             inside = (pos < self.s1) & (self.idx1[pos.clamp(max=self.s1 - 1)] == t1.row_idx)
-            if bool(inside.all()):
-                slot = torch.full((self.s1,), -1, dtype=torch.int32, device=dev)
-                slot[pos] = torch.arange(t1.n_rows, dtype=torch.int32, device=dev)
-                self._slot1 = slot
-                self._cnt_signed1 = torch.where(t1.kind == 1, -t1.cnt, t1.cnt).contiguous()
+            if not bool(inside.all()) and mixed_ok and not self._split1:
+                self._out1 = t1.n_rows - t1.order_inside_first(self.idx1, self.s1)
+            if bool(inside.all()) or self._out1:
+                self._slot1, self._cnt_signed1 = _loss_slots(t1, self.idx1, self.s1, dev)
                 self._lp1_blocks = _lib.lib().gd_rows_gemm_wgrad_blocks(self.s1)
-                self._lp1 = torch.zeros(2 * max(1, self._lp1_blocks), **f32)
+                self._lp1 = torch.zeros(2 * max(1, self._lp1_blocks + t1.outside_blocks()), **f32)
                 self._fuse_loss1 = True
         # The launch-sized tail of the step (two split-K reductions with Adam + the loss finalize) as ONE launch
         # (gd_step_tail_f32) where both optimizers step in every iteration and both layers run their fused loss forms
@@ -338,7 +382,7 @@ class NodeembEngine:
         self._fuse_wg2 = self._tail and self._fuse_l2 and os.environ.get('GD_NO_FUSED_WGRAD2') != '1'
         if self._fuse_wg2:
             self._lp2_blocks = _lib.lib().gd_rows_gemm_wgrad_blocks(self.s2)
-            self._lp2 = torch.zeros(2 * max(1, self._lp2_blocks), **f32)
+            self._lp2 = torch.zeros(2 * max(1, self._lp2_blocks + self.t2.outside_blocks()), **f32)
         self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat', SAGEConv: 'sage', RGCNConv: 'rgcn'}[type(conv2)]
         self._gat_dots = os.environ.get('GD_NO_GAT_DOTS') != '1'      # attention logits from the GEMM epilogue
         self._gat_r1 = None                                            # (att_src W2, att_dst W2): constants of the frozen conv2
@@ -384,7 +428,8 @@ class NodeembEngine:
         # `value` is measured that way); the trainer turns it on.  Verified closed under the graph first.
         self._rows_only = False
         gin_ok = self._mode == 'gin' and conv1.nn.out_features <= conv1.nn.in_features and conv2.nn.out_features <= conv2.nn.in_features
-        if affected_rows_only and (self._mode in ('gcn', 'gat', 'sage') or gin_ok) and self._split2 and self.s2 > 0:
+        if (affected_rows_only and (self._mode in ('gcn', 'gat', 'sage') or gin_ok) and self._split2 and self.s2 > 0
+                and not self._out1 and not self._out2):        # (loss rows outside the Del rows read conv outputs of rows outside S2)
             g = self.graph
             in2 = torch.zeros(n, dtype=torch.bool, device=dev)
             in2[self.idx2.long()] = True
@@ -729,6 +774,8 @@ class NodeembEngine:
             # ---- layer-1 loss (+ its W_D1 step for the layer-wise types)
             if not self._fuse_loss1 and lt != 'only2_all':      # (only2_all: neither its update nor its log line reads layer 1)
                 self.t1.launch(self.z1, self.dz1, s1)
+            elif self._out1 and lt != 'only2_all':
+                self.t1.launch_outside(self.z1, None, self._lp1[2 * self._lp1_blocks:])
             if lt == 'both_layerwise':
                 self._wgrad1(False, self.dh)
             elif lt == 'only1':
@@ -737,6 +784,8 @@ class NodeembEngine:
             self._conv2_forward()
             if self._fuse_l2:
                 self._del2_fused()
+                if self._out2:
+                    self.t2.launch_outside(self.p2, self.dz2, self._lp2[2 * self._lp2_blocks:])
             else:
                 ops.rows_gemm(self.p2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
                 self.t2.launch(self.z2, self.dz2, s2)
@@ -761,8 +810,10 @@ class NodeembEngine:
                 if not self._fuse_l2 and not self._tail:
                     self.adam2.apply(self.g2)
             # ---- loss sums -> history ring, advance the iteration counter (Adam's step number)
-            p1, n1 = (self._lp1, self._lp1_blocks) if self._fuse_loss1 else (self.t1.partials, self.t1.n_partial_blocks())
-            p2, n2 = (self._lp2, self._lp2_blocks) if self._fuse_l2 else (self.t2.partials, self.t2.n_partial_blocks())
+            p1, n1 = ((self._lp1, self._lp1_blocks + (self.t1.outside_blocks() if self._out1 else 0)) if self._fuse_loss1
+                      else (self.t1.partials, self.t1.n_partial_blocks()))
+            p2, n2 = ((self._lp2, self._lp2_blocks + (self.t2.outside_blocks() if self._out2 else 0)) if self._fuse_l2
+                      else (self.t2.partials, self.t2.n_partial_blocks()))
 
             def finalize():
                 check(_lib.lib().gd_loss_finalize_f32(

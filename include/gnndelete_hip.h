@@ -524,7 +524,8 @@ int gd_rowpair_mse_f32(const float* z, int64_t ld_z, const float* o, int64_t ld_
  * K (sum_t |o_t|^2 - cnt |tbar|^2, added on the host):
  *       diff = z[row,:] - tm[u,:];  dz[row,:] = coef[u] * diff;  sums[kind[u]] += cnt[u] * |diff|^2
  * Pure streaming, deterministic; `partials` holds gd_rowtarget_mse_workspace(n_rows) floats;
- * sums[2] is accumulated into (zero it first). */
+ * sums[2] is accumulated into (zero it first).  row_idx need not be ascending.  dz = NULL: the loss sums only (rows whose
+ * gradient feeds no trainable weight - the layer-1 DEC rows outside the Del-1 mask of a knowledge-graph request). */
 int64_t gd_rowtarget_mse_workspace(int32_t n_rows);
 int gd_rowtarget_mse_f32(const float* z, int64_t ld_z, const float* tm, int32_t d,
                          const int32_t* row_idx, const float* coef, const float* cnt, const int32_t* kind,
