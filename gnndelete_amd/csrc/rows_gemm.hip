@@ -115,15 +115,29 @@ __global__ __launch_bounds__(QUEUE ? 1024 : kGemmThreads, (NP && KC) ? 2 : 4) vo
       for (int q = 0; q < 3; ++q) wimg[q * pstride + off] = pc[q];
     }
   }
-  for (int e = tid; !NP && e < d_in * 32; e += kGemmThreads) {
-    const int k = e >> 5, r = e & 31;
-    float v[NTP];
+  // (kFill steps of a thread requested together: a launch with a tile or two per wave - the Del products of a small request -
+  //  lasts about as long as this fill, and a step-by-step fill is d_in * 32 / threads dependent round trips: 23 us for
+  //  15,434 rows of a 128 x 128 product against 28 us for 60,000, tools/experiments/small_rows_time.py)
+  constexpr int kFill = 8;                            // (one pass at d_in = 128)
+  for (int e0 = tid; !NP && e0 < d_in * 32; e0 += kGemmThreads * kFill) {
+    float v[kFill][NTP];
 #pragma unroll
-    for (int t = 0; t < NTP; ++t)
-      v[t] = t < NT ? (trans_w ? w[(int64_t)(32 * t + r) * d_in + k] : w[(int64_t)k * d_out + 32 * t + r]) : 0.f;
-    if (NTP == 4) *reinterpret_cast<float4*>(wl + e * 4) = make_float4(v[0], v[1], v[2], v[3 % NTP]);
-    else if (NTP == 2) *reinterpret_cast<float2*>(wl + e * 2) = make_float2(v[0], v[1 % NTP]);
-    else wl[e] = v[0];
+    for (int u = 0; u < kFill; ++u) {
+      const int e = min(e0 + u * kGemmThreads, d_in * 32 - 1);
+      const int k = e >> 5, r = e & 31;
+#pragma unroll
+      for (int t = 0; t < NTP; ++t)
+        v[u][t] = t < NT ? (trans_w ? w[(int64_t)(32 * t + r) * d_in + k] : w[(int64_t)k * d_out + 32 * t + r]) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kFill; ++u) {
+      const int e = e0 + u * kGemmThreads;
+      if (e < d_in * 32) {
+        if (NTP == 4) *reinterpret_cast<float4*>(wl + e * 4) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3 % NTP]);
+        else if (NTP == 2) *reinterpret_cast<float2*>(wl + e * 2) = make_float2(v[u][0], v[u][1 % NTP]);
+        else wl[e] = v[u][0];
+      }
+    }
   }
   __syncthreads();
 
@@ -197,7 +211,7 @@ __global__ __launch_bounds__(QUEUE ? 1024 : kGemmThreads, (NP && KC) ? 2 : 4) vo
   if constexpr (NP != 0 && KC != 0) {
     // ---- split form: whole half rows in registers (4 KC float4 per lane), the NEXT tile's in flight while this one feeds
     // the matrix cores - a 32-wide k chunk lasts < 1 us here, chunk-wise prefetch no longer covers the HBM latency
-    int tile = blockIdx.x * kWaves + wave;
+    int tile = wave * gridDim.x + blockIdx.x;          // (wave-major: see the static hand-out below)
     if (tile >= n_tiles) return;
     auto fetch = [&](int t_, float4 (&a)[4 * KC], int32_t& row) {
       row = row_of(min(t_, n_tiles - 1));
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(QUEUE ? 1024 : kGemmThreads, (NP && KC) ? 2 : 4) vo
     return;
   }
 
-  // tile hand-out: static (tile = block * waves + wave, + stride) or, with QUEUE, tickets from the block's LDS counter
+  // tile hand-out: static (tile = wave * blocks + block, + stride) or, with QUEUE, tickets from the block's LDS counter
   // over its contiguous range [t_lo, t_hi) - a ticket past the range ends the wave (n_tiles = "none")
   __shared__ int q_next;
   const int per_block = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -296,7 +310,10 @@ __global__ __launch_bounds__(QUEUE ? 1024 : kGemmThreads, (NP && KC) ? 2 : 4) vo
     t = __builtin_amdgcn_readfirstlane(t) + t_lo;
     return t < t_hi ? t : n_tiles;
   };
-  int tile = QUEUE ? grab() : blockIdx.x * kWaves + wave;
+  // (static: WAVE-major - tile = wave * blocks + block - so that a launch with fewer tiles than wave slots spreads them over the
+  //  compute units, one wave per SIMD first: a 128 x 128 tile is 6.8 us of matrix instructions, and 483 tiles on 61 blocks of
+  //  eight waves ran two per SIMD on a quarter of the chip - 23 us for 15,434 rows against 28 us for 60,000)
+  int tile = QUEUE ? grab() : wave * (int)gridDim.x + (int)blockIdx.x;
   if (tile >= n_tiles) return;
   int tile_nxt = QUEUE ? grab() : tile + stride;
   int32_t row_cur = row_of(tile);
@@ -886,6 +903,9 @@ static int rows_gemm_impl(const float* in, int64_t ld_in, const int32_t* idx, in
     // persistent blocks, 2 per CU by default (GD_ROWS_GEMM_GRID: A-B knob, read once)
     static const int grid_cap = [] { const char* e = getenv("GD_ROWS_GEMM_GRID"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
     if (grid > grid_cap) grid = grid_cap;
+    // fewer tiles than a wave per SIMD and CU: one block per compute unit, its tiles on different SIMDs (wave-major hand-out)
+    static const bool spread_on = [] { const char* e = getenv("GD_ROWS_GEMM_SPREAD"); return !(e && atoi(e) == 0); }();
+    if (spread_on && grid < ws_cu_count()) grid = n_tiles < ws_cu_count() ? n_tiles : ws_cu_count();
     // split arithmetic where its register-resident rows are instantiated (d_in = 64 / 128); other widths keep the fp32 instruction
     // (96 / 128 outputs with whole rows in registers; the 128 -> 64 product chunk-wise, which keeps 4 waves per SIMD)
     const int kc_split = (np && (d_in == 64 || d_in == 128) && d_out >= 96) ? d_in / 32 : 0;
