@@ -494,6 +494,193 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// FIRST-layer Del operator at 128 features, its folded loss and its weight gradient in one pass over the S_Df rows (round 5):
+//
+//     z[idx,:] = p[idx,:] @ W_D   (+ the packed [z > 0] pattern conv2's backward gates with)            DeletionLayer.forward
+//     g        = coef_u (z - tbar_u) + g_add[idx,:]     folded DEC + NI terms of the layer + the gradient that arrives through conv2
+//     dW_D    += p[idx,:]^T g                           (per-block partial matrices, reduced by gd_step_tail_f32)
+//
+// What the step ran before: the weight-stationary row GEMM (reads p, writes z: 59 us) and the loss-fused weight-gradient kernel
+// (reads p AGAIN, reads z back, reads tbar and g_add: 83 us at 0.45 of the matrix peak) - 549 MB; here p is read once and z is
+// only written: 366 MB.  The same weight-stationary scheme as del_loss_bwd_ws_kernel above, with the 128 x 128 weight and the
+// 128 x 128 gradient sums split by OUTPUT COLUMN HALF over the two waves of a pair: wave (pair, half) keeps W_D[:, 64 half ..]
+// as 128 registers of MFMA A-fragments and dW_D[:, 64 half ..] in 128 more, both waves fetch the pair's 16 rows (the second
+// fetch hits the L1 / L2), each forms its half of z, of the loss terms and of g; v_mfma_f32_16x16x4_f32, lane (r = lane & 15,
+// kq = lane >> 4):
+//   P1  z[r][cb + 16 t + 4 kq + c] = sum_(i,c') W[16 i + 4 kq + c'][cb + 16 t + .] p[r][16 i + 4 kq + c']   (B = the lane's eight float4 of its p row)
+//   loss / g in the accumulator layout (targets and g_add fetched in that layout), z stored, sign bits merged over kq
+//   P3  dW[16 ta + 4 kq + v][cb + 16 tb + j] += sum_rows p[row][16 ta + .] g[row][cb + 16 tb + j]: K = the unit's 16 rows; p and
+//       g go once through wave-private LDS tiles (16 x 144, 16 x 80) to come back feature-major; the product is issued
+//       right behind the NEXT unit's fetch, whose latency it covers.
+// One wave per SIMD, no block barrier in the loop.  Partial matrices: block b writes its sum to slot b and zeros to the slots
+// b + grid, ... < n_part (the reduction counts gd_rows_gemm_wgrad_blocks(n_sel) partials).
+template <bool HAS_ADD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void del1_loss_wgrad_ws_kernel(
+    const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ idx, int32_t n_sel, const float* __restrict__ w,
+    float* __restrict__ z, int64_t ld_z, uint32_t* __restrict__ sign_out, DelLoss loss, const float* __restrict__ g_add,
+    int64_t ld_ga, float* __restrict__ wg_partials, int32_t n_part) {
+  constexpr int D = 128, H = 64, PTP = 144, PTZ = 80;             // pitches: rows 16 banks apart
+  extern __shared__ __attribute__((aligned(16))) float wl[];      // 4 waves x (16 x PTP + 16 x PTZ), later 4 x D x H block sums
+  __shared__ float lred[2][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave & 1, pair = wave >> 1, cb = H * half;
+  const int r = lane & 15, kq = lane >> 4;
+  float* const tp = wl + wave * (16 * PTP + 16 * PTZ);
+  float* const tz = tp + 16 * PTP;
+  const int n_units = (n_sel + 15) >> 4;
+  const int n_pairs = gridDim.x * 2, pid = blockIdx.x * 2 + pair;
+  const int u_lo = (int)((int64_t)n_units * pid / n_pairs), u_hi = (int)((int64_t)n_units * (pid + 1) / n_pairs);
+
+  auto slot_of = [&](int u) -> int { return min(min(u, n_units - 1) * 16 + r, n_sel - 1); };
+  int32_t row_n = idx[slot_of(u_lo)], ls_n = loss.slot[slot_of(u_lo)];
+  int32_t row_nn = idx[slot_of(u_lo + 1)], ls_nn = loss.slot[slot_of(u_lo + 1)];
+  __builtin_amdgcn_sched_barrier(0);
+  float wr1[4][32];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int s_ = 0; s_ < 32; ++s_) wr1[t][s_] = w[(kq * 32 + s_) * D + cb + 16 * t + r];
+  f32x4w gacc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) gacc[i] = f32x4w{0.f, 0.f, 0.f, 0.f};
+  float ls0 = 0.f, ls1 = 0.f;
+
+  float4 x[8], tv[4], av[4];
+  float cf_raw, cn_raw;
+  int32_t ls_cur;
+  auto fetch_targets = [&](int32_t u, int32_t row) {              // branch-free: slot -1 reads slot 0, coefficient masked at use
+    const int uc = max(u, 0);
+    const float* trow = loss.tm + (int64_t)uc * D + cb + 4 * kq;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) tv[t] = *reinterpret_cast<const float4*>(trow + 16 * t);
+    if (HAS_ADD) {
+      const float* arow = g_add + (int64_t)row * ld_ga + cb + 4 * kq;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) av[t] = *reinterpret_cast<const float4*>(arow + 16 * t);
+    }
+    cf_raw = loss.coef[uc];
+    cn_raw = loss.cnt_signed[uc];
+    ls_cur = u;
+  };
+  auto fetch_rows = [&](int32_t row) {
+    const float4* src = reinterpret_cast<const float4*>(p + (int64_t)row * ld_p + kq * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = src[i];
+  };
+  if (u_lo < u_hi) {
+    fetch_rows(row_n);
+    fetch_targets(ls_n, row_n);
+    for (int u = u_lo; u < u_hi; ++u) {
+      const int32_t row = row_n;
+      const int s_a = min(u, n_units - 1) * 16 + r;
+      const bool live = s_a < n_sel;
+      const float livef = live ? 1.f : 0.f;
+      row_n = row_nn;
+      ls_n = ls_nn;
+      row_nn = idx[slot_of(u + 2)];
+      ls_nn = loss.slot[slot_of(u + 2)];
+      // ---- P1: this wave's 64 columns of z
+      f32x4w acc[4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xv[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (i == 0 && c == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr1[t][0], xv[0], f32x4w{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr1[t][4 * i + c], xv[c], acc[t], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- the p rows into their transposition tile (rows past the end zeroed: no weight-gradient contribution)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<float4*>(tp + r * PTP + kq * 32 + 4 * i) = make_float4(livef * x[i].x, livef * x[i].y, livef * x[i].z, livef * x[i].w);
+      // ---- loss gradient in the accumulator layout; z out, sign bits, g into its tile
+      const float cf = ls_cur >= 0 ? cf_raw : 0.f, cn = ls_cur >= 0 ? cn_raw : 0.f;
+      float sq = 0.f;
+      uint32_t bits[2] = {0u, 0u};
+      float* zrow = z + (int64_t)row * ld_z + cb + 4 * kq;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 zv = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        *reinterpret_cast<float4*>(zrow + 16 * t) = zv;
+        bits[t >> 1] |= ((zv.x > 0.f ? 1u : 0u) | (zv.y > 0.f ? 2u : 0u) | (zv.z > 0.f ? 4u : 0u) | (zv.w > 0.f ? 8u : 0u)) << (16 * (t & 1) + 4 * kq);
+        const float4 d4 = make_float4(zv.x - tv[t].x, zv.y - tv[t].y, zv.z - tv[t].z, zv.w - tv[t].w);
+        sq = fmaf(d4.x, d4.x, sq); sq = fmaf(d4.y, d4.y, sq); sq = fmaf(d4.z, d4.z, sq); sq = fmaf(d4.w, d4.w, sq);
+        float4 gv = make_float4(cf * d4.x, cf * d4.y, cf * d4.z, cf * d4.w);
+        if (HAS_ADD) gv = f4_add(gv, av[t]);
+        *reinterpret_cast<float4*>(tz + r * PTZ + 16 * t + 4 * kq) = gv;
+      }
+      sq *= livef;
+      if (cn >= 0.f) ls0 = fmaf(cn, sq, ls0); else ls1 = fmaf(-cn, sq, ls1);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        bits[q] |= (uint32_t)__shfl_xor((int)bits[q], 16);
+        bits[q] |= (uint32_t)__shfl_xor((int)bits[q], 32);
+      }
+      if (live && kq == 0) {
+        sign_out[(int64_t)s_a * 4 + 2 * half + 0] = bits[0];
+        sign_out[(int64_t)s_a * 4 + 2 * half + 1] = bits[1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_rows(row_n);                                           // the next unit's operands into the registers just consumed
+      fetch_targets(ls_n, row_n);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the tiles are wave-private: DS operations execute in issue order
+      __builtin_amdgcn_wave_barrier();
+      // ---- P3: this unit's weight-gradient product from the feature-major views (under the fetch just issued)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        float a_op[8], b_op[4];
+#pragma unroll
+        for (int ta = 0; ta < 8; ++ta) a_op[ta] = tp[(4 * sp + kq) * PTP + 16 * ta + r];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) b_op[tb] = tz[(4 * sp + kq) * PTZ + 16 * tb + r];
+#pragma unroll
+        for (int ta = 0; ta < 8; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb)
+            gacc[ta * 4 + tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op[ta], b_op[tb], gacc[ta * 4 + tb], 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the tiles are read before the next unit overwrites them)
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- block sum of the waves' D x H sums (pair order), loss sums
+  __syncthreads();
+  float* const red = wl;                                          // [4][D x H]
+#pragma unroll
+  for (int ta = 0; ta < 8; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[wave * D * H + (16 * ta + 4 * kq + v) * H + 16 * tb + r] = gacc[ta * 4 + tb][v];
+  __syncthreads();
+  for (int slot = blockIdx.x; slot < n_part; slot += gridDim.x) {
+    float* const out = wg_partials + (int64_t)slot * D * D;
+    const bool mine = slot == (int)blockIdx.x;
+    for (int e = tid; e < D * D; e += 256) {
+      const int i = e >> 7, c = e & 127, hf = c >> 6, ch = c & 63;
+      out[e] = mine ? red[hf * D * H + i * H + ch] + red[(2 + hf) * D * H + i * H + ch] : 0.f;
+    }
+  }
+  ls0 = wave_sum(ls0);
+  ls1 = wave_sum(ls1);
+  if (lane == 0) { lred[0][wave] = ls0; lred[1][wave] = ls1; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int slot = blockIdx.x; slot < n_part; slot += gridDim.x) {
+      const bool mine = slot == (int)blockIdx.x;
+      loss.partials[2 * slot + 0] = mine ? (lred[0][0] + lred[0][1]) + (lred[0][2] + lred[0][3]) : 0.f;
+      loss.partials[2 * slot + 1] = mine ? (lred[1][0] + lred[1][1]) + (lred[1][2] + lred[1][3]) : 0.f;
+    }
+  }
+}
+
 static inline int del_fused_grid(int32_t n_sel) {
   const int n_tiles = (n_sel + 31) / 32;
   int grid = (n_tiles + 3) / 4;
@@ -585,3 +772,43 @@ extern "C" int gd_del_loss_bwd_wgrad_f32(const float* p, int64_t ld_p, const int
   return del_loss_bwd_impl(p, ld_p, idx, n_sel, w, d, loss_slot, tm, coef, cnt_signed, dz, ld_dz, dp, ld_dp, loss_partials,
                            wgrad_partials, true, stream);
 }
+
+extern "C" int32_t gd_del1_loss_wgrad_covers(int32_t n_sel, int32_t d) {
+  static const bool on = [] { const char* e = getenv("GD_DEL1_FUSED"); return !(e && atoi(e) == 0); }();
+  return on && d == 128 && n_sel >= 65536 ? 1 : 0;
+}
+
+extern "C" int gd_del1_loss_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w, int32_t d,
+                                      float* z, int64_t ld_z, uint32_t* sign_out, const int32_t* loss_slot, const float* tm,
+                                      const float* coef, const float* cnt_signed, const float* g_add, int64_t ld_gadd,
+                                      float* loss_partials, float* wgrad_partials, void* stream) {
+  using namespace gd;
+  const char* name = "gd_del1_loss_wgrad_f32";
+  if (n_sel == 0) return GD_OK;
+  GD_REQUIRE(p && idx && w && z && sign_out && loss_slot && tm && coef && cnt_signed && loss_partials && wgrad_partials, GD_E_NULL,
+             "%s: null pointer", name);
+  GD_REQUIRE(d == 128, GD_E_DIM, "%s: d=%d must be 128 (other widths: gd_rows_gemm_signs_f32 + gd_rows_gemm_wgrad_loss_f32)", name, d);
+  GD_REQUIRE(ld_p >= d && ld_z >= d && ld_p % 4 == 0 && ld_z % 4 == 0 && (!g_add || (ld_gadd >= d && ld_gadd % 4 == 0)), GD_E_DIM,
+             "%s: bad row strides", name);
+  GD_REQUIRE(aligned16(p) && aligned16(z) && aligned16(tm) && aligned16(w) && (!g_add || aligned16(g_add)) && aligned16(wgrad_partials),
+             GD_E_ALIGN, "%s: unaligned", name);
+  GD_REQUIRE(p != z && g_add != z, GD_E_DIM, "%s: z must not alias p or g_add (the two waves of a pair read whole rows)", name);
+  hipStream_t s = (hipStream_t)stream;
+  const DelLoss loss{loss_slot, tm, coef, cnt_signed, loss_partials};
+  const int n_part = gd_rows_gemm_wgrad_blocks(n_sel);
+  const int grid = ws_cu_count() < n_part ? ws_cu_count() : n_part;
+  constexpr int kLds = 4 * 128 * 64 * 4;
+  if (g_add) {
+    static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&del1_loss_wgrad_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (a1 != hipSuccess) return fail(-(int)a1, "%s: %s", name, hipGetErrorString(a1));
+    hipLaunchKernelGGL((del1_loss_wgrad_ws_kernel<true>), dim3(grid), dim3(256), kLds, s, p, ld_p, idx, n_sel, w, z, ld_z, sign_out, loss, g_add,
+                       ld_gadd, wgrad_partials, n_part);
+  } else {
+    static const hipError_t a0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&del1_loss_wgrad_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (a0 != hipSuccess) return fail(-(int)a0, "%s: %s", name, hipGetErrorString(a0));
+    hipLaunchKernelGGL((del1_loss_wgrad_ws_kernel<false>), dim3(grid), dim3(256), kLds, s, p, ld_p, idx, n_sel, w, z, ld_z, sign_out, loss, nullptr,
+                       0, wgrad_partials, n_part);
+  }
+  return launched("del1_loss_wgrad_ws");
+}
+

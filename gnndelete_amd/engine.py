@@ -383,6 +383,12 @@ class NodeembEngine:
         if self._fuse_wg2:
             self._lp2_blocks = _lib.lib().gd_rows_gemm_wgrad_blocks(self.s2)
             self._lp2 = torch.zeros(2 * max(1, self._lp2_blocks + self.t2.outside_blocks()), **f32)
+        # (round 5) ... and where the W_D1 step of an iteration only waits for gradients that exist when Del-1 runs (the
+        # layer-wise types: this iteration's layer-1 loss + the gradient conv2 sent back in the PREVIOUS one), Del-1 itself, the
+        # layer-1 loss and the W_D1 weight gradient are ONE pass over the S1 rows (gd_del1_loss_wgrad_f32: pre1 read once, z1
+        # only written - the weight-gradient launch re-read both)
+        self._fuse_del1 = bool(self._tail and self._fuse_loss1 and self._split1 and loss_type in ('both_layerwise', 'only1')
+                               and _lib.lib().gd_del1_loss_wgrad_covers(self.s1, self.h))
         self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat', SAGEConv: 'sage', RGCNConv: 'rgcn'}[type(conv2)]
         self._gat_dots = os.environ.get('GD_NO_GAT_DOTS') != '1'      # attention logits from the GEMM epilogue
         self._gat_r1 = None                                            # (att_src W2, att_dst W2): constants of the frozen conv2
@@ -765,7 +771,10 @@ class NodeembEngine:
                 ops.rows_gemm(self.p1, self.idx1, self.wd1, out=self.z1, sign_bits=self.z1_pos)   # other rows stay = p1
             else:
                 self._conv1_forward()
-                ops.rows_gemm(self.pre1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1, sign_bits=self.z1_pos)
+                if self._fuse_del1:
+                    self._del1_fused(self.dh if lt == 'both_layerwise' else None)
+                else:
+                    ops.rows_gemm(self.pre1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1, sign_bits=self.z1_pos)
             fused_fin = self.t1.folded and self.t2.folded       # partials reduced by the finalize kernel
             if not fused_fin:
                 self.sums.zero_()
@@ -776,7 +785,9 @@ class NodeembEngine:
                 self.t1.launch(self.z1, self.dz1, s1)
             elif self._out1 and lt != 'only2_all':
                 self.t1.launch_outside(self.z1, None, self._lp1[2 * self._lp1_blocks:])
-            if lt == 'both_layerwise':
+            if self._fuse_del1:
+                pass                                             # (its weight-gradient partials came out of the Del-1 pass)
+            elif lt == 'both_layerwise':
                 self._wgrad1(False, self.dh)
             elif lt == 'only1':
                 self._wgrad1(False, None)
@@ -834,6 +845,17 @@ class NodeembEngine:
                 torch.cuda.current_stream().wait_stream(self._side)       # join: the iteration ends when both branches have
             else:
                 finalize()
+
+    def _del1_fused(self, g_add):
+        """Del-1 forward (+ sign bits) + folded layer-1 loss + the W_D1 weight gradient's partial sums in one kernel
+        (csrc/del_fused.hip, del1_loss_wgrad_ws_kernel); the tail launch reduces them and steps Adam."""
+        self.adam1.applied += 1
+        self._tail_acc[0] = 0
+        check(_lib.lib().gd_del1_loss_wgrad_f32(
+            ptr(self.pre1), self.pre1.stride(0), ptr(self.idx1), self.s1, ptr(self.wd1), self.h, ptr(self.z1), self.z1.stride(0),
+            ptr(self.z1_pos), ptr(self._slot1), ptr(self.t1.tm), ptr(self.t1.coef), ptr(self._cnt_signed1), ptr(g_add),
+            g_add.stride(0) if g_add is not None else 0, ptr(self._lp1), ptr(self.ws1), stream_ptr(self.x.device)),
+            'gd_del1_loss_wgrad_f32')
 
     def _del2_fused(self):
         """Del-2 forward + folded layer-2 loss + Del-2 input gradient (+ the W_D2 weight gradient's partial sums) in one

@@ -39,7 +39,8 @@ extern "C" {
                               6: gd_rows_gemm_ws_covers (weight-stationary form of the row GEMMs), gd_spmm_csr_rowgroup_f32;
                              7: gd_rgcn_wave_conv_f32 / gd_rgcn_wave_covers;
                              8: gd_build_source_hash (the library carries a stamp of the sources it was built from), gd_typed_wgrad_f32,
-                                gd_typed_edge_dot_f32, gd_spmm_csr_onepass_aux_f32; gd_agg_gemm_f32 and gd_spmm_csr_rowgroup_f32 removed (opt-in forms nobody defaulted) */
+                                gd_typed_edge_dot_f32, gd_spmm_csr_onepass_aux_f32, gd_del1_loss_wgrad_f32; gd_rowtarget_mse_f32 accepts dz = NULL;
+                                gd_agg_gemm_f32 and gd_spmm_csr_rowgroup_f32 removed (opt-in forms nobody defaulted) */
 
 enum {
   GD_OK = 0,
@@ -497,6 +498,21 @@ int gd_del_loss_bwd_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, 
                               const int32_t* loss_slot, const float* tm, const float* coef, const float* cnt_signed,
                               float* dz, int64_t ld_dz, float* dp, int64_t ld_dp, float* loss_partials,
                               float* wgrad_partials, void* stream);
+
+/* (ABI 8) FIRST-layer Del operator at d = 128, its folded loss and its weight gradient in one pass over the S_Df rows - what
+ * gd_rows_gemm_signs_f32 followed by gd_rows_gemm_wgrad_loss_f32 (dw = NULL) compute in two (p read once, z only written):
+ *     z[idx[s],:] = p[idx[s],:] @ W_D;   sign_out[s, 4] = packed [z > 0]  (the layout gd_rows_gemm_gated_f32 reads);
+ *     g_s = coef[u] (z - tm[u,:]) for u = loss_slot[s] >= 0, else 0;   + g_add[idx[s],:] when g_add != NULL
+ *     wgrad_partials[b] = the block's part of p[idx,:]^T g,  b < gd_rows_gemm_wgrad_blocks(n_sel)  (reduce: gd_step_tail_f32 /
+ *     gd_rows_gemm_wgrad_reduce_f32);  loss_partials[2b], [2b+1] = cnt |z - tm|^2 over the DEC / NI slots (as above).
+ * z must not alias p or g_add.  gd_del1_loss_wgrad_covers(n_sel, d): 1 where callers should prefer it (d = 128, launches of
+ * >= 65,536 rows; GD_DEL1_FUSED=0 turns it off).  Replaces DeletionLayer.forward of deletion1 + the layer-1 terms of the loss
+ * + autograd's deletion_weight gradient (framework/models/deletion.py:17-29, trainer/gnndelete_nodeemb.py:188-242). */
+int32_t gd_del1_loss_wgrad_covers(int32_t n_sel, int32_t d);
+int gd_del1_loss_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w, int32_t d, float* z,
+                           int64_t ld_z, uint32_t* sign_out, const int32_t* loss_slot, const float* tm, const float* coef,
+                           const float* cnt_signed, const float* g_add, int64_t ld_gadd, float* loss_partials,
+                           float* wgrad_partials, void* stream);
 
 /* ---------------------------------------------------------------- losses --------------- */
 

@@ -1411,3 +1411,66 @@ def test_typed_conv_on_a_row_partition_matches_the_whole_graph(n, m, R, world, f
         else:
             assert rel_l2(yr[lo:hi].cpu(), y[lo:hi].cpu()) < 1e-6 and rel_l2(dxr[lo:hi].cpu(), dx[lo:hi].cpu()) < 1e-6, rank
         assert float(yr[:lo].abs().sum()) == 0 and float(yr[hi:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize('with_add', [True, False])
+@pytest.mark.parametrize('n_sel', [66000, 70001])
+def test_del1_forward_loss_and_weight_gradient_in_one_pass(n_sel, with_add):
+    """gd_del1_loss_wgrad_f32 (first-layer Del at 128 features + folded loss + weight-gradient partials) against fp64: z and its
+    packed sign pattern, the two loss sums, dW after the fixed-order reduction; and against the two launches it replaces."""
+    from gnndelete_amd import _lib, ops
+    from gnndelete_amd._lib import ptr, check, stream_ptr
+    torch.manual_seed(n_sel)
+    dev, d, n = 'cuda', 128, 80000
+    p = torch.randn(n, d, device=dev)
+    w = (torch.eye(d, device=dev) + 0.05 * torch.randn(d, d, device=dev)).contiguous()
+    idx = torch.sort(torch.randperm(n, device=dev)[:n_sel]).values.to(torch.int32)
+    n_slots = n_sel - 5000
+    slot = torch.full((n_sel,), -1, dtype=torch.int32, device=dev)
+    has = torch.randperm(n_sel, device=dev)[:n_slots]
+    slot[has] = torch.randperm(n_slots, device=dev).to(torch.int32)
+    tm = torch.randn(n_slots, d, device=dev)
+    coef = torch.rand(n_slots, device=dev) * 1e-3
+    cnt = torch.randint(1, 4, (n_slots,), device=dev).float() * torch.where(torch.rand(n_slots, device=dev) < 0.3, -1.0, 1.0)
+    g_add = torch.randn(n, d, device=dev) * 1e-3 if with_add else None
+    lib = _lib.lib()
+    nb = lib.gd_rows_gemm_wgrad_blocks(n_sel)
+    z = torch.zeros(n, d, device=dev)
+    bits = torch.zeros(n_sel, 4, dtype=torch.int32, device=dev)
+    lp = torch.full((2 * nb,), float('nan'), device=dev)
+    ws = torch.full((max(1, lib.gd_rows_gemm_wgrad_workspace(n_sel, d, d)),), float('nan'), device=dev)
+    check(lib.gd_del1_loss_wgrad_f32(ptr(p), p.stride(0), ptr(idx), n_sel, ptr(w), d, ptr(z), z.stride(0), ptr(bits), ptr(slot), ptr(tm),
+                                     ptr(coef), ptr(cnt), ptr(g_add), d if with_add else 0, ptr(lp), ptr(ws), stream_ptr(p.device)),
+          'gd_del1_loss_wgrad_f32')
+    dw = torch.zeros(d, d, device=dev)
+    check(lib.gd_rows_gemm_wgrad_reduce_f32(ptr(ws), n_sel, d, d, ptr(dw), 0, None, None, None, None, 0.0, 0.0, 0.0, 0.0,
+                                            stream_ptr(p.device)), 'gd_rows_gemm_wgrad_reduce_f32')
+    li = idx.long()
+    p64, w64 = p.double()[li], w.double()
+    z64 = p64 @ w64
+    assert float((z[li].double() - z64).norm() / z64.norm()) < 1e-6
+    rest = torch.ones(n, dtype=torch.bool, device=dev)
+    rest[li] = False
+    assert float(z[rest].abs().max()) == 0.0                      # rows outside idx untouched
+    zk = z[li]
+    want_bits = ((zk > 0).view(n_sel, 4, 32).long() << torch.arange(32, device=dev)).sum(-1)
+    want_bits = torch.where(want_bits >= 2 ** 31, want_bits - 2 ** 32, want_bits).to(torch.int32)
+    assert torch.equal(bits, want_bits)                            # the pattern of the z the kernel stored
+    u = slot.long().clamp(min=0)
+    live = (slot >= 0).double()[:, None]
+    diff = (z64 - tm.double()[u]) * live
+    g64 = coef.double()[u][:, None] * diff
+    if with_add:
+        g64 = g64 + g_add.double()[li]
+    dw64 = p64.t() @ g64
+    assert float((dw.double() - dw64).norm() / dw64.norm()) < 2e-6
+    sq = (diff * diff).sum(1) * cnt.double()[u].abs()
+    neg = (cnt[u] < 0) & (slot >= 0)
+    sums = lp.view(-1, 2).double().sum(0)
+    assert abs(float(sums[0]) - float(sq[~neg].sum())) <= 1e-5 * float(sq[~neg].sum())
+    assert abs(float(sums[1]) - float(sq[neg].sum())) <= 1e-5 * float(sq[neg].sum())
+    # the two launches it replaces: same z up to the summation order of another matrix instruction, same sign bits where z is not at 0
+    z2 = torch.zeros(n, d, device=dev)
+    bits2 = torch.zeros(n_sel, 4, dtype=torch.int32, device=dev)
+    ops.rows_gemm(p, idx, w, out=z2, sign_bits=bits2)
+    assert float((z2 - z).abs().max()) < 1e-4
