@@ -32,6 +32,8 @@ PROTOTYPES = {
     'gd_rows_gemm_wgrad_reduce_f32': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _i32, _p, _p, _p, _p, _f64, _f64, _f64, _f64, _p]),
     'gd_step_tail_f32': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _f64, _f64, _f64, _f64,
                                         _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _p]),
+    'gd_step_tail_parts_f32': (ctypes.c_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _f64, _f64, _f64, _f64,
+                                        _p, _i32, _p, _i32, _p, _i32, _p, _p, _p, _p]),
     'gd_rgcn_conv_f32': (ctypes.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _i32, _i32, _p, _i64, _i32, _i32, _p]),
     'gd_rowpair_loss_f32': (ctypes.c_int, [_i32, _p, _i64, _p, _p, _i64, _p, _i32, _i32, _p, _p, _i64, _p]),
     'gd_random_walk': (ctypes.c_int, [_p, _p, _i32, _p, _i32, _i32, ctypes.c_uint64, _p, _p]),
@@ -83,7 +85,8 @@ PROTOTYPES = {
     'gd_del_loss_bwd_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     'gd_del_loss_bwd_wgrad_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p]),
     'gd_del1_loss_wgrad_covers': (ctypes.c_int32, [_i32, _i32]),
-    'gd_del1_loss_wgrad_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p]),
+    'gd_del1_loss_wgrad_parts': (ctypes.c_int32, [_i32]),
+    'gd_del1_loss_wgrad_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i32, _p]),
     'gd_rowtarget_mse_blocks': (_i32, [_i32]),
     'gd_loss_finalize_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p]),
     'gd_pairs_sigmoid_mse_workspace': (_i64, [_i32, _i32]),

@@ -778,10 +778,16 @@ extern "C" int32_t gd_del1_loss_wgrad_covers(int32_t n_sel, int32_t d) {
   return on && d == 128 && n_sel >= 65536 ? 1 : 0;
 }
 
+extern "C" int32_t gd_del1_loss_wgrad_parts(int32_t n_sel) {
+  if (n_sel <= 0) return 0;
+  const int nb = gd_rows_gemm_wgrad_blocks(n_sel);
+  return gd::ws_cu_count() < nb ? gd::ws_cu_count() : nb;
+}
+
 extern "C" int gd_del1_loss_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w, int32_t d,
                                       float* z, int64_t ld_z, uint32_t* sign_out, const int32_t* loss_slot, const float* tm,
                                       const float* coef, const float* cnt_signed, const float* g_add, int64_t ld_gadd,
-                                      float* loss_partials, float* wgrad_partials, void* stream) {
+                                      float* loss_partials, float* wgrad_partials, int32_t n_part, void* stream) {
   using namespace gd;
   const char* name = "gd_del1_loss_wgrad_f32";
   if (n_sel == 0) return GD_OK;
@@ -795,7 +801,8 @@ extern "C" int gd_del1_loss_wgrad_f32(const float* p, int64_t ld_p, const int32_
   GD_REQUIRE(p != z && g_add != z, GD_E_DIM, "%s: z must not alias p or g_add (the two waves of a pair read whole rows)", name);
   hipStream_t s = (hipStream_t)stream;
   const DelLoss loss{loss_slot, tm, coef, cnt_signed, loss_partials};
-  const int n_part = gd_rows_gemm_wgrad_blocks(n_sel);
+  GD_REQUIRE(n_part >= 1 && n_part <= gd_rows_gemm_wgrad_blocks(n_sel), GD_E_DIM,
+             "%s: n_part=%d outside [1, gd_rows_gemm_wgrad_blocks(n_sel)=%d]", name, n_part, gd_rows_gemm_wgrad_blocks(n_sel));
   const int grid = ws_cu_count() < n_part ? ws_cu_count() : n_part;
   constexpr int kLds = 4 * 128 * 64 * 4;
   if (g_add) {

@@ -1153,30 +1153,51 @@ extern "C" int gd_rows_gemm_wgrad_reduce_f32(const float* partials, int32_t n_se
                     const_cast<float*>(partials), param ? &adam : nullptr, stream, true);
 }
 
+static int step_tail_impl(const char* name, const float* partials1, int32_t nb1, int32_t d1, int32_t accumulate1, float* dw1, float* param1,
+                          float* exp_avg1, float* exp_avg_sq1, const float* partials2, int32_t nb2, int32_t d2, int32_t accumulate2,
+                          float* dw2, float* param2, float* exp_avg2, float* exp_avg_sq2, double lr, double beta1, double beta2,
+                          double eps, const float* loss_partials1, int32_t n1, const float* loss_partials2, int32_t n2, float* hist,
+                          int32_t capacity, int32_t* pos, int32_t* iter, int32_t* arrive, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(partials1 && dw1 && param1 && exp_avg1 && exp_avg_sq1 && partials2 && dw2 && param2 && exp_avg2 && exp_avg_sq2, GD_E_NULL,
+             "%s: null weight-gradient / optimizer pointer", name);
+  GD_REQUIRE(hist && pos && iter && arrive && capacity > 0 && (n1 == 0 || loss_partials1) && (n2 == 0 || loss_partials2), GD_E_NULL,
+             "%s: null bookkeeping pointer", name);
+  GD_REQUIRE(nb1 > 0 && nb2 > 0 && d1 > 0 && d2 > 0 && (d1 * d1) % 4 == 0 && (d2 * d2) % 4 == 0, GD_E_DIM,
+             "%s: both Del weights need rows and widths that are multiples of 2", name);
+  GD_REQUIRE(aligned16(partials1) && aligned16(dw1) && aligned16(partials2) && aligned16(dw2), GD_E_ALIGN, "%s: unaligned", name);
+  const TailJob j1{partials1, nb1, d1 * d1, accumulate1, dw1, param1, exp_avg1, exp_avg_sq1};
+  const TailJob j2{partials2, nb2, d2 * d2, accumulate2, dw2, param2, exp_avg2, exp_avg_sq2};
+  const TailFin fin{loss_partials1, n1, loss_partials2, n2, hist, capacity, pos, iter, arrive};
+  const int grid = (j1.n_elem / 4 + 15) / 16 + (j2.n_elem / 4 + 15) / 16 + 1;
+  GD_REQUIRE(grid <= 1024, GD_E_DIM, "%s: Del weights too large for the co-resident grid (%d blocks)", name, grid);
+  hipLaunchKernelGGL(step_tail_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, j1, j2, fin, lr, beta1, beta2, eps);
+  return launched("step_tail");
+}
+
 extern "C" int gd_step_tail_f32(const float* partials1, int32_t n_sel1, int32_t d1, int32_t accumulate1, float* dw1, float* param1,
                                 float* exp_avg1, float* exp_avg_sq1, const float* partials2, int32_t n_sel2, int32_t d2,
                                 int32_t accumulate2, float* dw2, float* param2, float* exp_avg2, float* exp_avg_sq2, double lr,
                                 double beta1, double beta2, double eps, const float* loss_partials1, int32_t n1,
                                 const float* loss_partials2, int32_t n2, float* hist, int32_t capacity, int32_t* pos, int32_t* iter,
                                 int32_t* arrive, void* stream) {
-  using namespace gd;
-  GD_REQUIRE(partials1 && dw1 && param1 && exp_avg1 && exp_avg_sq1 && partials2 && dw2 && param2 && exp_avg2 && exp_avg_sq2, GD_E_NULL,
-             "gd_step_tail_f32: null weight-gradient / optimizer pointer");
-  GD_REQUIRE(hist && pos && iter && arrive && capacity > 0 && (n1 == 0 || loss_partials1) && (n2 == 0 || loss_partials2), GD_E_NULL,
-             "gd_step_tail_f32: null bookkeeping pointer");
-  GD_REQUIRE(n_sel1 > 0 && n_sel2 > 0 && d1 > 0 && d2 > 0 && (d1 * d1) % 4 == 0 && (d2 * d2) % 4 == 0, GD_E_DIM,
-             "gd_step_tail_f32: both Del weights need rows and widths that are multiples of 2");
-  GD_REQUIRE(aligned16(partials1) && aligned16(dw1) && aligned16(partials2) && aligned16(dw2), GD_E_ALIGN, "gd_step_tail_f32: unaligned");
-  int nb1, nb2, rpb;
-  wgrad_geometry(n_sel1, &nb1, &rpb);
-  wgrad_geometry(n_sel2, &nb2, &rpb);
-  const TailJob j1{partials1, nb1, d1 * d1, accumulate1, dw1, param1, exp_avg1, exp_avg_sq1};
-  const TailJob j2{partials2, nb2, d2 * d2, accumulate2, dw2, param2, exp_avg2, exp_avg_sq2};
-  const TailFin fin{loss_partials1, n1, loss_partials2, n2, hist, capacity, pos, iter, arrive};
-  const int grid = (j1.n_elem / 4 + 15) / 16 + (j2.n_elem / 4 + 15) / 16 + 1;
-  GD_REQUIRE(grid <= 1024, GD_E_DIM, "gd_step_tail_f32: Del weights too large for the co-resident grid (%d blocks)", grid);
-  hipLaunchKernelGGL(step_tail_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, j1, j2, fin, lr, beta1, beta2, eps);
-  return launched("step_tail");
+  int nb1 = 0, nb2 = 0, rpb;
+  if (n_sel1 > 0) gd::wgrad_geometry(n_sel1, &nb1, &rpb);
+  if (n_sel2 > 0) gd::wgrad_geometry(n_sel2, &nb2, &rpb);
+  return step_tail_impl("gd_step_tail_f32", partials1, nb1, d1, accumulate1, dw1, param1, exp_avg1, exp_avg_sq1, partials2, nb2, d2, accumulate2,
+                        dw2, param2, exp_avg2, exp_avg_sq2, lr, beta1, beta2, eps, loss_partials1, n1, loss_partials2, n2, hist, capacity,
+                        pos, iter, arrive, stream);
+}
+
+extern "C" int gd_step_tail_parts_f32(const float* partials1, int32_t n_part1, int32_t d1, int32_t accumulate1, float* dw1, float* param1,
+                                      float* exp_avg1, float* exp_avg_sq1, const float* partials2, int32_t n_part2, int32_t d2,
+                                      int32_t accumulate2, float* dw2, float* param2, float* exp_avg2, float* exp_avg_sq2, double lr,
+                                      double beta1, double beta2, double eps, const float* loss_partials1, int32_t n1,
+                                      const float* loss_partials2, int32_t n2, float* hist, int32_t capacity, int32_t* pos,
+                                      int32_t* iter, int32_t* arrive, void* stream) {
+  return step_tail_impl("gd_step_tail_parts_f32", partials1, n_part1, d1, accumulate1, dw1, param1, exp_avg1, exp_avg_sq1, partials2, n_part2, d2,
+                        accumulate2, dw2, param2, exp_avg2, exp_avg_sq2, lr, beta1, beta2, eps, loss_partials1, n1, loss_partials2, n2,
+                        hist, capacity, pos, iter, arrive, stream);
 }
 
 extern "C" int32_t gd_rows_gemm_wgrad_blocks(int32_t n_sel) {

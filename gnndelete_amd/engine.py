@@ -389,6 +389,9 @@ class NodeembEngine:
         # only written - the weight-gradient launch re-read both)
         self._fuse_del1 = bool(self._tail and self._fuse_loss1 and self._split1 and loss_type in ('both_layerwise', 'only1')
                                and _lib.lib().gd_del1_loss_wgrad_covers(self.s1, self.h))
+        if self._fuse_del1:       # ... which leaves one partial matrix per compute unit (the tail launch is told how many)
+            self._lp1_blocks = _lib.lib().gd_del1_loss_wgrad_parts(self.s1)
+            self._lp1 = torch.zeros(2 * max(1, self._lp1_blocks + self.t1.outside_blocks()), **f32)
         self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat', SAGEConv: 'sage', RGCNConv: 'rgcn'}[type(conv2)]
         self._gat_dots = os.environ.get('GD_NO_GAT_DOTS') != '1'      # attention logits from the GEMM epilogue
         self._gat_r1 = None                                            # (att_src W2, att_dst W2): constants of the frozen conv2
@@ -834,11 +837,14 @@ class NodeembEngine:
                     ptr(self.iter_ctr), stream_ptr(self.x.device)), 'gd_loss_finalize_f32')
             if self._tail:
                 a1, a2 = self.adam1, self.adam2
-                check(_lib.lib().gd_step_tail_f32(
-                    ptr(self.ws1), self.s1, self.h, self._tail_acc[0], ptr(self.g1), ptr(a1.param), ptr(a1.m), ptr(a1.v),
-                    ptr(self.ws2), self.s2, self.o, self._tail_acc[1], ptr(self.g2), ptr(a2.param), ptr(a2.m), ptr(a2.v),
-                    a1.lr, a1.betas[0], a1.betas[1], a1.eps, ptr(p1), n1, ptr(p2), n2, ptr(self.hist), self.hist.shape[0],
-                    ptr(self.hist_pos), ptr(self.iter_ctr), ptr(self._arrive), stream_ptr(self.x.device)), 'gd_step_tail_f32')
+                lib_ = _lib.lib()
+                nw1 = self._lp1_blocks if self._fuse_del1 else lib_.gd_rows_gemm_wgrad_blocks(self.s1)      # partial matrices of W_D1
+                check(lib_.gd_step_tail_parts_f32(
+                    ptr(self.ws1), nw1, self.h, self._tail_acc[0], ptr(self.g1), ptr(a1.param), ptr(a1.m), ptr(a1.v),
+                    ptr(self.ws2), lib_.gd_rows_gemm_wgrad_blocks(self.s2), self.o, self._tail_acc[1], ptr(self.g2), ptr(a2.param),
+                    ptr(a2.m), ptr(a2.v), a1.lr, a1.betas[0], a1.betas[1], a1.eps, ptr(p1), n1, ptr(p2), n2, ptr(self.hist),
+                    self.hist.shape[0], ptr(self.hist_pos), ptr(self.iter_ctr), ptr(self._arrive), stream_ptr(self.x.device)),
+                    'gd_step_tail_parts_f32')
             elif self._overlap:
                 with self._fork():
                     finalize()
@@ -854,7 +860,7 @@ class NodeembEngine:
         check(_lib.lib().gd_del1_loss_wgrad_f32(
             ptr(self.pre1), self.pre1.stride(0), ptr(self.idx1), self.s1, ptr(self.wd1), self.h, ptr(self.z1), self.z1.stride(0),
             ptr(self.z1_pos), ptr(self._slot1), ptr(self.t1.tm), ptr(self.t1.coef), ptr(self._cnt_signed1), ptr(g_add),
-            g_add.stride(0) if g_add is not None else 0, ptr(self._lp1), ptr(self.ws1), stream_ptr(self.x.device)),
+            g_add.stride(0) if g_add is not None else 0, ptr(self._lp1), ptr(self.ws1), self._lp1_blocks, stream_ptr(self.x.device)),
             'gd_del1_loss_wgrad_f32')
 
     def _del2_fused(self):

@@ -458,6 +458,15 @@ int gd_step_tail_f32(const float* partials1, int32_t n_sel1, int32_t d1, int32_t
                      double beta1, double beta2, double eps, const float* loss_partials1, int32_t n1,
                      const float* loss_partials2, int32_t n2, float* hist, int32_t capacity, int32_t* pos, int32_t* iter,
                      int32_t* arrive, void* stream);
+/* (ABI 8) The same launch with the NUMBER OF PARTIAL MATRICES of each weight given instead of derived from a row count
+ * (gd_del1_loss_wgrad_f32 leaves gd_del1_loss_wgrad_parts(n_sel) of them - one per compute unit - where the weight-gradient
+ * entries leave gd_rows_gemm_wgrad_blocks(n_sel)): same summation order over the partials that exist. */
+int gd_step_tail_parts_f32(const float* partials1, int32_t n_part1, int32_t d1, int32_t accumulate1, float* dw1, float* param1,
+                           float* exp_avg1, float* exp_avg_sq1, const float* partials2, int32_t n_part2, int32_t d2,
+                           int32_t accumulate2, float* dw2, float* param2, float* exp_avg2, float* exp_avg_sq2, double lr,
+                           double beta1, double beta2, double eps, const float* loss_partials1, int32_t n1,
+                           const float* loss_partials2, int32_t n2, float* hist, int32_t capacity, int32_t* pos, int32_t* iter,
+                           int32_t* arrive, void* stream);
 
 /* Weight gradient whose upstream gradient is FORMED while it is fetched, from the folded DEC + NI
  * row-target terms of that layer (see gd_rowtarget_mse_f32): for selected row s with loss slot
@@ -503,16 +512,19 @@ int gd_del_loss_bwd_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, 
  * gd_rows_gemm_signs_f32 followed by gd_rows_gemm_wgrad_loss_f32 (dw = NULL) compute in two (p read once, z only written):
  *     z[idx[s],:] = p[idx[s],:] @ W_D;   sign_out[s, 4] = packed [z > 0]  (the layout gd_rows_gemm_gated_f32 reads);
  *     g_s = coef[u] (z - tm[u,:]) for u = loss_slot[s] >= 0, else 0;   + g_add[idx[s],:] when g_add != NULL
- *     wgrad_partials[b] = the block's part of p[idx,:]^T g,  b < gd_rows_gemm_wgrad_blocks(n_sel)  (reduce: gd_step_tail_f32 /
- *     gd_rows_gemm_wgrad_reduce_f32);  loss_partials[2b], [2b+1] = cnt |z - tm|^2 over the DEC / NI slots (as above).
+ *     wgrad_partials[b] = block b's part of p[idx,:]^T g and loss_partials[2b], [2b+1] = its cnt |z - tm|^2 over the DEC / NI slots,
+ *     b < n_part: the caller says how many partial slots it wants filled - gd_del1_loss_wgrad_parts(n_sel) (what the launch has
+ *     blocks for: reduce with gd_step_tail_parts_f32) up to gd_rows_gemm_wgrad_blocks(n_sel) (slots beyond the launch's blocks are
+ *     written as zeros, so that gd_rows_gemm_wgrad_reduce_f32 / gd_step_tail_f32, which count that many, finish it).
  * z must not alias p or g_add.  gd_del1_loss_wgrad_covers(n_sel, d): 1 where callers should prefer it (d = 128, launches of
  * >= 65,536 rows; GD_DEL1_FUSED=0 turns it off).  Replaces DeletionLayer.forward of deletion1 + the layer-1 terms of the loss
  * + autograd's deletion_weight gradient (framework/models/deletion.py:17-29, trainer/gnndelete_nodeemb.py:188-242). */
 int32_t gd_del1_loss_wgrad_covers(int32_t n_sel, int32_t d);
+int32_t gd_del1_loss_wgrad_parts(int32_t n_sel);
 int gd_del1_loss_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w, int32_t d, float* z,
                            int64_t ld_z, uint32_t* sign_out, const int32_t* loss_slot, const float* tm, const float* coef,
                            const float* cnt_signed, const float* g_add, int64_t ld_gadd, float* loss_partials,
-                           float* wgrad_partials, void* stream);
+                           float* wgrad_partials, int32_t n_part, void* stream);
 
 /* ---------------------------------------------------------------- losses --------------- */
 

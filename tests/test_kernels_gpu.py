@@ -1413,9 +1413,10 @@ def test_typed_conv_on_a_row_partition_matches_the_whole_graph(n, m, R, world, f
         assert float(yr[:lo].abs().sum()) == 0 and float(yr[hi:].abs().sum()) == 0
 
 
+@pytest.mark.parametrize('compact', [False, True])
 @pytest.mark.parametrize('with_add', [True, False])
 @pytest.mark.parametrize('n_sel', [66000, 70001])
-def test_del1_forward_loss_and_weight_gradient_in_one_pass(n_sel, with_add):
+def test_del1_forward_loss_and_weight_gradient_in_one_pass(n_sel, with_add, compact):
     """gd_del1_loss_wgrad_f32 (first-layer Del at 128 features + folded loss + weight-gradient partials) against fp64: z and its
     packed sign pattern, the two loss sums, dW after the fixed-order reduction; and against the two launches it replaces."""
     from gnndelete_amd import _lib, ops
@@ -1434,17 +1435,23 @@ def test_del1_forward_loss_and_weight_gradient_in_one_pass(n_sel, with_add):
     cnt = torch.randint(1, 4, (n_slots,), device=dev).float() * torch.where(torch.rand(n_slots, device=dev) < 0.3, -1.0, 1.0)
     g_add = torch.randn(n, d, device=dev) * 1e-3 if with_add else None
     lib = _lib.lib()
-    nb = lib.gd_rows_gemm_wgrad_blocks(n_sel)
+    # compact: one partial matrix per block of the launch (what gd_step_tail_parts_f32 is told); else as many slots as the
+    # weight-gradient entries leave, the ones beyond the launch's blocks zeroed (what gd_rows_gemm_wgrad_reduce_f32 counts)
+    nb = lib.gd_del1_loss_wgrad_parts(n_sel) if compact else lib.gd_rows_gemm_wgrad_blocks(n_sel)
+    assert 1 <= lib.gd_del1_loss_wgrad_parts(n_sel) <= lib.gd_rows_gemm_wgrad_blocks(n_sel)
     z = torch.zeros(n, d, device=dev)
     bits = torch.zeros(n_sel, 4, dtype=torch.int32, device=dev)
     lp = torch.full((2 * nb,), float('nan'), device=dev)
     ws = torch.full((max(1, lib.gd_rows_gemm_wgrad_workspace(n_sel, d, d)),), float('nan'), device=dev)
     check(lib.gd_del1_loss_wgrad_f32(ptr(p), p.stride(0), ptr(idx), n_sel, ptr(w), d, ptr(z), z.stride(0), ptr(bits), ptr(slot), ptr(tm),
-                                     ptr(coef), ptr(cnt), ptr(g_add), d if with_add else 0, ptr(lp), ptr(ws), stream_ptr(p.device)),
+                                     ptr(coef), ptr(cnt), ptr(g_add), d if with_add else 0, ptr(lp), ptr(ws), nb, stream_ptr(p.device)),
           'gd_del1_loss_wgrad_f32')
-    dw = torch.zeros(d, d, device=dev)
-    check(lib.gd_rows_gemm_wgrad_reduce_f32(ptr(ws), n_sel, d, d, ptr(dw), 0, None, None, None, None, 0.0, 0.0, 0.0, 0.0,
-                                            stream_ptr(p.device)), 'gd_rows_gemm_wgrad_reduce_f32')
+    if compact:
+        dw = ws[:nb * d * d].view(nb, d, d).double().sum(0).float()
+    else:
+        dw = torch.zeros(d, d, device=dev)
+        check(lib.gd_rows_gemm_wgrad_reduce_f32(ptr(ws), n_sel, d, d, ptr(dw), 0, None, None, None, None, 0.0, 0.0, 0.0, 0.0,
+                                                stream_ptr(p.device)), 'gd_rows_gemm_wgrad_reduce_f32')
     li = idx.long()
     p64, w64 = p.double()[li], w.double()
     z64 = p64 @ w64

@@ -28,7 +28,7 @@ def timed(fn, reps=30):
 
 def fused(ga):
     return lambda: check(lib.gd_del1_loss_wgrad_f32(ptr(p), p.stride(0), ptr(idx), s, ptr(w), d, ptr(z), z.stride(0), ptr(bits), ptr(slot), ptr(tm),
-                                                    ptr(coef), ptr(cnt), ptr(ga), d if ga is not None else 0, ptr(lp), ptr(ws), stream_ptr(p.device)), 'fused')
+                                                    ptr(coef), ptr(cnt), ptr(ga), d if ga is not None else 0, ptr(lp), ptr(ws), int(os.environ.get('PARTS', nb)), stream_ptr(p.device)), 'fused')
 print(f'fused with g_add {timed(fused(g_add)):.1f} us, without {timed(fused(None)):.1f} us')
 # cache-resident operands: every unit reads the same 16 rows / targets (what the kernel costs without memory)
 idx_keep, slot_keep = idx.clone(), slot.clone()
