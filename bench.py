@@ -134,7 +134,8 @@ def layer1_share(stage_profile, default=0.29):
             st = json.load(f)['stages']
         tot = sum(v['in_step_us'] for v in st.values())
         names = list(st)
-        l1 = sum(st[k]['in_step_us'] for k in names[:names.index('del1')]) if 'del1' in st else sum(st[k]['in_step_us'] for k in names[:2])
+        first_del = next((i for i, k in enumerate(names) if k.startswith('del1')), None)      # ('del1' or the fused 'del1_loss_wgrad1')
+        l1 = sum(st[k]['in_step_us'] for k in names[:first_del]) if first_del is not None else sum(st[k]['in_step_us'] for k in names[:2])
         return (l1 / tot, os.path.relpath(stage_profile, ROOT)) if tot > 0 else (default, 'default')
     except Exception:                                            # noqa: BLE001
         return default, 'default (no stage profile of this model)'
@@ -622,10 +623,17 @@ def stage_rooflines(eng, prof):
     stages = [
         ('xw1', 'x W1^T (frozen, recomputed every step)', lambda: eng._linear(eng.x, c1.lin.weight), 2.0 * n * f * h, 4.0 * (n * f + f * h + n * h)),
         ('spmm1', 'pre1 = A t1 + b1 (d=128)', lambda: ops._spmm_raw(g.rowptr, g.col, g.val, t1, c1.bias, 0.0, n, g.plan, out=y128), 2.0 * nnz * h, spmm_b(h)),
+    ] + ([
+        # (round 5: Del-1, the layer-1 loss and the W_D1 weight gradient in ONE pass - two products, four row streams: pre1 and the
+        #  targets and dh read, z1 written; the two launches below moved six)
+        ('del1_loss_wgrad1', 'z1[S1] = pre1[S1] W_D1 + sign bits, layer-1 loss sums, dW_D1 partial sums = pre1[S1]^T (coef (z1 - t) + dh)[S1]',
+         lambda: eng._del1_fused(eng.dh), 4.0 * s1 * h * h, 4.0 * (4 * s1 * h + h * h) + 20.0 * s1),
+    ] if eng._fuse_del1 else [
         ('del1', 'z1[S1] = pre1[S1] W_D1 + sign bits', lambda: ops.rows_gemm(eng.pre1, eng.idx1, eng.wd1, out=eng.z1, sign_bits=eng.z1_pos),
          2.0 * s1 * h * h, 4.0 * (2 * s1 * h + h * h) + 20.0 * s1),
         ('wgrad1', 'dW_D1 partial products = pre1[S1]^T (coef (z1 - t) + dh)[S1] + layer-1 loss sums',
          lambda: eng._wgrad1(False, eng.dh), 2.0 * s1 * h * h, 4.0 * 4 * s1 * h),
+    ]) + [
         ('t2', 't2 = relu(z1 | pre1) W2^T', lambda: eng._linear_relu_z1(c2.lin.weight), 2.0 * n * h * o, 4.0 * (n * h + n * o + h * o) + n),
         ('spmm2', 'p2 = A t2 + b2 (d=64)', lambda: ops._spmm_raw(g.rowptr, g.col, g.val, t2, c2.bias, 0.0, n, g.plan, out=y64), 2.0 * nnz * o, spmm_b(o)),
         # (three products and three row streams - p2 read, targets read, dp2 written - when the W_D2 weight gradient's partial

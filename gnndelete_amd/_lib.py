@@ -84,6 +84,8 @@ PROTOTYPES = {
     'gd_del_loss_bwd_blocks': (_i32, [_i32]),
     'gd_del_loss_bwd_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     'gd_del_loss_bwd_wgrad_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p]),
+    'gd_del_loss_bwd_wgrad_parts': (ctypes.c_int32, [_i32, _i32]),
+    'gd_del_loss_bwd_wgrad_parts_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i32, _p]),
     'gd_del1_loss_wgrad_covers': (ctypes.c_int32, [_i32, _i32]),
     'gd_del1_loss_wgrad_parts': (ctypes.c_int32, [_i32]),
     'gd_del1_loss_wgrad_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i32, _p]),

@@ -697,7 +697,7 @@ extern "C" int32_t gd_rows_gemm_wgrad_blocks(int32_t n_sel);
 static int del_loss_bwd_impl(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w,
                              int32_t d, const int32_t* loss_slot, const float* tm, const float* coef,
                              const float* cnt_signed, float* dz, int64_t ld_dz, float* dp, int64_t ld_dp,
-                             float* loss_partials, float* wgrad_partials, bool with_wgrad, void* stream) {
+                             float* loss_partials, float* wgrad_partials, bool with_wgrad, void* stream, int32_t n_part_req = 0) {
   using namespace gd;
   const char* name = with_wgrad ? "gd_del_loss_bwd_wgrad_f32" : "gd_del_loss_bwd_f32";
   if (n_sel == 0) return GD_OK;
@@ -724,7 +724,12 @@ static int del_loss_bwd_impl(const float* p, int64_t ld_p, const int32_t* idx, i
   // the D x D accumulators reuses the whole allocation: 4 D^2 floats <= what is there)
   static const bool ws_on = [] { const char* e = getenv("GD_DEL2_WS"); return !(e && atoi(e) == 0); }();
   if (ws_on && d == 64 && n_sel >= 65536) {       // weight-stationary form: one wave per SIMD, 16-row units (above)
-    const int n_part = gd_rows_gemm_wgrad_blocks(n_sel);
+    // n_part_req (gd_del_loss_bwd_wgrad_parts_f32): fill that many partial slots (>= this launch's blocks) instead of
+    // gd_rows_gemm_wgrad_blocks(n_sel) of them
+    const int n_all = gd_rows_gemm_wgrad_blocks(n_sel);
+    const int n_part = n_part_req > 0 ? n_part_req : n_all;
+    GD_REQUIRE(n_part <= n_all && n_part >= (ws_cu_count() < n_all ? ws_cu_count() : n_all), GD_E_DIM,
+               "%s: n_part=%d outside [gd_del_loss_bwd_wgrad_parts, gd_rows_gemm_wgrad_blocks = %d]", name, n_part, n_all);
     const int grid_ws = ws_cu_count() < n_part ? ws_cu_count() : n_part;
     constexpr int kLdsWs = 4 * 64 * 64 * 4;
     if (dz) {
@@ -740,6 +745,8 @@ static int del_loss_bwd_impl(const float* p, int64_t ld_p, const int32_t* idx, i
     }
     return launched("del_loss_bwd_ws");
   }
+  GD_REQUIRE(n_part_req == 0 || n_part_req == gd_rows_gemm_wgrad_blocks(n_sel), GD_E_DIM,
+             "%s: n_part=%d but this size leaves gd_rows_gemm_wgrad_blocks(n_sel) = %d partials", name, n_part_req, gd_rows_gemm_wgrad_blocks(n_sel));
   const dim3 grid(gd_rows_gemm_wgrad_blocks(n_sel));
 #define GD_DF_CASE(NT_)                                                                                                        \
   do {                                                                                                                         \
@@ -771,6 +778,24 @@ extern "C" int gd_del_loss_bwd_wgrad_f32(const float* p, int64_t ld_p, const int
                                          float* loss_partials, float* wgrad_partials, void* stream) {
   return del_loss_bwd_impl(p, ld_p, idx, n_sel, w, d, loss_slot, tm, coef, cnt_signed, dz, ld_dz, dp, ld_dp, loss_partials,
                            wgrad_partials, true, stream);
+}
+
+// partial matrices gd_del_loss_bwd_wgrad_parts_f32 has blocks for (the weight-stationary form: one per compute unit)
+extern "C" int32_t gd_del_loss_bwd_wgrad_parts(int32_t n_sel, int32_t d) {
+  if (n_sel <= 0) return 0;
+  const int nb = gd_rows_gemm_wgrad_blocks(n_sel);
+  static const bool ws_on = [] { const char* e = getenv("GD_DEL2_WS"); return !(e && atoi(e) == 0); }();
+  if (ws_on && d == 64 && n_sel >= 65536) return gd::ws_cu_count() < nb ? gd::ws_cu_count() : nb;
+  return nb;
+}
+
+extern "C" int gd_del_loss_bwd_wgrad_parts_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w, int32_t d,
+                                               const int32_t* loss_slot, const float* tm, const float* coef, const float* cnt_signed,
+                                               float* dz, int64_t ld_dz, float* dp, int64_t ld_dp, float* loss_partials,
+                                               float* wgrad_partials, int32_t n_part, void* stream) {
+  GD_REQUIRE(n_part > 0 || n_sel == 0, GD_E_DIM, "gd_del_loss_bwd_wgrad_parts_f32: n_part=%d", n_part);
+  return del_loss_bwd_impl(p, ld_p, idx, n_sel, w, d, loss_slot, tm, coef, cnt_signed, dz, ld_dz, dp, ld_dp, loss_partials,
+                           wgrad_partials, true, stream, n_part);
 }
 
 extern "C" int32_t gd_del1_loss_wgrad_covers(int32_t n_sel, int32_t d) {

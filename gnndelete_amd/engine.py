@@ -381,7 +381,7 @@ class NodeembEngine:
         # kernel itself (gd_del_loss_bwd_wgrad_f32: p2 and dz2 are in its registers) - no weight-gradient launch, no dz2 buffer
         self._fuse_wg2 = self._tail and self._fuse_l2 and os.environ.get('GD_NO_FUSED_WGRAD2') != '1'
         if self._fuse_wg2:
-            self._lp2_blocks = _lib.lib().gd_rows_gemm_wgrad_blocks(self.s2)
+            self._lp2_blocks = _lib.lib().gd_del_loss_bwd_wgrad_parts(self.s2, self.o)      # (one per compute unit in the step-sized form)
             self._lp2 = torch.zeros(2 * max(1, self._lp2_blocks + self.t2.outside_blocks()), **f32)
         # (round 5) ... and where the W_D1 step of an iteration only waits for gradients that exist when Del-1 runs (the
         # layer-wise types: this iteration's layer-1 loss + the gradient conv2 sent back in the PREVIOUS one), Del-1 itself, the
@@ -841,7 +841,8 @@ class NodeembEngine:
                 nw1 = self._lp1_blocks if self._fuse_del1 else lib_.gd_rows_gemm_wgrad_blocks(self.s1)      # partial matrices of W_D1
                 check(lib_.gd_step_tail_parts_f32(
                     ptr(self.ws1), nw1, self.h, self._tail_acc[0], ptr(self.g1), ptr(a1.param), ptr(a1.m), ptr(a1.v),
-                    ptr(self.ws2), lib_.gd_rows_gemm_wgrad_blocks(self.s2), self.o, self._tail_acc[1], ptr(self.g2), ptr(a2.param),
+                    ptr(self.ws2), self._lp2_blocks if self._fuse_wg2 else lib_.gd_rows_gemm_wgrad_blocks(self.s2), self.o,
+                    self._tail_acc[1], ptr(self.g2), ptr(a2.param),
                     ptr(a2.m), ptr(a2.v), a1.lr, a1.betas[0], a1.betas[1], a1.eps, ptr(p1), n1, ptr(p2), n2, ptr(self.hist),
                     self.hist.shape[0], ptr(self.hist_pos), ptr(self.iter_ctr), ptr(self._arrive), stream_ptr(self.x.device)),
                     'gd_step_tail_parts_f32')
@@ -867,11 +868,11 @@ class NodeembEngine:
         """Del-2 forward + folded layer-2 loss + Del-2 input gradient (+ the W_D2 weight gradient's partial sums) in one
         kernel (csrc/del_fused.hip)."""
         if self._fuse_wg2:
-            check(_lib.lib().gd_del_loss_bwd_wgrad_f32(
+            check(_lib.lib().gd_del_loss_bwd_wgrad_parts_f32(
                 ptr(self.p2), self.p2.stride(0), ptr(self.idx2), self.s2, ptr(self.wd2), self.o, ptr(self._slot2),
                 ptr(self.t2.tm), ptr(self.t2.coef), ptr(self._cnt_signed2), None, self.o,
-                ptr(self.dz2), self.dz2.stride(0), ptr(self._lp2), ptr(self.ws2), stream_ptr(self.x.device)),
-                'gd_del_loss_bwd_wgrad_f32')
+                ptr(self.dz2), self.dz2.stride(0), ptr(self._lp2), ptr(self.ws2), self._lp2_blocks, stream_ptr(self.x.device)),
+                'gd_del_loss_bwd_wgrad_parts_f32')
             return
         check(_lib.lib().gd_del_loss_bwd_f32(
             ptr(self.p2), self.p2.stride(0), ptr(self.idx2), self.s2, ptr(self.wd2), self.o, ptr(self._slot2),

@@ -369,6 +369,16 @@ class _Dense(torch.autograd.Function):
                 dx = rows_gemm(dy, None, w, trans_w=False)                  # dy [*, out] @ W [out, in]
             elif mfma_out_width(in_f):
                 dx = gemm_wide(dy, w)                                       # [*, out] @ [out, in], the K-tiled kernel
+            elif out_f <= 1024:
+                # a wide, odd input width (the reference never asks for this gradient: its wide inputs are the node features):
+                # 128 columns of dx at a time - dy [*, out] @ W[:, j : j + 128] - into a padded buffer (16-byte row pitch)
+                wide = (in_f + 127) // 128 * 128
+                dxp = torch.empty(dy.shape[0], wide, dtype=torch.float32, device=dy.device)
+                wp = torch.zeros(out_f, wide, dtype=torch.float32, device=dy.device)
+                wp[:, :in_f] = w
+                for j in range(0, wide, 128):
+                    rows_gemm(dy, None, wp[:, j:j + 128].contiguous(), trans_w=False, out=dxp[:, j:j + 128])
+                dx = dxp[:, :in_f].contiguous()
             else:
                 raise NotImplementedError(f'ops.dense: the input gradient of a {in_f} -> {out_f} product has no kernel; there is no '
                                           'vendor-BLAS fallback (the reference never asks for it: its wide inputs are the node features)')

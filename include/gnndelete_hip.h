@@ -507,6 +507,14 @@ int gd_del_loss_bwd_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, 
                               const int32_t* loss_slot, const float* tm, const float* coef, const float* cnt_signed,
                               float* dz, int64_t ld_dz, float* dp, int64_t ld_dp, float* loss_partials,
                               float* wgrad_partials, void* stream);
+/* (ABI 8) The same with the number of partial slots to fill given: gd_del_loss_bwd_wgrad_parts(n_sel, d) (what the launch has
+ * blocks for - one per compute unit in the weight-stationary form of d = 64 at >= 65,536 rows; reduce with
+ * gd_step_tail_parts_f32) ... gd_rows_gemm_wgrad_blocks(n_sel); loss_partials holds 2 * n_part floats. */
+int32_t gd_del_loss_bwd_wgrad_parts(int32_t n_sel, int32_t d);
+int gd_del_loss_bwd_wgrad_parts_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w, int32_t d,
+                                    const int32_t* loss_slot, const float* tm, const float* coef, const float* cnt_signed,
+                                    float* dz, int64_t ld_dz, float* dp, int64_t ld_dp, float* loss_partials,
+                                    float* wgrad_partials, int32_t n_part, void* stream);
 
 /* (ABI 8) FIRST-layer Del operator at d = 128, its folded loss and its weight gradient in one pass over the S_Df rows - what
  * gd_rows_gemm_signs_f32 followed by gd_rows_gemm_wgrad_loss_f32 (dw = NULL) compute in two (p read once, z only written):
