@@ -354,8 +354,20 @@ class _Dense(torch.autograd.Function):
             return gemm_wide(x, wt, b, const_x=const_x)
         if in_f <= 1024:
             return rows_gemm(x, None, w, trans_w=True, bias=b)            # any widths: the one-wave-per-row kernel
-        raise NotImplementedError(f'ops.dense: a {in_f} -> {out_f} product has no kernel (inputs above 1,024 floats need an output width '
-                                  'in {32, 64, 96, 128}); there is no vendor-BLAS fallback')
+        # a wide input with an output width the K-tiled kernel has no tile for (a class count, ...): blocks of <= 128 output
+        # columns, each zero-padded to a multiple of 32
+        y = torch.empty(x.shape[0], out_f, dtype=torch.float32, device=x.device)
+        for j in range(0, out_f, 128):
+            nb = min(128, out_f - j)
+            npad = (nb + 31) // 32 * 32
+            wt = torch.zeros(in_f, npad, dtype=torch.float32, device=x.device)
+            wt[:, :nb] = w[j:j + nb].t()
+            bp = None
+            if b is not None:
+                bp = torch.zeros(npad, dtype=torch.float32, device=x.device)
+                bp[:nb] = b[j:j + nb]
+            y[:, j:j + nb] = gemm_wide(x, wt, bp, const_x=const_x)[:, :nb]
+        return y
 
     @staticmethod
     def backward(ctx, dy):
