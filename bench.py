@@ -519,6 +519,14 @@ def time_wgrad(eng):
     from gnndelete_amd import ops
     if eng.s1 == 0 or not getattr(eng, '_fuse_loss1', False):
         return None
+    if getattr(eng, '_fuse_del1', False):
+        # round 5: the weight gradient comes out of the Del-1 pass itself (two products, four row streams: pre1 / targets / dh read, z1 written)
+        dur = _avg_seconds(lambda: eng._del1_fused(eng.dh))
+        flops = 4.0 * eng.s1 * eng.h * eng.h
+        nbytes = 4.0 * 4 * eng.s1 * eng.h
+        return {'kernel': 'del1_loss_wgrad_ws_kernel<true> (Del-1 forward + folded layer-1 loss + W_D1 gradient partial sums in one pass over the S1 rows, d=128)',
+                'avg_us': dur * 1e6, 'tflops': flops / dur / 1e12, 'frac_mfma': flops / dur / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                'hbm_gbs': nbytes / dur / 1e9, 'frac_hbm': nbytes / dur / 1e9 / HBM_PEAK_GBS, 'rows': eng.s1}
     dur = _avg_seconds(lambda: eng._wgrad1(False, eng.dh))     # (steps the Del weights: the engine is discarded afterwards)
     flops = 2.0 * eng.s1 * eng.h * eng.h
     nbytes = 4.0 * 4 * eng.s1 * eng.h

@@ -381,8 +381,8 @@ class NodeembEngine:
         # kernel itself (gd_del_loss_bwd_wgrad_f32: p2 and dz2 are in its registers) - no weight-gradient launch, no dz2 buffer
         self._fuse_wg2 = self._tail and self._fuse_l2 and os.environ.get('GD_NO_FUSED_WGRAD2') != '1'
         if self._fuse_wg2:
+            self._lp2 = torch.zeros(2 * max(1, _lib.lib().gd_rows_gemm_wgrad_blocks(self.s2) + self.t2.outside_blocks()), **f32)
             self._lp2_blocks = _lib.lib().gd_del_loss_bwd_wgrad_parts(self.s2, self.o)      # (one per compute unit in the step-sized form)
-            self._lp2 = torch.zeros(2 * max(1, self._lp2_blocks + self.t2.outside_blocks()), **f32)
         # (round 5) ... and where the W_D1 step of an iteration only waits for gradients that exist when Del-1 runs (the
         # layer-wise types: this iteration's layer-1 loss + the gradient conv2 sent back in the PREVIOUS one), Del-1 itself, the
         # layer-1 loss and the W_D1 weight gradient are ONE pass over the S1 rows (gd_del1_loss_wgrad_f32: pre1 read once, z1
@@ -390,8 +390,9 @@ class NodeembEngine:
         self._fuse_del1 = bool(self._tail and self._fuse_loss1 and self._split1 and loss_type in ('both_layerwise', 'only1')
                                and _lib.lib().gd_del1_loss_wgrad_covers(self.s1, self.h))
         if self._fuse_del1:       # ... which leaves one partial matrix per compute unit (the tail launch is told how many)
+            # (the buffer keeps the size of the two-launch form: bench.py's stand-alone timing of the weight-gradient kernel
+            #  writes gd_rows_gemm_wgrad_blocks(s1) block sums into it)
             self._lp1_blocks = _lib.lib().gd_del1_loss_wgrad_parts(self.s1)
-            self._lp1 = torch.zeros(2 * max(1, self._lp1_blocks + self.t1.outside_blocks()), **f32)
         self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat', SAGEConv: 'sage', RGCNConv: 'rgcn'}[type(conv2)]
         self._gat_dots = os.environ.get('GD_NO_GAT_DOTS') != '1'      # attention logits from the GEMM epilogue
         self._gat_r1 = None                                            # (att_src W2, att_dst W2): constants of the frozen conv2

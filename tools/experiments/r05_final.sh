@@ -15,6 +15,11 @@ python bench.py --gnn gat --no_cpu_baseline --no_cached_rate > gpurun_out/r05_be
 python bench.py --gnn sage --no_cpu_baseline --no_cached_rate > gpurun_out/r05_bench_sage.json 2>> gpurun_out/r05_bench_default.err
 python bench.py --workload synth-biokg --gnn rgcn --df in --df_size 2.5 > gpurun_out/r05_bench_synth_biokg_rgcn.json 2>> gpurun_out/r05_bench_default.err
 bash tools/experiments/bench_table.sh > gpurun_out/r05_bench_table.txt 2>&1
+# one R-GCN step as the profiler sees it (launch list + per-kernel totals)
+rm -rf /tmp/pmc/kt_rgcn
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pmc/kt_rgcn -o p -- python bench.py --workload synth-biokg --gnn rgcn --df in --df_size 2.5 --no_cpu_baseline --no_cached_rate --steps 20 --warmup 4 --repeats 1 > /tmp/pmc/kt_rgcn.log 2>&1
+python tools/rocpd_timeline.py /tmp/pmc/kt_rgcn/p_results.db step_tail 6 > gpurun_out/r05_rgcn_step_timeline.md 2>&1
+python tools/rocpd_summary.py /tmp/pmc/kt_rgcn/p_results.db gpurun_out/r05_rgcn_kernel_stats.md > /dev/null 2>&1
 tail -c 400 gpurun_out/r05_final_profile.log; tail -c 300 gpurun_out/r05_final_gat_profile.log; tail -c 300 gpurun_out/r05_final_sage_profile.log; cat gpurun_out/r05_bench_table.txt
 python - <<'PY'
 import json
