@@ -80,6 +80,14 @@ def test_full_size_training_parity(workload, gnn, df, df_size):
                         ni1, ni2, loss_type='both_layerwise', alpha=0.5, lr=1e-3)
     assert eng.perm is not None, 'full-size requests run in the locality order'
     assert eng.graph.plan.n_split > 0 or workload == 'synth-cora', 'hub rows are split over several work items at this size'
+    if workload == 'synth-collab':
+        # the collab-sized step runs the one-pass Del-1 form (round 5); its compact partial counts must not shrink the buffers the
+        # two-launch kernels write when bench.py times them on this engine (a 512-block loss-partial write into a 256-block buffer
+        # ran over the tail launch's check-in counter: a hang under the profiler, a memory fault in the GAT line)
+        from gnndelete_amd import _lib
+        assert eng._fuse_del1 and eng._fuse_wg2
+        assert eng._lp1.numel() >= 2 * _lib.lib().gd_rows_gemm_wgrad_blocks(eng.s1)
+        assert eng._lp2.numel() >= 2 * _lib.lib().gd_rows_gemm_wgrad_blocks(eng.s2)
     for _ in range(iters):
         eng.step()
     hist = eng.loss_history()
