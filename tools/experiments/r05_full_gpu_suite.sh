@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 > gpurun_out/r05_smoke.log
 timeout 2400 python -m pytest tests -x -q -m gpu --durations=15 2>&1 | tail -40 > gpurun_out/r05_full_gpu_suite.log
-tail -25 gpurun_out/r05_full_gpu_suite.log
+cat gpurun_out/r05_smoke.log; tail -25 gpurun_out/r05_full_gpu_suite.log
