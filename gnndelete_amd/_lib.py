@@ -72,6 +72,8 @@ PROTOTYPES = {
                                           _p, _p, _p]),
     'gd_rowtarget_mse_workspace': (_i64, [_i32]),
     'gd_rowtarget_mse_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p, _p, _p]),
+    'gd_rowtarget_mse_pair_covers': (ctypes.c_int32, [_i32, _i32]),
+    'gd_rowtarget_mse_pair_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p, _p, _i64, _p, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p, _p]),
     'gd_gemm_f32_workspace': (_i64, [_i32, _i32, _i32]),
     'gd_gemm_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _i32, _p, _p, _i64, _p, _p]),
     'gd_edge_dot_f32': (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _i64, _p, _i64, _p, _p]),

@@ -84,19 +84,25 @@ __global__ __launch_bounds__(256) void pair_sum_reduce_kernel(const float* __res
 // write dz[row_u] = coef_u (z - tbar),  sums[kind_u] += cnt_u |z - tbar|^2.
 // A wave takes 64 consecutive loss rows: one coalesced fetch of their (row, coef, cnt, kind),
 // then its G lane groups walk them 4 rows at a time (8 row loads in flight per group).
+struct RowTargetJob {
+  const float* z; int64_t ld_z; const float* tm; int32_t d4;
+  const int32_t* row_idx; const float* coef; const float* cnt; const int32_t* kind; int32_t n_rows;
+  float* dz; int64_t ld_dz; float* partials;
+};
+
 template <int LPR, int VPL>
-__global__ __launch_bounds__(256) void rowtarget_mse_kernel(
+__device__ __forceinline__ void rowtarget_mse_body(
     const float* __restrict__ z, int64_t ld_z, const float* __restrict__ tm, int32_t d4,
     const int32_t* __restrict__ row_idx, const float* __restrict__ coef, const float* __restrict__ cnt,
     const int32_t* __restrict__ kind, int32_t n_rows, float* __restrict__ dz, int64_t ld_dz,
-    float* __restrict__ partials) {
+    float* __restrict__ partials, const int block) {
   constexpr int G = kWave / LPR;
   constexpr int U = (kWave / G) >= 4 ? 4 : (kWave / G);
   __shared__ float red[2][4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int g = lane / LPR, li = lane % LPR;
-  const int u0 = (blockIdx.x * 4 + wave) * kWave;
+  const int u0 = (block * 4 + wave) * kWave;
   float s0 = 0.f, s1 = 0.f;
   if (u0 < n_rows) {
     const int n_here = min(kWave, n_rows - u0);
@@ -150,9 +156,29 @@ __global__ __launch_bounds__(256) void rowtarget_mse_kernel(
   if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    partials[2 * blockIdx.x + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    partials[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    partials[2 * block + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partials[2 * block + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
+}
+
+template <int LPR, int VPL>
+__global__ __launch_bounds__(256) void rowtarget_mse_kernel(
+    const float* __restrict__ z, int64_t ld_z, const float* __restrict__ tm, int32_t d4,
+    const int32_t* __restrict__ row_idx, const float* __restrict__ coef, const float* __restrict__ cnt,
+    const int32_t* __restrict__ kind, int32_t n_rows, float* __restrict__ dz, int64_t ld_dz,
+    float* __restrict__ partials) {
+  rowtarget_mse_body<LPR, VPL>(z, ld_z, tm, d4, row_idx, coef, cnt, kind, n_rows, dz, ld_dz, partials, blockIdx.x);
+}
+
+// Two row-target jobs of different widths in ONE launch (blocks [0, nb_a) walk job a, the rest job b): the two stand-alone
+// loss launches of a knowledge-graph step - the layer-1 DEC rows (128 floats, loss sums only) and the layer-2 DEC rows
+// (64 floats, gradient rows written) - are launch-sized on their own (293 blocks each).
+template <int LA, int LB>
+__global__ __launch_bounds__(256) void rowtarget_mse_pair_kernel(RowTargetJob a, RowTargetJob b, int32_t nb_a) {
+  if ((int)blockIdx.x < nb_a)
+    rowtarget_mse_body<LA, 1>(a.z, a.ld_z, a.tm, a.d4, a.row_idx, a.coef, a.cnt, a.kind, a.n_rows, a.dz, a.ld_dz, a.partials, blockIdx.x);
+  else
+    rowtarget_mse_body<LB, 1>(b.z, b.ld_z, b.tm, b.d4, b.row_idx, b.coef, b.cnt, b.kind, b.n_rows, b.dz, b.ld_dz, b.partials, blockIdx.x - nb_a);
 }
 
 static inline int mse_blocks(int32_t n_seg, int lpr) {
@@ -413,6 +439,38 @@ extern "C" int gd_rowtarget_mse_f32(const float* z, int64_t ld_z, const float* t
   if (rc || !sums) return rc;          // sums == NULL: the caller reduces the partials (gd_loss_finalize_f32)
   hipLaunchKernelGGL(pair_sum_reduce_kernel, dim3(1), dim3(256), 0, s, partials, nb, sums);
   return launched("pair_sum_reduce");
+}
+
+extern "C" int32_t gd_rowtarget_mse_pair_covers(int32_t d_a, int32_t d_b) {
+  return (d_a == 128 || d_a == 64) && (d_b == 128 || d_b == 64) ? 1 : 0;
+}
+
+extern "C" int gd_rowtarget_mse_pair_f32(const float* z_a, int64_t ld_z_a, const float* tm_a, int32_t d_a, const int32_t* row_idx_a,
+                                         const float* coef_a, const float* cnt_a, const int32_t* kind_a, int32_t n_rows_a, float* dz_a,
+                                         int64_t ld_dz_a, float* partials_a, const float* z_b, int64_t ld_z_b, const float* tm_b,
+                                         int32_t d_b, const int32_t* row_idx_b, const float* coef_b, const float* cnt_b,
+                                         const int32_t* kind_b, int32_t n_rows_b, float* dz_b, int64_t ld_dz_b, float* partials_b,
+                                         void* stream) {
+  using namespace gd;
+  GD_REQUIRE(gd_rowtarget_mse_pair_covers(d_a, d_b), GD_E_DIM, "gd_rowtarget_mse_pair_f32: widths %d / %d (64 or 128 each; else two gd_rowtarget_mse_f32 calls)", d_a, d_b);
+  GD_REQUIRE(n_rows_a > 0 && n_rows_b > 0, GD_E_DIM, "gd_rowtarget_mse_pair_f32: both jobs need rows");
+  GD_REQUIRE(z_a && tm_a && row_idx_a && coef_a && cnt_a && kind_a && partials_a && z_b && tm_b && row_idx_b && coef_b && cnt_b && kind_b && partials_b,
+             GD_E_NULL, "gd_rowtarget_mse_pair_f32: null pointer");
+  GD_REQUIRE(ld_z_a % 4 == 0 && ld_z_b % 4 == 0 && (!dz_a || ld_dz_a % 4 == 0) && (!dz_b || ld_dz_b % 4 == 0), GD_E_DIM,
+             "gd_rowtarget_mse_pair_f32: row strides must be multiples of 4");
+  GD_REQUIRE(aligned16(z_a) && aligned16(tm_a) && aligned16(dz_a) && aligned16(z_b) && aligned16(tm_b) && aligned16(dz_b), GD_E_ALIGN,
+             "gd_rowtarget_mse_pair_f32: unaligned matrix");
+  const RowTargetJob a{z_a, ld_z_a, tm_a, d_a / 4, row_idx_a, coef_a, cnt_a, kind_a, n_rows_a, dz_a, ld_dz_a, partials_a};
+  const RowTargetJob b{z_b, ld_z_b, tm_b, d_b / 4, row_idx_b, coef_b, cnt_b, kind_b, n_rows_b, dz_b, ld_dz_b, partials_b};
+  const int nb_a = (n_rows_a + 255) / 256, nb_b = (n_rows_b + 255) / 256;
+  hipStream_t s = (hipStream_t)stream;
+#define GD_RTP(LA, LB) hipLaunchKernelGGL((rowtarget_mse_pair_kernel<LA, LB>), dim3(nb_a + nb_b), dim3(256), 0, s, a, b, nb_a)
+  if (d_a == 128 && d_b == 64) GD_RTP(32, 16);
+  else if (d_a == 128) GD_RTP(32, 32);
+  else if (d_b == 64) GD_RTP(16, 16);
+  else GD_RTP(16, 32);
+#undef GD_RTP
+  return launched("rowtarget_mse_pair");
 }
 
 extern "C" int gd_edge_dot_f32(const float* z, int64_t ld_z, int32_t d, const int64_t* e0, const int64_t* e1,

@@ -147,6 +147,12 @@ class _LayerTerms:
                                               dz.stride(0) if dz is not None else 0, None, ptr(partials), stream_ptr(z.device)),
               'gd_rowtarget_mse_f32')
 
+    def outside_args(self, z, dz, partials):
+        """The argument run of one job of gd_rowtarget_mse_pair_f32 for the rows launch_outside() walks."""
+        k, n_out = self.n_in, self.n_rows - self.n_in
+        return (ptr(z), z.stride(0), ptr(self.tm[k:]), z.shape[1], ptr(self.row_idx[k:]), ptr(self.coef[k:]), ptr(self.cnt[k:]),
+                ptr(self.kind[k:]), n_out, ptr(dz) if dz is not None else None, dz.stride(0) if dz is not None else 0, ptr(partials))
+
     def launch(self, z, dz, sums):
         """sums = None (folded form only): leave the partials for gd_loss_finalize_f32."""
         d = z.shape[1]
@@ -393,6 +399,9 @@ class NodeembEngine:
             # (the buffer keeps the size of the two-launch form: bench.py's stand-alone timing of the weight-gradient kernel
             #  writes gd_rows_gemm_wgrad_blocks(s1) block sums into it)
             self._lp1_blocks = _lib.lib().gd_del1_loss_wgrad_parts(self.s1)
+        # ... and the two stand-alone loss launches of a knowledge-graph step (DEC rows outside the Del rows, both layers) are one
+        self._out_pair = bool(self._out1 and self._out2 and self._fuse_loss1 and self._fuse_l2 and loss_type != 'only2_all'
+                              and _lib.lib().gd_rowtarget_mse_pair_covers(self.h, self.o) and os.environ.get('GD_NO_LOSS_PAIR') != '1')
         self._mode = {GCNConv: 'gcn', GINConv: 'gin', GATConv: 'gat', SAGEConv: 'sage', RGCNConv: 'rgcn'}[type(conv2)]
         self._gat_dots = os.environ.get('GD_NO_GAT_DOTS') != '1'      # attention logits from the GEMM epilogue
         self._gat_r1 = None                                            # (att_src W2, att_dst W2): constants of the frozen conv2
@@ -635,7 +644,8 @@ class NodeembEngine:
                 ops.rgcn_typed_accumulate(self.typed_s1, self.dz2, c.weight.detach(), c.num_blocks or 1, 1, self._dxbuf)
             else:
                 self._rgcn_conv(c, self.dz2, self._dxbuf, 1)
-            # dh[S1] = dx[S1] * [z1[S1] > 0]  (ReLU backward from the packed sign bits of the Del-1 output)
+            # dh[S1] = dx[S1] * [z1[S1] > 0]  (ReLU backward from the packed sign bits of the Del-1 output; folding the gate into
+            # the typed launch's epilogue removed the launch and not a microsecond: tools/experiments/patches/r05_rgcn_gate_fold_*)
             ops.gate_rows(self._dxbuf, self.idx1, self.z1_pos, self.dh)
             return
         if self._mode == 'sage':
@@ -787,7 +797,7 @@ class NodeembEngine:
             # ---- layer-1 loss (+ its W_D1 step for the layer-wise types)
             if not self._fuse_loss1 and lt != 'only2_all':      # (only2_all: neither its update nor its log line reads layer 1)
                 self.t1.launch(self.z1, self.dz1, s1)
-            elif self._out1 and lt != 'only2_all':
+            elif self._out1 and lt != 'only2_all' and not self._out_pair:
                 self.t1.launch_outside(self.z1, None, self._lp1[2 * self._lp1_blocks:])
             if self._fuse_del1:
                 pass                                             # (its weight-gradient partials came out of the Del-1 pass)
@@ -799,7 +809,13 @@ class NodeembEngine:
             self._conv2_forward()
             if self._fuse_l2:
                 self._del2_fused()
-                if self._out2:
+                if self._out2 and self._out_pair and lt != 'only2_all':
+                    # both layers' DEC rows outside the Del rows in ONE launch (layer 1: loss sums only; layer 2: gradient rows)
+                    check(_lib.lib().gd_rowtarget_mse_pair_f32(
+                        *self.t1.outside_args(self.z1, None, self._lp1[2 * self._lp1_blocks:]),
+                        *self.t2.outside_args(self.p2, self.dz2, self._lp2[2 * self._lp2_blocks:]), stream_ptr(self.x.device)),
+                        'gd_rowtarget_mse_pair_f32')
+                elif self._out2:
                     self.t2.launch_outside(self.p2, self.dz2, self._lp2[2 * self._lp2_blocks:])
             else:
                 ops.rows_gemm(self.p2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)

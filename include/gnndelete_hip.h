@@ -566,6 +566,15 @@ int64_t gd_rowtarget_mse_workspace(int32_t n_rows);
 int gd_rowtarget_mse_f32(const float* z, int64_t ld_z, const float* tm, int32_t d,
                          const int32_t* row_idx, const float* coef, const float* cnt, const int32_t* kind,
                          int32_t n_rows, float* dz, int64_t ld_dz, float* sums, float* partials, void* stream);
+/* (ABI 8) Two such jobs of widths in {64, 128} in ONE launch (sums = NULL form: the per-block partials of each job go to its own
+ * array, gd_rowtarget_mse_blocks(n_rows) pairs each): the two stand-alone loss launches a knowledge-graph step needs for its DEC
+ * rows (layer 1: loss sums only, dz_a = NULL; layer 2: gradient rows written) are launch-sized on their own. */
+int32_t gd_rowtarget_mse_pair_covers(int32_t d_a, int32_t d_b);
+int gd_rowtarget_mse_pair_f32(const float* z_a, int64_t ld_z_a, const float* tm_a, int32_t d_a, const int32_t* row_idx_a,
+                              const float* coef_a, const float* cnt_a, const int32_t* kind_a, int32_t n_rows_a, float* dz_a,
+                              int64_t ld_dz_a, float* partials_a, const float* z_b, int64_t ld_z_b, const float* tm_b, int32_t d_b,
+                              const int32_t* row_idx_b, const float* coef_b, const float* cnt_b, const int32_t* kind_b,
+                              int32_t n_rows_b, float* dz_b, int64_t ld_dz_b, float* partials_b, void* stream);
 
 /* End-of-step bookkeeping in one launch: reduce the per-block partials of the two layers' loss
  * kernels (called with sums = NULL; n1/n2 = gd_rowtarget_mse_blocks(n_rows)) in a fixed order,

@@ -1481,3 +1481,42 @@ def test_del1_forward_loss_and_weight_gradient_in_one_pass(n_sel, with_add, comp
     bits2 = torch.zeros(n_sel, 4, dtype=torch.int32, device=dev)
     ops.rows_gemm(p, idx, w, out=z2, sign_bits=bits2)
     assert float((z2 - z).abs().max()) < 1e-4
+
+
+def test_two_row_target_loss_jobs_in_one_launch():
+    """gd_rowtarget_mse_pair_f32 = two gd_rowtarget_mse_f32 launches (128-wide loss sums only + 64-wide with gradient rows): same
+    per-block partials bit for bit, same gradient rows."""
+    from gnndelete_amd import _lib
+    from gnndelete_amd._lib import ptr, check, stream_ptr
+    torch.manual_seed(3)
+    dev, n = 'cuda', 9000
+    lib = _lib.lib()
+    jobs = []
+    for d, rows in ((128, 7001), (64, 6500)):
+        z = torch.randn(n, d, device=dev)
+        ridx = torch.randperm(n, device=dev)[:rows].to(torch.int32)
+        tm = torch.randn(rows, d, device=dev)
+        coef, cnt = torch.rand(rows, device=dev), torch.randint(1, 5, (rows,), device=dev).float()
+        kind = (torch.rand(rows, device=dev) < 0.3).to(torch.int32)
+        jobs.append((z, ridx, tm, coef, cnt, kind, rows, d))
+    def single(j, dz):
+        z, ridx, tm, coef, cnt, kind, rows, d = j
+        part = torch.zeros(2 * lib.gd_rowtarget_mse_blocks(rows), device=dev)
+        check(lib.gd_rowtarget_mse_f32(ptr(z), z.stride(0), ptr(tm), d, ptr(ridx), ptr(coef), ptr(cnt), ptr(kind), rows, ptr(dz),
+                                       dz.stride(0) if dz is not None else 0, None, ptr(part), stream_ptr(z.device)), 'single')
+        return part
+    dz_b = torch.zeros(n, 64, device=dev)
+    pa, pb = single(jobs[0], None), single(jobs[1], dz_b)
+    dz_b2 = torch.zeros(n, 64, device=dev)
+    qa, qb = torch.zeros_like(pa), torch.zeros_like(pb)
+    def args(j, dz, part):
+        z, ridx, tm, coef, cnt, kind, rows, d = j
+        return (ptr(z), z.stride(0), ptr(tm), d, ptr(ridx), ptr(coef), ptr(cnt), ptr(kind), rows, ptr(dz), dz.stride(0) if dz is not None else 0, ptr(part))
+    assert lib.gd_rowtarget_mse_pair_covers(128, 64) == 1 and lib.gd_rowtarget_mse_pair_covers(96, 64) == 0
+    check(lib.gd_rowtarget_mse_pair_f32(*args(jobs[0], None, qa), *args(jobs[1], dz_b2, qb), stream_ptr(torch.device(dev))), 'pair')
+    assert torch.equal(pa, qa) and torch.equal(pb, qb) and torch.equal(dz_b, dz_b2)
+    want = ((jobs[0][0][jobs[0][1].long()].double() - jobs[0][2].double()) ** 2).sum(1) * jobs[0][4].double()
+    got = qa.view(-1, 2).double().sum(0)
+    k0 = jobs[0][5] == 0
+    assert abs(float(got[0]) - float(want[k0].sum())) <= 1e-5 * float(want[k0].sum())
+    assert abs(float(got[1]) - float(want[~k0].sum())) <= 1e-5 * float(want[~k0].sum())
