@@ -681,6 +681,233 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same pass with the SECOND gradient stream formed in the kernel instead of read (round 5, GCN / GIN layer-wise steps):
+//     g_add[row,:] = (dt[row, 0:64] @ W_next) (.) [z_prev[row,:] > 0]     - conv2's input gradient of the PREVIOUS iteration, from
+// the aggregated layer-2 gradient dt that iteration left ([N, 64]) and the sign pattern ITS Del-1 pass stored - read here for a row
+// before this iteration's pattern of the same row is written by the same wave.  The stand-alone gated product (a [S1, 128] write
+// per step and its read back here: 183 MB, 40 us) is gone for 64 more matrix instructions per unit.  Both weights are LDS images
+// in the lanes' read order (W_D 64 KB, W_next 32 KB; in registers - 128 + 64 of them - nothing else would fit the 256 VGPRs the
+// compiler keeps MFMA A / B operands in); k order of the products: lane (r, kq) holds p[r][16 i + 4 kq + c] in x[i].c and
+// dt[r][16 i + 4 kq + c] in dv[i].c.  Otherwise as del1_loss_wgrad_ws_kernel: 16-row units, output columns split by half over the
+// two waves of a pair, one wave per SIMD, partial matrices per block.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void del1_chain_ws_kernel(
+    const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ idx, int32_t n_sel, const float* __restrict__ w,
+    float* __restrict__ z, int64_t ld_z, uint32_t* __restrict__ sign_io, DelLoss loss, const float* __restrict__ dt, int64_t ld_dt,
+    const float* __restrict__ w_next, float* __restrict__ wg_partials, int32_t n_part) {
+  constexpr int D = 128, H = 64, K2 = 64, PTP = 144, PTZ = 80;
+  constexpr int kTiles = 4 * (16 * PTP + 16 * PTZ);               // floats of the four waves' transposition tiles
+  extern __shared__ __attribute__((aligned(16))) float wl[];      // tiles | W_D image | W_next image; later 4 x D x H block sums
+  __shared__ float lred[2][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave & 1, pair = wave >> 1, cb = H * half;
+  const int r = lane & 15, kq = lane >> 4;
+  float* const tp = wl + wave * (16 * PTP + 16 * PTZ);
+  float* const tz = tp + 16 * PTP;
+  // wimg[((h 4 + t) 8 + i) 64 + lane] = W_D[16 i + 4 kq + 0..3][64 h + 16 t + r];  w2img[((h 4 + t) 4 + i) 64 + lane] = W_next[...] likewise
+  float4* const wimg = reinterpret_cast<float4*>(wl + kTiles);
+  float4* const w2img = wimg + 2 * 4 * 8 * 64;
+  {
+    float4 fv[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int e = tid + 256 * it;
+      const int ln = e & 63, i_ = (e >> 6) & 7, t_ = (e >> 9) & 3, h_ = e >> 11;
+      const float* src = w + (int64_t)(16 * i_ + 4 * (ln >> 4)) * D + 64 * h_ + 16 * t_ + (ln & 15);
+      fv[it] = make_float4(src[0], src[D], src[2 * D], src[3 * D]);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) wimg[tid + 256 * it] = fv[it];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int e = tid + 256 * it;
+      const int ln = e & 63, i_ = (e >> 6) & 3, t_ = (e >> 8) & 3, h_ = e >> 10;
+      const float* src = w_next + (int64_t)(16 * i_ + 4 * (ln >> 4)) * D + 64 * h_ + 16 * t_ + (ln & 15);
+      fv[it] = make_float4(src[0], src[D], src[2 * D], src[3 * D]);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) w2img[tid + 256 * it] = fv[it];
+  }
+  __syncthreads();
+  const float4* const wmine = wimg + (half * 4) * 8 * 64 + lane;
+  const float4* const w2mine = w2img + (half * 4) * 4 * 64 + lane;
+  const int n_units = (n_sel + 15) >> 4;
+  const int n_pairs = gridDim.x * 2, pid = blockIdx.x * 2 + pair;
+  const int u_lo = (int)((int64_t)n_units * pid / n_pairs), u_hi = (int)((int64_t)n_units * (pid + 1) / n_pairs);
+
+  auto slot_of = [&](int u) -> int { return min(min(u, n_units - 1) * 16 + r, n_sel - 1); };
+  int32_t row_n = idx[slot_of(u_lo)], ls_n = loss.slot[slot_of(u_lo)];
+  int32_t row_nn = idx[slot_of(u_lo + 1)], ls_nn = loss.slot[slot_of(u_lo + 1)];
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4w gacc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) gacc[i] = f32x4w{0.f, 0.f, 0.f, 0.f};
+  float ls0 = 0.f, ls1 = 0.f;
+
+  float4 x[8], dv[4], tv[4];
+  uint2 old_bits;                                                   // the row's previous sign words of this wave's column half
+  float cf_raw, cn_raw;
+  int32_t ls_cur;
+  auto fetch_targets = [&](int32_t u) {                           // branch-free: slot -1 reads slot 0, coefficient masked at use
+    const int uc = max(u, 0);
+    const float* trow = loss.tm + (int64_t)uc * D + cb + 4 * kq;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) tv[t] = *reinterpret_cast<const float4*>(trow + 16 * t);
+    cf_raw = loss.coef[uc];
+    cn_raw = loss.cnt_signed[uc];
+    ls_cur = u;
+  };
+  auto fetch_rows = [&](int32_t row, int u) {
+    const float4* src = reinterpret_cast<const float4*>(p + (int64_t)row * ld_p + 4 * kq);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = src[4 * i];
+    const float4* dsrc = reinterpret_cast<const float4*>(dt + (int64_t)row * ld_dt + 4 * kq);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dv[i] = dsrc[4 * i];
+    old_bits = *reinterpret_cast<const uint2*>(sign_io + (int64_t)slot_of(u) * 4 + 2 * half);
+  };
+  if (u_lo < u_hi) {
+    fetch_rows(row_n, u_lo);
+    fetch_targets(ls_n);
+    for (int u = u_lo; u < u_hi; ++u) {
+      const int32_t row = row_n;
+      const int s_a = min(u, n_units - 1) * 16 + r;
+      const bool live = s_a < n_sel;
+      const float livef = live ? 1.f : 0.f;
+      row_n = row_nn;
+      ls_n = ls_nn;
+      row_nn = idx[slot_of(u + 2)];
+      ls_nn = loss.slot[slot_of(u + 2)];
+      // ---- P1: this wave's 64 columns of z;  P_dh: its 64 columns of the previous iteration's input gradient
+      f32x4w acc[4], dacc[4];
+      {
+        float4 wq[2][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wq[0][t] = wmine[(t * 8) * 64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (i + 1 < 8) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wq[(i + 1) & 1][t] = wmine[(t * 8 + i + 1) * 64];
+          }
+          const float xv[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float4 wf = wq[i & 1][t];
+              const float wa = c == 0 ? wf.x : c == 1 ? wf.y : c == 2 ? wf.z : wf.w;
+              if (i == 0 && c == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, xv[0], f32x4w{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+              else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, xv[c], acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wq[0][t] = w2mine[(t * 4) * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i + 1 < 4) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wq[(i + 1) & 1][t] = w2mine[(t * 4 + i + 1) * 64];
+          }
+          const float xv[4] = {dv[i].x, dv[i].y, dv[i].z, dv[i].w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const float4 wf = wq[i & 1][t];
+              const float wa = c == 0 ? wf.x : c == 1 ? wf.y : c == 2 ? wf.z : wf.w;
+              if (i == 0 && c == 0) dacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, xv[0], f32x4w{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+              else dacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, xv[c], dacc[t], 0, 0, 0);
+            }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- the p rows into their transposition tile (rows past the end zeroed: no weight-gradient contribution)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<float4*>(tp + r * PTP + 16 * i + 4 * kq) = make_float4(livef * x[i].x, livef * x[i].y, livef * x[i].z, livef * x[i].w);
+      // ---- loss gradient in the accumulator layout + the gated previous gradient; z out, sign bits, g into its tile
+      const float cf = ls_cur >= 0 ? cf_raw : 0.f, cn = ls_cur >= 0 ? cn_raw : 0.f;
+      float sq = 0.f;
+      uint32_t bits[2] = {0u, 0u};
+      const uint32_t ob[2] = {old_bits.x, old_bits.y};
+      float* zrow = z + (int64_t)row * ld_z + cb + 4 * kq;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 zv = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        *reinterpret_cast<float4*>(zrow + 16 * t) = zv;
+        bits[t >> 1] |= ((zv.x > 0.f ? 1u : 0u) | (zv.y > 0.f ? 2u : 0u) | (zv.z > 0.f ? 4u : 0u) | (zv.w > 0.f ? 8u : 0u)) << (16 * (t & 1) + 4 * kq);
+        const float4 d4 = make_float4(zv.x - tv[t].x, zv.y - tv[t].y, zv.z - tv[t].z, zv.w - tv[t].w);
+        sq = fmaf(d4.x, d4.x, sq); sq = fmaf(d4.y, d4.y, sq); sq = fmaf(d4.z, d4.z, sq); sq = fmaf(d4.w, d4.w, sq);
+        const uint32_t m = ob[t >> 1] >> (16 * (t & 1) + 4 * kq);   // the previous pattern of these four columns
+        const float4 gv = make_float4(cf * d4.x + ((m & 1u) ? dacc[t][0] : 0.f), cf * d4.y + ((m & 2u) ? dacc[t][1] : 0.f),
+                                      cf * d4.z + ((m & 4u) ? dacc[t][2] : 0.f), cf * d4.w + ((m & 8u) ? dacc[t][3] : 0.f));
+        *reinterpret_cast<float4*>(tz + r * PTZ + 16 * t + 4 * kq) = gv;
+      }
+      sq *= livef;
+      if (cn >= 0.f) ls0 = fmaf(cn, sq, ls0); else ls1 = fmaf(-cn, sq, ls1);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        bits[q] |= (uint32_t)__shfl_xor((int)bits[q], 16);
+        bits[q] |= (uint32_t)__shfl_xor((int)bits[q], 32);
+      }
+      if (live && kq == 0) *reinterpret_cast<uint2*>(sign_io + (int64_t)s_a * 4 + 2 * half) = make_uint2(bits[0], bits[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_rows(row_n, u + 1);                                    // the next unit's operands into the registers just consumed
+      fetch_targets(ls_n);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the tiles are wave-private: DS operations execute in issue order
+      __builtin_amdgcn_wave_barrier();
+      // ---- P3: this unit's weight-gradient product from the feature-major views (under the fetch just issued)
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        float a_op[8], b_op[4];
+#pragma unroll
+        for (int ta = 0; ta < 8; ++ta) a_op[ta] = tp[(4 * sp + kq) * PTP + 16 * ta + r];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) b_op[tb] = tz[(4 * sp + kq) * PTZ + 16 * tb + r];
+#pragma unroll
+        for (int ta = 0; ta < 8; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb)
+            gacc[ta * 4 + tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op[ta], b_op[tb], gacc[ta * 4 + tb], 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the tiles are read before the next unit overwrites them)
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- block sum of the waves' D x H sums (pair order), loss sums
+  __syncthreads();
+  float* const red = wl;                                          // [4][D x H]
+#pragma unroll
+  for (int ta = 0; ta < 8; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[wave * D * H + (16 * ta + 4 * kq + v) * H + 16 * tb + r] = gacc[ta * 4 + tb][v];
+  __syncthreads();
+  for (int slot = blockIdx.x; slot < n_part; slot += gridDim.x) {
+    float* const out = wg_partials + (int64_t)slot * D * D;
+    const bool mine = slot == (int)blockIdx.x;
+    for (int e = tid; e < D * D; e += 256) {
+      const int i = e >> 7, c = e & 127, hf = c >> 6, ch = c & 63;
+      out[e] = mine ? red[hf * D * H + i * H + ch] + red[(2 + hf) * D * H + i * H + ch] : 0.f;
+    }
+  }
+  ls0 = wave_sum(ls0);
+  ls1 = wave_sum(ls1);
+  if (lane == 0) { lred[0][wave] = ls0; lred[1][wave] = ls1; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int slot = blockIdx.x; slot < n_part; slot += gridDim.x) {
+      const bool mine = slot == (int)blockIdx.x;
+      loss.partials[2 * slot + 0] = mine ? (lred[0][0] + lred[0][1]) + (lred[0][2] + lred[0][3]) : 0.f;
+      loss.partials[2 * slot + 1] = mine ? (lred[1][0] + lred[1][1]) + (lred[1][2] + lred[1][3]) : 0.f;
+    }
+  }
+}
+
 static inline int del_fused_grid(int32_t n_sel) {
   const int n_tiles = (n_sel + 31) / 32;
   int grid = (n_tiles + 3) / 4;
@@ -844,3 +1071,29 @@ extern "C" int gd_del1_loss_wgrad_f32(const float* p, int64_t ld_p, const int32_
   return launched("del1_loss_wgrad_ws");
 }
 
+extern "C" int gd_del1_chain_loss_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w, int32_t d,
+                                            float* z, int64_t ld_z, uint32_t* sign_io, const int32_t* loss_slot, const float* tm,
+                                            const float* coef, const float* cnt_signed, const float* dt, int64_t ld_dt, int32_t d_next,
+                                            const float* w_next, float* loss_partials, float* wgrad_partials, int32_t n_part,
+                                            void* stream) {
+  using namespace gd;
+  const char* name = "gd_del1_chain_loss_wgrad_f32";
+  if (n_sel == 0) return GD_OK;
+  GD_REQUIRE(p && idx && w && z && sign_io && loss_slot && tm && coef && cnt_signed && dt && w_next && loss_partials && wgrad_partials, GD_E_NULL,
+             "%s: null pointer", name);
+  GD_REQUIRE(d == 128 && d_next == 64, GD_E_DIM, "%s: widths %d / %d must be 128 / 64", name, d, d_next);
+  GD_REQUIRE(ld_p >= d && ld_z >= d && ld_dt >= d_next && ld_p % 4 == 0 && ld_z % 4 == 0 && ld_dt % 4 == 0, GD_E_DIM, "%s: bad row strides", name);
+  GD_REQUIRE(aligned16(p) && aligned16(z) && aligned16(tm) && aligned16(dt) && aligned16(wgrad_partials) && (reinterpret_cast<uintptr_t>(sign_io) & 7u) == 0,
+             GD_E_ALIGN, "%s: unaligned", name);
+  GD_REQUIRE(p != z && dt != z, GD_E_DIM, "%s: z must not alias p or dt", name);
+  GD_REQUIRE(n_part >= 1 && n_part <= gd_rows_gemm_wgrad_blocks(n_sel), GD_E_DIM,
+             "%s: n_part=%d outside [1, gd_rows_gemm_wgrad_blocks(n_sel)=%d]", name, n_part, gd_rows_gemm_wgrad_blocks(n_sel));
+  const DelLoss loss{loss_slot, tm, coef, cnt_signed, loss_partials};
+  const int grid = ws_cu_count() < n_part ? ws_cu_count() : n_part;
+  constexpr int kLds = (4 * (16 * 144 + 16 * 80) + 128 * 128 + 64 * 128) * 4;      // tiles + W_D image + W_next image = 155,648 B (>= the 128 KB block sums)
+  static const hipError_t at = hipFuncSetAttribute(reinterpret_cast<const void*>(&del1_chain_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+  if (at != hipSuccess) return fail(-(int)at, "%s: %s", name, hipGetErrorString(at));
+  hipLaunchKernelGGL(del1_chain_ws_kernel, dim3(grid), dim3(256), kLds, (hipStream_t)stream, p, ld_p, idx, n_sel, w, z, ld_z, sign_io, loss, dt, ld_dt,
+                     w_next, wgrad_partials, n_part);
+  return launched("del1_chain_ws");
+}

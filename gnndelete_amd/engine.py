@@ -399,6 +399,12 @@ class NodeembEngine:
             # (the buffer keeps the size of the two-launch form: bench.py's stand-alone timing of the weight-gradient kernel
             #  writes gd_rows_gemm_wgrad_blocks(s1) block sums into it)
             self._lp1_blocks = _lib.lib().gd_del1_loss_wgrad_parts(self.s1)
+        # ... and for GCN / GIN the gradient conv2 sent back in the previous iteration is FORMED in that pass too, from the aggregated
+        # layer-2 gradient the previous iteration left and the sign pattern its Del-1 stored (gd_del1_chain_loss_wgrad_f32): the
+        # gated [S1, 64] x [64, 128] product at the end of the step, its [S1, 128] write and the read-back are gone
+        self._chain1 = bool(self._fuse_del1 and loss_type == 'both_layerwise' and isinstance(conv2, (GCNConv, GINConv))
+                            and self.h == 128 and self.o == 64 and os.environ.get('GD_DEL1_CHAIN') != '0')
+        self._dt2_keep = torch.zeros(n, self.o, **f32) if self._chain1 else None
         # ... and the two stand-alone loss launches of a knowledge-graph step (DEC rows outside the Del rows, both layers) are one
         self._out_pair = bool(self._out1 and self._out2 and self._fuse_loss1 and self._fuse_l2 and loss_type != 'only2_all'
                               and _lib.lib().gd_rowtarget_mse_pair_covers(self.h, self.o) and os.environ.get('GD_NO_LOSS_PAIR') != '1')
@@ -653,7 +659,8 @@ class NodeembEngine:
                        plan=self._plan_t1 if self._rows_only else None)
             dt2, w2 = self.dcat, self._w2cat
         elif self._mode in ('gcn', 'gin'):
-            dt2 = torch.empty(self.n, self.o, dtype=torch.float32, device=self.x.device)
+            chain = self._chain1 and not self._rows_only
+            dt2 = self._dt2_keep if chain else torch.empty(self.n, self.o, dtype=torch.float32, device=self.x.device)
             if self._mode == 'gcn' and self._rows_only:
                 dt2 = self._dt2buf
                 self._spmm(True, g.val_t, self.dz2, dt2, None, 0.0, plan=self._plan_t1)
@@ -668,6 +675,8 @@ class NodeembEngine:
             else:
                 self._spmm(True, None, self.dz2, dt2, None, 1.0 + c.eps)
                 w2 = c.nn.weight
+            if chain:
+                return                    # (the NEXT iteration's Del-1 pass forms dh[S1] = (dt2[S1] W2) * [z1[S1] > 0] itself)
         else:
             dt2, da_s, da_d = ops.gat_backward_raw(g, self._h2, self._a_src, self._a_dst, self._rowmax, self._rowsum,
                                                    self.dz2, c.negative_slope,
@@ -875,6 +884,15 @@ class NodeembEngine:
         (csrc/del_fused.hip, del1_loss_wgrad_ws_kernel); the tail launch reduces them and steps Adam."""
         self.adam1.applied += 1
         self._tail_acc[0] = 0
+        if self._chain1 and not self._rows_only:
+            c2 = self.model.conv2
+            w_next = (c2.lin if self._mode == 'gcn' else c2.nn).weight.detach()
+            check(_lib.lib().gd_del1_chain_loss_wgrad_f32(
+                ptr(self.pre1), self.pre1.stride(0), ptr(self.idx1), self.s1, ptr(self.wd1), self.h, ptr(self.z1), self.z1.stride(0),
+                ptr(self.z1_pos), ptr(self._slot1), ptr(self.t1.tm), ptr(self.t1.coef), ptr(self._cnt_signed1), ptr(self._dt2_keep),
+                self._dt2_keep.stride(0), self.o, ptr(w_next), ptr(self._lp1), ptr(self.ws1), self._lp1_blocks,
+                stream_ptr(self.x.device)), 'gd_del1_chain_loss_wgrad_f32')
+            return
         check(_lib.lib().gd_del1_loss_wgrad_f32(
             ptr(self.pre1), self.pre1.stride(0), ptr(self.idx1), self.s1, ptr(self.wd1), self.h, ptr(self.z1), self.z1.stride(0),
             ptr(self.z1_pos), ptr(self._slot1), ptr(self.t1.tm), ptr(self.t1.coef), ptr(self._cnt_signed1), ptr(g_add),
@@ -971,6 +989,8 @@ class NodeembEngine:
     def _mutable_state(self):
         state = [self.wd1.data, self.wd2.data, self.g1, self.g2, self.adam1.m, self.adam1.v, self.iter_ctr,
                  self.adam2.m, self.adam2.v, self.hist, self.hist_pos, self.dz1, self.dz2, self.dh]
+        if getattr(self, '_chain1', False):                 # carried from one iteration to the next in the chained form
+            state += [self._dt2_keep, self.z1_pos]
         if getattr(self, '_arrive', None) is not None:      # step_tail's check-in counter: a launch that did not finish must not
             state.append(self._arrive)                       # leave it non-zero for the replays
         return state

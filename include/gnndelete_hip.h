@@ -533,6 +533,15 @@ int gd_del1_loss_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, int
                            int64_t ld_z, uint32_t* sign_out, const int32_t* loss_slot, const float* tm, const float* coef,
                            const float* cnt_signed, const float* g_add, int64_t ld_gadd, float* loss_partials,
                            float* wgrad_partials, int32_t n_part, void* stream);
+/* (ABI 8) The same pass with the second gradient stream FORMED in the kernel instead of read (the GCN / GIN layer-wise step, where it
+ * is conv2's input gradient of the previous iteration):  g_add[idx[s],:] = (dt[idx[s], 0:64] @ w_next[64, 128]) (.) the sign
+ * pattern sign_io[s, 4] holds when the call starts - i.e. the one the PREVIOUS call stored; the call then overwrites it with this
+ * z's.  Replaces gd_rows_gemm_gated_f32 (+ its [S, 128] write and read-back) in front of gd_del1_loss_wgrad_f32; d = 128,
+ * d_next = 64 only; sign_io 8-byte aligned. */
+int gd_del1_chain_loss_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w, int32_t d, float* z,
+                                 int64_t ld_z, uint32_t* sign_io, const int32_t* loss_slot, const float* tm, const float* coef,
+                                 const float* cnt_signed, const float* dt, int64_t ld_dt, int32_t d_next, const float* w_next,
+                                 float* loss_partials, float* wgrad_partials, int32_t n_part, void* stream);
 
 /* ---------------------------------------------------------------- losses --------------- */
 

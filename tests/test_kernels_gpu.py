@@ -1520,3 +1520,63 @@ def test_two_row_target_loss_jobs_in_one_launch():
     k0 = jobs[0][5] == 0
     assert abs(float(got[0]) - float(want[k0].sum())) <= 1e-5 * float(want[k0].sum())
     assert abs(float(got[1]) - float(want[~k0].sum())) <= 1e-5 * float(want[~k0].sum())
+
+
+@pytest.mark.parametrize('n_sel', [1000, 66000])
+def test_del1_pass_forms_the_previous_input_gradient_itself(n_sel):
+    """gd_del1_chain_loss_wgrad_f32 = gd_rows_gemm_gated_f32 (dh = (dt[idx] @ W_next) gated by the stored sign pattern) followed by
+    gd_del1_loss_wgrad_f32 with g_add = dh: same z, the new sign pattern of that z, same loss sums, same dW - up to the summation
+    order of the products."""
+    from gnndelete_amd import _lib, ops
+    from gnndelete_amd._lib import ptr, check, stream_ptr
+    torch.manual_seed(n_sel + 1)
+    dev, d, o, n = 'cuda', 128, 64, 80000
+    p = torch.randn(n, d, device=dev)
+    w = (torch.eye(d, device=dev) + 0.05 * torch.randn(d, d, device=dev)).contiguous()
+    w_next = (torch.randn(o, d, device=dev) / 8).contiguous()
+    dt = torch.randn(n, o, device=dev) * 1e-3
+    idx = torch.sort(torch.randperm(n, device=dev)[:n_sel]).values.to(torch.int32)
+    n_slots = max(1, n_sel - n_sel // 9)
+    slot = torch.full((n_sel,), -1, dtype=torch.int32, device=dev)
+    slot[torch.randperm(n_sel, device=dev)[:n_slots]] = torch.randperm(n_slots, device=dev).to(torch.int32)
+    tm = torch.randn(n_slots, d, device=dev)
+    coef = torch.rand(n_slots, device=dev) * 1e-3
+    cnt = torch.randint(1, 4, (n_slots,), device=dev).float() * torch.where(torch.rand(n_slots, device=dev) < 0.3, -1.0, 1.0)
+    prev = torch.randint(-2 ** 31, 2 ** 31 - 1, (n_sel, 4), device=dev, dtype=torch.int64).to(torch.int32)      # the stored pattern
+    lib = _lib.lib()
+    nb = lib.gd_del1_loss_wgrad_parts(n_sel)
+    ws_n = max(1, lib.gd_rows_gemm_wgrad_workspace(n_sel, d, d))
+
+    def reduce_(ws):
+        return ws[:nb * d * d].view(nb, d, d).double().sum(0)
+    # reference: the two entries it replaces
+    dh = torch.zeros(n, d, device=dev)
+    ops.rows_gemm(dt, idx, w_next, out=dh, gate_bits=prev.clone())
+    z_r, bits_r = torch.zeros(n, d, device=dev), prev.clone()
+    lp_r, ws_r = torch.zeros(2 * nb, device=dev), torch.zeros(ws_n, device=dev)
+    check(lib.gd_del1_loss_wgrad_f32(ptr(p), p.stride(0), ptr(idx), n_sel, ptr(w), d, ptr(z_r), z_r.stride(0), ptr(bits_r), ptr(slot), ptr(tm),
+                                     ptr(coef), ptr(cnt), ptr(dh), d, ptr(lp_r), ptr(ws_r), nb, stream_ptr(p.device)), 'ref')
+    z_c, bits_c = torch.zeros(n, d, device=dev), prev.clone()
+    lp_c, ws_c = torch.zeros(2 * nb, device=dev), torch.zeros(ws_n, device=dev)
+    check(lib.gd_del1_chain_loss_wgrad_f32(ptr(p), p.stride(0), ptr(idx), n_sel, ptr(w), d, ptr(z_c), z_c.stride(0), ptr(bits_c), ptr(slot),
+                                           ptr(tm), ptr(coef), ptr(cnt), ptr(dt), dt.stride(0), o, ptr(w_next), ptr(lp_c), ptr(ws_c), nb,
+                                           stream_ptr(p.device)), 'chain')
+    assert float((z_c - z_r).abs().max()) < 1e-4
+    li = idx.long()
+    zk = z_c[li]
+    want_bits = ((zk > 0).view(n_sel, 4, 32).long() << torch.arange(32, device=dev)).sum(-1)
+    want_bits = torch.where(want_bits >= 2 ** 31, want_bits - 2 ** 32, want_bits).to(torch.int32)
+    assert torch.equal(bits_c, want_bits)
+    dw_r, dw_c = reduce_(ws_r), reduce_(ws_c)
+    assert float((dw_c - dw_r).norm() / dw_r.norm()) < 2e-6
+    assert torch.allclose(lp_c.view(-1, 2).double().sum(0), lp_r.view(-1, 2).double().sum(0), rtol=1e-5)
+    # the gate really is the STORED pattern: with an all-zero pattern the second stream vanishes
+    z_0, bits_0 = torch.zeros(n, d, device=dev), torch.zeros(n_sel, 4, dtype=torch.int32, device=dev)
+    ws_0 = torch.zeros(ws_n, device=dev)
+    check(lib.gd_del1_chain_loss_wgrad_f32(ptr(p), p.stride(0), ptr(idx), n_sel, ptr(w), d, ptr(z_0), z_0.stride(0), ptr(bits_0), ptr(slot),
+                                           ptr(tm), ptr(coef), ptr(cnt), ptr(dt), dt.stride(0), o, ptr(w_next), ptr(lp_c), ptr(ws_0), nb,
+                                           stream_ptr(p.device)), 'chain0')
+    ws_n0 = torch.zeros(ws_n, device=dev)
+    check(lib.gd_del1_loss_wgrad_f32(ptr(p), p.stride(0), ptr(idx), n_sel, ptr(w), d, ptr(z_r), z_r.stride(0), ptr(bits_r), ptr(slot), ptr(tm),
+                                     ptr(coef), ptr(cnt), None, 0, ptr(lp_r), ptr(ws_n0), nb, stream_ptr(p.device)), 'ref0')
+    assert float((reduce_(ws_0) - reduce_(ws_n0)).norm() / reduce_(ws_n0).norm()) < 2e-6
