@@ -524,7 +524,11 @@ def time_wgrad(eng):
         dur = _avg_seconds(lambda: eng._del1_fused(eng.dh))
         flops = 4.0 * eng.s1 * eng.h * eng.h
         nbytes = 4.0 * 4 * eng.s1 * eng.h
-        return {'kernel': 'del1_loss_wgrad_ws_kernel<true> (Del-1 forward + folded layer-1 loss + W_D1 gradient partial sums in one pass over the S1 rows, d=128)',
+        if getattr(eng, '_chain1', False):
+            flops += 2.0 * eng.s1 * eng.o * eng.h
+            nbytes = 4.0 * (3 * eng.s1 * eng.h + eng.s1 * eng.o)
+        return {'kernel': ('del1_chain_ws_kernel (previous input gradient + ' if getattr(eng, '_chain1', False) else 'del1_loss_wgrad_ws_kernel<true> (')
+                          + 'Del-1 forward + folded layer-1 loss + W_D1 gradient partial sums in one pass over the S1 rows, d=128)',
                 'avg_us': dur * 1e6, 'tflops': flops / dur / 1e12, 'frac_mfma': flops / dur / 1e12 / MFMA_F32_PEAK_TFLOPS,
                 'hbm_gbs': nbytes / dur / 1e9, 'frac_hbm': nbytes / dur / 1e9 / HBM_PEAK_GBS, 'rows': eng.s1}
     dur = _avg_seconds(lambda: eng._wgrad1(False, eng.dh))     # (steps the Del weights: the engine is discarded afterwards)
@@ -634,6 +638,12 @@ def stage_rooflines(eng, prof):
     ] + ([
         # (round 5: Del-1, the layer-1 loss and the W_D1 weight gradient in ONE pass - two products, four row streams: pre1 and the
         #  targets and dh read, z1 written; the two launches below moved six)
+        # (chained form: dh[S1] = (dt2[S1] W2) * [z1_prev[S1] > 0] of the previous iteration is formed in the pass too - three
+        #  products; rows streamed: pre1, dt2 (64 wide) and the targets read, z1 written)
+        ('del1_loss_wgrad1', 'dh[S1] = (dt2[S1] W2) * [z1_prev > 0] (previous iteration), z1[S1] = pre1[S1] W_D1 + sign bits, layer-1 loss sums, '
+         'dW_D1 partial sums = pre1[S1]^T (coef (z1 - t) + dh)[S1]',
+         lambda: eng._del1_fused(eng.dh), 4.0 * s1 * h * h + 2.0 * s1 * o * h, 4.0 * (3 * s1 * h + s1 * o + h * h + o * h) + 36.0 * s1),
+    ] if getattr(eng, '_chain1', False) else [
         ('del1_loss_wgrad1', 'z1[S1] = pre1[S1] W_D1 + sign bits, layer-1 loss sums, dW_D1 partial sums = pre1[S1]^T (coef (z1 - t) + dh)[S1]',
          lambda: eng._del1_fused(eng.dh), 4.0 * s1 * h * h, 4.0 * (4 * s1 * h + h * h) + 20.0 * s1),
     ] if eng._fuse_del1 else [
@@ -653,9 +663,10 @@ def stage_rooflines(eng, prof):
          lambda: eng._wgrad(eng.p2, eng.dz2c, None, s2, eng.g2, False, eng.ws2, a_idx=eng.idx2, adam=eng.adam2), 2.0 * s2 * o * o, 4.0 * 2 * s2 * o),
     ]) + [
         ('spmm2_t', 'dt2 = A^T dp2 (d=64)', lambda: ops._spmm_raw(g.rowptr_t, g.col_t, g.val_t, eng.dz2, None, 0.0, n, g.plan_t, out=y64), 2.0 * nnz * o, spmm_b(o)),
+    ] + ([] if getattr(eng, '_chain1', False) else [
         ('dh', 'dh[S1] = (dt2[S1] W2) * [z1[S1] > 0]', lambda: ops.rows_gemm(dt2, eng.idx1, c2.lin.weight, trans_w=False, out=eng.dh, gate_bits=eng.z1_pos),
          2.0 * s1 * o * h, 4.0 * (s1 * o + s1 * h) + 16.0 * s1),
-    ]
+    ])
     ridge = MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)          # flop per byte where the two roofs meet
     pst = (prof or {}).get('stages', {})
     out = []

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p /tmp/pmc gpurun_out
 TAG=${TAG:-r05_final}
 GNN=${GNN:-gcn}
-STAGES=${STAGES:-$([ "$GNN" = gcn ] && echo xw1,spmm1,del1_loss_wgrad1,t2,spmm2,del2_loss_bwd,spmm2_t,dh,tail || echo auto)}
+STAGES=${STAGES:-$([ "$GNN" = gcn ] && echo xw1,spmm1,del1_loss_wgrad1,t2,spmm2,del2_loss_bwd,spmm2_t,tail || echo auto)}
 ARGS="bench.py --gnn $GNN --steps 40 --warmup 10 --repeats 1 --no_cpu_baseline --no_cached_rate --pretrain_epochs 0"
 rm -rf /tmp/pmc/kt /tmp/pmc/f /tmp/pmc/w
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pmc/kt -o p -- python $ARGS > /tmp/pmc/kt.log 2>&1

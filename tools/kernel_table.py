@@ -11,7 +11,7 @@ NEXT = {
     'xw1': 'weight-stationary register form (rows_gemm_ws.hip, round 4: 88.5 -> 72 us); at the 1.95-2.2 GHz the part sustains here the matrix pipe alone needs 59 us - left: the tail (14.4 -> 15 units per wave), the launch and drain (a one-unit launch takes 8.8 us; the weight prologue itself is hidden behind the row loads of the first unit - a packed operand image that skips it changes nothing, NOTES round 4)',
     'spmm1': 'at the fabric rate (traffic 628 MB at 6.0-6.4 TB/s); ceiling 0.41 on this graph with per-XCD row ranges (computed from the committed floor / probe records)',
     'del1': 'as xw1 (+ packed sign bits merged with v_permlane swaps): 68.7 -> 62 us',
-    'del1_loss_wgrad1': 'round 5: Del-1 + folded layer-1 loss + the W_D1 weight gradient in one weight-stationary pass (was 59 + 83 us in two launches, 549 MB; now 366 MB): instruction-bound - 139 us with cache-resident rows against 146 us on the real ones; one wave per SIMD issues in order, so the loss arithmetic, the LDS transposition and the operand reads of a 16-row unit (~4,500 of its 12,700 cycles) run with the matrix pipe idle; deeper row prefetch, an LDS weight image and sched_group_barrier interleaving all measured slower (NOTES round 5)',
+    'del1_loss_wgrad1': 'round 5: the previous iteration\'s conv2 input gradient (dt2[S1] W2, gated by the stored sign pattern) + Del-1 + folded layer-1 loss + the W_D1 weight gradient in ONE weight-stationary pass (was 59 + 83 + 40 us in three launches, 690 MB; now ~320 MB): instruction-bound (one wave per SIMD issues in order; 320 matrix instructions per 16-row unit and wave at the ~2.0 GHz the part sustains are 5.1 us of its ~6.9); both weights are LDS images (register-resident fragments leave no room for the third product); row-register rings, sched_group_barrier interleaving and a four-way column split all measured equal or slower (NOTES round 5)',
     'wgrad1': 'memory-side (366 MB algorithmic = 61 us at the fabric rate): 2 blocks per CU alternate fetch and MFMA phases; the output-stationary register form measured SLOWER (93 us, NOTES round 4) - it needs more rows in flight per CU, not fewer waves',
     't2': 'weight-stationary form with the two-buffer row selector and ReLU in the operand path: 52.1 -> 45 us; 193 MB at 4.3 TB/s',
     'spmm2': 'latency / window-bound at 4.2-4.8 TB/s of traffic; the one-row-per-lane-group kernel (round 4) moves bytes 10-15 % faster and 16 % more of them - no gain, opt-in',

@@ -11,7 +11,8 @@ import argparse
 import json
 import sqlite3
 
-GCN_STEP = ['xw1', 'spmm1', 'del1_loss_wgrad1', 't2', 'spmm2', 'del2_loss_bwd', 'spmm2_t', 'dh', 'tail']
+GCN_STEP = ['xw1', 'spmm1', 'del1_loss_wgrad1', 't2', 'spmm2', 'del2_loss_bwd', 'spmm2_t', 'tail']          # (chained Del-1 pass: dh is formed in it)
+GCN_STEP_R05A = ['xw1', 'spmm1', 'del1_loss_wgrad1', 't2', 'spmm2', 'del2_loss_bwd', 'spmm2_t', 'dh', 'tail']   # (GD_DEL1_CHAIN=0)
 GCN_STEP_R04 = ['xw1', 'spmm1', 'del1', 'wgrad1', 't2', 'spmm2', 'del2_loss_bwd', 'spmm2_t', 'dh', 'tail']     # (GD_DEL1_FUSED=0: two launches)
 
 
