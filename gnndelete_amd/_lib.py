@@ -90,7 +90,7 @@ PROTOTYPES = {
     'gd_del_loss_bwd_wgrad_parts_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _i32, _p]),
     'gd_del1_loss_wgrad_covers': (ctypes.c_int32, [_i32, _i32]),
     'gd_del1_loss_wgrad_parts': (ctypes.c_int32, [_i32]),
-    'gd_del1_chain_loss_wgrad_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p]),
+    'gd_del1_chain_loss_wgrad_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _p]),
     'gd_del1_loss_wgrad_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _i32, _p]),
     'gd_rowtarget_mse_blocks': (_i32, [_i32]),
     'gd_loss_finalize_f32': (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p]),

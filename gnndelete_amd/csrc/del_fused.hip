@@ -691,10 +691,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // compiler keeps MFMA A / B operands in); k order of the products: lane (r, kq) holds p[r][16 i + 4 kq + c] in x[i].c and
 // dt[r][16 i + 4 kq + c] in dv[i].c.  Otherwise as del1_loss_wgrad_ws_kernel: 16-row units, output columns split by half over the
 // two waves of a pair, one wave per SIMD, partial matrices per block.
+// RANK1 (GATConv behind the gate): the formed gradient gets ra[row] ua[col] + rb[row] ub[col] added BEFORE the gate - the two
+// rank-1 terms of GAT's input gradient (d a_src (x) att_src W2 and d a_dst (x) att_dst W2; gd_rows_gemm_gated_rank1_f32's epilogue).
+struct ChainRank1 { const float* ra; const float* ua; const float* rb; const float* ub; };
+template <bool RANK1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void del1_chain_ws_kernel(
     const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ idx, int32_t n_sel, const float* __restrict__ w,
     float* __restrict__ z, int64_t ld_z, uint32_t* __restrict__ sign_io, DelLoss loss, const float* __restrict__ dt, int64_t ld_dt,
-    const float* __restrict__ w_next, float* __restrict__ wg_partials, int32_t n_part) {
+    const float* __restrict__ w_next, float* __restrict__ wg_partials, int32_t n_part, ChainRank1 r1) {
   constexpr int D = 128, H = 64, K2 = 64, PTP = 144, PTZ = 80;
   constexpr int kTiles = 4 * (16 * PTP + 16 * PTZ);               // floats of the four waves' transposition tiles
   extern __shared__ __attribute__((aligned(16))) float wl[];      // tiles | W_D image | W_next image; later 4 x D x H block sums
@@ -746,6 +750,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float ls0 = 0.f, ls1 = 0.f;
 
   float4 x[8], dv[4], tv[4];
+  float4 ua4[RANK1 ? 4 : 1], ub4[RANK1 ? 4 : 1];                    // (RANK1) this lane's columns of the two column vectors
+  float ra_row = 0.f, rb_row = 0.f;                                 // (RANK1) this lane's row scalars
+  if (RANK1) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ua4[t] = *reinterpret_cast<const float4*>(r1.ua + cb + 16 * t + 4 * kq);
+      ub4[t] = *reinterpret_cast<const float4*>(r1.ub + cb + 16 * t + 4 * kq);
+    }
+  }
   uint2 old_bits;                                                   // the row's previous sign words of this wave's column half
   float cf_raw, cn_raw;
   int32_t ls_cur;
@@ -766,6 +779,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < 4; ++i) dv[i] = dsrc[4 * i];
     old_bits = *reinterpret_cast<const uint2*>(sign_io + (int64_t)slot_of(u) * 4 + 2 * half);
+    if (RANK1) { ra_row = r1.ra[row]; rb_row = r1.rb[row]; }
   };
   if (u_lo < u_hi) {
     fetch_rows(row_n, u_lo);
@@ -832,6 +846,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       float sq = 0.f;
       uint32_t bits[2] = {0u, 0u};
       const uint32_t ob[2] = {old_bits.x, old_bits.y};
+      const float ra_c = ra_row, rb_c = rb_row;
       float* zrow = z + (int64_t)row * ld_z + cb + 4 * kq;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -841,8 +856,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float4 d4 = make_float4(zv.x - tv[t].x, zv.y - tv[t].y, zv.z - tv[t].z, zv.w - tv[t].w);
         sq = fmaf(d4.x, d4.x, sq); sq = fmaf(d4.y, d4.y, sq); sq = fmaf(d4.z, d4.z, sq); sq = fmaf(d4.w, d4.w, sq);
         const uint32_t m = ob[t >> 1] >> (16 * (t & 1) + 4 * kq);   // the previous pattern of these four columns
-        const float4 gv = make_float4(cf * d4.x + ((m & 1u) ? dacc[t][0] : 0.f), cf * d4.y + ((m & 2u) ? dacc[t][1] : 0.f),
-                                      cf * d4.z + ((m & 4u) ? dacc[t][2] : 0.f), cf * d4.w + ((m & 8u) ? dacc[t][3] : 0.f));
+        float4 dq = make_float4(dacc[t][0], dacc[t][1], dacc[t][2], dacc[t][3]);
+        if (RANK1) {
+          dq.x = fmaf(rb_c, ub4[t].x, fmaf(ra_c, ua4[t].x, dq.x)); dq.y = fmaf(rb_c, ub4[t].y, fmaf(ra_c, ua4[t].y, dq.y));
+          dq.z = fmaf(rb_c, ub4[t].z, fmaf(ra_c, ua4[t].z, dq.z)); dq.w = fmaf(rb_c, ub4[t].w, fmaf(ra_c, ua4[t].w, dq.w));
+        }
+        const float4 gv = make_float4(cf * d4.x + ((m & 1u) ? dq.x : 0.f), cf * d4.y + ((m & 2u) ? dq.y : 0.f),
+                                      cf * d4.z + ((m & 4u) ? dq.z : 0.f), cf * d4.w + ((m & 8u) ? dq.w : 0.f));
         *reinterpret_cast<float4*>(tz + r * PTZ + 16 * t + 4 * kq) = gv;
       }
       sq *= livef;
@@ -1074,7 +1094,8 @@ extern "C" int gd_del1_loss_wgrad_f32(const float* p, int64_t ld_p, const int32_
 extern "C" int gd_del1_chain_loss_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w, int32_t d,
                                             float* z, int64_t ld_z, uint32_t* sign_io, const int32_t* loss_slot, const float* tm,
                                             const float* coef, const float* cnt_signed, const float* dt, int64_t ld_dt, int32_t d_next,
-                                            const float* w_next, float* loss_partials, float* wgrad_partials, int32_t n_part,
+                                            const float* w_next, const float* row_a, const float* col_a, const float* row_b,
+                                            const float* col_b, float* loss_partials, float* wgrad_partials, int32_t n_part,
                                             void* stream) {
   using namespace gd;
   const char* name = "gd_del1_chain_loss_wgrad_f32";
@@ -1091,9 +1112,20 @@ extern "C" int gd_del1_chain_loss_wgrad_f32(const float* p, int64_t ld_p, const 
   const DelLoss loss{loss_slot, tm, coef, cnt_signed, loss_partials};
   const int grid = ws_cu_count() < n_part ? ws_cu_count() : n_part;
   constexpr int kLds = (4 * (16 * 144 + 16 * 80) + 128 * 128 + 64 * 128) * 4;      // tiles + W_D image + W_next image = 155,648 B (>= the 128 KB block sums)
-  static const hipError_t at = hipFuncSetAttribute(reinterpret_cast<const void*>(&del1_chain_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-  if (at != hipSuccess) return fail(-(int)at, "%s: %s", name, hipGetErrorString(at));
-  hipLaunchKernelGGL(del1_chain_ws_kernel, dim3(grid), dim3(256), kLds, (hipStream_t)stream, p, ld_p, idx, n_sel, w, z, ld_z, sign_io, loss, dt, ld_dt,
-                     w_next, wgrad_partials, n_part);
+  const bool rank1 = row_a || col_a || row_b || col_b;
+  GD_REQUIRE(!rank1 || (row_a && col_a && row_b && col_b && aligned16(col_a) && aligned16(col_b)), GD_E_NULL,
+             "%s: the rank-1 terms come as four pointers (row_a, col_a, row_b, col_b; 16-byte aligned column vectors)", name);
+  const ChainRank1 r1{row_a, col_a, row_b, col_b};
+  if (rank1) {
+    static const hipError_t at = hipFuncSetAttribute(reinterpret_cast<const void*>(&del1_chain_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (at != hipSuccess) return fail(-(int)at, "%s: %s", name, hipGetErrorString(at));
+    hipLaunchKernelGGL(del1_chain_ws_kernel<true>, dim3(grid), dim3(256), kLds, (hipStream_t)stream, p, ld_p, idx, n_sel, w, z, ld_z, sign_io, loss, dt,
+                       ld_dt, w_next, wgrad_partials, n_part, r1);
+  } else {
+    static const hipError_t at = hipFuncSetAttribute(reinterpret_cast<const void*>(&del1_chain_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (at != hipSuccess) return fail(-(int)at, "%s: %s", name, hipGetErrorString(at));
+    hipLaunchKernelGGL(del1_chain_ws_kernel<false>, dim3(grid), dim3(256), kLds, (hipStream_t)stream, p, ld_p, idx, n_sel, w, z, ld_z, sign_io, loss, dt,
+                       ld_dt, w_next, wgrad_partials, n_part, r1);
+  }
   return launched("del1_chain_ws");
 }

@@ -404,7 +404,15 @@ class NodeembEngine:
         # gated [S1, 64] x [64, 128] product at the end of the step, its [S1, 128] write and the read-back are gone
         self._chain1 = bool(self._fuse_del1 and loss_type == 'both_layerwise' and isinstance(conv2, (GCNConv, GINConv))
                             and self.h == 128 and self.o == 64 and os.environ.get('GD_DEL1_CHAIN') != '0')
-        self._dt2_keep = torch.zeros(n, self.o, **f32) if self._chain1 else None
+        # (GATConv: the same with its two rank-1 terms added in front of the gate; the message gradient and the two logit gradients the
+        #  previous iteration's backward left live in buffers this engine owns)
+        self._gat_bufs = None
+        if (self._fuse_del1 and loss_type == 'both_layerwise' and isinstance(conv2, GATConv) and self.h == 128 and self.o == 64
+                and self._mfma_weight(conv2.lin_src.weight) and os.environ.get('GD_NO_GAT_RANK1_EPILOGUE') != '1'
+                and os.environ.get('GD_DEL1_CHAIN') != '0'):
+            self._chain1 = True
+            self._gat_bufs = {'dh': torch.zeros(n, self.o, **f32), 'da_src': torch.zeros(n, **f32), 'da_dst': torch.zeros(n, **f32)}
+        self._dt2_keep = torch.zeros(n, self.o, **f32) if (self._chain1 and self._gat_bufs is None) else None
         # ... and the two stand-alone loss launches of a knowledge-graph step (DEC rows outside the Del rows, both layers) are one
         self._out_pair = bool(self._out1 and self._out2 and self._fuse_loss1 and self._fuse_l2 and loss_type != 'only2_all'
                               and _lib.lib().gd_rowtarget_mse_pair_covers(self.h, self.o) and os.environ.get('GD_NO_LOSS_PAIR') != '1')
@@ -678,10 +686,14 @@ class NodeembEngine:
             if chain:
                 return                    # (the NEXT iteration's Del-1 pass forms dh[S1] = (dt2[S1] W2) * [z1[S1] > 0] itself)
         else:
+            chain = self._chain1 and not self._rows_only
             dt2, da_s, da_d = ops.gat_backward_raw(g, self._h2, self._a_src, self._a_dst, self._rowmax, self._rowsum,
                                                    self.dz2, c.negative_slope,
                                                    plan=self._plan2 if self._rows_only else None,
-                                                   plan_t=self._plan_t1 if self._rows_only else None)
+                                                   plan_t=self._plan_t1 if self._rows_only else None,
+                                                   bufs=self._gat_bufs if chain else None)
+            if chain:
+                return            # (the NEXT iteration's Del-1 pass forms dh[S1] from dt2, da_src, da_dst and the stored sign pattern)
             w2 = c.lin_src.weight
             if self._mfma_weight(w2) and os.environ.get('GD_NO_GAT_RANK1_EPILOGUE') != '1':
                 # dh2 = A_alpha^T dy + da_src (x) att_src + da_dst (x) att_dst only feeds the product below: the two
@@ -886,11 +898,16 @@ class NodeembEngine:
         self._tail_acc[0] = 0
         if self._chain1 and not self._rows_only:
             c2 = self.model.conv2
-            w_next = (c2.lin if self._mode == 'gcn' else c2.nn).weight.detach()
+            if self._mode == 'gat':
+                w_next, dt = c2.lin_src.weight.detach(), self._gat_bufs['dh']
+                rank1 = (ptr(self._gat_bufs['da_src']), ptr(self._gat_r1[0]), ptr(self._gat_bufs['da_dst']), ptr(self._gat_r1[1]))
+            else:
+                w_next, dt = (c2.lin if self._mode == 'gcn' else c2.nn).weight.detach(), self._dt2_keep
+                rank1 = (None, None, None, None)
             check(_lib.lib().gd_del1_chain_loss_wgrad_f32(
                 ptr(self.pre1), self.pre1.stride(0), ptr(self.idx1), self.s1, ptr(self.wd1), self.h, ptr(self.z1), self.z1.stride(0),
-                ptr(self.z1_pos), ptr(self._slot1), ptr(self.t1.tm), ptr(self.t1.coef), ptr(self._cnt_signed1), ptr(self._dt2_keep),
-                self._dt2_keep.stride(0), self.o, ptr(w_next), ptr(self._lp1), ptr(self.ws1), self._lp1_blocks,
+                ptr(self.z1_pos), ptr(self._slot1), ptr(self.t1.tm), ptr(self.t1.coef), ptr(self._cnt_signed1), ptr(dt),
+                dt.stride(0), self.o, ptr(w_next), *rank1, ptr(self._lp1), ptr(self.ws1), self._lp1_blocks,
                 stream_ptr(self.x.device)), 'gd_del1_chain_loss_wgrad_f32')
             return
         check(_lib.lib().gd_del1_loss_wgrad_f32(
@@ -990,7 +1007,8 @@ class NodeembEngine:
         state = [self.wd1.data, self.wd2.data, self.g1, self.g2, self.adam1.m, self.adam1.v, self.iter_ctr,
                  self.adam2.m, self.adam2.v, self.hist, self.hist_pos, self.dz1, self.dz2, self.dh]
         if getattr(self, '_chain1', False):                 # carried from one iteration to the next in the chained form
-            state += [self._dt2_keep, self.z1_pos]
+            state += [self.z1_pos] + ([self._dt2_keep] if self._dt2_keep is not None else
+                                      [self._gat_bufs[k] for k in ('dh', 'da_src', 'da_dst')])
         if getattr(self, '_arrive', None) is not None:      # step_tail's check-in counter: a launch that did not finish must not
             state.append(self._arrive)                       # leave it non-zero for the replays
         return state

@@ -536,11 +536,13 @@ int gd_del1_loss_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, int
 /* (ABI 8) The same pass with the second gradient stream FORMED in the kernel instead of read (the GCN / GIN layer-wise step, where it
  * is conv2's input gradient of the previous iteration):  g_add[idx[s],:] = (dt[idx[s], 0:64] @ w_next[64, 128]) (.) the sign
  * pattern sign_io[s, 4] holds when the call starts - i.e. the one the PREVIOUS call stored; the call then overwrites it with this
- * z's.  Replaces gd_rows_gemm_gated_f32 (+ its [S, 128] write and read-back) in front of gd_del1_loss_wgrad_f32; d = 128,
- * d_next = 64 only; sign_io 8-byte aligned. */
+ * z's.  row_a / col_a / row_b / col_b (all four or none): row_a[idx[s]] col_a[:] + row_b[idx[s]] col_b[:] is added to the product
+ * before the gate (GATConv's two rank-1 input-gradient terms).  Replaces gd_rows_gemm_gated_f32 / gd_rows_gemm_gated_rank1_f32 (+ its
+ * [S, 128] write and read-back) in front of gd_del1_loss_wgrad_f32; d = 128, d_next = 64 only; sign_io 8-byte aligned. */
 int gd_del1_chain_loss_wgrad_f32(const float* p, int64_t ld_p, const int32_t* idx, int32_t n_sel, const float* w, int32_t d, float* z,
                                  int64_t ld_z, uint32_t* sign_io, const int32_t* loss_slot, const float* tm, const float* coef,
                                  const float* cnt_signed, const float* dt, int64_t ld_dt, int32_t d_next, const float* w_next,
+                                 const float* row_a, const float* col_a, const float* row_b, const float* col_b,
                                  float* loss_partials, float* wgrad_partials, int32_t n_part, void* stream);
 
 /* ---------------------------------------------------------------- losses --------------- */

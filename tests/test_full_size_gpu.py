@@ -86,6 +86,7 @@ def test_full_size_training_parity(workload, gnn, df, df_size):
         # ran over the tail launch's check-in counter: a hang under the profiler, a memory fault in the GAT line)
         from gnndelete_amd import _lib
         assert eng._fuse_del1 and eng._fuse_wg2
+        assert eng._chain1 == (gnn in ('gcn', 'gat', 'gin')), 'GCN / GIN / GAT form the previous input gradient inside the Del-1 pass'
         assert eng._lp1.numel() >= 2 * _lib.lib().gd_rows_gemm_wgrad_blocks(eng.s1)
         assert eng._lp2.numel() >= 2 * _lib.lib().gd_rows_gemm_wgrad_blocks(eng.s2)
     for _ in range(iters):

@@ -1522,8 +1522,9 @@ def test_two_row_target_loss_jobs_in_one_launch():
     assert abs(float(got[1]) - float(want[~k0].sum())) <= 1e-5 * float(want[~k0].sum())
 
 
+@pytest.mark.parametrize('rank1', [False, True])
 @pytest.mark.parametrize('n_sel', [1000, 66000])
-def test_del1_pass_forms_the_previous_input_gradient_itself(n_sel):
+def test_del1_pass_forms_the_previous_input_gradient_itself(n_sel, rank1):
     """gd_del1_chain_loss_wgrad_f32 = gd_rows_gemm_gated_f32 (dh = (dt[idx] @ W_next) gated by the stored sign pattern) followed by
     gd_del1_loss_wgrad_f32 with g_add = dh: same z, the new sign pattern of that z, same loss sums, same dW - up to the summation
     order of the products."""
@@ -1551,7 +1552,11 @@ def test_del1_pass_forms_the_previous_input_gradient_itself(n_sel):
         return ws[:nb * d * d].view(nb, d, d).double().sum(0)
     # reference: the two entries it replaces
     dh = torch.zeros(n, d, device=dev)
-    ops.rows_gemm(dt, idx, w_next, out=dh, gate_bits=prev.clone())
+    r1 = None
+    if rank1:      # GATConv's two rank-1 terms in front of the gate (gd_rows_gemm_gated_rank1_f32's epilogue)
+        r1 = (torch.randn(n, device=dev) * 1e-3, torch.randn(d, device=dev), torch.randn(n, device=dev) * 1e-3, torch.randn(d, device=dev))
+    r1p = tuple(ptr(t) for t in r1) if rank1 else (None, None, None, None)
+    ops.rows_gemm(dt, idx, w_next, out=dh, gate_bits=prev.clone(), rank1=r1)
     z_r, bits_r = torch.zeros(n, d, device=dev), prev.clone()
     lp_r, ws_r = torch.zeros(2 * nb, device=dev), torch.zeros(ws_n, device=dev)
     check(lib.gd_del1_loss_wgrad_f32(ptr(p), p.stride(0), ptr(idx), n_sel, ptr(w), d, ptr(z_r), z_r.stride(0), ptr(bits_r), ptr(slot), ptr(tm),
@@ -1559,7 +1564,7 @@ def test_del1_pass_forms_the_previous_input_gradient_itself(n_sel):
     z_c, bits_c = torch.zeros(n, d, device=dev), prev.clone()
     lp_c, ws_c = torch.zeros(2 * nb, device=dev), torch.zeros(ws_n, device=dev)
     check(lib.gd_del1_chain_loss_wgrad_f32(ptr(p), p.stride(0), ptr(idx), n_sel, ptr(w), d, ptr(z_c), z_c.stride(0), ptr(bits_c), ptr(slot),
-                                           ptr(tm), ptr(coef), ptr(cnt), ptr(dt), dt.stride(0), o, ptr(w_next), ptr(lp_c), ptr(ws_c), nb,
+                                           ptr(tm), ptr(coef), ptr(cnt), ptr(dt), dt.stride(0), o, ptr(w_next), *r1p, ptr(lp_c), ptr(ws_c), nb,
                                            stream_ptr(p.device)), 'chain')
     assert float((z_c - z_r).abs().max()) < 1e-4
     li = idx.long()
@@ -1574,7 +1579,7 @@ def test_del1_pass_forms_the_previous_input_gradient_itself(n_sel):
     z_0, bits_0 = torch.zeros(n, d, device=dev), torch.zeros(n_sel, 4, dtype=torch.int32, device=dev)
     ws_0 = torch.zeros(ws_n, device=dev)
     check(lib.gd_del1_chain_loss_wgrad_f32(ptr(p), p.stride(0), ptr(idx), n_sel, ptr(w), d, ptr(z_0), z_0.stride(0), ptr(bits_0), ptr(slot),
-                                           ptr(tm), ptr(coef), ptr(cnt), ptr(dt), dt.stride(0), o, ptr(w_next), ptr(lp_c), ptr(ws_0), nb,
+                                           ptr(tm), ptr(coef), ptr(cnt), ptr(dt), dt.stride(0), o, ptr(w_next), *r1p, ptr(lp_c), ptr(ws_0), nb,
                                            stream_ptr(p.device)), 'chain0')
     ws_n0 = torch.zeros(ws_n, device=dev)
     check(lib.gd_del1_loss_wgrad_f32(ptr(p), p.stride(0), ptr(idx), n_sel, ptr(w), d, ptr(z_r), z_r.stride(0), ptr(bits_r), ptr(slot), ptr(tm),
