@@ -50,7 +50,7 @@ def parse():
                         'else 1): a 20-step region is 14 ms, shorter than the clock / power ramp of the part')
     p.add_argument('--stage_profile', default=None,
                    help='per-stage in-step kernel durations + PMC traffic from the committed rocprofv3 runs (tools/rocpd_stage_table.py); '
-                        'default profiles/r05_final_stages.json (gcn) / profiles/r05_final_stages_<gnn>.json')
+                        'default profiles/r06_final_stages.json (gcn) / profiles/r06_final_stages_<gnn>.json / ..._<workload>_<gnn>.json')
     p.add_argument('--probe_partition', action='store_true', help=argparse.SUPPRESS)   # child-process self test
     p.add_argument('--probe_overlap', action='store_true', help=argparse.SUPPRESS)     # ... of the overlapped exchanges
     p.add_argument('--parallel', default='auto', choices=['auto', 'partition', 'replicas'],
@@ -62,7 +62,8 @@ def parse():
                         'request (no data-path collective, "scaling": "weak") as the headline, on explicit request only')
     a = p.parse_args()
     if a.stage_profile is None:
-        a.stage_profile = os.path.join(ROOT, 'profiles', 'r05_final_stages.json' if a.gnn == 'gcn' else f'r05_final_stages_{a.gnn}.json')
+        tag = ('' if a.gnn == 'gcn' else f'_{a.gnn}') if a.workload == 'synth-collab' else f"_{a.workload.replace('synth-', '').replace('-', '_')}_{a.gnn}"
+        a.stage_profile = os.path.join(ROOT, 'profiles', f'r06_final_stages{tag}.json')
     return a
 
 
@@ -162,6 +163,41 @@ def partition_estimate(eng, world, ctl, single_us, link_gbs=100.0, l1_share=0.29
     return {'single_gpu_step_us': single_us, 'predicted_partitioned_step_us': comp + exch, 'compute_us': comp, 'exchange_us': exch,
             'assumed_link_gbs': link_gbs, 'layer1_share_of_step': l1_share, 'layer1_share_from': l1_source,
             'note': 'informational: the partitioned step is the headline at every N; link rate and launch overheads are assumptions, no multi-GPU run has been recorded'}
+
+
+def planner_curve(eng, single_us, link_gbs=100.0, l1_share=0.29, worlds=(2, 4, 8)):
+    """the planner's model of the row-partitioned step at EVERY world size of the scaling curve, from one
+    run - per N the heaviest rank's halo bytes (both exchanges), the largest single pair, the layer-1 rows a rank recomputes
+    for its halo, and the step the model of partition_estimate() predicts from them (compute = the measured single-GPU step
+    scaled by rows worked on + launches, exchange = heaviest rank's bytes over its N - 1 links at an ASSUMED sustained
+    link rate + the packed all-reduce).  Computed on the engine's replicated graph structure (the same halo_plan the engine
+    itself uses, in the engine's internal node order); informational, never `value`."""
+    from gnndelete_amd.collectives import halo_plan, row_blocks
+    g, n = eng.graph, eng.n
+    dev = g.rowptr.device
+    m1 = torch.zeros(n, dtype=torch.bool, device=dev)
+    sdf1 = eng.model.deletion1.mask.to(dev)
+    m1[:] = sdf1[eng.perm] if getattr(eng, 'perm', None) is not None else sdf1
+    row_f, row_b = 4 * getattr(eng, 'wf', eng.o), 4 * eng.o
+    out = {}
+    for world in worlds:
+        chunk, _ = row_blocks(n, world)
+        f = halo_plan(g.rowptr, g.col, n, 0, world, chunk)
+        b = halo_plan(g.rowptr_t, g.col_t, n, 0, world, chunk, m1) if eng._mode != 'gat' else f
+        pf, pb = torch.tensor(f.pair_counts), torch.tensor(b.pair_counts)          # [receiver, sender] rows
+        recv = row_f * pf.sum(1) + row_b * pb.sum(1)
+        pair = row_f * (pf + pf.t()) + row_b * (pb + pb.t())
+        need1 = pf.sum(1)                                   # halo rows whose layer-1 output a rank recomputes
+        own = torch.tensor([min(n, (q + 1) * chunk) - min(n, q * chunk) for q in range(world)])
+        compute = (single_us * (l1_share * (own + need1).double() / n + (1 - l1_share) * own.double() / n) + 60.0).max()
+        exchange = float(recv.max()) / max(1, world - 1) / (link_gbs * 1e3) + 30.0
+        out[str(world)] = {'rows_per_rank': int(chunk), 'recv_bytes_per_step_max_rank': int(recv.max()),
+                           'recv_bytes_per_step_every_rank': [int(v) for v in recv.tolist()], 'pair_bytes_per_step_max': int(pair.max()),
+                           'layer1_rows_recomputed_max_rank': int(need1.max()), 'allreduce_bytes': 4 * (eng.h * eng.h + eng.o * eng.o + 4),
+                           'predicted_step_us': float(compute) + exchange, 'predicted_compute_us': float(compute), 'predicted_exchange_us': exchange}
+    return {'single_gpu_step_us': single_us, 'assumed_link_gbs': link_gbs, 'layer1_share_of_step': l1_share, 'per_world': out,
+            'note': 'model only: the link rate and the launch overheads are assumptions - no multi-GPU run has been recorded; '
+                    'compare predicted_step_us with the measured ms_per_step of the SCALE runs at the same N'}
 
 
 def make_kg_engine(args, data, model, neg, ni1, ni2, device, rank=0, world=1, group=None, partition=False, **engine_opts):
@@ -342,13 +378,7 @@ def kg_main(args, device, rank=0, world=1, group=None, barrier=lambda: None, ctl
             out['extras'][key + '_W_rel_l2_vs_full_step_after_10_iterations'] = [rel_(w_opt[0], w_full[0]), rel_(w_opt[1], w_full[1])]
             model.load_state_dict(state)
             e2 = make_kg_engine(args, data, model, neg, ni1, ni2, device, **opts)
-            for _ in range(args.warmup):
-                e2.step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            e2.run(args.steps, unroll=args.unroll)
-            torch.cuda.synchronize()
-            out['extras'][key] = args.steps / (time.perf_counter() - t1)
+            out['extras'][key], out['extras'][key + '_ms_per_step_each_region'] = median_rate(e2, args)
             del e2
         model.load_state_dict(state)
     if not args.no_cpu_baseline:
@@ -363,6 +393,184 @@ def kg_main(args, device, rank=0, world=1, group=None, barrier=lambda: None, ctl
         rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm())
         out['parity'] = {'iterations': iters, 'W_D1_rel_l2': rel(model.deletion1.deletion_weight.detach(), ref.deletion1.deletion_weight.detach()),
                          'W_D2_rel_l2': rel(model.deletion2.deletion_weight.detach(), ref.deletion2.deletion_weight.detach())}
+    print(json.dumps(out))
+
+
+def build_nodecls_request(args):
+    """BASELINE config 5: delete_node.py's request (delete_node.py:77-142) - `df_size` % of the NODES deleted with every edge
+    touching them, S_Df = 2-hop / 1-hop enclosing subgraph on the undirected edge_index - on the node-classification
+    stand-in of the named shape (`synth-collab-nodecls`: 235,868 nodes, 4 classes; out_dim = #classes, delete_node.py:63-64)."""
+    from types import SimpleNamespace
+    from gnndelete_amd.framework.graph_utils import k_hop_subgraph, negative_sampling
+    from gnndelete_amd.framework.models import GATDelete, GCNDelete, GINDelete, SAGEDelete
+    from gnndelete_amd.framework.synth import make_nodecls_dataset
+    from gnndelete_amd.framework.utils import seed_everything
+    data = make_nodecls_dataset(args.workload[:-len('-nodecls')], seed=args.seed)
+    n = data.num_nodes
+    seed_everything(args.seed)
+    df_nodes = torch.randperm(n)[:int(args.df_size / 100 * n)]
+    gone = torch.zeros(n, dtype=torch.bool)
+    gone[df_nodes] = True
+    E = data.edge_index
+    df_mask = gone[E[0]] | gone[E[1]]
+    df_edge = E[:, df_mask]
+    data.directed_df_edge_index = df_edge[:, df_edge[0] < df_edge[1]]
+    seeds = df_edge.flatten().unique()
+    _, e2, _, m2e = k_hop_subgraph(seeds, 2, E, num_nodes=n)
+    _, e1, _, _ = k_hop_subgraph(seeds, 1, E, num_nodes=n)
+    s1, s2 = torch.zeros(n, dtype=torch.bool), torch.zeros(n, dtype=torch.bool)
+    s1[e1.flatten().unique()] = True
+    s2[e2.flatten().unique()] = True
+    data.sdf_node_1hop_mask, data.sdf_node_2hop_mask, data.sdf_mask, data.df_mask = s1, s2, m2e, df_mask
+    data.dr_mask = data.dtrain_mask = ~df_mask
+    data.train_pos_edge_index = E                      # (the oracle's loop reads the edges under this name)
+    cls = {'gcn': GCNDelete, 'gat': GATDelete, 'gin': GINDelete, 'sage': SAGEDelete}[args.gnn]
+    model = cls(SimpleNamespace(in_dim=data.x.shape[1], hidden_dim=128, out_dim=data.num_classes), s1, s2)
+    neg = negative_sampling(E, n, int(df_mask.sum()))
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[data.directed_df_edge_index.flatten().unique()] = False
+    return data, model, neg, s1 & keep, s2 & keep
+
+
+def time_gat_aggregation(eng):
+    """The layer-1 attention-scored aggregation of the GAT step (d = 128: edge scores, softmax over a row's in-edges and the
+    weighted gather in one kernel) back to back on the step's own graph.  Algorithmic bytes: rowptr + col + h read once + out
+    written once + the two logit vectors + row max / row sum written (SURVEY 8d's SpMM formula without a value stream)."""
+    from gnndelete_amd import ops
+    g, n, h = eng.graph, eng.n, eng.h
+    c = eng.model.conv1
+    h1 = torch.randn(n, h, device=eng.x.device)
+    a_src, a_dst = ops.row_dots(h1, c.att_src, c.att_dst)
+    out = torch.empty_like(h1)
+    dur = _avg_seconds(lambda: ops.gat_forward_raw(g, h1, a_src, a_dst, c.bias, c.negative_slope, out=out))
+    nbytes = 4 * (n + 1) + 4 * g.nnz + 8 * n * h + 16 * n
+    return {'kernel': 'gat_items_fwd_kernel (layer-1 attention-scored aggregation: scores, softmax, weighted gather; d=128)',
+            'bound': 'hbm', 'achieved': nbytes / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': nbytes / dur / 1e9 / HBM_PEAK_GBS,
+            'traffic': None, 'algorithmic_bytes': nbytes, 'avg_us': dur * 1e6}
+
+
+def nodecls_main(args, device, rank=0, world=1, barrier=lambda: None, ctl=None):
+    """`--workload synth-collab-nodecls --gnn gat` (BASELINE config 5): steady-state Del epochs of the node-
+    deletion request - one step = one epoch of GNNDeleteNodeClassificationTrainer's loop body (gnndelete_nodeemb.py:570-607),
+    the whole graph, nothing cached across steps - with the same JSON contract.  N > 1: independent replicas (no collective)."""
+    from gnndelete_amd.engine import NodeembEngine
+    data, model, neg, ni1, ni2 = build_nodecls_request(args)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model = model.to(device)
+    x, E = data.x.to(device), data.edge_index.to(device)
+    e_sdf, e_dr = E[:, data.sdf_mask.to(device)].contiguous(), E[:, data.dr_mask.to(device)].contiguous()
+    with torch.no_grad():
+        z1o, z2o = model.get_original_embeddings(x, e_dr, return_all_emb=True)
+    common = (model, x, e_sdf, z1o, z2o, E[:, data.df_mask.to(device)], neg.to(device), ni1, ni2)
+
+    def engine(**opts):
+        model.load_state_dict(state)
+        return NodeembEngine(*common, loss_type='both_layerwise', alpha=0.5, lr=1e-3, use_graph=not args.no_graph, **opts)
+
+    def rate(eng_, regions):
+        if args.unroll > 1 and not args.no_graph:
+            eng_.prepare_unrolled(args.unroll)
+        for _ in range(args.warmup):
+            eng_.step()
+        out_ = []
+        for _ in range(regions):
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng_.run(args.steps, unroll=args.unroll)
+            torch.cuda.synchronize()
+            barrier()
+            dt_ = time.perf_counter() - t0
+            if world > 1:
+                import torch.distributed as dist
+                tmax = torch.tensor([dt_], dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=ctl)
+                dt_ = float(tmax)
+            out_.append(dt_)
+        return out_
+    n_regions = args.repeats if args.repeats > 0 else (5 if args.steps < 100 else 1)
+    eng = engine()
+    region_s = rate(eng, n_regions)
+    dt = sorted(region_s)[len(region_s) // 2]
+    if rank != 0:
+        return
+    out = {'metric': 'Del-op train iters/sec', 'value': world * args.steps / dt, 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': f'{args.workload} {args.gnn.upper()} 2-layer, {args.df_size}% NODE deletion (delete_node.py), full-graph Del '
+                                  f'epoch (both_layerwise, mse_mean)',
+                      'num_nodes': data.num_nodes, 'in_dim': int(data.x.shape[1]), 'hidden_dim': 128, 'out_dim': int(data.num_classes),
+                      'out_dim_padded_to': int(eng.o), 'df_nodes': int(args.df_size / 100 * data.num_nodes),
+                      'df_edges_undirected': int(data.df_mask.sum()), 'sdf_edges': int(data.sdf_mask.sum()), 'spmm_nnz': eng.graph.nnz,
+                      'S1': int(data.sdf_node_1hop_mask.sum()), 'S2': int(data.sdf_node_2hop_mask.sum()), 'backbone': 'random init',
+                      'hip_graph': not args.no_graph, 'iterations_per_graph_launch': 1 if args.no_graph else args.unroll,
+                      'matrix_products': matrix_products_label(), 'parallelism': 'single' if world == 1 else f'replicas x{world}',
+                      'ranks_seen': world, 'chained_del1': bool(eng._chain1), 'fused_layer2': bool(eng._fuse_l2)},
+           'timing': {'regions': n_regions, 'steps_per_region': args.steps, 'reported': 'median region',
+                      'ms_per_step_each_region': [1e3 * t / args.steps for t in region_s]},
+           'final_loss': float(eng.loss_history()[-1, 0])}
+    if world > 1:
+        print(json.dumps(out))
+        return
+    prof, prof_note = load_stage_profile(args.stage_profile, data.num_nodes, eng.graph.nnz)
+    if args.gnn == 'gat':
+        out['roofline'] = time_gat_aggregation(eng)
+    else:
+        kdur, kbytes = time_dominant_kernel(eng)
+        out['roofline'] = {'kernel': 'spmm_persist_kernel<32,1,4,true,true> (layer-1 CSR SpMM, d=128)', 'bound': 'hbm', 'achieved': kbytes / kdur / 1e9,
+                           'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kbytes / kdur / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                           'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6}
+    first = next(iter(prof.get('stages', {}).values()), None) if prof else None
+    out['roofline']['stage_profile'] = os.path.relpath(args.stage_profile, ROOT) if prof else prof_note
+    out['extras'] = {'stage_rooflines': stage_table_from_profile(prof)}
+    if not args.no_cached_rate:
+        # informational only (never `value`): what the trainer runs by default (frozen layer-1 output computed once, only the rows
+        # the request can influence), and the same full step WITHOUT the padded class dimension (generic-width layer-2 kernels)
+        out['extras']['iters_per_s_trainer_default'] = median_rate(engine(cache_layer1=True, affected_rows_only=True), args)[0]
+        if eng._user_wd2 is not None:
+            os.environ['GD_PAD_OUT'] = '0'
+            try:
+                out['extras']['iters_per_s_unpadded_class_dimension'] = median_rate(engine(), args)[0]
+            finally:
+                os.environ.pop('GD_PAD_OUT')
+    if not args.no_cpu_baseline:
+        from oracle import gnndelete_ref as R
+        threads = min(os.cpu_count() or 1, 32)
+        torch.set_num_threads(threads)
+        iters = max(2, min(args.cpu_baseline_iters, 6))
+        ref = R.TwoLayerDelete(args.gnn, data.x.shape[1], 128, data.num_classes, data.sdf_node_1hop_mask, data.sdf_node_2hop_mask)
+        ref.load_state_dict(state, strict=False)
+        Ec = data.edge_index
+        with torch.no_grad():
+            r1o, r2o = ref.get_original_embeddings(data.x, Ec[:, data.dr_mask], return_all_emb=True)
+        targets = dict(z1_ori=r1o, z2_ori=r2o, pos_edge=Ec[:, data.df_mask], neg_edge=neg, ni_mask1=ni1, ni_mask2=ni2)
+        opt = R.make_optimizer(ref, 'both_layerwise', 1e-3)
+        c_sdf = Ec[:, data.sdf_mask]
+        times = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            R.nodeemb_epoch(ref, lambda: ref(data.x, c_sdf, return_all_emb=True), targets, opt, 'both_layerwise', 0.5, R.LOSSES['mse_mean'])
+            times.append(time.perf_counter() - t0)
+        med = sorted(times[1:])[len(times[1:]) // 2]
+        out['cpu_baseline'] = {'value': 1.0 / med, 'unit': 'iters/s', 'cores': threads, 'kind': 'port',
+                               'sample': f'{iters - 1} full-graph epochs of the same request after 1 warm-up, median ({med:.2f} s; oracle '
+                                         f'nodeemb_epoch = gnndelete_nodeemb.py:570-607 restated, torch CPU, {threads} of {os.cpu_count()} host threads)'}
+        out['speedup_vs_cpu'] = out['value'] / out['cpu_baseline']['value']
+        e2 = engine()
+        for _ in range(iters):
+            e2.step()
+        torch.cuda.synchronize()
+        rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm())
+        with torch.no_grad():
+            rr1, rr2 = ref(data.x, Ec[:, data.dr_mask], return_all_emb=True)
+            hh1, hh2 = model(x, e_dr, return_all_emb=True)
+        s1m, s2m = data.sdf_node_1hop_mask, data.sdf_node_2hop_mask
+        acc = lambda z: float((z.argmax(1).cpu()[data.test_mask] == data.y[data.test_mask]).float().mean())
+        out['parity'] = {'iterations': iters, 'W_D1_rel_l2': rel(model.deletion1.deletion_weight.detach(), ref.deletion1.deletion_weight.detach()),
+                         'W_D2_rel_l2': rel(model.deletion2.deletion_weight.detach(), ref.deletion2.deletion_weight.detach()),
+                         'z1_affected_rel_l2': rel(hh1[s1m.to(device)], rr1[s1m]), 'z2_affected_rel_l2': rel(hh2[s2m.to(device)], rr2[s2m]),
+                         'test_accuracy_hip': acc(hh2), 'test_accuracy_cpu_oracle': acc(rr2),
+                         'note': 'HIP engine vs CPU oracle from identical state, negatives and iteration count (random-init backbone)'}
     print(json.dumps(out))
 
 
@@ -493,10 +701,38 @@ def time_del_gemm(eng, reps=20):
     torch.cuda.synchronize()
     dur_s = e0.elapsed_time(e1) / 1e3 / reps
     flops = 2.0 * eng.s1 * eng.h * eng.h
-    return {'kernel': 'rows_gemm_mfma_kernel<4,0> (Del operator, S1 rows, d=128)', 'bound': 'mfma',
+    from gnndelete_amd import _lib
+    ws = bool(_lib.lib().gd_rows_gemm_ws_covers(eng.s1, eng.h, eng.h)) and ops.matrix_split() == 0
+    return {'kernel': ('rows_gemm_ws_kernel<128,128> (weight-stationary row GEMM)' if ws else 'rows_gemm_mfma_kernel<4,0>')
+                      + ' - the STAND-ALONE Del-1 product on the S1 rows, d=128 (ops.rows_gemm, what DeletionLayer.forward runs outside '
+                        'the engine); not a launch of the fused step, which forms Del-1 inside its Del-1 pass: see stage_rooflines.del1_loss_wgrad1',
+            'bound': 'mfma',
             'achieved': flops / dur_s / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': flops / dur_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 'avg_us': dur_s * 1e6, 'rows': eng.s1,
             'hbm_gbs': 4.0 * (2 * eng.s1 * eng.h + eng.h * eng.h + eng.s1) / dur_s / 1e9}
+
+
+def median_rate(eng, args, regions=None):
+    """iters/s of an engine the way the headline is timed: warm-up, then `regions` regions of exactly
+    --steps steps each (5 when --steps < 100: a 20-step region is shorter than the clock ramp of the part), the MEDIAN
+    region.  -> (rate, [ms per step of every region])."""
+    regions = regions or (args.repeats if args.repeats > 0 else (5 if args.steps < 100 else 1))
+    if args.unroll > 1 and not args.no_graph and hasattr(eng, 'prepare_unrolled'):
+        eng.prepare_unrolled(args.unroll)
+    for _ in range(args.warmup):
+        eng.step()
+    ts = []
+    for _ in range(regions):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if hasattr(eng, 'run') and not args.no_graph:
+            eng.run(args.steps, unroll=args.unroll)
+        else:
+            for _ in range(args.steps):
+                eng.step()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return args.steps / sorted(ts)[len(ts) // 2], [1e3 * t / args.steps for t in ts]
 
 
 def _avg_seconds(launch, reps=20):
@@ -837,19 +1073,28 @@ def launch_ranks(n):
     its output is relayed and its exit code returned."""
     import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    print(f'bench.py: --gpus {n} without WORLD_SIZE in the environment - launching {n} ranks: {" ".join(cmd[1:8])} ...', file=sys.stderr, flush=True)
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for line in proc.stdout:
-        sys.stdout.write(line)
+    rc = 1
+    for attempt in range(3):
+        # a port that is free NOW can be taken before torchrun binds it (two bench runs started together by a scale script):
+        # a launch that dies on the rendezvous address before any rank printed a line is retried on a fresh port (ADVICE r5)
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f'bench.py: --gpus {n} without WORLD_SIZE in the environment - launching {n} ranks: {" ".join(cmd[1:8])} ...', file=sys.stderr, flush=True)
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        out, err = proc.communicate()
+        sys.stdout.write(out)
         sys.stdout.flush()
-    return proc.wait()
+        sys.stderr.write(err[-4000:])
+        rc = proc.returncode
+        in_use = 'EADDRINUSE' in err or 'Address already in use' in err or 'address already in use' in err
+        if rc == 0 or not in_use or out.strip():
+            break
+    return rc
 
 
 def main():
@@ -909,6 +1154,11 @@ def main():
         if args.probe_partition:
             args.workload, args.steps, args.warmup, args.repeats = 'synth-kg-small', 3, 1, 1
         kg_main(args, device, rank, world, group, barrier, ctl)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if args.workload.endswith('-nodecls'):
+        nodecls_main(args, device, rank, world, barrier, ctl)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -1065,6 +1315,10 @@ def main():
         out['config']['ranks_seen'] = world          # WORLD_SIZE of the torch.distributed job this line was measured in
         if auto_est is not None:
             out['config']['parallel_auto'] = auto_est
+            try:        # the whole curve's model from this one run (halo bytes and predicted step at N = 2 / 4 / 8)
+                out['config']['planner_curve'] = planner_curve(eng, auto_est['single_gpu_step_us'], l1_share=auto_est['layer1_share_of_step'])
+            except Exception as e:                                   # noqa: BLE001
+                out['config']['planner_curve'] = f'unavailable: {type(e).__name__}: {str(e)[:120]}'
         if world > 1:
             out['config']['halo_exchanges'] = ('overlapped with compute (the probe reproduced the synchronous result)' if getattr(args, 'dist_overlap', None)
                                                else f'synchronous ({overlap_note})')
@@ -1081,14 +1335,11 @@ def main():
             from gnndelete_amd.engine import NodeembEngine
             model.load_state_dict(state)
             ceng = NodeembEngine(*eng_args, loss_type=args.loss_type, alpha=0.5, lr=1e-3, cache_layer1=True)
-            for _ in range(args.warmup):
-                ceng.step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                ceng.step()
-            torch.cuda.synchronize()
-            out['extras'] = {'iters_per_s_with_loop_invariant_layer1_cached': args.steps / (time.perf_counter() - t1)}
+            # (every informational rate below: the median of as many --steps regions as the headline, not ONE region)
+            out['extras'] = {'timing': 'median region, as the headline', 'ms_per_step_each_region': {}}
+            per_region = out['extras']['ms_per_step_each_region']
+            out['extras']['iters_per_s_with_loop_invariant_layer1_cached'], per_region['layer1_cached'] = median_rate(ceng, args)
+            del ceng
             # informational only: the step restricted to the rows the request can influence (identical results,
             # DESIGN.md section 2), without and with the layer-1 cache - the latter is what the trainer runs
             for key, cached in (('iters_per_s_affected_rows_only', False), ('iters_per_s_trainer_default', True)):
@@ -1097,13 +1348,8 @@ def main():
                                      affected_rows_only=True)
                 if not getattr(reng, '_rows_only', False):
                     continue
-                for _ in range(args.warmup):
-                    reng.step()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                reng.run(args.steps, unroll=args.unroll)
-                torch.cuda.synchronize()
-                out['extras'][key] = args.steps / (time.perf_counter() - t1)
+                out['extras'][key], per_region[key.replace('iters_per_s_', '')] = median_rate(reng, args)
+                del reng
             out['extras']['affected_rows'] = {'S2': int(data.sdf_node_2hop_mask.sum()), 'of': data.num_nodes}
             # informational only: the same full step with the 128-wide row GEMMs' fp32 products formed from bf16 partial
             # products (gd_set_matrix_split(6), opt-in) - `value` above uses the fp32 instruction
@@ -1113,15 +1359,7 @@ def main():
                 try:
                     model.load_state_dict(state)
                     seng = NodeembEngine(*eng_args, loss_type=args.loss_type, alpha=0.5, lr=1e-3)
-                    if args.unroll > 1:
-                        seng.prepare_unrolled(args.unroll)
-                    for _ in range(args.warmup):
-                        seng.step()
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    seng.run(args.steps, unroll=args.unroll)
-                    torch.cuda.synchronize()
-                    out['extras']['iters_per_s_bf16x6_split_products'] = args.steps / (time.perf_counter() - t1)
+                    out['extras']['iters_per_s_bf16x6_split_products'], per_region['bf16x6_split_products'] = median_rate(seng, args)
                     out['extras']['roofline_del_gemm_bf16x6_split'] = time_del_gemm(seng)
                 finally:
                     _ops.set_matrix_split(0)

@@ -87,7 +87,9 @@ __device__ __forceinline__ float lanes_sum(float v) {
 template <int LPR>
 __device__ __forceinline__ float4 f4_group_sum(float4 a) {
 #pragma unroll
-  for (int off = LPR; off < 16; off <<= 1) a = f4_add(a, f4_shfl_xor(a, off));
+  for (int off = LPR; off < 8; off <<= 1) a = f4_add(a, f4_shfl_xor(a, off));
+  // l ^ 8 inside a 16-lane row is a rotation by 8: one DPP add per float instead of a trip through the LDS crossbar
+  if (LPR <= 8) a = make_float4(dpp_add<0x128>(a.x), dpp_add<0x128>(a.y), dpp_add<0x128>(a.z), dpp_add<0x128>(a.w));
   if (LPR <= 16) a = make_float4(xor16_sum(a.x), xor16_sum(a.y), xor16_sum(a.z), xor16_sum(a.w));
   if (LPR <= 32) a = make_float4(xor32_sum(a.x), xor32_sum(a.y), xor32_sum(a.z), xor32_sum(a.w));
   return a;

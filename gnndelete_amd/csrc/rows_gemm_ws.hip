@@ -44,7 +44,10 @@ __device__ __forceinline__ uint32_t or_row_lanes(uint32_t v) {
 //         gd_rows_gemm_dots_f32), 4: gated like 2 after the rank-1 correction out[row, n] += o1[row] u1[n] + o2[row] u2[n]
 //         (gd_rows_gemm_gated_rank1_f32: o1 / o2 are per-row scalars READ by row id), 5: plain + bias (u1 = the bias vector: the
 //         accumulators of a unit start from it instead of from zero)
-// SEL: row r comes from in_alt where sel[r] != 0 (dense only)
+// SEL: row r comes from in_alt where sel[r] != 0.  With an index list as well (round 6: the rows-only step's t2 / GAT logits
+//      products) the selector byte of a listed row is a DEPENDENT load behind its row id: the ids are requested three units
+//      ahead, the selector two units ahead from the id that has landed by then, and the pair travels as one descriptor word
+//      (row id | selector << 31) - no wait on a fresh load anywhere in the loop.
 template <int DIN, int DOUT, int MODE, bool HASIDX, bool SEL, bool RELU>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rows_gemm_ws_kernel(
     const float* __restrict__ in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel, const float* __restrict__ w,
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float* __restrict__ u1, const float* __restrict__ u2, float* o1, float* o2) {
   constexpr int KQ = DIN / 4, NT = DOUT / 16, XV = KQ / 4, NW = DOUT / 32;
   constexpr bool GATE = MODE == 2 || MODE == 4, DOTS = MODE == 3, RANK1 = MODE == 4, BIAS = MODE == 5;
-  static_assert(!(HASIDX && SEL), "the selector form is dense");
+  constexpr bool BOTH = HASIDX && SEL;
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar loop control)
@@ -66,16 +69,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // what a unit's row loads need and cannot compute: the row id (index list) or the row's selector byte
   auto slot_of = [&](int u) -> int { return min(u * 16 + r, n_sel - 1); };
+  auto id_of = [&](int u) -> int32_t { return idx[slot_of(min(u, n_units - 1))]; };
+  auto with_sel = [&](int32_t row) -> int32_t { return row | (sel[row] ? (int32_t)0x80000000 : 0); };
   auto desc_of = [&](int u) -> int32_t {
     const int s_ = slot_of(min(u, n_units - 1));
+    if (BOTH) return with_sel(idx[s_]);
     return HASIDX ? idx[s_] : (SEL ? (int32_t)sel[s_] : 0);
   };
+  auto row_of = [&](int32_t desc) -> int32_t { return BOTH ? (desc & 0x7fffffff) : desc; };
   auto src_of = [&](int u, int32_t desc) -> const float4* {
-    const int64_t row = HASIDX ? (int64_t)desc : (int64_t)slot_of(min(u, n_units - 1));
-    const float* base = (SEL && desc) ? in_alt : in;
+    const int64_t row = HASIDX ? (int64_t)row_of(desc) : (int64_t)slot_of(min(u, n_units - 1));
+    const float* base = (SEL && (BOTH ? desc < 0 : desc != 0)) ? in_alt : in;
     return reinterpret_cast<const float4*>(base + row * ld_in + kq * KQ);
   };
   int32_t d_cur = desc_of(u_first), d_nxt = desc_of(u_first + 1);
+  int32_t id_nn = BOTH ? id_of(u_first + 2) : 0;             // (BOTH) row id of the unit after next, its selector still to fetch
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- weight image wl[k DOUT + n + 16 (k / KQ)]: the two k quarters one 32-lane LDS access touches sit 16 banks apart
@@ -129,9 +137,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   f32x4v acc_a[NT], acc_b[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc_a[t] = acc_b[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  float* dst_prev = out + (HASIDX ? (int64_t)d_cur : (int64_t)slot_of(u_lo)) * ld_out + 4 * kq;
+  float* dst_prev = out + (HASIDX ? (int64_t)row_of(d_cur) : (int64_t)slot_of(u_lo)) * ld_out + 4 * kq;
   int sa_prev = slot_of(u_lo);
-  int row_prev = HASIDX ? d_cur : slot_of(u_lo);            // row id of the unit whose results are stored next (MODE 3 / 4)
+  int row_prev = HASIDX ? row_of(d_cur) : slot_of(u_lo);    // row id of the unit whose results are stored next (MODE 3 / 4)
   uint32_t sg[NW], gsh[NW];
 #pragma unroll
   for (int q = 0; q < NW; ++q) sg[q] = gsh[q] = 0;
@@ -201,7 +209,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   // one unit: products into acc, the previous unit's results (old) out, the next unit's rows in
   auto unit = [&](int u, f32x4v (&acc)[NT], const f32x4v (&old)[NT]) {
-    const int32_t d_nn = desc_of(u + 2);                     // used a unit from now
+    int32_t d_nn, id_n3 = 0;
+    if (BOTH) {
+      id_n3 = id_of(u + 3);                                  // lands during this unit
+      d_nn = with_sel(id_nn);                                // the id requested a unit ago: no wait
+    } else {
+      d_nn = desc_of(u + 2);                                 // used a unit from now
+    }
     const float4* nsrc = src_of(u + 1, d_nxt);
     uint32_t gcur[NW];
     if (GATE) {
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int q = 0; q < NW; ++q) gcur[q] = gp[q];
     }
-    const int row_cur = HASIDX ? d_cur : slot_of(u);
+    const int row_cur = HASIDX ? row_of(d_cur) : slot_of(u);
     float ra_cur = 0.f, rb_cur = 0.f;
     if (RANK1) {
       ra_cur = o1[row_cur];
@@ -252,10 +266,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       rb_prev = rb_cur;
     }
     row_prev = row_cur;
-    dst_prev = out + (HASIDX ? (int64_t)d_cur : (int64_t)slot_of(u)) * ld_out + 4 * kq;
+    dst_prev = out + (HASIDX ? (int64_t)row_of(d_cur) : (int64_t)slot_of(u)) * ld_out + 4 * kq;
     sa_prev = slot_of(u);
     d_cur = d_nxt;
     d_nxt = d_nn;
+    if (BOTH) id_nn = id_n3;
   };
   int u = u_lo;
   if ((u_hi - u_lo) & 1) {
@@ -312,6 +327,7 @@ static int ws_dispatch(const float* in, int64_t ld_in, const int32_t* idx, int32
       return 1;
     }
     if constexpr (DIN == 128) {
+      if (sel && idx) { if (relu_in) GD_WS(3, true, true, true); else GD_WS(3, true, true, false); }
       if (sel) { if (relu_in) GD_WS(3, false, true, true); else GD_WS(3, false, true, false); }
       if (idx) { if (relu_in) GD_WS(3, true, false, true); else GD_WS(3, true, false, false); }
       if (relu_in) GD_WS(3, false, false, true);
@@ -328,6 +344,7 @@ static int ws_dispatch(const float* in, int64_t ld_in, const int32_t* idx, int32
     if (relu_in) GD_WS(5, false, false, true);
     GD_WS(5, false, false, false);
   }
+  if (sel && idx) { if (relu_in) GD_WS(0, true, true, true); else GD_WS(0, true, true, false); }
   if (sel) { if (relu_in) GD_WS(0, false, true, true); else GD_WS(0, false, true, false); }
   if (idx) { if (relu_in) GD_WS(0, true, false, true); else GD_WS(0, true, false, false); }
   if (relu_in) GD_WS(0, false, false, true);
@@ -350,7 +367,7 @@ static int ws_min_rows() {
 
 // -> GD_OK / error when the weight-stationary kernel took the call, 1 when it does not cover it (the caller goes on with
 // the LDS-operand form).  Covered: widths in {64, 128}, bias only in the plain mode, no saved input, out not aliasing an input, enough rows that
-// every wave gets units; ReLU on the input only in the plain / dots modes; the selector form only dense; row dots (u1 .. o2,
+// every wave gets units; ReLU on the input only in the plain / dots modes; the selector form dense or with an index list; row dots (u1 .. o2,
 // no gate) behind a 128-wide input, the rank-1 + gate form (u1 .. o2 with gate_bits) in front of a 128-wide output.
 int rows_gemm_ws_try(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t d_in, int32_t d_out,
                      int32_t trans_w, const float* bias, int32_t relu_in, const uint32_t* gate_bits, uint32_t* sign_out, float* out,
@@ -359,7 +376,8 @@ int rows_gemm_ws_try(const float* in, int64_t ld_in, const int32_t* idx, int32_t
   if (!ws_on() || matrix_split() != 0 || save_in || n_sel < ws_min_rows()) return 1;
   if (bias && (gate_bits || sign_out || u1 || !aligned16(bias) || !epi_on())) return 1;
   if (!((d_in == 64 || d_in == 128) && (d_out == 64 || d_out == 128))) return 1;
-  if (in == out || in_alt == out || (sel && idx) || (relu_in && (gate_bits || sign_out)) || (sel && (gate_bits || sign_out))) return 1;
+  if (in == out || in_alt == out || (relu_in && (gate_bits || sign_out)) || (sel && (gate_bits || sign_out))) return 1;
+  if (sel && idx && u1 && d_in != 128) return 1;
   if (!aligned16(in) || !aligned16(out) || !aligned16(w) || (in_alt && !aligned16(in_alt)) || ld_in % 4 || ld_out % 4) return 1;
   if (u1 && (!u2 || !o1 || !o2 || sign_out || !aligned16(u1) || !aligned16(u2) || !epi_on())) return 1;
   hipStream_t s = (hipStream_t)stream;

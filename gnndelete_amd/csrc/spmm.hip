@@ -10,6 +10,7 @@
 // partial sums are combined with a log2(G)-step xor-shuffle tree, so the summation order is
 // fixed (bit-reproducible run to run).  HBM-bound: bytes = 4(n+1) + 8 nnz + 8 n d.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(const int32_t* __restrict
 // aux_sum[row]: the transposition pass that used to make both (gat_transpose_edge_kernel, 33 us of the 775 us GAT step: 1.84 M
 // random 8-byte gathers at 8 lanes per row) disappears into this kernel, where the same gather is one more load per visit
 // that arrives behind the row gathers.  perm is fetched a visit ahead with the indices, aux at the top of the visit.
-template <int LPR, int VPL, int U, bool EXACT, bool ADDR32, bool AUX = false>
+template <int LPR, int VPL, int U, bool EXACT, bool ADDR32, bool AUX = false, bool NOVAL = false>
 __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items, int32_t n_items,
                                                   const int32_t* __restrict__ xcd_bounds,
                                                   const int32_t* __restrict__ col, const float* __restrict__ val,
@@ -136,6 +137,9 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
   const int per = (n_items + kXcd - 1) / kXcd;
   const int i0 = xcd_bounds ? xcd_bounds[xcd] : xcd * per;
   const int i1 = xcd_bounds ? xcd_bounds[xcd + 1] : min(n_items, i0 + per);
+  // group items (slot == -2) meet at block barriers: block-uniform only with range limits that are multiples of 4 - a table
+  // that breaks this aborts the launch instead of deadlocking it (invariant stated in include/gnndelete_hip.h)
+  if (xcd_bounds && ((i0 | i1) & 3)) __builtin_trap();
 
   // per-lane constants: byte offset of this lane's vectors inside a row, its slice of the bias
   uint32_t lo[VPL];
@@ -168,7 +172,7 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
   Desc d0 = uniform(dv), d1 = uniform(dv1);
   int kk = min(d0.start + lane, nnz - 1);
   int c = col[kk];
-  float w = AUX ? 0.f : (val ? val[kk] : 1.0f);
+  float w = (AUX || NOVAL) ? 0.f : (val ? val[kk] : 1.0f);
   int pk = AUX ? perm[kk] : 0;
   // One-launch form (gd_spmm_csr_onepass_f32): slot == -2 marks a GROUP member - the four waves of a block visit four
   // consecutive, 4-aligned items at the same time, and a hub row (more than 64 in-edges) is laid out as such a
@@ -194,7 +198,7 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
     kk = min(d1.start + lane, nnz - 1);
     c = col[kk];
     if (AUX) pk = perm[kk];
-    else w = val ? val[kk] : 1.0f;
+    else if (!NOVAL) w = val ? val[kk] : 1.0f;
     float a_sum = 0.f;                                   // AUX: sum of the addends of a group member's chunks
     float4 acc[VPL];
 #pragma unroll
@@ -211,7 +215,8 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
     // list belongs to row (j >= b1) + (j >= b2) + (j >= b3).  A row's edges are dealt to the lane groups by their position in
     // the ITEM, so its sum is associated differently from the single-row form's - deterministic, equal to fp32 rounding.
     constexpr int kFar = 1 << 20;
-    constexpr int MAXR = VPL > 1 ? 1 : (LPR >= 32 ? 1 : (LPR == 16 ? 2 : 4));
+    constexpr int W4 = LPR * VPL;                       // float4 vectors of a row this instantiation covers
+    constexpr int MAXR = W4 >= 32 ? 1 : (W4 == 16 ? 2 : 4);
     const bool multi = MAXR > 1 && slot <= -16;
     int nr = 1, b1 = kFar, b2 = kFar, b3 = kFar;
     if (multi) {
@@ -221,14 +226,22 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
       b2 = (MAXR > 2 && nr > 2) ? (v >> 7) & 127 : kFar;
       b3 = (MAXR > 3 && nr > 3) ? (v >> 14) & 127 : kFar;
     }
-    float4 mb[MAXR > 1 ? MAXR - 1 : 1];                // accumulators of rows 1 .. MAXR - 1 of a multi-row item (row 0: acc[0])
+    float4 mb[MAXR > 1 ? MAXR - 1 : 1][VPL];           // accumulators of rows 1 .. MAXR - 1 of a multi-row item (row 0: acc)
 #pragma unroll
-    for (int q = 0; q < (MAXR > 1 ? MAXR - 1 : 1); ++q) mb[q] = f4_zero();
-    auto add_multi = [&](int j, float wv, const float4& xr) {
+    for (int q = 0; q < (MAXR > 1 ? MAXR - 1 : 1); ++q)
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) mb[q][v] = f4_zero();
+    auto add_multi = [&](int j, float wv, const float4(&xr)[VPL]) {
       const int r = (j >= b1) + (MAXR > 2 ? (j >= b2) + (j >= b3) : 0);
-      acc[0] = f4_fma(r == 0 ? wv : 0.f, xr, acc[0]);
+      const float w0 = r == 0 ? wv : 0.f;
 #pragma unroll
-      for (int q = 0; q < MAXR - 1; ++q) mb[q] = f4_fma(r == q + 1 ? wv : 0.f, xr, mb[q]);
+      for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(w0, xr[v], acc[v]);
+#pragma unroll
+      for (int q = 0; q < MAXR - 1; ++q) {
+        const float wq = r == q + 1 ? wv : 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) mb[q][v] = f4_fma(wq, xr[v], mb[q][v]);
+      }
     };
     const bool whole = (slot == -1 || multi) && row >= 0, self = whole && !multi && self_coef != 0.0f;
     // the accumulators of lane group 0 start from the bias (requested with the gathers: no round trip of its
@@ -259,7 +272,10 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
       auto fetch = [&](int t, float4(&xv)[VPL], float& wj) {
         const int j4 = 4 * (t * G) + 4 * g;
         const int cs = __builtin_amdgcn_ds_bpermute(min(j4, last4), c_cur);
-        wj = __int_as_float(__builtin_amdgcn_ds_bpermute(min(j4, end4), __float_as_int(w_cur)));
+        // (NOVAL: an unweighted sum - the row scales of a normalised adjacency live in the producers' / this kernel's epilogue -
+        //  has no weight stream: a slot is live or padding, decided from its position)
+        if (NOVAL) wj = j4 < end4 ? 1.0f : 0.f;
+        else wj = __int_as_float(__builtin_amdgcn_ds_bpermute(min(j4, end4), __float_as_int(w_cur)));
         if (ADDR32) {   // row byte offset by one full-rate 24-bit multiply, 32-bit offset on a scalar base
           const uint32_t ro = __umul24((uint32_t)cs, pitch_b);
   #pragma unroll
@@ -283,7 +299,7 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
             for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
         } else {
   #pragma unroll
-          for (int u = 0; u < U; ++u) add_multi((t0 + u) * G + g, wj[u], xv[u][0]);
+          for (int u = 0; u < U; ++u) add_multi((t0 + u) * G + g, wj[u], xv[u]);
         }
       }
       if (U > 1) {
@@ -301,7 +317,7 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
   #pragma unroll
                 for (int v = 0; v < VPL; ++v) acc[v] = f4_fma(wj[u], xv[u][v], acc[v]);
               } else {
-                add_multi((t0 + u) * G + g, wj[u], xv[u][0]);
+                add_multi((t0 + u) * G + g, wj[u], xv[u]);
               }
             }
         }
@@ -315,7 +331,7 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
         const float2 ad = aux[perm[k2]];
         w_raw = ad.x;
         a_raw = ad.y;
-      } else {
+      } else if (!NOVAL) {
         w_raw = val ? val[k2] : 1.0f;
       }
     }
@@ -331,13 +347,16 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
 #pragma unroll
       for (int q = 0; q < MAXR; ++q) {
         if (q < nr) {                              // (wave-uniform)
-          float4 o = f4_group_sum<LPR>(q == 0 ? acc[0] : mb[(q > 0 && q < MAXR) ? q - 1 : 0]);
-          if (g == 0 && (EXACT || li < d4)) {
-            const int64_t rq = (int64_t)row + q;
-            if (self_coef != 0.0f)
-              o = f4_fma(self_coef, *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xs + rq * ldx) + lo[0]), o);
-            if (bias) o = f4_add(o, *reinterpret_cast<const float4*>(bb + lo[0]));
-            *reinterpret_cast<float4*>(reinterpret_cast<char*>(y + rq * ldy) + lo[0]) = o;
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) {
+            float4 o = f4_group_sum<LPR>(q == 0 ? acc[v] : mb[(q > 0 && q < MAXR) ? q - 1 : 0][v]);
+            if (g == 0 && (EXACT || li + v * LPR < d4)) {
+              const int64_t rq = (int64_t)row + q;
+              if (self_coef != 0.0f)
+                o = f4_fma(self_coef, *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xs + rq * ldx) + lo[v]), o);
+              if (bias) o = f4_add(o, *reinterpret_cast<const float4*>(bb + lo[v]));
+              *reinterpret_cast<float4*>(reinterpret_cast<char*>(y + rq * ldy) + lo[v]) = o;
+            }
           }
         }
       }
@@ -391,7 +410,7 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
   }
 }
 
-template <int LPR, int VPL, int U, bool EXACT, bool ADDR32>
+template <int LPR, int VPL, int U, bool EXACT, bool ADDR32, bool NOVAL = false>
 __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restrict__ items, int32_t n_items,
                                                            const int32_t* __restrict__ xcd_bounds,
                                                            const int32_t* __restrict__ col,
@@ -401,8 +420,8 @@ __global__ __launch_bounds__(256) void spmm_persist_kernel(const int4* __restric
                                                            const float* __restrict__ bias, float self_coef,
                                                            const float* __restrict__ xs,
                                                            float* __restrict__ scratch, int32_t d4, int32_t nnz) {
-  spmm_persist_body<LPR, VPL, U, EXACT, ADDR32>(items, n_items, xcd_bounds, col, val, x, ldx, y, ldy, bias, self_coef, xs,
-                                                scratch, d4, nnz);
+  spmm_persist_body<LPR, VPL, U, EXACT, ADDR32, false, NOVAL>(items, n_items, xcd_bounds, col, val, x, ldx, y, ldy, bias, self_coef, xs,
+                                                              scratch, d4, nnz);
 }
 
 // spmm_persist_body with edge values read through a permutation (AUX above): the source-major aggregation of GATConv's backward
@@ -593,6 +612,22 @@ static int launch_persist(const int32_t* items, int32_t n_items, const int32_t* 
       else GD_ITEMS_LAUNCH(LPR, VPL, false, false);                                                                \
     }                                                                                                              \
   } while (0)
+  // LAB (round 6): the 64-float launch in other shapes, chosen per call by GD_SPMM_D64_FORM
+  //   8x2u2 / 8x2u4 : eight lanes x two float4 per row (eight neighbours per trip), 2 / 4 trips in flight
+  //   + "n" suffix  : the unweighted instantiation when val == NULL (no weight stream, no second crossbar read per trip)
+  if (d4 == 16 && addr32) {
+    const char* form = getenv("GD_SPMM_D64_FORM");
+    if (form && *form) {
+      const bool nv = val == nullptr && strchr(form, 'n') != nullptr;
+#define GD_LAB_LAUNCH(LPR, VPL, UU, NV)                                                                             \
+  hipLaunchKernelGGL((spmm_persist_kernel<LPR, VPL, UU, true, true, NV>), grid, block, 0, s, it, n_items, xcd_bounds, col, val, x, \
+                     ldx, y, ldy, bias, self_coef, xs, scratch, d4, nnz)
+      if (!strncmp(form, "8x2u2", 5)) { if (nv) GD_LAB_LAUNCH(8, 2, 2, true); else GD_LAB_LAUNCH(8, 2, 2, false); return launched("spmm_persist"); }
+      if (!strncmp(form, "8x2u4", 5)) { if (nv) GD_LAB_LAUNCH(8, 2, 4, true); else GD_LAB_LAUNCH(8, 2, 4, false); return launched("spmm_persist"); }
+      if (!strncmp(form, "16x1", 4) && nv) { GD_LAB_LAUNCH(16, 1, 4, true); return launched("spmm_persist"); }
+#undef GD_LAB_LAUNCH
+    }
+  }
   if (d4 <= 1) GD_ITEMS_CASE(1, 1);
   else if (d4 <= 2) GD_ITEMS_CASE(2, 1);
   else if (d4 <= 4) GD_ITEMS_CASE(4, 1);

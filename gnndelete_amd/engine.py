@@ -48,16 +48,18 @@ class _LayerTerms:
     (folded once in fp64).  If some row carries both kinds (never the case for the reference's
     masks, where NI rows exclude the Df endpoints) the general segmented kernel is used instead."""
 
-    def __init__(self, pos_edge, neg_edge, ni_mask, z_ori, coef_r, coef_l, reduction, row_range=None):
+    def __init__(self, pos_edge, neg_edge, ni_mask, z_ori, coef_r, coef_l, reduction, row_range=None, d_norm=None):
         """row_range=(lo, hi): keep only the terms whose z row lies in [lo, hi) (1-D row
-        partition); the mean normalisers stay the GLOBAL term counts."""
+        partition); the mean normalisers stay the GLOBAL term counts.  d_norm: the width the 'mean' reduction divides
+        by when z_ori carries zero padding columns behind it (NodeembEngine's padded class dimension)."""
         device = z_ori.device
         d = z_ori.shape[1]
+        dn = d if d_norm is None else int(d_norm)
         pos, neg = pos_edge.to(device).long(), neg_edge.to(device).long()
         ni_rows = ni_mask.to(device).nonzero().flatten()
         m = pos.shape[1]
-        self.n_r = (2 * m * d) if reduction == 'mean' else 1
-        self.n_l = (ni_rows.numel() * d) if reduction == 'mean' else 1
+        self.n_r = (2 * m * dn) if reduction == 'mean' else 1
+        self.n_l = (ni_rows.numel() * dn) if reduction == 'mean' else 1
         self.count_r, self.count_l = 2 * m, int(ni_rows.numel())
         w_r, w_l = coef_r / max(self.n_r, 1), coef_l / max(self.n_l, 1)
         rows = torch.cat([pos[0], pos[1], ni_rows])
@@ -217,6 +219,54 @@ def _loss_slots(terms, idx, n_sel, device):
     return slot, torch.where(terms.kind == 1, -terms.cnt, terms.cnt).contiguous()
 
 
+def _padded_out_shadow(model, o_pad):
+    """The model with layer 2 widened to o_pad output columns by ZERO columns (conv2's weights, bias and attention vectors, W_D2):
+    a node-classification request has out_dim = #classes (4 on the DBLP / collab stand-ins, delete_node.py:63-64), a width none of
+    the matrix-core / weight-stationary / fused forms is built for.  The padding columns of every layer-2 quantity are exactly zero
+    in every iteration - t2 = relu(z1) W2^T has zero columns where W2 has zero rows, the aggregation and the bias keep them zero,
+    W_D2's padding rows / columns start at zero and their gradient p2^T dz2 is zero (p2 = 0 there, dz2 = coef (z2 - 0) = 0), and
+    Adam on an all-zero gradient history moves nothing - so the top-left block follows the unpadded trajectory with the same
+    products added in the same order plus exact zeros.  conv1 / deletion1 are the caller's own modules."""
+    from types import SimpleNamespace
+    import torch.nn as nn
+    c2 = model.conv2
+    wd2 = model.deletion2.deletion_weight
+    o = wd2.shape[0]
+    dev = wd2.device
+
+    def rows(w):                                   # [o, in] -> [o_pad, in]
+        out = torch.zeros(o_pad, *w.shape[1:], dtype=w.dtype, device=w.device)
+        out[:o] = w.detach()
+        return nn.Parameter(out, requires_grad=False)
+
+    def last(v):                                   # [..., o] -> [..., o_pad]
+        out = torch.zeros(*v.shape[:-1], o_pad, dtype=v.dtype, device=v.device)
+        out[..., :o] = v.detach()
+        return nn.Parameter(out, requires_grad=False)
+    if isinstance(c2, GCNConv):
+        s2 = GCNConv(c2.in_channels, o_pad)
+        s2.lin.weight, s2.bias = rows(c2.lin.weight), last(c2.bias)
+    elif isinstance(c2, GATConv):
+        s2 = GATConv(c2.in_channels, o_pad, c2.negative_slope)
+        s2.lin_src.weight, s2.bias = rows(c2.lin_src.weight), last(c2.bias)
+        s2.att_src, s2.att_dst = last(c2.att_src), last(c2.att_dst)
+    elif isinstance(c2, GINConv):
+        lin = nn.Linear(c2.nn.in_features, o_pad, bias=c2.nn.bias is not None)
+        lin.weight = rows(c2.nn.weight)
+        if c2.nn.bias is not None:
+            lin.bias = last(c2.nn.bias)
+        s2 = GINConv(lin, c2.eps)
+    elif isinstance(c2, SAGEConv):
+        s2 = SAGEConv(c2.in_channels, o_pad)
+        s2.lin_l.weight, s2.lin_l.bias, s2.lin_r.weight = rows(c2.lin_l.weight), last(c2.lin_l.bias), rows(c2.lin_r.weight)
+    else:
+        raise NotImplementedError(type(c2).__name__)
+    w = torch.zeros(o_pad, o_pad, dtype=wd2.dtype, device=dev)
+    w[:o, :o] = wd2.detach()
+    del2 = SimpleNamespace(deletion_weight=nn.Parameter(w, requires_grad=False), mask=model.deletion2.mask)
+    return SimpleNamespace(conv1=model.conv1, conv2=s2.to(dev), deletion1=model.deletion1, deletion2=del2)
+
+
 class NodeembEngine:
     """One object per unlearning request (fixed graph, fixed Df, fixed negatives)."""
 
@@ -250,6 +300,18 @@ class NodeembEngine:
         dev = x.device
         if dev.type != 'cuda':
             raise _lib.GnnDeleteHipError('NodeembEngine needs CUDA(HIP) tensors (no CPU fallback)')
+        # (round 6) A class dimension below 32 (node classification: out_dim = #classes) is padded with zero columns to the
+        # width the fused layer-2 forms are built for (GD_PAD_OUT = 32 | 64, 0 = off): same trajectory (see _padded_out_shadow),
+        # W_D2's top-left block is copied back into the caller's parameter at the end of every iteration.
+        self._o_true = int(model.deletion2.deletion_weight.shape[0])
+        self._user_wd2 = None
+        pad_to = int(os.environ.get('GD_PAD_OUT', '64'))
+        if (not isinstance(conv2, RGCNConv) and self._o_true < 32 and pad_to in (32, 64)
+                and model.deletion1.deletion_weight.shape[0] == 128):
+            self._user_wd2 = model.deletion2.deletion_weight
+            model = _padded_out_shadow(model, pad_to)
+            conv2 = model.conv2
+            z2_ori = torch.nn.functional.pad(z2_ori.float(), (0, pad_to - self._o_true))
         self.model, self.loss_type, self.alpha = model, loss_type, alpha
         self.n = n = x.shape[0]
         none = torch.zeros(n, dtype=torch.bool)           # a model built without masks: Del = identity
@@ -279,7 +341,7 @@ class NodeembEngine:
         self.z1_ori, self.z2_ori = ops._f32_rows(z1_ori), ops._f32_rows(z2_ori)
         coef_r, coef_l = _loss_coefficients(loss_type, alpha)
         self.t1 = _LayerTerms(pos_edge, neg_edge, ni_mask1, self.z1_ori, coef_r, coef_l, reduction)
-        self.t2 = _LayerTerms(pos_edge, neg_edge, ni_mask2, self.z2_ori, coef_r, coef_l, reduction)
+        self.t2 = _LayerTerms(pos_edge, neg_edge, ni_mask2, self.z2_ori, coef_r, coef_l, reduction, d_norm=self._o_true)
         self.uses_l1 = loss_type in ('both_all', 'both_layerwise', 'only1')
         self.uses_l2 = loss_type != 'only1'
         # does a gradient of loss-2 w.r.t. W_D1 (through conv2) ever reach an optimizer step?
@@ -487,6 +549,10 @@ class NodeembEngine:
                     self.pre1.zero_()
                 self.p2.zero_()
                 self._rows_only = True
+        if self._rows_only and self._chain1 and self._dt2_keep is not None:
+            # (round 6) the rows-only step is chained as well: its transposed aggregation writes the S1 rows of the buffer the next
+            # iteration's Del-1 pass reads (all it reads); before, `_chain1` stayed set while the step ran the unchained form
+            self._dt2buf = self._dt2_keep
         self.cache_layer1 = cache_layer1
         if cache_layer1:
             with torch.no_grad():
@@ -632,7 +698,8 @@ class NodeembEngine:
             self._spmm(False, self.graph.val, t2[:, :self.o], self.p2, c.lin_l.bias, 1.0, x_self=t2[:, self.o:])
         else:   # gat
             wsrc = c.lin_src.weight
-            if self._gat_dots and self._split1 and ops.rows_gemm_dots_ok(wsrc.shape[1], wsrc.shape[0], self.n, selected=self._rows_only):
+            if self._gat_dots and self._split1 and ops.rows_gemm_dots_ok(wsrc.shape[1], wsrc.shape[0], self.s2 if self._rows_only else self.n,
+                                                                        selected=self._rows_only):
                 ro = self._rows_only
                 h2, self._a_src, self._a_dst = ops.rows_gemm_dots(
                     self.pre1, wsrc, c.att_src, c.att_dst, inp_alt=self.z1, sel=self._sel1, relu_in=True, const_w=True,
@@ -667,7 +734,7 @@ class NodeembEngine:
                        plan=self._plan_t1 if self._rows_only else None)
             dt2, w2 = self.dcat, self._w2cat
         elif self._mode in ('gcn', 'gin'):
-            chain = self._chain1 and not self._rows_only
+            chain = self._chain1
             dt2 = self._dt2_keep if chain else torch.empty(self.n, self.o, dtype=torch.float32, device=self.x.device)
             if self._mode == 'gcn' and self._rows_only:
                 dt2 = self._dt2buf
@@ -686,7 +753,7 @@ class NodeembEngine:
             if chain:
                 return                    # (the NEXT iteration's Del-1 pass forms dh[S1] = (dt2[S1] W2) * [z1[S1] > 0] itself)
         else:
-            chain = self._chain1 and not self._rows_only
+            chain = self._chain1
             dt2, da_s, da_d = ops.gat_backward_raw(g, self._h2, self._a_src, self._a_dst, self._rowmax, self._rowsum,
                                                    self.dz2, c.negative_slope,
                                                    plan=self._plan2 if self._rows_only else None,
@@ -890,13 +957,15 @@ class NodeembEngine:
                 torch.cuda.current_stream().wait_stream(self._side)       # join: the iteration ends when both branches have
             else:
                 finalize()
+            if self._user_wd2 is not None:          # padded class dimension: the caller's W_D2 is the top-left block
+                self._user_wd2.data.copy_(self.wd2.data[:self._o_true, :self._o_true])
 
     def _del1_fused(self, g_add):
         """Del-1 forward (+ sign bits) + folded layer-1 loss + the W_D1 weight gradient's partial sums in one kernel
         (csrc/del_fused.hip, del1_loss_wgrad_ws_kernel); the tail launch reduces them and steps Adam."""
         self.adam1.applied += 1
         self._tail_acc[0] = 0
-        if self._chain1 and not self._rows_only:
+        if self._chain1:
             c2 = self.model.conv2
             if self._mode == 'gat':
                 w_next, dt = c2.lin_src.weight.detach(), self._gat_bufs['dh']
@@ -1011,6 +1080,8 @@ class NodeembEngine:
                                       [self._gat_bufs[k] for k in ('dh', 'da_src', 'da_dst')])
         if getattr(self, '_arrive', None) is not None:      # step_tail's check-in counter: a launch that did not finish must not
             state.append(self._arrive)                       # leave it non-zero for the replays
+        if getattr(self, '_user_wd2', None) is not None:    # the caller's W_D2 behind a padded class dimension
+            state.append(self._user_wd2.data)
         return state
 
     def _capture(self):

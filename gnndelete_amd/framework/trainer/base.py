@@ -25,6 +25,13 @@ from ._log import fmt, wandb_log
 device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
 
 
+def _all_pairs(z):
+    """z z^T on the host, as Trainer.eval(pred_all=True) hands it to test() / save_log (framework/trainer/base.py:288 upstream);
+    the product runs on the HIP dense kernels (ops.gram), not on torch's matmul."""
+    from ... import ops
+    return ops.gram(z.detach()).cpu()
+
+
 def _require_gpu():
     if not torch.cuda.is_available():
         from ... import _lib
@@ -208,7 +215,7 @@ class Trainer:
         else:
             df_auc = df_aup = np.nan
 
-        logit_all_pair = (z @ z.t()).cpu() if pred_all else None
+        logit_all_pair = _all_pairs(z) if pred_all else None
         log = {
             f'{stage}_loss': loss,
             f'{stage}_dt_auc': dt_auc,

@@ -61,13 +61,18 @@ def CosineDistanceSum(logits, truth):
 
 
 def centering(K):
-    n = K.shape[0]
-    H = torch.eye(n, device=K.device, dtype=K.dtype) - 1.0 / n
-    return H @ K @ H
+    """H K H with H = I - 11^T / n (gnndelete_nodeemb.py:30-35), written out: K minus its row means and column means plus
+    its total mean - the same matrix without two n x n x n products."""
+    return K - K.mean(0, keepdim=True) - K.mean(1, keepdim=True) + K.mean()
+
+
+def _gram(X):
+    from ... import ops
+    return ops.gram(X)
 
 
 def rbf(X, sigma=None):
-    gram = X @ X.T
+    gram = _gram(X)
     sq = torch.diag(gram) - gram
     dist = sq + sq.T
     if sigma is None:
@@ -76,7 +81,7 @@ def rbf(X, sigma=None):
 
 
 def linear_HSIC(X, Y):
-    return torch.sum(centering(X @ X.T) * centering(Y @ Y.T))
+    return torch.sum(centering(_gram(X)) * centering(_gram(Y)))
 
 
 def kernel_HSIC(X, Y, sigma=None):
@@ -179,8 +184,10 @@ def _export_adam_state(engine, model, optimizer):
                          (opts[1], engine.adam2, model.deletion2.deletion_weight)]:
         steps = adam.applied if adam.iter_ctr is not None else int(adam.step)
         if steps:
-            opt.state[p] = {'step': torch.tensor(float(steps)), 'exp_avg': adam.m.clone(),
-                            'exp_avg_sq': adam.v.clone()}
+            # (the engine's W_D2 may carry zero padding behind the parameter's own block - NodeembEngine's padded class dimension)
+            r, c = p.shape
+            opt.state[p] = {'step': torch.tensor(float(steps)), 'exp_avg': adam.m[:r, :c].clone(),
+                            'exp_avg_sq': adam.v[:r, :c].clone()}
 
 
 class _EmbeddingUnlearner:

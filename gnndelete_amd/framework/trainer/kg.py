@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from ..evaluation import verification_error
 from ..metrics import batched_average_precision, batched_roc_auc
 from ..utils import get_link_labels, negative_sampling_kg
-from .base import Trainer, _require_gpu, device
+from .base import Trainer, _all_pairs, _require_gpu, device
 from .gnndelete_nodeemb import _four_terms, _non_df_masks, get_loss_fct
 from . import sampler as _sampler
 from ._log import wandb_log
@@ -105,7 +105,7 @@ class KGTrainer(Trainer):
             df_aup = float(batched_average_precision(scores, labels).mean())
         else:
             df_auc = df_aup = np.nan
-        logit_all_pair = (z @ z.t()).cpu() if pred_all else None
+        logit_all_pair = _all_pairs(z) if pred_all else None
         log = {f'{stage}_loss': loss, f'{stage}_dt_auc': dt_auc, f'{stage}_dt_aup': dt_aup, f'{stage}_df_auc': df_auc,
                f'{stage}_df_aup': df_aup,
                f'{stage}_df_logit_mean': np.mean(df_logit) if len(df_logit) > 0 else np.nan,

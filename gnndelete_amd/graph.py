@@ -217,6 +217,8 @@ class SplitPlan:
                 total += tail
             bounds.append(total)
         items = torch.cat(parts, 0).to(torch.int32).contiguous()
+        # the kernels' barrier invariant (include/gnndelete_hip.h): limits and group starts at multiples of 4
+        assert all(b % 4 == 0 for b in bounds) and total % 4 == 0, bounds
         hit = (items, total, torch.tensor(bounds, dtype=torch.int32, device=dev))
         self._onepass[key] = hit
         self.n_multirow_items = n_multi

@@ -231,9 +231,9 @@ def rows_gemm_dots_ok(d_in, d_out, n_rows=0, selected=False):
     """Whether fusing the row dots into the GEMM epilogue pays (the engine's choice; the entry itself takes 128 too).
     n_rows / selected (rows from two buffers AND an index list): what decides whether the weight-stationary kernel takes the
     call - it carries the dots at 128 outputs as well (csrc/rows_gemm_ws.hip, MODE 3)."""
-    if (d_in == 128 and d_out in (64, 128) and not selected and os.environ.get('GD_ROWS_GEMM_WS_EPI', '1') != '0'
+    if (d_in == 128 and d_out in (64, 128) and os.environ.get('GD_ROWS_GEMM_WS_EPI', '1') != '0'
             and _lib.lib().gd_rows_gemm_ws_covers(int(n_rows), d_in, d_out)):
-        return True
+        return True                       # (round 6: also with a selector AND an index list - n_rows = the listed rows)
     # d_out <= 64: the 128-wide variant of the LDS-operand kernel runs out of registers (spills: measured 7 % slower than
     # the separate pass)
     return d_in % 32 == 0 and d_out % 32 == 0 and d_out <= 64 and d_in * d_out * 4 <= 64 * 1024
@@ -334,7 +334,10 @@ class _Dense(torch.autograd.Function):
     (framework/models/gcn.py:11-12 ...): every product on the HIP matrix-core kernels where the widths allow -
     forward (whole weight in LDS for in <= 128, K-tiled for wider inputs), input gradient, weight gradient (row
     reduction kernel; for a wide input the K-tiled kernel on a cached x^T); odd widths run the generic kernels, and a shape
-    without a kernel raises - no torch matmul anywhere."""
+    without a kernel raises - this op never falls back to torch's matmul.  (What of the package still calls torch / rocBLAS
+    products is listed in DESIGN.md section 4: two [1, 64] x [64, 128] constants folded at engine set-up, and RGCNConv / RGATConv's
+    einsum over relation weights whose block widths the typed kernels do not take - odd or above 128 - none of them on a
+    BASELINE configuration.)"""
 
     @staticmethod
     def forward(ctx, x, weight, bias, const_x):
@@ -420,6 +423,18 @@ def dense(x, weight, bias=None, const_x=False):
     """torch.nn.functional.linear on the HIP kernels (see _Dense); const_x: x is the same matrix on every call (the
     node features) - padded / transposed copies of it are cached."""
     return _Dense.apply(x, weight, bias, const_x)
+
+
+def gram(x, y=None):
+    """x @ y^T (y = x unless given) for device tensors, 128 output columns per product on the kernels of `dense` (matrix-core
+    forms where the widths allow, the generic row kernel otherwise; autograd through both operands): the Gram matrices of the
+    CKA losses (framework/trainer/gnndelete_nodeemb.py:30-66) and the all-pairs logits z z^T of Trainer.test (base.py:288) -
+    the last two products of the path that went through torch's matmul (rocBLAS).  Host tensors (the CPU-side loss-zoo checks)
+    take the torch expression."""
+    y = x if y is None else y
+    if not x.is_cuda:
+        return x @ y.t()
+    return torch.cat([dense(x, y[j:j + 128].contiguous()) for j in range(0, y.shape[0], 128)], 1)
 
 
 def rows_gemm_wgrad(a, a_idx, g, g_idx, n_sel, relu_mask=None, out=None, accumulate=False, g_add=None):

@@ -144,6 +144,12 @@ int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, const int32_
  *                            A row's sum is associated by edge position in the ITEM: equal to fp32 rounding to its one-row form.
  *   xcd_bounds (required, 9 ascending item indices, all multiples of 4, [0] = 0, [8] = n_items): the item range each of
  *   the 8 XCDs sweeps.  Groups may sit anywhere in a range (the planner puts a range's hub rows first, heaviest first).
+ *   INVARIANT (the caller's, SplitPlan.onepass keeps it by construction): every limit is a multiple of 4 and every group starts at
+ *   a multiple of 4 - the four waves of a block then always hold one aligned quadruple of items, which is what makes the group
+ *   path's block barriers uniform.  The table lives in device memory, so the entry cannot check it without a synchronisation;
+ *   the KERNEL aborts the launch (trap -> hipErrorLaunchFailure at the next synchronisation) when a limit of its range is not a
+ *   multiple of 4 instead of deadlocking.  The same holds for gd_spmm_csr_onepass_aux_f32 and the one-launch form of
+ *   gd_gat_edge_grads_balanced_f32.
  * The sum of a hub row is associated differently from the balanced form's (piece partials in slot order), so the two
  * entries agree to fp32 rounding, not bit for bit; each is bit-reproducible run to run. */
 int gd_spmm_csr_onepass_f32(const int32_t* items, int32_t n_items, const int32_t* col, const float* val,

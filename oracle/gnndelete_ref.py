@@ -174,6 +174,24 @@ def linear_cka(x, y):
     return _linear_hsic(x, y) / (torch.sqrt(_linear_hsic(x, x)) * torch.sqrt(_linear_hsic(y, y)))
 
 
+def _rbf(x, sigma):
+    """gnndelete_nodeemb.py:38-47 with the sigma given (the default-sigma branch calls `math.sqrt` in a module that never
+    imports math: NameError upstream)."""
+    g = x @ x.T
+    k = torch.diag(g) - g
+    k = k + k.T
+    return torch.exp(k * (-0.5 / (sigma * sigma)))
+
+
+def _kernel_hsic(x, y, sigma):
+    return (_center(_rbf(x, sigma)) * _center(_rbf(y, sigma))).sum()
+
+
+def rbf_cka(x, y, sigma):
+    """gnndelete_nodeemb.py:49-50,62-66 (RBFCKA)."""
+    return _kernel_hsic(x, y, sigma) / (torch.sqrt(_kernel_hsic(x, x, sigma)) * torch.sqrt(_kernel_hsic(y, y, sigma)))
+
+
 LOSSES = {
     'mse_mean': nn.MSELoss(reduction='mean'),
     'mse_sum': nn.MSELoss(reduction='sum'),
@@ -182,6 +200,7 @@ LOSSES = {
     'cosine_mean': _cosine('mean'),
     'cosine_sum': _cosine('sum'),
     'linear_cka': linear_cka,
+    'rbf_cka': rbf_cka,                      # (x, y, sigma)
 }
 
 

@@ -213,8 +213,8 @@ def gpu_checks(rank, world, rccl=False, direct=False):
     cases = [(GCNDelete, 'both_layerwise'), (GINDelete, 'both_all'), (GCNDelete, 'only2_all'), (SAGEDelete, 'both_layerwise'),
              (SAGEDelete, 'both_all'), (GCNDelete, 'only1'), (GINDelete, 'only2_layerwise'), (GATDelete, 'both_layerwise'),
              (GATDelete, 'both_all')]
-    if world > 2:             # three ranks time-share the box's one GPU (10 x the two-rank run): one case per backbone
-        cases = [(GCNDelete, 'both_layerwise'), (SAGEDelete, 'both_all'), (GINDelete, 'only2_layerwise'), (GATDelete, 'both_layerwise')]
+    if world > 2:             # three ranks time-share the box's one GPU (10 x the two-rank run): ONE backbone, synchronous and
+        cases = [(GCNDelete, 'both_layerwise')]        # overlapped (two ranks run every backbone and loss type)
     group = None
     if rccl:                  # a world of one over RCCL: the data-path communicator the GPU node uses
         cases = [(GCNDelete, 'both_layerwise'), (SAGEDelete, 'both_all'), (GATDelete, 'both_layerwise')]
@@ -308,6 +308,81 @@ def rgcn_checks(rank, world):
             print(f'RGCNDelete {lt}: partitioned == single (rel err {err:.2e})', flush=True)
 
 
+def rgcn_cpu_checks(rank, world):
+    """The TYPED row partition at any world size, on CPU (the R-GCN partition had only ever seen two
+    ranks).  Everything PartitionedNodeembEngine builds for mode 'rgcn' - this rank's TypedNodeCSR(row_range) (in-edges of the
+    own target rows forward, out-edges of the own source rows with the GLOBAL mean weights backward) and the two halo lists
+    derived from the untyped union graph - drives a dense emulation of conv2's forward on the own target rows and of its input
+    gradient on the own source rows, reading ONLY own + received rows (everything else is NaN); both against the oracle's
+    RGCNConv with autograd on the whole graph.  The ranks' typed edge sets must tile the global ones exactly."""
+    from gnndelete_amd.collectives import all_reduce_sum, exchange_rows, halo_plan, row_blocks
+    from gnndelete_amd.graph import TypedNodeCSR, build_csr
+    from oracle import pyg_semantics as pyg
+    torch.manual_seed(5)
+    n, r, e, d_in, d_out, nb = 331, 10, 2600, 16, 8, 2          # (n not a multiple of 8: the last rank's block is short)
+    src, dst = torch.randint(0, n, (e,)), torch.randint(0, n, (e,))
+    keep = src != dst
+    ei = torch.unique(torch.stack([src[keep], dst[keep], torch.randint(0, r, (int(keep.sum()),))]), dim=1)
+    ei, et = ei[:2].contiguous(), ei[2].contiguous()
+    x = torch.randn(n, d_in, dtype=torch.float64, requires_grad=True)
+    weight = torch.randn(r, nb, d_in // nb, d_out // nb, dtype=torch.float64) * 0.3
+    root, bias = torch.randn(d_in, d_out, dtype=torch.float64) * 0.3, torch.randn(d_out, dtype=torch.float64)
+    want = pyg.rgcn_conv(x, ei, et, weight, root, bias, num_blocks=nb)
+    dy = torch.randn(n, d_out, dtype=torch.float64)
+    want_dx, = torch.autograd.grad(want, x, dy)
+    chunk, _ = row_blocks(n, world)
+    lo, hi = min(n, rank * chunk), min(n, (rank + 1) * chunk)
+    whole = TypedNodeCSR(ei, et, n, r)
+    mine = TypedNodeCSR(ei, et, n, r, row_range=(lo, hi))
+    # ---- tiling: this rank's forward / backward edges are exactly the whole graph's edges into / out of its rows
+    cnt = torch.tensor([mine.fwd[3].numel(), mine.bwd[3].numel()], dtype=torch.float32)
+    all_reduce_sum(cnt, world)
+    assert cnt.tolist() == [whole.fwd[3].numel(), whole.bwd[3].numel()], cnt
+    g = build_csr(ei, n, 'sum')                                   # the untyped union graph: structure of the halo lists
+    halo_f = halo_plan(g.rowptr, g.col, n, rank, world, chunk)
+    halo_b = halo_plan(g.rowptr_t, g.col_t, n, rank, world, chunk)
+    wblk = torch.zeros(r, d_in, d_out, dtype=torch.float64)        # block-diagonal relation weights, dense
+    bi, bo = d_in // nb, d_out // nb
+    for b in range(nb):
+        wblk[:, b * bi:(b + 1) * bi, b * bo:(b + 1) * bo] = weight[:, b]
+
+    def runs(side):
+        node_ptr, seg_ptr, seg_rel, col, w = side
+        seg_len = (seg_ptr[1:] - seg_ptr[:-1]).long()
+        node_of_run = torch.repeat_interleave(torch.arange(n), (node_ptr[1:] - node_ptr[:-1]).long())
+        return (torch.repeat_interleave(node_of_run, seg_len), torch.repeat_interleave(seg_rel.long(), seg_len), col.long(), w.double())
+
+    def exchange(buf, plan):
+        send = buf.index_select(0, plan.send_rows).float()
+        assert not torch.isnan(send).any()
+        recv = torch.empty(max(1, plan.n_recv), buf.shape[1])
+        exchange_rows(send, recv, plan, world)
+        return recv[:plan.n_recv].double()
+    # ---- forward on the own target rows: gathers own + received source rows
+    xd = x.detach()
+    xin = torch.full((n, d_in), float('nan'), dtype=torch.float64)
+    xin[lo:hi] = xd[lo:hi]
+    xin.index_copy_(0, halo_f.recv_rows, exchange(xin, halo_f))
+    tgt, rel, col, w = runs(mine.fwd)
+    assert bool(((tgt >= lo) & (tgt < hi)).all())
+    msg = torch.einsum('ei,eio->eo', xin[col] * w[:, None], wblk[rel])
+    out = (xd[lo:hi] @ root + bias).index_add_(0, tgt - lo, msg)
+    assert not torch.isnan(out).any()
+    assert torch.allclose(out.float(), want.detach()[lo:hi].float(), rtol=2e-5, atol=2e-6), float((out - want.detach()[lo:hi]).abs().max())
+    # ---- input gradient on the own source rows: gathers own + received rows of dy (transposed graph, global mean weights)
+    dyin = torch.full((n, d_out), float('nan'), dtype=torch.float64)
+    dyin[lo:hi] = dy[lo:hi]
+    dyin.index_copy_(0, halo_b.recv_rows, exchange(dyin, halo_b))
+    s_node, rel, col, w = runs(mine.bwd)                          # node = the SOURCE row, col = the target whose dy is gathered
+    assert bool(((s_node >= lo) & (s_node < hi)).all())
+    gmsg = torch.einsum('eo,eio->ei', dyin[col] * w[:, None], wblk[rel])
+    dx = (dy[lo:hi] @ root.t()).index_add_(0, s_node - lo, gmsg)
+    assert not torch.isnan(dx).any()
+    assert torch.allclose(dx.float(), want_dx[lo:hi].float(), rtol=2e-5, atol=2e-6), float((dx - want_dx[lo:hi]).abs().max())
+    if rank == 0:
+        print(f'typed partition x{world}: forward and input gradient of the own rows == whole-graph oracle', flush=True)
+
+
 def main():
     mode = sys.argv[1]
     dist.init_process_group('gloo')
@@ -318,6 +393,8 @@ def main():
             gpu_checks(rank, world, rccl=True, direct=mode == 'direct1')
         elif mode == 'rgcn':
             rgcn_checks(rank, world)
+        elif mode == 'rgcn_cpu':
+            rgcn_cpu_checks(rank, world)
         else:
             (cpu_checks if mode == 'cpu' else gpu_checks)(rank, world)
         dist.barrier()

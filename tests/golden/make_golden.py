@@ -350,6 +350,12 @@ def golden_losses(T):
         v.backward()
         out[f'{name}::value'] = np_(v)
         out[f'{name}::grad'] = np_(a.grad)
+    # rbf_cka: upstream's default sigma path needs `math`, which the module never imports (NameError) - the
+    # explicit-sigma call is the one that can run
+    a = a0.clone().requires_grad_(True)
+    v = T.get_loss_fct('rbf_cka')(a, b0, sigma=2.0)
+    v.backward()
+    out['rbf_cka_sigma2::value'], out['rbf_cka_sigma2::grad'] = np_(v), np_(a.grad)
     np.savez_compressed(os.path.join(HERE, 'losses.npz'), **out)
 
 
@@ -1362,6 +1368,10 @@ def main():
         return
     if sys.argv[1:] == ['orig_minibatch']:
         golden_original_minibatch(B, A)
+        write_manifest(None)
+        return
+    if sys.argv[1:] == ['losses']:              # round 6 (+ rbf_cka with an explicit sigma)
+        golden_losses(T)
         write_manifest(None)
         return
     if sys.argv[1:] == ['edgeprob_minibatch']:  # round 4

@@ -73,6 +73,30 @@ def test_bench_launches_its_own_ranks_and_auto_keeps_the_partitioned_headline():
     assert 'row-partition' in d['config']['parallelism'] and est['chosen'] == 'partition'
     assert est['predicted_partitioned_step_us'] > 0 and est['single_gpu_step_us'] > 0 and 0 < est['layer1_share_of_step'] < 1
     assert d['extras']['iters_per_s_independent_replicas'] > 0
+    # (round 6) ... and the planner's model of the WHOLE curve from this one run: halo bytes and predicted step at N = 2 / 4 / 8
+    curve = d['config']['planner_curve']['per_world']
+    assert set(curve) == {'2', '4', '8'}, d['config']['planner_curve']
+    for w_, rec in curve.items():
+        assert len(rec['recv_bytes_per_step_every_rank']) == int(w_) and rec['predicted_step_us'] > 0 and rec['pair_bytes_per_step_max'] > 0
+    # its N = 2 halo bytes are the measured engine's own
+    assert curve['2']['recv_bytes_per_step_max_rank'] == max(v[0] for v in d['config']['halo_recv_send_bytes_per_rank'])
+
+
+def test_bench_node_deletion_workload_line():
+    """BASELINE config 5 as a bench line: `--workload synth-small-nodecls --gnn gat` - delete_node.py's request on
+    the node-classification stand-in (out_dim = #classes = 4, padded inside the engine), the JSON contract with roofline,
+    cpu_baseline (the oracle's epoch loop) and HIP-vs-oracle parity after the same iterations."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', 'synth-small-nodecls', '--gnn', 'gat', '--steps', '8',
+                        '--warmup', '2', '--cpu_baseline_iters', '3'], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d['n_gpus'] == 1 and d['unit'] == 'iters/s' and d['dtype'] == 'f32' and d['value'] > 0 and d['vs_baseline'] is None
+    assert 'NODE deletion' in d['config']['workload'] and d['config']['out_dim'] == 4 and d['config']['out_dim_padded_to'] in (32, 64)
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(d['roofline'])
+    assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['value'] > 0 and d['cpu_baseline']['cores'] >= 1
+    assert d['parity']['W_D1_rel_l2'] < 1e-4 and d['parity']['W_D2_rel_l2'] < 1e-4
+    assert d['parity']['z1_affected_rel_l2'] < 1e-4 and d['parity']['z2_affected_rel_l2'] < 1e-4
+    assert d['extras']['iters_per_s_trainer_default'] > 0 and d['extras']['iters_per_s_unpadded_class_dimension'] > 0
 
 
 def test_bench_failing_ranks_give_a_nonzero_exit():

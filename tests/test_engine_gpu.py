@@ -434,6 +434,63 @@ def test_gin_affected_rows_only_matches_oracle_training(cache_layer1):
     assert rel_l2(m.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
 
 
+@pytest.mark.parametrize('gnn,pad,loss_type,opts', [('gcn', '64', 'both_layerwise', {}), ('gat', '64', 'both_layerwise', {}),
+                                                    ('gat', '32', 'both_all', dict(affected_rows_only=True)),
+                                                    ('sage', '64', 'both_layerwise', dict(cache_layer1=True, affected_rows_only=True)),
+                                                    ('gin', '32', 'only2_layerwise', {}), ('gcn', '32', 'only1', dict(cache_layer1=True))])
+def test_padded_class_dimension_reproduces_the_unpadded_trajectory(gnn, pad, loss_type, opts, monkeypatch):
+    """A node-classification request has out_dim = #classes = 4 (delete_node.py:63-64): the engine pads layer 2 with zero
+    columns to the width its matrix-core / fused forms are built for (engine._padded_out_shadow; GD_PAD_OUT = 32 | 64).  Same
+    trajectory as the unpadded engine (GD_PAD_OUT=0: generic-width kernels) and as autograd on the CPU oracle with the
+    reference's update rules, 'mean' normalisers of the TRUE width; the caller's W_D2 keeps its 4 x 4 shape and is current
+    after every step; the padding block of the engine's W_D2 stays exactly zero."""
+    from gnndelete_amd.engine import NodeembEngine
+    from oracle import gnndelete_ref as R
+    fx = load_golden('traj_gcn_both_all.npz')
+    _, data, rest = split_fixture(fx)
+    n = data['x'].shape[0]
+    torch.manual_seed(21)
+    data = dict(data, x=torch.randn(n, 32) * 0.3)
+    mo = R.TwoLayerDelete(gnn, 32, 128, 4, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+    with torch.no_grad():      # (Del weights away from the ones/1000 start: the layer-2 products should matter)
+        mo.deletion1.deletion_weight.copy_(torch.eye(128) * 0.6 + 0.02 * torch.randn(128, 128))
+        mo.deletion2.deletion_weight.copy_(torch.eye(4) * 0.7 + 0.05 * torch.randn(4, 4))
+    state = {k: v.clone() for k, v in mo.state_dict().items()}
+    steps = 6
+    logs, _ = R.nodeemb_fullbatch(mo, data, steps, loss_type, 0.4, 'mse_mean', 0.01, neg_edge=t(rest['neg']))
+    dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    E = dev['train_pos_edge_index']
+    ni1, ni2 = R.non_df_masks(n, data['directed_df_edge_index'], data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+
+    def run(pad_env):
+        monkeypatch.setenv('GD_PAD_OUT', pad_env)
+        m = hip_model(gnn, state, data['sdf_node_1hop_mask'], data['sdf_node_2hop_mask'])
+        with torch.no_grad():
+            z1o, z2o = m.get_original_embeddings(dev['x'], E[:, dev['dr_mask']], return_all_emb=True)
+        eng = NodeembEngine(m, dev['x'], E[:, dev['sdf_mask']].contiguous(), z1o, z2o, E[:, dev['df_mask']], t(rest['neg']).cuda(),
+                            ni1, ni2, loss_type=loss_type, alpha=0.4, lr=0.01, **opts)
+        for _ in range(steps):
+            eng.step()
+        torch.cuda.synchronize()
+        return eng, m
+    eng, m = run(pad)
+    assert eng.o == int(pad) and eng._user_wd2 is not None and tuple(m.deletion2.deletion_weight.shape) == (4, 4)
+    assert eng._fuse_l2, 'the padded width takes the fused layer-2 form'
+    wpad = eng.wd2.detach().clone()
+    assert torch.equal(wpad[:4, :4], m.deletion2.deletion_weight.detach())
+    wpad[:4, :4] = 0
+    assert float(wpad.abs().max()) == 0.0, 'padding rows / columns of W_D2 never move'
+    eng0, m0 = run('0')
+    assert eng0.o == 4 and eng0._user_wd2 is None
+    hist, hist0 = eng.loss_history().numpy(), eng0.loss_history().numpy()
+    for col, key in enumerate(['train_loss', 'loss_r', 'loss_l']):
+        np.testing.assert_allclose(hist[:, col], [l[key] for l in logs], rtol=1e-4, atol=1e-8, err_msg=key)
+        np.testing.assert_allclose(hist[:, col], hist0[:, col], rtol=1e-4, atol=1e-8, err_msg=key)
+    for got in (m, m0):
+        assert rel_l2(got.deletion1.deletion_weight.detach().cpu(), mo.deletion1.deletion_weight.detach()) < 1e-4
+        assert rel_l2(got.deletion2.deletion_weight.detach().cpu(), mo.deletion2.deletion_weight.detach()) < 1e-4
+
+
 @pytest.mark.parametrize('cache_layer1', [False, True])
 def test_sage_affected_rows_only_matches_oracle_training(cache_layer1, loss_type='both_layerwise', use_graph=True):
     """GraphSAGE (BASELINE.json config 3; not in the reference, so the oracle restatement is the

@@ -95,6 +95,22 @@ def test_full_size_training_parity(workload, gnn, df, df_size):
     for i, log in enumerate(logs):
         assert abs(float(hist[i, 0]) - log['train_loss']) <= 1e-4 * abs(log['train_loss']), (i, float(hist[i, 0]), log)
     wts = lambda m_: (m_.deletion1.deletion_weight.detach().double().cpu(), m_.deletion2.deletion_weight.detach().double().cpu())
+    if workload == 'synth-collab':
+        # (round 6) the same iterations restricted to the rows the request can influence - `--affected_rows_only`, now CHAINED like
+        # the full step and with the weight-stationary row GEMMs on (index list + selector) operands: the same sums over the same
+        # affected rows, so the Del weights agree with the full step's far inside the parity bound
+        import copy
+        hip_r = copy.deepcopy(hip)
+        hip_r.load_state_dict(state)
+        eng_r = NodeembEngine(hip_r, data.x.to(dev), e_sdf.to(dev).contiguous(), z1o.to(dev), z2o.to(dev), pos.to(dev), neg.to(dev),
+                              ni1, ni2, loss_type='both_layerwise', alpha=0.5, lr=1e-3, affected_rows_only=True)
+        assert eng_r._rows_only and eng_r.s2 < eng_r.n and eng_r._chain1 == eng._chain1
+        for _ in range(iters):
+            eng_r.step()
+        assert torch.allclose(eng_r.loss_history(), hist, rtol=1e-5, atol=0)
+        for a_, b_ in zip(wts(hip_r), wts(hip)):
+            assert rel_l2(a_, b_) < 2e-5, rel_l2(a_, b_)
+        del eng_r, hip_r
     def run_oracle(dtype, perm):           # one oracle at a time (their autograd tapes at collab size are tens of GB)
         import gc
         step, snap, _ = oracle_runner(gnn, data, state, neg, ni1, ni2, dtype, dev, perm=perm)
@@ -147,18 +163,34 @@ def test_full_size_rgcn_forward_and_del_gradients():
 
     def loss_of(z1, z2, a, b):
         return (z1[a] ** 2).mean() + (z2[b] ** 2).mean()
+    # (inputs of Del-1 and dL/dz1 of both implementations, for the gate-masked comparison of the W_D1 gradient below)
+    kept = {}
+    ref.deletion1.register_forward_hook(lambda mod, inp, out: kept.__setitem__('p_ref', inp[0].detach()))
+    hip.deletion1.register_forward_hook(lambda mod, inp, out: kept.__setitem__('p_hip', inp[0].detach()))
     r1, r2 = ref(data.x, ei, ety, return_all_emb=True)
+    r1.retain_grad()
     loss_of(r1, r2, m1, m2).backward()
     hip = hip.cuda()
     h1, h2 = hip(data.x.cuda(), ei.cuda(), ety.cuda(), return_all_emb=True)
+    h1.retain_grad()
     loss_of(h1, h2, m1.cuda(), m2.cuda()).backward()
     assert rel_l2(h1.detach().cpu()[m1], r1.detach()[m1]) < 1e-4
     assert rel_l2(h2.detach().cpu()[m2], r2.detach()[m2]) < 1e-4
     assert rel_l2(hip.deletion2.deletion_weight.grad.cpu(), ref.deletion2.deletion_weight.grad) < 1e-4
     # W_D1's gradient passes the ReLU between the layers: of the 12 M entries of z1 a handful lie within fp32 rounding
     # of zero, and two correct implementations gate such an entry differently (tools/experiments/diag_rgcn_row.py: ONE
-    # row of dL/dz1 off by its gated term, every other row equal to 3e-9) - hence 1e-3 here
-    assert rel_l2(hip.deletion1.deletion_weight.grad.cpu(), ref.deletion1.deletion_weight.grad) < 1e-3
+    # row of dL/dz1 off by its gated term, every other row equal to 3e-9).  So the comparison is
+    # GATE-MASKED instead of loosened: the rows of z1 whose sign pattern differs between the two
+    # implementations - a handful, counted - are taken out of BOTH gradients (dW_D1 = sum over the Del-1 rows of
+    # p1[i]^T dL/dz1[i]); what is left must agree to the bound every other quantity here is held to.
+    hz, rz = h1.detach().cpu(), r1.detach()
+    flip = ((hz > 0) != (rz > 0)).any(1) & m1
+    n_flip = int(flip.sum())
+    print(f'[synth-biokg rgcn forward] Del-1 rows whose ReLU sign pattern differs between HIP and the CPU oracle: {n_flip} of {int(m1.sum())}')
+    assert n_flip <= 16, n_flip
+    g_hip = hip.deletion1.deletion_weight.grad.double().cpu() - kept['p_hip'].double().cpu()[flip].T @ h1.grad.double().cpu()[flip]
+    g_ref = ref.deletion1.deletion_weight.grad.double() - kept['p_ref'].double()[flip].T @ r1.grad.double()[flip]
+    assert rel_l2(g_hip, g_ref) < 1e-4, rel_l2(g_hip, g_ref)
     # DistMult scores of the validation triples on the unlearned embeddings
     s_hip = hip.decode(h2, data.val_pos_edge_index.cuda(), data.val_edge_type.cuda())
     s_ref = ref.decode(r2, data.val_pos_edge_index, data.val_edge_type)
@@ -231,7 +263,15 @@ def test_full_size_rgcn_fused_engine_matches_oracle():
         d_ens, d_hip = [rel_l2(e[k], r) for e in ens], rel_l2(h, r)
         print(f'[synth-biokg rgcn] {name} after {iters} iterations, rel-L2 to the fp64 oracle: fp32 ensemble '
               + ' '.join(f'{v:.2e}' for v in d_ens) + f' / HIP {d_hip:.2e}')
-        assert d_hip <= max(1e-4, 2.0 * max(d_ens)), (name, d_hip, d_ens)
+        #  north_star's 1e-4 is asserted AS IS whenever the fp32 ensemble itself is inside it; only where correct fp32
+        # implementations are themselves outside (said so loudly below) is HIP held to twice their distance instead
+        if max(d_ens) <= 1e-4:
+            assert d_hip <= 1e-4, (name, d_hip, d_ens)
+        else:
+            import warnings
+            warnings.warn(f'[synth-biokg rgcn] {name}: the fp32 ENSEMBLE is {max(d_ens):.2e} from the fp64 oracle after {iters} iterations - '
+                          f'outside north_star\'s 1e-4 bound on its own; HIP ({d_hip:.2e}) is held to twice that distance')
+            assert d_hip <= 2.0 * max(d_ens), (name, d_hip, d_ens)
 
 
 def test_full_size_node_deletion_gat_matches_oracle(tmp_path, monkeypatch):

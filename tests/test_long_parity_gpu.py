@@ -41,7 +41,8 @@ RATIO = 2.0                   # measured ratios: profiles/r03_long_parity.txt, p
 # full-size test adds the CPU oracle + three more GPU members at its 20-iteration horizon)
 # (four CPU members: with six the two synth-small cases took 50 s more of a suite that is asked to stay near 800 s, and the record of the
 #  seven-member runs - profiles/r05_long_parity.txt - has its extremes among the first five; running the CPU members in threads was
-#  tried and is slower: 136 / 160 s against 81 / 102)
+#  tried and is slower: 136 / 160 s against 81 / 102.  Round 6: they run as CHILD PROCESSES (tests/parity_member.py), started
+#  before the GPU runs of the test and collected after them - same members, same seeds, same arithmetic)
 PERMS = {'synth-small': (('cuda', None), ('cpu', None), ('cpu', 1), ('cpu', 2), ('cpu', 3)),
          'synth-collab': (('cuda', None), ('cuda', 1), ('cuda', 2))}
 
@@ -85,14 +86,42 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
         gc.collect()
         torch.cuda.empty_cache()
         return snaps, z_ori
+    # the CPU members of the ensemble: child processes, training while the GPU runs below go on
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    children, tmp = [], None
+    cpu_members = [perm for where, perm in PERMS[workload] if where == 'cpu']
+    if cpu_members:
+        tmp = tempfile.TemporaryDirectory()
+        req = os.path.join(tmp.name, 'request.pt')
+        torch.save(dict(gnn=gnn, data={k: (v.cpu() if torch.is_tensor(v) else v) for k, v in data.items()}, state=state, neg=neg.cpu(),
+                        ni1=ni1.cpu(), ni2=ni2.cpu(), loss_type=lt, alpha=alpha, lr=lr, check=CHECK), req)
+        here = os.path.dirname(os.path.abspath(__file__))
+        for perm in cpu_members:
+            out_ = os.path.join(tmp.name, f'member_{perm}.pt')
+            env = dict(os.environ, OMP_NUM_THREADS='8', HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+            children.append((perm, out_, subprocess.Popen([sys.executable, os.path.join(here, 'parity_member.py'), req,
+                                                           'none' if perm is None else str(perm), out_], env=env,
+                                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     s64_all, _ = run_oracle(torch.float64, None)
     d_members, s32_last, z_ori32 = [], None, None
     for where, perm in PERMS[workload]:       # the fp32 ensemble: distances to the fp64 run at every check
+        if where == 'cpu':
+            continue
         snaps, z_ori = run_oracle(torch.float32, perm, where)
         d_members.append([[rel_l2(sn[i], s64[i]) for i in range(4)] for sn, s64 in zip(snaps, s64_all)])
         if perm is None and where == 'cuda':
             s32_last, z_ori32 = snaps[-1], z_ori
         del snaps
+    for perm, out_, proc in children:
+        log_, _ = proc.communicate(timeout=900)
+        assert proc.returncode == 0, f'CPU ensemble member (edge-order seed {perm}) failed:\n{log_[-2000:]}'
+        snaps = torch.load(out_, weights_only=False)
+        d_members.append([[rel_l2(sn[i], s64[i]) for i in range(4)] for sn, s64 in zip(snaps, s64_all)])
+    if tmp is not None:
+        tmp.cleanup()
     z1o, z2o = z_ori32
     model.load_state_dict(state)
     hip = model.to(dev)

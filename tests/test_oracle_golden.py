@@ -40,6 +40,19 @@ def test_loss_zoo_matches_reference(name):
     assert rel_l2(a.grad, fx[f'{name}::grad']) < 1e-5
 
 
+def test_rbf_cka_with_explicit_sigma_matches_reference():
+    """RBFCKA (gnndelete_nodeemb.py:38-66) where upstream's own code can run: sigma given (its default-sigma branch raises
+    NameError: `math` is never imported).  Oracle and the framework's torch form against the reference's value and gradient."""
+    from gnndelete_amd.framework.trainer.gnndelete_nodeemb import get_loss_fct
+    fx = load_golden('losses.npz')
+    for fn in (lambda a, b: R.LOSSES['rbf_cka'](a, b, 2.0), lambda a, b: get_loss_fct('rbf_cka')(a, b, sigma=2.0)):
+        a = t(fx['a']).requires_grad_(True)
+        v = fn(a, t(fx['b']))
+        v.backward()
+        assert rel_l2(v.detach(), fx['rbf_cka_sigma2::value']) < TOL
+        assert rel_l2(a.grad, fx['rbf_cka_sigma2::grad']) < 1e-5
+
+
 @pytest.mark.parametrize('gnn', ['gcn', 'gat', 'gin'])
 def test_delete_wiring_matches_reference(gnn):
     fx = load_golden(f'wiring_{gnn}.npz')
