@@ -137,9 +137,6 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
   const int per = (n_items + kXcd - 1) / kXcd;
   const int i0 = xcd_bounds ? xcd_bounds[xcd] : xcd * per;
   const int i1 = xcd_bounds ? xcd_bounds[xcd + 1] : min(n_items, i0 + per);
-  // group items (slot == -2) meet at block barriers: block-uniform only with range limits that are multiples of 4 - a table
-  // that breaks this aborts the launch instead of deadlocking it (invariant stated in include/gnndelete_hip.h)
-  if (xcd_bounds && ((i0 | i1) & 3)) __builtin_trap();
 
   // per-lane constants: byte offset of this lane's vectors inside a row, its slice of the bias
   uint32_t lo[VPL];
@@ -371,6 +368,10 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
       if (lane == 0) aux_sum[row] = s1;
     }
     if (slot == -2) {          // group member (block-uniform: the planner aligns the quadruples and the XCD ranges to 4)
+      // ... which the barriers below rely on: a range table that breaks the invariant (a limit that is not a multiple of 4) aborts
+      // the launch here instead of deadlocking it (include/gnndelete_hip.h states the invariant.  The piece form of
+      // gd_spmm_csr_balanced_f32 has no group items and takes limits cut anywhere)
+      if ((i0 | i1) & 3) __builtin_trap();
       const int wave = threadIdx.x >> 6;
       if (g == 0) {
 #pragma unroll
