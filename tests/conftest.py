@@ -31,3 +31,29 @@ def _release_gpu_memory_between_tests():
     gc.collect()
     if torch.cuda.is_available():
         torch.cuda.empty_cache()
+
+
+def pytest_collection_finish(session):
+    """When the session runs the long GPU parity tests, start their CPU-oracle legs NOW as child processes (tests/oracle_jobs.py,
+    tests/test_long_parity_gpu.prepare): they compute on the host while the tests in front of them use the GPU, and the long
+    tests only collect the results (the suite against the driver's time limit).  Single-test runs start
+    their own leg when they reach it."""
+    import torch
+    if not torch.cuda.is_available() or session.config.option.collectonly:
+        return
+    ids = [it.nodeid for it in session.items if 'gpu' in it.keywords]
+    if len(ids) < 40:                        # (a targeted run: nothing to overlap with)
+        return
+    try:
+        import oracle_jobs
+        wanted = {'full-collab-gcn': 'test_full_size_training_parity[synth-collab-gcn', 'full-collab-sage': 'test_full_size_training_parity[synth-collab-sage',
+                  'full-collab-gat': 'test_full_size_training_parity[synth-collab-gat', 'full-nodecls-gat': 'test_full_size_node_deletion_gat'}
+        for job, needle in wanted.items():
+            if any(needle in i for i in ids):
+                oracle_jobs.start(job)
+        import test_long_parity_gpu as LP
+        for gnn in ('gcn', 'gat'):
+            if any(f'fp32_oracle[synth-small-{gnn}]' in i for i in ids):
+                LP.prepare('synth-small', gnn)
+    except Exception as e:                   # noqa: BLE001  (a failed prefetch must not fail the session: the tests start their own legs)
+        print(f'conftest: prefetch of the CPU-oracle legs skipped ({type(e).__name__}: {e})')

@@ -58,9 +58,16 @@ def _assert_del_weights_within_fp32_spread(tag, hip_w, w64, ens, iters):
                                                      ('synth-collab', 'gcn', 'in', 5.0),       # the metric's own model
                                                      ('synth-collab', 'sage', 'in', 5.0), ('synth-collab', 'gat', 'in', 5.0)])
 def test_full_size_training_parity(workload, gnn, df, df_size):
+    import oracle_jobs
     from gnndelete_amd.engine import NodeembEngine
     iters = ITERS[gnn]
     from oracle import gnndelete_ref as R
+    # the CPU oracle's iterations at collab size (30 s of host time for GCN) run in a child process from the same seeded request
+    # (tests/oracle_jobs.py; started at session start when the whole suite runs) while this process uses the GPU
+    job = f'full-collab-{gnn}' if workload == 'synth-collab' else None
+    if job:
+        assert oracle_jobs.JOBS[job][1] == dict(workload=workload, gnn=gnn, df=df, df_size=df_size, iters=iters)
+        oracle_jobs.start(job)
     data, model, neg, ni1, ni2 = _request(workload, gnn, df, df_size)
     state = {k: v.clone() for k, v in model.state_dict().items()}
     torch.set_num_threads(min(32, torch.get_num_threads()))
@@ -70,10 +77,11 @@ def test_full_size_training_parity(workload, gnn, df, df_size):
     e_dr, e_sdf, pos = E[:, data.dr_mask], E[:, data.sdf_mask], E[:, data.df_mask]
     with torch.no_grad():
         z1o, z2o = ref.get_original_embeddings(data.x, e_dr, return_all_emb=True)
-    targets = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=pos, neg_edge=neg, ni_mask1=ni1, ni_mask2=ni2)
-    opt = R.make_optimizer(ref, 'both_layerwise', 1e-3)
-    logs = [R.nodeemb_epoch(ref, lambda: ref(data.x, e_sdf, return_all_emb=True), targets, opt, 'both_layerwise', 0.5,
-                            R.LOSSES['mse_mean']) for _ in range(iters)]
+    if not job:
+        targets = dict(z1_ori=z1o, z2_ori=z2o, pos_edge=pos, neg_edge=neg, ni_mask1=ni1, ni_mask2=ni2)
+        opt = R.make_optimizer(ref, 'both_layerwise', 1e-3)
+        logs = [R.nodeemb_epoch(ref, lambda: ref(data.x, e_sdf, return_all_emb=True), targets, opt, 'both_layerwise', 0.5,
+                                R.LOSSES['mse_mean']) for _ in range(iters)]
     dev = torch.device('cuda')
     hip = model.to(dev)
     eng = NodeembEngine(hip, data.x.to(dev), e_sdf.to(dev).contiguous(), z1o.to(dev), z2o.to(dev), pos.to(dev), neg.to(dev),
@@ -92,8 +100,6 @@ def test_full_size_training_parity(workload, gnn, df, df_size):
     for _ in range(iters):
         eng.step()
     hist = eng.loss_history()
-    for i, log in enumerate(logs):
-        assert abs(float(hist[i, 0]) - log['train_loss']) <= 1e-4 * abs(log['train_loss']), (i, float(hist[i, 0]), log)
     wts = lambda m_: (m_.deletion1.deletion_weight.detach().double().cpu(), m_.deletion2.deletion_weight.detach().double().cpu())
     if workload == 'synth-collab':
         # (round 6) the same iterations restricted to the rows the request can influence - `--affected_rows_only`, now CHAINED like
@@ -111,6 +117,15 @@ def test_full_size_training_parity(workload, gnn, df, df_size):
         for a_, b_ in zip(wts(hip_r), wts(hip)):
             assert rel_l2(a_, b_) < 2e-5, rel_l2(a_, b_)
         del eng_r, hip_r
+    if job:                                # the CPU oracle's result: its log, and its final Del weights into `ref`
+        res = oracle_jobs.result(job)
+        assert res['checksum'] == oracle_jobs.checksum(state, neg), 'the child built another request than this process'
+        logs = res['logs']
+        with torch.no_grad():
+            ref.deletion1.deletion_weight.copy_(res['w1'])
+            ref.deletion2.deletion_weight.copy_(res['w2'])
+    for i, log in enumerate(logs):
+        assert abs(float(hist[i, 0]) - log['train_loss']) <= 1e-4 * abs(log['train_loss']), (i, float(hist[i, 0]), log)
     def run_oracle(dtype, perm):           # one oracle at a time (their autograd tapes at collab size are tens of GB)
         import gc
         step, snap, _ = oracle_runner(gnn, data, state, neg, ni1, ni2, dtype, dev, perm=perm)
@@ -278,47 +293,27 @@ def test_full_size_node_deletion_gat_matches_oracle(tmp_path, monkeypatch):
     """BASELINE config 5 at the size it names: delete_node.py's request (5 % of the NODES deleted with every edge touching
     them, S_Df on the undirected edge_index, delete_node.py:77-142) on the ogbl-collab-shaped node-classification stand-in
     (235,868 nodes, 4 classes), GAT.  The HIP node-classification trainer (GNNDeleteNodeClassificationTrainer ->
-    fused engine; out_dim = 4 takes the generic-width kernels for everything behind layer 1) against the oracle's
+    fused engine; out_dim = 4: the engine pads layer 2 to 64 zero columns, engine._padded_out_shadow) against the oracle's
     restatement of the same loop (gnndelete_nodeemb.py:498-657) from the same state with the same negatives: per-epoch
     losses, Del weights, affected-node embeddings, test accuracy.  The epoch time of the HIP path is printed."""
     import time
+    import oracle_jobs
     from gnndelete_amd.framework.data import Data
-    from gnndelete_amd.framework.graph_utils import k_hop_subgraph, negative_sampling
-    from gnndelete_amd.framework.models import GATDelete
-    from gnndelete_amd.framework.synth import make_nodecls_dataset
     from gnndelete_amd.framework.trainer import gnndelete_nodeemb as TN
-    from gnndelete_amd.framework.utils import seed_everything
     from oracle import gnndelete_ref as R
-    data = make_nodecls_dataset('synth-collab', seed=42)
-    n = data.num_nodes
-    seed_everything(42)
-    df_nodes = torch.randperm(n)[:int(0.05 * n)]
-    gone = torch.zeros(n, dtype=torch.bool)
-    gone[df_nodes] = True
-    E = data.edge_index
-    df_mask = gone[E[0]] | gone[E[1]]
-    df_edge = E[:, df_mask]
-    data.directed_df_edge_index = df_edge[:, df_edge[0] < df_edge[1]]
-    seeds = df_edge.flatten().unique()
-    _, e2, _, m2e = k_hop_subgraph(seeds, 2, E, num_nodes=n)
-    _, e1, _, _ = k_hop_subgraph(seeds, 1, E, num_nodes=n)
-    s1, s2 = torch.zeros(n, dtype=torch.bool), torch.zeros(n, dtype=torch.bool)
-    s1[e1.flatten().unique()] = True
-    s2[e2.flatten().unique()] = True
-    data.sdf_node_1hop_mask, data.sdf_node_2hop_mask, data.sdf_mask, data.df_mask = s1, s2, m2e, df_mask
-    data.dr_mask = data.dtrain_mask = ~df_mask
-    torch.manual_seed(9)
-    hip = GATDelete(SimpleNamespace(in_dim=data.x.shape[1], hidden_dim=128, out_dim=data.num_classes), s1, s2)
-    state = {k: v.clone() for k, v in hip.state_dict().items()}
-    neg = negative_sampling(E, n, int(df_mask.sum()), generator=torch.Generator().manual_seed(4))
     epochs, lr, alpha = 10, 1e-2, 0.5
-    # ---- oracle (CPU)
+    # ---- oracle (CPU): its ten epochs run in a child process from the same seeded request (tests/oracle_jobs.py) while this
+    # process drives the GPU
+    assert oracle_jobs.JOBS['full-nodecls-gat'][1] == dict(epochs=epochs, lr=lr, alpha=alpha)
+    oracle_jobs.start('full-nodecls-gat')
+    data, hip, state, neg = oracle_jobs.nodecls_request()
+    n, E = data.num_nodes, data.edge_index
+    s1, s2 = data.sdf_node_1hop_mask, data.sdf_node_2hop_mask
     torch.set_num_threads(min(32, torch.get_num_threads()))
     ref = R.TwoLayerDelete('gat', data.x.shape[1], 128, data.num_classes, s1, s2)
     ref.load_state_dict(state, strict=False)
     d = {k: v for k, v in data.items()}
     d['train_pos_edge_index'] = E
-    logs, _ = R.nodeemb_fullbatch(ref, d, epochs, 'both_layerwise', alpha, 'mse_mean', lr, neg_edge=neg)
     # ---- HIP trainer
     monkeypatch.setattr(TN, 'negative_sampling', lambda *a, **k: neg.cuda())
     args = SimpleNamespace(unlearning_model='gnndelete_nodeemb', dataset='synth-collab', checkpoint_dir=str(tmp_path),
@@ -332,8 +327,6 @@ def test_full_size_node_deletion_gat_matches_oracle(tmp_path, monkeypatch):
     print(f'config 5 at collab size: {epochs} Del epochs + validation + checkpoints {time.time() - t0:.2f} s; '
           f'train_time per epoch {tr.trainer_log["log"][0].get("train_time", float("nan")) * 1e3:.2f} ms')
     hist = torch.tensor(tr.trainer_log['loss_history'])
-    for i, log in enumerate(logs):
-        assert abs(float(hist[i, 0]) - log['train_loss']) <= 1e-4 * abs(log['train_loss']), (i, float(hist[i, 0]), log)
     # Del weights: HIP's distance to an fp64 run of the same loop against the spread of an fp32 ensemble (the CPU oracle above +
     # the same oracle as torch ops on the GPU with three scatter orders), as in test_full_size_training_parity
     import gc
@@ -353,7 +346,16 @@ def test_full_size_node_deletion_gat_matches_oracle(tmp_path, monkeypatch):
     logs64, w64 = run_oracle(torch.float64, None)
     for i, log in enumerate(logs64):
         assert abs(float(hist[i, 0]) - log['train_loss']) <= 1e-4 * abs(log['train_loss']), (i, float(hist[i, 0]), log)
-    ens = [wts(ref)] + [run_oracle(torch.float32, p)[1] for p in (None, 1, 2)]
+    gpu_members = [run_oracle(torch.float32, p)[1] for p in (None, 1, 2)]
+    res = oracle_jobs.result('full-nodecls-gat')                    # the CPU oracle's epochs: log + final Del weights into `ref`
+    assert res['checksum'] == oracle_jobs.checksum(state, neg), 'the child built another request than this process'
+    logs = res['logs']
+    with torch.no_grad():
+        ref.deletion1.deletion_weight.copy_(res['w1'])
+        ref.deletion2.deletion_weight.copy_(res['w2'])
+    for i, log in enumerate(logs):
+        assert abs(float(hist[i, 0]) - log['train_loss']) <= 1e-4 * abs(log['train_loss']), (i, float(hist[i, 0]), log)
+    ens = [wts(ref)] + gpu_members
     _assert_del_weights_within_fp32_spread('synth-collab node deletion gat', wts(hip), w64, ens, epochs)
     e_dr = E[:, data.dr_mask]
     with torch.no_grad():

@@ -308,3 +308,20 @@ def test_bench_attaches_a_stage_profile_only_to_the_kernels_it_was_taken_with(tm
     assert 0.35 < c['frac'] < 0.5 and abs(c['frac'] - fl['algorithmic_bytes'] / fl['lru_bytes'] * c['fabric_tbs'] * 1e3 / bench.HBM_PEAK_GBS) < 1e-12
     assert bench.fabric_ceiling(fl['n'] + 1, fl['nnz'], fl['d']) is None
     assert bench.spmm_algorithmic_bytes(10, 50, 64) == 4 * 11 + 4 * 50 + 4 * 50 + 2 * 4 * 10 * 64
+
+
+def test_cpu_oracle_job_in_a_child_process_reproduces_the_in_process_run():
+    """tests/oracle_jobs.py: the CPU-oracle legs of the long GPU tests run as child processes (so that the GPU is not idle while
+    they compute).  A child rebuilds its request from seeds: it must arrive at exactly the same weights / negatives (checksum)
+    and at the oracle results of the same function run in this process (to the run-to-run noise of the oracle's threaded
+    scatters: two runs in ONE process differ by ~5e-8 in the Del weights)."""
+    import oracle_jobs as J
+    from helpers import rel_l2
+    J.start('selftest-small')
+    kind, params = J.JOBS['selftest-small']
+    here = J._run_linkpred(**params)
+    there = J.result('selftest-small')
+    assert here['checksum'] == there['checksum']
+    for a, b in zip(here['logs'], there['logs']):
+        assert abs(a['train_loss'] - b['train_loss']) <= 1e-6 * abs(a['train_loss'])
+    assert rel_l2(there['w1'], here['w1']) < 1e-6 and rel_l2(there['w2'], here['w2']) < 1e-6

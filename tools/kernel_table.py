@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """The per-kernel state table of DESIGN.md section 4, generated from the committed measurements:
-  profiles/r05_bench_default.json   (extras.stage_rooflines: algorithmic work, live timing, in-step timing, traffic)
-  profiles/r05_final_stages.json    (tools/rocpd_stage_table.py over the rocprofv3 kernel-trace + PMC passes)
--> markdown on stdout, profiles/r05_kernel_table.json (the same rows, machine-checkable).  No GPU needed."""
+  profiles/r06_bench_default.json   (extras.stage_rooflines: algorithmic work, live timing, in-step timing, traffic)
+  profiles/r06_final_stages.json    (tools/rocpd_stage_table.py over the rocprofv3 kernel-trace + PMC passes)
+-> markdown on stdout, profiles/r06_kernel_table.json (the same rows, machine-checkable).  No GPU needed."""
 import json
 import os
 
@@ -14,19 +14,19 @@ NEXT = {
     'del1_loss_wgrad1': 'round 5: the previous iteration\'s conv2 input gradient (dt2[S1] W2, gated by the stored sign pattern) + Del-1 + folded layer-1 loss + the W_D1 weight gradient in ONE weight-stationary pass (was 59 + 83 + 40 us in three launches, 690 MB; now ~320 MB): instruction-bound (one wave per SIMD issues in order; 320 matrix instructions per 16-row unit and wave at the ~2.0 GHz the part sustains are 5.1 us of its ~6.9); both weights are LDS images (register-resident fragments leave no room for the third product); row-register rings, sched_group_barrier interleaving and a four-way column split all measured equal or slower (NOTES round 5)',
     'wgrad1': 'memory-side (366 MB algorithmic = 61 us at the fabric rate): 2 blocks per CU alternate fetch and MFMA phases; the output-stationary register form measured SLOWER (93 us, NOTES round 4) - it needs more rows in flight per CU, not fewer waves',
     't2': 'weight-stationary form with the two-buffer row selector and ReLU in the operand path: 52.1 -> 45 us; 193 MB at 4.3 TB/s',
-    'spmm2': 'latency / window-bound at 4.2-4.8 TB/s of traffic; the one-row-per-lane-group kernel (round 4) moves bytes 10-15 % faster and 16 % more of them - no gain, opt-in',
+    'spmm2': 'latency / window-bound at 4.2-4.8 TB/s of traffic; round 6: eight lanes x two float4 per row (half the visits\' crossbar reads and address products) is 20-32 % SLOWER back to back and +6 % on the step - a row\'s two 128-byte lines asked for by different instructions; the weight stream is worth 3.7 / 1.6 us, all of it the load (profiles/r06_spmm_forms.txt, r06_spmm_forms_pmc.txt)',
     'del2_loss_bwd': 'weight-stationary form (round 4: W_D twice + the 64 x 64 dW sums in registers, 16-row units, no scratch): 62 -> 52 us; the three products of a unit are serial in one wave (loss arithmetic and the LDS transposition between them)',
     'spmm2_t': 'as spmm2 (transposed CSR, S1 rows feed the next product)',
     'dh': 'weight-stationary form with the gate bits fetched a unit ahead: 47.2 -> 41 us; 148 MB at 3.6 TB/s',
     'tail': 'both split-K reductions + Adam + loss finalize in one launch (gd_step_tail_f32); launch-sized',
 }
-EVID = 'profiles/r05_final_stages.json, r05_final_step_timeline.md'
+EVID = 'profiles/r06_final_stages.json, r06_final_step_timeline.md'
 
 
 def main():
-    with open(os.path.join(ROOT, 'profiles', 'r05_bench_default.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r06_bench_default.json')) as f:
         line = json.loads(f.read().strip().splitlines()[-1])
-    with open(os.path.join(ROOT, 'profiles', 'r05_final_stages.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r06_final_stages.json')) as f:
         st = json.load(f)
     roof = {e['stage']: e for e in line['extras']['stage_rooflines']}
     rows = []
@@ -44,7 +44,7 @@ def main():
                      'traffic_mb': round(ps['traffic_bytes'] / 1e6, 1) if ps.get('traffic_bytes') else None,
                      'traffic_over_algorithmic': round(e['traffic_over_algorithmic'], 2) if e.get('traffic_over_algorithmic') else None,
                      'evidence': EVID, 'next': NEXT.get(key, '')})
-    with open(os.path.join(ROOT, 'profiles', 'r05_kernel_table.json'), 'w') as f:
+    with open(os.path.join(ROOT, 'profiles', 'r06_kernel_table.json'), 'w') as f:
         json.dump({'step_us_under_rocprof': st['step_span_us'], 'ms_per_step_bench': line['ms_per_step'], 'rows': rows}, f, indent=1)
     print('| stage | kernel | in step us | GF / MB (algorithmic) | bound | fraction in step | PMC traffic (x algorithmic) | state / next |')
     print('|---|---|---|---|---|---|---|---|')
