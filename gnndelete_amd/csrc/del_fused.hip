@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ idx, int32_t n_sel, const float* __restrict__ w,
     float* __restrict__ z, int64_t ld_z, uint32_t* __restrict__ sign_io, DelLoss loss, const float* __restrict__ dt, int64_t ld_dt,
     const float* __restrict__ w_next, float* __restrict__ wg_partials, int32_t n_part, ChainRank1 r1) {
-  constexpr int D = 128, H = 64, K2 = 64, PTP = 144, PTZ = 80;
+  constexpr int D = 128, H = 64, PTP = 144, PTZ = 80;
   constexpr int kTiles = 4 * (16 * PTP + 16 * PTZ);               // floats of the four waves' transposition tiles
   extern __shared__ __attribute__((aligned(16))) float wl[];      // tiles | W_D image | W_next image; later 4 x D x H block sums
   __shared__ float lred[2][4];

@@ -48,12 +48,12 @@ def pytest_collection_finish(session):
         import oracle_jobs
         wanted = {'full-collab-gcn': 'test_full_size_training_parity[synth-collab-gcn', 'full-collab-sage': 'test_full_size_training_parity[synth-collab-sage',
                   'full-collab-gat': 'test_full_size_training_parity[synth-collab-gat', 'full-nodecls-gat': 'test_full_size_node_deletion_gat'}
-        for job, needle in wanted.items():
-            if any(needle in i for i in ids):
-                oracle_jobs.start(job)
+        names = [job for job, needle in wanted.items() if any(needle in i for i in ids)]
+        members = []
         import test_long_parity_gpu as LP
         for gnn in ('gcn', 'gat'):
             if any(f'fp32_oracle[synth-small-{gnn}]' in i for i in ids):
-                LP.prepare('synth-small', gnn)
+                LP.prepare('synth-small', gnn, queue=members)
+        oracle_jobs.prefetch(names, members)          # ONE background worker, oracle_jobs.BG_THREADS threads, in this order
     except Exception as e:                   # noqa: BLE001  (a failed prefetch must not fail the session: the tests start their own legs)
         print(f'conftest: prefetch of the CPU-oracle legs skipped ({type(e).__name__}: {e})')

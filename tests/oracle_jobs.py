@@ -7,11 +7,16 @@ of state + negatives is compared with the parent's), so it can run in a child pr
 suite runs, OTHER tests - use the GPU.  Same oracle code, same inputs, same thread count as before; nothing about what is
 compared changes.
 
-  start(name)    -> launches the job's child once (idempotent)
-  result(name)   -> waits for it, returns what it saved (torch.load)
-  prefetch()     -> start() for every job (tests/conftest.py calls it at session start when the session runs the long tests)
+  start(name)        -> launches the job's own child once (idempotent; a test run on its own overlaps its CPU leg with its GPU legs)
+  result(name)       -> waits for it, returns what it saved (torch.load)
+  prefetch(names, members)
+                     -> ONE background worker that runs the named jobs and then the given ensemble members of the 600-epoch
+                        tests (tests/parity_member.py) one after the other on BG_THREADS host threads (tests/conftest.py calls it at
+                        session start when the whole suite runs).  One worker, few threads, on purpose: the GPU boxes run under a
+                        cgroup quota of 16 CPUs (256 are visible) - twelve children with 128 threads between them throttled the
+                        whole session (the suite took 980 s instead of 640, profiles/NOTES.md round 6).
 
-Run as a script (`python tests/oracle_jobs.py <name> <out.pt>`) this file IS the child."""
+Run as a script (`python tests/oracle_jobs.py <name> <out.pt>` / `--queue <spec.pt>`) this file IS the child."""
 import os
 import subprocess
 import sys
@@ -34,8 +39,10 @@ JOBS = {
 # host threads per job: four jobs + the eight 8-thread ensemble members of the 600-epoch tests run side by side at session start
 # (128 threads in all); the oracle's epoch is as fast on 16 threads as on 32 (1.68 against 1.56 s, bench.py's thread sweep)
 THREADS = 16
+BG_THREADS = 8            # the session-start worker: half of the box's CPU quota, the session itself keeps the rest
 _running = {}
 _tmp = None
+_queue = None             # (worker process, {job name or member out file: out file})
 
 
 def checksum(state, neg):
@@ -124,7 +131,7 @@ def _tmpdir():
 
 
 def start(name):
-    if name in _running:
+    if name in _running or (_queue is not None and name in _queue[1]):
         return
     out = os.path.join(_tmpdir(), name + '.pt')
     env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='', PYTHONPATH=ROOT + os.pathsep + HERE)
@@ -134,7 +141,27 @@ def start(name):
     _running[name] = (proc, out)
 
 
+def wait_for_file(out, timeout=1800):
+    """Block until the session-start worker has written `out` (it renames a finished file into place) -> True; False when the
+    worker is gone without having written it."""
+    import time
+    t0 = time.time()
+    while not os.path.exists(out):
+        if _queue is None or _queue[0].poll() is not None:
+            return os.path.exists(out)
+        assert time.time() - t0 < timeout, f'timed out waiting for {out}'
+        time.sleep(0.2)
+    return True
+
+
 def result(name, timeout=1800):
+    if _queue is not None and name in _queue[1] and name not in _running:
+        out = _queue[1][name]
+        if wait_for_file(out, timeout):
+            return torch.load(out, weights_only=False)
+        log = _queue[0].stdout.read() if _queue[0].stdout else ''
+        print(f'oracle_jobs: the background worker ended without {name} - running it directly\n{(log or "")[-1500:]}')
+        _queue[1].pop(name)
     start(name)
     proc, out = _running[name]
     log, _ = proc.communicate(timeout=timeout)
@@ -142,15 +169,42 @@ def result(name, timeout=1800):
     return torch.load(out, weights_only=False)
 
 
-def prefetch():
-    for name in JOBS:
-        if not name.startswith('selftest'):
-            start(name)
+def prefetch(names, members=()):
+    """names: jobs of JOBS; members: (request file, edge-order seed or None, out file) of tests/parity_member.py.  One worker
+    process runs them in this order."""
+    global _queue
+    if _queue is not None or not (names or members):
+        return
+    outs = {n: os.path.join(_tmpdir(), n + '.pt') for n in names}
+    spec = os.path.join(_tmpdir(), 'queue.pt')
+    torch.save(dict(jobs=[(n, outs[n]) for n in names], members=list(members)), spec)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='', PYTHONPATH=ROOT + os.pathsep + HERE,
+               OMP_NUM_THREADS=str(BG_THREADS), OMP_WAIT_POLICY='PASSIVE', GD_ORACLE_JOB_THREADS=str(BG_THREADS))
+    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--queue', spec], env=env, stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, text=True)
+    for _, _, out in members:
+        outs[out] = out
+    _queue = (proc, outs)
+
+
+def _run(name, out):
+    kind, params = JOBS[name]
+    res = _run_linkpred(**params) if kind == 'linkpred' else _run_nodecls(**params)
+    torch.save(res, out + '.part')
+    os.replace(out + '.part', out)
 
 
 if __name__ == '__main__':
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
-    kind, params = JOBS[sys.argv[1]]
-    res = _run_linkpred(**params) if kind == 'linkpred' else _run_nodecls(**params)
-    torch.save(res, sys.argv[2])
+    THREADS = int(os.environ.get('GD_ORACLE_JOB_THREADS', THREADS))
+    if sys.argv[1] == '--queue':
+        spec = torch.load(sys.argv[2], weights_only=False)
+        for name_, out_ in spec['jobs']:
+            _run(name_, out_)
+        import parity_member
+        for req, perm, out_ in spec['members']:
+            parity_member.run(req, perm, out_ + '.part', threads=THREADS)
+            os.replace(out_ + '.part', out_)
+    else:
+        _run(sys.argv[1], sys.argv[2])

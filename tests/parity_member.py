@@ -12,15 +12,16 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402
 
 
-def main():
-    req_path, perm, out_path = sys.argv[1], sys.argv[2], sys.argv[3]
+def run(req_path, perm, out_path, threads=None):
+    """perm: an edge-order seed, None / 'none' = the edge lists as given."""
     from gnndelete_amd.framework.data import Data
     from helpers import oracle_runner
     req = torch.load(req_path, weights_only=False)
-    torch.set_num_threads(int(os.environ.get('OMP_NUM_THREADS', '8')))
+    n_threads = int(threads or os.environ.get('OMP_NUM_THREADS', '8'))
     data = Data(req['data'])
     step, snap, _ = oracle_runner(req['gnn'], data, req['state'], req['neg'], req['ni1'], req['ni2'], torch.float32, torch.device('cpu'),
-                                  req['loss_type'], req['alpha'], req['lr'], perm=None if perm == 'none' else int(perm))
+                                  req['loss_type'], req['alpha'], req['lr'], perm=None if perm in (None, 'none') else int(perm))
+    torch.set_num_threads(n_threads)            # (after oracle_runner, which sets its own default)
     snaps, done = [], 0
     for upto in req['check']:
         for _ in range(upto - done):
@@ -31,4 +32,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    run(sys.argv[1], sys.argv[2], sys.argv[3])

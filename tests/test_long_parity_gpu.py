@@ -61,11 +61,12 @@ LT, ALPHA, LR = 'both_layerwise', 0.5, 1e-3
 _PREPARED = {}
 
 
-def prepare(workload, gnn):
+def prepare(workload, gnn, queue=None):
     """The request of one case - seeded build, a backbone with signal trained on the GPU (set-up) - and, for the cases with CPU
-    ensemble members, those members started as child processes (tests/parity_member.py).  Cached: tests/conftest.py calls this
-    at session start when the whole suite runs, so that the members train while OTHER tests use the GPU; the test itself
-    picks the prepared case up (or prepares it, when run on its own)."""
+    ensemble members, those members as child processes (tests/parity_member.py): started here, one process each, when the test
+    runs on its own; with `queue` (a list) only DESCRIBED - (request file, edge-order seed, out file) appended to it - for the
+    session-start background worker of tests/oracle_jobs.py, which trains them one after the other while other tests use the
+    GPU (tests/conftest.py).  Cached: the test picks the prepared case up."""
     key = (workload, gnn)
     if key in _PREPARED:
         return _PREPARED[key]
@@ -89,7 +90,12 @@ def prepare(workload, gnn):
         here = os.path.dirname(os.path.abspath(__file__))
         for perm in cpu_members:
             out_ = os.path.join(tmp.name, f'member_{perm}.pt')
-            env = dict(os.environ, OMP_NUM_THREADS='8', HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+            if queue is not None:
+                queue.append((req, perm, out_))
+                children.append((perm, out_, None))
+                continue
+            # (a run of this test alone: four children of 4 threads - the boxes run under a 16-CPU quota)
+            env = dict(os.environ, OMP_NUM_THREADS='4', HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
             children.append((perm, out_, subprocess.Popen([sys.executable, os.path.join(here, 'parity_member.py'), req,
                                                            'none' if perm is None else str(perm), out_], env=env,
                                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -99,6 +105,7 @@ def prepare(workload, gnn):
 
 @pytest.mark.parametrize('workload,gnn', [('synth-small', 'gcn'), ('synth-collab', 'gcn'), ('synth-small', 'gat')])
 def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, gnn):
+    import os
     from gnndelete_amd.engine import NodeembEngine
     dev = torch.device('cuda')
     case = prepare(workload, gnn)
@@ -139,8 +146,14 @@ def test_hip_tracks_the_fp64_trajectory_as_closely_as_the_fp32_oracle(workload, 
             s32_last, z_ori32 = snaps[-1], z_ori
         del snaps
     for perm, out_, proc in children:
-        log_, _ = proc.communicate(timeout=900)
-        assert proc.returncode == 0, f'CPU ensemble member (edge-order seed {perm}) failed:\n{log_[-2000:]}'
+        if proc is None:                         # trained by the session-start worker (or here, should that worker have died)
+            import oracle_jobs
+            import parity_member
+            if not oracle_jobs.wait_for_file(out_):
+                parity_member.run(os.path.join(os.path.dirname(out_), 'request.pt'), perm, out_, threads=8)
+        else:
+            log_, _ = proc.communicate(timeout=900)
+            assert proc.returncode == 0, f'CPU ensemble member (edge-order seed {perm}) failed:\n{log_[-2000:]}'
         snaps = torch.load(out_, weights_only=False)
         d_members.append([[rel_l2(sn[i], s64[i]) for i in range(4)] for sn, s64 in zip(snaps, s64_all)])
     if tmp is not None:
