@@ -25,6 +25,22 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32-input matrix peak, v_mfma_f32_32x32x
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def cpu_quota():
+    """CPUs the container may actually use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown: the GPU boxes
+    show 256 logical CPUs and run under a quota of 16 - what `cpu_baseline.cores` threads can really get."""
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        return None if q == 'max' else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
@@ -292,8 +308,9 @@ def kg_cpu_baseline(args, data, state, neg, ni1, ni2, iters):
         R.nodeemb_epoch(m, lambda: m(data.x, ei, et, return_all_emb=True), targets, opt, args.loss_type, 0.5, R.LOSSES['mse_mean'])
         times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
-    return {'value': 1.0 / med, 'unit': 'iters/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{iters} full-graph R-GCN iterations of the same request, median ({med:.1f} s; torch CPU, {threads} host threads)'}, m
+    return {'value': 1.0 / med, 'unit': 'iters/s', 'cores': threads, 'cpu_quota': cpu_quota(), 'kind': 'port',
+            'sample': f'{iters} full-graph R-GCN iterations of the same request, median ({med:.1f} s; torch CPU, {threads} host threads, '
+                      f'cgroup quota {cpu_quota()} CPUs)'}, m
 
 
 def kg_main(args, device, rank=0, world=1, group=None, barrier=lambda: None, ctl=None):
@@ -552,9 +569,9 @@ def nodecls_main(args, device, rank=0, world=1, barrier=lambda: None, ctl=None):
             R.nodeemb_epoch(ref, lambda: ref(data.x, c_sdf, return_all_emb=True), targets, opt, 'both_layerwise', 0.5, R.LOSSES['mse_mean'])
             times.append(time.perf_counter() - t0)
         med = sorted(times[1:])[len(times[1:]) // 2]
-        out['cpu_baseline'] = {'value': 1.0 / med, 'unit': 'iters/s', 'cores': threads, 'kind': 'port',
+        out['cpu_baseline'] = {'value': 1.0 / med, 'unit': 'iters/s', 'cores': threads, 'cpu_quota': cpu_quota(), 'kind': 'port',
                                'sample': f'{iters - 1} full-graph epochs of the same request after 1 warm-up, median ({med:.2f} s; oracle '
-                                         f'nodeemb_epoch = gnndelete_nodeemb.py:570-607 restated, torch CPU, {threads} of {os.cpu_count()} host threads)'}
+                                         f'nodeemb_epoch = gnndelete_nodeemb.py:570-607 restated, torch CPU, {threads} of {os.cpu_count()} host threads, cgroup quota {cpu_quota()} CPUs)'}
         out['speedup_vs_cpu'] = out['value'] / out['cpu_baseline']['value']
         e2 = engine()
         for _ in range(iters):
@@ -957,10 +974,10 @@ def cpu_baseline(args, data, model_state, neg, iters):
         R.nodeemb_epoch(m, fwd, targets, opt, args.loss_type, 0.5, R.LOSSES['mse_mean'])
         times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
-    rec = {'value': 1.0 / med, 'unit': 'iters/s', 'cores': threads, 'kind': 'port', 'mode': 'faithful',
+    rec = {'value': 1.0 / med, 'unit': 'iters/s', 'cores': threads, 'cpu_quota': cpu_quota(), 'kind': 'port', 'mode': 'faithful',
            'sample': f'{iters} full-graph iterations of the same request after 1 warm-up, median '
                      f'({med:.2f} s; min {min(times):.2f}, max {max(times):.2f}; torch CPU, {threads} of {os.cpu_count()} '
-                     f'host threads - the fastest setting, see thread_sweep). Faithful = the frozen layer 1 (x W1^T and its '
+                     f'host threads, cgroup quota {cpu_quota()} CPUs - the fastest setting, see thread_sweep). Faithful = the frozen layer 1 (x W1^T and its '
                      f'aggregation) recomputed every iteration as upstream does; the >= 10x target is quoted against this one'}
     # the *fair* mode next to it (loop-invariant layer-1 output computed once), and the thread
     # sweep that justifies `cores`; bounded samples on copies of the model so that `m` keeps the state parity is checked on

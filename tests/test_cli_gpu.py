@@ -22,6 +22,22 @@ def run(cmd, cwd):
     return r.stdout
 
 
+@pytest.fixture(scope='module')
+def prepared(tmp_path_factory):
+    """prepare_dataset.py run ONCE per stand-in for this module (it is the same seeded command in every pipeline test; a
+    subprocess start costs ~3 s of the suite's time limit): -> copy(cwd, dataset) that puts its output under a test's cwd."""
+    import shutil
+    base = str(tmp_path_factory.mktemp('prepared'))
+    done = set()
+
+    def copy(cwd, dataset):
+        if dataset not in done:
+            run([os.path.join(ROOT, 'prepare_dataset.py'), '--dataset', dataset, '--seeds', '42'], base)
+            done.add(dataset)
+        shutil.copytree(os.path.join(base, 'data', dataset), os.path.join(cwd, 'data', dataset))
+    return copy
+
+
 def test_trainer_eval_matches_reference_golden(tmp_path):
     from types import SimpleNamespace
     from gnndelete_amd.framework.data import Data
@@ -50,9 +66,9 @@ def test_trainer_eval_matches_reference_golden(tmp_path):
                                                   ('gat', 'gnndelete_nodeemb', 'both_all'),
                                                   ('gin', 'gnndelete', 'both_layerwise'),
                                                   ('sage', 'gnndelete_nodeemb', 'both_layerwise')])
-def test_cli_pipeline(tmp_path, gnn, method, loss_type):
+def test_cli_pipeline(tmp_path, prepared, gnn, method, loss_type):
     cwd = str(tmp_path)
-    run([os.path.join(ROOT, 'prepare_dataset.py'), '--dataset', 'synth-tiny', '--seeds', '42'], cwd)
+    prepared(cwd, 'synth-tiny')
     common = ['--dataset', 'synth-tiny', '--gnn', gnn, '--random_seed', '42']
     run([os.path.join(ROOT, 'train_gnn.py')] + common + ['--epochs', '30', '--valid_freq', '10'], cwd)
     orig = os.path.join(cwd, 'checkpoint', 'synth-tiny', gnn, 'original', '42')
@@ -78,13 +94,13 @@ def test_cli_pipeline(tmp_path, gnn, method, loss_type):
 
 
 @pytest.mark.parametrize('gnn', ['rgcn', 'rgat'])
-def test_cli_pipeline_knowledge_graph(tmp_path, monkeypatch, gnn):
+def test_cli_pipeline_knowledge_graph(tmp_path, monkeypatch, prepared, gnn):
     """R-GCN / R-GAT on a synthetic KG: original training, then Del training on random-walk batches."""
     cwd = str(tmp_path)
     monkeypatch.setenv('GNNDELETE_FORCE_EPOCHS', '3')
     monkeypatch.setenv('GNNDELETE_FORCE_VALID_FREQ', '3')
     monkeypatch.setenv('GNNDELETE_FORCE_NUM_STEPS', '4')
-    run([os.path.join(ROOT, 'prepare_dataset.py'), '--dataset', 'synth-kg-tiny', '--seeds', '42'], cwd)
+    prepared(cwd, 'synth-kg-tiny')
     common = ['--dataset', 'synth-kg-tiny', '--gnn', gnn, '--random_seed', '42', '--in_dim', '32', '--hidden_dim', '32',
               '--out_dim', '16']
     run([os.path.join(ROOT, 'train_gnn.py')] + common, cwd)
@@ -98,14 +114,14 @@ def test_cli_pipeline_knowledge_graph(tmp_path, monkeypatch, gnn):
     assert 'node_emb.weight' in state and 'W' in state and state['conv1.weight'].shape[0] == 8
 
 
-def test_cli_knowledge_graph_fullgraph_fused_step(tmp_path, monkeypatch):
+def test_cli_knowledge_graph_fullgraph_fused_step(tmp_path, monkeypatch, prepared):
     """delete_gnn.py --gnn rgcn --fullgraph: the fused R-GCN engine behind the KG trainer (one hipGraph per epoch on the
     whole Dr graph) - runs end to end, lowers its loss and writes the reference's checkpoint layout (the engine itself is
     checked against the oracle in tests/test_engine_gpu.py::test_rgcn_engine_matches_oracle_training)."""
     cwd = str(tmp_path)
     monkeypatch.setenv('GNNDELETE_FORCE_EPOCHS', '6')
     monkeypatch.setenv('GNNDELETE_FORCE_VALID_FREQ', '3')
-    run([os.path.join(ROOT, 'prepare_dataset.py'), '--dataset', 'synth-kg-tiny', '--seeds', '42'], cwd)
+    prepared(cwd, 'synth-kg-tiny')
     common = ['--dataset', 'synth-kg-tiny', '--gnn', 'rgcn', '--random_seed', '42', '--in_dim', '32', '--hidden_dim', '32',
               '--out_dim', '16']
     run([os.path.join(ROOT, 'train_gnn.py')] + common, cwd)
@@ -124,8 +140,8 @@ def test_cli_knowledge_graph_fullgraph_fused_step(tmp_path, monkeypatch):
 
 @pytest.mark.parametrize('gnn', ['gat', 'gcn'])
 def test_cli_node_deletion(tmp_path, monkeypatch, gnn):
-    """delete_node.py: node unlearning with accuracy / F1 evaluation (out_dim = #classes = 4, so
-    the Del-2 GEMM takes the generic-dimension kernels)."""
+    """delete_node.py: node unlearning with accuracy / F1 evaluation (out_dim = #classes = 4: the engine pads layer 2 with
+    zero columns to the width of its fused forms, engine._padded_out_shadow; the checkpoint keeps the 4 x 4 W_D2)."""
     cwd = str(tmp_path)
     monkeypatch.setenv('GNNDELETE_FORCE_EPOCHS', '20')
     monkeypatch.setenv('GNNDELETE_FORCE_VALID_FREQ', '10')
