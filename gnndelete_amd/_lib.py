@@ -14,7 +14,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'gnndelete_hip.h')
 _i32, _i64, _f32, _f64, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
 # name -> (restype, argtypes); must list every symbol the header declares
-ABI_VERSION = 8          # GD_ABI_VERSION of include/gnndelete_hip.h this binding was written against
+ABI_VERSION = 9          # GD_ABI_VERSION of include/gnndelete_hip.h this binding was written against
 
 PROTOTYPES = {
     'gd_abi_version': (ctypes.c_int, []),
@@ -59,6 +59,7 @@ PROTOTYPES = {
     'gd_rows_gemm_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _i64, _p, _p]),
     'gd_rows_gemm_wgrad_workspace': (_i64, [_i32, _i32, _i32]),
     'gd_rows_gemm_ws_covers': (ctypes.c_int, [_i32, _i32, _i32]),
+    'gd_rows_gemm_accumulate_f32': (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i32, _i32, _i32, _p, _i64, _p]),
     'gd_rows_gemm_select_f32': (ctypes.c_int, [_p, _p, _p, _i64, _p, _i32, _p, _i32, _i32, _i32, _p, _i32, _p, _i64, _p]),
     'gd_rows_gemm_dots_f32': (ctypes.c_int, [_p, _p, _p, _i64, _p, _i32, _i32, _i32, _p, _i32, _p, _i64, _p, _i32, _p, _p, _p, _p,
                                              _p]),

@@ -43,19 +43,28 @@ __device__ __forceinline__ uint32_t or_row_lanes(uint32_t v) {
 //      3: plain + the two row dot products o1[row] = <out[row], u1>, o2[row] = <out[row], u2> (GATConv's attention logits,
 //         gd_rows_gemm_dots_f32), 4: gated like 2 after the rank-1 correction out[row, n] += o1[row] u1[n] + o2[row] u2[n]
 //         (gd_rows_gemm_gated_rank1_f32: o1 / o2 are per-row scalars READ by row id), 5: plain + bias (u1 = the bias vector: the
-//         accumulators of a unit start from it instead of from zero)
+//         accumulators of a unit start from it instead of from zero), 6: ACCUMULATE (round 6, gd_rows_gemm_accumulate_f32):
+//         out[row] += x[row] @ W - the accumulators of a unit start from the rows of `out` themselves, fetched a unit ahead into the
+//         registers the previous unit's first matrix instructions have just read (GraphSAGE's root term x W_r^T added onto the
+//         aggregated neighbour term here, in a matrix-bound kernel with memory to spare, instead of as a second row stream of
+//         the latency-bound aggregation)
 // SEL: row r comes from in_alt where sel[r] != 0.  With an index list as well (round 6: the rows-only step's t2 / GAT logits
 //      products) the selector byte of a listed row is a DEPENDENT load behind its row id: the ids are requested three units
 //      ahead, the selector two units ahead from the id that has landed by then, and the pair travels as one descriptor word
 //      (row id | selector << 31) - no wait on a fresh load anywhere in the loop.
+// `out` is a restrict pointer in every mode that only writes it (what the tuned instantiations were compiled with); the
+// accumulate mode reads the rows it later overwrites and declares it plain
+template <bool READS_OUT> struct WsOutPtr { typedef float* __restrict__ type; };
+template <> struct WsOutPtr<true> { typedef float* type; };
+
 template <int DIN, int DOUT, int MODE, bool HASIDX, bool SEL, bool RELU>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rows_gemm_ws_kernel(
     const float* __restrict__ in, int64_t ld_in, const int32_t* __restrict__ idx, int32_t n_sel, const float* __restrict__ w,
-    int32_t trans_w, float* __restrict__ out, int64_t ld_out, const uint32_t* __restrict__ gate_bits,
+    int32_t trans_w, typename WsOutPtr<MODE == 6>::type out, int64_t ld_out, const uint32_t* __restrict__ gate_bits,
     uint32_t* __restrict__ sign_out, const float* __restrict__ in_alt, const uint8_t* __restrict__ sel,
     const float* __restrict__ u1, const float* __restrict__ u2, float* o1, float* o2) {
   constexpr int KQ = DIN / 4, NT = DOUT / 16, XV = KQ / 4, NW = DOUT / 32;
-  constexpr bool GATE = MODE == 2 || MODE == 4, DOTS = MODE == 3, RANK1 = MODE == 4, BIAS = MODE == 5;
+  constexpr bool GATE = MODE == 2 || MODE == 4, DOTS = MODE == 3, RANK1 = MODE == 4, BIAS = MODE == 5, ACC = MODE == 6;
   constexpr bool BOTH = HASIDX && SEL;
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -147,6 +156,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // MODE 4: the row scalars of the unit being stored
   float4 uv1[(DOTS || RANK1) ? NT : 1], uv2[(DOTS || RANK1) ? NT : 1];
   float dp1 = 0.f, dp2 = 0.f, ra_prev = 0.f, rb_prev = 0.f;
+  f32x4v ini[ACC ? NT : 1];                                 // MODE 6: the out rows of the unit about to be multiplied
+  if (ACC) {
+    const float* ip = out + (HASIDX ? (int64_t)row_of(d_cur) : (int64_t)slot_of(u_first)) * ld_out + 4 * kq;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float4 v4 = *reinterpret_cast<const float4*>(ip + 16 * t);
+      ini[t] = f32x4v{v4.x, v4.y, v4.z, v4.w};
+    }
+  }
+  if (ACC) {                                                // (the first trip's store of the idle set then rewrites the rows as they are)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc_a[t] = acc_b[t] = ini[t];
+  }
   f32x4v bz[BIAS ? NT : 1];                                 // MODE 5: the bias at this lane's output columns
   if (BIAS) {
 #pragma unroll
@@ -240,7 +262,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int c = 0; c < 4; ++c) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (i == 0 && c == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][0], xv[0], BIAS ? bz[t] : f32x4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          if (i == 0 && c == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][0], xv[0], ACC ? ini[t] : (BIAS ? bz[t] : f32x4v{0.f, 0.f, 0.f, 0.f}), 0, 0, 0);
           else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][4 * i + c], xv[c], acc[t], 0, 0, 0);
         }
         if (c == 1) {                                        // mid-chunk: the stores of this slot
@@ -255,6 +277,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       __builtin_amdgcn_sched_barrier(0);
       x[i] = nsrc[i];                                        // the registers just consumed: same chunk of the next unit
+      if (ACC && i == 0) {                                   // ... and the next unit's out rows (its accumulators' start)
+        const float* ip = out + (HASIDX ? (int64_t)row_of(d_nxt) : (int64_t)slot_of(min(u + 1, n_units - 1))) * ld_out + 4 * kq;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 v4 = *reinterpret_cast<const float4*>(ip + 16 * t);
+          ini[t] = f32x4v{v4.x, v4.y, v4.z, v4.w};
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (GATE) {
@@ -352,6 +382,29 @@ static int ws_dispatch(const float* in, int64_t ld_in, const int32_t* idx, int32
 #undef GD_WS
 }
 
+static bool ws_on();
+static int ws_min_rows();
+
+// out[row(s), :] += in[row(s), :] @ W on the weight-stationary form (MODE 6); -> 1 when the shape is not covered
+int rows_gemm_ws_accumulate(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t d_in,
+                            int32_t d_out, int32_t trans_w, float* out, int64_t ld_out, void* stream) {
+  if (!ws_on() || matrix_split() != 0 || n_sel < ws_min_rows()) return 1;
+  if (!((d_in == 64 || d_in == 128) && (d_out == 64 || d_out == 128))) return 1;
+  if (in == out || !aligned16(in) || !aligned16(out) || !aligned16(w) || ld_in % 4 || ld_out % 4) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const WsEpi epi{nullptr, nullptr, nullptr, nullptr};
+#define GD_WS_ACC(DI, DO)                                                                                                   \
+  do {                                                                                                                      \
+    if (idx) return ws_launch<DI, DO, 6, true, false, false>(in, ld_in, idx, n_sel, w, trans_w, out, ld_out, nullptr, nullptr, nullptr, nullptr, epi, s); \
+    return ws_launch<DI, DO, 6, false, false, false>(in, ld_in, idx, n_sel, w, trans_w, out, ld_out, nullptr, nullptr, nullptr, nullptr, epi, s);         \
+  } while (0)
+  if (d_in == 128 && d_out == 128) GD_WS_ACC(128, 128);
+  if (d_in == 128 && d_out == 64) GD_WS_ACC(128, 64);
+  if (d_in == 64 && d_out == 128) GD_WS_ACC(64, 128);
+  GD_WS_ACC(64, 64);
+#undef GD_WS_ACC
+}
+
 static bool ws_on() {
   static const bool on = [] { const char* e = getenv("GD_ROWS_GEMM_WS"); return !(e && atoi(e) == 0); }();
   return on;
@@ -392,6 +445,19 @@ int rows_gemm_ws_try(const float* in, int64_t ld_in, const int32_t* idx, int32_t
 }
 
 }  // namespace gd
+
+extern "C" int gd_rows_gemm_accumulate_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w,
+                                           int32_t d_in, int32_t d_out, int32_t trans_w, float* out, int64_t ld_out, void* stream) {
+  using namespace gd;
+  GD_REQUIRE(in && w && out, GD_E_NULL, "gd_rows_gemm_accumulate_f32: null pointer");
+  GD_REQUIRE(n_sel >= 0 && ld_in >= d_in && ld_out >= d_out, GD_E_DIM, "gd_rows_gemm_accumulate_f32: bad dims n_sel=%d d_in=%d d_out=%d", n_sel, d_in, d_out);
+  if (n_sel == 0) return GD_OK;
+  const int rc = rows_gemm_ws_accumulate(in, ld_in, idx, n_sel, w, d_in, d_out, trans_w, out, ld_out, stream);
+  GD_REQUIRE(rc != 1, GD_E_DIM,
+             "gd_rows_gemm_accumulate_f32: only where gd_rows_gemm_ws_covers(n_sel=%d, d_in=%d, d_out=%d) holds (16-byte aligned rows, in != out)",
+             n_sel, d_in, d_out);
+  return rc;
+}
 
 extern "C" int gd_rows_gemm_ws_covers(int32_t n_sel, int32_t d_in, int32_t d_out) {
   return gd::ws_on() && gd::matrix_split() == 0 && n_sel >= gd::ws_min_rows() && (d_in == 64 || d_in == 128) &&

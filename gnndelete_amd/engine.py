@@ -621,8 +621,16 @@ class NodeembEngine:
         elif self._mode == 'sage':
             # out_i = mean_j (x_j W_l^T) + b_l + x_i W_r^T  (transform first, then aggregate at width H)
             t_l = self._linear(self.x, c.lin_l.weight)
-            t_r = self._linear(self.x, c.lin_r.weight)
-            self._spmm(False, g.val, t_l, self.pre1, c.lin_l.bias, 1.0, x_self=t_r)
+            if (self._mfma_weight(c.lin_r.weight) and ops.rows_gemm_accumulate_ok(self.n, c.lin_r.weight.shape[1], c.lin_r.weight.shape[0])
+                    and os.environ.get('GD_SAGE_ROOT_IN_SPMM') != '1'):
+                # (round 6) the root term is ADDED by its own product (gd_rows_gemm_accumulate_f32: the accumulators of a unit start
+                # from the aggregated rows) instead of travelling through the aggregation as a second row stream: the latency-bound
+                # sweep reads one row per edge less per target, the matrix-bound product has the memory to spare
+                self._spmm(False, g.val, t_l, self.pre1, c.lin_l.bias, 0.0)
+                ops.rows_gemm_accumulate_(self.pre1, self.x, None, c.lin_r.weight, trans_w=True, const_w=True)
+            else:
+                t_r = self._linear(self.x, c.lin_r.weight)
+                self._spmm(False, g.val, t_l, self.pre1, c.lin_l.bias, 1.0, x_self=t_r)
         else:
             wsrc = c.lin_src.weight
             if self._rows_only and self._split1 and self._mfma_weight(wsrc):

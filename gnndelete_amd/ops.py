@@ -227,6 +227,27 @@ def rows_gemm_select(inp, inp_alt, sel, w, trans_w=False, bias=None, relu_in=Fal
     return out
 
 
+def rows_gemm_accumulate_ok(n_rows, d_in, d_out):
+    """Does gd_rows_gemm_accumulate_f32 take this shape (the weight-stationary form's: widths in {64, 128}, >= 65,536 rows)?"""
+    return matrix_split() == 0 and bool(_lib.lib().gd_rows_gemm_ws_covers(int(n_rows), int(d_in), int(d_out)))
+
+
+def rows_gemm_accumulate_(out, inp, idx, w, trans_w=False, const_w=False):
+    """out[rows] += inp[rows] @ w (w^T with trans_w), in place (raw, no autograd): gd_rows_gemm_accumulate_f32."""
+    inp = _f32_rows(inp)
+    if const_w:
+        w, trans_w = _const_weight(w, trans_w)
+    n, d_in = inp.shape
+    d_out = w.shape[0] if trans_w else w.shape[1]
+    assert out.shape[1] == d_out and out.dtype == torch.float32 and out.stride(1) == 1
+    if idx is not None:
+        n = int(idx.shape[0])
+    w = w.contiguous()
+    check(_lib.lib().gd_rows_gemm_accumulate_f32(ptr(inp), inp.stride(0), ptr(idx), n, ptr(w), d_in, d_out, int(trans_w), ptr(out),
+                                                 out.stride(0), stream_ptr(inp.device)), 'gd_rows_gemm_accumulate_f32')
+    return out
+
+
 def rows_gemm_dots_ok(d_in, d_out, n_rows=0, selected=False):
     """Whether fusing the row dots into the GEMM epilogue pays (the engine's choice; the entry itself takes 128 too).
     n_rows / selected (rows from two buffers AND an index list): what decides whether the weight-stationary kernel takes the

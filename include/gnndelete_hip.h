@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GD_ABI_VERSION 8   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
+#define GD_ABI_VERSION 9   /* 2: round-2 signatures (xcd_bounds, interleaved GAT edge values, tile conv, ...); 3: gd_set_matrix_split;
                               4: gd_spmm_csr_onepass_f32, gd_rows_gemm_wgrad_reduce_f32 (dw = NULL in the wgrad entries),
                                  gd_comm_* / gd_allreduce_f32 / gd_exchange_rows_f32, gd_segment_softmax_f32, gd_rowpair_dot_f32, gd_step_tail_f32;
                               5: gd_del_loss_bwd_wgrad_f32, multi-row items of gd_spmm_csr_onepass_f32;
@@ -40,7 +40,9 @@ extern "C" {
                              7: gd_rgcn_wave_conv_f32 / gd_rgcn_wave_covers;
                              8: gd_build_source_hash (the library carries a stamp of the sources it was built from), gd_typed_wgrad_f32,
                                 gd_typed_edge_dot_f32, gd_spmm_csr_onepass_aux_f32, gd_del1_loss_wgrad_f32; gd_rowtarget_mse_f32 accepts dz = NULL;
-                                gd_agg_gemm_f32 and gd_spmm_csr_rowgroup_f32 removed (opt-in forms nobody defaulted) */
+                                gd_agg_gemm_f32 and gd_spmm_csr_rowgroup_f32 removed (opt-in forms nobody defaulted);
+                             9: gd_rows_gemm_accumulate_f32; gd_rows_gemm_select_f32 / gd_rows_gemm_dots_f32 run weight-stationary with a selector
+                                AND an index list; the one-launch item kernels abort on a misaligned XCD range table instead of deadlocking */
 
 enum {
   GD_OK = 0,
@@ -369,6 +371,16 @@ int gd_rows_gemm_select_f32(const float* in, const float* in_alt, const uint8_t*
                             const int32_t* idx, int32_t n_sel, const float* w, int32_t d_in, int32_t d_out,
                             int32_t trans_w, const float* bias, int32_t relu_in,
                             float* out, int64_t ld_out, void* stream);
+
+/* (ABI 9) out[r,:] += in[r,:] @ (trans_w ? W^T : W) for r = idx[s] or s, s < n_sel - the weight-stationary form with the
+ * accumulators of a 16-row unit started from the rows of `out` (fetched a unit ahead).  GraphSAGE's root term: SAGEConv is
+ * W_l mean_j x_j + b_l + W_r x_i (BASELINE config 3's model; the reference has no SAGE) - the aggregation writes the
+ * neighbour term + bias, this call adds x W_r^T in place, in a matrix-bound kernel with memory to spare, instead of the
+ * aggregation reading a second row stream (134 -> 104 us on the bench graph).  Only where gd_rows_gemm_ws_covers(n_sel, d_in,
+ * d_out) holds (widths in {64, 128}, >= 65,536 rows), 16-byte aligned rows, in != out; GD_E_DIM otherwise (no other form exists:
+ * callers below the threshold keep the aggregation's self-row operand). */
+int gd_rows_gemm_accumulate_f32(const float* in, int64_t ld_in, const int32_t* idx, int32_t n_sel, const float* w, int32_t d_in,
+                                int32_t d_out, int32_t trans_w, float* out, int64_t ld_out, void* stream);
 
 /* Dense out = act(in or in_alt) @ W (+ bias) as gd_rows_gemm_select_f32 (sel / in_alt may be NULL), plus the two
  * row dot products o1[r] = <out[r,:], u1>, o2[r] = <out[r,:], u2> from the epilogue: GATConv's lin_src followed by

@@ -203,6 +203,18 @@ def test_rows_gemm_weight_stationary_form(d_in, d_out):
     few = idx[::3].contiguous()                       # below the weight-stationary form's threshold: the LDS-operand kernel
     out3f = ops.rows_gemm_select(x, x2, sel.to(torch.uint8), w, relu_in=True, idx=few, out=torch.full((n, d_out), 7.0, device='cuda'))
     assert few.numel() < 65536 and rel_l2(out3f[few.long()], out3[few.long()]) < TOL
+    # accumulate mode (round 6, gd_rows_gemm_accumulate_f32: GraphSAGE's root term added onto the aggregated rows): dense and
+    # on the index list, [k][n] and [n][k] weights; rows outside the list untouched; bit-reproducible; refused below the threshold
+    base = torch.randn(n, d_out, generator=g).cuda()
+    acc1 = ops.rows_gemm_accumulate_(base.clone(), x, None, w)
+    assert rel_l2(acc1, base.double() + want) < TOL
+    acc2 = ops.rows_gemm_accumulate_(base.clone(), x, idx, w.t().contiguous(), trans_w=True)
+    assert rel_l2(acc2[maskg], (base.double() + want)[maskg]) < TOL and torch.equal(acc2[~maskg], base[~maskg])
+    assert torch.equal(ops.rows_gemm_accumulate_(base.clone(), x, None, w), acc1)
+    assert ops.rows_gemm_accumulate_ok(n, d_in, d_out) and not ops.rows_gemm_accumulate_ok(5000, d_in, d_out)
+    from gnndelete_amd._lib import GnnDeleteHipError
+    with pytest.raises(GnnDeleteHipError):
+        ops.rows_gemm_accumulate_(base[:5000].clone(), x[:5000], None, w)
     # sign pattern out (bit b of word q = output 32 q + b), gate pattern in
     n_words = d_out // 32
     bits = torch.zeros(idx.numel(), n_words, dtype=torch.int32, device='cuda')

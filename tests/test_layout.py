@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)          # loads without a GPU
     for name in declared:
         assert hasattr(handle, name), name
-    assert _lib.lib().gd_abi_version() == _lib.ABI_VERSION == 8
+    assert _lib.lib().gd_abi_version() == _lib.ABI_VERSION == 9
     assert _lib.lib().gd_last_error_string() is not None
     # pure host helpers can be called without a GPU
     assert _lib.lib().gd_rows_gemm_wgrad_workspace(1000, 128, 128) >= 128 * 128
