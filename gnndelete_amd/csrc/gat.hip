@@ -450,6 +450,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 1 ? 
   const int wx = (blockIdx.x / kXcd) * 4 + (threadIdx.x >> 6);
   const int per = (n_items + kXcd - 1) / kXcd;
   const int i0 = xcd_bounds ? xcd_bounds[xcd] : xcd * per, i1 = xcd_bounds ? xcd_bounds[xcd + 1] : min(n_items, i0 + per);
+  //  with a range table (= the one-launch form) hub rows are group items whose four member waves meet at block
+  // barriers: only block-uniform when every limit is a multiple of 4.  A table that breaks this aborts the launch instead of
+  // deadlocking it (the invariant is the caller's, include/gnndelete_hip.h)
+  if (xcd_bounds && ((i0 | i1) & 3)) __builtin_trap();
   int i = i0 + wx;
   if (i >= i1) return;
   __shared__ float pbuf[4][kWave];
@@ -575,10 +579,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 1 ? 
     as = lane < cnt ? a_src[c] : 0.f;
     }
     if (member) {              // (block-uniform: the planner aligns the quadruples and the XCD ranges to 4)
-      //  ... which the barriers below rely on: with a range limit that is not a multiple of 4 the four waves of a
-      // block do not hold one aligned quadruple of items - abort the launch instead of deadlocking it (the invariant is the
-      // caller's, include/gnndelete_hip.h)
-      if ((i0 | i1) & 3) __builtin_trap();
       const int wave = threadIdx.x >> 6;
       if (lane == 0) grp_t[wave] = t_acc;
       __syncthreads();

@@ -137,6 +137,12 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
   const int per = (n_items + kXcd - 1) / kXcd;
   const int i0 = xcd_bounds ? xcd_bounds[xcd] : xcd * per;
   const int i1 = xcd_bounds ? xcd_bounds[xcd + 1] : min(n_items, i0 + per);
+  // One-launch form (no scratch rows: hub rows are GROUP items whose four member waves meet at block barriers further down): that
+  // is only block-uniform when every range limit is a multiple of 4 - a table that breaks the invariant aborts the launch here
+  // instead of deadlocking it (include/gnndelete_hip.h states the invariant; in the prologue, where it costs the sweep
+  // no register - inside the group branch it took the 64- and 128-float kernels from 7 / 8 to 6 / 7 waves per SIMD).  The piece
+  // form (gd_spmm_csr_balanced_f32, always a non-NULL scratch pointer) has no group items and takes limits cut anywhere.
+  if (xcd_bounds && !scratch && ((i0 | i1) & 3)) __builtin_trap();
 
   // per-lane constants: byte offset of this lane's vectors inside a row, its slice of the bias
   uint32_t lo[VPL];
@@ -368,10 +374,6 @@ __device__ __forceinline__ void spmm_persist_body(const int4* __restrict__ items
       if (lane == 0) aux_sum[row] = s1;
     }
     if (slot == -2) {          // group member (block-uniform: the planner aligns the quadruples and the XCD ranges to 4)
-      // ... which the barriers below rely on: a range table that breaks the invariant (a limit that is not a multiple of 4) aborts
-      // the launch here instead of deadlocking it (include/gnndelete_hip.h states the invariant.  The piece form of
-      // gd_spmm_csr_balanced_f32 has no group items and takes limits cut anywhere)
-      if ((i0 | i1) & 3) __builtin_trap();
       const int wave = threadIdx.x >> 6;
       if (g == 0) {
 #pragma unroll
@@ -663,7 +665,10 @@ extern "C" int gd_spmm_csr_balanced_f32(const int32_t* items, int32_t n_items, c
   const int d4 = d / 4;
   const float* xs = x_self ? x_self : x;            // rows of the self / residual term (same pitch as x)
   GD_REQUIRE(aligned16(xs) && xs != y, GD_E_ALIGN, "gd_spmm_csr_balanced_f32: bad x_self");
-  int rc = launch_persist(items, n_items, col, val, x, ldx, y, ldy, bias, self_coef, xs, scratch, d, nnz, x_rows,
+  // (a plan without split rows needs no scratch rows; the kernel tells the two forms apart by this pointer - see its prologue -
+  //  so the piece form always hands it one: never dereferenced without split rows)
+  float* scratch_arg = scratch ? scratch : reinterpret_cast<float*>(const_cast<int32_t*>(items));
+  int rc = launch_persist(items, n_items, col, val, x, ldx, y, ldy, bias, self_coef, xs, scratch_arg, d, nnz, x_rows,
                           xcd_bounds, s);
   if (rc || n_split == 0) return rc;
   hipLaunchKernelGGL(spmm_fixup_kernel, dim3((n_split + 3) / 4), dim3(256), 0, s, reinterpret_cast<const int4*>(split),
