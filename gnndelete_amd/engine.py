@@ -475,6 +475,16 @@ class NodeembEngine:
             self._chain1 = True
             self._gat_bufs = {'dh': torch.zeros(n, self.o, **f32), 'da_src': torch.zeros(n, **f32), 'da_dst': torch.zeros(n, **f32)}
         self._dt2_keep = torch.zeros(n, self.o, **f32) if (self._chain1 and self._gat_bufs is None) else None
+        # OPT-IN (GD_SMALL_SIDE_W1=1), measured in round 6 and NOT the default: on SMALL requests (below the row count of the fused
+        # Del-1 pass) the loss-fused W_D1 weight-gradient launch reads only what exists once Del-1 has run and nothing reads its
+        # partial sums before the tail, and at a few thousand rows neither it nor layer 2's launches fill the chip - so it can run
+        # on a side stream next to layer 2's forward, joined before the iteration overwrites dh.  synth-dblp 0.1834 -> 0.192 ms,
+        # synth-cora 0.4765 -> 0.484 ms (3 alternating pairs, profiles/r06_side_w1_ab.txt): the cross-queue dependencies of the
+        # replayed hipGraph cost more than the 17 us launch they hide - the same answer as GD_SIDE_STREAM gave at step size in round 3.
+        self._side_w1 = bool(self._tail and self._fuse_loss1 and not self._fuse_del1 and loss_type == 'both_layerwise'
+                             and self.s1 > 0 and not self._overlap and os.environ.get('GD_SMALL_SIDE_W1') == '1')
+        if self._side_w1 and self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
         # ... and the two stand-alone loss launches of a knowledge-graph step (DEC rows outside the Del rows, both layers) are one
         self._out_pair = bool(self._out1 and self._out2 and self._fuse_loss1 and self._fuse_l2 and loss_type != 'only2_all'
                               and _lib.lib().gd_rowtarget_mse_pair_covers(self.h, self.o) and os.environ.get('GD_NO_LOSS_PAIR') != '1')
@@ -897,6 +907,9 @@ class NodeembEngine:
                 self.t1.launch_outside(self.z1, None, self._lp1[2 * self._lp1_blocks:])
             if self._fuse_del1:
                 pass                                             # (its weight-gradient partials came out of the Del-1 pass)
+            elif lt == 'both_layerwise' and self._side_w1:
+                with self._fork():
+                    self._wgrad1(False, self.dh)
             elif lt == 'both_layerwise':
                 self._wgrad1(False, self.dh)
             elif lt == 'only1':
@@ -917,6 +930,8 @@ class NodeembEngine:
                 ops.rows_gemm(self.p2, self.idx2, self.wd2, out=self.z2, save_in=self.xs2)
                 self.t2.launch(self.z2, self.dz2, s2)
             # ---- backward + update
+            if self._side_w1:                                    # (join: the backward below overwrites dh, the tail reads the partials)
+                torch.cuda.current_stream().wait_stream(self._side)
             if lt == 'both_layerwise':
                 self._layer2_backward()                          # leaves dh for the next iteration
                 if not self._fuse_l2 and not self._tail:
