@@ -377,11 +377,14 @@ class NodeembEngine:
             self._lp2_blocks = _lib.lib().gd_del_loss_bwd_blocks(self.s2)
             self._lp2 = torch.zeros(2 * max(1, self._lp2_blocks + self.t2.outside_blocks()), **f32)
             self.dz2c = torch.zeros(self.s2, self.o, **f32)          # dz2 on the S2 rows (compact)
-        # Same for layer 1 (not with the cached layer-1 output, which is a fixed buffer already): conv1 writes
-        # pre1, Del-1 writes z1[S1] from pre1[S1]; conv2's Linear reads row r from z1 if r is in S1, else from
-        # pre1 (gd_rows_gemm_select_f32).  Upstream clones the whole [N, H] matrix for this (deletion.py:24).
-        self._split1 = (not cache_layer1 and _rows_inside(self.t1, self.idx1, self.s1)
-                        and os.environ.get('GD_NO_SPLIT') != '1')
+        # Same for layer 1: conv1 writes pre1, Del-1 writes z1[S1] from pre1[S1]; conv2's Linear reads row r from z1 if r is in
+        # S1, else from pre1 (gd_rows_gemm_select_f32).  Upstream clones the whole [N, H] matrix for this (deletion.py:24).
+        # (round 6) Also with the cached layer-1 output - pre1 is then that fixed buffer, filled once - so that the trainer's
+        # default step runs the same fused / chained Del-1 pass as the full step instead of three launches (Del-1, the loss-fused
+        # weight gradient, the gated product); GD_CACHE_SPLIT=0: the round-5 form (z1 = a copy of the cached output whose S1 rows
+        # are overwritten every step).
+        self._split1 = ((not cache_layer1 or os.environ.get('GD_CACHE_SPLIT', '1') != '0')
+                        and _rows_inside(self.t1, self.idx1, self.s1) and os.environ.get('GD_NO_SPLIT') != '1')
         self.pre1 = torch.empty(n, self.h, **f32) if self._split1 else self.z1
         self._sel1 = m1.to(torch.uint8).contiguous() if self._split1 else None
         if self._split1:
@@ -566,10 +569,13 @@ class NodeembEngine:
         self.cache_layer1 = cache_layer1
         if cache_layer1:
             with torch.no_grad():
-                self._conv1_forward()
-                self.p1 = self.z1.clone()
-                if self.s1:
-                    self.xs1.copy_(self.p1[self.idx1.long()])
+                self._conv1_forward()                  # (writes pre1: its own buffer in the split form, else z1)
+                if self._split1:
+                    self.p1 = self.pre1
+                else:
+                    self.p1 = self.z1.clone()
+                    if self.s1:
+                        self.xs1.copy_(self.p1[self.idx1.long()])
 
     # ------------------------------------------------------------------ pieces
     @staticmethod
@@ -887,14 +893,14 @@ class NodeembEngine:
         # this engine: a captured graph replays from their addresses (ops.keep_constants)
         with torch.no_grad(), ops.keep_constants(self._const_refs):
             # ---- forward, layer 1
-            if self.cache_layer1:
-                ops.rows_gemm(self.p1, self.idx1, self.wd1, out=self.z1, sign_bits=self.z1_pos)   # other rows stay = p1
-            else:
+            if not self.cache_layer1:
                 self._conv1_forward()
-                if self._fuse_del1:
-                    self._del1_fused(self.dh if lt == 'both_layerwise' else None)
-                else:
-                    ops.rows_gemm(self.pre1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1, sign_bits=self.z1_pos)
+            if self.cache_layer1 and not self._split1:
+                ops.rows_gemm(self.p1, self.idx1, self.wd1, out=self.z1, sign_bits=self.z1_pos)   # other rows stay = p1
+            elif self._fuse_del1:
+                self._del1_fused(self.dh if lt == 'both_layerwise' else None)
+            else:
+                ops.rows_gemm(self.pre1, self.idx1, self.wd1, out=self.z1, save_in=self.xs1, sign_bits=self.z1_pos)
             fused_fin = self.t1.folded and self.t2.folded       # partials reduced by the finalize kernel
             if not fused_fin:
                 self.sums.zero_()
