@@ -695,6 +695,28 @@ def time_dominant_kernel(eng, reps=20):
     return dur_s, int(spmm_algorithmic_bytes(eng.n, g.nnz, h) * frac) if frac < 0.999 else spmm_algorithmic_bytes(eng.n, g.nnz, h)
 
 
+def time_dominant_kernel_in_context(eng, reps=20):
+    """The same launch timed where it runs in the step - BEHIND the kernel that precedes it there (the frozen product x W1^T: a
+    matrix-bound launch that leaves the part at its matrix-load clock and the caches holding t1's tail): HIP events around `reps`
+    (x W1^T; SpMM) pairs minus the same loop of x W1^T alone.  Twenty back-to-back launches of the SpMM alone run 7-8 % faster than
+    the launch does inside the replayed step (96 against 104 us: VERDICT r5 could not reconcile the bench line's fraction with the
+    committed rocprofv3 table); this figure is the one `roofline.achieved` / `frac` are computed from.  GCN full step only (-> None
+    otherwise: the caller keeps the back-to-back figure)."""
+    from gnndelete_amd import ops
+    if getattr(eng, '_mode', None) != 'gcn' or not hasattr(eng, '_linear') or getattr(eng, 'plan', None) is not None:
+        return None
+    g, c1 = eng.graph, eng.model.conv1
+    y = torch.empty(eng.n, eng.h, device=eng.x.device)
+
+    def first():
+        return eng._linear(eng.x, c1.lin.weight)
+
+    def pair():
+        ops._spmm_raw(g.rowptr, g.col, g.val, first(), c1.bias, 0.0, eng.n, g.plan, out=y)
+    t_pair, t_first = _avg_seconds(pair, reps), _avg_seconds(first, reps)
+    return max(t_pair - t_first, 0.0)
+
+
 def time_del_gemm(eng, reps=20):
     """Average duration of the layer-1 Del operator (row-subset GEMM over the S1 rows, d = 128) launched
     back to back between two HIP events with the step's own operands; flops = 2 S d^2."""
@@ -1286,7 +1308,9 @@ def main():
     rep_rate = (rep_rate_auto if auto_est is not None else replicas_rate(args, model, state, device, world, barrier)) \
         if (partitioned and world > 1) else None
     if rank == 0:
-        kdur, kbytes = time_dominant_kernel(eng)
+        kdur_b2b, kbytes = time_dominant_kernel(eng)
+        kdur_ctx = time_dominant_kernel_in_context(eng) if world == 1 else None
+        kdur = kdur_ctx if kdur_ctx else kdur_b2b           # (in the step's context where that can be measured: see the function)
         achieved = kbytes / kdur / 1e9
         prof, prof_note = load_stage_profile(args.stage_profile, data.num_nodes, eng.graph.nnz) if world == 1 else ({}, 'N > 1')
         traffic = prof.get('stages', {}).get('spmm1', {}).get('traffic_bytes')
@@ -1319,6 +1343,9 @@ def main():
                                           + os.path.relpath(args.stage_profile, ROOT) + ')') if prof else None,
                          'stage_profile': os.path.relpath(args.stage_profile, ROOT) if prof else prof_note,
                          'algorithmic_bytes': kbytes, 'avg_us': kdur * 1e6,
+                         'timing': ('HIP events around 20 (x W1^T; SpMM) pairs minus 20 x W1^T alone: the launch behind the kernel that '
+                                    'precedes it in the step' if kdur_ctx else 'HIP events around 20 back-to-back launches'),
+                         'back_to_back_us': kdur_b2b * 1e6, 'frac_back_to_back': kbytes / kdur_b2b / 1e9 / HBM_PEAK_GBS,
                          'in_step_us': prof.get('stages', {}).get('spmm1', {}).get('in_step_us'),
                          # what any kernel with one contiguous row range per XCD can reach on this graph (measurement):
                          # the private L2s make the fabric carry every x row once per XCD that gathers it
@@ -1327,6 +1354,9 @@ def main():
             'timing': {'regions': n_regions, 'steps_per_region': args.steps, 'reported': 'median region',
                        'ms_per_step_each_region': [1e3 * t / args.steps for t in region_s]},
         }
+        if args.gnn == 'gat' and world == 1 and hasattr(eng, 'model'):
+            # (round 6) the GAT step never runs the plain SpMM: its dominant HBM kernel is the attention-scored aggregation
+            out['roofline'] = dict(time_gat_aggregation(eng), stage_profile=out['roofline']['stage_profile'])
         if note:
             out['config']['partition_fallback'] = note
         out['config']['ranks_seen'] = world          # WORLD_SIZE of the torch.distributed job this line was measured in
