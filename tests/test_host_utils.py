@@ -325,3 +325,52 @@ def test_cpu_oracle_job_in_a_child_process_reproduces_the_in_process_run():
     for a, b in zip(here['logs'], there['logs']):
         assert abs(a['train_loss'] - b['train_loss']) <= 1e-6 * abs(a['train_loss'])
     assert rel_l2(there['w1'], here['w1']) < 1e-6 and rel_l2(there['w2'], here['w2']) < 1e-6
+
+
+@pytest.mark.parametrize('gnn', ['gcn', 'gat', 'gin', 'sage'])
+def test_padded_class_dimension_is_exact_in_the_oracle_arithmetic(gnn):
+    """engine._padded_out_shadow (round 6): layer 2 of a node-classification model (out_dim = #classes = 4) widened to 64 output
+    columns by ZERO columns.  Host-side check of the claim the engine relies on, in the oracle's own conv arithmetic (no HIP):
+    the padded conv2's first 4 output columns are the unpadded conv2's, the other 60 are exactly zero; the padded W_D2 carries the
+    caller's block top-left and zeros elsewhere; Del-2 on the padded output keeps the padding at zero; conv1 / deletion1 are shared."""
+    from types import SimpleNamespace
+    from gnndelete_amd.engine import _padded_out_shadow
+    from gnndelete_amd.framework import models as M
+    torch.manual_seed(3)
+    n, f, h, o, pad = 60, 12, 128, 4, 64
+    ei = torch.randint(0, n, (2, 300))
+    ei = ei[:, ei[0] != ei[1]]
+    m1, m2 = torch.rand(n) < 0.5, torch.rand(n) < 0.8
+    cls = {'gcn': M.GCNDelete, 'gat': M.GATDelete, 'gin': M.GINDelete, 'sage': M.SAGEDelete}[gnn]
+    model = cls(SimpleNamespace(in_dim=f, hidden_dim=h, out_dim=o), m1, m2)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.startswith('conv2') and 'bias' in name:
+                p.copy_(torch.randn_like(p) * 0.1)
+        model.deletion2.deletion_weight.copy_(torch.eye(o) * 0.7 + 0.05 * torch.randn(o, o))
+    sh = _padded_out_shadow(model, pad)
+    assert sh.conv1 is model.conv1 and sh.deletion1 is model.deletion1 and sh.deletion2.mask is model.deletion2.mask
+    x = torch.randn(n, h).clamp(min=0)                       # relu(z1)
+
+    def conv2(c):
+        if gnn == 'gcn':
+            return pyg.gcn_conv(x, ei, c.lin.weight, c.bias)
+        if gnn == 'gat':
+            return pyg.gat_conv(x, ei, c.lin_src.weight, c.att_src, c.att_dst, c.bias, c.negative_slope)
+        if gnn == 'gin':
+            return pyg.gin_conv(x, ei, c.nn.weight, c.nn.bias, c.eps)
+        return pyg.sage_conv(x, ei, c.lin_l.weight, c.lin_l.bias, c.lin_r.weight)
+    with torch.no_grad():
+        want, got = conv2(model.conv2), conv2(sh.conv2)
+        assert got.shape == (n, pad) and float(got[:, o:].abs().max()) == 0.0
+        assert torch.allclose(got[:, :o], want, rtol=1e-6, atol=1e-7)
+        wp = sh.deletion2.deletion_weight
+        assert torch.equal(wp[:o, :o], model.deletion2.deletion_weight) and float(wp[o:].abs().max()) == 0.0 and float(wp[:, o:].abs().max()) == 0.0
+        z2 = got.clone()
+        z2[m2] = got[m2] @ wp
+        assert float(z2[:, o:].abs().max()) == 0.0
+        # the gradient of any loss on the first o columns is zero in the padding block: p2^T dz2 with p2 = 0 / dz2 = 0 there
+        dz2 = torch.zeros(n, pad)
+        dz2[:, :o] = torch.randn(n, o)
+        gw = got[m2].t() @ dz2[m2]
+        assert float(gw[o:].abs().max()) == 0.0 and float(gw[:, o:].abs().max()) == 0.0
